@@ -1,0 +1,37 @@
+// ABI bookkeeping + a self-test entry for the transposing wave reduction.
+#include "fg_common.h"
+
+extern "C" int fg_abi_version(void) { return FG_ABI_VERSION; }
+
+extern "C" const char* fg_error_string(int code) {
+  switch (code) {
+    case FG_OK: return "ok";
+    case FG_ERR_INVALID_ARG: return "invalid argument";
+    case FG_ERR_LAUNCH: return "HIP launch failed";
+    case FG_ERR_WORKSPACE: return "workspace too small";
+    case FG_ERR_UNSUPPORTED: return "unsupported configuration";
+    default: return "unknown error";
+  }
+}
+
+namespace {
+// in[64][16] -> out[16]: out[i] = sum over lanes of in[lane][i], written by lane 4i.
+__global__ void __launch_bounds__(64) debug_reduce16_kernel(const float* __restrict__ in, float* __restrict__ out) {
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = in[threadIdx.x * 16 + i];
+  const float r = fg::wave_reduce16_transposed(v);
+  if ((threadIdx.x & 3) == 0) out[threadIdx.x >> 2] = r;
+  // every lane of a quad must agree
+  out[16 + threadIdx.x] = r;
+  out[80 + threadIdx.x] = fg::wave_sum(in[threadIdx.x * 16]);
+}
+}  // namespace
+
+// Test hook (not part of the drop-in surface): in[64*16] floats, out[144] floats.
+extern "C" int fg_debug_wave_reduce16(const float* in, float* out, fg_stream_t stream) {
+  if (!in || !out) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(debug_reduce16_kernel, dim3(1), dim3(64), 0, fg_hip_stream(stream), in, out);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}

@@ -1,0 +1,190 @@
+// K3: tile binning -- prefix scan of per-Gaussian tile counts, (tile|depth, id) emission and
+// per-tile ranges of the sorted list.  Integer path: results are bit-exact by construction.
+//
+// Replaces the binning stage implied by tile_size=16 at
+// /root/reference freegaussian/freegaussian_model.py:806,857.
+#include "fg_common.h"
+
+namespace {
+
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_ITEMS = 8;                       // per thread
+constexpr int SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;  // 2048 elements per workgroup
+
+// inclusive scan across the 64 lanes of a wave (DPP row_shr + row broadcasts through SGPRs)
+__device__ __forceinline__ int64_t wave_inclusive_scan(int64_t v) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int64_t o = __shfl_up(v, d);
+    if (fg::lane_id() >= d) v += o;
+  }
+  return v;
+}
+
+// workgroup-wide inclusive scan of one value per thread; returns the thread's inclusive
+// prefix and the workgroup total.
+__device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t* wave_sums, int64_t& total) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int64_t incl = wave_inclusive_scan(v);
+  if (lane == 63) wave_sums[wave] = incl;
+  __syncthreads();
+  int64_t base = 0;
+  int64_t tot = 0;
+#pragma unroll
+  for (int w = 0; w < SCAN_BLOCK / 64; ++w) {
+    const int64_t s = wave_sums[w];
+    if (w < wave) base += s;
+    tot += s;
+  }
+  total = tot;
+  __syncthreads();
+  return incl + base;
+}
+
+// pass 1: per-workgroup totals
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_reduce_kernel(int N, const int32_t* __restrict__ in, int64_t* __restrict__ block_sums) {
+  __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
+  const int base = blockIdx.x * SCAN_TILE;
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    const int i = base + k * SCAN_BLOCK + threadIdx.x;
+    if (i < N) s += in[i];
+  }
+  int64_t total;
+  block_inclusive_scan(s, wave_sums, total);
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+// pass 2: exclusive scan of the workgroup totals, one workgroup
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_blocksums_kernel(int nblocks, int64_t* __restrict__ block_sums) {
+  __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
+  int64_t carry = 0;
+  for (int base = 0; base < nblocks; base += SCAN_BLOCK) {
+    const int i = base + threadIdx.x;
+    const int64_t v = (i < nblocks) ? block_sums[i] : 0;
+    int64_t total;
+    const int64_t incl = block_inclusive_scan(v, wave_sums, total);
+    if (i < nblocks) block_sums[i] = carry + incl - v;
+    carry += total;
+  }
+}
+
+// pass 3: inclusive scan inside each workgroup, offset by the scanned totals.  Thread t owns
+// SCAN_ITEMS consecutive elements so the sequential order matches the array order.
+__global__ void __launch_bounds__(SCAN_BLOCK)
+scan_apply_kernel(int N, const int32_t* __restrict__ in, const int64_t* __restrict__ block_sums,
+                  int64_t* __restrict__ out) {
+  __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
+  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
+  int32_t v[SCAN_ITEMS];
+  int64_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    v[k] = (base + k < N) ? in[base + k] : 0;
+    s += v[k];
+  }
+  int64_t total;
+  const int64_t incl = block_inclusive_scan(s, wave_sums, total);
+  int64_t run = block_sums[blockIdx.x] + incl - s;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; ++k) {
+    run += v[k];
+    if (base + k < N) out[base + k] = run;
+  }
+}
+
+// One lane per Gaussian writes its (key, id) pairs, row-major over its tile rectangle.
+__global__ void __launch_bounds__(256)
+tile_bin_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+                const float* __restrict__ depths, const int64_t* __restrict__ cum_tiles, int tile_size,
+                int tile_w, int tile_h, int64_t* __restrict__ isect_ids, int32_t* __restrict__ flatten_ids) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int radius = radii[i];
+  if (radius <= 0) return;
+  const float ts = (float)tile_size;
+  const float r = (float)radius / ts;
+  const float tx = means2d[2 * i] / ts, ty = means2d[2 * i + 1] / ts;
+  const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
+  const int y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
+  int64_t cur = (i == 0) ? 0 : cum_tiles[i - 1];
+  const int64_t dbits = (int64_t)(uint32_t)__float_as_int(depths[i]);
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      const int64_t tile = (int64_t)y * tile_w + x;
+      isect_ids[cur] = (tile << 32) | dbits;
+      flatten_ids[cur] = i;
+      ++cur;
+    }
+}
+
+// tile_offsets[t] = first sorted index whose tile id is >= t; tile_offsets[n_tiles] = n.
+__global__ void __launch_bounds__(256)
+tile_ranges_kernel(int64_t n, const int64_t* __restrict__ keys, int n_tiles, int32_t* __restrict__ offsets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) {
+    if (i <= n_tiles) offsets[i] = 0;
+    return;
+  }
+  if (i >= n) return;
+  const int cur = (int)(keys[i] >> 32);
+  if (i == 0) {
+    for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+  } else {
+    const int prev = (int)(keys[i - 1] >> 32);
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+  }
+  if (i == n - 1) {
+    for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t fg_scan_workspace_bytes(int N) {
+  const size_t nblocks = ((size_t)(N > 0 ? N : 1) + SCAN_TILE - 1) / SCAN_TILE;
+  return nblocks * sizeof(int64_t);
+}
+
+extern "C" int fg_scan_tiles(int N, const int32_t* tiles_touched, int64_t* cum_tiles, void* workspace,
+                             size_t workspace_bytes, fg_stream_t stream) {
+  if (N < 0) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!tiles_touched || !cum_tiles || !workspace) return FG_ERR_INVALID_ARG;
+  if (workspace_bytes < fg_scan_workspace_bytes(N)) return FG_ERR_WORKSPACE;
+  const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
+  int64_t* block_sums = static_cast<int64_t*>(workspace);
+  hipStream_t s = fg_hip_stream(stream);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched, block_sums);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched, block_sums,
+                     cum_tiles);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_tile_bin(int N, const float* means2d, const int32_t* radii, const float* depths,
+                           const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
+                           int64_t* isect_ids, int32_t* flatten_ids, fg_stream_t stream) {
+  if (N < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means2d || !radii || !depths || !cum_tiles) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(tile_bin_kernel, dim3((N + 255) / 256), dim3(256), 0, fg_hip_stream(stream), N, means2d,
+                     radii, depths, cum_tiles, tile_size, tile_w, tile_h, isect_ids, flatten_ids);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_tile_ranges(int64_t n, const int64_t* sorted_keys, int n_tiles, int32_t* tile_offsets,
+                              fg_stream_t stream) {
+  if (n < 0 || n_tiles <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
+  if (n > 0 && !sorted_keys) return FG_ERR_INVALID_ARG;
+  const int64_t work = n > 0 ? n : (int64_t)n_tiles + 1;
+  hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0,
+                     fg_hip_stream(stream), n, sorted_keys, n_tiles, tile_offsets);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}

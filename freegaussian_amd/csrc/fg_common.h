@@ -1,0 +1,107 @@
+// Shared device helpers for the gfx950 kernels (wave = 64 lanes everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/fgraster.h"
+
+#define FG_WAVE 64
+
+#define FG_RETURN_IF_LAUNCH_FAILED()                  \
+  do {                                                \
+    if (hipGetLastError() != hipSuccess) return FG_ERR_LAUNCH; \
+  } while (0)
+
+static inline hipStream_t fg_hip_stream(fg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// blending constants (build constants; see DESIGN.md "constants")
+#define FG_ALPHA_SKIP (1.0f / 255.0f)
+#define FG_ALPHA_MAX 0.999f
+#define FG_T_STOP 1e-4f
+#define FG_FOV_CLAMP 1.3f
+
+namespace fg {
+
+__device__ __forceinline__ int lane_id() { return __lane_id(); }
+
+// ---- DPP / permlane cross-lane moves (no LDS traffic) ------------------------------------
+template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
+__device__ __forceinline__ float dpp_mov(float v) {
+  return __builtin_bit_cast(
+      float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, BOUND));
+}
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_mov_keep(float old, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                               __builtin_bit_cast(int, v), CTRL, ROW_MASK,
+                                                               BANK_MASK, false));
+}
+#define FG_DPP_QUAD_XOR1 0xB1  // quad_perm [1,0,3,2]
+#define FG_DPP_QUAD_XOR2 0x4E  // quad_perm [2,3,0,1]
+#define FG_DPP_ROW_SHL4 0x104
+#define FG_DPP_ROW_SHR4 0x114
+#define FG_DPP_ROW_ROR8 0x128
+
+// Sum of v over the 64 lanes, result in every lane.
+__device__ __forceinline__ float wave_sum(float v) {
+  v += dpp_mov<FG_DPP_QUAD_XOR1>(v);
+  v += dpp_mov<FG_DPP_QUAD_XOR2>(v);
+  v += dpp_mov<0x124>(v);  // row_ror:4
+  v += dpp_mov<FG_DPP_ROW_ROR8>(v);
+  // rows of 16 now hold their sum in every lane; combine the 4 rows through SGPRs
+  float a = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 0));
+  float b = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  float c = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 32));
+  float d = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return (a + b) + (c + d);
+}
+
+__device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) v = max(v, __shfl_xor(v, m));
+  return v;
+}
+
+// Transposing wave reduction: 16 per-lane values -> after the call lane l holds, in the
+// return value, the 64-lane sum of value index (l >> 2).  ~37 VALU instructions and no LDS.
+__device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16]) {
+  const int lane = lane_id();
+  // step 1: lanes l <-> l^32 (v_permlane32_swap): 16 -> 8 registers, bit5 selects j / j+8
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[j]),
+                                              __builtin_bit_cast(unsigned, v[j + 8]), false, false);
+    v[j] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  }
+  // step 2: lanes l <-> l^16 (v_permlane16_swap): 8 -> 4, bit4 selects j / j+4
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v[j]),
+                                              __builtin_bit_cast(unsigned, v[j + 4]), false, false);
+    v[j] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+  }
+  // step 3: lanes l <-> l^8 (DPP row_ror:8): 4 -> 2, bit3 selects j / j+2
+  const bool b3 = (lane & 8) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    float keep = b3 ? v[j + 2] : v[j];
+    float send = b3 ? v[j] : v[j + 2];
+    v[j] = keep + dpp_mov<FG_DPP_ROW_ROR8>(send);
+  }
+  // step 4: lanes l <-> l^4 (row_shl:4 into banks 0,2; row_shr:4 into banks 1,3): 2 -> 1
+  const bool b2 = (lane & 4) != 0;
+  {
+    float keep = b2 ? v[1] : v[0];
+    float send = b2 ? v[0] : v[1];
+    float got = dpp_mov_keep<FG_DPP_ROW_SHL4, 0xf, 0x5>(0.f, send);
+    got = dpp_mov_keep<FG_DPP_ROW_SHR4, 0xf, 0xA>(got, send);
+    v[0] = keep + got;
+  }
+  // step 5: sum the quad
+  float r = v[0];
+  r += dpp_mov<FG_DPP_QUAD_XOR1>(r);
+  r += dpp_mov<FG_DPP_QUAD_XOR2>(r);
+  return r;
+}
+
+}  // namespace fg

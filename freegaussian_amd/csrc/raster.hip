@@ -1,0 +1,429 @@
+// K5 / K6: front-to-back alpha compositing over 16x16 pixel tiles, forward and backward.
+//
+// Replaces the rasterize stage of the rasterization(...) call at
+// /root/reference freegaussian/freegaussian_model.py:847-868 (render_mode, packed=False,
+// absgrad=True) and its autograd backward.
+//
+// Design for gfx950 (DESIGN.md "raster kernels"):
+//  * every Gaussian is one 64-byte, line-aligned record [x y o a | b c f0 f1 | f2.. ] so the
+//    per-tile gather is one cache line per list entry;
+//  * a workgroup owns one tile; each lane owns PPT pixels of one column (PPT = 1, 2 or 4, i.e.
+//    4, 2 or 1 wavefronts per tile).  With PPT = 4 a single 64-lane wavefront owns the whole
+//    tile: no cross-wave reduction is needed in the backward and one LDS broadcast read of a
+//    record feeds 4 pixel evaluations per lane;
+//  * the tile's list is staged through LDS in batches of one entry per lane; records are read
+//    back at a wave-uniform address (LDS broadcast, conflict-free ds_read_b128);
+//  * backward: per-lane partial gradients of the 16 accumulators are summed over the wave with
+//    a transposing butterfly (v_permlane32_swap / v_permlane16_swap / DPP, no LDS) that leaves
+//    accumulator i in lanes 4i..4i+3, then ONE atomic instruction adds 16 consecutive floats
+//    (one 64-byte line) of the Gaussian's gradient record;
+//  * blockIdx -> tile mapping keeps each XCD (blockIdx % 8) on its own horizontal band of the
+//    image so neighbouring tiles share records in one 4 MiB L2.
+#include "fg_common.h"
+
+#include <stdlib.h>
+
+namespace {
+
+constexpr int TILE = 16;
+
+__host__ __device__ constexpr int rec_vec4(int C) { return (6 + C + 3) / 4; }
+
+// XCD-aware bijective remap: workgroups with equal (id % 8) get consecutive tiles.
+__device__ __forceinline__ int tile_of_block(int b, int n) {
+  const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+  const int first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return first + k;
+}
+
+struct Splat {
+  float x, y, o, a, b, c;
+};
+
+template <int C>
+__device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (&f)[C]) {
+  const float4 v0 = rec[0];
+  const float4 v1 = rec[1];
+  s.x = v0.x; s.y = v0.y; s.o = v0.z; s.a = v0.w; s.b = v1.x; s.c = v1.y;
+  float tmp[4 * rec_vec4(C) - 6];
+  tmp[0] = v1.z; tmp[1] = v1.w;
+#pragma unroll
+  for (int v = 2; v < rec_vec4(C); ++v) {
+    const float4 q = rec[v];
+    tmp[4 * v - 6] = q.x; tmp[4 * v - 5] = q.y; tmp[4 * v - 4] = q.z; tmp[4 * v - 3] = q.w;
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) f[c] = tmp[c];
+}
+
+template <int C, int PPT>
+__global__ void __launch_bounds__(256 / PPT)
+raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* __restrict__ splats,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+  constexpr int NT = 256 / PPT;
+  constexpr int RSTEP = TILE / PPT;
+  constexpr int NV = rec_vec4(C);
+  __shared__ float4 lds[NT][NV];
+
+  const int tile = tile_of_block(blockIdx.x, n_tiles);
+  const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
+  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
+  const int ix = tile_x * TILE + col;
+  const float px = (float)ix + 0.5f;
+
+  float T[PPT], acc[PPT][C];
+  int last[PPT];
+  bool done[PPT];
+  float py[PPT];
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int iy = tile_y * TILE + row0 + k * RSTEP;
+    py[k] = (float)iy + 0.5f;
+    T[k] = 1.f;
+    last[k] = start - 1;
+    done[k] = !(ix < width && iy < height);
+#pragma unroll
+    for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
+  }
+
+  for (int batch = start; batch < end; batch += NT) {
+    bool all_done = true;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+    // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
+    if (__syncthreads_and(all_done)) break;
+    const int idx = batch + (int)threadIdx.x;
+    if (idx < end) {
+      const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) lds[threadIdx.x][v] = rec[v];
+    }
+    __syncthreads();
+    const int nb = min(NT, end - batch);
+    for (int j = 0; j < nb; ++j) {
+      if (__all(all_done)) break;  // this wavefront has nothing left to do
+      Splat s;
+      float f[C];
+      read_record<C>(lds[j], s, f);
+      const float dx = s.x - px;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        if (done[k]) continue;
+        const float dy = s.y - py[k];
+        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+        const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
+        if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+        const float next_T = T[k] * (1.f - alpha);
+        if (next_T <= FG_T_STOP) {
+          done[k] = true;
+          continue;
+        }
+        const float vis = alpha * T[k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
+        last[k] = batch + j;
+        T[k] = next_T;
+      }
+      all_done = true;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+    }
+  }
+
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int iy = tile_y * TILE + row0 + k * RSTEP;
+    if (ix < width && iy < height) {
+      const size_t pix = (size_t)iy * width + ix;
+#pragma unroll
+      for (int c = 0; c < C; ++c) render[pix * C + c] = acc[k][c];
+      alphas[pix] = 1.f - T[k];
+      last_ids[pix] = last[k];
+    }
+  }
+}
+
+template <int C, int PPT>
+__global__ void __launch_bounds__(256 / PPT)
+raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* __restrict__ splats,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ v_splats) {
+  constexpr int NT = 256 / PPT;
+  constexpr int NW = NT / 64;
+  constexpr int RSTEP = TILE / PPT;
+  constexpr int NV = rec_vec4(C);
+  __shared__ float4 lds[NT][NV];
+  __shared__ int32_t lds_gid[NT];
+  __shared__ int32_t lds_max[NW];
+
+  const int tile = tile_of_block(blockIdx.x, n_tiles);
+  const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
+  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  if (end <= start) return;
+  const int lane = fg::lane_id();
+  const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
+  const int ix = tile_x * TILE + col;
+  const float px = (float)ix + 0.5f;
+
+  float T[PPT], T_final[PPT], va[PPT], vr[PPT][C], buf[PPT][C], py[PPT];
+  int last[PPT];
+  int my_max = start - 1;
+#pragma unroll
+  for (int k = 0; k < PPT; ++k) {
+    const int iy = tile_y * TILE + row0 + k * RSTEP;
+    py[k] = (float)iy + 0.5f;
+    const bool inside = ix < width && iy < height;
+    const size_t pix = (size_t)iy * width + ix;
+    T_final[k] = inside ? 1.f - alphas[pix] : 1.f;
+    T[k] = T_final[k];
+    last[k] = inside ? last_ids[pix] : start - 1;
+    va[k] = inside ? v_alphas[pix] : 0.f;
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      vr[k][c] = inside ? v_render[pix * C + c] : 0.f;
+      buf[k][c] = 0.f;
+    }
+    my_max = max(my_max, last[k]);
+  }
+  // last list entry any pixel of the tile used
+  int bin_final = fg::wave_max_i32(my_max);
+  if (NW > 1) {
+    if (lane == 0) lds_max[threadIdx.x >> 6] = bin_final;
+    __syncthreads();
+#pragma unroll
+    for (int w = 0; w < NW; ++w) bin_final = max(bin_final, lds_max[w]);
+  }
+  const int n_used = bin_final - start + 1;
+  if (n_used <= 0) return;
+  const int n_batches = (n_used + NT - 1) / NT;
+
+  for (int b = n_batches - 1; b >= 0; --b) {
+    const int batch = start + b * NT;
+    __syncthreads();
+    const int idx = batch + (int)threadIdx.x;
+    if (idx <= bin_final) {
+      const int gid = flatten_ids[idx];
+      lds_gid[threadIdx.x] = gid;
+      const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
+#pragma unroll
+      for (int v = 0; v < NV; ++v) lds[threadIdx.x][v] = rec[v];
+    }
+    __syncthreads();
+    const int nb = min(NT, bin_final + 1 - batch);
+    for (int j = nb - 1; j >= 0; --j) {
+      const int idx_j = batch + j;
+      // wave-uniform skip: no pixel of this wavefront reaches this entry
+      bool reach = false;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
+      if (!__any(reach)) continue;
+
+      Splat s;
+      float f[C];
+      read_record<C>(lds[j], s, f);
+      const float dx = s.x - px;
+      float g[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) g[i] = 0.f;
+      bool contributed = false;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        if (idx_j > last[k]) continue;
+        const float dy = s.y - py[k];
+        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+        const float vis = __expf(-sigma);
+        const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
+        if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+        contributed = true;
+        const float ra = 1.f / (1.f - alpha);
+        T[k] *= ra;
+        const float fac = alpha * T[k];
+        float v_alpha = 0.f;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          g[8 + c] += fac * vr[k][c];
+          v_alpha += (f[c] * T[k] - buf[k][c] * ra) * vr[k][c];
+          buf[k][c] += f[c] * fac;
+        }
+        v_alpha += T_final[k] * ra * va[k];
+        if (s.o * vis <= FG_ALPHA_MAX) {
+          const float v_sigma = -s.o * vis * v_alpha;
+          g[3] += 0.5f * v_sigma * dx * dx;
+          g[4] += v_sigma * dx * dy;
+          g[5] += 0.5f * v_sigma * dy * dy;
+          const float gx = v_sigma * (s.a * dx + s.b * dy);
+          const float gy = v_sigma * (s.b * dx + s.c * dy);
+          g[0] += gx;
+          g[1] += gy;
+          g[6] += fabsf(gx);
+          g[7] += fabsf(gy);
+          g[2] += vis * v_alpha;
+        }
+      }
+      if (!__any(contributed)) continue;
+      const float total = fg::wave_reduce16_transposed(g);
+      if ((lane & 3) == 0) {
+        float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
+        __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+pack_splats_kernel(int N, int C, const float* __restrict__ means2d, const float* __restrict__ conics,
+                   const float* __restrict__ opacities, const float* __restrict__ features,
+                   float* __restrict__ splats) {
+  // 16 lanes per Gaussian: lane l of the group writes float l of the record (coalesced 64 B)
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 4;
+  const int l = (int)(t & 15);
+  if (i >= N) return;
+  float v = 0.f;
+  if (l < 2) v = means2d[2 * i + l];
+  else if (l == 2) v = opacities[i];
+  else if (l < 6) v = conics[3 * i + (l - 3)];
+  else if (l - 6 < C) v = features[(size_t)i * C + (l - 6)];
+  splats[i * FG_SPLAT_FLOATS + l] = v;
+}
+
+__global__ void __launch_bounds__(256)
+unpack_grads_kernel(int N, int C, const float* __restrict__ v_splats, float* __restrict__ v_means2d,
+                    float* __restrict__ v_means2d_abs, float* __restrict__ v_conics,
+                    float* __restrict__ v_opacities, float* __restrict__ v_features) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t i = t >> 4;
+  const int l = (int)(t & 15);
+  if (i >= N) return;
+  const float v = v_splats[i * FG_SPLAT_FLOATS + l];
+  if (l < 2) {
+    if (v_means2d) v_means2d[2 * i + l] = v;
+  } else if (l == 2) {
+    if (v_opacities) v_opacities[i] = v;
+  } else if (l < 6) {
+    if (v_conics) v_conics[3 * i + (l - 3)] = v;
+  } else if (l < 8) {
+    if (v_means2d_abs) v_means2d_abs[2 * i + (l - 6)] = v;
+  } else if (l - 8 < C) {
+    if (v_features) v_features[(size_t)i * C + (l - 8)] = v;
+  }
+}
+
+int raster_ppt() {
+  static int ppt = [] {
+    const char* e = getenv("FG_RASTER_PPT");
+    const int v = e ? atoi(e) : 4;
+    return (v == 1 || v == 2 || v == 4) ? v : 4;
+  }();
+  return ppt;
+}
+
+template <int C, int PPT>
+int launch_fwd(int width, int height, const float* splats, const int32_t* tile_offsets,
+               const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  const int n_tiles = tile_w * tile_h;
+  hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(n_tiles), dim3(256 / PPT), 0, s, width, height, tile_w,
+                     n_tiles, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas,
+                     last_ids);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
+template <int C, int PPT>
+int launch_bwd(int width, int height, const float* splats, const int32_t* tile_offsets,
+               const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
+               const float* v_alphas, float* v_splats, hipStream_t s) {
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  const int n_tiles = tile_w * tile_h;
+  hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(n_tiles), dim3(256 / PPT), 0, s, width, height, tile_w,
+                     n_tiles, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
+                     v_render, v_alphas, v_splats);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
+#define FG_DISPATCH_C(CALL)                  \
+  switch (channels) {                        \
+    case 1: CALL(1); break;                  \
+    case 2: CALL(2); break;                  \
+    case 3: CALL(3); break;                  \
+    case 4: CALL(4); break;                  \
+    case 5: CALL(5); break;                  \
+    case 6: CALL(6); break;                  \
+    case 7: CALL(7); break;                  \
+    case 8: CALL(8); break;                  \
+    default: return FG_ERR_UNSUPPORTED;      \
+  }
+
+}  // namespace
+
+extern "C" int fg_pack_splats(int N, int channels, const float* means2d, const float* conics,
+                              const float* opacities, const float* features, float* splats,
+                              fg_stream_t stream) {
+  if (N < 0 || channels < 1 || channels > FG_MAX_CHANNELS) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means2d || !conics || !opacities || !features || !splats) return FG_ERR_INVALID_ARG;
+  const int64_t threads = (int64_t)N * 16;
+  hipLaunchKernelGGL(pack_splats_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     fg_hip_stream(stream), N, channels, means2d, conics, opacities, features, splats);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
+                               float* v_means2d_abs, float* v_conics, float* v_opacities,
+                               float* v_features, fg_stream_t stream) {
+  if (N < 0 || channels < 1 || channels > FG_MAX_CHANNELS) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!v_splats) return FG_ERR_INVALID_ARG;
+  const int64_t threads = (int64_t)N * 16;
+  hipLaunchKernelGGL(unpack_grads_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0,
+                     fg_hip_stream(stream), N, channels, v_splats, v_means2d, v_means2d_abs, v_conics,
+                     v_opacities, v_features);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                             const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
+                             float* alphas, int32_t* last_ids, fg_stream_t stream) {
+  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
+  if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
+  if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
+  hipStream_t s = fg_hip_stream(stream);
+  int rc = FG_OK;
+  const int ppt = raster_ppt();
+#define CALL(CC)                                                                                              \
+  rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
+       : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
+                    : launch_fwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s)
+  FG_DISPATCH_C(CALL)
+#undef CALL
+  return rc;
+}
+
+extern "C" int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                             const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
+                             const int32_t* last_ids, const float* v_render, const float* v_alphas,
+                             float* v_splats, fg_stream_t stream) {
+  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
+  if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
+  if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_splats)
+    return FG_ERR_INVALID_ARG;
+  hipStream_t s = fg_hip_stream(stream);
+  int rc = FG_OK;
+  const int ppt = raster_ppt();
+#define CALL(CC)                                                                                          \
+  rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, s)                                    \
+       : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, s)                                    \
+                    : launch_bwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, s)
+  FG_DISPATCH_C(CALL)
+#undef CALL
+  return rc;
+}

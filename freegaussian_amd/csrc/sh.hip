@@ -1,0 +1,233 @@
+// K2 / K8: view-dependent colour from real spherical harmonics, forward and backward.
+//
+// coeffs is [N, k_stored, 3] (the reference concatenates features_dc/features_rest into
+// [N,16,3], freegaussian/freegaussian_model.py:801) -- an array of 192-byte rows.  A lane per
+// Gaussian reading its row directly would touch 64 cache lines per load instruction, so a
+// 256-Gaussian workgroup first streams its contiguous [256 x 3k] slab through LDS with fully
+// coalesced loads (consecutive lanes -> consecutive dwords), padded to an odd row stride so
+// the per-lane row reads are bank-conflict free.  The backward writes v_coeffs the same way.
+#include "fg_common.h"
+
+namespace {
+
+constexpr float C0 = 0.28209479177387814f;
+constexpr float C1 = 0.4886025119029199f;
+constexpr float C2_0 = 1.0925484305920792f, C2_1 = -1.0925484305920792f, C2_2 = 0.31539156525252005f,
+                C2_3 = -1.0925484305920792f, C2_4 = 0.5462742152960396f;
+constexpr float C3_0 = -0.5900435899266435f, C3_1 = 2.890611442640554f, C3_2 = -0.4570457994644658f,
+                C3_3 = 0.3731763325901154f, C3_4 = -0.4570457994644658f, C3_5 = 1.445305721320277f,
+                C3_6 = -0.5900435899266435f;
+
+constexpr int BLOCK = 256;
+constexpr int ROW = 49;  // 48 floats (16 bases x 3) + 1 pad -> odd stride, conflict-free
+
+// camera position = -W^-1 t for the 3x4 world->camera transform
+__device__ __forceinline__ void camera_position(const float* __restrict__ vm, float& cx, float& cy, float& cz) {
+  const float a = vm[0], b = vm[1], c = vm[2], d = vm[4], e = vm[5], f = vm[6], g = vm[8], h = vm[9], i = vm[10];
+  const float tx = vm[3], ty = vm[7], tz = vm[11];
+  const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
+  const float det = a * A + b * B + c * C;
+  const float id = 1.f / det;
+  // inverse = adj / det
+  const float i00 = A * id, i01 = -(b * i - c * h) * id, i02 = (b * f - c * e) * id;
+  const float i10 = B * id, i11 = (a * i - c * g) * id, i12 = -(a * f - c * d) * id;
+  const float i20 = C * id, i21 = -(a * h - b * g) * id, i22 = (a * e - b * d) * id;
+  cx = -(i00 * tx + i01 * ty + i02 * tz);
+  cy = -(i10 * tx + i11 * ty + i12 * tz);
+  cz = -(i20 * tx + i21 * ty + i22 * tz);
+}
+
+// basis values b[k] for k < (degree+1)^2
+__device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, float (&b)[16]) {
+  b[0] = C0;
+  if (degree > 0) {
+    b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
+  }
+  if (degree > 1) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    b[4] = C2_0 * xy; b[5] = C2_1 * yz; b[6] = C2_2 * (2.f * zz - xx - yy); b[7] = C2_3 * xz;
+    b[8] = C2_4 * (xx - yy);
+    if (degree > 2) {
+      b[9] = C3_0 * y * (3.f * xx - yy);
+      b[10] = C3_1 * xy * z;
+      b[11] = C3_2 * y * (4.f * zz - xx - yy);
+      b[12] = C3_3 * z * (2.f * zz - 3.f * xx - 3.f * yy);
+      b[13] = C3_4 * x * (4.f * zz - xx - yy);
+      b[14] = C3_5 * z * (xx - yy);
+      b[15] = C3_6 * x * (xx - 3.f * yy);
+    }
+  }
+}
+
+// d basis / d(x,y,z)
+__device__ __forceinline__ void sh_basis_grad(int degree, float x, float y, float z, float (&dx)[16],
+                                              float (&dy)[16], float (&dz)[16]) {
+#pragma unroll
+  for (int k = 0; k < 16; ++k) dx[k] = dy[k] = dz[k] = 0.f;
+  if (degree > 0) {
+    dy[1] = -C1; dz[2] = C1; dx[3] = -C1;
+  }
+  if (degree > 1) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    dx[4] = C2_0 * y; dy[4] = C2_0 * x;
+    dy[5] = C2_1 * z; dz[5] = C2_1 * y;
+    dx[6] = -2.f * C2_2 * x; dy[6] = -2.f * C2_2 * y; dz[6] = 4.f * C2_2 * z;
+    dx[7] = C2_3 * z; dz[7] = C2_3 * x;
+    dx[8] = 2.f * C2_4 * x; dy[8] = -2.f * C2_4 * y;
+    if (degree > 2) {
+      dx[9] = C3_0 * 6.f * xy; dy[9] = C3_0 * (3.f * xx - 3.f * yy);
+      dx[10] = C3_1 * yz; dy[10] = C3_1 * xz; dz[10] = C3_1 * xy;
+      dx[11] = C3_2 * (-2.f * xy); dy[11] = C3_2 * (4.f * zz - xx - 3.f * yy); dz[11] = C3_2 * 8.f * yz;
+      dx[12] = C3_3 * (-6.f * xz); dy[12] = C3_3 * (-6.f * yz); dz[12] = C3_3 * (6.f * zz - 3.f * xx - 3.f * yy);
+      dx[13] = C3_4 * (4.f * zz - 3.f * xx - yy); dy[13] = C3_4 * (-2.f * xy); dz[13] = C3_4 * 8.f * xz;
+      dx[14] = C3_5 * 2.f * xz; dy[14] = C3_5 * (-2.f * yz); dz[14] = C3_5 * (xx - yy);
+      dx[15] = C3_6 * (3.f * xx - 3.f * yy); dy[15] = C3_6 * (-6.f * xy);
+    }
+  }
+}
+
+// Stream the first k3 = 3*(degree+1)^2 floats of each of the block's rows into LDS.
+__device__ __forceinline__ void stage_rows_in(float* lds, const float* __restrict__ coeffs, int row0, int nrows,
+                                              int k3, int row_floats) {
+  const int total = nrows * k3;
+  for (int e = threadIdx.x; e < total; e += BLOCK) {
+    const int r = e / k3, c = e - r * k3;
+    lds[r * ROW + c] = coeffs[(size_t)(row0 + r) * row_floats + c];
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+sh_fwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, const float* __restrict__ viewmat,
+              const float* __restrict__ coeffs, const int32_t* __restrict__ radii, float* __restrict__ colors) {
+  __shared__ float lds[BLOCK * ROW];
+  const int row0 = blockIdx.x * BLOCK;
+  const int nrows = min(BLOCK, N - row0);
+  const int kk = (degree + 1) * (degree + 1);
+  stage_rows_in(lds, coeffs, row0, nrows, 3 * kk, 3 * k_stored);
+  __syncthreads();
+  const int i = row0 + threadIdx.x;
+  if (i >= N) return;
+  float r = 0.f, g = 0.f, b = 0.f;
+  if (!radii || radii[i] > 0) {
+    float cx, cy, cz;
+    camera_position(viewmat, cx, cy, cz);
+    float dx = means[3 * i] - cx, dy = means[3 * i + 1] - cy, dz = means[3 * i + 2] - cz;
+    const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+    dx *= inv; dy *= inv; dz *= inv;
+    float basis[16];
+    sh_basis(degree, dx, dy, dz, basis);
+    const float* row = lds + threadIdx.x * ROW;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      if (k < kk) {
+        r += basis[k] * row[3 * k];
+        g += basis[k] * row[3 * k + 1];
+        b += basis[k] * row[3 * k + 2];
+      }
+    }
+    r = fmaxf(r + 0.5f, 0.f);
+    g = fmaxf(g + 0.5f, 0.f);
+    b = fmaxf(b + 0.5f, 0.f);
+  }
+  colors[3 * i] = r;
+  colors[3 * i + 1] = g;
+  colors[3 * i + 2] = b;
+}
+
+__global__ void __launch_bounds__(BLOCK)
+sh_bwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, const float* __restrict__ viewmat,
+              const float* __restrict__ coeffs, const int32_t* __restrict__ radii,
+              const float* __restrict__ colors, const float* __restrict__ v_colors,
+              float* __restrict__ v_coeffs, float* __restrict__ v_means) {
+  __shared__ float lds[BLOCK * ROW];
+  const int row0 = blockIdx.x * BLOCK;
+  const int nrows = min(BLOCK, N - row0);
+  const int kk = (degree + 1) * (degree + 1);
+  const int i = row0 + threadIdx.x;
+  const bool need_dir = (v_means != nullptr) && degree > 0;
+  if (need_dir) {
+    stage_rows_in(lds, coeffs, row0, nrows, 3 * kk, 3 * k_stored);
+    __syncthreads();
+  }
+  float vr = 0.f, vg = 0.f, vb = 0.f;
+  float basis[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+  float gmx = 0.f, gmy = 0.f, gmz = 0.f;
+  const bool active = (i < N) && (!radii || radii[i] > 0);
+  if (active) {
+    // clamp: colour = max(sh + 0.5, 0) passes gradient only where the output is positive
+    vr = colors[3 * i] > 0.f ? v_colors[3 * i] : 0.f;
+    vg = colors[3 * i + 1] > 0.f ? v_colors[3 * i + 1] : 0.f;
+    vb = colors[3 * i + 2] > 0.f ? v_colors[3 * i + 2] : 0.f;
+    float cx, cy, cz;
+    camera_position(viewmat, cx, cy, cz);
+    const float ux = means[3 * i] - cx, uy = means[3 * i + 1] - cy, uz = means[3 * i + 2] - cz;
+    const float inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
+    const float dx = ux * inv, dy = uy * inv, dz = uz * inv;
+    sh_basis(degree, dx, dy, dz, basis);
+    if (need_dir) {
+      float bx[16], by[16], bz[16];
+      sh_basis_grad(degree, dx, dy, dz, bx, by, bz);
+      const float* row = lds + threadIdx.x * ROW;
+      float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+#pragma unroll
+      for (int k = 1; k < 16; ++k) {
+        if (k < kk) {
+          const float s = vr * row[3 * k] + vg * row[3 * k + 1] + vb * row[3 * k + 2];
+          vdx += bx[k] * s; vdy += by[k] * s; vdz += bz[k] * s;
+        }
+      }
+      // through the normalisation d = u/|u|
+      const float dp = vdx * dx + vdy * dy + vdz * dz;
+      gmx = (vdx - dp * dx) * inv;
+      gmy = (vdy - dp * dy) * inv;
+      gmz = (vdz - dp * dz) * inv;
+    }
+  }
+  if (v_means && i < N) {
+    v_means[3 * i] = gmx; v_means[3 * i + 1] = gmy; v_means[3 * i + 2] = gmz;
+  }
+  // v_coeffs[i][k][c] = basis[k] * v_colour[c]; stage through LDS, then stream out whole rows
+  if (need_dir) __syncthreads();  // everyone is done reading coeffs from lds
+  {
+    float* row = lds + threadIdx.x * ROW;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float bk = (k < kk) ? basis[k] : 0.f;
+      row[3 * k] = bk * vr; row[3 * k + 1] = bk * vg; row[3 * k + 2] = bk * vb;
+    }
+  }
+  __syncthreads();
+  const int row_floats = 3 * k_stored;
+  const int total = nrows * row_floats;
+  for (int e = threadIdx.x; e < total; e += BLOCK) {
+    const int r = e / row_floats, c = e - r * row_floats;
+    v_coeffs[(size_t)(row0 + r) * row_floats + c] = (c < 48) ? lds[r * ROW + c] : 0.f;
+  }
+}
+
+}  // namespace
+
+extern "C" int fg_sh_fwd(int N, int degree, int k_stored, const float* means, const float* viewmat,
+                         const float* coeffs, const int32_t* radii, float* colors, fg_stream_t stream) {
+  if (N < 0 || degree < 0 || degree > 3 || k_stored < (degree + 1) * (degree + 1)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !viewmat || !coeffs || !colors) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(sh_fwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     degree, k_stored, means, viewmat, coeffs, radii, colors);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_sh_bwd(int N, int degree, int k_stored, const float* means, const float* viewmat,
+                         const float* coeffs, const int32_t* radii, const float* colors,
+                         const float* v_colors, float* v_coeffs, float* v_means, fg_stream_t stream) {
+  if (N < 0 || degree < 0 || degree > 3 || k_stored < (degree + 1) * (degree + 1)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !viewmat || !coeffs || !colors || !v_colors || !v_coeffs) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(sh_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     degree, k_stored, means, viewmat, coeffs, radii, colors, v_colors, v_coeffs, v_means);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}

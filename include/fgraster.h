@@ -1,0 +1,151 @@
+/*
+ * fgraster.h -- C ABI of libfgraster.so, the MI355X (gfx950) Gaussian-raster hot path.
+ *
+ * This is the drop-in boundary for the ONE call the reference makes into native code:
+ *     gsplat.rendering.rasterization(...)
+ *         freegaussian/freegaussian_model.py:847-868          (stage 1 training / eval)
+ *         freegaussian/freegaussian_control_model.py:158-179  (stage 2)
+ *         preprocess/knn_gaussian.py:93-113, preprocess/render_depth.py:99,157,
+ *         preprocess/render_color.py:93, preprocess/o3d_color_splat.py:188   (packed / "ED")
+ * and for the flow-derivative math of preprocess/epipolar_flow.py:274-309 and
+ * docs/index.html:256-300.  The Python binding that calls these symbols is
+ * freegaussian_amd/_lib.py (ctypes); INTEGRATION.md shows the stub a maintainer adds.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless the comment says "host";
+ *   - the library allocates nothing, keeps no global state and never synchronises: the
+ *     caller owns every buffer (scratch sizes from the *_workspace_bytes queries) and every
+ *     call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
+ *   - re-entrant across streams; return 0 on success, a negative FG_ERR_* code otherwise;
+ *     nothing is thrown across the ABI;
+ *   - all floating data is fp32, row-major, contiguous; "radii" is int32 with >0 <=> visible;
+ *   - one camera per call (the reference asserts camera.shape[0]==1,
+ *     freegaussian_model.py:773); views are sharded over processes, not batched.
+ */
+#ifndef FGRASTER_H
+#define FGRASTER_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* fg_stream_t;
+
+#define FG_OK 0
+#define FG_ERR_INVALID_ARG (-1)
+#define FG_ERR_LAUNCH (-2)
+#define FG_ERR_WORKSPACE (-3)
+#define FG_ERR_UNSUPPORTED (-4)
+
+#define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
+#define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
+#define FG_ABI_VERSION 1
+
+int fg_abi_version(void);
+const char* fg_error_string(int code);
+
+/* ---- K1: projection (replaces the fully-fused projection stage implied by the kwargs
+ * viewmats/Ks/near_plane/far_plane/rasterize_mode at freegaussian_model.py:847-865) --------
+ * means[N,3] quats[N,4](wxyz, any norm) scales[N,3]; viewmat[16] world->camera (OpenCV axes,
+ * as built by freegaussian/utils.py:162-179); K[9].  Outputs (culled Gaussians: 0):
+ * radii[N] means2d[N,2] depths[N] conics[N,3] compensations[N](nullable) and
+ * tiles_touched[N] = number of tile_size x tile_size tiles in the splat's bounding rectangle. */
+int fg_project_fwd(int N, const float* means, const float* quats, const float* scales,
+                   const float* viewmat, const float* K, int width, int height, float eps2d,
+                   float near_plane, float far_plane, float radius_clip, int tile_size,
+                   int32_t* radii, float* means2d, float* depths, float* conics,
+                   float* compensations, int32_t* tiles_touched, fg_stream_t stream);
+
+/* Backward of K1 (autograd of the call at freegaussian_model.py:847; viewmat gradients are
+ * not produced: camera_optimizer mode is "off", freegaussian_model.py:120).
+ * v_compensations / compensations nullable together.  Writes v_means[N,3] v_quats[N,4]
+ * v_scales[N,3] (zeros where radii==0). */
+int fg_project_bwd(int N, const float* means, const float* quats, const float* scales,
+                   const float* viewmat, const float* K, int width, int height, float eps2d,
+                   const int32_t* radii, const float* conics, const float* compensations,
+                   const float* v_means2d, const float* v_depths, const float* v_conics,
+                   const float* v_compensations, float* v_means, float* v_quats,
+                   float* v_scales, fg_stream_t stream);
+
+/* ---- K2: spherical harmonics (sh_degree / colors[N,K,3] kwargs, freegaussian_model.py:801,
+ * :826-830).  colour = max(SH(dir) + 0.5, 0), dir = mean - camera position (derived from
+ * viewmat).  coeffs[N,k_stored,3]; degree 0..3; only radii>0 rows are shaded (others 0). */
+int fg_sh_fwd(int N, int degree, int k_stored, const float* means, const float* viewmat,
+              const float* coeffs, const int32_t* radii, float* colors, fg_stream_t stream);
+/* v_coeffs[N,k_stored,3] is written densely (sparse_grad=False, freegaussian_model.py:863);
+ * v_means[N,3] (nullable) receives the view-direction gradient. */
+int fg_sh_bwd(int N, int degree, int k_stored, const float* means, const float* viewmat,
+              const float* coeffs, const int32_t* radii, const float* colors,
+              const float* v_colors, float* v_coeffs, float* v_means, fg_stream_t stream);
+
+/* ---- K3: tile binning (tile_size=16, freegaussian_model.py:806) --------------------------
+ * fg_scan_tiles: inclusive prefix sum, cum_tiles[N] int64; cum_tiles[N-1] = I, the number of
+ * (Gaussian, tile) intersections, which the host reads to size the lists. */
+size_t fg_scan_workspace_bytes(int N);
+int fg_scan_tiles(int N, const int32_t* tiles_touched, int64_t* cum_tiles, void* workspace,
+                  size_t workspace_bytes, fg_stream_t stream);
+/* isect_ids[I]  = (tile_id << 32) | float32 bits of depth;  flatten_ids[I] = Gaussian id.
+ * Emission order: Gaussian-major, row-major over the tile rectangle. */
+int fg_tile_bin(int N, const float* means2d, const int32_t* radii, const float* depths,
+                const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
+                int64_t* isect_ids, int32_t* flatten_ids, fg_stream_t stream);
+
+/* ---- K4: stable LSD radix sort of (key, value) pairs on key bits [0, end_bit), in place
+ * (workspace holds the ping-pong copies and histograms), then per-tile ranges:
+ * tile_offsets[n_tiles+1], tile t owns sorted entries [tile_offsets[t], tile_offsets[t+1]). */
+size_t fg_sort_workspace_bytes(int64_t n);
+int fg_sort_pairs(int64_t n, int64_t* keys, int32_t* vals, int end_bit, void* workspace,
+                  size_t workspace_bytes, fg_stream_t stream);
+int fg_tile_ranges(int64_t n, const int64_t* sorted_keys, int n_tiles, int32_t* tile_offsets,
+                   fg_stream_t stream);
+
+/* ---- K5/K6: front-to-back alpha compositing over 16x16 tiles -----------------------------
+ * fg_pack_splats builds one 64-byte record per Gaussian:
+ *   [x, y, opacity, conic_a, conic_b, conic_c, f0..f(C-1), 0...]      C <= FG_MAX_CHANNELS
+ * features[N,C] are the composited channels (RGB | RGB+depth | depth | +flow ...). */
+int fg_pack_splats(int N, int channels, const float* means2d, const float* conics,
+                   const float* opacities, const float* features, float* splats,
+                   fg_stream_t stream);
+/* render[H,W,C] alphas[H,W] last_ids[H,W] (index into the sorted list of the last splat that
+ * contributed; tile start - 1 if none).  No background: the caller composites it
+ * (freegaussian_model.py:875-877). */
+int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                  const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
+                  float* alphas, int32_t* last_ids, fg_stream_t stream);
+/* v_splats[N,16] must be ZEROED by the caller; per-Gaussian gradients are accumulated as
+ *   [v_x, v_y, v_opacity, v_conic_a, v_conic_b, v_conic_c, |v_x|, |v_y|, v_f0..v_f(C-1)]
+ * (|v_x|,|v_y| = absgrad, freegaussian_model.py:864 / :377). */
+int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                  const int32_t* tile_offsets, const int32_t* flatten_ids,
+                  const float* alphas, const int32_t* last_ids, const float* v_render,
+                  const float* v_alphas, float* v_splats, fg_stream_t stream);
+/* Split v_splats back into per-tensor gradients (any output nullable). */
+int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
+                    float* v_means2d_abs, float* v_conics, float* v_opacities,
+                    float* v_features, fg_stream_t stream);
+
+/* ---- F: flow derivative -------------------------------------------------------------------
+ * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at
+ * integer coordinates, infinite depth -> 0, :315-317).  depth[H,W], veloc[3], omega[3],
+ * flow[H,W,2]. */
+int fg_camera_flow(int width, int height, const float* depth, const float* K,
+                   const float* veloc, const float* omega, float* flow, fg_stream_t stream);
+/* Per-Gaussian projection-flow Jacobian (Lemma 1, docs/index.html:256-273, code sign
+ * convention of epipolar_flow.py:277-298): for visible Gaussian i at means2d mu_i, depth Z_i,
+ * camera-frame velocity vel[i]:   u_gs[i] = A(mu_i) vel[i] / Z_i
+ *                                 u_cam[i] = A(mu_i) veloc / Z_i + B(mu_i) omega. */
+int fg_flow_fwd(int N, const float* means2d, const float* depths, const int32_t* radii,
+                const float* vel, const float* K, const float* veloc, const float* omega,
+                float* u_gs, float* u_cam, fg_stream_t stream);
+int fg_flow_bwd(int N, const float* means2d, const float* depths, const int32_t* radii,
+                const float* vel, const float* K, const float* veloc, const float* omega,
+                const float* v_u_gs, const float* v_u_cam, float* v_means2d, float* v_depths,
+                float* v_vel, fg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FGRASTER_H */
