@@ -1,0 +1,208 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Mpixels/s of the Gaussian raster path, forward + backward, on the
+synthetic 1M-Gaussian 1920x1080 scene of BASELINE.json (configs "DyNeRF multi-view 1080p,
+~1M Gaussians"; generator: freegaussian_amd/scenes.py north_star_scene).
+
+One process per GPU; each rank renders its own camera view of the shared scene (view = rank
+mod 8) through ``freegaussian_amd.rasterization`` -- the drop-in for the call at reference
+freegaussian_model.py:847 -- and back-propagates a fixed N(0,1) image gradient.  For N > 1 the
+flat Gaussian-parameter gradient buffer (59 floats per Gaussian) is all-reduced over RCCL
+inside the timed region, as view-sharded training does every step.
+
+A step = one view per rank, forward + backward (+ all-reduce).  value = total pixels rendered
+by all ranks / max-over-ranks wall time.  Inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0) with the contract keys plus "roofline" (dominant kernel) and
+"cpu_baseline" (the CPU oracle timed on a bounded crop of the same view, N=1 only)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from freegaussian_amd import ops, rasterization  # noqa: E402
+from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
+from freegaussian_amd.viewdp import FlatGaussianParams  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n-gauss", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-crop", type=str, default="480x272")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(N, V, I, P, T, k, p):
+    """SURVEY.md §8d per-stage algorithmic HBM bytes for one view (fp32)."""
+    return {
+        "fg_project_fwd": 44 * N + 32 * V,
+        "fg_sh_fwd": 12 * k * V + 12 * V,
+        "fg_tile_bin": 12 * I,
+        "fg_sort_pairs": 24 * p * I,
+        "fg_tile_ranges": 8 * I + 8 * T,
+        "fg_raster_fwd": 40 * I + 20 * P,
+        "fg_raster_bwd": 40 * I + 36 * P + 44 * V,
+        "fg_project_bwd": 88 * V + 44 * N,
+        "fg_sh_bwd": 12 * k * V + 12 * 16 * N,
+    }
+
+
+def cpu_baseline(scene, view, crop, sh_degree):
+    """The CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is the absent
+    CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd."""
+    from oracle import raster_oracle as O
+
+    cw, ch = (int(x) for x in crop.split("x"))
+    K = scene.Ks[view].clone()
+    x0, y0 = (scene.width - cw) // 2, (scene.height - ch) // 2
+    K[0, 2] -= x0
+    K[1, 2] -= y0
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ins = [t.clone().requires_grad_(True) for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.colors)]
+    g = torch.Generator().manual_seed(1)
+    vr = torch.randn(1, ch, cw, 3, generator=g)
+    t0 = time.perf_counter()
+    r, a, info = O.rasterization(*ins, scene.viewmats[view : view + 1], K[None], cw, ch, sh_degree=sh_degree,
+                                 render_mode="RGB", packed=False)  # fmt: skip
+    (r * vr).sum().backward()
+    dt = time.perf_counter() - t0
+    return {
+        "value": cw * ch / dt / 1e6,
+        "unit": "Mpix/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"centre {cw}x{ch} crop of view {view} of the same scene (all {scene.means.shape[0]} Gaussians "
+        f"projected, {info['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 run, {dt:.1f} s; "
+        "pure-PyTorch CPU oracle (extrapolates by pixel count)",
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the raster path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=8, sh_degree=args.sh_degree, seed=42)
+    view = rank % 8
+    W, H = scene.width, scene.height
+    params = FlatGaussianParams.from_scene(scene, dev)  # flat parameter + flat gradient buffers
+    vm = scene.viewmats[view : view + 1].to(dev)
+    K = scene.Ks[view : view + 1].to(dev)
+    vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+
+    def step():
+        params.zero_grad()
+        means, quats, scales, opac, colors = params.raster_inputs()
+        r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
+                                   render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+        (r * vr).sum().backward()
+        if world > 1:
+            params.all_reduce_grads()
+        return info
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        info = step()
+    fence()
+    ops.stage_timer = ops.StageTimer()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        info = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stages = ops.stage_timer.summary()
+    ops.stage_timer = None
+    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dt = float(t.item())
+
+    N = args.n_gauss
+    V = int((info["radii"] > 0).sum())
+    I = int(info["flatten_ids"].numel())
+    P = W * H
+    T = info["tile_width"] * info["tile_height"]
+    k = (args.sh_degree + 1) ** 2
+    nbits = 32 + max(T - 1, 1).bit_length()
+    p = (nbits + 7) // 8
+    alg = algorithmic_bytes(N, V, I, P, T, k, p)
+    dom = max(stages, key=lambda s: stages[s])
+    roof = {
+        "bound": "hbm",
+        "kernel": dom,
+        "achieved": alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9,
+        "peak": HBM_PEAK_GBS,
+        "unit": "GB/s",
+        "traffic": None,
+        "algorithmic_bytes": alg.get(dom, 0),
+        "avg_ms": stages[dom],
+    }
+    roof["frac"] = roof["achieved"] / roof["peak"]
+    total_alg = 280 * N + (176 + 24 * k) * V + (100 + 24 * p) * I + 56 * P + 8 * T
+    out = {
+        "metric": "Mpixels/s fwd+bwd @ 1M Gaussians 1080p",
+        "value": world * args.steps * P / dt / 1e6,
+        "unit": "Mpix/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {
+            "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank "
+            f"per step (8-view ring), fwd+bwd, RGB, absgrad" + (", RCCL grad all-reduce" if world > 1 else ""),
+            "N": N, "V": V, "I": I, "P": P, "T": T, "k": k, "sort_passes": p,
+            "parallelism": f"view-dp{world}",
+        },
+        "roofline": roof,
+        "whole_step": {
+            "algorithmic_bytes": total_alg,
+            "achieved_GBs": total_alg / (dt / args.steps) / 1e9,
+            "frac_of_hbm_peak": total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+        },
+        "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
+    }  # fmt: skip
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,76 @@
+"""ctypes binding of ``libfgraster.so`` (the C ABI declared in ``include/fgraster.h``).
+
+There is NO fallback: if the HIP library is missing or a symbol is absent, importing the ops
+raises.  PyTorch is only used by callers for device memory and streams; nothing here takes a
+torch type -- pointers are plain integers."""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfgraster.so")
+
+P = c_void_p
+
+# name -> (restype, argtypes); must list every symbol of include/fgraster.h
+SIGNATURES = {
+    "fg_abi_version": (c_int, []),
+    "fg_error_string": (c_char_p, [c_int]),
+    "fg_project_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_float, c_float, c_float, c_float, c_int,
+                               P, P, P, P, P, P, P]),
+    "fg_project_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "fg_sh_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),
+    "fg_sh_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "fg_scan_workspace_bytes": (c_size_t, [c_int]),
+    "fg_scan_tiles": (c_int, [c_int, P, P, P, c_size_t, P]),
+    "fg_tile_bin": (c_int, [c_int, P, P, P, P, c_int, c_int, c_int, P, P, P]),
+    "fg_sort_workspace_bytes": (c_size_t, [c_int64]),
+    "fg_sort_pairs": (c_int, [c_int64, P, P, c_int, P, c_size_t, P]),
+    "fg_tile_ranges": (c_int, [c_int64, P, c_int, P, P]),
+    "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
+    "fg_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
+    "fg_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
+    "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
+    "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
+    "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
+}  # fmt: skip
+
+# test hooks, not declared in the public header
+_EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
+
+ABI_VERSION = 1
+_lib = None
+
+
+class FgRasterError(RuntimeError):
+    pass
+
+
+def load() -> ctypes.CDLL:
+    """Load the library once; raise loudly when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FgRasterError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C freegaussian_amd/csrc`.  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is absent
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fg_abi_version() != ABI_VERSION:
+        raise FgRasterError(f"ABI mismatch: library {lib.fg_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str) -> None:
+    if code != 0:
+        msg = load().fg_error_string(code).decode()
+        raise FgRasterError(f"{what} failed: {msg} ({code})")

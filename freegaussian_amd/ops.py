@@ -1,0 +1,327 @@
+"""Torch-facing operators over the C ABI: one autograd Function per stage of the raster path.
+
+PyTorch supplies device memory, the current HIP stream and the autograd tape; every byte of
+arithmetic happens in ``libfgraster.so``.  All operators require CUDA(HIP) tensors and raise
+otherwise -- there is no CPU path in the product (the CPU restatement lives in ``oracle/`` and
+is test infrastructure only)."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+TILE_SIZE = 16
+SPLAT_FLOATS = 16
+MAX_CHANNELS = 8
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class StageTimer:
+    """Optional per-stage HIP-event timing of the C-ABI calls (bench.py turns it on for the
+    timed region).  Events are recorded on the stream the kernels are launched on; nothing
+    synchronises until ``summary()``."""
+
+    def __init__(self):
+        self.events = {}
+
+    def record(self, name):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        self.events.setdefault(name, []).append((a, b))
+        return a, b
+
+    def summary(self):
+        torch.cuda.synchronize()
+        return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items()}
+
+
+stage_timer: Optional[StageTimer] = None
+
+
+def _call(name: str, *args) -> None:
+    """Invoke one C-ABI entry point on the current stream, optionally bracketed by HIP events."""
+    fn = getattr(_lib.load(), name)
+    ev = stage_timer.record(name) if stage_timer is not None else None
+    if ev:
+        ev[0].record()
+    rc = fn(*args)
+    if ev:
+        ev[1].record()
+    _lib.check(rc, name)
+
+
+def _f32(t: torch.Tensor, name: str) -> torch.Tensor:
+    if not t.is_cuda:
+        raise _lib.FgRasterError(f"{name} must be a CUDA/HIP tensor: the raster path has no CPU fallback")
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# --------------------------------------------------------------------------------------------
+# K1 projection
+
+
+class _Project(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip, tile_size,
+                calc_comp):  # fmt: skip
+        lib = _lib.load()
+        N = means.shape[0]
+        dev = means.device
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(N, dtype=torch.float32, device=dev)
+        conics = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        comp = torch.empty(N, dtype=torch.float32, device=dev) if calc_comp else None
+        tiles = torch.empty(N, dtype=torch.int32, device=dev)
+        _call("fg_project_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmat), _ptr(K), width, height,
+                               eps2d, near, far, radius_clip, tile_size, _ptr(radii), _ptr(means2d), _ptr(depths),
+                               _ptr(conics), _ptr(comp), _ptr(tiles), _stream())  # fmt: skip
+        ctx.save_for_backward(means, quats, scales, viewmat, K, radii, conics, comp)
+        ctx.args = (width, height, eps2d)
+        ctx.mark_non_differentiable(radii, tiles)
+        if comp is None:
+            comp = torch.empty(0, device=dev)
+            ctx.mark_non_differentiable(comp)
+        return radii, means2d, depths, conics, comp, tiles
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comp, _v_tiles):
+        lib = _lib.load()
+        means, quats, scales, viewmat, K, radii, conics, comp = ctx.saved_tensors
+        width, height, eps2d = ctx.args
+        N = means.shape[0]
+        dev = means.device
+
+        def z(shape):
+            return torch.zeros(shape, dtype=torch.float32, device=dev)
+
+        v_means2d = z((N, 2)) if v_means2d is None else v_means2d.contiguous()
+        v_depths = z((N,)) if v_depths is None else v_depths.contiguous()
+        v_conics = z((N, 3)) if v_conics is None else v_conics.contiguous()
+        v_comp = None if (comp is None or v_comp is None or v_comp.numel() == 0) else v_comp.contiguous()
+        v_means = torch.empty_like(means)
+        v_quats = torch.empty_like(quats)
+        v_scales = torch.empty_like(scales)
+        _call("fg_project_bwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmat), _ptr(K), width, height,
+                               eps2d, _ptr(radii), _ptr(conics), _ptr(comp), _ptr(v_means2d), _ptr(v_depths),
+                               _ptr(v_conics), _ptr(v_comp), _ptr(v_means), _ptr(v_quats), _ptr(v_scales),
+                               _stream())  # fmt: skip
+        return (v_means, v_quats, v_scales) + (None,) * 10
+
+
+def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+            radius_clip=0.0, tile_size=TILE_SIZE, calc_compensations=False):  # fmt: skip
+    """-> radii[N] int32, means2d[N,2], depths[N], conics[N,3], compensations[N]|empty, tiles_touched[N]."""
+    means, quats, scales = _f32(means, "means"), _f32(quats, "quats"), _f32(scales, "scales")
+    viewmat, K = _f32(viewmat, "viewmat"), _f32(K, "K")
+    return _Project.apply(means, quats, scales, viewmat, K, int(width), int(height), float(eps2d),
+                          float(near_plane), float(far_plane), float(radius_clip), int(tile_size),
+                          bool(calc_compensations))  # fmt: skip
+
+
+# --------------------------------------------------------------------------------------------
+# K2 spherical harmonics
+
+
+class _SH(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, degree, means, viewmat, coeffs, radii):
+        lib = _lib.load()
+        N, k_stored = coeffs.shape[0], coeffs.shape[1]
+        colors = torch.empty(N, 3, dtype=torch.float32, device=means.device)
+        _call("fg_sh_fwd", N, degree, k_stored, _ptr(means), _ptr(viewmat), _ptr(coeffs), _ptr(radii), _ptr(colors),
+                          _stream())  # fmt: skip
+        ctx.save_for_backward(means, viewmat, coeffs, radii, colors)
+        ctx.degree = degree
+        return colors
+
+    @staticmethod
+    def backward(ctx, v_colors):
+        lib = _lib.load()
+        means, viewmat, coeffs, radii, colors = ctx.saved_tensors
+        N, k_stored = coeffs.shape[0], coeffs.shape[1]
+        v_coeffs = torch.empty_like(coeffs)
+        v_means = torch.empty_like(means) if ctx.needs_input_grad[1] else None
+        _call("fg_sh_bwd", N, ctx.degree, k_stored, _ptr(means), _ptr(viewmat), _ptr(coeffs), _ptr(radii),
+                          _ptr(colors), _ptr(v_colors.contiguous()), _ptr(v_coeffs), _ptr(v_means), _stream())  # fmt: skip
+        return None, v_means, None, v_coeffs, None
+
+
+def spherical_harmonics(degree: int, means, viewmat, coeffs, radii=None):
+    """colour[N,3] = max(SH_degree(mean - campos) + 0.5, 0); rows with radii<=0 are 0."""
+    means, viewmat, coeffs = _f32(means, "means"), _f32(viewmat, "viewmat"), _f32(coeffs, "coeffs")
+    if coeffs.dim() != 3 or coeffs.shape[2] != 3 or coeffs.shape[1] > 16:
+        raise ValueError("coeffs must be [N, K<=16, 3]")
+    if not 0 <= degree <= 3 or coeffs.shape[1] < (degree + 1) ** 2:
+        raise ValueError("sh degree must be 0..3 with K >= (degree+1)^2 coefficients")
+    return _SH.apply(int(degree), means, viewmat, coeffs, radii)
+
+
+# --------------------------------------------------------------------------------------------
+# K3 + K4 binning and sort (integer path, no gradients)
+
+
+@torch.no_grad()
+def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, sort=True):
+    """-> (isect_ids[I] int64, flatten_ids[I] int32, tile_offsets[T+1] int32).
+    One host read-back (I) sizes the lists, as in the reference's rasterizer."""
+    lib = _lib.load()
+    N = means2d.shape[0]
+    dev = means2d.device
+    n_tiles = tile_w * tile_h
+    cum = torch.empty(N, dtype=torch.int64, device=dev)
+    ws = torch.empty(max(int(lib.fg_scan_workspace_bytes(N)), 8), dtype=torch.uint8, device=dev)
+    _call("fg_scan_tiles", N, _ptr(tiles_touched), _ptr(cum), _ptr(ws), ws.numel(), _stream())
+    n_isects = int(cum[-1].item()) if N > 0 else 0
+    if n_isects >= 2**31:
+        raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+    isect_ids = torch.empty(n_isects, dtype=torch.int64, device=dev)
+    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    if n_isects > 0:
+        _call("fg_tile_bin", N, _ptr(means2d), _ptr(radii), _ptr(depths), _ptr(cum), tile_size, tile_w, tile_h,
+                            _ptr(isect_ids), _ptr(flatten_ids), _stream())  # fmt: skip
+        if sort:
+            sort_pairs(isect_ids, flatten_ids, 32 + max(n_tiles - 1, 1).bit_length())
+    _call("fg_tile_ranges", n_isects, _ptr(isect_ids), n_tiles, _ptr(offsets), _stream())
+    return isect_ids, flatten_ids, offsets
+
+
+@torch.no_grad()
+def sort_pairs(keys: torch.Tensor, vals: torch.Tensor, end_bit: int = 64) -> None:
+    """In-place stable radix sort of (int64 key, int32 value) pairs on key bits [0, end_bit)."""
+    lib = _lib.load()
+    n = keys.numel()
+    assert keys.dtype == torch.int64 and vals.dtype == torch.int32 and vals.numel() == n
+    assert keys.is_cuda and keys.is_contiguous() and vals.is_contiguous()
+    ws = torch.empty(max(int(lib.fg_sort_workspace_bytes(n)), 8), dtype=torch.uint8, device=keys.device)
+    _call("fg_sort_pairs", n, _ptr(keys), _ptr(vals), int(end_bit), _ptr(ws), ws.numel(), _stream())  # fmt: skip
+
+
+# --------------------------------------------------------------------------------------------
+# K5 / K6 compositing
+
+
+class _Rasterize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, conics, features, opacities, width, height, tile_size, tile_offsets, flatten_ids,
+                absgrad):  # fmt: skip
+        lib = _lib.load()
+        m2 = means2d.reshape(-1, 2)
+        N, C = features.shape
+        dev = features.device
+        splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        _call("fg_pack_splats", N, C, _ptr(m2), _ptr(conics), _ptr(opacities), _ptr(features), _ptr(splats), _stream())  # fmt: skip
+        render = torch.empty(height, width, C, dtype=torch.float32, device=dev)
+        alphas = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        _call("fg_raster_fwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
+                              _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
+        ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids)
+        ctx.geom = (N, C, width, height, tile_size, absgrad, tuple(means2d.shape))
+        ctx.means2d_ref = means2d if absgrad else None  # the object that receives .absgrad
+        ctx.mark_non_differentiable(last_ids)
+        return render, alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _v_last):
+        lib = _lib.load()
+        splats, tile_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        N, C, width, height, tile_size, absgrad, m2_shape = ctx.geom
+        dev = splats.device
+        v_render = torch.zeros_like(alphas).expand(height, width, C) if v_render is None else v_render
+        v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas
+        v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
+                              _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()),
+                              _ptr(v_alphas.contiguous()), _ptr(v_splats), _stream())  # fmt: skip
+        v_means2d = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        v_abs = torch.empty(N, 2, dtype=torch.float32, device=dev) if absgrad else None
+        v_conics = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        v_opac = torch.empty(N, dtype=torch.float32, device=dev)
+        v_feat = torch.empty(N, C, dtype=torch.float32, device=dev)
+        _call("fg_unpack_grads", N, C, _ptr(v_splats), _ptr(v_means2d), _ptr(v_abs), _ptr(v_conics), _ptr(v_opac),
+                                _ptr(v_feat), _stream())  # fmt: skip
+        if absgrad and ctx.means2d_ref is not None:
+            # side channel read by the densification heuristics
+            # (reference freegaussian_model.py:377 `self.xys.absgrad`)
+            ctx.means2d_ref.absgrad = v_abs.reshape(m2_shape)
+            ctx.means2d_ref = None
+        return v_means2d.reshape(m2_shape), v_conics, v_feat, v_opac, None, None, None, None, None, None
+
+
+def rasterize_to_pixels(means2d, conics, features, opacities, width, height, tile_size, tile_offsets, flatten_ids,
+                        absgrad=False):  # fmt: skip
+    """-> render[H,W,C], alphas[H,W,1], last_ids[H,W].  means2d may be [N,2] or [1,N,2]; the
+    very tensor object passed here receives ``.absgrad`` after backward."""
+    if tile_size != TILE_SIZE:
+        raise ValueError("tile_size must be 16")
+    C = features.shape[1]
+    if not 1 <= C <= MAX_CHANNELS:
+        raise ValueError(f"1..{MAX_CHANNELS} composited channels supported, got {C}")
+    if not means2d.is_cuda:
+        raise _lib.FgRasterError("rasterize_to_pixels needs CUDA/HIP tensors: no CPU fallback")
+    return _Rasterize.apply(means2d, conics.contiguous(), features.contiguous(), opacities.contiguous(), int(width),
+                            int(height), int(tile_size), tile_offsets, flatten_ids, bool(absgrad))  # fmt: skip
+
+
+# --------------------------------------------------------------------------------------------
+# F flow derivative
+
+
+def camera_flow(depth: torch.Tensor, K: torch.Tensor, veloc: torch.Tensor, omega: torch.Tensor) -> torch.Tensor:
+    """Per-pixel camera flow ``A v/Z + B w`` (reference preprocess/epipolar_flow.py:274-317).
+    depth[H,W] -> flow[H,W,2]."""
+    lib = _lib.load()
+    depth, K = _f32(depth, "depth"), _f32(K, "K")
+    veloc, omega = _f32(veloc, "veloc"), _f32(omega, "omega")
+    H, W = depth.shape
+    flow = torch.empty(H, W, 2, dtype=torch.float32, device=depth.device)
+    _call("fg_camera_flow", W, H, _ptr(depth), _ptr(K), _ptr(veloc), _ptr(omega), _ptr(flow), _stream())  # fmt: skip
+    return flow
+
+
+class _GaussianFlow(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means2d, depths, vel, radii, K, veloc, omega):
+        lib = _lib.load()
+        N = depths.shape[0]
+        u_gs = torch.empty(N, 2, dtype=torch.float32, device=depths.device)
+        u_cam = torch.empty_like(u_gs)
+        _call("fg_flow_fwd", N, _ptr(means2d), _ptr(depths), _ptr(radii), _ptr(vel), _ptr(K), _ptr(veloc), _ptr(omega),
+                            _ptr(u_gs), _ptr(u_cam), _stream())  # fmt: skip
+        ctx.save_for_backward(means2d, depths, vel, radii, K, veloc, omega)
+        return u_gs, u_cam
+
+    @staticmethod
+    def backward(ctx, v_gs, v_cam):
+        lib = _lib.load()
+        means2d, depths, vel, radii, K, veloc, omega = ctx.saved_tensors
+        N = depths.shape[0]
+        v_gs = torch.zeros(N, 2, device=depths.device) if v_gs is None else v_gs.contiguous()
+        v_cam = torch.zeros(N, 2, device=depths.device) if v_cam is None else v_cam.contiguous()
+        v_m = torch.empty_like(means2d)
+        v_d = torch.empty_like(depths)
+        v_v = torch.empty_like(vel)
+        _call("fg_flow_bwd", N, _ptr(means2d), _ptr(depths), _ptr(radii), _ptr(vel), _ptr(K), _ptr(veloc), _ptr(omega),
+                            _ptr(v_gs), _ptr(v_cam), _ptr(v_m), _ptr(v_d), _ptr(v_v), _stream())  # fmt: skip
+        return v_m, v_d, v_v, None, None, None, None
+
+
+def gaussian_flow(means2d, depths, vel, K, veloc, omega, radii=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Per-Gaussian projection-flow Jacobian terms (Lemma 1, reference docs/index.html:256-273):
+    ``u_gs = A(mu) vel / Z`` and ``u_cam = A(mu) v / Z + B(mu) w``; both [N,2], differentiable
+    w.r.t. means2d, depths and vel."""
+    means2d, depths, vel = _f32(means2d, "means2d"), _f32(depths, "depths"), _f32(vel, "vel")
+    K, veloc, omega = _f32(K, "K"), _f32(veloc, "veloc"), _f32(omega, "omega")
+    return _GaussianFlow.apply(means2d.reshape(-1, 2), depths, vel, radii, K, veloc, omega)

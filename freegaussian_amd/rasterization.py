@@ -1,0 +1,171 @@
+"""Drop-in replacement for ``gsplat.rendering.rasterization`` as the reference calls it.
+
+Call sites this mirrors (kwargs, return values, error behaviour):
+  * ``freegaussian/freegaussian_model.py:847-868``          training / eval, ``packed=False``
+  * ``freegaussian/freegaussian_control_model.py:158-179``  stage 2, same kwargs
+  * ``preprocess/knn_gaussian.py:93-113`` etc.              ``packed=True``, ``render_mode="ED"``
+
+plus the two helpers the reference imports from gsplat: ``quat_to_rotmat``
+(``freegaussian_model.py:15,535``) and ``num_sh_bases`` (``:21,165``).
+
+Everything below the argument checks runs in ``libfgraster.so`` (hand-written gfx950 HIP); the
+Python here only sequences the stages and owns the autograd tape.  There is no CPU path."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+
+RENDER_MODES = ("RGB", "D", "ED", "RGB+D", "RGB+ED")
+
+
+def num_sh_bases(degree: int) -> int:
+    """Number of SH basis functions for ``degree`` (reference use: freegaussian_model.py:165)."""
+    return (degree + 1) ** 2
+
+
+def quat_to_rotmat(quats: torch.Tensor) -> torch.Tensor:
+    """[M,4] wxyz (any norm) -> [M,3,3]; component order of reference utils.py:287-301.
+    Used on the host by split_gaussians (freegaussian_model.py:535): plain torch, any device."""
+    q = quats / quats.norm(dim=-1, keepdim=True)
+    w, x, y, z = q.unbind(-1)
+    R = torch.stack(
+        [
+            1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y),
+            2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x),
+            2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y),
+        ],
+        dim=-1,
+    )  # fmt: skip
+    return R.reshape(quats.shape[:-1] + (3, 3))
+
+
+def rasterization(
+    means: torch.Tensor,  # [N,3]
+    quats: torch.Tensor,  # [N,4] wxyz, normalised by the callee
+    scales: torch.Tensor,  # [N,3]
+    opacities: torch.Tensor,  # [N]
+    colors: torch.Tensor,  # [N,K,3] SH coefficients, or [N,C] when sh_degree is None
+    viewmats: torch.Tensor,  # [1,4,4] world->camera
+    Ks: torch.Tensor,  # [1,3,3]
+    width: int,
+    height: int,
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    sh_degree: Optional[int] = None,
+    packed: bool = True,
+    tile_size: int = 16,
+    backgrounds: Optional[torch.Tensor] = None,
+    render_mode: str = "RGB",
+    sparse_grad: bool = False,
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    extra_channels: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
+    """Render one camera.  Returns ``(render [1,H,W,C], alpha [1,H,W,1], info)``.
+
+    ``info["means2d"]`` is a non-leaf tensor in the graph ([1,N,2], or [nnz,2] when packed):
+    ``.retain_grad()`` works on it and after backward it carries ``.absgrad`` when
+    ``absgrad=True`` (reference freegaussian_model.py:869-872, :377).  ``info["radii"]`` is
+    int32 [1,N] (``>0`` <=> visible).  ``extra_channels`` [N,E] (an extension) are composited
+    like colours and appended after the render-mode channels -- used for the flow channels."""
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    if render_mode not in RENDER_MODES:
+        raise ValueError(f"Unknown render_mode: {render_mode}")
+    if sparse_grad:
+        raise NotImplementedError("sparse_grad=True is never used by the reference (freegaussian_model.py:863)")
+    if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
+        raise ValueError("exactly one camera per call (reference asserts camera.shape[0]==1)")
+    N = means.shape[0]
+    if not (means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3) and opacities.shape == (N,)):
+        raise ValueError("means[N,3] quats[N,4] scales[N,3] opacities[N] expected")
+    if sh_degree is None:
+        if colors.dim() != 2 or colors.shape[0] != N:
+            raise ValueError("colors must be [N,C] when sh_degree is None")
+    else:
+        if colors.dim() != 3 or colors.shape[0] != N or colors.shape[2] != 3:
+            raise ValueError("colors must be [N,K,3] SH coefficients when sh_degree is given")
+        if (sh_degree + 1) ** 2 > colors.shape[1]:
+            raise ValueError("sh_degree too large for the given coefficients")
+
+    viewmat = viewmats[0]
+    K = Ks[0]
+    radii, means2d_n, depths, conics, comp, tiles = ops.project(
+        means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
+        calc_compensations=(rasterize_mode == "antialiased"),
+    )  # fmt: skip
+    opac = opacities.float()
+    if rasterize_mode == "antialiased":
+        opac = opac * comp
+
+    if sh_degree is None:
+        rgb = colors.float()
+    else:
+        rgb = ops.spherical_harmonics(sh_degree, means, viewmat, colors, radii)
+
+    chans = []
+    if render_mode.startswith("RGB"):
+        chans.append(rgb)
+    if render_mode.endswith("D"):
+        chans.append(depths[:, None])
+    if extra_channels is not None:
+        chans.append(extra_channels.float())
+    feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
+
+    tile_w = (width + tile_size - 1) // tile_size
+    tile_h = (height + tile_size - 1) // tile_size
+    isect_ids, flatten_ids, offsets = ops.isect_tiles(
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
+    )
+
+    if packed:
+        # the reference's packed call sites (knn_gaussian.py:116-130) index these by nnz
+        gids = torch.nonzero(radii > 0).squeeze(-1)
+        means2d_info = means2d_n[gids]
+        means2d_in = means2d_n
+    else:
+        means2d_info = means2d_n.unsqueeze(0)  # [1,N,2]: the tensor that is retain_grad()'ed
+        means2d_in = means2d_info
+
+    render, alpha, last_ids = ops.rasterize_to_pixels(
+        means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
+    )
+    if backgrounds is not None:
+        render = render + (1.0 - alpha) * backgrounds.reshape(1, 1, -1)
+    if render_mode in ("ED", "RGB+ED"):
+        di = 3 if render_mode == "RGB+ED" else 0
+        d = render[..., di : di + 1] / alpha.clamp(min=1e-10)
+        render = torch.cat([render[..., :di], d, render[..., di + 1 :]], dim=-1)
+
+    info = {
+        "radii": radii[None],
+        "means2d": means2d_info,
+        "depths": depths[None],
+        "conics": conics[None],
+        "opacities": opac[None],
+        "tile_width": tile_w,
+        "tile_height": tile_h,
+        "tiles_per_gauss": tiles[None],
+        "isect_ids": isect_ids,
+        "flatten_ids": flatten_ids,
+        "isect_offsets": offsets,
+        "last_ids": last_ids,
+        "width": width,
+        "height": height,
+        "tile_size": tile_size,
+        "n_cameras": 1,
+    }
+    if packed:
+        info.update(
+            camera_ids=torch.zeros_like(gids),
+            gaussian_ids=gids,
+            radii=radii[gids],
+            depths=depths[gids],
+            conics=conics[gids],
+        )
+    return render[None], alpha[None], info

@@ -1,0 +1,340 @@
+"""GPU parity: every HIP stage, called through the C ABI, against the CPU oracle on the same
+seeded inputs.  Integer results (radii, tile counts, sort keys, list order, tile ranges) must be
+bit-exact; floating results within REL_TOL = 1e-4 (scale-relative), the bar BASELINE.json's
+north_star states.  PARITY UNPINNED w.r.t. gsplat itself: see oracle/raster_oracle.py header."""
+import math
+
+import pytest
+import torch
+
+from freegaussian_amd import _lib, ops, rasterization
+from freegaussian_amd.scenes import plumbing_scene, synthetic_scene
+from helpers import REL_TOL, psnr, rel_err, rel_l2
+from oracle import raster_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (no CPU fallback exists)")
+    _lib.load()
+
+
+def _scene(n=6000, w=200, h=120, seed=3, **kw):
+    return synthetic_scene(n, w, h, n_views=2, seed=seed, **kw)
+
+
+# ------------------------------------------------------------------------------------------
+def test_wave_reduce16_transposed():
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(-8, 9, (64, 16), generator=g).float()  # integers: exact sums
+    out = torch.zeros(144, device=DEV)
+    _lib.check(lib.fg_debug_wave_reduce16(x.to(DEV).data_ptr(), out.data_ptr(), None), "dbg")
+    torch.cuda.synchronize()
+    out = out.cpu()
+    assert torch.equal(out[:16], x.sum(0))
+    assert torch.equal(out[16:80], x.sum(0).repeat_interleave(4))
+    assert torch.equal(out[80:144], x[:, 0].sum().expand(64))
+
+
+@pytest.mark.parametrize("n,end_bit", [(1, 64), (63, 64), (4096, 40), (4097, 45), (100_003, 45), (1_000_000, 45)])
+def test_sort_pairs_bit_exact_and_stable(n, end_bit):
+    g = torch.Generator().manual_seed(n)
+    # few distinct high bits + many duplicate keys exercise stability
+    keys = torch.randint(0, 2**13, (n,), generator=g) << 32 | torch.randint(0, 2**10, (n,), generator=g) << 20
+    keys &= (1 << end_bit) - 1
+    vals = torch.arange(n, dtype=torch.int32)
+    ref_k, order = torch.sort(keys, stable=True)
+    k, v = keys.to(DEV), vals.to(DEV)
+    ops.sort_pairs(k, v, end_bit)
+    assert torch.equal(k.cpu(), ref_k)
+    assert torch.equal(v.cpu(), vals[order])
+
+
+def test_sort_full_64bit_random():
+    g = torch.Generator().manual_seed(7)
+    n = 300_000
+    keys = torch.randint(-(2**62), 2**62, (n,), generator=g).abs()
+    vals = torch.arange(n, dtype=torch.int32)
+    ref_k, order = torch.sort(keys, stable=True)
+    k, v = keys.to(DEV), vals.to(DEV)
+    ops.sort_pairs(k, v, 64)
+    assert torch.equal(k.cpu(), ref_k) and torch.equal(v.cpu(), vals[order])
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("view", [0, 1])
+def test_project_bit_exact(view):
+    sc = _scene()
+    # put some Gaussians behind / beside the camera and make a few huge
+    sc.means[:50] *= 4.0
+    sc.scales[50:60] *= 30.0
+    vm, K = sc.viewmats[view], sc.Ks[view]
+    ref = O.project(sc.means, sc.quats, sc.scales, vm, K, sc.width, sc.height)
+    radii, m2, d, con, comp, tiles = ops.project(
+        sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), vm.to(DEV), K.to(DEV), sc.width, sc.height,
+        calc_compensations=True,
+    )  # fmt: skip
+    assert 0 < (ref.radii > 0).sum() < sc.means.shape[0]
+    assert torch.equal(radii.cpu(), ref.radii)
+    # bit-exact floats feeding the integer path
+    assert torch.equal(m2.cpu().view(torch.int32), ref.means2d.view(torch.int32))
+    assert torch.equal(d.cpu().view(torch.int32), ref.depths.view(torch.int32))
+    assert torch.equal(con.cpu().view(torch.int32), ref.conics.view(torch.int32))
+    assert torch.equal(comp.cpu().view(torch.int32), ref.compensations.view(torch.int32))
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    cnt, _, _ = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=False)
+    assert torch.equal(tiles.cpu(), cnt)
+
+
+def test_isect_keys_order_and_ranges_bit_exact():
+    sc = _scene(n=20000, w=333, h=207)  # ragged right/bottom tiles
+    sc.scales[:30] *= 20.0
+    vm, K = sc.viewmats[0], sc.Ks[0]
+    ref = O.project(sc.means, sc.quats, sc.scales, vm, K, sc.width, sc.height)
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    _, keys_u, vals_u = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=False)
+    _, keys_s, vals_s = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=True)
+    offs_ref = O.isect_offsets(keys_s, tw * th)
+    radii, m2, d, con, comp, tiles = ops.project(
+        sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), vm.to(DEV), K.to(DEV), sc.width, sc.height
+    )
+    ku, vu, _ = ops.isect_tiles(m2, radii, d, tiles, 16, tw, th, sort=False)
+    assert torch.equal(ku.cpu(), keys_u) and torch.equal(vu.cpu(), vals_u)
+    ks, vs, offs = ops.isect_tiles(m2, radii, d, tiles, 16, tw, th, sort=True)
+    assert torch.equal(ks.cpu(), keys_s)
+    assert torch.equal(vs.cpu(), vals_s)
+    assert torch.equal(offs.cpu(), offs_ref)
+
+
+def test_isect_empty_scene():
+    """All Gaussians behind the camera: I = 0, every range empty, render = 0."""
+    sc = plumbing_scene()
+    means = sc.means.clone()
+    means[:, 2] -= 100.0
+    r, a, info = rasterization(means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), sc.opacities.to(DEV),
+                               sc.colors.to(DEV), sc.viewmats.to(DEV), sc.Ks.to(DEV), 128, 128, sh_degree=0,
+                               packed=False)  # fmt: skip
+    assert info["flatten_ids"].numel() == 0
+    assert int(info["isect_offsets"].abs().sum()) == 0
+    assert float(r.abs().max()) == 0.0 and float(a.abs().max()) == 0.0
+    assert int((info["radii"] > 0).sum()) == 0
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("degree", [0, 1, 2, 3])
+def test_sh_forward_backward(degree):
+    sc = _scene(n=3000)
+    vm = sc.viewmats[1]
+    radii = torch.ones(3000, dtype=torch.int32)
+    radii[::7] = 0
+    coeffs = sc.colors.clone().requires_grad_(True)
+    means = sc.means.clone().requires_grad_(True)
+    campos = torch.linalg.inv(vm)[:3, 3]
+    ref = torch.clamp_min(O.sh_eval(degree, means - campos, coeffs) + 0.5, 0.0) * (radii > 0)[:, None]
+    vcol = torch.randn(3000, 3, generator=torch.Generator().manual_seed(1))
+    (ref * vcol).sum().backward()
+    c2 = sc.colors.to(DEV).requires_grad_(True)
+    m2 = sc.means.to(DEV).requires_grad_(True)
+    out = ops.spherical_harmonics(degree, m2, vm.to(DEV), c2, radii.to(DEV))
+    (out * vcol.to(DEV)).sum().backward()
+    assert rel_err(out, ref) < REL_TOL
+    assert rel_err(c2.grad, coeffs.grad) < REL_TOL
+    if degree > 0:
+        assert rel_err(m2.grad, means.grad) < REL_TOL
+    else:
+        assert float(m2.grad.abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------------------------------
+def _raster_inputs(sc, view=0, channels=3, seed=0):
+    vm, K = sc.viewmats[view], sc.Ks[view]
+    ref = O.project(sc.means, sc.quats, sc.scales, vm, K, sc.width, sc.height)
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    _, keys, vals = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th)
+    offs = O.isect_offsets(keys, tw * th)
+    g = torch.Generator().manual_seed(seed)
+    feats = torch.rand(sc.means.shape[0], channels, generator=g)
+    return ref, feats, offs, vals
+
+
+@pytest.mark.parametrize("channels", [1, 3, 4, 6, 8])
+def test_raster_forward_backward_vs_oracle(channels):
+    sc = _scene(n=8000, w=150, h=100)  # 150x100: partial tiles on both edges
+    sc.opacities[:400] = 1.0  # exercise the 0.999 clamp branch
+    ref, feats, offs, vals = _raster_inputs(sc, channels=channels)
+    W, H = sc.width, sc.height
+    r_ref, a_ref, last_ref = O.rasterize(ref.means2d, ref.conics, feats, sc.opacities, W, H, 16, offs, vals)
+    g = torch.Generator().manual_seed(5)
+    vr, va = torch.randn(H, W, channels, generator=g), torch.randn(H, W, 1, generator=g)
+    gref = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, W, H, 16, offs, vals, vr, va[..., 0])
+
+    m2 = ref.means2d.to(DEV).requires_grad_(True)
+    con = ref.conics.to(DEV).requires_grad_(True)
+    ft = feats.to(DEV).requires_grad_(True)
+    op = sc.opacities.to(DEV).requires_grad_(True)
+    r, a, last = ops.rasterize_to_pixels(m2, con, ft, op, W, H, 16, offs.to(DEV), vals.to(DEV), absgrad=True)
+    ((r * vr.to(DEV)).sum() + (a * va.to(DEV)).sum()).backward()
+    assert rel_err(r, r_ref) < REL_TOL
+    assert rel_err(a, a_ref) < REL_TOL
+    # last contributing index: integer, allow only knife-edge pixels to differ
+    assert (last.cpu() != last_ref).float().mean().item() < 1e-3
+    for name, x, y in [("means2d", m2.grad, gref[0]), ("absgrad", m2.absgrad, gref[1]), ("conics", con.grad, gref[2]),
+                       ("features", ft.grad, gref[3]), ("opacities", op.grad, gref[4])]:  # fmt: skip
+        assert rel_l2(x, y) < REL_TOL, name
+        assert rel_err(x, y) < 10 * REL_TOL, name
+
+
+def test_raster_dense_stack_hits_transmittance_stop():
+    """Many opaque splats on top of each other: pixels must stop at T <= 1e-4 like the oracle."""
+    g = torch.Generator().manual_seed(11)
+    N, W, H = 600, 64, 48
+    m2 = torch.rand(N, 2, generator=g) * torch.tensor([W, H])
+    conics = torch.tensor([[0.02, 0.0, 0.02]]).repeat(N, 1)
+    op = torch.full((N,), 0.9)
+    depths = torch.rand(N, generator=g) + 1
+    radii = torch.full((N,), 40, dtype=torch.int32)
+    feats = torch.rand(N, 3, generator=g)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    _, keys, vals = O.isect_tiles(m2, radii, depths, 16, tw, th)
+    offs = O.isect_offsets(keys, tw * th)
+    r_ref, a_ref, last_ref = O.rasterize(m2, conics, feats, op, W, H, 16, offs, vals)
+    assert (a_ref > 1 - 1.5e-4).float().mean() > 0.5  # the stop rule is what ends most pixels
+    vr, va = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g)
+    gref = O.rasterize_backward(m2, conics, feats, op, W, H, 16, offs, vals, vr, va[..., 0])
+    t = [x.to(DEV).requires_grad_(True) for x in (m2, conics, feats, op)]
+    r, a, last = ops.rasterize_to_pixels(*t, W, H, 16, offs.to(DEV), vals.to(DEV), absgrad=True)
+    ((r * vr.to(DEV)).sum() + (a * va.to(DEV)).sum()).backward()
+    assert rel_err(r, r_ref) < REL_TOL and rel_err(a, a_ref) < REL_TOL
+    assert (last.cpu() != last_ref).float().mean().item() < 1e-3
+    for x, y in zip([t[0].grad, t[0].absgrad, t[1].grad, t[2].grad, t[3].grad], gref):
+        assert rel_l2(x, y) < 2 * REL_TOL
+
+
+# ------------------------------------------------------------------------------------------
+def _run_both(sc, view, render_mode, sh_degree, rasterize_mode="classic", extra=None, seed=0):
+    names = ["means", "quats", "scales", "opacities", "colors"]
+    cpu = [sc.means, sc.quats, sc.scales, sc.opacities, sc.colors]
+    ref_in = [t.clone().requires_grad_(True) for t in cpu]
+    gpu_in = [t.to(DEV).requires_grad_(True) for t in cpu]
+    kw = dict(width=sc.width, height=sc.height, sh_degree=sh_degree, render_mode=render_mode, packed=False,
+              absgrad=True, rasterize_mode=rasterize_mode)  # fmt: skip
+    vm, K = sc.viewmats[view : view + 1], sc.Ks[view : view + 1]
+    r0, a0, i0 = O.rasterization(*ref_in, vm, K, extra_channels=extra, **kw)
+    r1, a1, i1 = rasterization(*gpu_in, vm.to(DEV), K.to(DEV),
+                               extra_channels=None if extra is None else extra.to(DEV), **kw)  # fmt: skip
+    i1["means2d"].retain_grad()
+    g = torch.Generator().manual_seed(seed)
+    vr, va = torch.randn(r0.shape, generator=g), torch.randn(a0.shape, generator=g)
+    ((r0 * vr).sum() + (a0 * va).sum()).backward()
+    ((r1 * vr.to(DEV)).sum() + (a1 * va.to(DEV)).sum()).backward()
+    return dict(zip(names, ref_in)), dict(zip(names, gpu_in)), (r0, a0, i0), (r1, a1, i1)
+
+
+def test_cfg1_plumbing_end_to_end():
+    """BASELINE configs[0]: 1k Gaussians, 128x128, one view."""
+    sc = plumbing_scene()
+    ref_in, gpu_in, (r0, a0, i0), (r1, a1, i1) = _run_both(sc, 0, "RGB", 0)
+    assert torch.equal(i1["radii"].cpu(), i0["radii"])
+    assert torch.equal(i1["isect_ids"].cpu(), i0["isect_ids"])
+    assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
+    assert torch.equal(i1["isect_offsets"].cpu(), i0["isect_offsets"])
+    assert rel_err(r1, r0) < REL_TOL and rel_err(a1, a0) < REL_TOL
+    assert psnr(r1, r0) > 80
+    for k in ref_in:
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < REL_TOL, k
+    assert i1["means2d"].grad is not None and i1["means2d"].absgrad.shape == (1, 1000, 2)
+    assert i1["radii"].shape == (1, 1000) and i1["radii"].dtype == torch.int32
+
+
+@pytest.mark.parametrize("render_mode,sh_degree,rmode", [("RGB", 3, "classic"), ("RGB+ED", 2, "classic"),
+                                                         ("ED", 3, "classic"), ("RGB+ED", 3, "antialiased"),
+                                                         ("RGB", None, "classic")])  # fmt: skip
+def test_full_pipeline_modes(render_mode, sh_degree, rmode):
+    sc = _scene(n=15000, w=256, h=144, seed=9)
+    if sh_degree is None:
+        sc.colors = torch.sigmoid(sc.colors[:, 0, :])
+    ref_in, gpu_in, (r0, a0, i0), (r1, a1, i1) = _run_both(sc, 1, render_mode, sh_degree, rmode)
+    assert torch.equal(i1["isect_ids"].cpu(), i0["isect_ids"])
+    assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
+    assert r1.shape == r0.shape and a1.shape == a0.shape
+    assert rel_err(r1, r0) < 3 * REL_TOL and rel_err(a1, a0) < REL_TOL
+    for k in ref_in:
+        if ref_in[k].grad is None:
+            continue
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+
+
+def test_packed_mode_info():
+    """packed=True + render_mode='ED' as preprocess/knn_gaussian.py:93-130 uses it."""
+    sc = _scene(n=5000)
+    sc.means[:100] *= 5
+    with torch.no_grad():
+        r0, a0, i0 = O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, sc.viewmats[:1],
+                                     sc.Ks[:1], sc.width, sc.height, sh_degree=3, packed=True, render_mode="ED")
+        r1, a1, i1 = rasterization(sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), sc.opacities.to(DEV),
+                                   sc.colors.to(DEV), sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), sc.width,
+                                   sc.height, sh_degree=3, packed=True, render_mode="ED")  # fmt: skip
+    assert r1.shape == (1, sc.height, sc.width, 1)
+    assert torch.equal(i1["gaussian_ids"].cpu(), i0["gaussian_ids"])
+    assert i1["means2d"].shape == (i0["gaussian_ids"].numel(), 2)
+    assert torch.equal(i1["means2d"].cpu(), i0["means2d"]) and torch.equal(i1["depths"].cpu(), i0["depths"])
+    assert rel_err(r1, r0) < 3 * REL_TOL
+
+
+def test_backward_is_repeatable_within_tolerance():
+    """Atomic accumulation order may change the last bits, never more."""
+    sc = _scene(n=8000)
+    outs = []
+    for _ in range(2):
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, _ = rasterization(*t, sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), sc.width, sc.height, sh_degree=3,
+                                packed=False, absgrad=True)  # fmt: skip
+        (r.square().sum() + a.sum()).backward()
+        outs.append([x.grad.clone() for x in t] + [r.detach().clone()])
+    assert torch.equal(outs[0][-1], outs[1][-1])  # forward is deterministic
+    for x, y in zip(outs[0][:-1], outs[1][:-1]):
+        assert rel_l2(x, y) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+def test_flow_kernels_vs_oracle():
+    g = torch.Generator().manual_seed(2)
+    N, W, H = 5000, 96, 64
+    K = torch.tensor([[80.0, 0, 47.5], [0, 90.0, 31.0], [0, 0, 1]])
+    veloc, omega = torch.tensor([0.02, -0.01, 0.03]), torch.tensor([0.004, 0.01, -0.006])
+    m2 = (torch.rand(N, 2, generator=g) * torch.tensor([W, H])).requires_grad_(True)
+    dep = (torch.rand(N, generator=g) * 3 + 0.5).requires_grad_(True)
+    vel = torch.randn(N, 3, generator=g).requires_grad_(True)
+    ugs0, ucam0 = O.gaussian_flow(m2, dep, vel, K[0, 0], K[1, 1], K[0, 2], K[1, 2], veloc, omega)
+    v1, v2 = torch.randn(N, 2, generator=g), torch.randn(N, 2, generator=g)
+    ((ugs0 * v1).sum() + (ucam0 * v2).sum()).backward()
+    t = [x.detach().to(DEV).requires_grad_(True) for x in (m2, dep, vel)]
+    ugs1, ucam1 = ops.gaussian_flow(*t, K.to(DEV), veloc.to(DEV), omega.to(DEV))
+    ((ugs1 * v1.to(DEV)).sum() + (ucam1 * v2.to(DEV)).sum()).backward()
+    assert rel_err(ugs1, ugs0) < REL_TOL and rel_err(ucam1, ucam0) < REL_TOL
+    for x, y in zip(t, (m2, dep, vel)):
+        assert rel_l2(x.grad, y.grad) < REL_TOL
+    Z = torch.rand(H, W, generator=g) * 4 + 0.3
+    Z[3, 5] = float("inf")
+    f0 = O.camera_flow(Z, K[0, 0], K[1, 1], K[0, 2], K[1, 2], veloc, omega)
+    f1 = ops.camera_flow(Z.to(DEV), K.to(DEV), veloc.to(DEV), omega.to(DEV))
+    assert rel_err(f1, f0) < REL_TOL and float(f1[3, 5].abs().max()) == 0.0
+
+
+def test_composited_flow_channels_f1():
+    """F1 (Corollary 1): sum_i T_i alpha_i (mu_t - mu_0) as two extra composited channels, with
+    gradients reaching both sets of Gaussian positions."""
+    sc = _scene(n=6000, w=128, h=96, seed=4)
+    g = torch.Generator().manual_seed(8)
+    disp = torch.randn(6000, 2, generator=g)
+    ref_in, gpu_in, (r0, a0, i0), (r1, a1, i1) = _run_both(sc, 0, "RGB+ED", 3, extra=disp)
+    assert r1.shape[-1] == 6
+    assert rel_err(r1[..., 4:], r0[..., 4:]) < 3 * REL_TOL
+    for k in ref_in:
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
