@@ -62,6 +62,20 @@ __device__ __forceinline__ int wave_max_i32(int v) {
   return v;
 }
 
+// a' = [a.lo32, b.lo32], b' = [a.hi32, b.hi32]; returns a' + b'.  Inline asm: the builtin's
+// second result is mis-extracted by ROCm 7.2's hipcc when bit-cast to float (both operands of
+// the add became the first result).  The s_nops cover the VALU->permlane-swap wait states that
+// hipcc does not insert around asm statements.
+__device__ __forceinline__ float swap32_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+// rows of 16 lanes: a' = [a.r0, b.r0, a.r2, b.r2], b' = [a.r1, b.r1, a.r3, b.r3]
+__device__ __forceinline__ float swap16_add(float a, float b) {
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
 // Transposing wave reduction: 16 per-lane values -> after the call lane l holds, in the
 // return value, the 64-lane sum of value index (l >> 2).  ~37 VALU instructions and no LDS.
 __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16]) {
@@ -69,16 +83,12 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16]) {
   // step 1: lanes l <-> l^32 (v_permlane32_swap): 16 -> 8 registers, bit5 selects j / j+8
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
-    auto r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, v[j]),
-                                              __builtin_bit_cast(unsigned, v[j + 8]), false, false);
-    v[j] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    v[j] = swap32_add(v[j], v[j + 8]);
   }
   // step 2: lanes l <-> l^16 (v_permlane16_swap): 8 -> 4, bit4 selects j / j+4
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    auto r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, v[j]),
-                                              __builtin_bit_cast(unsigned, v[j + 4]), false, false);
-    v[j] = __builtin_bit_cast(float, r[0]) + __builtin_bit_cast(float, r[1]);
+    v[j] = swap16_add(v[j], v[j + 4]);
   }
   // step 3: lanes l <-> l^8 (DPP row_ror:8): 4 -> 2, bit3 selects j / j+2
   const bool b3 = (lane & 8) != 0;

@@ -128,8 +128,9 @@ def _project_core(means, quats, scales, viewmat, K, width, height, eps2d):
             CC[j][i] = CC[i][j]
 
     # perspective Jacobian, evaluated at the FOV-clamped point
-    tan_fovx = 0.5 * width / fx
-    tan_fovy = 0.5 * height / fy
+    # NB: `python_float / tensor` is reciprocal-then-multiply in torch; use a true IEEE division
+    tan_fovx = torch.full_like(fx, 0.5 * width) / fx
+    tan_fovy = torch.full_like(fy, 0.5 * height) / fy
     lim_x = FOV_CLAMP * tan_fovx
     lim_y = FOV_CLAMP * tan_fovy
     rz = 1.0 / z
