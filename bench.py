@@ -74,7 +74,9 @@ def cpu_baseline(scene, view, crop, sh_degree):
     x0, y0 = (scene.width - cw) // 2, (scene.height - ch) // 2
     K[0, 2] -= x0
     K[1, 2] -= y0
-    cores = os.cpu_count() or 1
+    # the oracle is thousands of small tensor ops: beyond a few threads they only add
+    # synchronisation cost, so it is run on (and reported for) at most 8 threads
+    cores = min(os.cpu_count() or 1, 8)
     torch.set_num_threads(cores)
     ins = [t.clone().requires_grad_(True) for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.colors)]
     g = torch.Generator().manual_seed(1)
@@ -88,6 +90,7 @@ def cpu_baseline(scene, view, crop, sh_degree):
         "value": cw * ch / dt / 1e6,
         "unit": "Mpix/s",
         "cores": cores,
+        "host_cpus": os.cpu_count(),
         "kind": "port",
         "sample": f"centre {cw}x{ch} crop of view {view} of the same scene (all {scene.means.shape[0]} Gaussians "
         f"projected, {info['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 run, {dt:.1f} s; "

@@ -313,12 +313,21 @@ unpack_grads_kernel(int N, int C, const float* __restrict__ v_splats, float* __r
   }
 }
 
-int raster_ppt() {
-  static int ppt = [] {
-    const char* e = getenv("FG_RASTER_PPT");
-    const int v = e ? atoi(e) : 4;
-    return (v == 1 || v == 2 || v == 4) ? v : 4;
-  }();
+// Pixels per lane.  Measured on MI355X (1M Gaussians, 1080p, profiles/r01_ppt_sweep.md): the
+// forward is fastest with 1 pixel per lane (4 wavefronts per tile: more latency hiding for
+// the LDS-broadcast loop), the backward with 4 (one wavefront per tile: the 16-value wave
+// reduction + atomic is paid once per 256 pixels).  FG_RASTER_PPT_FWD / _BWD override.
+int env_ppt(const char* name, int dflt) {
+  const char* e = getenv(name);
+  const int v = e ? atoi(e) : dflt;
+  return (v == 1 || v == 2 || v == 4) ? v : dflt;
+}
+int raster_ppt_fwd() {
+  static int ppt = env_ppt("FG_RASTER_PPT_FWD", 1);
+  return ppt;
+}
+int raster_ppt_bwd() {
+  static int ppt = env_ppt("FG_RASTER_PPT_BWD", 4);
   return ppt;
 }
 
@@ -395,7 +404,7 @@ extern "C" int fg_raster_fwd(int channels, int width, int height, int tile_size,
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt();
+  const int ppt = raster_ppt_fwd();
 #define CALL(CC)                                                                                              \
   rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
@@ -415,7 +424,7 @@ extern "C" int fg_raster_bwd(int channels, int width, int height, int tile_size,
     return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt();
+  const int ppt = raster_ppt_bwd();
 #define CALL(CC)                                                                                          \
   rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, s)                                    \
