@@ -1,0 +1,83 @@
+"""Screen-space flow derivative: host side.
+
+* ``relative_camera_motion`` -- (v, w) between two nerfstudio (OpenGL) camera poses with the
+  conventions of the reference's ``diff_2d_epipolar_flow`` (preprocess/epipolar_flow.py:244-270):
+  both poses are converted OpenGL->OpenCV incl. the world-axis swap, w = XYZ Euler angles of
+  R0^-1 R1, v = t1 - t0.  Checked against the reference's own output (tests/golden/g_flow.npz).
+* ``camera_flow_map`` -- the per-pixel camera flow  A v / Z + B w  (epipolar_flow.py:272-317) on
+  the GPU (HIP kernel ``fg_camera_flow``).
+* ``flow_channels`` / ``render_with_flow`` -- F1 of SURVEY.md §8a: the composited Gaussian flow
+  of Corollary 1 (docs/index.html:293-299), sum_i T_i alpha_i (mu_{i,t} - mu_{i,0}), rendered as
+  two extra channels of the same raster pass, plus F2 (Lemma 1) per-Gaussian Jacobian terms
+  through ``ops.gaussian_flow``.  The reference ships no loss that consumes these (SURVEY.md §0
+  finding 3); the loss form here (L1 on finite-depth pixels) is a build choice."""
+from __future__ import annotations
+
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from . import ops
+from .rasterization import rasterization
+
+
+def _opengl_to_opencv(c2w: torch.Tensor) -> torch.Tensor:
+    """[3,4] or [4,4] camera-to-world, OpenGL -> OpenCV with the z-up/y-swap world change the
+    reference applies (epipolar_flow.py:212-229, keep_original_world_coordinate=False)."""
+    m = torch.eye(4, dtype=c2w.dtype, device=c2w.device)
+    m[: c2w.shape[0]] = c2w
+    m[2, :] = -m[2, :]
+    m = m[[0, 2, 1, 3], :]
+    m[0:3, 1:3] = -m[0:3, 1:3]
+    return m
+
+
+def _euler_xyz(R: torch.Tensor) -> torch.Tensor:
+    """Extrinsic x-y-z Euler angles (scipy 'xyz'):  R = Rz(c) Ry(b) Rx(a)  ->  (a, b, c)."""
+    b = -torch.asin(R[2, 0].clamp(-1.0, 1.0))
+    a = torch.atan2(R[2, 1], R[2, 2])
+    c = torch.atan2(R[1, 0], R[0, 0])
+    return torch.stack([a, b, c])
+
+
+def relative_camera_motion(c2w0: torch.Tensor, c2w1: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """-> (veloc [3], omega [3]) in float64."""
+    p0, p1 = _opengl_to_opencv(c2w0.double()), _opengl_to_opencv(c2w1.double())
+    R_rel = torch.linalg.inv(p0[:3, :3]) @ p1[:3, :3]
+    return p1[:3, 3] - p0[:3, 3], _euler_xyz(R_rel)
+
+
+def camera_flow_map(depth: torch.Tensor, K: torch.Tensor, veloc: torch.Tensor, omega: torch.Tensor) -> torch.Tensor:
+    """depth [H,W] or [H,W,1] (inf allowed) -> camera flow [H,W,2] (fp32, GPU)."""
+    return ops.camera_flow(depth.reshape(depth.shape[0], depth.shape[1]), K, veloc, omega)
+
+
+def render_with_flow(
+    means_t, means_0, quats, scales, opacities, colors, viewmat_t, viewmat_0, K, width, height,
+    sh_degree: Optional[int] = 3, render_mode: str = "RGB+ED", rasterize_mode: str = "classic",
+) -> Dict[str, torch.Tensor]:  # fmt: skip
+    """One raster pass that also composites the Gaussian flow (F1).
+
+    ``means_t`` are the Gaussian centres at the current time under the current camera
+    ``viewmat_t``; ``means_0`` the same Gaussians ``interval`` frames earlier under
+    ``viewmat_0`` (the reference attaches that pose as ``cameras0``,
+    freegaussian_model.py:769-770).  mu_0 comes from a second projection pass (K1 only)."""
+    r0, mu0, _, _, _, _ = ops.project(means_0, quats, scales, viewmat_0[0], K[0], width, height)
+    rt, mut, _, _, _, _ = ops.project(means_t, quats, scales, viewmat_t[0], K[0], width, height)
+    both = ((r0 > 0) & (rt > 0)).unsqueeze(-1)
+    disp = torch.where(both, mut - mu0, torch.zeros_like(mut))
+    render, alpha, info = rasterization(
+        means_t, quats, scales, opacities, colors, viewmat_t, K, width, height, sh_degree=sh_degree, packed=False,
+        render_mode=render_mode, absgrad=True, rasterize_mode=rasterize_mode, extra_channels=disp,
+    )  # fmt: skip
+    n = render.shape[-1] - 2
+    return {"render": render[..., :n], "flow_gs": render[..., n:], "alpha": alpha, "info": info}
+
+
+def flow_loss(flow_gs: torch.Tensor, interflow: torch.Tensor, depth: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """L1 between the composited Gaussian flow and a target ``interflow`` map on pixels with
+    finite depth (build choice, see module docstring)."""
+    diff = (flow_gs - interflow).abs()
+    if depth is not None:
+        diff = diff[torch.isfinite(depth).expand_as(diff[..., :1]).squeeze(-1)]
+    return diff.mean()

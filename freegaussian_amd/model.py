@@ -1,0 +1,309 @@
+"""Host-side mirror of the reference's model surface around the raster call.
+
+``FreeGaussianModel.get_outputs(camera)`` here reproduces rows H1-H4 + O1 of SURVEY.md §8a --
+the ~50 lines of reference ``freegaussian/freegaussian_model.py:753-898`` that assemble the
+inputs of ``rasterization(...)`` and post-process its outputs -- and S1 (``after_train_iter``,
+:369-392).  ``FreeGaussianControlModel.get_outputs`` mirrors the stage-2 variant
+(``freegaussian_control_model.py:52-209``).  nerfstudio is not a dependency: ``Camera`` is a
+minimal stand-in for the fields of ``nerfstudio.cameras.Cameras`` the reference touches, and
+``nerfstudio_adapter.py`` registers the method only if nerfstudio imports.
+
+Everything here is plain torch (small elementwise ops and the MLP GEMMs); the raster itself is
+the HIP library behind ``freegaussian_amd.rasterization``."""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Union
+
+import torch
+from torch import nn
+
+from .deform import FreeGaussianControllableModel, FreeGaussianDeformableModel
+from .rasterization import num_sh_bases, rasterization
+from .utils import from_homogenous, get_viewmat, random_quat_tensor, resize_image, to_homogenous
+
+
+@dataclass
+class Camera:
+    """One pinhole camera (the reference asserts a batch of exactly one, :773)."""
+
+    camera_to_worlds: torch.Tensor  # [1,3,4] OpenGL convention (nerfstudio)
+    fx: float
+    fy: float
+    cx: float
+    cy: float
+    width: int
+    height: int
+    times: Optional[torch.Tensor] = None  # [1,1]
+    metadata: Dict = field(default_factory=dict)
+
+    @property
+    def shape(self):
+        return (self.camera_to_worlds.shape[0],)
+
+    def rescale_output_resolution(self, s: float) -> None:
+        """In place, like nerfstudio's Cameras.rescale_output_resolution: intrinsics scale
+        linearly, the image size rounds half up.  (nerfstudio's source is not readable here:
+        SURVEY.md citation discipline -- this is the documented behaviour, re-stated.)"""
+        self.fx, self.fy, self.cx, self.cy = self.fx * s, self.fy * s, self.cx * s, self.cy * s
+        self.width = int(self.width * s + 0.5)
+        self.height = int(self.height * s + 0.5)
+
+    def get_intrinsics_matrices(self) -> torch.Tensor:
+        return torch.tensor([[[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]]])
+
+
+@dataclass
+class FreeGaussianModelConfig:
+    """Raster-relevant subset of reference FreeGaussianModelConfig (:51-131), same names/defaults."""
+
+    warm_up: int = 3000
+    refine_every: int = 100
+    resolution_schedule: int = 3000
+    background_color: str = "random"
+    num_downscales: int = 2
+    sh_degree_interval: int = 1000
+    sh_degree: int = 3
+    stop_split_at: int = 15000
+    output_depth_during_training: bool = False
+    rasterize_mode: str = "classic"
+    num_random: int = 50000
+    random_scale: float = 10.0
+
+
+class FreeGaussianModel(nn.Module):
+    """Gaussian parameter store + deform/control MLPs + ``get_outputs``."""
+
+    def __init__(self, config: Optional[FreeGaussianModelConfig] = None, num_points: Optional[int] = None,
+                 seed_points: Optional[torch.Tensor] = None, is_blender: bool = True):  # fmt: skip
+        super().__init__()
+        self.config = config or FreeGaussianModelConfig()
+        if seed_points is not None:
+            means = seed_points.float()
+        else:
+            n = num_points or self.config.num_random
+            means = (torch.rand(n, 3) - 0.5) * self.config.random_scale
+        n = means.shape[0]
+        dim_sh = num_sh_bases(self.config.sh_degree)
+        # layout and activations of reference gauss_params (:187-196): log-scales, logit-opacities
+        self.gauss_params = nn.ParameterDict(
+            {
+                "means": nn.Parameter(means),
+                "scales": nn.Parameter(torch.full((n, 3), -4.0)),
+                "quats": nn.Parameter(random_quat_tensor(n)),
+                "features_dc": nn.Parameter(torch.rand(n, 3)),
+                "features_rest": nn.Parameter(torch.zeros(n, dim_sh - 1, 3)),
+                "opacities": nn.Parameter(torch.logit(0.1 * torch.ones(n, 1))),
+            }
+        )
+        self.deform = FreeGaussianDeformableModel(is_blender=is_blender)  # :198
+        self.control = FreeGaussianControllableModel()  # :200
+        self.step = 0
+        self.background_color = torch.zeros(3)
+        self.xys: Optional[torch.Tensor] = None
+        self.radii: Optional[torch.Tensor] = None
+        self.xys_grad_norm: Optional[torch.Tensor] = None
+        self.vis_counts: Optional[torch.Tensor] = None
+        self.max_2Dsize: Optional[torch.Tensor] = None
+        self.last_size = (1, 1)
+
+    # -- accessors with the reference's names -------------------------------------------------
+    means = property(lambda self: self.gauss_params["means"])
+    scales = property(lambda self: self.gauss_params["scales"])
+    quats = property(lambda self: self.gauss_params["quats"])
+    features_dc = property(lambda self: self.gauss_params["features_dc"])
+    features_rest = property(lambda self: self.gauss_params["features_rest"])
+    opacities = property(lambda self: self.gauss_params["opacities"])
+    num_points = property(lambda self: self.gauss_params["means"].shape[0])
+    device = property(lambda self: self.gauss_params["means"].device)
+
+    # -- H3 ---------------------------------------------------------------------------------------
+    def _get_downscale_factor(self) -> int:
+        """2^max(num_downscales - step // resolution_schedule, 0) while training, else 1 (:626-633)."""
+        if self.training:
+            return 2 ** max(self.config.num_downscales - self.step // self.config.resolution_schedule, 0)
+        return 1
+
+    def _get_background_color(self) -> torch.Tensor:
+        """(:648-660)"""
+        mode = self.config.background_color
+        if mode == "random":
+            return torch.rand(3, device=self.device) if self.training else self.background_color.to(self.device)
+        if mode == "white":
+            return torch.ones(3, device=self.device)
+        if mode == "black":
+            return torch.zeros(3, device=self.device)
+        raise ValueError(f"Unknown background color {mode}")
+
+    def get_gt_img(self, image: torch.Tensor) -> torch.Tensor:
+        """(:900-909)"""
+        if image.dtype == torch.uint8:
+            image = image.float() / 255.0
+        d = self._get_downscale_factor()
+        return (resize_image(image, d) if d > 1 else image).to(self.device)
+
+    # -- the pieces of get_outputs shared by stage 1 and stage 2 ------------------------------------
+    def _camera_setup(self, camera: Camera):
+        """viewmat, K, W, H at the scheduled resolution (:806-815)."""
+        s = self._get_downscale_factor()
+        camera.rescale_output_resolution(1 / s)
+        viewmat = get_viewmat(camera.camera_to_worlds.to(self.device))
+        K = camera.get_intrinsics_matrices().to(self.device)
+        W, H = int(camera.width), int(camera.height)
+        self.last_size = (H, W)
+        camera.rescale_output_resolution(s)
+        return viewmat, K, W, H
+
+    def _colors_and_degree(self):
+        """(:801, :826-830)"""
+        colors = torch.cat((self.features_dc[:, None, :], self.features_rest), dim=1)
+        if self.config.sh_degree > 0:
+            return colors, min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
+        return torch.sigmoid(colors), None
+
+    def _render_mode(self) -> str:
+        if self.config.rasterize_mode not in ("antialiased", "classic"):
+            raise ValueError("Unknown rasterize_mode: %s", self.config.rasterize_mode)
+        return "RGB+ED" if (self.config.output_depth_during_training or not self.training) else "RGB"
+
+    def _rasterize_and_finish(self, means, quats, scales, colors, sh_degree, viewmat, K, W, H):
+        """The raster call with the reference's exact kwargs (:847-868) and O1 (:869-898)."""
+        render_mode = self._render_mode()
+        render, alpha, info = rasterization(
+            means=means,
+            quats=quats,
+            scales=scales,
+            opacities=torch.sigmoid(self.opacities).squeeze(-1),
+            colors=colors,
+            viewmats=viewmat,
+            Ks=K,
+            width=W,
+            height=H,
+            tile_size=16,
+            packed=False,
+            near_plane=0.01,
+            far_plane=1e10,
+            render_mode=render_mode,
+            sh_degree=sh_degree,
+            sparse_grad=False,
+            absgrad=True,
+            rasterize_mode=self.config.rasterize_mode,
+        )
+        if self.training and info["means2d"].requires_grad:
+            info["means2d"].retain_grad()
+        self.xys = info["means2d"]  # [1,N,2]
+        self.radii = info["radii"][0]  # [N]
+        background = self._get_background_color()
+        rgb = torch.clamp(render[..., :3] + (1 - alpha) * background, 0.0, 1.0)
+        if render_mode == "RGB+ED":
+            depth = render[..., 3:4]
+            depth = torch.where(alpha > 0, depth, depth.detach().max()).squeeze(0)
+        else:
+            depth = None
+        if not self.training:
+            background = background.expand(H, W, 3)
+        return {"rgb": rgb.squeeze(0), "depth": depth, "accumulation": alpha.squeeze(0), "background": background}
+
+    # -- H1 + H4 -----------------------------------------------------------------------------------
+    def get_outputs(self, camera: Camera) -> Dict[str, Union[torch.Tensor, List, None]]:
+        if not isinstance(camera, Camera):
+            print("Called get_outputs with not a camera")
+            return {}
+        if "cameras0" not in camera.metadata:
+            camera.metadata["cameras0"] = camera
+        if self.training:
+            assert camera.shape[0] == 1, "Only one camera at a time"
+        viewmat, K, W, H = self._camera_setup(camera)
+        colors, sh_degree = self._colors_and_degree()
+        if self.step < self.config.warm_up:
+            means = self.means
+            d_rotation, d_scaling = 0.0, 0.0
+        else:
+            times = camera.times.to(self.device).expand(self.num_points, -1)
+            d_xyz, d_rotation, d_scaling = self.deform(self.means.detach(), times)
+            means = from_homogenous(torch.bmm(d_xyz, to_homogenous(self.means).unsqueeze(-1)).squeeze(-1))
+        scales = torch.exp(self.scales) + d_scaling
+        quats = self.quats / self.quats.norm(dim=-1, keepdim=True) + d_rotation
+        return self._rasterize_and_finish(means, quats, scales, colors, sh_degree, viewmat, K, W, H)
+
+    @torch.no_grad()
+    def get_outputs_for_camera(self, camera: Camera):
+        """(:992-1003)"""
+        return self.get_outputs(camera)
+
+    # -- S1 -----------------------------------------------------------------------------------------
+    def step_cb(self, step: int) -> None:
+        self.step = step
+
+    def after_train_iter(self, step: int) -> None:
+        """Densification statistics from ``xys.absgrad`` and ``radii`` (:369-392)."""
+        assert step == self.step
+        if self.step >= self.config.stop_split_at:
+            return
+        with torch.no_grad():
+            visible = (self.radii > 0).flatten()
+            grads = self.xys.absgrad[0][visible].norm(dim=-1)
+            if self.xys_grad_norm is None:
+                self.xys_grad_norm = torch.zeros(self.num_points, device=self.device)
+                self.vis_counts = torch.ones(self.num_points, device=self.device)
+            self.vis_counts[visible] += 1
+            self.xys_grad_norm[visible] += grads
+            if self.max_2Dsize is None:
+                self.max_2Dsize = torch.zeros(self.num_points, device=self.device)
+            new = self.radii[visible].float() / float(max(self.last_size))
+            self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible], new)
+
+    def get_gaussian_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        return {k: [self.gauss_params[k]] for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")}
+
+    def get_param_groups(self) -> Dict[str, List[nn.Parameter]]:
+        groups = self.get_gaussian_param_groups()
+        groups["deform"] = list(self.deform.parameters())
+        groups["control"] = list(self.control.parameters())
+        return groups
+
+
+class FreeGaussianControlModel(FreeGaussianModel):
+    """Stage 2 (reference freegaussian_control_model.py): a frozen deform net supplies the mean
+    displacement of each attribute's Gaussians; the control MLP turns it into per-Gaussian
+    deltas scattered into the full set; then the same raster call."""
+
+    def __init__(self, gaussian_mask: torch.Tensor, init_camera: Camera, **kw):
+        super().__init__(**kw)
+        self.register_buffer("gaussian_mask", gaussian_mask.bool())  # [N,M] (gaussian_mask_NxM.npy)
+        self.init_camera = copy.deepcopy(init_camera)
+        self.step = 30000  # load_state_dict forces this (:280): SH maxed, warm-up over
+        self.control_values: Optional[torch.Tensor] = None  # viewer-supplied [M,3] when no cameras0
+
+    def get_outputs(self, camera: Camera):
+        if not isinstance(camera, Camera):
+            print("Called get_outputs with not a camera")
+            return {}
+        viewmat, K, W, H = self._camera_setup(camera)
+        colors, sh_degree = self._colors_and_degree()
+        sel = self.gaussian_mask.any(-1)
+        pts = self.means[sel]
+        pmask = self.gaussian_mask[sel]  # [n,M]
+        if not self.training and "cameras0" not in camera.metadata and self.control_values is not None:
+            d_avg = self.control_values.to(self.device)
+        else:
+            with torch.no_grad():  # (:128-138)
+                def deformed(t):
+                    T, _, _ = self.deform(pts, t.to(self.device).expand(pts.shape[0], -1))
+                    return from_homogenous(torch.bmm(T, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
+
+                delta = deformed(camera.times) - deformed(self.init_camera.times)
+                d_avg = torch.stack([delta[pmask[:, i]].mean(0) for i in range(pmask.shape[1])])
+        value = pmask.float() @ d_avg / pmask.sum(-1, keepdim=True)  # (:140)
+        d_xyz, d_rot, d_scale = self.control(pts, value)
+        means = self.means + torch.zeros_like(self.means).index_put((sel.nonzero().squeeze(-1),), d_xyz)
+        scales = torch.exp(self.scales) + torch.zeros_like(self.scales).index_put((sel.nonzero().squeeze(-1),), d_scale)
+        qn = self.quats / self.quats.norm(dim=-1, keepdim=True)
+        quats = qn + torch.zeros_like(self.quats).index_put((sel.nonzero().squeeze(-1),), d_rot)
+        return self._rasterize_and_finish(means, quats, scales, colors, sh_degree, viewmat, K, W, H)
+
+    def get_param_groups(self):
+        groups = super().get_param_groups()
+        groups.pop("deform")  # (:215-218)
+        return groups

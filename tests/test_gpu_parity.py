@@ -338,3 +338,104 @@ def test_composited_flow_channels_f1():
     assert rel_err(r1[..., 4:], r0[..., 4:]) < 3 * REL_TOL
     for k in ref_in:
         assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+
+
+# ------------------------------------------------------------------------------------------
+# H1-H4, O1, S1: the host mirror of FreeGaussianModel.get_outputs around the HIP raster
+def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True):
+    import copy
+
+    from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig
+    from freegaussian_amd.scenes import look_at_viewmat
+
+    torch.manual_seed(0)
+    cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=3000)
+    model = FreeGaussianModel(cfg, seed_points=(torch.rand(n, 3) - 0.5) * 2.0)
+    with torch.no_grad():
+        model.gauss_params["scales"].fill_(-3.2)
+        model.gauss_params["features_rest"].normal_(0, 0.1)
+        for p in model.deform.parameters():
+            p.mul_(0.3)
+    model.step = step
+    model.train(training)
+    w2c = look_at_viewmat(torch.tensor([0.3, -0.2, -3.0]), torch.zeros(3))
+    c2w_cv = torch.linalg.inv(w2c)
+    c2w_gl = c2w_cv.clone()
+    c2w_gl[:3, 1:3] *= -1  # OpenCV -> OpenGL camera axes (get_viewmat flips them back)
+    cam = Camera(c2w_gl[None, :3], 140.0, 150.0, W / 2, H / 2, W, H, times=torch.tensor([[0.4]]))
+    ref = copy.deepcopy(model)
+    return model.to(DEV), ref, cam
+
+
+def _oracle_outputs(ref, cam, render_mode):
+    """The same host math on CPU tensors, with the CPU oracle in place of the HIP raster."""
+    from freegaussian_amd.utils import from_homogenous, get_viewmat, to_homogenous
+
+    viewmat = get_viewmat(cam.camera_to_worlds)
+    K = cam.get_intrinsics_matrices()
+    colors, deg = ref._colors_and_degree()
+    times = cam.times.expand(ref.num_points, -1)
+    d_xyz, d_rot, d_scale = ref.deform(ref.means.detach(), times)
+    means = from_homogenous(torch.bmm(d_xyz, to_homogenous(ref.means).unsqueeze(-1)).squeeze(-1))
+    scales = torch.exp(ref.scales) + d_scale
+    quats = ref.quats / ref.quats.norm(dim=-1, keepdim=True) + d_rot
+    r, a, info = O.rasterization(means, quats, scales, torch.sigmoid(ref.opacities).squeeze(-1), colors, viewmat, K,
+                                 cam.width, cam.height, sh_degree=deg, render_mode=render_mode, packed=False)  # fmt: skip
+    rgb = torch.clamp(r[..., :3] + (1 - a) * torch.ones(3), 0.0, 1.0)
+    return rgb.squeeze(0), a.squeeze(0), r, info
+
+
+def test_model_get_outputs_training_step_matches_oracle():
+    model, ref, cam = _model_and_camera()
+    out = model.get_outputs(cam)
+    rgb0, acc0, _, info0 = _oracle_outputs(ref, cam, "RGB")
+    assert out["depth"] is None and out["rgb"].shape == (cam.height, cam.width, 3)
+    assert rel_err(out["rgb"], rgb0) < 3 * REL_TOL and rel_err(out["accumulation"], acc0) < 3 * REL_TOL
+    assert torch.equal(model.radii.cpu(), info0["radii"][0])
+    gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(3))
+    (out["rgb"] - gt.to(DEV)).abs().mean().backward()
+    (rgb0 - gt).abs().mean().backward()
+    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+        assert rel_l2(model.gauss_params[k].grad, ref.gauss_params[k].grad) < 5 * REL_TOL, k
+    gd = torch.cat([p.grad.flatten() for p in model.deform.parameters()])
+    gd0 = torch.cat([p.grad.flatten() for p in ref.deform.parameters()])
+    assert rel_l2(gd, gd0) < 2e-3  # GEMM chains in different orders on CPU/GPU
+    # S1: densification statistics consume xys.absgrad / radii exactly as the reference does
+    model.after_train_iter(model.step)
+    vis = model.radii > 0
+    assert model.xys.absgrad.shape == (1, model.num_points, 2) and model.xys.grad is not None
+    assert torch.equal(model.vis_counts, 1.0 + vis.float())
+    assert torch.allclose(model.xys_grad_norm[vis], model.xys.absgrad[0][vis].norm(dim=-1))
+    assert torch.allclose(model.max_2Dsize[vis], model.radii[vis].float() / max(cam.width, cam.height))
+
+
+def test_model_get_outputs_eval_depth_and_background():
+    model, ref, cam = _model_and_camera(training=False)
+    model.background_color = torch.ones(3)
+    out = model.get_outputs_for_camera(cam)
+    with torch.no_grad():
+        rgb0, acc0, r0, _ = _oracle_outputs(ref, cam, "RGB+ED")
+    d0 = torch.where(acc0 > 0, r0[0, ..., 3:4], r0[0, ..., 3:4].max())
+    assert out["depth"].shape == (cam.height, cam.width, 1) and out["background"].shape == (cam.height, cam.width, 3)
+    assert rel_err(out["rgb"], rgb0) < 3 * REL_TOL and rel_err(out["depth"], d0) < 3 * REL_TOL
+
+
+def test_control_model_stage2_scatter_and_render():
+    from freegaussian_amd.model import FreeGaussianControlModel, FreeGaussianModelConfig
+
+    model, ref, cam = _model_and_camera(n=3000, training=False)
+    mask = torch.zeros(3000, 3, dtype=torch.bool)
+    mask[:60, 0] = True
+    mask[40:100, 1] = True
+    mask[200:230, 2] = True
+    init_cam = type(cam)(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height,
+                         times=torch.tensor([[0.0]]))  # fmt: skip
+    cm = FreeGaussianControlModel(mask, init_cam, config=FreeGaussianModelConfig(background_color="black"),
+                                  seed_points=ref.means.detach().clone())  # fmt: skip
+    cm.load_state_dict(ref.state_dict(), strict=False)
+    cm = cm.to(DEV).eval()
+    cam.metadata["cameras0"] = init_cam
+    with torch.no_grad():
+        out = cm.get_outputs(cam)
+    assert out["rgb"].shape == (cam.height, cam.width, 3) and bool(torch.isfinite(out["rgb"]).all())
+    assert float(out["accumulation"].max()) > 0.1 and "deform" not in cm.get_param_groups()

@@ -1,0 +1,125 @@
+"""CPU: host glue (utils, MLPs, flow conventions) against golden vectors produced by running the
+reference's own Python (tests/golden/make_golden.py; data only)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from freegaussian_amd import deform as D
+from freegaussian_amd import flow as FL
+from freegaussian_amd import utils as U
+from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig
+from freegaussian_amd.rasterization import num_sh_bases, quat_to_rotmat
+from oracle import raster_oracle as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+from make_golden import fill_params  # noqa: E402  (pure helper; importing does not touch /root/reference)
+
+
+def _load(name):
+    z = np.load(os.path.join(GOLD, name))
+    return lambda k: torch.from_numpy(z[k])
+
+
+def test_utils_match_reference_goldens():
+    t = _load("g_utils.npz")
+    assert torch.equal(U.get_viewmat(t("viewmat_c2w")), t("viewmat_out"))
+    assert torch.allclose(U.exp_se3(t("se3_S"), t("se3_theta")), t("se3_out"), atol=1e-7)
+    e3, n3 = U.get_embedder(10, 3)
+    e1, n1 = U.get_embedder(6, 1)
+    e1b, n1b = U.get_embedder(10, 1)
+    assert [n3, n1, n1b] == t("emb_dims").tolist() == [63, 13, 21]
+    assert torch.equal(e3(t("emb_x3")), t("emb_x3_out")) and torch.equal(e1(t("emb_t1")), t("emb_t1_out"))
+    assert torch.equal(e1b(t("emb_t1")), t("emb_t1_10_out"))
+    assert torch.allclose(U.RGB2SH(t("rgb")), t("rgb2sh")) and torch.allclose(U.SH2RGB(t("rgb")), t("sh2rgb"))
+    assert torch.allclose(U.resize_image(t("img"), 2), t("img_d2"), atol=1e-7)
+    assert torch.allclose(U.resize_image(t("img"), 4), t("img_d4"), atol=1e-7)
+    assert torch.equal(U.to_homogenous(t("hom_v")), t("hom_to"))
+    assert torch.allclose(U.from_homogenous(torch.cat([t("hom_v"), torch.full((3, 1), 2.0)], -1)), t("hom_from"))
+
+
+def test_bilinear_interp_reference_quirk_is_recorded_not_default():
+    t = _load("g_utils.npz")
+    img, x, y = t("bil_img"), t("bil_x"), t("bil_y")
+    assert torch.allclose(U.bilinear_interp(img, x, y, reference_quirk=True), t("bil_out"))
+    # integer coordinates: the reference returns 0 (floor == ceil), true bilinear returns the texel
+    assert float(t("bil_out")[0, 3].abs().max()) == 0.0
+    assert torch.equal(U.bilinear_interp(img, x, y)[0, 3], img[0, 1, 2])
+
+
+@pytest.mark.parametrize("tag,kw", [("deform", {}), ("deform_blender", {"is_blender": True})])
+def test_deform_mlp_matches_reference(tag, kw):
+    t = _load("g_mlp.npz")
+    m = D.FreeGaussianDeformableModel(**kw)
+    fill_params(m)
+    assert len(m.state_dict()) == int(t(tag + ".keys")[0])
+    for ti, tt in enumerate((0.0, 0.5, 1.0)):
+        dx, rot, sc = m(t("x"), torch.full((16, 1), tt))
+        assert torch.allclose(dx, t(f"{tag}.t{ti}.d_xyz"), atol=1e-6)
+        assert torch.allclose(rot, t(f"{tag}.t{ti}.rot"), atol=1e-6)
+        assert torch.allclose(sc, t(f"{tag}.t{ti}.scale"), atol=1e-6)
+    assert dx.shape == (16, 4, 4)
+
+
+def test_control_mlp_matches_reference_and_state_dict_names():
+    t = _load("g_mlp.npz")
+    m = D.FreeGaussianControllableModel()
+    fill_params(m)
+    dx, rot, sc = m(t("x"), t("control.value"))
+    assert torch.allclose(dx, t("control.d_xyz"), atol=1e-6) and torch.allclose(rot, t("control.rot"), atol=1e-6)
+    assert torch.allclose(sc, t("control.scale"), atol=1e-6)
+    keys = set(m.state_dict())
+    assert {"linear.0.weight", "linear.7.bias", "d_xyz.weight", "d_scale.bias", "d_rot.weight"} <= keys
+    dkeys = set(D.FreeGaussianDeformableModel(is_blender=True).state_dict())
+    assert {"timenet.0.weight", "timenet.2.bias", "branch_w.weight", "branch_v.bias", "gaussian_rotation.weight",
+            "gaussian_scaling.bias", "linear.5.weight"} <= dkeys  # fmt: skip
+
+
+@pytest.mark.parametrize("tag", ["trans", "rot"])
+def test_camera_flow_matches_reference_epipolar_flow(tag):
+    t = _load("g_flow.npz")
+    fx, fy, cx, cy = t("K").tolist()
+    v, w = FL.relative_camera_motion(t("c2w0"), t(tag + ".c2w1"))
+    sf = O.camera_flow(t("Z")[..., 0], fx, fy, cx, cy, v, w)
+    assert torch.allclose(sf, t(tag + ".sceneflow"), atol=1e-6)
+    inter = sf + t("opticalflow").double()
+    inter[torch.isinf(t("Z")[..., 0])] = 0.0
+    assert torch.allclose(inter, t(tag + ".interflow").double(), atol=1e-6)
+    assert float(sf[1, 2].abs().max()) == 0.0  # infinite depth -> 0
+
+
+def test_flow_AB_sign_convention_is_the_codes():
+    A, B = O.camera_flow_AB(torch.tensor([3.0]), torch.tensor([1.0]), 7.0, 9.0, 2.5, 1.5)
+    assert A[0].tolist() == [[7.0, 0.0, -0.5], [0.0, 9.0, 0.5]]  # +fx, cx - x: -1x the project page
+    assert B[0, 0, 1].item() == pytest.approx(7.0 + 0.25 / 7.0)
+
+
+def test_gsplat_helper_replacements():
+    assert [num_sh_bases(d) for d in range(4)] == [1, 4, 9, 16]
+    q = torch.tensor([[2.0, 0, 0, 0], [0.5, 0.5, 0.5, 0.5]])
+    R = quat_to_rotmat(q)
+    assert torch.allclose(R[0], torch.eye(3))
+    assert torch.allclose(R[1], torch.tensor([[0.0, 0, 1], [1, 0, 0], [0, 1, 0]]), atol=1e-6)
+    assert torch.allclose(R, O.quat_to_rotmat(q), atol=1e-6)
+
+
+def test_model_schedules_and_camera_rescale():
+    m = FreeGaussianModel(FreeGaussianModelConfig(), num_points=10)
+    m.train()
+    assert [m._get_downscale_factor() for m.step in (0, 2999, 3000, 5999, 6000, 30000)] == [4, 4, 2, 2, 1, 1]
+    m.eval()
+    assert m._get_downscale_factor() == 1
+    m.step = 2500
+    colors, deg = m._colors_and_degree()
+    assert colors.shape == (10, 16, 3) and deg == 2
+    cam = Camera(torch.eye(4)[None, :3], 1000.0, 1000.0, 960.0, 540.0, 1920, 1080)
+    cam.rescale_output_resolution(0.25)
+    assert (cam.width, cam.height, cam.fx, cam.cx) == (480, 270, 250.0, 240.0)
+    g = m.get_param_groups()
+    assert set(g) == {"means", "scales", "quats", "features_dc", "features_rest", "opacities", "deform", "control"}
+    m.config.background_color = "bogus"
+    with pytest.raises(ValueError):
+        m._get_background_color()

@@ -1,0 +1,187 @@
+"""CPU: the two independently written CPU restatements (PyTorch, plain C) pin each other, and
+closed-form / gradcheck cases pin the algorithm.  PARITY UNPINNED w.r.t. gsplat (no golden
+vectors exist for the raster boundary: SURVEY.md §8c) -- these tests are what stands in."""
+import math
+
+import pytest
+import torch
+
+from freegaussian_amd.scenes import plumbing_scene, synthetic_scene
+from helpers import REL_TOL, rel_err, rel_l2
+from oracle import c_oracle as CO
+from oracle import raster_oracle as O
+
+
+def _scene():
+    sc = synthetic_scene(20000, 333, 207, n_views=2, seed=3)
+    sc.means[:50] *= 4.0  # outside the 1.3x FOV clamp, behind the camera, ...
+    sc.scales[50:60] *= 30.0  # huge splats spanning many tiles
+    return sc
+
+
+@pytest.mark.parametrize("view", [0, 1])
+def test_projection_and_integer_path_bit_exact_between_oracles(view):
+    sc = _scene()
+    W, H = sc.width, sc.height
+    ref = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[view], sc.Ks[view], W, H)
+    radii, m2, d, con, comp = CO.project(sc.means, sc.quats, sc.scales, sc.viewmats[view], sc.Ks[view], W, H)
+    assert 0 < int((radii > 0).sum()) < radii.numel()
+    assert torch.equal(radii, ref.radii)
+    for a, b in ((m2, ref.means2d), (d, ref.depths), (con, ref.conics), (comp, ref.compensations)):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    for sort in (False, True):
+        c0, k0, v0 = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=sort)
+        c1, k1, v1 = CO.isect_tiles(m2, radii, d, 16, tw, th, sort=sort)
+        assert torch.equal(c0, c1) and torch.equal(k0, k1) and torch.equal(v0, v1)
+    assert torch.equal(O.isect_offsets(k0, tw * th), CO.tile_offsets(k1, tw * th))
+    # keys really are sorted, ties broken by Gaussian id (stability)
+    assert bool((k0[1:] >= k0[:-1]).all())
+    same = k0[1:] == k0[:-1]
+    assert bool((v0[1:][same] > v0[:-1][same]).all())
+
+
+def test_raster_forward_backward_between_oracles():
+    """Vectorised PyTorch compositing vs the scalar per-pixel C loop."""
+    sc = synthetic_scene(6000, 150, 100, seed=5)
+    sc.opacities[:300] = 1.0
+    ref = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], 150, 100)
+    tw, th = 10, 7
+    _, keys, vals = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th)
+    offs = O.isect_offsets(keys, tw * th)
+    feats = torch.rand(6000, 4, generator=torch.Generator().manual_seed(0))
+    r0, a0, l0 = O.rasterize(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals)
+    r1, a1, l1 = CO.raster_fwd(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals)
+    assert rel_err(r1, r0) < REL_TOL and rel_err(a1, a0) < REL_TOL
+    assert (l0 != l1).float().mean().item() < 1e-3
+    g = torch.Generator().manual_seed(1)
+    vr, va = torch.randn(100, 150, 4, generator=g), torch.randn(100, 150, 1, generator=g)
+    g0 = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals, vr, va[..., 0])
+    g1 = CO.raster_bwd(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals, a1, l1, vr, va)
+    for x, y in zip(g1, g0):
+        assert rel_l2(x, y) < REL_TOL
+
+
+def test_analytic_backward_equals_autograd_fp64():
+    torch.manual_seed(1)
+    N, W, H = 300, 64, 48
+    dt = torch.float64
+    m2 = torch.rand(N, 2, dtype=dt) * torch.tensor([W, H], dtype=dt)
+    L = torch.randn(N, 2, 2, dtype=dt) * 0.15 + torch.eye(2, dtype=dt) * 0.25
+    con = torch.linalg.inv(L @ L.transpose(1, 2) * 30)
+    conics = torch.stack([con[:, 0, 0], con[:, 0, 1], con[:, 1, 1]], -1)
+    op = torch.rand(N, dtype=dt) * 0.98 + 0.01
+    op[:20] = 1.0
+    colors = torch.rand(N, 4, dtype=dt)
+    radii = torch.full((N,), 12, dtype=torch.int32)
+    _, keys, vals = O.isect_tiles(m2, radii, torch.rand(N, dtype=dt) + 1, 16, 4, 3)
+    offs = O.isect_offsets(keys, 12)
+    t = [x.requires_grad_(True) for x in (m2, conics, colors, op)]
+    r, a, _ = O.rasterize(*t, W, H, 16, offs, vals)
+    vr, va = torch.randn_like(r), torch.randn_like(a)
+    ((r * vr).sum() + (a * va).sum()).backward()
+    g = O.rasterize_backward(*[x.detach() for x in t], W, H, 16, offs, vals, vr, va[..., 0])
+    for x, y in zip([t[0].grad, t[1].grad, t[2].grad, t[3].grad], [g[0], g[2], g[3], g[4]]):
+        assert (x - y).abs().max().item() < 1e-10
+    assert bool((g[1] >= g[0].abs() - 1e-12).all())  # absgrad dominates |grad|
+
+
+def test_closed_form_single_gaussian_centred_on_a_pixel():
+    """One isotropic splat exactly on the centre of pixel (8,8): alpha there = opacity, colour =
+    opacity * c, and the profile along the row is opacity * exp(-d^2 / (2 s^2))."""
+    s2 = 9.0
+    m2 = torch.tensor([[8.5, 8.5]])
+    conics = torch.tensor([[1 / s2, 0.0, 1 / s2]])
+    op, col = torch.tensor([0.6]), torch.tensor([[0.2, 0.5, 1.0]])
+    _, keys, vals = O.isect_tiles(m2, torch.tensor([9], dtype=torch.int32), torch.tensor([2.0]), 16, 1, 1)
+    offs = O.isect_offsets(keys, 1)
+    r, a, last = O.rasterize(m2, conics, col, op, 16, 16, 16, offs, vals)
+    assert math.isclose(a[8, 8, 0].item(), 0.6, rel_tol=1e-6)
+    assert torch.allclose(r[8, 8], 0.6 * col[0])
+    for d in range(1, 7):
+        assert math.isclose(a[8, 8 + d, 0].item(), 0.6 * math.exp(-d * d / (2 * s2)), rel_tol=1e-5)
+    # below 1/255 the splat is skipped entirely
+    far = a[0, 0, 0].item()
+    assert far == 0.0 if 0.6 * math.exp(-(8**2 + 8**2) / (2 * s2)) < 1 / 255 else far > 0
+    rc, ac, _ = CO.raster_fwd(m2, conics, col, op, 16, 16, 16, offs, vals)
+    assert torch.allclose(rc, r, atol=1e-6) and torch.allclose(ac, a, atol=1e-6)
+
+
+def test_closed_form_two_overlapping_gaussians_order_and_transmittance():
+    m2 = torch.tensor([[8.5, 8.5], [8.5, 8.5]])
+    conics = torch.tensor([[0.05, 0.0, 0.05]]).repeat(2, 1)
+    op = torch.tensor([0.5, 0.8])
+    col = torch.tensor([[1.0, 0.0, 0.0], [0.0, 1.0, 0.0]])
+    radii = torch.tensor([14, 14], dtype=torch.int32)
+    for depths, first in ((torch.tensor([1.0, 2.0]), 0), (torch.tensor([2.0, 1.0]), 1)):
+        _, keys, vals = O.isect_tiles(m2, radii, depths, 16, 1, 1)
+        assert vals.tolist() == [first, 1 - first]  # front-to-back
+        r, a, last = O.rasterize(m2, conics, col, op, 16, 16, 16, O.isect_offsets(keys, 1), vals)
+        a_f, a_b = op[first].item(), op[1 - first].item()
+        assert math.isclose(a[8, 8, 0].item(), 1 - (1 - a_f) * (1 - a_b), rel_tol=1e-6)
+        assert math.isclose(r[8, 8, first].item(), a_f, rel_tol=1e-6)
+        assert math.isclose(r[8, 8, 1 - first].item(), (1 - a_f) * a_b, rel_tol=1e-6)
+        assert last[8, 8].item() == 1
+
+
+def test_gaussian_on_a_tile_edge_lands_in_both_tiles_and_culls():
+    K = torch.tensor([[100.0, 0, 16.0], [0, 100.0, 16.0], [0, 0, 1]])
+    vm = torch.eye(4)
+    means = torch.tensor([[0.0, 0.0, 2.0], [0.0, 0.0, -1.0], [0.0, 0.0, 0.005], [50.0, 0.0, 2.0]])
+    quats = torch.tensor([[1.0, 0, 0, 0]]).repeat(4, 1)
+    scales = torch.full((4, 3), 0.02)
+    p = O.project(means, quats, scales, vm, K, 32, 32)
+    # 0: centre of the image = corner of 4 tiles; 1: behind camera; 2: nearer than near plane; 3: off screen
+    assert p.radii[0] > 0 and p.radii[1:].tolist() == [0, 0, 0]
+    assert p.means2d[0].tolist() == [16.0, 16.0]
+    cnt, keys, vals = O.isect_tiles(p.means2d, p.radii, p.depths, 16, 2, 2)
+    assert cnt.tolist() == [4, 0, 0, 0] and sorted((keys >> 32).tolist()) == [0, 1, 2, 3]
+    cr, cm, cd, cc, _ = CO.project(means, quats, scales, vm, K, 32, 32)
+    assert torch.equal(cr, p.radii) and torch.equal(cm, p.means2d)
+
+
+def test_whole_boundary_gradcheck_fp64_tiny_scene():
+    """gradcheck through project -> SH -> bin -> composite in float64 on 12 Gaussians."""
+    g = torch.Generator().manual_seed(3)
+    N = 12
+    dt = torch.float64
+    means = (torch.rand(N, 3, generator=g, dtype=dt) - 0.5) * 1.2
+    quats = torch.randn(N, 4, generator=g, dtype=dt)
+    scales = torch.rand(N, 3, generator=g, dtype=dt) * 0.2 + 0.15
+    opac = torch.rand(N, generator=g, dtype=dt) * 0.6 + 0.2
+    colors = torch.randn(N, 4, 3, generator=g, dtype=dt) * 0.3
+    vm = torch.eye(4, dtype=dt)
+    vm[2, 3] = 3.0
+    K = torch.tensor([[20.0, 0, 8.0], [0, 20.0, 8.0], [0, 0, 1]], dtype=dt)
+    w = torch.randn(1, 16, 16, 4, generator=g, dtype=dt)
+
+    def f(m, q, s, o, c):
+        r, a, _ = O.rasterization(m, q, s, o, c, vm[None], K[None], 16, 16, sh_degree=1, render_mode="RGB+ED")
+        return (r * w).sum() + a.sum()
+
+    ins = [x.requires_grad_(True) for x in (means, quats, scales, opac, colors)]
+    assert torch.autograd.gradcheck(f, ins, eps=1e-6, atol=1e-5, rtol=1e-3, nondet_tol=0.0)
+
+
+def test_cfg1_plumbing_scene_cpu_forward():
+    """BASELINE configs[0]: 1k Gaussians, 128x128, CPU forward only (no GPU)."""
+    sc = plumbing_scene()
+    r, a, info = O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, sc.viewmats, sc.Ks, 128, 128,
+                                 sh_degree=0, packed=False)  # fmt: skip
+    assert r.shape == (1, 128, 128, 3) and a.shape == (1, 128, 128, 1)
+    assert int((info["radii"] > 0).sum()) == 1000 and 0.3 < a.mean().item() < 0.9
+    assert info["radii"].shape == (1, 1000) and info["means2d"].shape == (1, 1000, 2)
+    assert bool(torch.isfinite(r).all())
+    rp, ap, ip = O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, sc.viewmats, sc.Ks, 128, 128,
+                                 sh_degree=0, packed=True, render_mode="ED")  # fmt: skip
+    assert rp.shape == (1, 128, 128, 1) and ip["gaussian_ids"].numel() == 1000
+    with pytest.raises(ValueError):
+        O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, sc.viewmats, sc.Ks, 128, 128,
+                        rasterize_mode="bogus")  # fmt: skip
+
+
+def test_oracle_sqrt_is_correctly_rounded():
+    import numpy as np
+
+    x = torch.rand(500_000, generator=torch.Generator().manual_seed(0)) * 100
+    assert np.array_equal(O._sqrt(x).numpy(), np.sqrt(x.numpy()))
