@@ -29,6 +29,13 @@ SIGNATURES = {
     "fg_sort_workspace_bytes": (c_size_t, [c_int64]),
     "fg_sort_pairs": (c_int, [c_int64, P, P, c_int, P, c_size_t, P]),
     "fg_tile_ranges": (c_int, [c_int64, P, c_int, P, P]),
+    "fg_sort32_workspace_bytes": (c_size_t, [c_int64]),
+    "fg_sort_pairs32": (c_int, [c_int64, P, P, c_int, P, c_size_t, P]),
+    "fg_bin_prepare_workspace_bytes": (c_size_t, [c_int]),
+    "fg_bin_prepare": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
+    "fg_bin_emit_workspace_bytes": (c_size_t, [c_int64]),
+    "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "fg_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),

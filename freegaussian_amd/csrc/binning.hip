@@ -4,6 +4,7 @@
 // Replaces the binning stage implied by tile_size=16 at
 // /root/reference freegaussian/freegaussian_model.py:806,857.
 #include "fg_common.h"
+#include "radix_sort.h"
 
 namespace {
 
@@ -43,14 +44,15 @@ __device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t* wave
 
 // pass 1: per-workgroup totals
 __global__ void __launch_bounds__(SCAN_BLOCK)
-scan_reduce_kernel(int N, const int32_t* __restrict__ in, int64_t* __restrict__ block_sums) {
+scan_reduce_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
+                   int64_t* __restrict__ block_sums) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
   const int base = blockIdx.x * SCAN_TILE;
   int64_t s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     const int i = base + k * SCAN_BLOCK + threadIdx.x;
-    if (i < N) s += in[i];
+    if (i < N) s += in[order ? order[i] : i];
   }
   int64_t total;
   block_inclusive_scan(s, wave_sums, total);
@@ -75,15 +77,15 @@ scan_blocksums_kernel(int nblocks, int64_t* __restrict__ block_sums) {
 // pass 3: inclusive scan inside each workgroup, offset by the scanned totals.  Thread t owns
 // SCAN_ITEMS consecutive elements so the sequential order matches the array order.
 __global__ void __launch_bounds__(SCAN_BLOCK)
-scan_apply_kernel(int N, const int32_t* __restrict__ in, const int64_t* __restrict__ block_sums,
-                  int64_t* __restrict__ out) {
+scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
+                  const int64_t* __restrict__ block_sums, int64_t* __restrict__ out) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   int32_t v[SCAN_ITEMS];
   int64_t s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
-    v[k] = (base + k < N) ? in[base + k] : 0;
+    v[k] = (base + k < N) ? in[order ? order[base + k] : base + k] : 0;
     s += v[k];
   }
   int64_t total;
@@ -142,6 +144,71 @@ tile_ranges_kernel(int64_t n, const int64_t* __restrict__ keys, int n_tiles, int
   }
 }
 
+// ---- depth-first binning (DESIGN.md "binning without a 45-bit sort") ------------------------
+// key = float bits of depth for visible Gaussians (depth > 0: integer order == float order),
+// 0xFFFFFFFF for culled ones; value = Gaussian id.
+__global__ void __launch_bounds__(256)
+depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __restrict__ radii,
+                  uint32_t* __restrict__ keys, int32_t* __restrict__ order) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  keys[i] = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+  order[i] = i;
+}
+
+// lane k of the depth-sorted sequence writes (tile id, Gaussian id) for every tile of its splat
+__global__ void __launch_bounds__(256)
+tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
+                        const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
+                        int tile_w, int tile_h, uint32_t* __restrict__ tile_keys,
+                        int32_t* __restrict__ flatten_ids) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= N) return;
+  const int i = order[k];
+  const int radius = radii[i];
+  if (radius <= 0) return;
+  const float ts = (float)tile_size;
+  const float r = (float)radius / ts;
+  const float tx = means2d[2 * i] / ts, ty = means2d[2 * i + 1] / ts;
+  const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
+  const int y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
+  int64_t cur = (k == 0) ? 0 : cum_tiles[k - 1];
+  for (int y = y0; y < y1; ++y)
+    for (int x = x0; x < x1; ++x) {
+      tile_keys[cur] = (uint32_t)(y * tile_w + x);
+      flatten_ids[cur] = i;
+      ++cur;
+    }
+}
+
+__global__ void __launch_bounds__(256)
+tile_ranges32_kernel(int64_t n, const uint32_t* __restrict__ keys, int n_tiles, int32_t* __restrict__ offsets) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n == 0) {
+    if (i <= n_tiles) offsets[i] = 0;
+    return;
+  }
+  if (i >= n) return;
+  const int cur = (int)keys[i];
+  if (i == 0) {
+    for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+  } else {
+    const int prev = (int)keys[i - 1];
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+  }
+  if (i == n - 1) {
+    for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+isect_keys_kernel(int64_t n, const uint32_t* __restrict__ tile_keys, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ depths, int64_t* __restrict__ isect_ids) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  isect_ids[i] = ((int64_t)tile_keys[i] << 32) | (int64_t)(uint32_t)__float_as_int(depths[flatten_ids[i]]);
+}
+
 }  // namespace
 
 extern "C" size_t fg_scan_workspace_bytes(int N) {
@@ -158,10 +225,11 @@ extern "C" int fg_scan_tiles(int N, const int32_t* tiles_touched, int64_t* cum_t
   const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
   int64_t* block_sums = static_cast<int64_t*>(workspace);
   hipStream_t s = fg_hip_stream(stream);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched, block_sums);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
+                     (const int32_t*)nullptr, block_sums);
   hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched, block_sums,
-                     cum_tiles);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
+                     (const int32_t*)nullptr, block_sums, cum_tiles);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -185,6 +253,81 @@ extern "C" int fg_tile_ranges(int64_t n, const int64_t* sorted_keys, int n_tiles
   const int64_t work = n > 0 ? n : (int64_t)n_tiles + 1;
   hipLaunchKernelGGL(tile_ranges_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0,
                      fg_hip_stream(stream), n, sorted_keys, n_tiles, tile_offsets);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+// ---- depth-first binning entry points --------------------------------------------------------
+static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" size_t fg_bin_prepare_workspace_bytes(int N) {
+  const size_t n = (size_t)(N > 0 ? N : 1);
+  return al256(n * 4) + fg_sort::workspace_bytes<uint32_t>((int64_t)n) + al256(fg_scan_workspace_bytes(N));
+}
+
+extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, const int32_t* tiles_touched,
+                              int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes,
+                              fg_stream_t stream) {
+  if (N < 0) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!depths || !radii || !tiles_touched || !order || !cum_tiles || !workspace) return FG_ERR_INVALID_ARG;
+  if (workspace_bytes < fg_bin_prepare_workspace_bytes(N)) return FG_ERR_WORKSPACE;
+  hipStream_t s = fg_hip_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(ws);
+  ws += al256((size_t)N * 4);
+  void* sort_ws = ws;
+  const size_t sort_bytes = fg_sort::workspace_bytes<uint32_t>(N);
+  ws += sort_bytes;
+  int64_t* block_sums = reinterpret_cast<int64_t*>(ws);
+  hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
+  const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s);
+  if (rc != FG_OK) return rc;
+  const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
+                     (const int32_t*)order, block_sums);
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
+                     (const int32_t*)order, block_sums, cum_tiles);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
+  return fg_sort::workspace_bytes<uint32_t>(n_isects > 0 ? n_isects : 1);
+}
+
+extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_t* radii,
+                                const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
+                                int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
+                                void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+  if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
+  hipStream_t s = fg_hip_stream(stream);
+  const int n_tiles = tile_w * tile_h;
+  if (n_isects > 0) {
+    if (!means2d || !radii || !order || !cum_tiles || !tile_keys || !flatten_ids || !workspace) return FG_ERR_INVALID_ARG;
+    hipLaunchKernelGGL(tile_bin_ordered_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
+                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids);
+    int bits = 1;
+    while ((1 << bits) < n_tiles) ++bits;
+    const int rc = fg_sort::sort_pairs<uint32_t>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits,
+                                                 workspace, workspace_bytes, s);
+    if (rc != FG_OK) return rc;
+  }
+  const int64_t work = n_isects > 0 ? n_isects : (int64_t)n_tiles + 1;
+  hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, tile_keys,
+                     n_tiles, tile_offsets);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* flatten_ids,
+                             const float* depths, int64_t* isect_ids, fg_stream_t stream) {
+  if (n_isects < 0) return FG_ERR_INVALID_ARG;
+  if (n_isects == 0) return FG_OK;
+  if (!tile_keys || !flatten_ids || !depths || !isect_ids) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(isect_keys_kernel, dim3((unsigned)((n_isects + 255) / 256)), dim3(256), 0, fg_hip_stream(stream),
+                     n_isects, tile_keys, flatten_ids, depths, isect_ids);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -198,6 +198,54 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
 
 
 @torch.no_grad()
+def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h):
+    """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
+    -> (tile_keys[I] uint32-as-int32, flatten_ids[I] int32, tile_offsets[T+1] int32); the lists are
+    bit-identical to ``isect_tiles`` (same (tile, depth, id) order)."""
+    lib = _lib.load()
+    N = means2d.shape[0]
+    dev = means2d.device
+    n_tiles = tile_w * tile_h
+    offsets = torch.empty(n_tiles + 1, dtype=torch.int32, device=dev)
+    if N == 0:
+        offsets.zero_()
+        return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), offsets
+    order = torch.empty(N, dtype=torch.int32, device=dev)
+    cum = torch.empty(N, dtype=torch.int64, device=dev)
+    ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
+    _call("fg_bin_prepare", N, _ptr(depths), _ptr(radii), _ptr(tiles_touched), _ptr(order), _ptr(cum), _ptr(ws),
+          ws.numel(), _stream())  # fmt: skip
+    n_isects = int(cum[-1].item())
+    if n_isects >= 2**31:
+        raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+    tile_keys = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+    ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
+    _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size, tile_w,
+          tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
+    return tile_keys, flatten_ids, offsets
+
+
+@torch.no_grad()
+def isect_keys(tile_keys, flatten_ids, depths):
+    """Reference-style 64-bit keys (tile << 32 | depth bits) of the sorted list."""
+    n = tile_keys.numel()
+    out = torch.empty(n, dtype=torch.int64, device=tile_keys.device)
+    _call("fg_isect_keys", n, _ptr(tile_keys), _ptr(flatten_ids), _ptr(depths), _ptr(out), _stream())
+    return out
+
+
+@torch.no_grad()
+def sort_pairs32(keys: torch.Tensor, vals: torch.Tensor, end_bit: int = 32) -> None:
+    """In-place stable radix sort of (uint32-as-int32 key, int32 value) pairs on bits [0, end_bit)."""
+    lib = _lib.load()
+    n = keys.numel()
+    assert keys.dtype == torch.int32 and vals.dtype == torch.int32 and vals.numel() == n and keys.is_cuda
+    ws = torch.empty(max(int(lib.fg_sort32_workspace_bytes(n)), 8), dtype=torch.uint8, device=keys.device)
+    _call("fg_sort_pairs32", n, _ptr(keys), _ptr(vals), int(end_bit), _ptr(ws), ws.numel(), _stream())
+
+
+@torch.no_grad()
 def sort_pairs(keys: torch.Tensor, vals: torch.Tensor, end_bit: int = 64) -> None:
     """In-place stable radix sort of (int64 key, int32 value) pairs on key bits [0, end_bit)."""
     lib = _lib.load()

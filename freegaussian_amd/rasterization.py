@@ -42,6 +42,23 @@ def quat_to_rotmat(quats: torch.Tensor) -> torch.Tensor:
     return R.reshape(quats.shape[:-1] + (3, 3))
 
 
+class _Info(dict):
+    """``info`` dict whose expensive, rarely-read entries are computed on first access."""
+
+    def lazy(self, key, thunk):
+        self.__dict__.setdefault("_thunks", {})[key] = thunk
+
+    def __missing__(self, key):
+        thunks = self.__dict__.get("_thunks", {})
+        if key in thunks:
+            self[key] = thunks.pop(key)()
+            return self[key]
+        raise KeyError(key)
+
+    def __contains__(self, key):
+        return dict.__contains__(self, key) or key in self.__dict__.get("_thunks", {})
+
+
 def rasterization(
     means: torch.Tensor,  # [N,3]
     quats: torch.Tensor,  # [N,4] wxyz, normalised by the callee
@@ -119,7 +136,7 @@ def rasterization(
 
     tile_w = (width + tile_size - 1) // tile_size
     tile_h = (height + tile_size - 1) // tile_size
-    isect_ids, flatten_ids, offsets = ops.isect_tiles(
+    tile_keys, flatten_ids, offsets = ops.bin_tiles(
         means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
     )
 
@@ -142,7 +159,7 @@ def rasterization(
         d = render[..., di : di + 1] / alpha.clamp(min=1e-10)
         render = torch.cat([render[..., :di], d, render[..., di + 1 :]], dim=-1)
 
-    info = {
+    info = _Info({
         "radii": radii[None],
         "means2d": means2d_info,
         "depths": depths[None],
@@ -151,7 +168,7 @@ def rasterization(
         "tile_width": tile_w,
         "tile_height": tile_h,
         "tiles_per_gauss": tiles[None],
-        "isect_ids": isect_ids,
+        "tile_keys": tile_keys,
         "flatten_ids": flatten_ids,
         "isect_offsets": offsets,
         "last_ids": last_ids,
@@ -159,7 +176,9 @@ def rasterization(
         "height": height,
         "tile_size": tile_size,
         "n_cameras": 1,
-    }
+    })
+    # the 64-bit (tile | depth) keys of the sorted list are only materialised if somebody asks
+    info.lazy("isect_ids", lambda: ops.isect_keys(tile_keys, flatten_ids, depths.detach()))
     if packed:
         info.update(
             camera_ids=torch.zeros_like(gids),

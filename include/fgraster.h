@@ -102,6 +102,32 @@ int fg_sort_pairs(int64_t n, int64_t* keys, int32_t* vals, int end_bit, void* wo
 int fg_tile_ranges(int64_t n, const int64_t* sorted_keys, int n_tiles, int32_t* tile_offsets,
                    fg_stream_t stream);
 
+/* 32-bit-key variant of fg_sort_pairs (same kernels, half the key traffic). */
+size_t fg_sort32_workspace_bytes(int64_t n);
+int fg_sort_pairs32(int64_t n, uint32_t* keys, int32_t* vals, int end_bit, void* workspace,
+                    size_t workspace_bytes, fg_stream_t stream);
+
+/* ---- K3+K4, depth-first form (what rasterization() uses; identical final lists) -------------
+ * Instead of sorting I 45-bit (tile|depth) keys, sort the N Gaussians by depth once
+ * (fg_bin_prepare: order[N] = ids by ascending depth bits, culled last, stable; cum_tiles[k] =
+ * inclusive tile count of order[0..k]), emit (tile, id) pairs in that order, and stably sort
+ * them on the ceil(log2 T) tile bits only (fg_bin_emit_sort).  A stable sort by tile of a
+ * depth-ordered sequence IS the (tile, depth, id) order of the 64-bit-key sort, so
+ * flatten_ids / tile_offsets are bit-identical to fg_tile_bin + fg_sort_pairs + fg_tile_ranges,
+ * at ~1/7 of the sort traffic.  The host reads cum_tiles[N-1] (= I) between the two calls.
+ * fg_isect_keys rebuilds the reference-style 64-bit keys (tile << 32 | depth bits) on demand. */
+size_t fg_bin_prepare_workspace_bytes(int N);
+int fg_bin_prepare(int N, const float* depths, const int32_t* radii, const int32_t* tiles_touched,
+                   int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes,
+                   fg_stream_t stream);
+size_t fg_bin_emit_workspace_bytes(int64_t n_isects);
+int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_t* radii,
+                     const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
+                     int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
+                     void* workspace, size_t workspace_bytes, fg_stream_t stream);
+int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* flatten_ids,
+                  const float* depths, int64_t* isect_ids, fg_stream_t stream);
+
 /* ---- K5/K6: front-to-back alpha compositing over 16x16 tiles -----------------------------
  * fg_pack_splats builds one 64-byte record per Gaussian:
  *   [x, y, opacity, conic_a, conic_b, conic_c, f0..f(C-1), 0...]      C <= FG_MAX_CHANNELS

@@ -112,6 +112,38 @@ def test_isect_keys_order_and_ranges_bit_exact():
     assert torch.equal(offs.cpu(), offs_ref)
 
 
+def test_depth_first_binning_equals_full_key_sort():
+    """bin_tiles (depth sort + 13-bit tile sort) must reproduce the 64-bit-key sort bit for bit."""
+    sc = _scene(n=30000, w=333, h=207)
+    sc.scales[:30] *= 20.0
+    sc.means[100:140] = sc.means[100:101]  # identical depths: ties must stay in id order
+    vm, K = sc.viewmats[1], sc.Ks[1]
+    ref = O.project(sc.means, sc.quats, sc.scales, vm, K, sc.width, sc.height)
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    _, keys_s, vals_s = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=True)
+    radii, m2, d, con, comp, tiles = ops.project(
+        sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), vm.to(DEV), K.to(DEV), sc.width, sc.height
+    )
+    tk, ids, offs = ops.bin_tiles(m2, radii, d, tiles, 16, tw, th)
+    assert torch.equal(ids.cpu(), vals_s)
+    assert torch.equal(tk.cpu().long(), keys_s >> 32)
+    assert torch.equal(offs.cpu(), O.isect_offsets(keys_s, tw * th))
+    assert torch.equal(ops.isect_keys(tk, ids, d).cpu(), keys_s)
+
+
+@pytest.mark.parametrize("n,end_bit", [(5, 32), (4097, 13), (250_001, 32), (3_000_000, 13)])
+def test_sort_pairs32_bit_exact_and_stable(n, end_bit):
+    g = torch.Generator().manual_seed(n)
+    keys = torch.randint(0, 2**31 - 1, (n,), generator=g) & ((1 << end_bit) - 1)
+    if end_bit == 32:
+        keys[::5] = keys[0]
+    vals = torch.arange(n, dtype=torch.int32)
+    ref_k, order = torch.sort(keys, stable=True)
+    k, v = keys.to(torch.int32).to(DEV), vals.to(DEV)
+    ops.sort_pairs32(k, v, end_bit)
+    assert torch.equal(k.cpu().long(), ref_k) and torch.equal(v.cpu(), vals[order])
+
+
 def test_isect_empty_scene():
     """All Gaussians behind the camera: I = 0, every range empty, render = 0."""
     sc = plumbing_scene()
