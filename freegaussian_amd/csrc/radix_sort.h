@@ -1,12 +1,12 @@
 // Stable least-significant-digit radix sort of (key, uint32 value) pairs for 64-lane wavefronts,
 // 8-bit digits, keys of 32 or 64 bits, only bits [0, end_bit) sorted.
 //
-// Per pass (3 launches + 1 tiny one):
-//   hist    : each workgroup histograms its 4096-key tile in LDS        -> block_hist[block][256]
-//   group   : G <= 64 workgroups; thread d prefix-sums digit d over the group's workgroups
-//   top     : one workgroup; prefix over groups, then over digits        -> absolute bucket bases
-//   scatter : each workgroup recomputes stable ranks for its tile with wave-ballot match masks
-//             and writes keys+values to their final slots
+// Per pass (3 launches):
+//   hist    : each workgroup histograms its key tile in LDS               -> block_hist[block][256]
+//   scan    : workgroup d turns column d of block_hist into an exclusive prefix over workgroups
+//             and writes the digit total
+//   scatter : each workgroup scans the 256 digit totals, recomputes stable ranks for its tile
+//             with wave-ballot match masks and writes keys+values to their final slots
 // Stability: wave w of a workgroup owns the w-th contiguous quarter of the tile, rounds inside a
 // wave advance through consecutive 64-key groups, ranks inside a round follow the lane order.
 #pragma once
@@ -21,7 +21,6 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int KEYS_PER_THREAD = 16;
 constexpr int TILE = BLOCK * KEYS_PER_THREAD;  // 4096 keys per workgroup
 constexpr int WAVE_SPAN = 64 * KEYS_PER_THREAD;
-constexpr int MAX_GROUPS = 64;
 
 template <typename KeyT>
 __device__ __forceinline__ unsigned digit_of(KeyT key, int shift) {
@@ -44,62 +43,68 @@ hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, uint32_t* __res
   block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x] = hist[threadIdx.x];
 }
 
-// thread d of group g: exclusive prefix of digit d over the group's workgroups (in place),
-// group total to group_sums[g][d]
+// workgroup d: exclusive prefix over workgroups of column d of block_hist (in place) and the
+// column total.  Thread t owns a contiguous chunk of the column.
 static __global__ void __launch_bounds__(BLOCK)
-group_scan_kernel(int nblocks, int group_size, uint32_t* __restrict__ block_hist,
-                  uint32_t* __restrict__ group_sums) {
-  const int b0 = blockIdx.x * group_size, b1 = min(nblocks, b0 + group_size);
-  uint32_t run = 0;
-  for (int b = b0; b < b1; ++b) {
-    uint32_t* p = block_hist + (size_t)b * RADIX + threadIdx.x;
-    const uint32_t c = *p;
-    *p = run;
-    run += c;
-  }
-  group_sums[blockIdx.x * RADIX + threadIdx.x] = run;
-}
-
-// one workgroup: group_sums[g][d] <- (start of digit d's bucket) + (digit-d keys in groups < g)
-static __global__ void __launch_bounds__(BLOCK)
-top_scan_kernel(int ngroups, uint32_t* __restrict__ group_sums) {
+digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wave_tot[WAVES];
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  uint32_t run = 0;
-  for (int g = 0; g < ngroups; ++g) {
-    uint32_t* p = group_sums + g * RADIX + threadIdx.x;
-    const uint32_t c = *p;
-    *p = run;
-    run += c;
-  }
-  // exclusive scan of the digit totals across the 256 threads
-  uint32_t incl = run;
+  const int d = blockIdx.x, lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int chunk = (nblocks + BLOCK - 1) / BLOCK;
+  const int b0 = min(nblocks, (int)threadIdx.x * chunk), b1 = min(nblocks, b0 + chunk);
+  uint32_t sum = 0;
+  for (int b = b0; b < b1; ++b) sum += block_hist[(size_t)b * RADIX + d];
+  uint32_t incl = sum;
 #pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const uint32_t o = __shfl_up(incl, d);
-    if (lane >= d) incl += o;
+  for (int k = 1; k < 64; k <<= 1) {
+    const uint32_t o = __shfl_up(incl, k);
+    if (lane >= k) incl += o;
   }
   if (lane == 63) wave_tot[wave] = incl;
   __syncthreads();
-  uint32_t base = incl - run;
+  uint32_t run = incl - sum, total = 0;
 #pragma unroll
-  for (int w = 0; w < WAVES; ++w)
-    if (w < wave) base += wave_tot[w];
-  for (int g = 0; g < ngroups; ++g) group_sums[g * RADIX + threadIdx.x] += base;
+  for (int w = 0; w < WAVES; ++w) {
+    if (w < wave) run += wave_tot[w];
+    total += wave_tot[w];
+  }
+  for (int b = b0; b < b1; ++b) {
+    uint32_t* p = block_hist + (size_t)b * RADIX + d;
+    const uint32_t c = *p;
+    *p = run;
+    run += c;
+  }
+  if (threadIdx.x == 0) digit_total[d] = total;
 }
 
 template <typename KeyT>
 __global__ void __launch_bounds__(BLOCK)
 scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-               KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift, int group_size,
-               const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ group_sums) {
+               KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
+               const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wave_cnt[WAVES][RADIX];
+  __shared__ uint32_t scan_tmp[WAVES];
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
-  // global slot of this workgroup's first key of digit (threadIdx.x)
-  const uint32_t digit_start = group_sums[(blockIdx.x / group_size) * RADIX + threadIdx.x] +
-                               block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x];
+  // global slot of this workgroup's first key of digit (threadIdx.x): exclusive scan of the 256
+  // digit totals + this workgroup's offset inside the digit's bucket
+  uint32_t digit_start;
+  {
+    const uint32_t v = digit_total[threadIdx.x];
+    uint32_t incl = v;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const uint32_t o = __shfl_up(incl, k);
+      if (lane >= k) incl += o;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - v;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+      if (w < wave) base += scan_tmp[w];
+    digit_start = base + block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x];
+  }
   __syncthreads();
 
   // phase 1: ranks within the wave's own 1024-key span
@@ -166,7 +171,7 @@ static inline size_t workspace_bytes(int64_t n) {
   if (n < 0) n = 0;
   const size_t nb = (size_t)num_blocks(n) + 1;
   return align256((size_t)n * sizeof(KeyT)) + align256((size_t)n * 4) + align256(nb * RADIX * 4) +
-         align256((size_t)MAX_GROUPS * RADIX * 4);
+         align256((size_t)RADIX * 4);
 }
 
 // Sorts in place (result copied back into keys/vals if it ends in the scratch copy).
@@ -177,8 +182,6 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   if (n > 0xFFFFFFFFll) return FG_ERR_UNSUPPORTED;
   if (ws_bytes < workspace_bytes<KeyT>(n)) return FG_ERR_WORKSPACE;
   const int nb = num_blocks(n);
-  const int group_size = (nb + MAX_GROUPS - 1) / MAX_GROUPS;
-  const int ngroups = (nb + group_size - 1) / group_size;
   char* ws = static_cast<char*>(workspace);
   KeyT* keys_alt = reinterpret_cast<KeyT*>(ws);
   ws += align256((size_t)n * sizeof(KeyT));
@@ -186,7 +189,7 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   ws += align256((size_t)n * 4);
   uint32_t* block_hist = reinterpret_cast<uint32_t*>(ws);
   ws += align256(((size_t)nb + 1) * RADIX * 4);
-  uint32_t* group_sums = reinterpret_cast<uint32_t*>(ws);
+  uint32_t* digit_total = reinterpret_cast<uint32_t*>(ws);
 
   KeyT *kin = keys, *kout = keys_alt;
   uint32_t *vin = vals, *vout = vals_alt;
@@ -194,10 +197,9 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   for (int p = 0; p < passes; ++p) {
     const int shift = p * RADIX_BITS;
     hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, kin, shift, block_hist);
-    hipLaunchKernelGGL(group_scan_kernel, dim3(ngroups), dim3(BLOCK), 0, s, nb, group_size, block_hist, group_sums);
-    hipLaunchKernelGGL(top_scan_kernel, dim3(1), dim3(BLOCK), 0, s, ngroups, group_sums);
+    hipLaunchKernelGGL(digit_scan_kernel, dim3(RADIX), dim3(BLOCK), 0, s, nb, block_hist, digit_total);
     hipLaunchKernelGGL(scatter_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, kin, vin, kout, vout, shift,
-                       group_size, block_hist, group_sums);
+                       block_hist, digit_total);
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }

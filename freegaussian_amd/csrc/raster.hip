@@ -56,6 +56,40 @@ __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (
   for (int c = 0; c < C; ++c) f[c] = tmp[c];
 }
 
+// Which of the tile's four 4-row strips can this splat reach with alpha >= 1/255?
+// alpha = o exp(-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o); the ellipse sigma <= tau has the
+// axis-aligned half extents sqrt(2 tau c / det), sqrt(2 tau a / det).  The extents are inflated
+// (x1.0005 + 0.02 px) so that rounding can only ever ADD work: a culled (splat, strip) pair would
+// have failed the per-pixel alpha test anyway, i.e. the culling never changes a result.
+__device__ __forceinline__ unsigned strip_mask(float gx, float gy, float o, float a, float b, float c,
+                                               float tile_x0, float tile_y0) {
+  if (!(o == o)) return 0xFu;           // NaN opacity: keep the reference behaviour (propagates)
+  const float t255 = 255.f * o;
+  if (!(t255 >= 1.f)) return 0u;        // can never reach 1/255
+  const float det = a * c - b * b;
+  if (!(det > 0.f)) return 0xFu;        // degenerate conic: no culling
+  const float tau2 = 2.f * __logf(t255) + 1e-4f;
+  float ex = sqrtf(tau2 * c / det), ey = sqrtf(tau2 * a / det);
+  if (!(ex == ex) || !(ey == ey)) return 0xFu;
+  ex = ex * 1.0005f + 0.02f;
+  ey = ey * 1.0005f + 0.02f;
+  if (gx + ex < tile_x0 + 0.5f || gx - ex > tile_x0 + (TILE - 0.5f)) return 0u;
+  unsigned m = 0;
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    const float ylo = tile_y0 + 4.f * s4 + 0.5f;
+    if (!(gy + ey < ylo || gy - ey > ylo + 3.f)) m |= 1u << s4;
+  }
+  return m;
+}
+
+// strips (4-row bands of the tile) owned by wavefront `wave`; pixel slot k of a lane lies in
+// strip  wave + k * (4 / PPT)
+template <int PPT>
+__device__ __forceinline__ unsigned wave_strips(int wave) {
+  return PPT == 1 ? (1u << wave) : PPT == 2 ? ((1u << wave) | (1u << (wave + 2))) : 0xFu;
+}
+
 template <int C, int PPT>
 __global__ void __launch_bounds__(256 / PPT)
 raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* __restrict__ splats,
@@ -65,13 +99,17 @@ raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
   __shared__ float4 lds[NT][NV];
+  __shared__ uint32_t lds_mask[NT];
 
   const int tile = tile_of_block(blockIdx.x, n_tiles);
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
+  const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
+  const unsigned my_strips = wave_strips<PPT>(wave);
 
   float T[PPT], acc[PPT][C];
   int last[PPT];
@@ -95,40 +133,54 @@ raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
     // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
     if (__syncthreads_and(all_done)) break;
     const int idx = batch + (int)threadIdx.x;
+    unsigned mask = 0;
     if (idx < end) {
       const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
+      float4 v[NV];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) lds[threadIdx.x][v] = rec[v];
-    }
-    __syncthreads();
-    const int nb = min(NT, end - batch);
-    for (int j = 0; j < nb; ++j) {
-      if (__all(all_done)) break;  // this wavefront has nothing left to do
-      Splat s;
-      float f[C];
-      read_record<C>(lds[j], s, f);
-      const float dx = s.x - px;
-#pragma unroll
-      for (int k = 0; k < PPT; ++k) {
-        if (done[k]) continue;
-        const float dy = s.y - py[k];
-        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
-        const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
-        if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
-        const float next_T = T[k] * (1.f - alpha);
-        if (next_T <= FG_T_STOP) {
-          done[k] = true;
-          continue;
-        }
-        const float vis = alpha * T[k];
-#pragma unroll
-        for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
-        last[k] = batch + j;
-        T[k] = next_T;
+      for (int q = 0; q < NV; ++q) {
+        v[q] = rec[q];
+        lds[threadIdx.x][q] = v[q];
       }
-      all_done = true;
+      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+    }
+    lds_mask[threadIdx.x] = mask;
+    __syncthreads();
+    // each wavefront walks only the entries that can reach its own strips, in list order
+    for (int i = 0; i < NT / 64 && !__all(all_done); ++i) {
+      uint64_t todo = __ballot((lds_mask[64 * i + lane] & my_strips) != 0u);
+      while (todo != 0ull) {
+        if (__all(all_done)) break;  // this wavefront has nothing left to do
+        const int j = 64 * i + __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
+        Splat s;
+        float f[C];
+        read_record<C>(lds[j], s, f);
+        const float dx = s.x - px;
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+        for (int k = 0; k < PPT; ++k) {
+          if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
+          if (done[k]) continue;
+          const float dy = s.y - py[k];
+          const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+          const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
+          if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+          const float next_T = T[k] * (1.f - alpha);
+          if (next_T <= FG_T_STOP) {
+            done[k] = true;
+            continue;
+          }
+          const float vis = alpha * T[k];
+#pragma unroll
+          for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
+          last[k] = batch + j;
+          T[k] = next_T;
+        }
+        all_done = true;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+      }
     }
   }
 
@@ -158,16 +210,19 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
   constexpr int NV = rec_vec4(C);
   __shared__ float4 lds[NT][NV];
   __shared__ int32_t lds_gid[NT];
+  __shared__ uint32_t lds_mask[NT];
   __shared__ int32_t lds_max[NW];
 
   const int tile = tile_of_block(blockIdx.x, n_tiles);
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
-  const int lane = fg::lane_id();
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
+  const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
+  const unsigned my_strips = wave_strips<PPT>(wave);
 
   float T[PPT], T_final[PPT], va[PPT], vr[PPT][C], buf[PPT][C], py[PPT];
   int last[PPT];
@@ -205,70 +260,85 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
     const int batch = start + b * NT;
     __syncthreads();
     const int idx = batch + (int)threadIdx.x;
+    unsigned mask = 0;
     if (idx <= bin_final) {
       const int gid = flatten_ids[idx];
       lds_gid[threadIdx.x] = gid;
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
+      float4 v[NV];
 #pragma unroll
-      for (int v = 0; v < NV; ++v) lds[threadIdx.x][v] = rec[v];
-    }
-    __syncthreads();
-    const int nb = min(NT, bin_final + 1 - batch);
-    for (int j = nb - 1; j >= 0; --j) {
-      const int idx_j = batch + j;
-      // wave-uniform skip: no pixel of this wavefront reaches this entry
-      bool reach = false;
-#pragma unroll
-      for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
-      if (!__any(reach)) continue;
-
-      Splat s;
-      float f[C];
-      read_record<C>(lds[j], s, f);
-      const float dx = s.x - px;
-      float g[16];
-#pragma unroll
-      for (int i = 0; i < 16; ++i) g[i] = 0.f;
-      bool contributed = false;
-#pragma unroll
-      for (int k = 0; k < PPT; ++k) {
-        if (idx_j > last[k]) continue;
-        const float dy = s.y - py[k];
-        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
-        const float vis = __expf(-sigma);
-        const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
-        if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
-        contributed = true;
-        const float ra = 1.f / (1.f - alpha);
-        T[k] *= ra;
-        const float fac = alpha * T[k];
-        float v_alpha = 0.f;
-#pragma unroll
-        for (int c = 0; c < C; ++c) {
-          g[8 + c] += fac * vr[k][c];
-          v_alpha += (f[c] * T[k] - buf[k][c] * ra) * vr[k][c];
-          buf[k][c] += f[c] * fac;
-        }
-        v_alpha += T_final[k] * ra * va[k];
-        if (s.o * vis <= FG_ALPHA_MAX) {
-          const float v_sigma = -s.o * vis * v_alpha;
-          g[3] += 0.5f * v_sigma * dx * dx;
-          g[4] += v_sigma * dx * dy;
-          g[5] += 0.5f * v_sigma * dy * dy;
-          const float gx = v_sigma * (s.a * dx + s.b * dy);
-          const float gy = v_sigma * (s.b * dx + s.c * dy);
-          g[0] += gx;
-          g[1] += gy;
-          g[6] += fabsf(gx);
-          g[7] += fabsf(gy);
-          g[2] += vis * v_alpha;
-        }
+      for (int q = 0; q < NV; ++q) {
+        v[q] = rec[q];
+        lds[threadIdx.x][q] = v[q];
       }
-      if (!__any(contributed)) continue;
-      const float total = fg::wave_reduce16_transposed(g);
-      if ((lane & 3) == 0) {
-        float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
-        __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+    }
+    lds_mask[threadIdx.x] = mask;
+    __syncthreads();
+    // back to front over the entries that can reach this wavefront's strips
+    for (int i = NT / 64 - 1; i >= 0; --i) {
+      uint64_t todo = __ballot((lds_mask[64 * i + lane] & my_strips) != 0u);
+      while (todo != 0ull) {
+        const int bit = 63 - __builtin_clzll(todo);
+        todo &= ~(1ull << bit);
+        const int j = 64 * i + bit;
+        const int idx_j = batch + j;
+        const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
+        // wave-uniform skip: no pixel of this wavefront reaches this entry
+        bool reach = false;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
+        if (!__any(reach)) continue;
+
+        Splat s;
+        float f[C];
+        read_record<C>(lds[j], s, f);
+        const float dx = s.x - px;
+        float g[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) g[q] = 0.f;
+        bool contributed = false;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
+          if (idx_j > last[k]) continue;
+          const float dy = s.y - py[k];
+          const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+          const float vis = __expf(-sigma);
+          const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
+          if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+          contributed = true;
+          const float ra = 1.f / (1.f - alpha);
+          T[k] *= ra;
+          const float fac = alpha * T[k];
+          float v_alpha = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            g[8 + c] += fac * vr[k][c];
+            v_alpha += (f[c] * T[k] - buf[k][c] * ra) * vr[k][c];
+            buf[k][c] += f[c] * fac;
+          }
+          v_alpha += T_final[k] * ra * va[k];
+          if (s.o * vis <= FG_ALPHA_MAX) {
+            const float v_sigma = -s.o * vis * v_alpha;
+            g[3] += 0.5f * v_sigma * dx * dx;
+            g[4] += v_sigma * dx * dy;
+            g[5] += 0.5f * v_sigma * dy * dy;
+            const float gx = v_sigma * (s.a * dx + s.b * dy);
+            const float gy = v_sigma * (s.b * dx + s.c * dy);
+            g[0] += gx;
+            g[1] += gy;
+            g[6] += fabsf(gx);
+            g[7] += fabsf(gy);
+            g[2] += vis * v_alpha;
+          }
+        }
+        if (!__any(contributed)) continue;
+        const float total = fg::wave_reduce16_transposed(g);
+        if ((lane & 3) == 0) {
+          float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
+          __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
