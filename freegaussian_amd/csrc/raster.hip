@@ -383,17 +383,17 @@ unpack_grads_kernel(int N, int C, const float* __restrict__ v_splats, float* __r
   }
 }
 
-// Pixels per lane.  Measured on MI355X (1M Gaussians, 1080p, profiles/r01_ppt_sweep.md): the
-// forward is fastest with 1 pixel per lane (4 wavefronts per tile: more latency hiding for
-// the LDS-broadcast loop), the backward with 4 (one wavefront per tile: the 16-value wave
-// reduction + atomic is paid once per 256 pixels).  FG_RASTER_PPT_FWD / _BWD override.
+// Pixels per lane.  Measured on MI355X (1M Gaussians, 1080p, profiles/r01_ppt_sweep.md): with
+// strip culling the forward is fastest with 2 pixels per lane (2 wavefronts per tile) and the
+// backward with 4 (one wavefront per tile: the 16-value wave reduction + atomic is paid once
+// per 256 pixels and no cross-wave step exists).  FG_RASTER_PPT_FWD / _BWD override.
 int env_ppt(const char* name, int dflt) {
   const char* e = getenv(name);
   const int v = e ? atoi(e) : dflt;
   return (v == 1 || v == 2 || v == 4) ? v : dflt;
 }
 int raster_ppt_fwd() {
-  static int ppt = env_ppt("FG_RASTER_PPT_FWD", 1);
+  static int ppt = env_ppt("FG_RASTER_PPT_FWD", 2);
   return ppt;
 }
 int raster_ppt_bwd() {
