@@ -29,9 +29,21 @@ constexpr int TILE = 16;
 
 __host__ __device__ constexpr int rec_vec4(int C) { return (6 + C + 3) / 4; }
 
-// XCD-aware bijective remap: workgroups with equal (id % 8) get consecutive tiles.
-__device__ __forceinline__ int tile_of_block(int b, int n) {
-  const int q = n >> 3, r = n & 7, xcd = b & 7, k = b >> 3;
+// XCD-aware workgroup -> tile maps.  Workgroups are dealt round-robin over the 8 XCDs in id
+// order, so ids with equal (id % 8) share an L2 -- and an XCD that gets the heavy part of the
+// image stalls the in-order dispatcher for everybody.
+//  mode 0 "rows":  tile row r goes to XCD r % 8 (every XCD sees every part of the image: balanced;
+//                  horizontal neighbours still share an L2).  Grid = 8 * ceil(tile_h/8) * tile_w,
+//                  ids past an XCD's last row own no tile (-1).
+//  mode 1 "bands": each XCD owns a contiguous band of tiles (best L2 sharing, worst balance).
+__device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_h, int mode) {
+  const int xcd = b & 7, k = b >> 3;
+  if (mode == 0) {
+    const int row = (k / tile_w) * 8 + xcd;
+    return row < tile_h ? row * tile_w + (k % tile_w) : -1;
+  }
+  if (b >= n) return -1;
+  const int q = n >> 3, r = n & 7;
   const int first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   return first + k;
 }
@@ -92,7 +104,7 @@ __device__ __forceinline__ unsigned wave_strips(int wave) {
 
 template <int C, int PPT>
 __global__ void __launch_bounds__(256 / PPT)
-raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* __restrict__ splats,
+raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                   float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
   constexpr int NT = 256 / PPT;
@@ -101,7 +113,8 @@ raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
   __shared__ float4 lds[NT][NV];
   __shared__ uint32_t lds_mask[NT];
 
-  const int tile = tile_of_block(blockIdx.x, n_tiles);
+  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
+  if (tile < 0) return;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
@@ -199,7 +212,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
 
 template <int C, int PPT>
 __global__ void __launch_bounds__(256 / PPT)
-raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* __restrict__ splats,
+raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                   const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
@@ -213,7 +226,8 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
   __shared__ uint32_t lds_mask[NT];
   __shared__ int32_t lds_max[NW];
 
-  const int tile = tile_of_block(blockIdx.x, n_tiles);
+  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
+  if (tile < 0) return;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
@@ -224,7 +238,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
   const unsigned my_strips = wave_strips<PPT>(wave);
 
-  float T[PPT], T_final[PPT], va[PPT], vr[PPT][C], buf[PPT][C], py[PPT];
+  float T[PPT], tva[PPT], vr[PPT][C], bsum[PPT], py[PPT];
   int last[PPT];
   int my_max = start - 1;
 #pragma unroll
@@ -233,15 +247,12 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
     py[k] = (float)iy + 0.5f;
     const bool inside = ix < width && iy < height;
     const size_t pix = (size_t)iy * width + ix;
-    T_final[k] = inside ? 1.f - alphas[pix] : 1.f;
-    T[k] = T_final[k];
+    T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
     last[k] = inside ? last_ids[pix] : start - 1;
-    va[k] = inside ? v_alphas[pix] : 0.f;
+    tva[k] = inside ? T[k] * v_alphas[pix] : 0.f;  // T_final * dL/dalpha
+    bsum[k] = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      vr[k][c] = inside ? v_render[pix * C + c] : 0.f;
-      buf[k][c] = 0.f;
-    }
+    for (int c = 0; c < C; ++c) vr[k][c] = inside ? v_render[pix * C + c] : 0.f;
     my_max = max(my_max, last[k]);
   }
   // last list entry any pixel of the tile used
@@ -308,17 +319,18 @@ raster_bwd_kernel(int width, int height, int tile_w, int n_tiles, const float4* 
           const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
           if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
           contributed = true;
-          const float ra = 1.f / (1.f - alpha);
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; 1 - alpha >= 1e-3
           T[k] *= ra;
           const float fac = alpha * T[k];
-          float v_alpha = 0.f;
+          // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
+          float cdot = 0.f;
 #pragma unroll
           for (int c = 0; c < C; ++c) {
             g[8 + c] += fac * vr[k][c];
-            v_alpha += (f[c] * T[k] - buf[k][c] * ra) * vr[k][c];
-            buf[k][c] += f[c] * fac;
+            cdot += f[c] * vr[k][c];
           }
-          v_alpha += T_final[k] * ra * va[k];
+          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
+          bsum[k] += cdot * fac;
           if (s.o * vis <= FG_ALPHA_MAX) {
             const float v_sigma = -s.o * vis * v_alpha;
             g[3] += 0.5f * v_sigma * dx * dx;
@@ -392,6 +404,13 @@ int env_ppt(const char* name, int dflt) {
   const int v = e ? atoi(e) : dflt;
   return (v == 1 || v == 2 || v == 4) ? v : dflt;
 }
+int tile_order_mode() {  // FG_TILE_ORDER=bands selects mode 1
+  static int mode = [] {
+    const char* e = getenv("FG_TILE_ORDER");
+    return (e && e[0] == 'b') ? 1 : 0;
+  }();
+  return mode;
+}
 int raster_ppt_fwd() {
   static int ppt = env_ppt("FG_RASTER_PPT_FWD", 2);
   return ppt;
@@ -405,10 +424,11 @@ template <int C, int PPT>
 int launch_fwd(int width, int height, const float* splats, const int32_t* tile_offsets,
                const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int n_tiles = tile_w * tile_h;
-  hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(n_tiles), dim3(256 / PPT), 0, s, width, height, tile_w,
-                     n_tiles, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas,
-                     last_ids);
+  const int mode = tile_order_mode();
+  const int grid = mode == 0 ? 8 * ((tile_h + 7) / 8) * tile_w : tile_w * tile_h;
+  hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
+                     tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
+                     alphas, last_ids);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -417,10 +437,11 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
                const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
                const float* v_alphas, float* v_splats, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int n_tiles = tile_w * tile_h;
-  hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(n_tiles), dim3(256 / PPT), 0, s, width, height, tile_w,
-                     n_tiles, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
-                     v_render, v_alphas, v_splats);
+  const int mode = tile_order_mode();
+  const int grid = mode == 0 ? 8 * ((tile_h + 7) / 8) * tile_w : tile_w * tile_h;
+  hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
+                     tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
+                     last_ids, v_render, v_alphas, v_splats);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
