@@ -77,12 +77,15 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
 }
 
 template <typename KeyT>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK, 3)
 scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
                KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
                const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wave_cnt[WAVES][RADIX];
   __shared__ uint32_t scan_tmp[WAVES];
+  __shared__ uint32_t global_delta[RADIX];  // (global slot) - (slot in the LDS image) per digit
+  __shared__ KeyT skeys[TILE];              // the tile, re-ordered by digit
+  __shared__ uint32_t svals[TILE];
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
 #pragma unroll
   for (int w = 0; w < WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
@@ -107,10 +110,18 @@ scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __re
   }
   __syncthreads();
 
-  // phase 1: ranks within the wave's own 1024-key span
-  const int64_t wave_base = (int64_t)blockIdx.x * TILE + (int64_t)wave * WAVE_SPAN;
+  // phase 1: ranks within the wave's own 1024-key span.  Per round the lowest lane of each
+  // group of equal digits adds the group size to the wave's running LDS counter with a
+  // returning atomic; the 16 atomics of a lane are issued back to back (same-address LDS
+  // atomics of one wave retire in issue order, so the returned values are the prefix counts)
+  // and only then consumed.
+  const int64_t tile_base = (int64_t)blockIdx.x * TILE;
+  const int64_t wave_base = tile_base + (int64_t)wave * WAVE_SPAN;
   KeyT key[KEYS_PER_THREAD];
   uint32_t val[KEYS_PER_THREAD];
+  // rank[k]: bits 0-15 = keys of the same digit before this one in the wave's span (first the
+  // in-round count below this lane, or -- on a group's leader lane, whose in-round count is 0 --
+  // the running count returned by the atomic), bits 16-21 = the group's leader lane
   uint32_t rank[KEYS_PER_THREAD];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -119,6 +130,10 @@ scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __re
     const bool in = i < n;
     key[k] = in ? keys_in[i] : (KeyT)~(KeyT)0;
     val[k] = in ? vals_in[i] : 0u;
+  }
+#pragma unroll
+  for (int k = 0; k < KEYS_PER_THREAD; ++k) {
+    const bool in = wave_base + k * 64 + lane < n;
     const unsigned d = digit_of(key[k], shift);
     uint64_t peers = __ballot(in);  // lanes holding the same digit
 #pragma unroll
@@ -126,38 +141,66 @@ scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __re
       const uint64_t m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
-    volatile uint32_t* cnt = &wave_cnt[wave][d];  // shared by the lanes of this wave across rounds
-    const uint32_t before = *cnt;
-    rank[k] = before + (uint32_t)__popcll(peers & lt_mask);
-    // all peers have read `before` (same wave, program order, LDS completes in order); the
-    // highest peer lane publishes the new running count
-    __builtin_amdgcn_wave_barrier();
-    if (in && (peers >> lane) == 1ull) *cnt = before + (uint32_t)__popcll(peers);
-    __builtin_amdgcn_wave_barrier();
+    const uint32_t leader = in ? (uint32_t)__builtin_ctzll(peers) : (uint32_t)lane;
+    uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+    if (in && leader == (uint32_t)lane) r = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(peers));
+    rank[k] = r | (leader << 16);
   }
-  __syncthreads();
-
-  // phase 2: start slot of each wave's keys of digit (threadIdx.x)
-  {
-    uint32_t run = digit_start;
-#pragma unroll
-    for (int w = 0; w < WAVES; ++w) {
-      const uint32_t c = wave_cnt[w][threadIdx.x];
-      wave_cnt[w][threadIdx.x] = run;
-      run += c;
-    }
-  }
-  __syncthreads();
-
-  // phase 3: scatter
 #pragma unroll
   for (int k = 0; k < KEYS_PER_THREAD; ++k) {
-    const int64_t i = wave_base + k * 64 + lane;
-    if (i < n) {
-      const uint32_t pos = wave_cnt[wave][digit_of(key[k], shift)] + rank[k];
-      keys_out[pos] = key[k];
-      vals_out[pos] = val[k];
+    const uint32_t leader = rank[k] >> 16;
+    const uint32_t before = (uint32_t)__shfl((int)(rank[k] & 0xFFFFu), (int)leader);
+    rank[k] = (leader == (uint32_t)lane) ? before : before + (rank[k] & 0xFFFFu);
+  }
+  __syncthreads();
+
+  // phase 2 (thread t = digit t): place the digits back to back in the LDS image
+  {
+    uint32_t c[WAVES], tot = 0;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      c[w] = wave_cnt[w][threadIdx.x];
+      tot += c[w];
     }
+    uint32_t incl = tot;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const uint32_t o = __shfl_up(incl, k);
+      if (lane >= k) incl += o;
+    }
+    if (lane == 63) scan_tmp[wave] = incl;
+    __syncthreads();
+    uint32_t local = incl - tot;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w)
+      if (w < wave) local += scan_tmp[w];
+    global_delta[threadIdx.x] = digit_start - local;
+#pragma unroll
+    for (int w = 0; w < WAVES; ++w) {
+      wave_cnt[w][threadIdx.x] = local;
+      local += c[w];
+    }
+  }
+  __syncthreads();
+
+  // phase 3: scatter into the LDS image
+#pragma unroll
+  for (int k = 0; k < KEYS_PER_THREAD; ++k) {
+    if (wave_base + k * 64 + lane < n) {
+      const uint32_t lp = wave_cnt[wave][digit_of(key[k], shift)] + rank[k];
+      skeys[lp] = key[k];
+      svals[lp] = val[k];
+    }
+  }
+  __syncthreads();
+
+  // phase 4: stream the image out; consecutive lanes hit consecutive slots of a bucket
+  const int count = (int)min((int64_t)TILE, n - tile_base);
+  for (int e = threadIdx.x; e < count; e += BLOCK) {
+    const KeyT kk = skeys[e];
+    const uint32_t pos = (uint32_t)e + global_delta[digit_of(kk, shift)];
+    keys_out[pos] = kk;
+    vals_out[pos] = svals[e];
   }
 }
 

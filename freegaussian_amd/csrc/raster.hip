@@ -35,12 +35,22 @@ __host__ __device__ constexpr int rec_vec4(int C) { return (6 + C + 3) / 4; }
 //  mode 0 "rows":  tile row r goes to XCD r % 8 (every XCD sees every part of the image: balanced;
 //                  horizontal neighbours still share an L2).  Grid = 8 * ceil(tile_h/8) * tile_w,
 //                  ids past an XCD's last row own no tile (-1).
-//  mode 1 "bands": each XCD owns a contiguous band of tiles (best L2 sharing, worst balance).
+//  mode 1 "bands": each XCD owns a contiguous band of tiles, walked row-major.
+//  mode 2 "cols":  each XCD owns a band of whole tile rows, walked column-major, so a tile and
+//                  its vertical neighbours (which share most of their splats) run back to back.
 __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_h, int mode) {
   const int xcd = b & 7, k = b >> 3;
   if (mode == 0) {
     const int row = (k / tile_w) * 8 + xcd;
     return row < tile_h ? row * tile_w + (k % tile_w) : -1;
+  }
+  if (mode == 2) {  // row bands, walked column-major: vertical neighbours are adjacent in time
+    const int q = tile_h >> 3, r = tile_h & 7;
+    const int rows = q + (xcd < r ? 1 : 0);
+    const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    if (rows == 0) return -1;
+    const int col = k / rows, row = row0 + k % rows;
+    return col < tile_w ? row * tile_w + col : -1;
   }
   if (b >= n) return -1;
   const int q = n >> 3, r = n & 7;
@@ -404,10 +414,11 @@ int env_ppt(const char* name, int dflt) {
   const int v = e ? atoi(e) : dflt;
   return (v == 1 || v == 2 || v == 4) ? v : dflt;
 }
-int tile_order_mode() {  // FG_TILE_ORDER=bands selects mode 1
+int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measured best: profiles/r01_tile_order.md)
   static int mode = [] {
     const char* e = getenv("FG_TILE_ORDER");
-    return (e && e[0] == 'b') ? 1 : 0;
+    if (!e) return 2;
+    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : 1;
   }();
   return mode;
 }
@@ -425,7 +436,7 @@ int launch_fwd(int width, int height, const float* splats, const int32_t* tile_o
                const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 0 ? 8 * ((tile_h + 7) / 8) * tile_w : tile_w * tile_h;
+  const int grid = mode == 1 ? tile_w * tile_h : 8 * ((tile_h + 7) / 8) * tile_w;
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
                      alphas, last_ids);
@@ -438,7 +449,7 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
                const float* v_alphas, float* v_splats, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 0 ? 8 * ((tile_h + 7) / 8) * tile_w : tile_w * tile_h;
+  const int grid = mode == 1 ? tile_w * tile_h : 8 * ((tile_h + 7) / 8) * tile_w;
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
                      last_ids, v_render, v_alphas, v_splats);
