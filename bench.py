@@ -52,6 +52,10 @@ def parse():
 def algorithmic_bytes(N, V, I, P, T, k, p):
     """SURVEY.md §8d per-stage algorithmic HBM bytes for one view (fp32)."""
     return {
+        "fg_preprocess_fwd": 44 * N + (12 * k + 44) * V,
+        "fg_preprocess_bwd": (88 + 12 * k) * V + 44 * N + 12 * 16 * N,
+        "fg_bin_prepare": 8 * N + 2 * 4 * 16 * N + 16 * N,
+        "fg_bin_emit_sort": 8 * I + 2 * 16 * I + 4 * I,
         "fg_project_fwd": 44 * N + 32 * V,
         "fg_sh_fwd": 12 * k * V + 12 * V,
         "fg_tile_bin": 12 * I,
@@ -119,11 +123,12 @@ def main():
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
 
     def step():
-        params.zero_grad()
-        means, quats, scales, opac, colors = params.raster_inputs()
-        r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
-                                   render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
-        (r * vr).sum().backward()
+        # gradients land directly in the flat all-reduce buffer (dense overwrite: no zeroing needed)
+        with params.direct_grads():
+            means, quats, scales, opac, colors = params.raster_inputs()
+            r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
+                                       render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+            (r * vr).sum().backward()
         if world > 1:
             params.all_reduce_grads()
         return info

@@ -1,0 +1,375 @@
+// Fused per-Gaussian stages: K1 + K2 + record packing (forward) and record unpacking + K8 + K7
+// (backward), one pass over the parameters each way.
+//
+// Forward  reads 44 B (means, quats, scales, opacity) + 12k B of SH coefficients per Gaussian and
+// writes the info arrays (radii, means2d, depths, conics, tiles_touched: 32 B) plus the 64-byte
+// splat record the raster kernels gather.  Backward reads the 64-byte gradient record the raster
+// backward accumulated (+ v_means2d, which autograd routes separately so that
+// info["means2d"].grad exists) and writes v_means / v_quats / v_scales / v_opacities and the dense
+// 192-byte v_coeffs row.  Both directions stream the [256 x 48] coefficient slab and the
+// [256 x 16] record slab of a 256-Gaussian workgroup through LDS so every global access is a
+// fully coalesced 16-byte-per-lane stream; rows are read back per lane at padded strides
+// (49 / 20 floats) that are LDS-bank-conflict free.
+//
+// Same arithmetic as project.hip / sh.hip (shared headers); results are bit-identical to the
+// unfused entry points.
+#include "project_math.h"
+#include "sh_math.h"
+
+namespace {
+using namespace fgp;
+using namespace fgsh;
+
+constexpr int REC = FG_SPLAT_FLOATS;  // 16 floats per record
+constexpr int RSTRIDE = 20;           // padded LDS stride of a record (floats, 16-B aligned)
+
+struct FeatLayout {
+  int sh_degree;  // >= 0: colours are SH coefficients [N,k_stored,3]; -1: direct colours [N,n_color]
+  int k_stored;
+  int n_color;    // colour channels composited (3 for SH; 0 if the render mode has no colour)
+  int with_depth; // append the camera depth as a channel
+  int n_extra;    // extra per-Gaussian channels [N,n_extra]
+};
+
+// coalesced copy of a workgroup's contiguous [nrows x row_floats] slab into padded LDS rows
+__device__ __forceinline__ void slab_to_lds(float* lds, int lds_stride, const float* __restrict__ src, int nrows,
+                                            int row_floats, int use_floats) {
+  if (use_floats == row_floats && (row_floats & 3) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    const int total4 = nrows * row_floats / 4;
+    for (int q = threadIdx.x; q < total4; q += BLOCK) {
+      const float4 v = src4[q];
+      const int e = 4 * q, r = e / row_floats, c = e - r * row_floats;
+      float* d = lds + r * lds_stride + c;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    const int total = nrows * use_floats;
+    for (int e = threadIdx.x; e < total; e += BLOCK) {
+      const int r = e / use_floats, c = e - r * use_floats;
+      lds[r * lds_stride + c] = src[(size_t)r * row_floats + c];
+    }
+  }
+}
+
+// coalesced copy of padded LDS rows out to a contiguous [nrows x row_floats] slab; columns
+// >= lds_cols are written as zero
+__device__ __forceinline__ void lds_to_slab(float* __restrict__ dst, const float* lds, int lds_stride, int nrows,
+                                            int row_floats, int lds_cols) {
+  if ((row_floats & 3) == 0 && (lds_cols & 3) == 0) {
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    const int total4 = nrows * row_floats / 4;
+    for (int q = threadIdx.x; q < total4; q += BLOCK) {
+      const int e = 4 * q, r = e / row_floats, c = e - r * row_floats;
+      const float* s = lds + r * lds_stride + c;
+      dst4[q] = (c < lds_cols) ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+  } else {
+    const int total = nrows * row_floats;
+    for (int e = threadIdx.x; e < total; e += BLOCK) {
+      const int r = e / row_floats, c = e - r * row_floats;
+      dst[e] = (c < lds_cols) ? lds[r * lds_stride + c] : 0.f;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK)
+preprocess_fwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, const float* __restrict__ quats,
+                      const float* __restrict__ scales, const float* __restrict__ opacities,
+                      const float* __restrict__ colors, const float* __restrict__ extra,
+                      const float* __restrict__ viewmat, const float* __restrict__ K, int width, int height,
+                      float eps2d, float near_plane, float far_plane, float radius_clip, int tile_size, int tile_w,
+                      int tile_h, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
+                      float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ compensations,
+                      int32_t* __restrict__ tiles_touched, float* __restrict__ splats) {
+  __shared__ float lds[BLOCK * ROW];  // coefficient slab, then the record slab
+  const int row0 = blockIdx.x * BLOCK;
+  const int nrows = min(BLOCK, N - row0);
+  const int i = row0 + threadIdx.x;
+  const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
+  if (kk > 0) slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+
+  // ---- K1 -------------------------------------------------------------------------------------
+  bool ok = false;
+  Fwd f;
+  float mx = 0.f, my = 0.f, mz = 0.f;
+  if (i < N) {
+    const Cam cam = load_cam(viewmat, K);
+    mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
+    const float4 q = reinterpret_cast<const float4*>(quats)[i];
+    f = project_core(cam, mx, my, mz, q.x, q.y, q.z, q.w, scales[3 * i], scales[3 * i + 1], scales[3 * i + 2],
+                     width, height, eps2d);
+    ok = (f.pz >= near_plane) && (f.pz <= far_plane) && (f.det > 0.0f);
+    ok = ok && isfinite(f.radius_f) && (f.radius_f > radius_clip);
+    const float fw = (float)width, fh = (float)height;
+    ok = ok && !((f.m2x + f.radius_f <= 0.0f) || (f.m2x - f.radius_f >= fw) || (f.m2y + f.radius_f <= 0.0f) ||
+                 (f.m2y - f.radius_f >= fh));
+  }
+  float rec[REC];
+#pragma unroll
+  for (int c = 0; c < REC; ++c) rec[c] = 0.f;
+  int32_t radius = 0, touched = 0;
+  float o_comp = 0.f;
+  if (ok) {
+    radius = (int32_t)f.radius_f;
+    const float ts = (float)tile_size;
+    const float r = (float)radius / ts;
+    const float tx = f.m2x / ts, ty = f.m2y / ts;
+    const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
+    const int y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
+    touched = (x1 - x0) * (y1 - y0);
+    o_comp = f.comp;
+    rec[0] = f.m2x; rec[1] = f.m2y;
+    rec[2] = antialiased ? opacities[i] * f.comp : opacities[i];
+    rec[3] = f.conic_a; rec[4] = f.conic_b; rec[5] = f.conic_c;
+  }
+  if (i < N) {
+    radii[i] = radius;
+    means2d[2 * i] = rec[0];
+    means2d[2 * i + 1] = rec[1];
+    depths[i] = ok ? f.pz : 0.f;
+    conics[3 * i] = rec[3]; conics[3 * i + 1] = rec[4]; conics[3 * i + 2] = rec[5];
+    if (compensations) compensations[i] = o_comp;
+    tiles_touched[i] = touched;
+  }
+
+  // ---- K2 + features ----------------------------------------------------------------------------
+  if (kk > 0) __syncthreads();
+  if (ok) {
+    int c0 = 6;
+    if (kk > 0) {
+      float cx, cy, cz;
+      camera_position(viewmat, cx, cy, cz);
+      float dx = mx - cx, dy = my - cy, dz = mz - cz;
+      const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      float basis[16];
+      sh_basis(fl.sh_degree, dx, dy, dz, basis);
+      const float* row = lds + threadIdx.x * ROW;
+      float r = 0.f, g = 0.f, b = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < kk) {
+          r += basis[k] * row[3 * k];
+          g += basis[k] * row[3 * k + 1];
+          b += basis[k] * row[3 * k + 2];
+        }
+      }
+      rec[6] = fmaxf(r + 0.5f, 0.f); rec[7] = fmaxf(g + 0.5f, 0.f); rec[8] = fmaxf(b + 0.5f, 0.f);
+      c0 = 9;
+    } else {
+#pragma unroll
+      for (int c = 0; c < FG_MAX_CHANNELS; ++c)
+        if (c < fl.n_color) rec[6 + c] = colors[(size_t)i * fl.n_color + c];
+      c0 = 6 + fl.n_color;
+    }
+    // depth and extra channels land at a run-time offset: unrolled select, no dynamic indexing
+    const float depth_v = f.pz;
+#pragma unroll
+    for (int c = 6; c < REC - 2; ++c) {
+      if (fl.with_depth && c == c0) rec[c] = depth_v;
+      const int e = c - c0 - fl.with_depth;
+      if (e >= 0 && e < fl.n_extra && c >= c0 + fl.with_depth) rec[c] = extra[(size_t)i * fl.n_extra + e];
+    }
+  }
+  // ---- record slab out through LDS (coalesced 16 B per lane) -----------------------------------
+  __syncthreads();
+  {
+    float* row = lds + threadIdx.x * RSTRIDE;
+#pragma unroll
+    for (int c = 0; c < REC; ++c) row[c] = rec[c];
+  }
+  __syncthreads();
+  lds_to_slab(splats + (size_t)row0 * REC, lds, RSTRIDE, nrows, REC, REC);
+}
+
+__global__ void __launch_bounds__(BLOCK)
+preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, const float* __restrict__ quats,
+                      const float* __restrict__ scales, const float* __restrict__ opacities,
+                      const float* __restrict__ colors, const float* __restrict__ viewmat,
+                      const float* __restrict__ K, int width, int height, float eps2d, int antialiased,
+                      const int32_t* __restrict__ radii, const float* __restrict__ v_splats,
+                      const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
+                      const float* __restrict__ v_conics, float* __restrict__ v_means, float* __restrict__ v_quats,
+                      float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
+                      float* __restrict__ v_extra) {
+  __shared__ float lds[BLOCK * ROW];       // coefficient slab in, v_coeffs slab out
+  __shared__ float lds_rec[BLOCK * RSTRIDE];  // gradient records
+  const int row0 = blockIdx.x * BLOCK;
+  const int nrows = min(BLOCK, N - row0);
+  const int i = row0 + threadIdx.x;
+  const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
+  slab_to_lds(lds_rec, RSTRIDE, v_splats + (size_t)row0 * REC, nrows, REC, REC);
+  if (kk > 1) slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+  __syncthreads();
+
+  float g_m[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f}, g_s[3] = {0.f, 0.f, 0.f};
+  float g_o = 0.f;
+  float vr = 0.f, vg = 0.f, vb = 0.f;
+  float basis[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+  float rec[REC];
+#pragma unroll
+  for (int c = 0; c < REC; ++c) rec[c] = 0.f;
+  const bool active = (i < N) && radii[i] > 0;
+  if (active) {
+    const float* row = lds_rec + threadIdx.x * RSTRIDE;
+#pragma unroll
+    for (int c = 0; c < REC; ++c) rec[c] = row[c];
+    const Cam cam = load_cam(viewmat, K);
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    const float4 q = reinterpret_cast<const float4*>(quats)[i];
+    const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
+    const Fwd f = project_core(cam, mx, my, mz, q.x, q.y, q.z, q.w, s[0], s[1], s[2], width, height, eps2d);
+
+    // feature gradients: [colour | depth | extra] start at record slot 8
+    const int ncol = kk > 0 ? 3 : fl.n_color;
+    float v_depth = v_depths ? v_depths[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < FG_MAX_CHANNELS; ++c)
+      if (fl.with_depth && c == ncol) v_depth += rec[8 + c];
+
+    // ---- K8 -----------------------------------------------------------------------------------
+    if (kk > 0) {
+      float cx, cy, cz;
+      camera_position(viewmat, cx, cy, cz);
+      const float ux = mx - cx, uy = my - cy, uz = mz - cz;
+      const float inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
+      const float dx = ux * inv, dy = uy * inv, dz = uz * inv;
+      sh_basis(fl.sh_degree, dx, dy, dz, basis);
+      const float* crow = lds + threadIdx.x * ROW;
+      // recompute the clamp mask: colour = max(sh + 0.5, 0)
+      float cr = 0.f, cg = 0.f, cb = 0.f;
+      if (kk > 1) {
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+          if (k < kk) {
+            cr += basis[k] * crow[3 * k]; cg += basis[k] * crow[3 * k + 1]; cb += basis[k] * crow[3 * k + 2];
+          }
+      } else {
+        const float* c0p = colors + (size_t)i * 3 * fl.k_stored;
+        cr = basis[0] * c0p[0]; cg = basis[0] * c0p[1]; cb = basis[0] * c0p[2];
+      }
+      vr = (cr + 0.5f > 0.f) ? rec[8] : 0.f;
+      vg = (cg + 0.5f > 0.f) ? rec[9] : 0.f;
+      vb = (cb + 0.5f > 0.f) ? rec[10] : 0.f;
+      if (kk > 1) {
+        float bx[16], by[16], bz[16];
+        sh_basis_grad(fl.sh_degree, dx, dy, dz, bx, by, bz);
+        float vdx = 0.f, vdy = 0.f, vdz = 0.f;
+#pragma unroll
+        for (int k = 1; k < 16; ++k)
+          if (k < kk) {
+            const float sdot = vr * crow[3 * k] + vg * crow[3 * k + 1] + vb * crow[3 * k + 2];
+            vdx += bx[k] * sdot; vdy += by[k] * sdot; vdz += bz[k] * sdot;
+          }
+        const float dp = vdx * dx + vdy * dy + vdz * dz;
+        g_m[0] = (vdx - dp * dx) * inv;
+        g_m[1] = (vdy - dp * dy) * inv;
+        g_m[2] = (vdz - dp * dz) * inv;
+      }
+    }
+    // ---- opacity / compensation -----------------------------------------------------------------
+    float vcomp = 0.f;
+    if (antialiased) {
+      g_o = rec[2] * f.comp;
+      vcomp = rec[2] * opacities[i];
+    } else {
+      g_o = rec[2];
+    }
+    // ---- K7 -------------------------------------------------------------------------------------
+    const float vca = rec[3] + (v_conics ? v_conics[3 * i] : 0.f);
+    const float vcb = rec[4] + (v_conics ? v_conics[3 * i + 1] : 0.f);
+    const float vcc = rec[5] + (v_conics ? v_conics[3 * i + 2] : 0.f);
+    project_backward(cam, f, s, eps2d, v_means2d[2 * i], v_means2d[2 * i + 1], v_depth, vca, vcb, vcc,
+                     antialiased != 0, vcomp, g_m, g_q, g_s);
+  }
+  if (i < N) {
+    v_means[3 * i] = g_m[0]; v_means[3 * i + 1] = g_m[1]; v_means[3 * i + 2] = g_m[2];
+    reinterpret_cast<float4*>(v_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
+    v_scales[3 * i] = g_s[0]; v_scales[3 * i + 1] = g_s[1]; v_scales[3 * i + 2] = g_s[2];
+    v_opacities[i] = g_o;
+    const int ncol = kk > 0 ? 3 : fl.n_color;
+    if (kk == 0) {
+#pragma unroll
+      for (int c = 0; c < FG_MAX_CHANNELS; ++c)
+        if (c < fl.n_color) v_colors[(size_t)i * fl.n_color + c] = rec[8 + c];
+    }
+    if (v_extra) {
+#pragma unroll
+      for (int c = 0; c < FG_MAX_CHANNELS; ++c) {
+        const int e = c - ncol - fl.with_depth;
+        if (e >= 0 && e < fl.n_extra) v_extra[(size_t)i * fl.n_extra + e] = rec[8 + c];
+      }
+    }
+  }
+  // ---- v_coeffs rows out through LDS -------------------------------------------------------------
+  if (kk > 0) {
+    __syncthreads();  // everyone is done reading the coefficient slab
+    float* row = lds + threadIdx.x * ROW;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const float bk = (k < kk) ? basis[k] : 0.f;
+      row[3 * k] = bk * vr; row[3 * k + 1] = bk * vg; row[3 * k + 2] = bk * vb;
+    }
+    __syncthreads();
+    lds_to_slab(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, ROW, nrows, 3 * fl.k_stored, 48);
+  }
+}
+
+bool layout_ok(const FeatLayout& fl) {
+  if (fl.sh_degree > 3 || fl.n_extra < 0 || fl.n_color < 0) return false;
+  if (fl.sh_degree >= 0 && (fl.k_stored < (fl.sh_degree + 1) * (fl.sh_degree + 1) || fl.k_stored > 16)) return false;
+  const int ncol = fl.sh_degree >= 0 ? 3 : fl.n_color;
+  const int total = ncol + (fl.with_depth ? 1 : 0) + fl.n_extra;
+  return total >= 1 && total <= FG_MAX_CHANNELS;
+}
+
+}  // namespace
+
+extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, const float* scales,
+                                 const float* opacities, const float* colors, int sh_degree, int k_stored,
+                                 int n_color, int with_depth, const float* extra, int n_extra,
+                                 const float* viewmat, const float* K, int width, int height, float eps2d,
+                                 float near_plane, float far_plane, float radius_clip, int tile_size,
+                                 int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
+                                 float* compensations, int32_t* tiles_touched, float* splats,
+                                 fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !means2d || !depths || !conics ||
+      !tiles_touched || !splats)
+    return FG_ERR_INVALID_ARG;
+  if ((fl.n_color > 0 && !colors) || (n_extra > 0 && !extra)) return FG_ERR_INVALID_ARG;
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     fl, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
+                     near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
+                     depths, conics, compensations, tiles_touched, splats);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
+                                 const float* opacities, const float* colors, int sh_degree, int k_stored,
+                                 int n_color, int with_depth, int n_extra, const float* viewmat, const float* K,
+                                 int width, int height, float eps2d, int antialiased, const int32_t* radii,
+                                 const float* v_splats, const float* v_means2d, const float* v_depths,
+                                 const float* v_conics, float* v_means, float* v_quats, float* v_scales,
+                                 float* v_opacities, float* v_colors, float* v_extra, fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d ||
+      !v_means || !v_quats || !v_scales || !v_opacities)
+    return FG_ERR_INVALID_ARG;
+  if ((fl.n_color > 0 && (!colors || !v_colors)) || (n_extra > 0 && !v_extra)) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     fl, means, quats, scales, opacities, colors, viewmat, K, width, height, eps2d, antialiased,
+                     radii, v_splats, v_means2d, v_depths, v_conics, v_means, v_quats, v_scales, v_opacities,
+                     v_colors, v_extra);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}

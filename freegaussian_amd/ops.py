@@ -324,6 +324,137 @@ def rasterize_to_pixels(means2d, conics, features, opacities, width, height, til
 
 
 # --------------------------------------------------------------------------------------------
+# Fused path: K1+K2+pack in one pass, raster on records, unpack+K8+K7 in one pass
+
+# Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
+# written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
+# The kernels overwrite their outputs densely, so the buffer needs no zeroing.
+grad_alloc = None
+
+
+def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
+    if grad_alloc is not None:
+        buf = grad_alloc(t)
+        if buf is not None:
+            return buf
+    return torch.empty_like(t)
+
+
+class _Preprocess(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, means, quats, scales, opacities, colors, extra, viewmat, K, cfg):
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg
+        N = means.shape[0]
+        dev = means.device
+        if sh_degree >= 0:
+            k_stored, n_color = colors.shape[1], 3
+        else:
+            k_stored, n_color = 0, (0 if colors is None else colors.shape[1])
+        n_extra = 0 if extra is None else extra.shape[1]
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(N, dtype=torch.float32, device=dev)
+        conics = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
+        tiles = torch.empty(N, dtype=torch.int32, device=dev)
+        splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        _call("fg_preprocess_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
+              sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
+              height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
+              _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _stream())  # fmt: skip
+        ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii)
+        ctx.cfg = cfg
+        ctx.layout = (k_stored, n_color, n_extra)
+        ctx.mark_non_differentiable(radii, tiles)
+        return radii, means2d, depths, conics, tiles, splats
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
+        means, quats, scales, opacities, colors, extra, viewmat, K, radii = ctx.saved_tensors
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg
+        k_stored, n_color, n_extra = ctx.layout
+        N = means.shape[0]
+        dev = means.device
+        if v_splats is None:
+            v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        if v_means2d is None:
+            v_means2d = torch.zeros(N, 2, dtype=torch.float32, device=dev)
+        v_means, v_quats, v_scales = _alloc_grad(means), _alloc_grad(quats), _alloc_grad(scales)
+        v_opac = _alloc_grad(opacities)
+        v_colors = _alloc_grad(colors) if colors is not None else None
+        v_extra = torch.empty_like(extra) if extra is not None else None
+        _call("fg_preprocess_bwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
+              sh_degree, k_stored, n_color, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d,
+              int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d.contiguous()),
+              _ptr(None if v_depths is None else v_depths.contiguous()),
+              _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
+              _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _ptr(v_extra), _stream())  # fmt: skip
+        return v_means, v_quats, v_scales, v_opac, v_colors, v_extra, None, None, None
+
+
+def preprocess(means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d=0.3,
+               near_plane=0.01, far_plane=1e10, radius_clip=0.0, tile_size=TILE_SIZE, antialiased=False,
+               sh_degree=-1, with_depth=False):  # fmt: skip
+    """Fused projection + colour + record packing.
+    -> radii[N], means2d[N,2], depths[N], conics[N,3], tiles_touched[N], splats[N,16]."""
+    means, quats, scales = _f32(means, "means"), _f32(quats, "quats"), _f32(scales, "scales")
+    opacities, viewmat, K = _f32(opacities, "opacities"), _f32(viewmat, "viewmat"), _f32(K, "K")
+    colors = None if colors is None else _f32(colors, "colors")
+    extra = None if extra is None else _f32(extra, "extra_channels")
+    cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+           int(tile_size), bool(antialiased), int(sh_degree), bool(with_depth))  # fmt: skip
+    return _Preprocess.apply(means, quats, scales, opacities, colors, extra, viewmat, K, cfg)
+
+
+class _RasterSplats(torch.autograd.Function):
+    """Compositing on packed records.  ``means2d`` is a routing input only: its gradient carries
+    the xy slots of the record gradient (so ``info["means2d"].grad`` exists, as with gsplat) and
+    the very tensor object receives ``.absgrad``; fg_preprocess_bwd ignores the xy slots of
+    v_splats accordingly."""
+
+    @staticmethod
+    def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad):
+        dev = splats.device
+        render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
+        alphas = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
+        last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
+        _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+              _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
+        ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids)
+        ctx.geom = (channels, width, height, tile_size, absgrad, tuple(means2d.shape))
+        ctx.means2d_ref = means2d if absgrad else None
+        ctx.mark_non_differentiable(last_ids)
+        return render, alphas, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _v_last):
+        splats, tile_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        C, width, height, tile_size, absgrad, m2_shape = ctx.geom
+        N = splats.shape[0]
+        v_render = torch.zeros(height, width, C, device=splats.device) if v_render is None else v_render
+        v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas
+        v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
+        _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
+              _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()),
+              _ptr(v_splats), _stream())  # fmt: skip
+        v_means2d = v_splats[:, 0:2].contiguous().reshape(m2_shape)
+        if absgrad and ctx.means2d_ref is not None:
+            ctx.means2d_ref.absgrad = v_splats[:, 6:8].contiguous().reshape(m2_shape)
+            ctx.means2d_ref = None
+        return v_splats, v_means2d, None, None, None, None, None, None, None
+
+
+def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad=False):
+    """-> render[H,W,C], alphas[H,W,1], last_ids[H,W] from packed records (fused path)."""
+    if tile_size != TILE_SIZE:
+        raise ValueError("tile_size must be 16")
+    if not 1 <= channels <= MAX_CHANNELS:
+        raise ValueError(f"1..{MAX_CHANNELS} composited channels supported, got {channels}")
+    return _RasterSplats.apply(splats, means2d, int(channels), int(width), int(height), int(tile_size), tile_offsets,
+                               flatten_ids, bool(absgrad))  # fmt: skip
+
+
+# --------------------------------------------------------------------------------------------
 # F flow derivative
 
 

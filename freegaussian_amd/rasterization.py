@@ -82,6 +82,7 @@ def rasterization(
     absgrad: bool = False,
     rasterize_mode: str = "classic",
     extra_channels: Optional[torch.Tensor] = None,
+    fused: bool = True,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Render one camera.  Returns ``(render [1,H,W,C], alpha [1,H,W,1], info)``.
 
@@ -89,7 +90,9 @@ def rasterization(
     ``.retain_grad()`` works on it and after backward it carries ``.absgrad`` when
     ``absgrad=True`` (reference freegaussian_model.py:869-872, :377).  ``info["radii"]`` is
     int32 [1,N] (``>0`` <=> visible).  ``extra_channels`` [N,E] (an extension) are composited
-    like colours and appended after the render-mode channels -- used for the flow channels."""
+    like colours and appended after the render-mode channels -- used for the flow channels.
+    ``fused=False`` runs the stage-by-stage operators (one C-ABI call per stage of SURVEY §8a)
+    instead of the fused per-Gaussian passes; both give the same results."""
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     if render_mode not in RENDER_MODES:
@@ -112,30 +115,45 @@ def rasterization(
 
     viewmat = viewmats[0]
     K = Ks[0]
-    radii, means2d_n, depths, conics, comp, tiles = ops.project(
-        means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
-        calc_compensations=(rasterize_mode == "antialiased"),
-    )  # fmt: skip
-    opac = opacities.float()
-    if rasterize_mode == "antialiased":
-        opac = opac * comp
-
-    if sh_degree is None:
-        rgb = colors.float()
-    else:
-        rgb = ops.spherical_harmonics(sh_degree, means, viewmat, colors, radii)
-
-    chans = []
-    if render_mode.startswith("RGB"):
-        chans.append(rgb)
-    if render_mode.endswith("D"):
-        chans.append(depths[:, None])
-    if extra_channels is not None:
-        chans.append(extra_channels.float())
-    feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
-
     tile_w = (width + tile_size - 1) // tile_size
     tile_h = (height + tile_size - 1) // tile_size
+    with_rgb, with_depth = render_mode.startswith("RGB"), render_mode.endswith("D")
+    antialiased = rasterize_mode == "antialiased"
+    n_extra = 0 if extra_channels is None else extra_channels.shape[1]
+
+    if fused:
+        # one pass: projection + SH colour + 64-byte record per Gaussian
+        n_color = (3 if sh_degree is not None else colors.shape[1]) if with_rgb else 0
+        channels = n_color + int(with_depth) + n_extra
+        if not 1 <= channels <= ops.MAX_CHANNELS:
+            raise ValueError(f"1..{ops.MAX_CHANNELS} composited channels supported, got {channels}")
+        radii, means2d_n, depths, conics, tiles, splats = ops.preprocess(
+            means, quats, scales, opacities, colors if with_rgb else None, extra_channels, viewmat, K, width,
+            height, eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased,
+            (sh_degree if (sh_degree is not None and with_rgb) else -1), with_depth,
+        )  # fmt: skip
+        opac = splats[:, 2]
+    else:
+        radii, means2d_n, depths, conics, comp, tiles = ops.project(
+            means, quats, scales, viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
+            calc_compensations=antialiased,
+        )  # fmt: skip
+        opac = opacities.float()
+        if antialiased:
+            opac = opac * comp
+        if sh_degree is None:
+            rgb = colors.float()
+        else:
+            rgb = ops.spherical_harmonics(sh_degree, means, viewmat, colors, radii)
+        chans = []
+        if with_rgb:
+            chans.append(rgb)
+        if with_depth:
+            chans.append(depths[:, None])
+        if extra_channels is not None:
+            chans.append(extra_channels.float())
+        feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
+
     tile_keys, flatten_ids, offsets = ops.bin_tiles(
         means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
     )
@@ -149,13 +167,18 @@ def rasterization(
         means2d_info = means2d_n.unsqueeze(0)  # [1,N,2]: the tensor that is retain_grad()'ed
         means2d_in = means2d_info
 
-    render, alpha, last_ids = ops.rasterize_to_pixels(
-        means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
-    )
+    if fused:
+        render, alpha, last_ids = ops.rasterize_splats(
+            splats, means2d_in, channels, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
+        )
+    else:
+        render, alpha, last_ids = ops.rasterize_to_pixels(
+            means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
+        )
     if backgrounds is not None:
         render = render + (1.0 - alpha) * backgrounds.reshape(1, 1, -1)
     if render_mode in ("ED", "RGB+ED"):
-        di = 3 if render_mode == "RGB+ED" else 0
+        di = ((3 if sh_degree is not None else colors.shape[1]) if with_rgb else 0)  # depth follows the colours
         d = render[..., di : di + 1] / alpha.clamp(min=1e-10)
         render = torch.cat([render[..., :di], d, render[..., di + 1 :]], dim=-1)
 

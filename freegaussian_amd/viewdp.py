@@ -46,13 +46,16 @@ class FlatGaussianParams:
         self.flat_grad = torch.zeros_like(self.flat)
         self.params: Dict[str, torch.Tensor] = {}
         off = 0
+        self.grad_views: Dict[str, torch.Tensor] = {}
         for name, shape in LAYOUT:
             cnt = n * _numel(shape)
             p = self.flat[off : off + cnt].view((n,) + shape).requires_grad_(True)
-            p.grad = self.flat_grad[off : off + cnt].view((n,) + shape)
+            self.grad_views[name] = self.flat_grad[off : off + cnt].view((n,) + shape)
+            p.grad = self.grad_views[name]
             self.params[name] = p
             off += cnt
         assert off == self.flat.numel()
+        self._by_ptr = {p.data_ptr(): self.grad_views[k] for k, p in self.params.items()}
 
     @classmethod
     def from_scene(cls, scene, device) -> "FlatGaussianParams":
@@ -68,6 +71,38 @@ class FlatGaussianParams:
 
     def zero_grad(self) -> None:
         self.flat_grad.zero_()
+        for k, p in self.params.items():
+            p.grad = self.grad_views[k]
+
+    def direct_grads(self):
+        """Context manager: while active, the fused raster backward writes the gradients of these
+        parameters STRAIGHT into their slices of the flat buffer (``ops.grad_alloc`` hook) and
+        ``.grad`` is unbound first, so autograd adopts those slices instead of adding into them:
+        no AccumulateGrad pass and no zeroing (the kernels overwrite densely).  Valid when every
+        parameter is used by exactly one ``rasterization`` call per backward (one view per step per
+        rank -- the bench / view-DP case); use plain ``zero_grad()`` accumulation otherwise."""
+        import contextlib
+
+        from . import ops
+
+        @contextlib.contextmanager
+        def cm():
+            for p in self.params.values():
+                p.grad = None
+            prev = ops.grad_alloc
+            def alloc(t):
+                # a FRESH view object each time: autograd only adopts (instead of cloning) a
+                # gradient tensor nobody else holds a reference to
+                base = self._by_ptr.get(t.data_ptr())
+                return None if base is None else base.view(base.shape)
+
+            ops.grad_alloc = alloc
+            try:
+                yield self
+            finally:
+                ops.grad_alloc = prev
+
+        return cm()
 
     def all_reduce_grads(self, average: bool = True, group=None) -> None:
         """Sum (then average) the flat gradient over all ranks: the one exchange step of a

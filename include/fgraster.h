@@ -153,6 +153,35 @@ int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d
                     float* v_means2d_abs, float* v_conics, float* v_opacities,
                     float* v_features, fg_stream_t stream);
 
+/* ---- Fused per-Gaussian stages (what rasterization() uses) ----------------------------------
+ * fg_preprocess_fwd = fg_project_fwd + fg_sh_fwd + fg_pack_splats in one pass; bit-identical
+ * outputs.  Composited channels of the record, in order: colour (3 from SH when sh_degree >= 0
+ * with colors[N,k_stored,3]; or n_color direct channels colors[N,n_color] when sh_degree = -1;
+ * n_color may be 0), camera depth if with_depth, then n_extra channels from extra[N,n_extra];
+ * at most FG_MAX_CHANNELS in total.  antialiased != 0 multiplies the record's opacity by the
+ * compensation (rasterize_mode="antialiased", freegaussian_model.py:110-119). */
+int fg_preprocess_fwd(int N, const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* colors, int sh_degree, int k_stored,
+                      int n_color, int with_depth, const float* extra, int n_extra,
+                      const float* viewmat, const float* K, int width, int height, float eps2d,
+                      float near_plane, float far_plane, float radius_clip, int tile_size,
+                      int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
+                      float* compensations, int32_t* tiles_touched, float* splats,
+                      fg_stream_t stream);
+/* fg_preprocess_bwd = fg_unpack_grads + fg_sh_bwd + fg_project_bwd in one pass.  v_splats[N,16]
+ * is the record fg_raster_bwd accumulated; its xy slots are IGNORED and v_means2d[N,2] is used
+ * instead (autograd routes that gradient through info["means2d"] so .grad exists there);
+ * v_depths[N] / v_conics[N,3] (nullable) are extra gradients on those outputs.  Every output is
+ * overwritten densely (zeros for culled Gaussians): v_means[N,3] v_quats[N,4] v_scales[N,3]
+ * v_opacities[N] v_colors (same shape as colors) v_extra[N,n_extra]. */
+int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
+                      const float* opacities, const float* colors, int sh_degree, int k_stored,
+                      int n_color, int with_depth, int n_extra, const float* viewmat, const float* K,
+                      int width, int height, float eps2d, int antialiased, const int32_t* radii,
+                      const float* v_splats, const float* v_means2d, const float* v_depths,
+                      const float* v_conics, float* v_means, float* v_quats, float* v_scales,
+                      float* v_opacities, float* v_colors, float* v_extra, fg_stream_t stream);
+
 /* ---- F: flow derivative -------------------------------------------------------------------
  * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at
  * integer coordinates, infinite depth -> 0, :315-317).  depth[H,W], veloc[3], omega[3],

@@ -471,3 +471,60 @@ def test_control_model_stage2_scatter_and_render():
         out = cm.get_outputs(cam)
     assert out["rgb"].shape == (cam.height, cam.width, 3) and bool(torch.isfinite(out["rgb"]).all())
     assert float(out["accumulation"].max()) > 0.1 and "deform" not in cm.get_param_groups()
+
+
+# ------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("render_mode,sh_degree,rmode,extra", [("RGB", 3, "classic", False), ("RGB+ED", 1, "antialiased", True),
+                                                               ("ED", 3, "classic", False), ("RGB", None, "classic", True),
+                                                               ("RGB+ED", 0, "classic", False)])  # fmt: skip
+def test_fused_path_equals_stagewise_path(render_mode, sh_degree, rmode, extra):
+    """fg_preprocess_fwd/bwd (fused) vs project + SH + pack / unpack + SH bwd + project bwd."""
+    sc = _scene(n=12000, w=208, h=130, seed=21)
+    sc.means[:40] *= 4.0
+    colors = sc.colors if sh_degree is not None else torch.sigmoid(sc.colors[:, 0, :])
+    ex = torch.randn(12000, 2, generator=torch.Generator().manual_seed(2)) if extra else None
+    outs = []
+    for fused in (True, False):
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, colors)]
+        e = None if ex is None else ex.to(DEV).requires_grad_(True)
+        r, a, info = rasterization(*t, sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), sc.width, sc.height,
+                                   sh_degree=sh_degree, render_mode=render_mode, packed=False, absgrad=True,
+                                   rasterize_mode=rmode, extra_channels=e, fused=fused)  # fmt: skip
+        info["means2d"].retain_grad()
+        g = torch.Generator().manual_seed(4)
+        vr, va = torch.randn(r.shape, generator=g).to(DEV), torch.randn(a.shape, generator=g).to(DEV)
+        ((r * vr).sum() + (a * va).sum()).backward()
+        outs.append((r.detach(), a.detach(), info, [x.grad for x in t] + ([e.grad] if e is not None else []),
+                     info["means2d"].grad, info["means2d"].absgrad))
+    (r0, a0, i0, g0, m0, ab0), (r1, a1, i1, g1, m1, ab1) = outs
+    # identical forward: same records, same lists, same kernels
+    assert torch.equal(r0, r1) and torch.equal(a0, a1)
+    for k in ("radii", "means2d", "depths", "conics", "flatten_ids", "isect_offsets", "tiles_per_gauss"):
+        assert torch.equal(i0[k], i1[k]), k
+    for x, y in zip(g0, g1):
+        assert rel_l2(x, y) < 1e-5
+    assert rel_l2(m0, m1) < 1e-5 and rel_l2(ab0, ab1) < 1e-5
+
+
+def test_direct_grad_buffers_fill_the_flat_gradient():
+    """viewdp.FlatGaussianParams.direct_grads(): the fused backward writes straight into the flat
+    all-reduce buffer (no AccumulateGrad add, no zeroing) and matches ordinary autograd."""
+    from freegaussian_amd.viewdp import FlatGaussianParams
+
+    sc = _scene(n=9000, w=160, h=112, seed=6)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
+    ref = [getattr(sc, n).to(DEV).requires_grad_(True) for n in ("means", "quats", "scales", "opacities", "colors")]
+    r, _, _ = rasterization(*ref, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True)
+    (r * vr).sum().backward()
+    fp = FlatGaussianParams.from_scene(sc, DEV)
+    fp.flat_grad.fill_(float("nan"))  # must be fully overwritten
+    with fp.direct_grads():
+        r2, _, _ = rasterization(*fp.raster_inputs(), vm, K, sc.width, sc.height, sh_degree=3, packed=False,
+                                 absgrad=True)  # fmt: skip
+        (r2 * vr).sum().backward()
+    assert torch.equal(r, r2) and bool(torch.isfinite(fp.flat_grad).all())
+    for p, q in zip(fp.raster_inputs(), ref):
+        assert p.grad.data_ptr() >= fp.flat_grad.data_ptr()
+        assert p.grad.data_ptr() < fp.flat_grad.data_ptr() + fp.flat_grad.numel() * 4
+        assert rel_l2(p.grad, q.grad) < 1e-5
