@@ -169,31 +169,17 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     }
     lds_mask[threadIdx.x] = mask;
     __syncthreads();
-    // each wavefront walks only the entries that can reach its own strips, in list order; the
-    // LDS reads of entry n+1 are issued before entry n is processed (software pipeline)
+    // each wavefront walks only the entries that can reach its own strips, in list order
     for (int i = 0; i < NT / 64 && !__all(all_done); ++i) {
       uint64_t todo = __ballot((lds_mask[64 * i + lane] & my_strips) != 0u);
-      if (todo == 0ull) continue;
-      int j = 64 * i + __builtin_ctzll(todo);
-      todo &= todo - 1ull;
-      Splat s;
-      float f[C];
-      unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
-      read_record<C>(lds[j], s, f);
-      while (true) {
-        const bool more = todo != 0ull;
-        int jn = j;
-        Splat sn = s;
-        float fn[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) fn[c] = f[c];
-        unsigned smask_n = smask;
-        if (more) {
-          jn = 64 * i + __builtin_ctzll(todo);
-          todo &= todo - 1ull;
-          smask_n = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[jn]);
-          read_record<C>(lds[jn], sn, fn);
-        }
+      while (todo != 0ull) {
+        if (__all(all_done)) break;  // this wavefront has nothing left to do
+        const int j = 64 * i + __builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
+        Splat s;
+        float f[C];
+        read_record<C>(lds[j], s, f);
         const float dx = s.x - px;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -217,12 +203,6 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         all_done = true;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
-        if (!more || __all(all_done)) break;
-        j = jn;
-        s = sn;
-        smask = smask_n;
-#pragma unroll
-        for (int c = 0; c < C; ++c) f[c] = fn[c];
       }
     }
   }
@@ -316,97 +296,71 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     }
     lds_mask[threadIdx.x] = mask;
     __syncthreads();
-    // back to front over the entries that can reach this wavefront's strips; the LDS reads of
-    // the next entry are issued before the current one is processed (software pipeline)
+    // back to front over the entries that can reach this wavefront's strips
     for (int i = NT / 64 - 1; i >= 0; --i) {
       uint64_t todo = __ballot((lds_mask[64 * i + lane] & my_strips) != 0u);
-      if (todo == 0ull) continue;
-      int bit = 63 - __builtin_clzll(todo);
-      todo &= ~(1ull << bit);
-      int j = 64 * i + bit;
-      Splat s;
-      float f[C];
-      unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
-      int gid = lds_gid[j];
-      read_record<C>(lds[j], s, f);
-      while (true) {
-        const bool more = todo != 0ull;
-        int jn = j, gid_n = gid;
-        Splat sn = s;
-        float fn[C];
-#pragma unroll
-        for (int c = 0; c < C; ++c) fn[c] = f[c];
-        unsigned smask_n = smask;
-        if (more) {
-          bit = 63 - __builtin_clzll(todo);
-          todo &= ~(1ull << bit);
-          jn = 64 * i + bit;
-          smask_n = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[jn]);
-          gid_n = lds_gid[jn];
-          read_record<C>(lds[jn], sn, fn);
-        }
+      while (todo != 0ull) {
+        const int bit = 63 - __builtin_clzll(todo);
+        todo &= ~(1ull << bit);
+        const int j = 64 * i + bit;
         const int idx_j = batch + j;
+        const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
         // wave-uniform skip: no pixel of this wavefront reaches this entry
         bool reach = false;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
-        if (__any(reach)) {
-          const float dx = s.x - px;
-          float g[16];
+        if (!__any(reach)) continue;
+
+        Splat s;
+        float f[C];
+        read_record<C>(lds[j], s, f);
+        const float dx = s.x - px;
+        float g[16];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) g[q] = 0.f;
-          bool contributed = false;
+        for (int q = 0; q < 16; ++q) g[q] = 0.f;
+        bool contributed = false;
 #pragma unroll
-          for (int k = 0; k < PPT; ++k) {
-            if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-            if (idx_j > last[k]) continue;
-            const float dy = s.y - py[k];
-            const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
-            const float vis = __expf(-sigma);
-            const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
-            if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
-            contributed = true;
-            const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; 1 - alpha >= 1e-3
-            T[k] *= ra;
-            const float fac = alpha * T[k];
-            // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
-            float cdot = 0.f;
+        for (int k = 0; k < PPT; ++k) {
+          if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
+          if (idx_j > last[k]) continue;
+          const float dy = s.y - py[k];
+          const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+          const float vis = __expf(-sigma);
+          const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
+          if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+          contributed = true;
+          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; 1 - alpha >= 1e-3
+          T[k] *= ra;
+          const float fac = alpha * T[k];
+          // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
+          float cdot = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; ++c) {
-              g[8 + c] += fac * vr[k][c];
-              cdot += f[c] * vr[k][c];
-            }
-            const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
-            bsum[k] += cdot * fac;
-            if (s.o * vis <= FG_ALPHA_MAX) {
-              const float v_sigma = -s.o * vis * v_alpha;
-              g[3] += 0.5f * v_sigma * dx * dx;
-              g[4] += v_sigma * dx * dy;
-              g[5] += 0.5f * v_sigma * dy * dy;
-              const float gx = v_sigma * (s.a * dx + s.b * dy);
-              const float gy = v_sigma * (s.b * dx + s.c * dy);
-              g[0] += gx;
-              g[1] += gy;
-              g[6] += fabsf(gx);
-              g[7] += fabsf(gy);
-              g[2] += vis * v_alpha;
-            }
+          for (int c = 0; c < C; ++c) {
+            g[8 + c] += fac * vr[k][c];
+            cdot += f[c] * vr[k][c];
           }
-          if (__any(contributed)) {
-            const float total = fg::wave_reduce16_transposed(g);
-            if ((lane & 3) == 0) {
-              float* dst = v_splats + (size_t)gid * FG_SPLAT_FLOATS + (lane >> 2);
-              __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
+          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
+          bsum[k] += cdot * fac;
+          if (s.o * vis <= FG_ALPHA_MAX) {
+            const float v_sigma = -s.o * vis * v_alpha;
+            g[3] += 0.5f * v_sigma * dx * dx;
+            g[4] += v_sigma * dx * dy;
+            g[5] += 0.5f * v_sigma * dy * dy;
+            const float gx = v_sigma * (s.a * dx + s.b * dy);
+            const float gy = v_sigma * (s.b * dx + s.c * dy);
+            g[0] += gx;
+            g[1] += gy;
+            g[6] += fabsf(gx);
+            g[7] += fabsf(gy);
+            g[2] += vis * v_alpha;
           }
         }
-        if (!more) break;
-        j = jn;
-        gid = gid_n;
-        s = sn;
-        smask = smask_n;
-#pragma unroll
-        for (int c = 0; c < C; ++c) f[c] = fn[c];
+        if (!__any(contributed)) continue;
+        const float total = fg::wave_reduce16_transposed(g);
+        if ((lane & 3) == 0) {
+          float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
+          __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
   }
