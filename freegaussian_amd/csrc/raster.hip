@@ -90,8 +90,10 @@ __device__ __forceinline__ unsigned strip_mask(float gx, float gy, float o, floa
   if (!(t255 >= 1.f)) return 0u;        // can never reach 1/255
   const float det = a * c - b * b;
   if (!(det > 0.f)) return 0xFu;        // degenerate conic: no culling
+  // 1-ulp hardware log / rcp / sqrt: their error is orders of magnitude inside the inflation below
   const float tau2 = 2.f * __logf(t255) + 1e-4f;
-  float ex = sqrtf(tau2 * c / det), ey = sqrtf(tau2 * a / det);
+  const float rdet = __builtin_amdgcn_rcpf(det);
+  float ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet), ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
   if (!(ex == ex) || !(ey == ey)) return 0xFu;
   ex = ex * 1.0005f + 0.02f;
   ey = ey * 1.0005f + 0.02f;
@@ -127,7 +129,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   if (tile < 0) return;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int lane = fg::lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
@@ -241,7 +243,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int lane = fg::lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
@@ -315,23 +317,31 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         float f[C];
         read_record<C>(lds[j], s, f);
         const float dx = s.x - px;
+        // Per pixel slot: one wave-uniform branch ("does any lane contribute?"), then straight-line
+        // select-predicated arithmetic.  Nested divergent ifs made the compiler re-materialise
+        // the 11 accumulators at every merge point (~30 v_mov per slot in the ISA).
+        // The 16 accumulators are zeroed by 16 separate asm moves: a plain `g[q] = 0` loop becomes a
+        // memset, SROA then promotes g to ONE <16 x float> value (a 512-bit register tuple) and
+        // every conditional update turns into whole-tuple copies (8 v_mov_b64 per slot per path).
         float g[16];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) g[q] = 0.f;
+        for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
         bool contributed = false;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-          if (idx_j > last[k]) continue;
           const float dy = s.y - py[k];
           const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
           const float vis = __expf(-sigma);
-          const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
-          if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+          const float ov = s.o * vis;
+          const float alpha = fminf(FG_ALPHA_MAX, ov);
+          const bool valid = (idx_j <= last[k]) && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+          if (!__any(valid)) continue;  // wave-uniform
           contributed = true;
-          const float ra = __builtin_amdgcn_rcpf(1.f - alpha);  // 1 ulp; 1 - alpha >= 1e-3
+          const float a_eff = valid ? alpha : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
           T[k] *= ra;
-          const float fac = alpha * T[k];
+          const float fac = a_eff * T[k];
           // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
           float cdot = 0.f;
 #pragma unroll
@@ -341,19 +351,18 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           }
           const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
           bsum[k] += cdot * fac;
-          if (s.o * vis <= FG_ALPHA_MAX) {
-            const float v_sigma = -s.o * vis * v_alpha;
-            g[3] += 0.5f * v_sigma * dx * dx;
-            g[4] += v_sigma * dx * dy;
-            g[5] += 0.5f * v_sigma * dy * dy;
-            const float gx = v_sigma * (s.a * dx + s.b * dy);
-            const float gy = v_sigma * (s.b * dx + s.c * dy);
-            g[0] += gx;
-            g[1] += gy;
-            g[6] += fabsf(gx);
-            g[7] += fabsf(gy);
-            g[2] += vis * v_alpha;
-          }
+          const bool open = valid && (ov <= FG_ALPHA_MAX);  // alpha not clamped: gradient flows
+          const float v_sigma = open ? -ov * v_alpha : 0.f;
+          g[3] += 0.5f * v_sigma * dx * dx;
+          g[4] += v_sigma * dx * dy;
+          g[5] += 0.5f * v_sigma * dy * dy;
+          const float gx = v_sigma * (s.a * dx + s.b * dy);
+          const float gy = v_sigma * (s.b * dx + s.c * dy);
+          g[0] += gx;
+          g[1] += gy;
+          g[6] += fabsf(gx);
+          g[7] += fabsf(gy);
+          g[2] += open ? vis * v_alpha : 0.f;
         }
         if (!__any(contributed)) continue;
         const float total = fg::wave_reduce16_transposed(g);
