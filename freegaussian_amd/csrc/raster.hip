@@ -186,21 +186,22 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-          if (done[k]) continue;
+          // one wave-uniform branch, then select-predicated straight-line code (no nested
+          // divergent ifs: each costs exec save/restore and merge copies)
           const float dy = s.y - py[k];
           const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
           const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
-          if (sigma < 0.f || alpha < FG_ALPHA_SKIP) continue;
+          const bool valid = !done[k] && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+          if (!__any(valid)) continue;
           const float next_T = T[k] * (1.f - alpha);
-          if (next_T <= FG_T_STOP) {
-            done[k] = true;
-            continue;
-          }
-          const float vis = alpha * T[k];
+          const bool stop = valid && (next_T <= FG_T_STOP);
+          const bool take = valid && !stop;
+          const float vis = take ? alpha * T[k] : 0.f;
 #pragma unroll
           for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
-          last[k] = batch + j;
-          T[k] = next_T;
+          last[k] = take ? batch + j : last[k];
+          T[k] = take ? next_T : T[k];
+          done[k] = done[k] || stop;
         }
         all_done = true;
 #pragma unroll
