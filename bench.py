@@ -128,7 +128,7 @@ def main():
             means, quats, scales, opac, colors = params.raster_inputs()
             r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
                                        render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
-            (r * vr).sum().backward()
+            r.backward(vr)  # upstream dL/d render = fixed N(0,1) image
         if world > 1:
             params.all_reduce_grads()
         return info
