@@ -43,7 +43,7 @@ SIGNATURES = {
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
                                   c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
-                                  c_float, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+                                  c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P]),
     "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -189,7 +189,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
                       const float* __restrict__ colors, const float* __restrict__ viewmat,
                       const float* __restrict__ K, int width, int height, float eps2d, int antialiased,
                       const int32_t* __restrict__ radii, const float* __restrict__ v_splats,
-                      const float* __restrict__ v_means2d, const float* __restrict__ v_depths,
+                      const float* __restrict__ v_means2d, int m2_stride, const float* __restrict__ v_depths,
                       const float* __restrict__ v_conics, float* __restrict__ v_means, float* __restrict__ v_quats,
                       float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
                       float* __restrict__ v_extra) {
@@ -282,7 +282,8 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
     const float vca = rec[3] + (v_conics ? v_conics[3 * i] : 0.f);
     const float vcb = rec[4] + (v_conics ? v_conics[3 * i + 1] : 0.f);
     const float vcc = rec[5] + (v_conics ? v_conics[3 * i + 2] : 0.f);
-    project_backward(cam, f, s, eps2d, v_means2d[2 * i], v_means2d[2 * i + 1], v_depth, vca, vcb, vcc,
+    project_backward(cam, f, s, eps2d, v_means2d[(size_t)m2_stride * i], v_means2d[(size_t)m2_stride * i + 1],
+                     v_depth, vca, vcb, vcc,
                      antialiased != 0, vcomp, g_m, g_q, g_s);
   }
   if (i < N) {
@@ -356,11 +357,12 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
                                  const float* opacities, const float* colors, int sh_degree, int k_stored,
                                  int n_color, int with_depth, int n_extra, const float* viewmat, const float* K,
                                  int width, int height, float eps2d, int antialiased, const int32_t* radii,
-                                 const float* v_splats, const float* v_means2d, const float* v_depths,
-                                 const float* v_conics, float* v_means, float* v_quats, float* v_scales,
-                                 float* v_opacities, float* v_colors, float* v_extra, fg_stream_t stream) {
+                                 const float* v_splats, const float* v_means2d, int v_means2d_stride,
+                                 const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                                 float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
+                                 fg_stream_t stream) {
   FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
-  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl) || v_means2d_stride < 2) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d ||
       !v_means || !v_quats || !v_scales || !v_opacities)
@@ -368,7 +370,8 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
   if ((fl.n_color > 0 && (!colors || !v_colors)) || (n_extra > 0 && !v_extra)) return FG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
                      fl, means, quats, scales, opacities, colors, viewmat, K, width, height, eps2d, antialiased,
-                     radii, v_splats, v_means2d, v_depths, v_conics, v_means, v_quats, v_scales, v_opacities,
+                     radii, v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats, v_scales,
+                     v_opacities,
                      v_colors, v_extra);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;

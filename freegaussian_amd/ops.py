@@ -383,9 +383,16 @@ class _Preprocess(torch.autograd.Function):
         v_opac = _alloc_grad(opacities)
         v_colors = _alloc_grad(colors) if colors is not None else None
         v_extra = torch.empty_like(extra) if extra is not None else None
+        # the xy gradient usually IS the xy slots of a record array (strided view made by
+        # _RasterSplats.backward): hand the kernel pointer + stride instead of compacting it
+        v_means2d = v_means2d.reshape(N, 2)
+        if v_means2d.stride(1) == 1 and v_means2d.stride(0) >= 2:
+            m2_stride = v_means2d.stride(0)
+        else:
+            v_means2d, m2_stride = v_means2d.contiguous(), 2
         _call("fg_preprocess_bwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
               sh_degree, k_stored, n_color, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d,
-              int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d.contiguous()),
+              int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
               _ptr(None if v_depths is None else v_depths.contiguous()),
               _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
               _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _ptr(v_extra), _stream())  # fmt: skip
@@ -437,9 +444,10 @@ class _RasterSplats(torch.autograd.Function):
         _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
               _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()),
               _ptr(v_splats), _stream())  # fmt: skip
-        v_means2d = v_splats[:, 0:2].contiguous().reshape(m2_shape)
+        # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
+        v_means2d = v_splats[:, 0:2].view(m2_shape)
         if absgrad and ctx.means2d_ref is not None:
-            ctx.means2d_ref.absgrad = v_splats[:, 6:8].contiguous().reshape(m2_shape)
+            ctx.means2d_ref.absgrad = v_splats[:, 6:8].view(m2_shape)
             ctx.means2d_ref = None
         return v_splats, v_means2d, None, None, None, None, None, None, None
 

@@ -169,8 +169,10 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       float* compensations, int32_t* tiles_touched, float* splats,
                       fg_stream_t stream);
 /* fg_preprocess_bwd = fg_unpack_grads + fg_sh_bwd + fg_project_bwd in one pass.  v_splats[N,16]
- * is the record fg_raster_bwd accumulated; its xy slots are IGNORED and v_means2d[N,2] is used
- * instead (autograd routes that gradient through info["means2d"] so .grad exists there);
+ * is the record fg_raster_bwd accumulated; its xy slots are IGNORED and v_means2d is used
+ * instead (autograd routes that gradient through info["means2d"] so .grad exists there): row i
+ * is at v_means2d + i * v_means2d_stride floats (2 = contiguous [N,2]; 16 = the xy slots of a
+ * record array, i.e. v_means2d may simply point at v_splats);
  * v_depths[N] / v_conics[N,3] (nullable) are extra gradients on those outputs.  Every output is
  * overwritten densely (zeros for culled Gaussians): v_means[N,3] v_quats[N,4] v_scales[N,3]
  * v_opacities[N] v_colors (same shape as colors) v_extra[N,n_extra]. */
@@ -178,9 +180,10 @@ int fg_preprocess_bwd(int N, const float* means, const float* quats, const float
                       const float* opacities, const float* colors, int sh_degree, int k_stored,
                       int n_color, int with_depth, int n_extra, const float* viewmat, const float* K,
                       int width, int height, float eps2d, int antialiased, const int32_t* radii,
-                      const float* v_splats, const float* v_means2d, const float* v_depths,
-                      const float* v_conics, float* v_means, float* v_quats, float* v_scales,
-                      float* v_opacities, float* v_colors, float* v_extra, fg_stream_t stream);
+                      const float* v_splats, const float* v_means2d, int v_means2d_stride,
+                      const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                      float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
+                      fg_stream_t stream);
 
 /* ---- F: flow derivative -------------------------------------------------------------------
  * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at

@@ -530,3 +530,54 @@ def test_direct_grad_buffers_fill_the_flat_gradient():
         assert p.grad.data_ptr() >= fp.flat_grad.data_ptr()
         assert p.grad.data_ptr() < fp.flat_grad.data_ptr() + fp.flat_grad.numel() * 4
         assert rel_l2(p.grad, q.grad) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------
+def test_full_size_cfg4_properties_and_oracle_crop():
+    """BASELINE.json's full size (1M Gaussians, 1920x1080): size-independent properties of the
+    whole path, plus a tile-aligned centre crop checked pixel by pixel against the C oracle."""
+    from freegaussian_amd.scenes import north_star_scene
+    from oracle import c_oracle as CO
+
+    sc = north_star_scene(n_views=1)
+    W, H = sc.width, sc.height
+    t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    r, a, info = rasterization(*t, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
+    keys, ids, offs = info["isect_ids"], info["flatten_ids"], info["isect_offsets"]
+    I, T = ids.numel(), info["tile_width"] * info["tile_height"]
+    # integer path: totals, sortedness, stability, ranges
+    assert int(info["tiles_per_gauss"].sum()) == I and int(offs[-1]) == I and int(offs[0]) == 0
+    assert bool((keys[1:] >= keys[:-1]).all())
+    same = keys[1:] == keys[:-1]
+    assert bool((ids[1:][same] > ids[:-1][same]).all())
+    tile_of = (keys >> 32).to(torch.int32)
+    assert torch.equal(offs, torch.searchsorted(tile_of, torch.arange(T + 1, device=DEV, dtype=torch.int32)).int())
+    assert bool((info["radii"][0][ids.long()] > 0).all())
+    # image: alpha in [0,1], finite, deterministic forward
+    assert bool(torch.isfinite(r).all()) and float(a.min()) >= 0.0 and float(a.max()) <= 1.0
+    r2, a2, _ = rasterization(*[x.detach() for x in t], vm, K, W, H, sh_degree=3, packed=False)
+    assert torch.equal(r2, r.detach()) and torch.equal(a2, a.detach())
+    # backward is linear in the upstream gradient
+    g = torch.Generator().manual_seed(0)
+    v1, v2 = torch.randn(r.shape, generator=g).to(DEV), torch.randn(r.shape, generator=g).to(DEV)
+    grads = []
+    for v in (v1, v2, v1 + v2):
+        grads.append(torch.autograd.grad(r, t, v, retain_graph=True))
+    for g1, g2, g12 in zip(*grads):
+        assert rel_l2(g1 + g2, g12) < 1e-4
+    assert all(bool(torch.isfinite(x).all()) for x in grads[2])
+    # centre crop (tile aligned) against the scalar C oracle
+    cw, ch = 160, 96
+    x0, y0 = (W - cw) // 2 // 16 * 16, (H - ch) // 2 // 16 * 16
+    Kc = sc.Ks[0].clone()
+    Kc[0, 2] -= x0
+    Kc[1, 2] -= y0
+    radii, m2, d, con, comp = CO.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], Kc, cw, ch)
+    campos = torch.linalg.inv(sc.viewmats[0])[:3, 3]
+    rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
+    _, ck, cv = CO.isect_tiles(m2, radii, d, 16, cw // 16, ch // 16)
+    coffs = CO.tile_offsets(ck, (cw // 16) * (ch // 16))
+    rc, ac, _ = CO.raster_fwd(m2, con, rgb, sc.opacities, cw, ch, 16, coffs, cv)
+    assert rel_err(r[0, y0 : y0 + ch, x0 : x0 + cw], rc) < 3 * REL_TOL
+    assert rel_err(a[0, y0 : y0 + ch, x0 : x0 + cw], ac) < REL_TOL
