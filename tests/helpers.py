@@ -19,3 +19,18 @@ def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     mse = ((a.detach().double().cpu() - b.detach().double().cpu()) ** 2).mean().item()
     return float("inf") if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item()
+
+
+def close_except_knife_edge(a: torch.Tensor, b: torch.Tensor, tol: float = REL_TOL, max_frac: float = 1e-3) -> bool:
+    """Images agree within `tol` (scale-relative) except on a vanishing fraction of pixels.
+
+    A pixel whose alpha for some splat lies within rounding of the 1/255 skip threshold (or whose
+    transmittance lies within rounding of the 1e-4 stop) legitimately takes the other branch under
+    a different exp() implementation: the pixel then differs by up to ~1/255 * colour.  At the
+    deep lists of the full-size scene (hundreds of evaluations per pixel) a handful of such
+    pixels per image is expected; they are bounded in number and in size here."""
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    scale = max(b.abs().max().item(), 1e-12)
+    err = (a - b).abs() / scale
+    frac_bad = (err.reshape(-1, err.shape[-1]).max(dim=-1).values > tol).double().mean().item()
+    return frac_bad <= max_frac and err.max().item() <= 2.0 / 255.0 and rel_l2(a, b) <= 10 * tol
