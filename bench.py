@@ -109,10 +109,19 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the raster path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % max(ndev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        # RCCL ("nccl") over xGMI is the product path; FG_BENCH_BACKEND=gloo only exists so that the
+        # N>1 control flow can be exercised on a 1-GPU box (ranks then share the device)
+        backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            if local_rank >= ndev:
+                raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPUs visible")
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=8, sh_degree=args.sh_degree, seed=42)
     view = rank % 8
