@@ -587,3 +587,140 @@ def test_full_size_cfg4_properties_and_oracle_crop():
     rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
     assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
+
+
+# ------------------------------------------------------------------------------------------
+# BASELINE.json configs[1], [2], [4] at (or near) their stated sizes
+def test_cfg2_conerf_like_300k_psnr_and_gradients():
+    """configs[1] 'CoNeRF single scene (~300k Gaussians), fwd+bwd PSNR match': 300k, 960x540
+    (dataset absent -> synthetic)."""
+    sc = synthetic_scene(300_000, 960, 540, n_views=1, seed=42)
+    ref_in, gpu_in, (r0, a0, i0), (r1, a1, i1) = _run_both(sc, 0, "RGB", 3)
+    assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
+    assert torch.equal(i1["isect_offsets"].cpu(), i0["isect_offsets"])
+    assert psnr(r1, r0) >= 60.0
+    assert close_except_knife_edge(r1, r0, 3 * REL_TOL) and close_except_knife_edge(a1, a0, REL_TOL)
+    for k in ref_in:
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+
+
+def test_cfg3_flow_derivative_scene():
+    """configs[2] 'LiveScene-sim scene with flow-derivative loss enabled': second pose = first pose
+    moved by dt=(0.02,0,0), dw=(0,0.01,0); per-Gaussian rigid screw motion; F1 composited flow via
+    render_with_flow, F2 per-Gaussian Jacobian terms, camera flow map -- all against the oracle."""
+    from freegaussian_amd import flow as FL
+    from freegaussian_amd.utils import exp_se3, from_homogenous, to_homogenous
+
+    N, W, H = 60_000, 480, 270
+    sc = synthetic_scene(N, W, H, n_views=1, seed=42)
+    g = torch.Generator().manual_seed(5)
+    screw = torch.cat([torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1),
+                       torch.randn(N, 3, generator=g) * 0.3], -1)  # fmt: skip
+    T = exp_se3(screw, torch.full((N, 1), 0.02))
+    means_t = from_homogenous(torch.bmm(T, to_homogenous(sc.means).unsqueeze(-1)).squeeze(-1))
+    vm_t = sc.viewmats[:1]
+    dvm = torch.eye(4)
+    ang = 0.01
+    dvm[:3, :3] = torch.tensor([[math.cos(ang), 0, math.sin(ang)], [0, 1, 0], [-math.sin(ang), 0, math.cos(ang)]])
+    dvm[0, 3] = 0.02
+    vm_0 = (dvm @ vm_t[0])[None]
+    K = sc.Ks[:1]
+
+    # oracle: two projections, displacement channels, one raster
+    ref = [x.clone().requires_grad_(True) for x in (means_t, sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    p0 = O.project(ref[1], ref[2], ref[3], vm_0[0], K[0], W, H)
+    pt = O.project(ref[0], ref[2], ref[3], vm_t[0], K[0], W, H)
+    both = ((p0.radii > 0) & (pt.radii > 0))[:, None]
+    disp = torch.where(both, pt.means2d - p0.means2d, torch.zeros_like(pt.means2d))
+    r0, a0, _ = O.rasterization(ref[0], ref[2], ref[3], ref[4], ref[5], vm_t, K, W, H, sh_degree=3,
+                                render_mode="RGB+ED", extra_channels=disp)  # fmt: skip
+    target = torch.randn(1, H, W, 2, generator=g) * 0.1
+    loss0 = (r0[..., 4:] - target).abs().mean() + r0[..., :3].mean()
+    loss0.backward()
+
+    gpu = [x.detach().to(DEV).requires_grad_(True) for x in ref]
+    out = FL.render_with_flow(gpu[0], gpu[1], gpu[2], gpu[3], gpu[4], gpu[5], vm_t.to(DEV), vm_0.to(DEV),
+                              K.to(DEV), W, H, sh_degree=3, render_mode="RGB+ED")  # fmt: skip
+    loss1 = FL.flow_loss(out["flow_gs"], target.to(DEV)) + out["render"][..., :3].mean()
+    loss1.backward()
+    assert out["flow_gs"].shape == (1, H, W, 2) and out["render"].shape == (1, H, W, 4)
+    assert close_except_knife_edge(out["flow_gs"], r0[..., 4:], 3 * REL_TOL)
+    assert close_except_knife_edge(out["render"], r0[..., :4], 3 * REL_TOL)
+    assert abs(loss1.item() - loss0.item()) < 1e-5
+    for a, b, name in zip(gpu, ref, ["means_t", "means_0", "quats", "scales", "opacities", "colors"]):
+        assert rel_l2(a.grad, b.grad) < 5 * REL_TOL, name
+
+    # F2 + camera flow map with the (v, w) of this camera pair
+    c2w_t, c2w_0 = torch.linalg.inv(vm_t[0]), torch.linalg.inv(vm_0[0])
+    for m in (c2w_t, c2w_0):
+        m[:3, 1:3] *= -1  # back to the OpenGL convention relative_camera_motion expects
+    v, w = FL.relative_camera_motion(c2w_0[:3], c2w_t[:3])
+    depth0 = r0[0, ..., 3].detach()
+    fx, fy, cx, cy = K[0, 0, 0], K[0, 1, 1], K[0, 0, 2], K[0, 1, 2]
+    cam0 = O.camera_flow(depth0.double(), fx.double(), fy.double(), cx.double(), cy.double(), v, w)
+    cam1 = FL.camera_flow_map(out["render"][0, ..., 3], K[0].to(DEV), v.float().to(DEV), w.float().to(DEV))
+    assert close_except_knife_edge(cam1, cam0.float(), 5 * REL_TOL)
+    vel = torch.randn(N, 3, generator=g)
+    ug0, uc0 = O.gaussian_flow(pt.means2d.detach(), pt.depths.detach().clamp_min(1e-3), vel, fx, fy, cx, cy, v.float(), w.float())
+    ug1, uc1 = ops.gaussian_flow(out["info"]["means2d"][0].detach(), out["info"]["depths"][0].detach().clamp_min(1e-3),
+                                 vel.to(DEV), K[0].to(DEV), v.float().to(DEV), w.float().to(DEV))  # fmt: skip
+    assert rel_err(ug1, ug0) < REL_TOL and rel_err(uc1, uc0) < REL_TOL
+
+
+def test_cfg5_control_stage2_matches_oracle_host_path():
+    """configs[4] 'freegaussian-control stage-2': frozen deform -> per-attribute mean displacement
+    -> control MLP -> deltas scattered into the masked Gaussians -> the same raster call."""
+    import copy
+
+    from freegaussian_amd.model import FreeGaussianControlModel, FreeGaussianModelConfig
+    from freegaussian_amd.utils import from_homogenous, get_viewmat, to_homogenous
+
+    _, base, cam = _model_and_camera(n=6000, training=True)
+    N = base.num_points
+    mask = torch.zeros(N, 3, dtype=torch.bool)
+    mask[:300, 0] = True
+    mask[200:500, 1] = True
+    mask[1000:1100, 2] = True
+    init_cam = type(cam)(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height,
+                         times=torch.tensor([[0.0]]))  # fmt: skip
+    cfg = FreeGaussianModelConfig(background_color="black")
+    cm_cpu = FreeGaussianControlModel(mask, init_cam, config=cfg, seed_points=base.means.detach().clone())
+    cm_cpu.load_state_dict(base.state_dict(), strict=False)
+    with torch.no_grad():
+        for p in cm_cpu.control.parameters():
+            p.mul_(0.2)
+    cm = copy.deepcopy(cm_cpu).to(DEV).train()
+    cm_cpu.train()
+    out = cm.get_outputs(cam)
+
+    # the same host math on CPU + the oracle raster
+    sel = mask.any(-1)
+    pts, pmask = cm_cpu.means[sel], mask[sel]
+    with torch.no_grad():
+        def deformed(t):
+            T, _, _ = cm_cpu.deform(pts, t.expand(pts.shape[0], -1))
+            return from_homogenous(torch.bmm(T, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
+
+        delta = deformed(cam.times) - deformed(init_cam.times)
+        d_avg = torch.stack([delta[pmask[:, i]].mean(0) for i in range(3)])
+    value = pmask.float() @ d_avg / pmask.sum(-1, keepdim=True)
+    d_xyz, d_rot, d_scale = cm_cpu.control(pts, value)
+    idx = sel.nonzero().squeeze(-1)
+    means = cm_cpu.means + torch.zeros_like(cm_cpu.means).index_put((idx,), d_xyz)
+    scales = torch.exp(cm_cpu.scales) + torch.zeros_like(cm_cpu.scales).index_put((idx,), d_scale)
+    quats = cm_cpu.quats / cm_cpu.quats.norm(dim=-1, keepdim=True) + torch.zeros_like(cm_cpu.quats).index_put((idx,), d_rot)
+    colors, deg = cm_cpu._colors_and_degree()
+    r0, a0, _ = O.rasterization(means, quats, scales, torch.sigmoid(cm_cpu.opacities).squeeze(-1), colors,
+                                get_viewmat(cam.camera_to_worlds), cam.get_intrinsics_matrices(), cam.width,
+                                cam.height, sh_degree=deg, render_mode="RGB", packed=False)  # fmt: skip
+    rgb0 = torch.clamp(r0[..., :3] + (1 - a0) * torch.zeros(3), 0.0, 1.0).squeeze(0)
+    assert deg == 3 and cm.step == 30000
+    assert close_except_knife_edge(out["rgb"], rgb0, 3 * REL_TOL)
+    gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(9))
+    (out["rgb"] - gt.to(DEV)).abs().mean().backward()
+    (rgb0 - gt).abs().mean().backward()
+    gc = torch.cat([p.grad.flatten() for p in cm.control.parameters()])
+    gc0 = torch.cat([p.grad.flatten() for p in cm_cpu.control.parameters()])
+    assert rel_l2(gc, gc0) < 2e-3
+    assert rel_l2(cm.gauss_params["means"].grad, cm_cpu.gauss_params["means"].grad) < 5 * REL_TOL
+    assert all(p.grad is None for p in cm.deform.parameters())  # frozen (evaluated under no_grad)
