@@ -170,7 +170,8 @@ def main():
     T = info["tile_width"] * info["tile_height"]
     k = (args.sh_degree + 1) ** 2
     nbits = 32 + max(T - 1, 1).bit_length()
-    p = (nbits + 7) // 8
+    p = (nbits + 7) // 8  # passes the reference-style 64-bit-key sort would need (SURVEY.md §8d formula)
+    tile_passes = (max(T - 1, 1).bit_length() + 7) // 8
     alg = algorithmic_bytes(N, V, I, P, T, k, p)
     dom = max(stages, key=lambda s: stages[s])
     roof = {
@@ -201,7 +202,9 @@ def main():
         "config": {
             "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank "
             f"per step (8-view ring), fwd+bwd, RGB, absgrad" + (", RCCL grad all-reduce" if world > 1 else ""),
-            "N": N, "V": V, "I": I, "P": P, "T": T, "k": k, "sort_passes": p,
+            "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
+            "binning": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I "
+            f"(the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
         },
         "roofline": roof,
