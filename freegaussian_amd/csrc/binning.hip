@@ -156,29 +156,64 @@ depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __rest
   order[i] = i;
 }
 
-// lane k of the depth-sorted sequence writes (tile id, Gaussian id) for every tile of its splat
+// Emission in depth order, wave-cooperative: the 64 Gaussians of a wavefront own ONE contiguous
+// output range [cum[k0-1], cum[k0+63]) (cum is the ordered inclusive scan), so the wave walks that
+// range 64 slots at a time -- every store instruction writes 64 consecutive (tile, id) pairs --
+// and each lane finds the splat that owns its slot by a 6-step binary search over the wave's
+// exclusive offsets (kept in LDS).  A lane-per-Gaussian loop wrote 8-byte pieces at 64 unrelated
+// addresses per instruction instead.
 __global__ void __launch_bounds__(256)
 tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
                         const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
                         int tile_w, int tile_h, uint32_t* __restrict__ tile_keys,
                         int32_t* __restrict__ flatten_ids) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
-  if (k >= N) return;
-  const int i = order[k];
-  const int radius = radii[i];
-  if (radius <= 0) return;
-  const float ts = (float)tile_size;
-  const float r = (float)radius / ts;
-  const float tx = means2d[2 * i] / ts, ty = means2d[2 * i + 1] / ts;
-  const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
-  const int y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
-  int64_t cur = (k == 0) ? 0 : cum_tiles[k - 1];
-  for (int y = y0; y < y1; ++y)
-    for (int x = x0; x < x1; ++x) {
-      tile_keys[cur] = (uint32_t)(y * tile_w + x);
-      flatten_ids[cur] = i;
-      ++cur;
+  __shared__ int32_t s_excl[4][64];  // exclusive slot offset of each lane's splat inside the wave's range
+  __shared__ int32_t s_gid[4][64];
+  __shared__ int32_t s_rect[4][64];  // x0 | y0 << 10 | width << 20
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int k0 = (blockIdx.x * 4 + wave) * 64;
+  if (k0 >= N) return;
+  const int k = k0 + lane;
+  const int64_t base = (k0 == 0) ? 0 : cum_tiles[k0 - 1];
+  const int klast = min(k0 + 63, N - 1);
+  const int total = (int)(cum_tiles[klast] - base);
+  int gid = 0, rect = 0;
+  int excl = total;  // lanes past N own nothing
+  if (k < N) {
+    gid = order[k];
+    excl = (int)(((k == 0) ? 0 : cum_tiles[k - 1]) - base);
+    const int radius = radii[gid];
+    if (radius > 0) {
+      const float ts = (float)tile_size;
+      const float r = (float)radius / ts;
+      const float tx = means2d[2 * gid] / ts, ty = means2d[2 * gid + 1] / ts;
+      const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
+      const int y0 = min(max((int)floorf(ty - r), 0), tile_h);
+      rect = x0 | (y0 << 10) | ((x1 - x0) << 20);
     }
+  }
+  s_excl[wave][lane] = excl;
+  s_gid[wave][lane] = gid;
+  s_rect[wave][lane] = rect;
+  __builtin_amdgcn_wave_barrier();  // same-wave LDS traffic only: program order suffices
+  for (int s0 = 0; s0 < total; s0 += 64) {
+    const int slot = s0 + lane;
+    if (slot < total) {
+      // owner = last lane whose exclusive offset is <= slot (empty splats share their successor's
+      // offset and are skipped by taking the LAST such lane)
+      int lo = 0;
+#pragma unroll
+      for (int step = 32; step > 0; step >>= 1)
+        if (s_excl[wave][lo + step] <= slot) lo += step;
+      const int t = slot - s_excl[wave][lo];
+      const int rc = s_rect[wave][lo];
+      const int w = rc >> 20;
+      const int ty = t / w, tx = t - ty * w;
+      const int64_t out = base + slot;
+      tile_keys[out] = (uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx);
+      flatten_ids[out] = s_gid[wave][lo];
+    }
+  }
 }
 
 __global__ void __launch_bounds__(256)
@@ -302,6 +337,7 @@ extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, c
                                 int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
                                 void* workspace, size_t workspace_bytes, fg_stream_t stream) {
   if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
+  if (tile_w > 1023 || tile_h > 1023) return FG_ERR_UNSUPPORTED;  // rectangle packing of the emit kernel
   hipStream_t s = fg_hip_stream(stream);
   const int n_tiles = tile_w * tile_h;
   if (n_isects > 0) {
