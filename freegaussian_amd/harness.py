@@ -1,0 +1,92 @@
+"""Minimal training harness around ``FreeGaussianModel`` (nerfstudio's Trainer is out of scope and
+not installed): optimizer groups and schedules of the reference method spec, the reference loss
+``0.8 L1 + 0.2 (1 - SSIM)`` (freegaussian_model.py:944-983), PSNR (:933), the per-step callback
+order of SURVEY.md §3.1, and the view-DP exchange step.  Enough to run `ns-train freegaussian`'s
+inner loop end to end on MI355X; dataset I/O and densification stay with the caller."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional
+
+import torch
+import torch.nn.functional as F
+
+from .method_config import STAGE1_OPTIMIZERS, OptimSpec
+from .model import Camera, FreeGaussianModel
+
+
+def _gauss_window(size: int = 11, sigma: float = 1.5, device=None) -> torch.Tensor:
+    x = torch.arange(size, dtype=torch.float32, device=device) - size // 2
+    g = torch.exp(-(x * x) / (2 * sigma * sigma))
+    g = g / g.sum()
+    return g[:, None] * g[None, :]
+
+
+def ssim(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
+    """Mean SSIM of [B,C,H,W] images, 11x11 Gaussian window sigma 1.5, 'valid' borders -- the
+    definition `pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3)` uses."""
+    C = a.shape[1]
+    w = _gauss_window(device=a.device).expand(C, 1, 11, 11).contiguous()
+    mu_a, mu_b = F.conv2d(a, w, groups=C), F.conv2d(b, w, groups=C)
+    s_aa = F.conv2d(a * a, w, groups=C) - mu_a * mu_a
+    s_bb = F.conv2d(b * b, w, groups=C) - mu_b * mu_b
+    s_ab = F.conv2d(a * b, w, groups=C) - mu_a * mu_b
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    m = ((2 * mu_a * mu_b + c1) * (2 * s_ab + c2)) / ((mu_a * mu_a + mu_b * mu_b + c1) * (s_aa + s_bb + c2))
+    return m.mean()
+
+
+def psnr(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
+    return -10.0 * torch.log10(F.mse_loss(pred, gt))
+
+
+def main_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2) -> torch.Tensor:
+    """pred, gt: [H,W,3] in [0,1]."""
+    l1 = (gt - pred).abs().mean()
+    sim = 1 - ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None])
+    return (1 - ssim_lambda) * l1 + ssim_lambda * sim
+
+
+def build_optimizers(model: FreeGaussianModel, table: Optional[Dict[str, OptimSpec]] = None):
+    table = table or STAGE1_OPTIMIZERS
+    groups = model.get_param_groups()
+    opts = {}
+    for name, spec in table.items():
+        if name in groups:
+            opts[name] = torch.optim.Adam(groups[name], lr=spec.lr, eps=spec.eps)
+    return opts
+
+
+def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = None) -> None:
+    """Exponential (log-linear) decay lr_init -> lr_final over max_steps, as nerfstudio's
+    ExponentialDecayScheduler without warm-up."""
+    table = table or STAGE1_OPTIMIZERS
+    for name, opt in opts.items():
+        spec = table[name]
+        if spec.lr_final is None:
+            continue
+        t = min(max(step / spec.max_steps, 0.0), 1.0)
+        lr = math.exp(math.log(spec.lr) * (1 - t) + math.log(spec.lr_final) * t)
+        for g in opt.param_groups:
+            g["lr"] = lr
+
+
+def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
+               grad_sync=None) -> Dict[str, float]:  # fmt: skip
+    """One iteration in the reference's callback order: step_cb -> get_outputs ->
+    loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter."""
+    model.step_cb(step)
+    for o in opts.values():
+        o.zero_grad(set_to_none=True)
+    out = model.get_outputs(camera)
+    gt = model.get_gt_img(gt_image)
+    loss = main_loss(out["rgb"], gt)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync(model)
+    apply_schedules(opts, step, table)
+    for o in opts.values():
+        o.step()
+    model.after_train_iter(step)
+    with torch.no_grad():
+        return {"loss": float(loss), "psnr": float(psnr(out["rgb"], gt)), "gaussian_count": model.num_points}

@@ -726,3 +726,24 @@ def test_cfg5_control_stage2_matches_oracle_host_path():
     assert rel_l2(gc, gc0) < 2e-3
     assert rel_l2(cm.gauss_params["means"].grad, cm_cpu.gauss_params["means"].grad) < 5 * REL_TOL
     assert all(p.grad is None for p in cm.deform.parameters())  # frozen (evaluated under no_grad)
+
+
+def test_harness_training_steps_reduce_loss():
+    """End to end: a few optimisation steps of the host harness (reference loss + optimizer table)
+    through the HIP raster must fit a target rendered from perturbed parameters."""
+    import copy
+
+    from freegaussian_amd import harness as Hn
+
+    model, _, cam = _model_and_camera(n=3000, W=128, H=96, step=1500, training=True)  # before warm_up: static
+    target = copy.deepcopy(model)
+    with torch.no_grad():
+        target.gauss_params["features_dc"].add_(0.3 * torch.randn_like(target.gauss_params["features_dc"]))
+        target.gauss_params["means"].add_(0.01 * torch.randn_like(target.gauss_params["means"]))
+    target.eval()
+    with torch.no_grad():
+        gt = target.get_outputs(copy.deepcopy(cam))["rgb"].clamp(0, 1)
+    opts = Hn.build_optimizers(model)
+    hist = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 1500 + i) for i in range(25)]
+    assert hist[-1]["loss"] < 0.7 * hist[0]["loss"] and hist[-1]["psnr"] > hist[0]["psnr"] + 1.0
+    assert model.xys_grad_norm is not None and float(model.vis_counts.max()) == 26.0

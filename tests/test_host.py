@@ -123,3 +123,34 @@ def test_model_schedules_and_camera_rescale():
     m.config.background_color = "bogus"
     with pytest.raises(ValueError):
         m._get_background_color()
+
+
+def test_method_specs_mirror_reference_tables():
+    from freegaussian_amd.method_config import METHODS, STAGE1_OPTIMIZERS, STAGE2_OPTIMIZERS, nerfstudio_method_specs
+
+    assert set(METHODS) == {"freegaussian", "freegaussian-control"}  # pyproject.toml:14-17
+    assert STAGE1_OPTIMIZERS["means"].lr == pytest.approx(8e-4) and STAGE1_OPTIMIZERS["means"].lr_final == pytest.approx(8e-6)
+    assert STAGE1_OPTIMIZERS["features_rest"].lr == pytest.approx(0.0025 / 20)
+    assert STAGE1_OPTIMIZERS["control"].max_steps == 15000 and "deform" not in STAGE2_OPTIMIZERS
+    assert set(STAGE2_OPTIMIZERS) == set(STAGE1_OPTIMIZERS) - {"deform"}
+    with pytest.raises(ImportError):
+        nerfstudio_method_specs()  # nerfstudio is not installed here
+
+
+def test_harness_loss_ssim_and_schedule():
+    from freegaussian_amd import harness as Hn
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand(40, 56, 3, generator=g)
+    assert float(Hn.ssim(a.permute(2, 0, 1)[None], a.permute(2, 0, 1)[None])) == pytest.approx(1.0, abs=1e-6)
+    b = (a + 0.1 * torch.randn(40, 56, 3, generator=g)).clamp(0, 1)
+    s = float(Hn.ssim(a.permute(2, 0, 1)[None], b.permute(2, 0, 1)[None]))
+    assert 0.3 < s < 0.999
+    assert float(Hn.main_loss(a, a)) == pytest.approx(0.0, abs=1e-6)
+    assert float(Hn.main_loss(b, a)) == pytest.approx(0.8 * (a - b).abs().mean().item() + 0.2 * (1 - s), rel=1e-5)
+    m = FreeGaussianModel(FreeGaussianModelConfig(), num_points=8)
+    opts = Hn.build_optimizers(m)
+    assert set(opts) == {"means", "features_dc", "features_rest", "opacities", "scales", "quats", "deform", "control"}
+    Hn.apply_schedules(opts, 15000)
+    assert opts["means"].param_groups[0]["lr"] == pytest.approx((8e-4 * 8e-6) ** 0.5, rel=1e-6)
+    assert opts["opacities"].param_groups[0]["lr"] == 0.05
