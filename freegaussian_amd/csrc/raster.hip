@@ -224,12 +224,12 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 }
 
 template <int C, int PPT>
-__device__ __forceinline__ void
-raster_bwd_tile(int tile, int width, int height, int tile_w, const float4* __restrict__ splats,
-                const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                float* __restrict__ v_splats) {
+__global__ void __launch_bounds__(256 / PPT)
+raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ v_splats) {
   constexpr int NT = 256 / PPT;
   constexpr int NW = NT / 64;
   constexpr int RSTEP = TILE / PPT;
@@ -239,6 +239,8 @@ raster_bwd_tile(int tile, int width, int height, int tile_w, const float4* __res
   __shared__ uint32_t lds_mask[NT];
   __shared__ int32_t lds_max[NW];
 
+  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
+  if (tile < 0) return;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
@@ -374,50 +376,6 @@ raster_bwd_tile(int tile, int width, int height, int tile_w, const float4* __res
   }
 }
 
-template <int C, int PPT>
-__global__ void __launch_bounds__(256 / PPT)
-raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
-                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ v_splats) {
-  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
-  if (tile < 0) return;
-  raster_bwd_tile<C, PPT>(tile, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids, v_render,
-                          v_alphas, v_splats);
-}
-
-// EXPERIMENT (FG_BWD_DYNAMIC=1): persistent single-wave workgroups pull tiles from 8 per-XCD queues
-// (column-major row bands, as tile order "cols"), stealing from the other bands when theirs is dry.
-__device__ unsigned int g_bwd_queue[8];
-
-template <int C>
-__global__ void __launch_bounds__(64)
-raster_bwd_dynamic_kernel(int width, int height, int tile_w, int tile_h, const float4* __restrict__ splats,
-                          const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                          const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                          const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                          float* __restrict__ v_splats) {
-  const int xcc = (int)(__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u);  // HW_REG_XCC_ID[3:0]
-  const int q = tile_h >> 3, r = tile_h & 7;
-  for (int d = 0; d < 8; ++d) {
-    const int band = (xcc + d) & 7;
-    const int rows = q + (band < r ? 1 : 0);
-    const int row0 = (band < r) ? band * (q + 1) : r * (q + 1) + (band - r) * q;
-    const unsigned n = (unsigned)(rows * tile_w);
-    while (true) {
-      unsigned k = 0;
-      if (fg::lane_id() == 0) k = atomicAdd(&g_bwd_queue[band], 1u);
-      k = __builtin_amdgcn_readfirstlane(k);
-      if (k >= n) break;
-      const int col = (int)k / rows, row = row0 + (int)k % rows;
-      raster_bwd_tile<C, 4>(row * tile_w + col, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
-                            last_ids, v_render, v_alphas, v_splats);
-      __syncthreads();  // LDS of the previous tile is dead before the next one stages into it
-    }
-  }
-}
-
 __global__ void __launch_bounds__(256)
 pack_splats_kernel(int N, int C, const float* __restrict__ means2d, const float* __restrict__ conics,
                    const float* __restrict__ opacities, const float* __restrict__ features,
@@ -502,16 +460,6 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
   const int grid = mode == 1 ? tile_w * tile_h : 8 * ((tile_h + 7) / 8) * tile_w;
-  static const int dyn = [] { const char* e = getenv("FG_BWD_DYNAMIC"); return e ? atoi(e) : 0; }();
-  if (PPT == 4 && dyn > 0) {
-    void* q = nullptr;
-    if (hipGetSymbolAddress(&q, HIP_SYMBOL(g_bwd_queue)) != hipSuccess) return FG_ERR_LAUNCH;
-    if (hipMemsetAsync(q, 0, sizeof(unsigned int) * 8, s) != hipSuccess) return FG_ERR_LAUNCH;
-    hipLaunchKernelGGL((raster_bwd_dynamic_kernel<C>), dim3(dyn), dim3(64), 0, s, width, height, tile_w, tile_h,
-                       reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
-                       v_render, v_alphas, v_splats);
-    return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
-  }
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
                      last_ids, v_render, v_alphas, v_splats);
