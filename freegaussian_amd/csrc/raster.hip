@@ -36,6 +36,8 @@ __host__ __device__ constexpr int rec_vec4(int C) { return (6 + C + 3) / 4; }
 //                  horizontal neighbours still share an L2).  Grid = 8 * ceil(tile_h/8) * tile_w,
 //                  ids past an XCD's last row own no tile (-1).
 //  mode 1 "bands": each XCD owns a contiguous band of tiles, walked row-major.
+//  mode 3 "split": as "cols" but every XCD owns two half-height bands, one from the upper and one
+//                  from the lower half of the image (better balance on centre-weighted scenes).
 //  mode 2 "cols":  each XCD owns a band of whole tile rows, walked column-major, so a tile and
 //                  its vertical neighbours (which share most of their splats) run back to back.
 __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_h, int mode) {
@@ -51,6 +53,19 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
     if (rows == 0) return -1;
     const int col = k / rows, row = row0 + k % rows;
     return col < tile_w ? row * tile_w + col : -1;
+  }
+  if (mode == 3) {  // 16 row groups; XCD x owns groups x and x+8 (a light and a heavy part of a
+                    // centre-weighted image), each walked column-major
+    int kk = k;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      const int g = xcd + 8 * half;
+      const int r0 = (g * tile_h) >> 4, r1 = ((g + 1) * tile_h) >> 4;
+      const int rows = r1 - r0, cnt = rows * tile_w;
+      if (kk < cnt) return (r0 + kk % rows) * tile_w + kk / rows;
+      kk -= cnt;
+    }
+    return -1;
   }
   if (b >= n) return -1;
   const int q = n >> 3, r = n & 7;
@@ -428,7 +443,7 @@ int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measur
   static int mode = [] {
     const char* e = getenv("FG_TILE_ORDER");
     if (!e) return 2;
-    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : 1;
+    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : 1;
   }();
   return mode;
 }
@@ -446,7 +461,8 @@ int launch_fwd(int width, int height, const float* splats, const int32_t* tile_o
                const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 1 ? tile_w * tile_h : 8 * ((tile_h + 7) / 8) * tile_w;
+  const int grid = mode == 1 ? tile_w * tile_h : mode == 3 ? 8 * 2 * ((tile_h + 15) / 16) * tile_w
+                                                           : 8 * ((tile_h + 7) / 8) * tile_w;
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
                      alphas, last_ids);
@@ -459,7 +475,8 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
                const float* v_alphas, float* v_splats, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 1 ? tile_w * tile_h : 8 * ((tile_h + 7) / 8) * tile_w;
+  const int grid = mode == 1 ? tile_w * tile_h : mode == 3 ? 8 * 2 * ((tile_h + 15) / 16) * tile_w
+                                                           : 8 * ((tile_h + 7) / 8) * tile_w;
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
                      last_ids, v_render, v_alphas, v_splats);
