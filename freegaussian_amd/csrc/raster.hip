@@ -67,6 +67,15 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
     }
     return -1;
   }
+  if (mode == 4 || mode == 5) {  // 4x2 (mode 4) or 2x4 (mode 5) rectangles, one per XCD, column-major
+    const int nx = mode == 4 ? 4 : 2, ny = 8 / nx;
+    const int rx = xcd % nx, ry = xcd / nx;
+    const int c0 = (rx * tile_w) / nx, c1 = ((rx + 1) * tile_w) / nx;
+    const int r0 = (ry * tile_h) / ny, r1 = ((ry + 1) * tile_h) / ny;
+    const int rows = r1 - r0, cnt = rows * (c1 - c0);
+    if (k >= cnt) return -1;
+    return (r0 + k % rows) * tile_w + c0 + k / rows;
+  }
   if (b >= n) return -1;
   const int q = n >> 3, r = n & 7;
   const int first = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
@@ -443,9 +452,18 @@ int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measur
   static int mode = [] {
     const char* e = getenv("FG_TILE_ORDER");
     if (!e) return 2;
-    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : 1;
+    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : e[0] == 'x' ? 4 : e[0] == 'y' ? 5 : 1;
   }();
   return mode;
+}
+int launch_grid(int mode, int tile_w, int tile_h) {
+  switch (mode) {
+    case 1: return tile_w * tile_h;
+    case 3: return 8 * 2 * ((tile_h + 15) / 16) * tile_w;
+    case 4: return 8 * ((tile_w + 3) / 4) * ((tile_h + 1) / 2);
+    case 5: return 8 * ((tile_w + 1) / 2) * ((tile_h + 3) / 4);
+    default: return 8 * ((tile_h + 7) / 8) * tile_w;
+  }
 }
 int raster_ppt_fwd() {
   static int ppt = env_ppt("FG_RASTER_PPT_FWD", 2);
@@ -461,8 +479,7 @@ int launch_fwd(int width, int height, const float* splats, const int32_t* tile_o
                const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 1 ? tile_w * tile_h : mode == 3 ? 8 * 2 * ((tile_h + 15) / 16) * tile_w
-                                                           : 8 * ((tile_h + 7) / 8) * tile_w;
+  const int grid = launch_grid(mode, tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
                      alphas, last_ids);
@@ -475,8 +492,7 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
                const float* v_alphas, float* v_splats, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = mode == 1 ? tile_w * tile_h : mode == 3 ? 8 * 2 * ((tile_h + 15) / 16) * tile_w
-                                                           : 8 * ((tile_h + 7) / 8) * tile_w;
+  const int grid = launch_grid(mode, tile_w, tile_h);
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
                      last_ids, v_render, v_alphas, v_splats);
