@@ -59,6 +59,27 @@ class _Info(dict):
         return dict.__contains__(self, key) or key in self.__dict__.get("_thunks", {})
 
 
+def _empty_result(means, width, height, tile_size, render_mode, sh_degree, colors, extra, packed):
+    dev = means.device
+    n_rgb = (3 if sh_degree is not None else colors.shape[1]) if render_mode.startswith("RGB") else 0
+    C = n_rgb + int(render_mode.endswith("D")) + (0 if extra is None else extra.shape[1])
+    tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+    zi = torch.zeros(0, dtype=torch.int32, device=dev)
+    zf = means.new_zeros(0)
+    info = _Info({
+        "radii": zi[None] if not packed else zi, "means2d": means.new_zeros((1, 0, 2) if not packed else (0, 2)),
+        "depths": zf[None] if not packed else zf, "conics": means.new_zeros((1, 0, 3) if not packed else (0, 3)),
+        "opacities": zf[None], "tile_width": tile_w, "tile_height": tile_h, "tiles_per_gauss": zi[None],
+        "tile_keys": zi, "flatten_ids": zi, "isect_ids": torch.zeros(0, dtype=torch.int64, device=dev),
+        "isect_offsets": torch.zeros(tile_w * tile_h + 1, dtype=torch.int32, device=dev),
+        "last_ids": torch.full((height, width), -1, dtype=torch.int32, device=dev),
+        "width": width, "height": height, "tile_size": tile_size, "n_cameras": 1,
+    })  # fmt: skip
+    if packed:
+        info.update(camera_ids=zi.long(), gaussian_ids=zi.long())
+    return means.new_zeros(1, height, width, C), means.new_zeros(1, height, width, 1), info
+
+
 def rasterization(
     means: torch.Tensor,  # [N,3]
     quats: torch.Tensor,  # [N,4] wxyz, normalised by the callee
@@ -112,6 +133,13 @@ def rasterization(
             raise ValueError("colors must be [N,K,3] SH coefficients when sh_degree is given")
         if (sh_degree + 1) ** 2 > colors.shape[1]:
             raise ValueError("sh_degree too large for the given coefficients")
+
+    if not means.is_cuda:
+        from ._lib import FgRasterError
+
+        raise FgRasterError("rasterization needs CUDA/HIP tensors: the raster path has no CPU fallback")
+    if N == 0:  # nothing to draw: empty image, empty lists (no kernel is launched on empty buffers)
+        return _empty_result(means, width, height, tile_size, render_mode, sh_degree, colors, extra_channels, packed)
 
     viewmat = viewmats[0]
     K = Ks[0]

@@ -747,3 +747,30 @@ def test_harness_training_steps_reduce_loss():
     hist = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 1500 + i) for i in range(25)]
     assert hist[-1]["loss"] < 0.7 * hist[0]["loss"] and hist[-1]["psnr"] > hist[0]["psnr"] + 1.0
     assert model.xys_grad_norm is not None and float(model.vis_counts.max()) == 26.0
+
+
+def test_edge_cases_zero_gaussians_and_short_sh_tables():
+    """N = 0 renders an empty image without launching on empty buffers; SH tables shorter than 16
+    bases ([N,9,3] with degree 2, [N,1,3] with degree 0) go through the fused path."""
+    z = torch.zeros
+    r, a, info = rasterization(z(0, 3, device=DEV), z(0, 4, device=DEV), z(0, 3, device=DEV), z(0, device=DEV),
+                               z(0, 16, 3, device=DEV), torch.eye(4, device=DEV)[None], torch.eye(3, device=DEV)[None],
+                               40, 24, sh_degree=3, packed=False, render_mode="RGB+ED")  # fmt: skip
+    assert r.shape == (1, 24, 40, 4) and float(r.abs().max()) == 0.0 and info["radii"].shape == (1, 0)
+    assert info["isect_offsets"].numel() == 3 * 2 + 1 and info["flatten_ids"].numel() == 0
+    sc = _scene(n=4000, w=96, h=64, seed=12)
+    for deg, K in ((2, 9), (0, 1), (1, 16)):
+        cpu = [sc.means, sc.quats, sc.scales, sc.opacities, sc.colors[:, :K].contiguous()]
+        ref = [t.clone().requires_grad_(True) for t in cpu]
+        gpu = [t.to(DEV).requires_grad_(True) for t in cpu]
+        r0, a0, _ = O.rasterization(*ref, sc.viewmats[:1], sc.Ks[:1], 96, 64, sh_degree=deg, packed=False)
+        r1, a1, _ = rasterization(*gpu, sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), 96, 64, sh_degree=deg, packed=False)
+        g = torch.randn(r0.shape, generator=torch.Generator().manual_seed(deg))
+        (r0 * g).sum().backward()
+        (r1 * g.to(DEV)).sum().backward()
+        assert close_except_knife_edge(r1, r0, 3 * REL_TOL)
+        assert gpu[4].grad.shape == (4000, K, 3) and rel_l2(gpu[4].grad, ref[4].grad) < 3 * REL_TOL
+        assert rel_l2(gpu[0].grad, ref[0].grad) < 3 * REL_TOL
+    with pytest.raises(ValueError):
+        rasterization(*[t.to(DEV) for t in cpu[:4]], torch.rand(4000, 9, device=DEV), sc.viewmats[:1].to(DEV),
+                      sc.Ks[:1].to(DEV), 96, 64, sh_degree=None, packed=False)  # 9 channels > 8
