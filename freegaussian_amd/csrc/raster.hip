@@ -175,16 +175,6 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
   }
 
-  // The id -> record gather of batch b+1 (two dependent global loads) is issued before batch b is
-  // processed and lands in registers meanwhile.
-  float4 pre[NV];
-#pragma unroll
-  for (int q = 0; q < NV; ++q) pre[q] = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (start + (int)threadIdx.x < end) {
-    const float4* rec = splats + (size_t)flatten_ids[start + threadIdx.x] * (FG_SPLAT_FLOATS / 4);
-#pragma unroll
-    for (int q = 0; q < NV; ++q) pre[q] = rec[q];
-  }
   for (int batch = start; batch < end; batch += NT) {
     bool all_done = true;
 #pragma unroll
@@ -194,16 +184,16 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     const int idx = batch + (int)threadIdx.x;
     unsigned mask = 0;
     if (idx < end) {
+      const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
+      float4 v[NV];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) lds[threadIdx.x][q] = pre[q];
-      mask = strip_mask(pre[0].x, pre[0].y, pre[0].z, pre[0].w, pre[1].x, pre[1].y, tile_x0, tile_y0);
+      for (int q = 0; q < NV; ++q) {
+        v[q] = rec[q];
+        lds[threadIdx.x][q] = v[q];
+      }
+      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
     }
     lds_mask[threadIdx.x] = mask;
-    if (idx + NT < end) {
-      const float4* rec = splats + (size_t)flatten_ids[idx + NT] * (FG_SPLAT_FLOATS / 4);
-#pragma unroll
-      for (int q = 0; q < NV; ++q) pre[q] = rec[q];
-    }
     __syncthreads();
     // each wavefront walks only the entries that can reach its own strips, in list order
     for (int i = 0; i < NT / 64 && !__all(all_done); ++i) {
