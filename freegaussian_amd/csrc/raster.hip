@@ -86,27 +86,6 @@ struct Splat {
   float x, y, o, a, b, c;
 };
 
-// Non-packed VALU instructions issue at one per 4 cycles per SIMD for a 64-lane wavefront (both
-// raster kernels measure ~4.1 cycles per VALU instruction: they are VALU-issue bound); packed
-// fp32 (v_pk_fma/mul/add_f32) handles two floats per lane at the same cost.  A lane's pixel
-// slots are therefore evaluated in PAIRS held in <2 x float> values for everything up to alpha.
-typedef float f2 __attribute__((ext_vector_type(2)));
-
-// alpha of one splat at a pair of pixels that share dx.  sigma = 0.5 (a dx^2 + c dy^2) + b dx dy
-// evaluated as (hc dy + bdx) dy + hadx2; forward and backward use this one function so that they
-// take identical skip decisions.
-__device__ __forceinline__ void pair_alpha(float o, float hadx2, float bdx, float hc, float sy, f2 py, f2& dy,
-                                           f2& sigma, f2& vis, f2& ov, f2& alpha) {
-  dy = sy - py;
-  sigma = (hc * dy + bdx) * dy + hadx2;
-  const f2 e = sigma * -1.4426950408889634f;
-  vis.x = __builtin_amdgcn_exp2f(e.x);
-  vis.y = __builtin_amdgcn_exp2f(e.y);
-  ov = o * vis;
-  alpha.x = fminf(FG_ALPHA_MAX, ov.x);
-  alpha.y = fminf(FG_ALPHA_MAX, ov.y);
-}
-
 template <int C>
 __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (&f)[C]) {
   const float4 v0 = rec[0];
@@ -183,29 +162,25 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
   const unsigned my_strips = wave_strips<PPT>(wave);
 
-  // slots in pairs: pair p = slots 2p, 2p+1 (PPT == 1 carries a dummy, permanently "done" second slot)
-  constexpr int NP = (PPT + 1) / 2;
-  f2 T2[NP], acc2[NP][C], py2[NP];
-  int last[2 * NP];
-  bool done[2 * NP];
+  float T[PPT], acc[PPT][C];
+  int last[PPT];
+  bool done[PPT];
+  float py[PPT];
 #pragma unroll
-  for (int k = 0; k < 2 * NP; ++k) {
+  for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
-    if (k & 1) py2[k >> 1].y = (float)iy + 0.5f; else py2[k >> 1].x = (float)iy + 0.5f;
+    py[k] = (float)iy + 0.5f;
+    T[k] = 1.f;
     last[k] = start - 1;
-    done[k] = !(k < PPT && ix < width && iy < height);
-  }
+    done[k] = !(ix < width && iy < height);
 #pragma unroll
-  for (int p2 = 0; p2 < NP; ++p2) {
-    T2[p2] = 1.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) acc2[p2][c] = 0.f;
+    for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
   }
 
   for (int batch = start; batch < end; batch += NT) {
     bool all_done = true;
 #pragma unroll
-    for (int k = 0; k < 2 * NP; ++k) all_done = all_done && done[k];
+    for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
     // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
     if (__syncthreads_and(all_done)) break;
     const int idx = batch + (int)threadIdx.x;
@@ -244,36 +219,31 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       float f[C];
       read_record<C>(lds[j], s, f);
       const float dx = s.x - px;
-      const float hadx2 = 0.5f * s.a * dx * dx, bdx = s.b * dx, hc = 0.5f * s.c;
 #pragma unroll
-      for (int p2 = 0; p2 < NP; ++p2) {
-        // PPT == 4: skip the pair if the splat reaches neither of its two strips
-        if (PPT == 4 && !((packed >> (8 + 2 * p2)) & 3u)) continue;
-        f2 dy, sigma, vis, ov, alpha;
-        pair_alpha(s.o, hadx2, bdx, hc, s.y, py2[p2], dy, sigma, vis, ov, alpha);
+      for (int k = 0; k < PPT; ++k) {
+        // PPT == 4: skip the strips the splat cannot reach; with 1-2 slots per lane the test
+        // costs more scalar work than it saves
+        if (PPT == 4 && !((packed >> (8 + k)) & 1u)) continue;
         // one wave-uniform branch, then select-predicated straight-line code (no nested
         // divergent ifs: each costs exec save/restore and merge copies)
-        const bool v0 = !done[2 * p2] && !(sigma.x < 0.f || alpha.x < FG_ALPHA_SKIP);
-        const bool v1 = !done[2 * p2 + 1] && !(sigma.y < 0.f || alpha.y < FG_ALPHA_SKIP);
-        if (!__any(v0 || v1)) continue;
-        const f2 next_T = T2[p2] * (1.f - alpha);
-        const bool stop0 = v0 && (next_T.x <= FG_T_STOP), stop1 = v1 && (next_T.y <= FG_T_STOP);
-        const bool take0 = v0 && !stop0, take1 = v1 && !stop1;
-        f2 w = alpha * T2[p2];
-        w.x = take0 ? w.x : 0.f;
-        w.y = take1 ? w.y : 0.f;
+        const float dy = s.y - py[k];
+        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+        const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
+        const bool valid = !done[k] && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+        if (!__any(valid)) continue;
+        const float next_T = T[k] * (1.f - alpha);
+        const bool stop = valid && (next_T <= FG_T_STOP);
+        const bool take = valid && !stop;
+        const float vis = take ? alpha * T[k] : 0.f;
 #pragma unroll
-        for (int c = 0; c < C; ++c) acc2[p2][c] += f[c] * w;
-        last[2 * p2] = take0 ? batch + j : last[2 * p2];
-        last[2 * p2 + 1] = take1 ? batch + j : last[2 * p2 + 1];
-        T2[p2].x = take0 ? next_T.x : T2[p2].x;
-        T2[p2].y = take1 ? next_T.y : T2[p2].y;
-        done[2 * p2] = done[2 * p2] || stop0;
-        done[2 * p2 + 1] = done[2 * p2 + 1] || stop1;
+        for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
+        last[k] = take ? batch + j : last[k];
+        T[k] = take ? next_T : T[k];
+        done[k] = done[k] || stop;
       }
       all_done = true;
 #pragma unroll
-      for (int k = 0; k < 2 * NP; ++k) all_done = all_done && done[k];
+      for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
     }
   }
 
@@ -283,8 +253,8 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     if (ix < width && iy < height) {
       const size_t pix = (size_t)iy * width + ix;
 #pragma unroll
-      for (int c = 0; c < C; ++c) render[pix * C + c] = (k & 1) ? acc2[k >> 1][c].y : acc2[k >> 1][c].x;
-      alphas[pix] = 1.f - ((k & 1) ? T2[k >> 1].y : T2[k >> 1].x);
+      for (int c = 0; c < C; ++c) render[pix * C + c] = acc[k][c];
+      alphas[pix] = 1.f - T[k];
       last_ids[pix] = last[k];
     }
   }
@@ -318,20 +288,13 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
   const unsigned my_strips = wave_strips<PPT>(wave);
 
-  constexpr int NP = (PPT + 1) / 2;  // pixel slots are tested in pairs (packed fp32), see pair_alpha
-  float T[2 * NP], tva[2 * NP], vr[2 * NP][C], bsum[2 * NP];
-  f2 py2[NP];
-  int last[2 * NP];
+  float T[PPT], tva[PPT], vr[PPT][C], bsum[PPT], py[PPT];
+  int last[PPT];
   int my_max = start - 1;
-  if (PPT == 1) {  // dummy second slot of the only pair: never reached
-    T[1] = 1.f; tva[1] = 0.f; bsum[1] = 0.f; last[1] = start - 1; py2[0].y = 0.f;
-#pragma unroll
-    for (int c = 0; c < C; ++c) vr[1][c] = 0.f;
-  }
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
-    if (k & 1) py2[k >> 1].y = (float)iy + 0.5f; else py2[k >> 1].x = (float)iy + 0.5f;
+    py[k] = (float)iy + 0.5f;
     const bool inside = ix < width && iy < height;
     const size_t pix = (size_t)iy * width + ix;
     T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
@@ -402,50 +365,42 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
         bool contributed = false;
-        const float hadx2 = 0.5f * s.a * dx * dx, bdx = s.b * dx, hc = 0.5f * s.c;
 #pragma unroll
-        for (int p2 = 0; p2 < NP; ++p2) {
-          // strips of the pair's two slots: wave + k * (4 / PPT); skip if neither is reachable
-          if (PPT == 4 && !((smask >> (2 * p2)) & 3u)) continue;  // wave-uniform
-          f2 dy2, sigma2, vis2, ov2, alpha2;
-          pair_alpha(s.o, hadx2, bdx, hc, s.y, py2[p2], dy2, sigma2, vis2, ov2, alpha2);
-          const bool val0 = (idx_j <= last[2 * p2]) && !(sigma2.x < 0.f || alpha2.x < FG_ALPHA_SKIP);
-          const bool val1 = (idx_j <= last[2 * p2 + 1]) && !(sigma2.y < 0.f || alpha2.y < FG_ALPHA_SKIP);
-          if (!__any(val0 || val1)) continue;  // wave-uniform
+        for (int k = 0; k < PPT; ++k) {
+          if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
+          const float dy = s.y - py[k];
+          const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
+          const float vis = __expf(-sigma);
+          const float ov = s.o * vis;
+          const float alpha = fminf(FG_ALPHA_MAX, ov);
+          const bool valid = (idx_j <= last[k]) && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+          if (!__any(valid)) continue;  // wave-uniform
+          contributed = true;
+          const float a_eff = valid ? alpha : 0.f;
+          const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
+          T[k] *= ra;
+          const float fac = a_eff * T[k];
+          // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
+          float cdot = 0.f;
 #pragma unroll
-          for (int h = 0; h < 2; ++h) {
-            const int k = 2 * p2 + h;
-            const bool valid = h ? val1 : val0;
-            if (!__any(valid)) continue;  // wave-uniform
-            const float dy = h ? dy2.y : dy2.x, vis = h ? vis2.y : vis2.x, ov = h ? ov2.y : ov2.x;
-            const float alpha = h ? alpha2.y : alpha2.x;
-            contributed = true;
-            const float a_eff = valid ? alpha : 0.f;
-            const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
-            T[k] *= ra;
-            const float fac = a_eff * T[k];
-            // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
-            float cdot = 0.f;
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-              g[8 + c] += fac * vr[k][c];
-              cdot += f[c] * vr[k][c];
-            }
-            const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
-            bsum[k] += cdot * fac;
-            const bool open = valid && (ov <= FG_ALPHA_MAX);  // alpha not clamped: gradient flows
-            const float v_sigma = open ? -ov * v_alpha : 0.f;
-            g[3] += 0.5f * v_sigma * dx * dx;
-            g[4] += v_sigma * dx * dy;
-            g[5] += 0.5f * v_sigma * dy * dy;
-            const float gx = v_sigma * (s.a * dx + s.b * dy);
-            const float gy = v_sigma * (s.b * dx + s.c * dy);
-            g[0] += gx;
-            g[1] += gy;
-            g[6] += fabsf(gx);
-            g[7] += fabsf(gy);
-            g[2] += open ? vis * v_alpha : 0.f;
+          for (int c = 0; c < C; ++c) {
+            g[8 + c] += fac * vr[k][c];
+            cdot += f[c] * vr[k][c];
           }
+          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
+          bsum[k] += cdot * fac;
+          const bool open = valid && (ov <= FG_ALPHA_MAX);  // alpha not clamped: gradient flows
+          const float v_sigma = open ? -ov * v_alpha : 0.f;
+          g[3] += 0.5f * v_sigma * dx * dx;
+          g[4] += v_sigma * dx * dy;
+          g[5] += 0.5f * v_sigma * dy * dy;
+          const float gx = v_sigma * (s.a * dx + s.b * dy);
+          const float gy = v_sigma * (s.b * dx + s.c * dy);
+          g[0] += gx;
+          g[1] += gy;
+          g[6] += fabsf(gx);
+          g[7] += fabsf(gy);
+          g[2] += open ? vis * v_alpha : 0.f;
         }
         if (!__any(contributed)) continue;
         const float total = fg::wave_reduce16_transposed(g);
