@@ -316,6 +316,9 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const int n_used = bin_final - start + 1;
   if (n_used <= 0) return;
   const int n_batches = (n_used + NT - 1) / NT;
+  float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
+#pragma unroll
+  for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
 
   for (int b = n_batches - 1; b >= 0; --b) {
     const int batch = start + b * NT;
@@ -345,11 +348,14 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         const int j = 64 * i + bit;
         const int idx_j = batch + j;
         const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
-        // wave-uniform skip: no pixel of this wavefront reaches this entry
-        bool reach = false;
+        if (NW > 1) {
+          // wave-uniform skip: no pixel of THIS wavefront reaches the entry (with one wavefront per
+          // tile every staged entry is <= bin_final = max(last), i.e. always reached by some pixel)
+          bool reach = false;
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
-        if (!__any(reach)) continue;
+          for (int k = 0; k < PPT; ++k) reach = reach || (idx_j <= last[k]);
+          if (!__any(reach)) continue;
+        }
 
         Splat s;
         float f[C];
@@ -361,9 +367,9 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         // The 16 accumulators are zeroed by 16 separate asm moves: a plain `g[q] = 0` loop becomes a
         // memset, SROA then promotes g to ONE <16 x float> value (a 512-bit register tuple) and
         // every conditional update turns into whole-tuple copies (8 v_mov_b64 per slot per path).
-        float g[16];
-#pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
+        // They are zeroed once per tile and again after each reduction that consumed them: an
+        // entry to which no lane contributes leaves them untouched (all updates sit behind the
+        // uniform any-valid branches).
         bool contributed = false;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -408,6 +414,8 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
           __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#pragma unroll
+        for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
       }
     }
   }
