@@ -25,10 +25,16 @@ __global__ void __launch_bounds__(64) debug_reduce16_kernel(const float* __restr
   // every lane of a quad must agree
   out[16 + threadIdx.x] = r;
   out[80 + threadIdx.x] = fg::wave_sum(in[threadIdx.x * 16]);
+  // 12-value variant on the first 12 columns
+  float w[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) w[i] = in[threadIdx.x * 16 + i];
+  const float r12 = fg::wave_reduce12_transposed(w);
+  if (fg::wave_reduce12_owner(threadIdx.x)) out[144 + fg::wave_reduce12_index(threadIdx.x)] = r12;
 }
 }  // namespace
 
-// Test hook (not part of the drop-in surface): in[64*16] floats, out[144] floats.
+// Test hook (not part of the drop-in surface): in[64*16] floats, out[156] floats.
 extern "C" int fg_debug_wave_reduce16(const float* in, float* out, fg_stream_t stream) {
   if (!in || !out) return FG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(debug_reduce16_kernel, dim3(1), dim3(64), 0, fg_hip_stream(stream), in, out);

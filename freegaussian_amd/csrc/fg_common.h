@@ -114,4 +114,32 @@ __device__ __forceinline__ float wave_reduce16_transposed(float (&v)[16]) {
   return r;
 }
 
+// 12-value variant (enough for <= 4 composited channels): 29 VALU ops.  After the call the lanes
+// with (lane & 3) == 0 and not (bit2 && bit3) hold the 64-lane sum of value index
+//   6*bit5 + 3*bit4 + (bit2 ? 2 : bit3)          (wave_reduce12_index(lane)).
+__device__ __forceinline__ float wave_reduce12_transposed(float (&v)[16]) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int j = 0; j < 6; ++j) v[j] = swap32_add(v[j], v[j + 6]);  // bit5 selects j / j+6
+#pragma unroll
+  for (int j = 0; j < 3; ++j) v[j] = swap16_add(v[j], v[j + 3]);  // bit4 selects j / j+3
+  const bool b3 = (lane & 8) != 0, b2 = (lane & 4) != 0;
+  // bit3 selects v0 / v1; v2 is summed over the xor-8 partner as it is
+  const float keep3 = b3 ? v[1] : v[0], send3 = b3 ? v[0] : v[1];
+  const float A = keep3 + dpp_mov<FG_DPP_ROW_ROR8>(send3);
+  const float B = v[2] + dpp_mov<FG_DPP_ROW_ROR8>(v[2]);
+  // bit2 selects A / B
+  const float keep2 = b2 ? B : A, send2 = b2 ? A : B;
+  float got = dpp_mov_keep<FG_DPP_ROW_SHL4, 0xf, 0x5>(0.f, send2);
+  got = dpp_mov_keep<FG_DPP_ROW_SHR4, 0xf, 0xA>(got, send2);
+  float r = keep2 + got;
+  r += dpp_mov<FG_DPP_QUAD_XOR1>(r);
+  r += dpp_mov<FG_DPP_QUAD_XOR2>(r);
+  return r;
+}
+__device__ __forceinline__ int wave_reduce12_index(int lane) {
+  return 6 * (lane >> 5) + 3 * ((lane >> 4) & 1) + ((lane & 4) ? 2 : ((lane >> 3) & 1));
+}
+__device__ __forceinline__ bool wave_reduce12_owner(int lane) { return (lane & 3) == 0 && (lane & 12) != 12; }
+
 }  // namespace fg

@@ -86,6 +86,24 @@ struct Splat {
   float x, y, o, a, b, c;
 };
 
+// exp(-sigma) = exp2(e2) with  e2 = -log2(e) * sigma,  sigma = 0.5 (a dx^2 + c dy^2) + b dx dy,
+// arranged per splat as e2 = (hc dy + bdx) dy + hadx2 (Horner in dy, constants folded): two FMAs per
+// pixel slot.  Forward and backward share it, so they take identical skip decisions.
+struct SigmaTerms {
+  float hc, bdx, hadx2;
+};
+__device__ __forceinline__ SigmaTerms sigma_terms(const Splat& s, float dx) {
+  constexpr float NL = -1.4426950408889634f;  // -log2(e)
+  SigmaTerms t;
+  t.hc = (0.5f * NL) * s.c;
+  t.bdx = (NL * s.b) * dx;
+  t.hadx2 = ((0.5f * NL) * s.a) * dx * dx;
+  return t;
+}
+__device__ __forceinline__ float neg_sigma_log2e(const SigmaTerms& t, float dy) {
+  return fmaf(fmaf(t.hc, dy, t.bdx), dy, t.hadx2);
+}
+
 template <int C>
 __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (&f)[C]) {
   const float4 v0 = rec[0];
@@ -219,6 +237,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       float f[C];
       read_record<C>(lds[j], s, f);
       const float dx = s.x - px;
+      const SigmaTerms st = sigma_terms(s, dx);
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         // PPT == 4: skip the strips the splat cannot reach; with 1-2 slots per lane the test
@@ -227,9 +246,9 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         // one wave-uniform branch, then select-predicated straight-line code (no nested
         // divergent ifs: each costs exec save/restore and merge copies)
         const float dy = s.y - py[k];
-        const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
-        const float alpha = fminf(FG_ALPHA_MAX, s.o * __expf(-sigma));
-        const bool valid = !done[k] && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+        const float e2 = neg_sigma_log2e(st, dy);
+        const float alpha = fminf(FG_ALPHA_MAX, s.o * __builtin_amdgcn_exp2f(e2));
+        const bool valid = !done[k] && !(e2 > 0.f || alpha < FG_ALPHA_SKIP);
         if (!__any(valid)) continue;
         const float next_T = T[k] * (1.f - alpha);
         const bool stop = valid && (next_T <= FG_T_STOP);
@@ -361,6 +380,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         float f[C];
         read_record<C>(lds[j], s, f);
         const float dx = s.x - px;
+        const SigmaTerms st = sigma_terms(s, dx);
         // Per pixel slot: one wave-uniform branch ("does any lane contribute?"), then straight-line
         // select-predicated arithmetic.  Nested divergent ifs made the compiler re-materialise
         // the 11 accumulators at every merge point (~30 v_mov per slot in the ISA).
@@ -375,11 +395,11 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         for (int k = 0; k < PPT; ++k) {
           if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
           const float dy = s.y - py[k];
-          const float sigma = 0.5f * (s.a * dx * dx + s.c * dy * dy) + s.b * dx * dy;
-          const float vis = __expf(-sigma);
+          const float e2 = neg_sigma_log2e(st, dy);
+          const float vis = __builtin_amdgcn_exp2f(e2);
           const float ov = s.o * vis;
           const float alpha = fminf(FG_ALPHA_MAX, ov);
-          const bool valid = (idx_j <= last[k]) && !(sigma < 0.f || alpha < FG_ALPHA_SKIP);
+          const bool valid = (idx_j <= last[k]) && !(e2 > 0.f || alpha < FG_ALPHA_SKIP);
           if (!__any(valid)) continue;  // wave-uniform
           contributed = true;
           const float a_eff = valid ? alpha : 0.f;
@@ -409,10 +429,18 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           g[2] += open ? vis * v_alpha : 0.f;
         }
         if (!__any(contributed)) continue;
-        const float total = fg::wave_reduce16_transposed(g);
-        if ((lane & 3) == 0) {
-          float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
-          __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (C <= 4) {  // only record slots 0..11 are in use: the cheaper 12-value butterfly
+          const float total = fg::wave_reduce12_transposed(g);
+          if (fg::wave_reduce12_owner(lane)) {
+            float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + fg::wave_reduce12_index(lane);
+            __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else {
+          const float total = fg::wave_reduce16_transposed(g);
+          if ((lane & 3) == 0) {
+            float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
+            __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
         }
 #pragma unroll
         for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
