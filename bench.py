@@ -68,6 +68,34 @@ def algorithmic_bytes(N, V, I, P, T, k, p):
     }
 
 
+# stage (C-ABI entry point) -> the single kernel it launches, for the PMC traffic lookup
+STAGE_KERNEL = {
+    "fg_raster_bwd": "raster_bwd_kernel",
+    "fg_raster_fwd": "raster_fwd_kernel",
+    "fg_preprocess_fwd": "preprocess_fwd_kernel",
+    "fg_preprocess_bwd": "preprocess_bwd_kernel",
+}
+
+
+def pmc_traffic(stage, workload_key):
+    """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes of this same
+    command (profiles/r01_pmc_traffic.json, produced by scripts/gpu_pmc.sh: separate FETCH_SIZE and
+    WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).  PMC collection cannot run inside
+    the timed process, so this is a recorded figure; None when the file is absent or was recorded
+    for another workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    kern = STAGE_KERNEL.get(stage)
+    if kern is None or not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("workload_key") != workload_key:
+        return None
+    for name, v in rec["kernels"].items():
+        if name.startswith(kern):
+            return v["hbm_bytes_per_launch"]
+    return None
+
+
 def cpu_baseline(scene, view, crop, sh_degree):
     """The CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is the absent
     CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd."""
@@ -180,7 +208,7 @@ def main():
         "achieved": alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "traffic": None,
+        "traffic": pmc_traffic(dom, f"{N}x{W}x{H}xsh{args.sh_degree}"),
         "algorithmic_bytes": alg.get(dom, 0),
         "avg_ms": stages[dom],
     }

@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
 nproc > $out/host.txt; grep -m1 "model name" /proc/cpuinfo >> $out/host.txt; free -g | head -2 >> $out/host.txt
-timeout 900 python -m pytest tests -m gpu -q --timeout 180 2>&1 | tail -40 > $out/pytest.log
+timeout 900 python -m pytest tests -m gpu -q --timeout 300 --durations=8 2>&1 | tail -40 > $out/pytest.log
 timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 > $out/smoke.log
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "rc=$?" >> $out/bench.err
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o stats -- python3 bench.py --steps 10 --warmup 3 --no-cpu-baseline > $out/prof_bench.json 2> $out/prof.err

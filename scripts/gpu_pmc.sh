@@ -24,6 +24,16 @@ for f in glob.glob(out+"/*/*counter_collection.csv")+glob.glob(out+"/*/*/*counte
         k=r["Kernel_Name"].replace("(anonymous namespace)::","").split("(")[0][:40]
         if "at::native" in k or "rocclr" in k: continue
         agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+import json
+traffic={}
+for k,c in agg.items():
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        f=sum(c["FETCH_SIZE"])/len(c["FETCH_SIZE"]); w=sum(c["WRITE_SIZE"])/len(c["WRITE_SIZE"])
+        # MI355X_MICROARCH.md "HBM": counters are in KiB; on gfx950 FETCH_SIZE tallies 128-B read
+        # requests at 64 B -> double it; WRITE_SIZE is exact for streaming stores and float atomics
+        traffic[k.replace("void ","")]={"FETCH_SIZE_KiB":f,"WRITE_SIZE_KiB":w,"hbm_bytes_per_launch":(2*f+w)*1024}
+json.dump({"workload_key":"1000000x1920x1080xsh3","source":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+           "correction":"bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024","kernels":traffic}, open(out+"/pmc_traffic.json","w"), indent=1)
 with open(out+"/pmc_summary.txt","w") as fo:
     for k in sorted(agg):
         line=k+": "+", ".join(f"{c}={sum(v)/len(v):.4g}" for c,v in sorted(agg[k].items()))

@@ -10,6 +10,12 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+    # The CPU oracle is thousands of small tensor ops; on a many-core host (the GPU box has 256)
+    # torch's default thread count makes every one of them a 256-way fork/join and the oracle
+    # several times slower.  Cap it.
+    import torch
+
+    torch.set_num_threads(min(os.cpu_count() or 1, 16))
 
 
 @pytest.fixture(scope="session", autouse=True)
