@@ -89,6 +89,23 @@ struct Splat {
 // exp(-sigma) = exp2(e2) with  e2 = -log2(e) * sigma,  sigma = 0.5 (a dx^2 + c dy^2) + b dx dy,
 // arranged per splat as e2 = (hc dy + bdx) dy + hadx2 (Horner in dy, constants folded): two FMAs per
 // pixel slot.  Forward and backward share it, so they take identical skip decisions.
+// Lane masks straight from one vector compare (v_cmp writing an SGPR pair), and selects that take
+// such a mask: predicates stay in scalar registers and are combined by the scalar unit.
+// Predicate codes are LLVM's FCmpInst values: OGE 3, OLE 5, ULE 13.
+__device__ __forceinline__ uint64_t lanes_oge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3); }
+__device__ __forceinline__ uint64_t lanes_ole(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }
+__device__ __forceinline__ uint64_t lanes_ule(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 13); }
+__device__ __forceinline__ float lane_select(uint64_t m, float if_set, float if_clear) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+__device__ __forceinline__ int lane_select(uint64_t m, int if_set, int if_clear) {
+  int r;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
+  return r;
+}
+
 struct SigmaTerms {
   float hc, bdx, hadx2;
 };
@@ -180,27 +197,32 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
   const unsigned my_strips = wave_strips<PPT>(wave);
 
+  // Per-slot pixel state.  The "finished" flags live as 64-bit lane masks in scalar registers and
+  // every predicate below is built from vector-compare results with scalar logic: as bool
+  // variables the compiler kept them as 0/1 VGPRs and paid 5-6 vector instructions per slot to
+  // convert back and forth (ISA of the bool version: v_and/v_cmp_eq/v_cndmask per flag per slot).
   float T[PPT], acc[PPT][C];
   int last[PPT];
-  bool done[PPT];
+  uint64_t done[PPT];
   float py[PPT];
+  const uint64_t full = __ballot(true);
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
     py[k] = (float)iy + 0.5f;
     T[k] = 1.f;
     last[k] = start - 1;
-    done[k] = !(ix < width && iy < height);
+    done[k] = __ballot(!(ix < width && iy < height));
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
   }
 
   for (int batch = start; batch < end; batch += NT) {
-    bool all_done = true;
+    uint64_t all_done = full;
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+    for (int k = 0; k < PPT; ++k) all_done &= done[k];
     // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
-    if (__syncthreads_and(all_done)) break;
+    if (__syncthreads_and(all_done == full)) break;
     const int idx = batch + (int)threadIdx.x;
     unsigned mask = 0;
     if (idx < end) {
@@ -230,8 +252,11 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     }
     __builtin_amdgcn_wave_barrier();  // the list is private to this wavefront
     for (int n = 0; n < cnt; ++n) {
-      if (__all(all_done)) break;  // this wavefront has nothing left to do
-      const unsigned packed = lds_list[wave][n];
+      if (all_done == full) break;  // this wavefront has nothing left to do
+      // the entry is wave-uniform: move it to a scalar register so that the record address and
+      // the list index are scalar arithmetic (as a vector value the compiler spent a quarter-rate
+      // v_mul_lo_u32 per entry on the address)
+      const unsigned packed = __builtin_amdgcn_readfirstlane((unsigned)lds_list[wave][n]);
       const int j = packed & 255u;
       Splat s;
       float f[C];
@@ -248,21 +273,22 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         const float dy = s.y - py[k];
         const float e2 = neg_sigma_log2e(st, dy);
         const float alpha = fminf(FG_ALPHA_MAX, s.o * __builtin_amdgcn_exp2f(e2));
-        const bool valid = !done[k] && !(e2 > 0.f || alpha < FG_ALPHA_SKIP);
-        if (!__any(valid)) continue;
+        // valid = !done && !(sigma < 0 || alpha < 1/255)
+        const uint64_t valid = lanes_ule(e2, 0.f) & lanes_oge(alpha, FG_ALPHA_SKIP) & ~done[k];
+        if (valid == 0ull) continue;
         const float next_T = T[k] * (1.f - alpha);
-        const bool stop = valid && (next_T <= FG_T_STOP);
-        const bool take = valid && !stop;
-        const float vis = take ? alpha * T[k] : 0.f;
+        const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
+        const uint64_t take = valid & ~stop;
+        const float vis = lane_select(take, alpha * T[k], 0.f);
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
-        last[k] = take ? batch + j : last[k];
-        T[k] = take ? next_T : T[k];
-        done[k] = done[k] || stop;
+        last[k] = lane_select(take, batch + j, last[k]);
+        T[k] = lane_select(take, next_T, T[k]);
+        done[k] |= stop;
       }
-      all_done = true;
+      all_done = full;
 #pragma unroll
-      for (int k = 0; k < PPT; ++k) all_done = all_done && done[k];
+      for (int k = 0; k < PPT; ++k) all_done &= done[k];
     }
   }
 
