@@ -5,6 +5,6 @@ package is the thin Python host that mirrors the reference's operator interface:
 
     from freegaussian_amd import rasterization, quat_to_rotmat, num_sh_bases
 """
-from .rasterization import num_sh_bases, quat_to_rotmat, rasterization  # noqa: F401
+from .rasterization import num_sh_bases, quat_to_rotmat, rasterization, rasterize_gauss_params  # noqa: F401
 
-__all__ = ["rasterization", "quat_to_rotmat", "num_sh_bases"]
+__all__ = ["rasterization", "rasterize_gauss_params", "quat_to_rotmat", "num_sh_bases"]

@@ -39,11 +39,18 @@ SIGNATURES = {
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
     "fg_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
+    "fg_raster_composite_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P]),
+    "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
                                   c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                   c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P]),
+    "fg_preprocess_raw_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P, P, c_int,
+                                      c_int, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P,
+                                      P]),
+    "fg_preprocess_raw_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
+                                      c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
@@ -70,7 +77,8 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "or `make -C freegaussian_amd/csrc`.  There is no CPU fallback."
         )
-    lib = ctypes.CDLL(LIB_PATH)
+    # FG_RASTER_LIB: load another build of the same library (the instrumented `make stats` one)
+    lib = ctypes.CDLL(os.environ.get("FG_RASTER_LIB", LIB_PATH))
     for name, (res, args) in {**SIGNATURES, **_EXTRA}.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is absent
         fn.restype = res

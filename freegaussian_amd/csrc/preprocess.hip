@@ -31,6 +31,115 @@ struct FeatLayout {
   int n_extra;    // extra per-Gaussian channels [N,n_extra]
 };
 
+// Raw parameter forms of the reference's gauss_params (freegaussian_model.py:187-196) and the
+// activations its get_outputs applies before the raster call (:801, :844-851), folded into this
+// pass:  quats -> q/|q| (+ d_quats),  scales = log-scales -> exp(.)
+// (+ d_scales),  opacities = logits -> sigmoid(.),  colours split into features_dc [N,3] (passed as
+// `colors`) and features_rest [N,k_stored-1,3].
+struct RawForm {
+  int enabled;
+  const float* d_quats;        // [N,4] nullable
+  const float* d_scales;       // [N,3] nullable
+  const float* features_rest;  // [N,k_stored-1,3]
+};
+
+struct Activated {
+  float q[4], s[3], o;
+  float qn[4], inv_norm;  // normalised raw quaternion and 1/|q| (raw form only)
+  float es[3];            // exp(log-scale) (raw form only)
+};
+
+__device__ __forceinline__ Activated load_activated(const RawForm& raw, int i, const float* __restrict__ quats,
+                                                    const float* __restrict__ scales,
+                                                    const float* __restrict__ opacities) {
+  Activated a;
+  const float4 q = reinterpret_cast<const float4*>(quats)[i];
+  const float s0 = scales[3 * i], s1 = scales[3 * i + 1], s2 = scales[3 * i + 2];
+  const float o = opacities[i];
+  if (!raw.enabled) {
+    a.q[0] = q.x; a.q[1] = q.y; a.q[2] = q.z; a.q[3] = q.w;
+    a.s[0] = s0; a.s[1] = s1; a.s[2] = s2;
+    a.o = o;
+    a.inv_norm = 1.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) a.qn[c] = a.q[c];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) a.es[c] = a.s[c];
+    return a;
+  }
+  a.inv_norm = 1.f / sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  a.qn[0] = q.x * a.inv_norm; a.qn[1] = q.y * a.inv_norm; a.qn[2] = q.z * a.inv_norm; a.qn[3] = q.w * a.inv_norm;
+  a.es[0] = expf(s0); a.es[1] = expf(s1); a.es[2] = expf(s2);
+#pragma unroll
+  for (int c = 0; c < 4; ++c) a.q[c] = a.qn[c] + (raw.d_quats ? raw.d_quats[4 * i + c] : 0.f);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) a.s[c] = a.es[c] + (raw.d_scales ? raw.d_scales[3 * i + c] : 0.f);
+  a.o = 1.f / (1.f + expf(-o));
+  return a;
+}
+
+// Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows at column
+// lds_col0, keeping the first use_floats columns of each row.  16-byte loads whenever the slab is
+// a whole number of float4 (any row length: the (row, column) of the four elements is stepped).
+__device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_stride, int lds_col0,
+                                               const float* __restrict__ src, int nrows, int row_floats,
+                                               int use_floats) {
+  const int total = nrows * row_floats;
+  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    for (int q = threadIdx.x; q < total / 4; q += BLOCK) {
+      const float4 v = src4[q];
+      const float vv[4] = {v.x, v.y, v.z, v.w};
+      int r = (4 * q) / row_floats, c = 4 * q - r * row_floats;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c < use_floats) lds[r * lds_stride + lds_col0 + c] = vv[j];
+        if (++c == row_floats) { c = 0; ++r; }
+      }
+    }
+  } else {
+    const int tot = nrows * use_floats;
+    for (int e = threadIdx.x; e < tot; e += BLOCK) {
+      const int r = e / use_floats, c = e - r * use_floats;
+      lds[r * lds_stride + lds_col0 + c] = src[(size_t)r * row_floats + c];
+    }
+  }
+}
+
+// The inverse: padded LDS rows (from column lds_col0) out to a contiguous [nrows x row_floats]
+// slab; columns >= lds_cols are written as zero.
+__device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_stride,
+                                               int lds_col0, int nrows, int row_floats, int lds_cols) {
+  const int total = nrows * row_floats;
+  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    for (int q = threadIdx.x; q < total / 4; q += BLOCK) {
+      int r = (4 * q) / row_floats, c = 4 * q - r * row_floats;
+      float vv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        vv[j] = (c < lds_cols) ? lds[r * lds_stride + lds_col0 + c] : 0.f;
+        if (++c == row_floats) { c = 0; ++r; }
+      }
+      dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    }
+  } else {
+    for (int e = threadIdx.x; e < total; e += BLOCK) {
+      const int r = e / row_floats, c = e - r * row_floats;
+      dst[e] = (c < lds_cols) ? lds[r * lds_stride + lds_col0 + c] : 0.f;
+    }
+  }
+}
+
+// raw form: SH coefficient rows of a workgroup, split in two arrays -> LDS rows [dc | rest]
+__device__ __forceinline__ void coeffs_to_lds(float* lds, const RawForm& raw, const float* __restrict__ colors,
+                                              int row0, int nrows, int k_stored, int kk) {
+  slab_to_lds_at(lds, ROW, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc
+  if (kk > 1)
+    slab_to_lds_at(lds, ROW, 3, raw.features_rest + (size_t)row0 * 3 * (k_stored - 1), nrows, 3 * (k_stored - 1),
+                   3 * (kk - 1));
+}
+
 // coalesced copy of a workgroup's contiguous [nrows x row_floats] slab into padded LDS rows
 __device__ __forceinline__ void slab_to_lds(float* lds, int lds_stride, const float* __restrict__ src, int nrows,
                                             int row_floats, int use_floats) {
@@ -74,7 +183,7 @@ __device__ __forceinline__ void lds_to_slab(float* __restrict__ dst, const float
 }
 
 __global__ void __launch_bounds__(BLOCK)
-preprocess_fwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, const float* __restrict__ quats,
+preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
                       const float* __restrict__ colors, const float* __restrict__ extra,
                       const float* __restrict__ viewmat, const float* __restrict__ K, int width, int height,
@@ -87,18 +196,22 @@ preprocess_fwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
-  if (kk > 0) slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+  if (kk > 0) {
+    if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
+    else slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+  }
 
   // ---- K1 -------------------------------------------------------------------------------------
   bool ok = false;
   Fwd f;
-  float mx = 0.f, my = 0.f, mz = 0.f;
+  float mx = 0.f, my = 0.f, mz = 0.f, opac = 0.f;
   if (i < N) {
     const Cam cam = load_cam(viewmat, K);
     mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
-    const float4 q = reinterpret_cast<const float4*>(quats)[i];
-    f = project_core(cam, mx, my, mz, q.x, q.y, q.z, q.w, scales[3 * i], scales[3 * i + 1], scales[3 * i + 2],
-                     width, height, eps2d);
+    const Activated a = load_activated(raw, i, quats, scales, opacities);
+    opac = a.o;
+    f = project_core(cam, mx, my, mz, a.q[0], a.q[1], a.q[2], a.q[3], a.s[0], a.s[1], a.s[2], width, height,
+                     eps2d);
     ok = (f.pz >= near_plane) && (f.pz <= far_plane) && (f.det > 0.0f);
     ok = ok && isfinite(f.radius_f) && (f.radius_f > radius_clip);
     const float fw = (float)width, fh = (float)height;
@@ -120,7 +233,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
     touched = (x1 - x0) * (y1 - y0);
     o_comp = f.comp;
     rec[0] = f.m2x; rec[1] = f.m2y;
-    rec[2] = antialiased ? opacities[i] * f.comp : opacities[i];
+    rec[2] = antialiased ? opac * f.comp : opac;
     rec[3] = f.conic_a; rec[4] = f.conic_b; rec[5] = f.conic_c;
   }
   if (i < N) {
@@ -184,7 +297,9 @@ preprocess_fwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
 }
 
 __global__ void __launch_bounds__(BLOCK)
-preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, const float* __restrict__ quats,
+preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d_quats,
+                      float* __restrict__ v_d_scales, float* __restrict__ v_features_rest,
+                      const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
                       const float* __restrict__ colors, const float* __restrict__ viewmat,
                       const float* __restrict__ K, int width, int height, float eps2d, int antialiased,
@@ -200,7 +315,10 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
   slab_to_lds(lds_rec, RSTRIDE, v_splats + (size_t)row0 * REC, nrows, REC, REC);
-  if (kk > 1) slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+  if (kk > 1) {
+    if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
+    else slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+  }
   __syncthreads();
 
   float g_m[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f}, g_s[3] = {0.f, 0.f, 0.f};
@@ -213,15 +331,17 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
 #pragma unroll
   for (int c = 0; c < REC; ++c) rec[c] = 0.f;
   const bool active = (i < N) && radii[i] > 0;
+  Activated a;
   if (active) {
     const float* row = lds_rec + threadIdx.x * RSTRIDE;
 #pragma unroll
     for (int c = 0; c < REC; ++c) rec[c] = row[c];
     const Cam cam = load_cam(viewmat, K);
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-    const float4 q = reinterpret_cast<const float4*>(quats)[i];
-    const float s[3] = {scales[3 * i], scales[3 * i + 1], scales[3 * i + 2]};
-    const Fwd f = project_core(cam, mx, my, mz, q.x, q.y, q.z, q.w, s[0], s[1], s[2], width, height, eps2d);
+    a = load_activated(raw, i, quats, scales, opacities);
+    const float s[3] = {a.s[0], a.s[1], a.s[2]};
+    const Fwd f = project_core(cam, mx, my, mz, a.q[0], a.q[1], a.q[2], a.q[3], s[0], s[1], s[2], width, height,
+                               eps2d);
 
     // feature gradients: [colour | depth | extra] start at record slot 8
     const int ncol = kk > 0 ? 3 : fl.n_color;
@@ -248,7 +368,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
             cr += basis[k] * crow[3 * k]; cg += basis[k] * crow[3 * k + 1]; cb += basis[k] * crow[3 * k + 2];
           }
       } else {
-        const float* c0p = colors + (size_t)i * 3 * fl.k_stored;
+        const float* c0p = colors + (size_t)i * 3 * (raw.enabled ? 1 : fl.k_stored);
         cr = basis[0] * c0p[0]; cg = basis[0] * c0p[1]; cb = basis[0] * c0p[2];
       }
       vr = (cr + 0.5f > 0.f) ? rec[8] : 0.f;
@@ -274,7 +394,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
     float vcomp = 0.f;
     if (antialiased) {
       g_o = rec[2] * f.comp;
-      vcomp = rec[2] * opacities[i];
+      vcomp = rec[2] * a.o;
     } else {
       g_o = rec[2];
     }
@@ -285,6 +405,20 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
     project_backward(cam, f, s, eps2d, v_means2d[(size_t)m2_stride * i], v_means2d[(size_t)m2_stride * i + 1],
                      v_depth, vca, vcb, vcc,
                      antialiased != 0, vcomp, g_m, g_q, g_s);
+    if (raw.enabled) {
+      // chain rule through the activations; the deltas receive the activated-value gradients as is
+      if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
+      if (v_d_scales) { v_d_scales[3 * i] = g_s[0]; v_d_scales[3 * i + 1] = g_s[1]; v_d_scales[3 * i + 2] = g_s[2]; }
+      const float dp = g_q[0] * a.qn[0] + g_q[1] * a.qn[1] + g_q[2] * a.qn[2] + g_q[3] * a.qn[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_q[c] = (g_q[c] - dp * a.qn[c]) * a.inv_norm;  // through q/|q|
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g_s[c] *= a.es[c];                              // through exp
+      g_o *= a.o * (1.f - a.o);                                                   // through sigmoid
+    }
+  } else if (raw.enabled && i < N) {
+    if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v_d_scales) { v_d_scales[3 * i] = 0.f; v_d_scales[3 * i + 1] = 0.f; v_d_scales[3 * i + 2] = 0.f; }
   }
   if (i < N) {
     v_means[3 * i] = g_m[0]; v_means[3 * i + 1] = g_m[1]; v_means[3 * i + 2] = g_m[2];
@@ -315,7 +449,14 @@ preprocess_bwd_kernel(int N, FeatLayout fl, const float* __restrict__ means, con
       row[3 * k] = bk * vr; row[3 * k + 1] = bk * vg; row[3 * k + 2] = bk * vb;
     }
     __syncthreads();
-    lds_to_slab(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, ROW, nrows, 3 * fl.k_stored, 48);
+    if (raw.enabled) {
+      lds_to_slab_at(v_colors + (size_t)row0 * 3, lds, ROW, 0, nrows, 3, 3);  // v_features_dc
+      if (fl.k_stored > 1)
+        lds_to_slab_at(v_features_rest + (size_t)row0 * 3 * (fl.k_stored - 1), lds, ROW, 3, nrows,
+                       3 * (fl.k_stored - 1), 45);
+    } else {
+      lds_to_slab(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, ROW, nrows, 3 * fl.k_stored, 48);
+    }
   }
 }
 
@@ -329,6 +470,62 @@ bool layout_ok(const FeatLayout& fl) {
 
 }  // namespace
 
+namespace {
+
+int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* quats, const float* scales,
+                          const float* opacities, const float* colors, int sh_degree, int k_stored, int n_color,
+                          int with_depth, const float* extra, int n_extra, const float* viewmat, const float* K,
+                          int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
+                          int tile_size, int antialiased, int32_t* radii, float* means2d, float* depths,
+                          float* conics, float* compensations, int32_t* tiles_touched, float* splats,
+                          fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !means2d || !depths || !conics ||
+      !tiles_touched || !splats)
+    return FG_ERR_INVALID_ARG;
+  if ((fl.n_color > 0 && !colors) || (n_extra > 0 && !extra)) return FG_ERR_INVALID_ARG;
+  if (raw.enabled && (sh_degree < 0 || (k_stored > 1 && !raw.features_rest))) return FG_ERR_INVALID_ARG;
+  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
+  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     fl, raw, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
+                     near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
+                     depths, conics, compensations, tiles_touched, splats);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scales, float* v_features_rest,
+                          const float* means, const float* quats, const float* scales, const float* opacities,
+                          const float* colors, int sh_degree, int k_stored, int n_color, int with_depth, int n_extra,
+                          const float* viewmat, const float* K, int width, int height, float eps2d, int antialiased,
+                          const int32_t* radii, const float* v_splats, const float* v_means2d, int v_means2d_stride,
+                          const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
+                          float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
+                          fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl) || v_means2d_stride < 2) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d ||
+      !v_means || !v_quats || !v_scales || !v_opacities)
+    return FG_ERR_INVALID_ARG;
+  if ((fl.n_color > 0 && (!colors || !v_colors)) || (n_extra > 0 && !v_extra)) return FG_ERR_INVALID_ARG;
+  if (raw.enabled) {
+    if (sh_degree < 0 || (k_stored > 1 && (!raw.features_rest || !v_features_rest))) return FG_ERR_INVALID_ARG;
+    if ((raw.d_quats != nullptr) != (v_d_quats != nullptr) || (raw.d_scales != nullptr) != (v_d_scales != nullptr))
+      return FG_ERR_INVALID_ARG;
+  }
+  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+                     fl, raw, v_d_quats, v_d_scales, v_features_rest, means, quats, scales, opacities, colors,
+                     viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
+                     v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+}  // namespace
+
 extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, const float* scales,
                                  const float* opacities, const float* colors, int sh_degree, int k_stored,
                                  int n_color, int with_depth, const float* extra, int n_extra,
@@ -337,20 +534,10 @@ extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, 
                                  int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                                  float* compensations, int32_t* tiles_touched, float* splats,
                                  fg_stream_t stream) {
-  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
-  if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
-  if (N == 0) return FG_OK;
-  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !means2d || !depths || !conics ||
-      !tiles_touched || !splats)
-    return FG_ERR_INVALID_ARG;
-  if ((fl.n_color > 0 && !colors) || (n_extra > 0 && !extra)) return FG_ERR_INVALID_ARG;
-  const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
-                     fl, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
-                     near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
-                     depths, conics, compensations, tiles_touched, splats);
-  FG_RETURN_IF_LAUNCH_FAILED();
-  return FG_OK;
+  return launch_preprocess_fwd(N, RawForm{0, nullptr, nullptr, nullptr}, means, quats, scales, opacities, colors,
+                               sh_degree, k_stored, n_color, with_depth, extra, n_extra, viewmat, K, width, height,
+                               eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased, radii, means2d,
+                               depths, conics, compensations, tiles_touched, splats, stream);
 }
 
 extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
@@ -361,18 +548,43 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
                                  const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                                  float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
                                  fg_stream_t stream) {
-  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
-  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl) || v_means2d_stride < 2) return FG_ERR_INVALID_ARG;
-  if (N == 0) return FG_OK;
-  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d ||
-      !v_means || !v_quats || !v_scales || !v_opacities)
-    return FG_ERR_INVALID_ARG;
-  if ((fl.n_color > 0 && (!colors || !v_colors)) || (n_extra > 0 && !v_extra)) return FG_ERR_INVALID_ARG;
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
-                     fl, means, quats, scales, opacities, colors, viewmat, K, width, height, eps2d, antialiased,
-                     radii, v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats, v_scales,
-                     v_opacities,
-                     v_colors, v_extra);
-  FG_RETURN_IF_LAUNCH_FAILED();
-  return FG_OK;
+  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, means, quats,
+                               scales, opacities, colors, sh_degree, k_stored, n_color, with_depth, n_extra, viewmat,
+                               K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
+                               v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
+                               stream);
+}
+
+extern "C" int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const float* d_quats,
+                                     const float* log_scales, const float* d_scales,
+                                     const float* opacity_logits, const float* features_dc,
+                                     const float* features_rest, int sh_degree, int k_stored, int with_depth,
+                                     const float* extra, int n_extra, const float* viewmat, const float* K,
+                                     int width, int height, float eps2d, float near_plane, float far_plane,
+                                     float radius_clip, int tile_size, int antialiased, int32_t* radii,
+                                     float* means2d, float* depths, float* conics, float* compensations,
+                                     int32_t* tiles_touched, float* splats, fg_stream_t stream) {
+  return launch_preprocess_fwd(N, RawForm{1, d_quats, d_scales, features_rest}, means, quats, log_scales,
+                               opacity_logits, features_dc, sh_degree, k_stored, 3, with_depth, extra, n_extra,
+                               viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
+                               antialiased, radii, means2d, depths, conics, compensations, tiles_touched, splats,
+                               stream);
+}
+
+extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
+                                     const float* log_scales, const float* d_scales,
+                                     const float* opacity_logits, const float* features_dc,
+                                     const float* features_rest, int sh_degree, int k_stored, int with_depth,
+                                     int n_extra, const float* viewmat, const float* K, int width, int height,
+                                     float eps2d, int antialiased, const int32_t* radii, const float* v_splats,
+                                     const float* v_means2d, int v_means2d_stride, const float* v_depths,
+                                     const float* v_conics, float* v_means, float* v_quats, float* v_d_quats,
+                                     float* v_log_scales, float* v_d_scales, float* v_opacity_logits,
+                                     float* v_features_dc, float* v_features_rest, float* v_extra,
+                                     fg_stream_t stream) {
+  return launch_preprocess_bwd(N, RawForm{1, d_quats, d_scales, features_rest}, v_d_quats, v_d_scales,
+                               v_features_rest, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
+                               k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
+                               v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats,
+                               v_log_scales, v_opacity_logits, v_features_dc, v_extra, stream);
 }

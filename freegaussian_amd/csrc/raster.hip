@@ -106,6 +106,25 @@ __device__ __forceinline__ int lane_select(uint64_t m, int if_set, int if_clear)
   return r;
 }
 
+// Optional post-composite folded into the raster kernels (reference O1, freegaussian_model.py:875-877):
+//   out[c] = render[c] + (1 - alpha) * background[c],  the first n_clamp channels clamped to [0,1].
+// clamp_mask[H,W] keeps, per pixel, bit c = "channel c was strictly outside [0,1]" (torch.clamp
+// passes the gradient at the bounds themselves), written by the forward and read by the backward.
+struct Composite {
+  const float* background;  // [C] or nullptr
+  int n_clamp;
+  uint8_t* clamp_mask;      // [H,W] when n_clamp > 0
+};
+
+// Optional work counters (make stats -> libfgraster_stats.so; never in the product library).
+#ifdef FG_RASTER_STATS
+__device__ unsigned long long fg_raster_stats[16];
+#define FG_STAT(i, n) do { const unsigned long long n_ = (unsigned long long)(n); \
+    if (fg::lane_id() == 0) atomicAdd(&fg_raster_stats[i], n_); } while (0)
+#else
+#define FG_STAT(i, n) do { } while (0)
+#endif
+
 struct SigmaTerms {
   float hc, bdx, hadx2;
 };
@@ -177,7 +196,8 @@ template <int C, int PPT>
 __global__ void __launch_bounds__(256 / PPT)
 raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids) {
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                  Composite comp) {
   constexpr int NT = 256 / PPT;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -256,6 +276,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       // the entry is wave-uniform: move it to a scalar register so that the record address and
       // the list index are scalar arithmetic (as a vector value the compiler spent a quarter-rate
       // v_mul_lo_u32 per entry on the address)
+      FG_STAT(8, 1);
       const unsigned packed = __builtin_amdgcn_readfirstlane((unsigned)lds_list[wave][n]);
       const int j = packed & 255u;
       Splat s;
@@ -275,7 +296,10 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         const float alpha = fminf(FG_ALPHA_MAX, s.o * __builtin_amdgcn_exp2f(e2));
         // valid = !done && !(sigma < 0 || alpha < 1/255)
         const uint64_t valid = lanes_ule(e2, 0.f) & lanes_oge(alpha, FG_ALPHA_SKIP) & ~done[k];
+        FG_STAT(9, 1);
         if (valid == 0ull) continue;
+        FG_STAT(10, 1);
+        FG_STAT(11, __popcll(valid));
         const float next_T = T[k] * (1.f - alpha);
         const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
         const uint64_t take = valid & ~stop;
@@ -297,9 +321,25 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     const int iy = tile_y * TILE + row0 + k * RSTEP;
     if (ix < width && iy < height) {
       const size_t pix = (size_t)iy * width + ix;
+      const float alpha_out = 1.f - T[k];
+      if (comp.background || comp.n_clamp > 0) {
+        const float om = 1.f - alpha_out;  // as the host expression (1 - alpha) rounds
+        unsigned blocked = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+          float v = acc[k][c];
+          if (comp.background) v += om * comp.background[c];
+          if (c < comp.n_clamp) {
+            if (v < 0.f || v > 1.f) blocked |= 1u << c;
+            v = fminf(fmaxf(v, 0.f), 1.f);
+          }
+          acc[k][c] = v;
+        }
+        if (comp.n_clamp > 0) comp.clamp_mask[pix] = (uint8_t)blocked;
+      }
 #pragma unroll
       for (int c = 0; c < C; ++c) render[pix * C + c] = acc[k][c];
-      alphas[pix] = 1.f - T[k];
+      alphas[pix] = alpha_out;
       last_ids[pix] = last[k];
     }
   }
@@ -311,7 +351,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
                   const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
                   const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ v_splats) {
+                  float* __restrict__ v_splats, Composite comp) {
   constexpr int NT = 256 / PPT;
   constexpr int NW = NT / 64;
   constexpr int RSTEP = TILE / PPT;
@@ -344,10 +384,17 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     const size_t pix = (size_t)iy * width + ix;
     T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
     last[k] = inside ? last_ids[pix] : start - 1;
-    tva[k] = inside ? T[k] * v_alphas[pix] : 0.f;  // T_final * dL/dalpha
+    float va = inside ? v_alphas[pix] : 0.f;
+    const unsigned blocked = (inside && comp.n_clamp > 0) ? comp.clamp_mask[pix] : 0u;
     bsum[k] = 0.f;
 #pragma unroll
-    for (int c = 0; c < C; ++c) vr[k][c] = inside ? v_render[pix * C + c] : 0.f;
+    for (int c = 0; c < C; ++c) {
+      float v = inside ? v_render[pix * C + c] : 0.f;
+      if ((blocked >> c) & 1u) v = 0.f;                  // clamped channel: no gradient
+      if (comp.background) va -= v * comp.background[c];  // d/dalpha of (1 - alpha) * bg
+      vr[k][c] = v;
+    }
+    tva[k] = T[k] * va;  // T_final * dL/dalpha
     my_max = max(my_max, last[k]);
   }
   // last list entry any pixel of the tile used
@@ -361,6 +408,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   const int n_used = bin_final - start + 1;
   if (n_used <= 0) return;
   const int n_batches = (n_used + NT - 1) / NT;
+  if (threadIdx.x == 0) { FG_STAT(5, n_used); FG_STAT(6, end - start); }
   float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
 #pragma unroll
   for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
@@ -402,6 +450,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           if (!__any(reach)) continue;
         }
 
+        FG_STAT(0, 1);
         Splat s;
         float f[C];
         read_record<C>(lds[j], s, f);
@@ -426,7 +475,10 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           const float ov = s.o * vis;
           const float alpha = fminf(FG_ALPHA_MAX, ov);
           const bool valid = (idx_j <= last[k]) && !(e2 > 0.f || alpha < FG_ALPHA_SKIP);
+          FG_STAT(1, 1);
           if (!__any(valid)) continue;  // wave-uniform
+          FG_STAT(2, 1);
+          FG_STAT(3, __popcll(__ballot(valid)));
           contributed = true;
           const float a_eff = valid ? alpha : 0.f;
           const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
@@ -455,6 +507,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           g[2] += open ? vis * v_alpha : 0.f;
         }
         if (!__any(contributed)) continue;
+        FG_STAT(4, 1);
         if (C <= 4) {  // only record slots 0..11 are in use: the cheaper 12-value butterfly
           const float total = fg::wave_reduce12_transposed(g);
           if (fg::wave_reduce12_owner(lane)) {
@@ -551,26 +604,27 @@ int raster_ppt_bwd() {
 
 template <int C, int PPT>
 int launch_fwd(int width, int height, const float* splats, const int32_t* tile_offsets,
-               const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, hipStream_t s) {
+               const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, Composite comp,
+               hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
   const int grid = launch_grid(mode, tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
-                     alphas, last_ids);
+                     alphas, last_ids, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
 template <int C, int PPT>
 int launch_bwd(int width, int height, const float* splats, const int32_t* tile_offsets,
                const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
-               const float* v_alphas, float* v_splats, hipStream_t s) {
+               const float* v_alphas, float* v_splats, Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
   const int grid = launch_grid(mode, tile_w, tile_h);
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
-                     last_ids, v_render, v_alphas, v_splats);
+                     last_ids, v_render, v_alphas, v_splats, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -616,43 +670,98 @@ extern "C" int fg_unpack_grads(int N, int channels, const float* v_splats, float
   return FG_OK;
 }
 
-extern "C" int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
-                             const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
-                             float* alphas, int32_t* last_ids, fg_stream_t stream) {
+namespace {
+
+int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
+                   const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
+                   int32_t* last_ids, Composite comp, fg_stream_t stream) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
+  if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
   const int ppt = raster_ppt_fwd();
-#define CALL(CC)                                                                                              \
-  rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
-       : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s) \
-                    : launch_fwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, s)
+#define CALL(CC)                                                                                                    \
+  rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+                                      comp, s)                                                                      \
+       : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+                                      comp, s)                                                                      \
+                    : launch_fwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+                                      comp, s)
   FG_DISPATCH_C(CALL)
 #undef CALL
   return rc;
+}
+
+int raster_bwd_any(int channels, int width, int height, int tile_size, const float* splats,
+                   const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
+                   const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
+                   Composite comp, fg_stream_t stream) {
+  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
+  if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
+  if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_splats)
+    return FG_ERR_INVALID_ARG;
+  if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
+  hipStream_t s = fg_hip_stream(stream);
+  int rc = FG_OK;
+  const int ppt = raster_ppt_bwd();
+#define CALL(CC)                                                                                            \
+  rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, comp, s)                                \
+       : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, comp, s)                                \
+                    : launch_bwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                      v_render, v_alphas, v_splats, comp, s)
+  FG_DISPATCH_C(CALL)
+#undef CALL
+  return rc;
+}
+
+}  // namespace
+
+extern "C" int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                             const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
+                             float* alphas, int32_t* last_ids, fg_stream_t stream) {
+  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, render, alphas,
+                        last_ids, Composite{nullptr, 0, nullptr}, stream);
 }
 
 extern "C" int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
                              const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                              const int32_t* last_ids, const float* v_render, const float* v_alphas,
                              float* v_splats, fg_stream_t stream) {
-  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
-  if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
-  if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_splats)
-    return FG_ERR_INVALID_ARG;
-  hipStream_t s = fg_hip_stream(stream);
-  int rc = FG_OK;
-  const int ppt = raster_ppt_bwd();
-#define CALL(CC)                                                                                          \
-  rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
-                                      v_render, v_alphas, v_splats, s)                                    \
-       : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
-                                      v_render, v_alphas, v_splats, s)                                    \
-                    : launch_bwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
-                                      v_render, v_alphas, v_splats, s)
-  FG_DISPATCH_C(CALL)
-#undef CALL
-  return rc;
+  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                        v_render, v_alphas, v_splats, Composite{nullptr, 0, nullptr}, stream);
 }
+
+extern "C" int fg_raster_composite_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                                       const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                       const float* background, int n_clamp, float* image, float* alphas,
+                                       int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream) {
+  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
+                        last_ids, Composite{background, n_clamp, clamp_mask}, stream);
+}
+
+extern "C" int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                                       const int32_t* tile_offsets, const int32_t* flatten_ids,
+                                       const float* background, int n_clamp, const uint8_t* clamp_mask,
+                                       const float* alphas, const int32_t* last_ids, const float* v_image,
+                                       const float* v_alphas, float* v_splats, fg_stream_t stream) {
+  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                        v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
+                        stream);
+}
+
+#ifdef FG_RASTER_STATS
+// out[16] on the host; reset != 0 clears the counters afterwards.  Only in libfgraster_stats.so.
+extern "C" int fg_debug_raster_stats(unsigned long long* out, int reset) {
+  if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_raster_stats), sizeof(unsigned long long) * 16) != hipSuccess)
+    return FG_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fg_raster_stats), z, sizeof(z)) != hipSuccess) return FG_ERR_LAUNCH;
+  }
+  return FG_OK;
+}
+#endif

@@ -70,6 +70,9 @@ class FreeGaussianModelConfig:
     rasterize_mode: str = "classic"
     num_random: int = 50000
     random_scale: float = 10.0
+    # build extension: fold the SH cat, exp / sigmoid / quaternion
+    # normalisation (+ MLP deltas) and the background composite + clamp into the HIP passes
+    fused_front_end: bool = True
 
 
 class FreeGaussianModel(nn.Module):
@@ -205,6 +208,45 @@ class FreeGaussianModel(nn.Module):
             background = background.expand(H, W, 3)
         return {"rgb": rgb.squeeze(0), "depth": depth, "accumulation": alpha.squeeze(0), "background": background}
 
+    def _render(self, means, d_rotation, d_scaling, viewmat, K, W, H):
+        """Activations (:801, :826-830, :844-851) + raster call + O1, either folded into the HIP
+        passes (``fused_front_end``; SH path only) or spelled out in torch exactly like the
+        reference."""
+        if self.config.fused_front_end and self.config.sh_degree > 0:
+            return self._rasterize_raw_and_finish(means, d_rotation, d_scaling, viewmat, K, W, H)
+        colors, sh_degree = self._colors_and_degree()
+        scales = torch.exp(self.scales) + d_scaling
+        quats = self.quats / self.quats.norm(dim=-1, keepdim=True) + d_rotation
+        return self._rasterize_and_finish(means, quats, scales, colors, sh_degree, viewmat, K, W, H)
+
+    def _rasterize_raw_and_finish(self, means, d_rotation, d_scaling, viewmat, K, W, H):
+        from .rasterization import rasterize_gauss_params
+
+        render_mode = self._render_mode()
+        background = self._get_background_color()
+        sh_degree = min(self.step // self.config.sh_degree_interval, self.config.sh_degree)
+        rgb, alpha, info = rasterize_gauss_params(
+            means, self.quats, self.scales, self.opacities, self.features_dc, self.features_rest, viewmat, K, W, H,
+            sh_degree,
+            d_quats=d_rotation if torch.is_tensor(d_rotation) else None,
+            d_scales=d_scaling if torch.is_tensor(d_scaling) else None,
+            background=background, clamp=True, near_plane=0.01, far_plane=1e10, tile_size=16,
+            render_mode=render_mode, absgrad=True, rasterize_mode=self.config.rasterize_mode,
+        )  # fmt: skip
+        if self.training and info["means2d"].requires_grad:
+            info["means2d"].retain_grad()
+        self.xys = info["means2d"]
+        self.radii = info["radii"][0]
+        if render_mode == "RGB+ED":
+            depth = rgb[..., 3:4]
+            depth = torch.where(alpha > 0, depth, depth.detach().max()).squeeze(0)
+        else:
+            depth = None
+        if not self.training:
+            background = background.expand(H, W, 3)
+        return {"rgb": rgb[..., :3].squeeze(0), "depth": depth, "accumulation": alpha.squeeze(0),
+                "background": background}  # fmt: skip
+
     # -- H1 + H4 -----------------------------------------------------------------------------------
     def get_outputs(self, camera: Camera) -> Dict[str, Union[torch.Tensor, List, None]]:
         if not isinstance(camera, Camera):
@@ -215,7 +257,6 @@ class FreeGaussianModel(nn.Module):
         if self.training:
             assert camera.shape[0] == 1, "Only one camera at a time"
         viewmat, K, W, H = self._camera_setup(camera)
-        colors, sh_degree = self._colors_and_degree()
         if self.step < self.config.warm_up:
             means = self.means
             d_rotation, d_scaling = 0.0, 0.0
@@ -223,9 +264,7 @@ class FreeGaussianModel(nn.Module):
             times = camera.times.to(self.device).expand(self.num_points, -1)
             d_xyz, d_rotation, d_scaling = self.deform(self.means.detach(), times)
             means = from_homogenous(torch.bmm(d_xyz, to_homogenous(self.means).unsqueeze(-1)).squeeze(-1))
-        scales = torch.exp(self.scales) + d_scaling
-        quats = self.quats / self.quats.norm(dim=-1, keepdim=True) + d_rotation
-        return self._rasterize_and_finish(means, quats, scales, colors, sh_degree, viewmat, K, W, H)
+        return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
 
     @torch.no_grad()
     def get_outputs_for_camera(self, camera: Camera):
@@ -281,7 +320,6 @@ class FreeGaussianControlModel(FreeGaussianModel):
             print("Called get_outputs with not a camera")
             return {}
         viewmat, K, W, H = self._camera_setup(camera)
-        colors, sh_degree = self._colors_and_degree()
         sel = self.gaussian_mask.any(-1)
         pts = self.means[sel]
         pmask = self.gaussian_mask[sel]  # [n,M]
@@ -297,11 +335,11 @@ class FreeGaussianControlModel(FreeGaussianModel):
                 d_avg = torch.stack([delta[pmask[:, i]].mean(0) for i in range(pmask.shape[1])])
         value = pmask.float() @ d_avg / pmask.sum(-1, keepdim=True)  # (:140)
         d_xyz, d_rot, d_scale = self.control(pts, value)
-        means = self.means + torch.zeros_like(self.means).index_put((sel.nonzero().squeeze(-1),), d_xyz)
-        scales = torch.exp(self.scales) + torch.zeros_like(self.scales).index_put((sel.nonzero().squeeze(-1),), d_scale)
-        qn = self.quats / self.quats.norm(dim=-1, keepdim=True)
-        quats = qn + torch.zeros_like(self.quats).index_put((sel.nonzero().squeeze(-1),), d_rot)
-        return self._rasterize_and_finish(means, quats, scales, colors, sh_degree, viewmat, K, W, H)
+        idx = (sel.nonzero().squeeze(-1),)
+        means = self.means + torch.zeros_like(self.means).index_put(idx, d_xyz)
+        d_scaling = torch.zeros_like(self.scales).index_put(idx, d_scale)
+        d_rotation = torch.zeros_like(self.quats).index_put(idx, d_rot)
+        return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
 
     def get_param_groups(self):
         groups = super().get_param_groups()

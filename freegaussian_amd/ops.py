@@ -413,6 +413,95 @@ def preprocess(means, quats, scales, opacities, colors, extra, viewmat, K, width
     return _Preprocess.apply(means, quats, scales, opacities, colors, extra, viewmat, K, cfg)
 
 
+class _PreprocessRaw(torch.autograd.Function):
+    """fg_preprocess_raw_*: the same pass on the reference's raw gauss_params (log-scales, opacity
+    logits, unnormalised quats, split SH features) with optional deltas from the deform / control
+    MLPs (freegaussian_model.py:801, :844-851); activations and their chain rule run in-kernel."""
+
+    @staticmethod
+    def forward(ctx, means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest,
+                extra, viewmat, K, cfg):  # fmt: skip
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg
+        N = means.shape[0]
+        dev = means.device
+        k_stored = 1 + features_rest.shape[1]
+        n_extra = 0 if extra is None else extra.shape[1]
+        radii = torch.empty(N, dtype=torch.int32, device=dev)
+        means2d = torch.empty(N, 2, dtype=torch.float32, device=dev)
+        depths = torch.empty(N, dtype=torch.float32, device=dev)
+        conics = torch.empty(N, 3, dtype=torch.float32, device=dev)
+        comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
+        tiles = torch.empty(N, dtype=torch.int32, device=dev)
+        splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        _call("fg_preprocess_raw_fwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
+              _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
+              _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, near, far, radius_clip, tile_size,
+              int(antialiased), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles),
+              _ptr(splats), _stream())  # fmt: skip
+        ctx.save_for_backward(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
+                              features_rest, extra, viewmat, K, radii)  # fmt: skip
+        ctx.cfg = cfg
+        ctx.mark_non_differentiable(radii, tiles)
+        return radii, means2d, depths, conics, tiles, splats
+
+    @staticmethod
+    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
+        (means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest, extra, viewmat, K,
+         radii) = ctx.saved_tensors  # fmt: skip
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg
+        N = means.shape[0]
+        dev = means.device
+        k_stored = 1 + features_rest.shape[1]
+        n_extra = 0 if extra is None else extra.shape[1]
+        if v_splats is None:
+            v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        if v_means2d is None:
+            v_means2d = torch.zeros(N, 2, dtype=torch.float32, device=dev)
+        v_means, v_quats, v_ls = _alloc_grad(means), _alloc_grad(quats), _alloc_grad(log_scales)
+        v_ol, v_dc, v_rest = _alloc_grad(opacity_logits), _alloc_grad(features_dc), _alloc_grad(features_rest)
+        v_dq = torch.empty_like(d_quats) if d_quats is not None else None
+        v_ds = torch.empty_like(d_scales) if d_scales is not None else None
+        v_extra = torch.empty_like(extra) if extra is not None else None
+        v_means2d = v_means2d.reshape(N, 2)
+        if v_means2d.stride(1) == 1 and v_means2d.stride(0) >= 2:
+            m2_stride = v_means2d.stride(0)
+        else:
+            v_means2d, m2_stride = v_means2d.contiguous(), 2
+        _call("fg_preprocess_raw_bwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
+              _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
+              n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, int(antialiased), _ptr(radii),
+              _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
+              _ptr(None if v_depths is None else v_depths.contiguous()),
+              _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats), _ptr(v_dq),
+              _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _ptr(v_extra), _stream())  # fmt: skip
+        return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, v_dc, v_rest, v_extra, None, None, None
+
+
+def preprocess_raw(means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmat, K, width, height,
+                   sh_degree, d_quats=None, d_scales=None, extra=None, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+                   radius_clip=0.0, tile_size=TILE_SIZE, antialiased=False, with_depth=False):  # fmt: skip
+    """Fused activations + projection + SH colour + record packing on raw gauss_params.
+    features_dc [N,3], features_rest [N,K-1,3], opacity_logits [N] or [N,1]; d_quats [N,4] /
+    d_scales [N,3] optional deltas added after normalisation / exp.
+    -> radii[N], means2d[N,2], depths[N], conics[N,3], tiles_touched[N], splats[N,16]."""
+    means, quats, log_scales = _f32(means, "means"), _f32(quats, "quats"), _f32(log_scales, "scales")
+    opacity_logits = _f32(opacity_logits.reshape(-1), "opacities")
+    features_dc, features_rest = _f32(features_dc, "features_dc"), _f32(features_rest, "features_rest")
+    viewmat, K = _f32(viewmat, "viewmat"), _f32(K, "K")
+    N = means.shape[0]
+    if features_dc.shape != (N, 3) or features_rest.dim() != 3 or features_rest.shape[0] != N:
+        raise ValueError("features_dc[N,3] features_rest[N,K-1,3] expected")
+    if sh_degree is None or not 0 <= sh_degree <= 3 or (sh_degree + 1) ** 2 > 1 + features_rest.shape[1]:
+        raise ValueError("the raw-parameter path needs 0 <= sh_degree <= 3 within the stored coefficients")
+    d_quats = None if d_quats is None else _f32(d_quats, "d_quats")
+    d_scales = None if d_scales is None else _f32(d_scales, "d_scales")
+    extra = None if extra is None else _f32(extra, "extra_channels")
+    cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+           int(tile_size), bool(antialiased), int(sh_degree), bool(with_depth))  # fmt: skip
+    return _PreprocessRaw.apply(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
+                                features_rest, extra, viewmat, K, cfg)  # fmt: skip
+
+
 class _RasterSplats(torch.autograd.Function):
     """Compositing on packed records.  ``means2d`` is a routing input only: its gradient carries
     the xy slots of the record gradient (so ``info["means2d"].grad`` exists, as with gsplat) and
@@ -420,14 +509,23 @@ class _RasterSplats(torch.autograd.Function):
     v_splats accordingly."""
 
     @staticmethod
-    def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad):
+    def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad,
+                background=None, n_clamp=0):  # fmt: skip
         dev = splats.device
         render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
         alphas = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
-        _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
-              _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
-        ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids)
+        composite = background is not None or n_clamp > 0
+        clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
+        if composite:  # O1 folded into the kernel epilogue: render is the finished image
+            _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+                  _ptr(flatten_ids), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas), _ptr(last_ids),
+                  _ptr(clamp_mask), _stream())  # fmt: skip
+        else:
+            _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+                  _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
+        ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask)
+        ctx.composite = (composite, int(n_clamp))
         ctx.geom = (channels, width, height, tile_size, absgrad, tuple(means2d.shape))
         ctx.means2d_ref = means2d if absgrad else None
         ctx.mark_non_differentiable(last_ids)
@@ -435,31 +533,46 @@ class _RasterSplats(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_last):
-        splats, tile_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
+        splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask = ctx.saved_tensors
         C, width, height, tile_size, absgrad, m2_shape = ctx.geom
+        composite, n_clamp = ctx.composite
         N = splats.shape[0]
         v_render = torch.zeros(height, width, C, device=splats.device) if v_render is None else v_render
         v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas
         v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
-        _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
-              _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()),
-              _ptr(v_splats), _stream())  # fmt: skip
+        if composite:
+            _call("fg_raster_composite_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+                  _ptr(flatten_ids), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas), _ptr(last_ids),
+                  _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()), _ptr(v_splats), _stream())  # fmt: skip
+        else:
+            _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
+                  _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()),
+                  _ptr(v_splats), _stream())  # fmt: skip
         # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
         v_means2d = v_splats[:, 0:2].view(m2_shape)
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_splats[:, 6:8].view(m2_shape)
             ctx.means2d_ref = None
-        return v_splats, v_means2d, None, None, None, None, None, None, None
+        return v_splats, v_means2d, None, None, None, None, None, None, None, None, None
 
 
-def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad=False):
-    """-> render[H,W,C], alphas[H,W,1], last_ids[H,W] from packed records (fused path)."""
+def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad=False,
+                     background=None, n_clamp=0):  # fmt: skip
+    """-> render[H,W,C], alphas[H,W,1], last_ids[H,W] from packed records (fused path).
+    ``background`` [C] (no gradient) and ``n_clamp`` fold the model's post-composite into the
+    kernels: render = clamp(render + (1 - alpha) * background) on the first n_clamp channels."""
+    if background is not None:
+        background = background.detach().to(device=splats.device, dtype=torch.float32).contiguous()
+        if background.numel() != channels:
+            raise ValueError(f"background must have {channels} values")
+    if not 0 <= n_clamp <= channels:
+        raise ValueError("n_clamp out of range")
     if tile_size != TILE_SIZE:
         raise ValueError("tile_size must be 16")
     if not 1 <= channels <= MAX_CHANNELS:
         raise ValueError(f"1..{MAX_CHANNELS} composited channels supported, got {channels}")
     return _RasterSplats.apply(splats, means2d, int(channels), int(width), int(height), int(tile_size), tile_offsets,
-                               flatten_ids, bool(absgrad))  # fmt: skip
+                               flatten_ids, bool(absgrad), background, int(n_clamp))  # fmt: skip
 
 
 # --------------------------------------------------------------------------------------------

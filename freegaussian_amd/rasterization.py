@@ -239,3 +239,92 @@ def rasterization(
             conics=conics[gids],
         )
     return render[None], alpha[None], info
+
+
+def rasterize_gauss_params(
+    means: torch.Tensor,  # [N,3] (already deformed, if a deform net is active)
+    quats: torch.Tensor,  # [N,4] raw parameter, normalised in-kernel
+    log_scales: torch.Tensor,  # [N,3] raw parameter, exp() in-kernel
+    opacity_logits: torch.Tensor,  # [N,1] or [N] raw parameter, sigmoid() in-kernel
+    features_dc: torch.Tensor,  # [N,3]
+    features_rest: torch.Tensor,  # [N,K-1,3]
+    viewmats: torch.Tensor,
+    Ks: torch.Tensor,
+    width: int,
+    height: int,
+    sh_degree: int,
+    d_quats: Optional[torch.Tensor] = None,  # [N,4] added after normalisation (:845)
+    d_scales: Optional[torch.Tensor] = None,  # [N,3] added after exp (:844)
+    background: Optional[torch.Tensor] = None,  # [3]; composited in the raster epilogue
+    clamp: bool = False,  # clamp the colour channels to [0,1] (:876)
+    near_plane: float = 0.01,
+    far_plane: float = 1e10,
+    radius_clip: float = 0.0,
+    eps2d: float = 0.3,
+    tile_size: int = 16,
+    render_mode: str = "RGB",
+    absgrad: bool = False,
+    rasterize_mode: str = "classic",
+    extra_channels: Optional[torch.Tensor] = None,
+) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
+    """The model-side front end of SURVEY.md section 8f row 3: what FreeGaussianModel.get_outputs
+    does around the raster call (freegaussian_model.py:801 SH ``cat``, :844-851 ``exp`` /
+    ``sigmoid`` / quaternion normalisation + MLP deltas, :875-877 background composite + clamp)
+    folded into the two per-Gaussian passes and the raster epilogue/prologue.  Same outputs as
+    ``rasterization(means, quats/|quats| + d_quats, exp(log_scales) + d_scales,
+    sigmoid(opacity_logits), cat(dc, rest), ...)`` followed by the composite, unpacked layout;
+    the returned ``render`` is the finished image when ``background``/``clamp`` are given
+    (depth, if any, stays accumulated-then-normalised as in ``rasterization``)."""
+    if rasterize_mode not in ("classic", "antialiased"):
+        raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
+    if render_mode not in RENDER_MODES:
+        raise ValueError(f"Unknown render_mode: {render_mode}")
+    if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
+        raise ValueError("exactly one camera per call (reference asserts camera.shape[0]==1)")
+    if not means.is_cuda:
+        from ._lib import FgRasterError
+
+        raise FgRasterError("rasterize_gauss_params needs CUDA/HIP tensors: the raster path has no CPU fallback")
+    if not render_mode.startswith("RGB"):
+        raise ValueError("the raw-parameter path renders colour: use rasterization() for depth-only modes")
+    N = means.shape[0]
+    if N == 0:
+        raise ValueError("empty Gaussian set")
+    with_depth = render_mode.endswith("D")
+    n_extra = 0 if extra_channels is None else extra_channels.shape[1]
+    channels = 3 + int(with_depth) + n_extra
+    if channels > ops.MAX_CHANNELS:
+        raise ValueError(f"1..{ops.MAX_CHANNELS} composited channels supported, got {channels}")
+    viewmat, K = viewmats[0], Ks[0]
+    tile_w = (width + tile_size - 1) // tile_size
+    tile_h = (height + tile_size - 1) // tile_size
+    radii, means2d_n, depths, conics, tiles, splats = ops.preprocess_raw(
+        means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmat, K, width, height, sh_degree,
+        d_quats=d_quats, d_scales=d_scales, extra=extra_channels, eps2d=eps2d, near_plane=near_plane,
+        far_plane=far_plane, radius_clip=radius_clip, tile_size=tile_size,
+        antialiased=(rasterize_mode == "antialiased"), with_depth=with_depth,
+    )  # fmt: skip
+    tile_keys, flatten_ids, offsets = ops.bin_tiles(
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
+    )
+    means2d_info = means2d_n.unsqueeze(0)
+    bg = None
+    if background is not None:
+        bg = torch.zeros(channels, device=means.device, dtype=torch.float32)
+        bg[:3] = background.detach().reshape(-1).to(means.device, torch.float32)
+    render, alpha, last_ids = ops.rasterize_splats(
+        splats, means2d_info, channels, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad,
+        background=bg, n_clamp=(3 if clamp else 0),
+    )  # fmt: skip
+    if with_depth:
+        d = render[..., 3:4] / alpha.clamp(min=1e-10)
+        render = torch.cat([render[..., :3], d, render[..., 4:]], dim=-1)
+    info = _Info({
+        "radii": radii[None], "means2d": means2d_info, "depths": depths[None], "conics": conics[None],
+        "opacities": splats[:, 2][None], "tile_width": tile_w, "tile_height": tile_h,
+        "tiles_per_gauss": tiles[None], "tile_keys": tile_keys, "flatten_ids": flatten_ids,
+        "isect_offsets": offsets, "last_ids": last_ids, "width": width, "height": height,
+        "tile_size": tile_size, "n_cameras": 1,
+    })  # fmt: skip
+    info.lazy("isect_ids", lambda: ops.isect_keys(tile_keys, flatten_ids, depths.detach()))
+    return render[None], alpha[None], info

@@ -148,6 +148,22 @@ int fg_raster_bwd(int channels, int width, int height, int tile_size, const floa
                   const int32_t* tile_offsets, const int32_t* flatten_ids,
                   const float* alphas, const int32_t* last_ids, const float* v_render,
                   const float* v_alphas, float* v_splats, fg_stream_t stream);
+/* The same kernels with the model's post-composite O1 folded in (SURVEY.md section 8f row 3;
+ * freegaussian_model.py:875-877 `rgb = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)`):
+ *   image[c] = render[c] + (1 - alpha) * background[c]   (background[C], nullable = none),
+ * the first n_clamp channels clamped to [0,1].  clamp_mask[H,W] (uint8, required when
+ * n_clamp > 0) receives per pixel bit c = "channel c was strictly outside [0,1]"; the backward
+ * takes it back, zeroes those channels of v_image and folds -sum_c v_image[c]*background[c]
+ * into the alpha gradient, so that v_image / v_alphas are the gradients of `rgb` / `alpha`. */
+int fg_raster_composite_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                            const int32_t* tile_offsets, const int32_t* flatten_ids,
+                            const float* background, int n_clamp, float* image, float* alphas,
+                            int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream);
+int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                            const int32_t* tile_offsets, const int32_t* flatten_ids,
+                            const float* background, int n_clamp, const uint8_t* clamp_mask,
+                            const float* alphas, const int32_t* last_ids, const float* v_image,
+                            const float* v_alphas, float* v_splats, fg_stream_t stream);
 /* Split v_splats back into per-tensor gradients (any output nullable). */
 int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
                     float* v_means2d_abs, float* v_conics, float* v_opacities,
@@ -184,6 +200,38 @@ int fg_preprocess_bwd(int N, const float* means, const float* quats, const float
                       const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                       float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
                       fg_stream_t stream);
+
+/* The same two passes on the RAW parameter forms of the reference's gauss_params
+ * (freegaussian_model.py:187-196), with the activations its get_outputs applies before the raster
+ * call folded in, SH path only (sh_degree >= 0):
+ *   quats          -> quats / |quats| + d_quats            (:845;  d_quats[N,4] nullable)
+ *   log_scales     -> exp(log_scales) + d_scales           (:844;  d_scales[N,3] nullable)
+ *   opacity_logits -> sigmoid(opacity_logits)              (:851;  [N])
+ *   colours        -> cat(features_dc[N,1,3], features_rest[N,k_stored-1,3])   (:801)
+ * The backward returns gradients of the raw forms (v_quats through the normalisation,
+ * v_log_scales through exp, v_opacity_logits through sigmoid, v_features_dc / v_features_rest)
+ * and of the deltas (v_d_quats / v_d_scales, required exactly when the delta was given); every
+ * output is overwritten densely. */
+int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const float* d_quats,
+                          const float* log_scales, const float* d_scales,
+                          const float* opacity_logits, const float* features_dc,
+                          const float* features_rest, int sh_degree, int k_stored, int with_depth,
+                          const float* extra, int n_extra, const float* viewmat, const float* K,
+                          int width, int height, float eps2d, float near_plane, float far_plane,
+                          float radius_clip, int tile_size, int antialiased, int32_t* radii,
+                          float* means2d, float* depths, float* conics, float* compensations,
+                          int32_t* tiles_touched, float* splats, fg_stream_t stream);
+int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
+                          const float* log_scales, const float* d_scales,
+                          const float* opacity_logits, const float* features_dc,
+                          const float* features_rest, int sh_degree, int k_stored, int with_depth,
+                          int n_extra, const float* viewmat, const float* K, int width, int height,
+                          float eps2d, int antialiased, const int32_t* radii, const float* v_splats,
+                          const float* v_means2d, int v_means2d_stride, const float* v_depths,
+                          const float* v_conics, float* v_means, float* v_quats, float* v_d_quats,
+                          float* v_log_scales, float* v_d_scales, float* v_opacity_logits,
+                          float* v_features_dc, float* v_features_rest, float* v_extra,
+                          fg_stream_t stream);
 
 /* ---- F: flow derivative -------------------------------------------------------------------
  * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at

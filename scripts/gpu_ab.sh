@@ -3,7 +3,7 @@
 tag=$1; shift
 out=gpurun_out/$tag
 mkdir -p $out
-timeout 900 python -m pytest tests -m gpu -q --timeout 180 -x 2>&1 | tail -5 > $out/pytest.log
+[ -n "$FG_AB_SKIP_TESTS" ] || timeout 900 python -m pytest tests -m gpu -q --timeout 300 -x 2>&1 | tail -5 > $out/pytest.log
 tail -3 $out/pytest.log
 i=0
 for cfg in "$@"; do

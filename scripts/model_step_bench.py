@@ -1,0 +1,71 @@
+"""Model-level step (FreeGaussianModel.get_outputs + backward, no deform MLP) on the bench scene:
+what a user of the reference model sees around the raster call (§8f row 3).
+Usage: python scripts/model_step_bench.py [n_gauss] [steps]"""
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from freegaussian_amd import ops  # noqa: E402
+from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig  # noqa: E402
+from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+W, H = 1920, 1080
+dev = torch.device("cuda", 0)
+sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
+cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9)
+model = FreeGaussianModel(cfg, seed_points=sc.means)
+with torch.no_grad():
+    gp = model.gauss_params
+    gp["scales"].copy_(sc.scales.log())
+    gp["quats"].copy_(sc.quats)
+    gp["opacities"].copy_(torch.logit(sc.opacities.clamp(1e-6, 1 - 1e-6))[:, None])
+    gp["features_dc"].copy_(sc.colors[:, 0])
+    gp["features_rest"].copy_(sc.colors[:, 1:])
+model = model.to(dev).train()
+model.step = 3000  # SH degree 3
+w2c = sc.viewmats[0]
+c2w = torch.linalg.inv(w2c)
+c2w[:3, 1:3] *= -1  # OpenCV -> OpenGL (get_viewmat flips back)
+K = sc.Ks[0]
+cam = Camera(c2w[None, :3], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H,
+             times=torch.tensor([[0.0]]))
+vr = torch.randn(H, W, 3, device=dev)
+params = list(model.gauss_params.values())
+
+
+def step():
+    for p in params:
+        p.grad = None
+    out = model.get_outputs(cam)
+    (out["rgb"] * vr).sum().backward()
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+ops.stage_timer = ops.StageTimer()
+t0 = time.perf_counter()
+for _ in range(steps):
+    step()
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps * 1e3
+stages = ops.stage_timer.summary()
+ops.stage_timer = None
+res = {"model_step_ms": dt, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
+if os.environ.get("FG_MODEL_PROFILE"):
+    from torch.profiler import ProfilerActivity, profile
+
+    with profile(activities=[ProfilerActivity.CUDA, ProfilerActivity.CPU]) as prof:
+        for _ in range(5):
+            step()
+        torch.cuda.synchronize()
+    rows = sorted(prof.key_averages(), key=lambda e: -e.device_time_total)[:25]
+    res["top_device_ops_us_per_step"] = {e.key[:70]: round(e.device_time_total / 5, 1) for e in rows if e.device_time_total > 0}
+print(json.dumps(res, indent=1))

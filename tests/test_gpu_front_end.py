@@ -1,0 +1,175 @@
+"""GPU parity of the fused model front end: activations of the raw
+gauss_params (freegaussian_model.py:801, :844-851) folded into fg_preprocess_raw_fwd/bwd and
+the post-composite O1 (:875-877) folded into fg_raster_composite_fwd/bwd, against the same math
+spelled out in torch around the plain C-ABI path (which the other GPU tests pin to the oracle)."""
+import copy
+
+import pytest
+import torch
+
+from freegaussian_amd import _lib, ops, rasterization, rasterize_gauss_params
+from freegaussian_amd.scenes import synthetic_scene
+from helpers import REL_TOL, close_except_knife_edge, rel_err, rel_l2
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (no CPU fallback exists)")
+    _lib.load()
+
+
+def _raw_params(n=12000, w=208, h=130, seed=21, deltas=True):
+    sc = synthetic_scene(n, w, h, n_views=2, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
+    raw = {
+        "means": sc.means.clone(),
+        "quats": sc.quats * (0.5 + 1.5 * torch.rand(n, 1, generator=g)),  # not unit length
+        "log_scales": sc.scales.log(),
+        "opacity_logits": torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4))[:, None],
+        "features_dc": sc.colors[:, 0].clone(),
+        "features_rest": sc.colors[:, 1:].clone(),
+    }
+    if deltas:
+        raw["d_quats"] = 0.03 * torch.randn(n, 4, generator=g)
+        raw["d_scales"] = 0.2 * sc.scales * torch.rand(n, 3, generator=g)
+    return sc, {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+
+
+def _torch_front_end(p, sc, sh_degree, render_mode, background, clamp, rmode="classic"):
+    quats = p["quats"] / p["quats"].norm(dim=-1, keepdim=True)
+    scales = torch.exp(p["log_scales"])
+    if "d_quats" in p:
+        quats, scales = quats + p["d_quats"], scales + p["d_scales"]
+    colors = torch.cat((p["features_dc"][:, None, :], p["features_rest"]), dim=1)
+    r, a, info = rasterization(p["means"], quats, scales, torch.sigmoid(p["opacity_logits"]).squeeze(-1), colors,
+                               sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), sc.width, sc.height, sh_degree=sh_degree,
+                               render_mode=render_mode, packed=False, absgrad=True, rasterize_mode=rmode)  # fmt: skip
+    rgb = r[..., :3]
+    if background is not None:
+        rgb = rgb + (1 - a) * background
+    if clamp:
+        rgb = torch.clamp(rgb, 0.0, 1.0)
+    return torch.cat([rgb, r[..., 3:]], dim=-1), a, info
+
+
+@pytest.mark.parametrize("deltas,sh_degree,render_mode,bg,clamp,rmode", [
+    (True, 3, "RGB", (1.0, 0.5, 0.0), True, "classic"),
+    (False, 3, "RGB", None, False, "classic"),
+    (True, 1, "RGB+ED", (1.0, 1.0, 1.0), True, "antialiased"),
+    (False, 0, "RGB", (0.2, 0.3, 0.4), False, "classic"),
+])  # fmt: skip
+def test_raw_front_end_matches_torch_activations(deltas, sh_degree, render_mode, bg, clamp, rmode):
+    sc, p0 = _raw_params(deltas=deltas)
+    p1 = {k: v.detach().clone().requires_grad_(True) for k, v in p0.items()}
+    background = None if bg is None else torch.tensor(bg, device=DEV)
+    r0, a0, i0 = _torch_front_end(p0, sc, sh_degree, render_mode, background, clamp, rmode)
+    r1, a1, i1 = rasterize_gauss_params(
+        p1["means"], p1["quats"], p1["log_scales"], p1["opacity_logits"], p1["features_dc"], p1["features_rest"],
+        sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV), sc.width, sc.height, sh_degree,
+        d_quats=p1.get("d_quats"), d_scales=p1.get("d_scales"), background=background, clamp=clamp,
+        render_mode=render_mode, absgrad=True, rasterize_mode=rmode)  # fmt: skip
+    assert r1.shape == r0.shape and a1.shape == a0.shape
+    # exp / sigmoid / rsqrt differ by an ulp between torch's kernels and the in-kernel versions:
+    # radii may flip on a knife edge for a handful of Gaussians
+    assert int((i0["radii"] != i1["radii"]).sum()) <= 3
+    assert rel_err(i1["means2d"], i0["means2d"]) < 1e-5 and rel_err(i1["depths"], i0["depths"]) < 1e-6
+    assert close_except_knife_edge(r1, r0, REL_TOL) and close_except_knife_edge(a1, a0, REL_TOL)
+    if clamp:
+        assert float(r1[..., :3].min()) >= 0.0 and float(r1[..., :3].max()) <= 1.0
+        assert float((r1[..., :3] == 1.0).float().mean()) > 1e-3 or bg != (1.0, 0.5, 0.0)  # the clamp is exercised
+    g = torch.Generator().manual_seed(4)
+    vr, va = torch.randn(r0.shape, generator=g).to(DEV), torch.randn(a0.shape, generator=g).to(DEV)
+    for r, a, info in ((r0, a0, i0), (r1, a1, i1)):
+        info["means2d"].retain_grad()
+        ((r * vr).sum() + (a * va).sum()).backward()
+    for k in p0:
+        assert p1[k].grad is not None, k
+        assert rel_l2(p1[k].grad, p0[k].grad) < 3 * REL_TOL, (k, rel_l2(p1[k].grad, p0[k].grad))
+    assert rel_l2(i1["means2d"].grad, i0["means2d"].grad) < 3 * REL_TOL
+    assert rel_l2(i1["means2d"].absgrad, i0["means2d"].absgrad) < 3 * REL_TOL
+
+
+def test_composite_epilogue_alone_is_exact_on_identical_records():
+    """Same records and lists through fg_raster_fwd + torch composite vs fg_raster_composite_fwd:
+    the kernels differ only in the epilogue/prologue."""
+    sc = synthetic_scene(8000, 176, 120, n_views=1, seed=5)
+    t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    vm, K = sc.viewmats[0].to(DEV), sc.Ks[0].to(DEV)
+    radii, m2, depths, conics, tiles, splats = ops.preprocess(*t, None, vm, K, sc.width, sc.height, sh_degree=3)
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    _, ids, offs = ops.bin_tiles(m2, radii, depths, tiles, 16, tw, th)
+    bg = torch.tensor([1.0, 0.25, 0.0], device=DEV)
+    outs = []
+    for fused in (False, True):
+        s = splats.detach().clone().requires_grad_(True)
+        m = m2.detach().clone().requires_grad_(True)
+        if fused:
+            r, a, _ = ops.rasterize_splats(s, m, 3, sc.width, sc.height, 16, offs, ids, absgrad=True, background=bg,
+                                           n_clamp=3)  # fmt: skip
+        else:
+            r, a, _ = ops.rasterize_splats(s, m, 3, sc.width, sc.height, 16, offs, ids, absgrad=True)
+            r = torch.clamp(r + (1 - a) * bg, 0.0, 1.0)
+        g = torch.Generator().manual_seed(9)
+        vr, va = torch.randn(r.shape, generator=g).to(DEV), torch.randn(a.shape, generator=g).to(DEV)
+        ((r * vr).sum() + (a * va).sum()).backward()
+        outs.append((r.detach(), a.detach(), s.grad.clone(), m.grad.clone()))
+    (r0, a0, gs0, gm0), (r1, a1, gs1, gm1) = outs
+    assert torch.equal(a0, a1)
+    assert float((r0 - r1).abs().max()) <= 2e-7  # an FMA in the epilogue at most
+    assert rel_l2(gs1[:, 2:], gs0[:, 2:]) < 1e-5 and rel_l2(gm1, gm0) < 1e-5
+
+
+def _models(step, training, n=4000, W=160, H=96):
+    from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig
+    from freegaussian_amd.scenes import look_at_viewmat
+
+    torch.manual_seed(0)
+    cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=3000, fused_front_end=True)
+    model = FreeGaussianModel(cfg, seed_points=(torch.rand(n, 3) - 0.5) * 2.0)
+    with torch.no_grad():
+        model.gauss_params["scales"].fill_(-3.2)
+        model.gauss_params["features_rest"].normal_(0, 0.1)
+        model.gauss_params["quats"].mul_(1.7)
+        for q in model.deform.parameters():
+            q.mul_(0.3)
+    model.step = step
+    model.train(training)
+    w2c = look_at_viewmat(torch.tensor([0.3, -0.2, -3.0]), torch.zeros(3))
+    c2w = torch.linalg.inv(w2c)
+    c2w[:3, 1:3] *= -1
+    cam = Camera(c2w[None, :3], 140.0, 150.0, W / 2, H / 2, W, H, times=torch.tensor([[0.4]]))
+    unfused = copy.deepcopy(model)
+    unfused.config = copy.deepcopy(cfg)
+    unfused.config.fused_front_end = False
+    return model.to(DEV), unfused.to(DEV), cam
+
+
+@pytest.mark.parametrize("step,training", [(1500, True), (4000, True), (4000, False)])
+def test_model_fused_front_end_equals_torch_front_end(step, training):
+    """FreeGaussianModel.get_outputs with the folded front end vs the reference's torch op
+    sequence (warm-up: no deltas, SH degree 1; deformed: MLP deltas, degree 3; eval: RGB+ED)."""
+    fused, plain, cam = _models(step, training)
+    o1, o0 = fused.get_outputs(cam), plain.get_outputs(cam)
+    assert int((fused.radii != plain.radii).sum()) <= 2
+    assert close_except_knife_edge(o1["rgb"], o0["rgb"], REL_TOL)
+    assert close_except_knife_edge(o1["accumulation"], o0["accumulation"], REL_TOL)
+    if not training:
+        assert o1["depth"] is not None and rel_err(o1["depth"], o0["depth"]) < 3 * REL_TOL
+        return
+    gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    (o1["rgb"] - gt).abs().mean().backward()
+    (o0["rgb"] - gt).abs().mean().backward()
+    for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+        g1, g0 = fused.gauss_params[k].grad, plain.gauss_params[k].grad
+        assert g1 is not None and rel_l2(g1, g0) < 3 * REL_TOL, (k, rel_l2(g1, g0))
+    if step >= 3000:
+        gd1 = torch.cat([q.grad.flatten() for q in fused.deform.parameters()])
+        gd0 = torch.cat([q.grad.flatten() for q in plain.deform.parameters()])
+        assert rel_l2(gd1, gd0) < 5 * REL_TOL
+    fused.after_train_iter(step)
+    plain.after_train_iter(step)
+    assert rel_l2(fused.xys_grad_norm, plain.xys_grad_norm) < 3 * REL_TOL
