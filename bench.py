@@ -56,6 +56,7 @@ def algorithmic_bytes(N, V, I, P, T, k, p):
         "fg_preprocess_bwd": (88 + 12 * k) * V + 44 * N + 12 * 16 * N,
         "fg_bin_prepare": 8 * N + 2 * 4 * 16 * N + 16 * N,
         "fg_bin_emit_sort": 8 * I + 2 * 16 * I + 4 * I,
+        "fg_bin_emit_sort_capacity": 8 * I + 2 * 16 * I + 4 * I,
         "fg_project_fwd": 44 * N + 32 * V,
         "fg_sh_fwd": 12 * k * V + 12 * V,
         "fg_tile_bin": 12 * I,

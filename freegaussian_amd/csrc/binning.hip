@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(256)
 tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
                         const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
                         int tile_w, int tile_h, uint32_t* __restrict__ tile_keys,
-                        int32_t* __restrict__ flatten_ids) {
+                        int32_t* __restrict__ flatten_ids, int64_t capacity) {
   __shared__ int32_t s_excl[4][64];  // exclusive slot offset of each lane's splat inside the wave's range
   __shared__ int32_t s_gid[4][64];
   __shared__ int32_t s_rect[4][64];  // x0 | y0 << 10 | width << 20
@@ -210,6 +210,7 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
       const int w = rc >> 20;
       const int ty = t / w, tx = t - ty * w;
       const int64_t out = base + slot;
+      if (out >= capacity) continue;  // capacity launch that guessed too low: the host redoes it
       tile_keys[out] = (uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx);
       flatten_ids[out] = s_gid[wave][lo];
     }
@@ -217,8 +218,10 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
 }
 
 __global__ void __launch_bounds__(256)
-tile_ranges32_kernel(int64_t n, const uint32_t* __restrict__ keys, int n_tiles, int32_t* __restrict__ offsets) {
+tile_ranges32_kernel(int64_t n, const int64_t* __restrict__ n_dev, const uint32_t* __restrict__ keys, int n_tiles,
+                     int32_t* __restrict__ offsets) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n_dev) n = min(n, *n_dev);
   if (n == 0) {
     if (i <= n_tiles) offsets[i] = 0;
     return;
@@ -332,10 +335,14 @@ extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
   return fg_sort::workspace_bytes<uint32_t>(n_isects > 0 ? n_isects : 1);
 }
 
-extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_t* radii,
-                                const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
-                                int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
-                                void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+namespace {
+
+// n_dev == nullptr: exactly n_isects intersections.  Otherwise n_isects is a capacity and the
+// count is read on the device from *n_dev (clamped to the capacity).
+int bin_emit_sort_any(int N, int64_t n_isects, const int64_t* n_dev, const float* means2d, const int32_t* radii,
+                      const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
+                      uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets, void* workspace,
+                      size_t workspace_bytes, fg_stream_t stream) {
   if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
   if (tile_w > 1023 || tile_h > 1023) return FG_ERR_UNSUPPORTED;  // rectangle packing of the emit kernel
   hipStream_t s = fg_hip_stream(stream);
@@ -343,18 +350,38 @@ extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, c
   if (n_isects > 0) {
     if (!means2d || !radii || !order || !cum_tiles || !tile_keys || !flatten_ids || !workspace) return FG_ERR_INVALID_ARG;
     hipLaunchKernelGGL(tile_bin_ordered_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
-                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids);
+                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
     int bits = 1;
     while ((1 << bits) < n_tiles) ++bits;
     const int rc = fg_sort::sort_pairs<uint32_t>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits,
-                                                 workspace, workspace_bytes, s);
+                                                 workspace, workspace_bytes, s, n_dev);
     if (rc != FG_OK) return rc;
   }
-  const int64_t work = n_isects > 0 ? n_isects : (int64_t)n_tiles + 1;
-  hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, tile_keys,
-                     n_tiles, tile_offsets);
+  const int64_t work = n_isects > (int64_t)n_tiles + 1 ? n_isects : (int64_t)n_tiles + 1;
+  hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, n_dev,
+                     tile_keys, n_tiles, tile_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
+}
+
+}  // namespace
+
+extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_t* radii,
+                                const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
+                                int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
+                                void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+  return bin_emit_sort_any(N, n_isects, nullptr, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
+                           tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream);
+}
+
+extern "C" int fg_bin_emit_sort_capacity(int N, int64_t capacity, const float* means2d, const int32_t* radii,
+                                         const int32_t* order, const int64_t* cum_tiles, int tile_size,
+                                         int tile_w, int tile_h, uint32_t* tile_keys, int32_t* flatten_ids,
+                                         int32_t* tile_offsets, void* workspace, size_t workspace_bytes,
+                                         fg_stream_t stream) {
+  if (N <= 0 || capacity <= 0 || !cum_tiles) return FG_ERR_INVALID_ARG;
+  return bin_emit_sort_any(N, capacity, cum_tiles + (N - 1), means2d, radii, order, cum_tiles, tile_size, tile_w,
+                           tile_h, tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream);
 }
 
 extern "C" int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* flatten_ids,

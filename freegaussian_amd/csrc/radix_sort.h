@@ -29,8 +29,10 @@ __device__ __forceinline__ unsigned digit_of(KeyT key, int shift) {
 
 template <typename KeyT>
 __global__ void __launch_bounds__(BLOCK)
-hist_kernel(int64_t n, const KeyT* __restrict__ keys, int shift, uint32_t* __restrict__ block_hist) {
+hist_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys, int shift,
+            uint32_t* __restrict__ block_hist) {
   __shared__ uint32_t hist[RADIX];
+  if (n_dev) n = min(n, *n_dev);  // device-side count (capacity launch): n is then the capacity
   hist[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
@@ -78,9 +80,10 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
 
 template <typename KeyT>
 __global__ void __launch_bounds__(BLOCK, 3)
-scatter_kernel(int64_t n, const KeyT* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-               KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int shift,
-               const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
+scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys_in,
+               const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+               int shift, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
+  if (n_dev) n = min(n, *n_dev);
   __shared__ uint32_t wave_cnt[WAVES][RADIX];
   __shared__ uint32_t scan_tmp[WAVES];
   __shared__ uint32_t global_delta[RADIX];  // (global slot) - (slot in the LDS image) per digit
@@ -218,9 +221,11 @@ static inline size_t workspace_bytes(int64_t n) {
 }
 
 // Sorts in place (result copied back into keys/vals if it ends in the scratch copy).
+// With n_dev != nullptr the element count is min(n, *n_dev), read on the device: n is then only the
+// capacity the launch grids and the scratch are sized for (no host round trip for the count).
 template <typename KeyT>
 static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit, void* workspace,
-                             size_t ws_bytes, hipStream_t s) {
+                             size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr) {
   if (n <= 1 || end_bit <= 0) return FG_OK;
   if (n > 0xFFFFFFFFll) return FG_ERR_UNSUPPORTED;
   if (ws_bytes < workspace_bytes<KeyT>(n)) return FG_ERR_WORKSPACE;
@@ -239,9 +244,9 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   const int passes = (end_bit + RADIX_BITS - 1) / RADIX_BITS;
   for (int p = 0; p < passes; ++p) {
     const int shift = p * RADIX_BITS;
-    hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, kin, shift, block_hist);
+    hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(RADIX), dim3(BLOCK), 0, s, nb, block_hist, digit_total);
-    hipLaunchKernelGGL(scatter_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, kin, vin, kout, vout, shift,
+    hipLaunchKernelGGL(scatter_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, vin, kout, vout, shift,
                        block_hist, digit_total);
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;

@@ -151,8 +151,19 @@ class FreeGaussianModel(nn.Module):
         """viewmat, K, W, H at the scheduled resolution (:806-815)."""
         s = self._get_downscale_factor()
         camera.rescale_output_resolution(1 / s)
-        viewmat = get_viewmat(camera.camera_to_worlds.to(self.device))
-        K = camera.get_intrinsics_matrices().to(self.device)
+        c2w = camera.camera_to_worlds
+        if c2w.is_cuda or self.device.type != "cuda":
+            viewmat = get_viewmat(c2w.to(self.device))
+            K = camera.get_intrinsics_matrices().to(self.device)
+        else:
+            # host-side pose: 25 floats through a pinned buffer, asynchronously.  A pageable
+            # `.to(device)` blocks the host until the queue has drained, i.e. until the previous
+            # step's backward has finished -- the host could then never run ahead of the GPU.
+            stage = torch.empty(25, dtype=torch.float32).pin_memory()
+            stage[:16] = get_viewmat(c2w.float()).reshape(-1)
+            stage[16:] = camera.get_intrinsics_matrices().reshape(-1)
+            dev = stage.to(self.device, non_blocking=True)
+            viewmat, K = dev[:16].view(1, 4, 4), dev[16:].view(1, 3, 3)
         W, H = int(camera.width), int(camera.height)
         self.last_size = (H, W)
         camera.rescale_output_resolution(s)

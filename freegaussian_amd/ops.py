@@ -197,6 +197,19 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
     return isect_ids, flatten_ids, offsets
 
 
+# bin_tiles: capacity guesses per (device, N, tile grid) and pinned readback buffers per device
+speculative_binning = True
+_isect_capacity: dict = {}
+_count_buffers: dict = {}
+
+
+def _count_buffer(dev) -> torch.Tensor:
+    buf = _count_buffers.get(dev)
+    if buf is None:
+        buf = _count_buffers[dev] = torch.empty(1, dtype=torch.int64).pin_memory()
+    return buf
+
+
 @torch.no_grad()
 def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h):
     """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
@@ -215,9 +228,31 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h):
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
     _call("fg_bin_prepare", N, _ptr(depths), _ptr(radii), _ptr(tiles_touched), _ptr(order), _ptr(cum), _ptr(ws),
           ws.numel(), _stream())  # fmt: skip
-    n_isects = int(cum[-1].item())
+    # The list length lives on the device.  Instead of stalling the queue on it, the emit + tile
+    # sort are enqueued right away on buffers sized from the previous call of the same shape
+    # (fg_bin_emit_sort_capacity reads the count on the device); the host then waits only for an
+    # asynchronous readback -- the GPU keeps working meanwhile -- and repeats the call with exact
+    # buffers in the rare case the guess was too small.
+    key = (dev, N, tile_w, tile_h)
+    count_host = _count_buffer(dev)
+    count_host.copy_(cum[N - 1 :], non_blocking=True)
+    ready = torch.cuda.Event()
+    ready.record()
+    capacity = _isect_capacity.get(key) if speculative_binning else None
+    tile_keys = flatten_ids = None
+    if capacity is not None:
+        tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev)
+        flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
+        ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(capacity)), dtype=torch.uint8, device=dev)
+        _call("fg_bin_emit_sort_capacity", N, capacity, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
+              tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
+    ready.synchronize()
+    n_isects = int(count_host[0])
     if n_isects >= 2**31:
         raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+    _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
+    if capacity is not None and n_isects <= capacity:
+        return tile_keys[:n_isects], flatten_ids[:n_isects], offsets
     tile_keys = torch.empty(n_isects, dtype=torch.int32, device=dev)
     flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
     ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)

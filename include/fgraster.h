@@ -125,6 +125,16 @@ int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_
                      const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
                      int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
                      void* workspace, size_t workspace_bytes, fg_stream_t stream);
+/* fg_bin_emit_sort without the host round trip for the count: the buffers hold `capacity`
+ * entries (tile_keys[capacity], flatten_ids[capacity], workspace for `capacity`), the number of
+ * intersections is read ON THE DEVICE from cum_tiles[N-1].  When that count exceeds the capacity
+ * the lists are truncated and invalid: the caller compares its own (asynchronous) readback of
+ * cum_tiles[N-1] with the capacity and repeats the call with exact buffers in that case. */
+int fg_bin_emit_sort_capacity(int N, int64_t capacity, const float* means2d, const int32_t* radii,
+                              const int32_t* order, const int64_t* cum_tiles, int tile_size,
+                              int tile_w, int tile_h, uint32_t* tile_keys, int32_t* flatten_ids,
+                              int32_t* tile_offsets, void* workspace, size_t workspace_bytes,
+                              fg_stream_t stream);
 int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* flatten_ids,
                   const float* depths, int64_t* isect_ids, fg_stream_t stream);
 

@@ -19,7 +19,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 W, H = 1920, 1080
 dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
-cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9)
+cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9,
+                              fused_front_end=not os.environ.get("FG_UNFUSED"))
 model = FreeGaussianModel(cfg, seed_points=sc.means)
 with torch.no_grad():
     gp = model.gauss_params
@@ -54,11 +55,12 @@ ops.stage_timer = ops.StageTimer()
 t0 = time.perf_counter()
 for _ in range(steps):
     step()
+issue = (time.perf_counter() - t0) / steps * 1e3  # host time to enqueue a step (includes the one host sync)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps * 1e3
 stages = ops.stage_timer.summary()
 ops.stage_timer = None
-res = {"model_step_ms": dt, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
+res = {"model_step_ms": dt, "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
 if os.environ.get("FG_MODEL_PROFILE"):
     from torch.profiler import ProfilerActivity, profile
 

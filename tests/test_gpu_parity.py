@@ -145,6 +145,30 @@ def test_sort_pairs32_bit_exact_and_stable(n, end_bit):
     assert torch.equal(k.cpu().long(), ref_k) and torch.equal(v.cpu(), vals[order])
 
 
+def test_speculative_binning_capacity_and_overflow():
+    """bin_tiles enqueues emit + sort on guessed buffers (count read on the device) and only then
+    waits for the count: same lists as the exact call; a guess that is too small is redone."""
+    sc = _scene(n=30000, w=320, h=200, seed=11)
+    p = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], sc.width, sc.height)
+    tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
+    args = (p.means2d.to(DEV), p.radii.to(DEV), p.depths.to(DEV), p.tiles_touched.to(DEV), 16, tw, th)
+    ops._isect_capacity.clear()
+    ops.speculative_binning = False
+    k0, f0, o0 = ops.bin_tiles(*args)
+    ops.speculative_binning = True
+    key = next(iter(ops._isect_capacity))
+    assert ops._isect_capacity[key] >= f0.numel()
+    k1, f1, o1 = ops.bin_tiles(*args)  # capacity path
+    assert f1.numel() == f0.numel() and f1._base is not None  # a slice of the capacity buffer
+    assert torch.equal(k0, k1) and torch.equal(f0, f1) and torch.equal(o0, o1)
+    ops._isect_capacity[key] = max(f0.numel() // 3, 1)  # far too small: truncated, detected, redone
+    k2, f2, o2 = ops.bin_tiles(*args)
+    assert torch.equal(k0, k2) and torch.equal(f0, f2) and torch.equal(o0, o2)
+    ops._isect_capacity[key] = f0.numel()  # exactly enough
+    k3, f3, o3 = ops.bin_tiles(*args)
+    assert torch.equal(k0, k3) and torch.equal(f0, f3) and torch.equal(o0, o3)
+
+
 def test_isect_empty_scene():
     """All Gaussians behind the camera: I = 0, every range empty, render = 0."""
     sc = plumbing_scene()
