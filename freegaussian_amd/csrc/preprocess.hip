@@ -78,55 +78,85 @@ __device__ __forceinline__ Activated load_activated(const RawForm& raw, int i, c
   return a;
 }
 
-// Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows at column
-// lds_col0, keeping the first use_floats columns of each row.  16-byte loads whenever the slab is
-// a whole number of float4 (any row length: the (row, column) of the four elements is stepped).
-__device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_stride, int lds_col0,
-                                               const float* __restrict__ src, int nrows, int row_floats,
-                                               int use_floats) {
+// Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows (stride STRIDE) at
+// column lds_col0, keeping the first use_floats columns of each row.  16-byte loads whenever the
+// slab is a whole number of float4, for ANY row length: all loads of a lane are issued first, the
+// (row, column) of an element comes from a multiply-shift division (exact for rows <= 48 floats
+// and slabs <= 2^14 elements), row wrap inside a float4 is branch-free and dropped columns land
+// in the row's last pad slot (column STRIDE-1), so there is no divergent code between load and store.
+constexpr int SLAB_MAX_Q = (BLOCK * 48 / 4 + BLOCK - 1) / BLOCK;  // float4 per lane of a full slab
+
+template <int STRIDE = ROW>
+__device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const float* __restrict__ src, int nrows,
+                                               int row_floats, int use_floats) {
   const int total = nrows * row_floats;
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const float4* src4 = reinterpret_cast<const float4*>(src);
-    for (int q = threadIdx.x; q < total / 4; q += BLOCK) {
-      const float4 v = src4[q];
-      const float vv[4] = {v.x, v.y, v.z, v.w};
-      int r = (4 * q) / row_floats, c = 4 * q - r * row_floats;
+    const int total4 = total / 4;
+    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
+    float4 v[SLAB_MAX_Q];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        if (c < use_floats) lds[r * lds_stride + lds_col0 + c] = vv[j];
-        if (++c == row_floats) { c = 0; ++r; }
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) v[t] = src4[q];
+    }
+#pragma unroll
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) {
+        const int e = 4 * q;
+        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
+        const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const bool wrap = c + jj >= row_floats;
+          const int cc = wrap ? c + jj - row_floats : c + jj;
+          const int row_base = (wrap ? r + 1 : r) * STRIDE;
+          lds[row_base + (cc < use_floats ? lds_col0 + cc : STRIDE - 1)] = vv[jj];
+        }
       }
     }
   } else {
     const int tot = nrows * use_floats;
     for (int e = threadIdx.x; e < tot; e += BLOCK) {
       const int r = e / use_floats, c = e - r * use_floats;
-      lds[r * lds_stride + lds_col0 + c] = src[(size_t)r * row_floats + c];
+      lds[r * STRIDE + lds_col0 + c] = src[(size_t)r * row_floats + c];
     }
   }
 }
 
 // The inverse: padded LDS rows (from column lds_col0) out to a contiguous [nrows x row_floats]
 // slab; columns >= lds_cols are written as zero.
-__device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_stride,
-                                               int lds_col0, int nrows, int row_floats, int lds_cols) {
+template <int STRIDE = ROW>
+__device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_col0, int nrows,
+                                               int row_floats, int lds_cols) {
   const int total = nrows * row_floats;
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     float4* dst4 = reinterpret_cast<float4*>(dst);
-    for (int q = threadIdx.x; q < total / 4; q += BLOCK) {
-      int r = (4 * q) / row_floats, c = 4 * q - r * row_floats;
-      float vv[4];
+    const int total4 = total / 4;
+    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        vv[j] = (c < lds_cols) ? lds[r * lds_stride + lds_col0 + c] : 0.f;
-        if (++c == row_floats) { c = 0; ++r; }
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) {
+        const int e = 4 * q;
+        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
+        float vv[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const bool wrap = c + jj >= row_floats;
+          const int cc = wrap ? c + jj - row_floats : c + jj;
+          const int row_base = (wrap ? r + 1 : r) * STRIDE;
+          const float x = lds[row_base + (cc < lds_cols ? lds_col0 + cc : STRIDE - 1)];
+          vv[jj] = cc < lds_cols ? x : 0.f;
+        }
+        dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       }
-      dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
     }
   } else {
     for (int e = threadIdx.x; e < total; e += BLOCK) {
       const int r = e / row_floats, c = e - r * row_floats;
-      dst[e] = (c < lds_cols) ? lds[r * lds_stride + lds_col0 + c] : 0.f;
+      dst[e] = (c < lds_cols) ? lds[r * STRIDE + lds_col0 + c] : 0.f;
     }
   }
 }
@@ -134,52 +164,10 @@ __device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const fl
 // raw form: SH coefficient rows of a workgroup, split in two arrays -> LDS rows [dc | rest]
 __device__ __forceinline__ void coeffs_to_lds(float* lds, const RawForm& raw, const float* __restrict__ colors,
                                               int row0, int nrows, int k_stored, int kk) {
-  slab_to_lds_at(lds, ROW, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc
+  slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc
   if (kk > 1)
-    slab_to_lds_at(lds, ROW, 3, raw.features_rest + (size_t)row0 * 3 * (k_stored - 1), nrows, 3 * (k_stored - 1),
+    slab_to_lds_at(lds, 3, raw.features_rest + (size_t)row0 * 3 * (k_stored - 1), nrows, 3 * (k_stored - 1),
                    3 * (kk - 1));
-}
-
-// coalesced copy of a workgroup's contiguous [nrows x row_floats] slab into padded LDS rows
-__device__ __forceinline__ void slab_to_lds(float* lds, int lds_stride, const float* __restrict__ src, int nrows,
-                                            int row_floats, int use_floats) {
-  if (use_floats == row_floats && (row_floats & 3) == 0) {
-    const float4* src4 = reinterpret_cast<const float4*>(src);
-    const int total4 = nrows * row_floats / 4;
-    for (int q = threadIdx.x; q < total4; q += BLOCK) {
-      const float4 v = src4[q];
-      const int e = 4 * q, r = e / row_floats, c = e - r * row_floats;
-      float* d = lds + r * lds_stride + c;
-      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
-    }
-  } else {
-    const int total = nrows * use_floats;
-    for (int e = threadIdx.x; e < total; e += BLOCK) {
-      const int r = e / use_floats, c = e - r * use_floats;
-      lds[r * lds_stride + c] = src[(size_t)r * row_floats + c];
-    }
-  }
-}
-
-// coalesced copy of padded LDS rows out to a contiguous [nrows x row_floats] slab; columns
-// >= lds_cols are written as zero
-__device__ __forceinline__ void lds_to_slab(float* __restrict__ dst, const float* lds, int lds_stride, int nrows,
-                                            int row_floats, int lds_cols) {
-  if ((row_floats & 3) == 0 && (lds_cols & 3) == 0) {
-    float4* dst4 = reinterpret_cast<float4*>(dst);
-    const int total4 = nrows * row_floats / 4;
-    for (int q = threadIdx.x; q < total4; q += BLOCK) {
-      const int e = 4 * q, r = e / row_floats, c = e - r * row_floats;
-      const float* s = lds + r * lds_stride + c;
-      dst4[q] = (c < lds_cols) ? make_float4(s[0], s[1], s[2], s[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-  } else {
-    const int total = nrows * row_floats;
-    for (int e = threadIdx.x; e < total; e += BLOCK) {
-      const int r = e / row_floats, c = e - r * row_floats;
-      dst[e] = (c < lds_cols) ? lds[r * lds_stride + c] : 0.f;
-    }
-  }
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -198,7 +186,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
   if (kk > 0) {
     if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
-    else slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+    else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
   }
 
   // ---- K1 -------------------------------------------------------------------------------------
@@ -293,7 +281,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
     for (int c = 0; c < REC; ++c) row[c] = rec[c];
   }
   __syncthreads();
-  lds_to_slab(splats + (size_t)row0 * REC, lds, RSTRIDE, nrows, REC, REC);
+  lds_to_slab_at<RSTRIDE>(splats + (size_t)row0 * REC, lds, 0, nrows, REC, REC);
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -314,10 +302,10 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
-  slab_to_lds(lds_rec, RSTRIDE, v_splats + (size_t)row0 * REC, nrows, REC, REC);
+  slab_to_lds_at<RSTRIDE>(lds_rec, 0, v_splats + (size_t)row0 * REC, nrows, REC, REC);
   if (kk > 1) {
     if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
-    else slab_to_lds(lds, ROW, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+    else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
   }
   __syncthreads();
 
@@ -450,12 +438,12 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
     }
     __syncthreads();
     if (raw.enabled) {
-      lds_to_slab_at(v_colors + (size_t)row0 * 3, lds, ROW, 0, nrows, 3, 3);  // v_features_dc
+      lds_to_slab_at(v_colors + (size_t)row0 * 3, lds, 0, nrows, 3, 3);  // v_features_dc
       if (fl.k_stored > 1)
-        lds_to_slab_at(v_features_rest + (size_t)row0 * 3 * (fl.k_stored - 1), lds, ROW, 3, nrows,
+        lds_to_slab_at(v_features_rest + (size_t)row0 * 3 * (fl.k_stored - 1), lds, 3, nrows,
                        3 * (fl.k_stored - 1), 45);
     } else {
-      lds_to_slab(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, ROW, nrows, 3 * fl.k_stored, 48);
+      lds_to_slab_at(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, 0, nrows, 3 * fl.k_stored, 48);
     }
   }
 }

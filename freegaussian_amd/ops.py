@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import _lib
@@ -198,7 +200,7 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
 
 
 # bin_tiles: capacity guesses per (device, N, tile grid) and pinned readback buffers per device
-speculative_binning = True
+speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
 _isect_capacity: dict = {}
 _count_buffers: dict = {}
 

@@ -151,8 +151,10 @@ def test_speculative_binning_capacity_and_overflow():
     sc = _scene(n=30000, w=320, h=200, seed=11)
     p = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], sc.width, sc.height)
     tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
-    args = (p.means2d.to(DEV), p.radii.to(DEV), p.depths.to(DEV), p.tiles_touched.to(DEV), 16, tw, th)
+    cnt, _, _ = O.isect_tiles(p.means2d, p.radii, p.depths, 16, tw, th, sort=False)
+    args = (p.means2d.to(DEV), p.radii.to(DEV), p.depths.to(DEV), cnt.to(DEV), 16, tw, th)
     ops._isect_capacity.clear()
+    was = ops.speculative_binning
     ops.speculative_binning = False
     k0, f0, o0 = ops.bin_tiles(*args)
     ops.speculative_binning = True
@@ -167,6 +169,7 @@ def test_speculative_binning_capacity_and_overflow():
     ops._isect_capacity[key] = f0.numel()  # exactly enough
     k3, f3, o3 = ops.bin_tiles(*args)
     assert torch.equal(k0, k3) and torch.equal(f0, f3) and torch.equal(o0, o3)
+    ops.speculative_binning = was
 
 
 def test_isect_empty_scene():
