@@ -297,12 +297,10 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
                       float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
                       float* __restrict__ v_extra) {
   __shared__ float lds[BLOCK * ROW];       // coefficient slab in, v_coeffs slab out
-  __shared__ float lds_rec[BLOCK * RSTRIDE];  // gradient records
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
-  slab_to_lds_at<RSTRIDE>(lds_rec, 0, v_splats + (size_t)row0 * REC, nrows, REC, REC);
   if (kk > 1) {
     if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
     else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
@@ -321,9 +319,15 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   const bool active = (i < N) && radii[i] > 0;
   Activated a;
   if (active) {
-    const float* row = lds_rec + threadIdx.x * RSTRIDE;
+    // the lane's own 64-byte gradient record, four 16-byte loads (the lines are shared by the four
+    // loads and served from cache after the first; staging them through LDS as well would cost
+    // 20 KB per workgroup, i.e. a third of the resident wavefronts of this bandwidth-bound pass)
+    const float4* rp = reinterpret_cast<const float4*>(v_splats) + (size_t)i * (REC / 4);
 #pragma unroll
-    for (int c = 0; c < REC; ++c) rec[c] = row[c];
+    for (int q4 = 0; q4 < REC / 4; ++q4) {
+      const float4 v = rp[q4];
+      rec[4 * q4] = v.x; rec[4 * q4 + 1] = v.y; rec[4 * q4 + 2] = v.z; rec[4 * q4 + 3] = v.w;
+    }
     const Cam cam = load_cam(viewmat, K);
     const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
     a = load_activated(raw, i, quats, scales, opacities);

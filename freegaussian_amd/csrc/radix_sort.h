@@ -32,14 +32,22 @@ __global__ void __launch_bounds__(BLOCK)
 hist_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys, int shift,
             uint32_t* __restrict__ block_hist) {
   __shared__ uint32_t hist[RADIX];
-  if (n_dev) n = min(n, *n_dev);  // device-side count (capacity launch): n is then the capacity
   hist[threadIdx.x] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * TILE;
-#pragma unroll 4
+  // keys are loaded up to the capacity n (in bounds); the device-side count, if any, is read in
+  // the same batch of loads and applied afterwards, so its latency is not serialised in front
+  KeyT key[KEYS_PER_THREAD];
+#pragma unroll
   for (int k = 0; k < KEYS_PER_THREAD; ++k) {
     const int64_t i = base + k * BLOCK + threadIdx.x;
-    if (i < n) atomicAdd(&hist[digit_of(keys[i], shift)], 1u);
+    key[k] = i < n ? keys[i] : (KeyT)0;
+  }
+  if (n_dev) n = min(n, *n_dev);
+#pragma unroll
+  for (int k = 0; k < KEYS_PER_THREAD; ++k) {
+    const int64_t i = base + k * BLOCK + threadIdx.x;
+    if (i < n) atomicAdd(&hist[digit_of(key[k], shift)], 1u);
   }
   __syncthreads();
   block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x] = hist[threadIdx.x];
@@ -83,7 +91,7 @@ __global__ void __launch_bounds__(BLOCK, 3)
 scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys_in,
                const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                int shift, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
-  if (n_dev) n = min(n, *n_dev);
+  const int64_t cap = n;
   __shared__ uint32_t wave_cnt[WAVES][RADIX];
   __shared__ uint32_t scan_tmp[WAVES];
   __shared__ uint32_t global_delta[RADIX];  // (global slot) - (slot in the LDS image) per digit
@@ -130,10 +138,11 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
 #pragma unroll
   for (int k = 0; k < KEYS_PER_THREAD; ++k) {
     const int64_t i = wave_base + k * 64 + lane;
-    const bool in = i < n;
+    const bool in = i < cap;  // in bounds of the buffers; the count proper is applied below
     key[k] = in ? keys_in[i] : (KeyT)~(KeyT)0;
     val[k] = in ? vals_in[i] : 0u;
   }
+  if (n_dev) n = min(n, *n_dev);  // device-side count: read alongside the keys, not in front of them
 #pragma unroll
   for (int k = 0; k < KEYS_PER_THREAD; ++k) {
     const bool in = wave_base + k * 64 + lane < n;
