@@ -218,8 +218,8 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
   }
 }
 
-// ---- single-kernel passes ("onesweep": chained scan with decoupled look-back) ---------------
-// One launch per pass instead of three.  The digit histograms of ALL passes come from one upfront
+// ---- single-kernel passes ("onesweep": chained scan with decoupled look-back), OPTIONAL -------
+// One launch per pass instead of three (off by default: see use_onesweep()).  The digit histograms of ALL passes come from one upfront
 // read of the keys (global_hist_kernel).  In a pass, a workgroup takes its tile number from an
 // atomic ticket (so tile t-1 is always already running when tile t waits on it), ranks its keys,
 // publishes its per-digit counts in status[tile][digit] (flag in the top two bits: AGGREGATE =
@@ -419,10 +419,14 @@ static inline size_t workspace_bytes(int64_t n) {
   return align256((size_t)n * sizeof(KeyT)) + align256((size_t)n * 4) + control_bytes(n);
 }
 
+// Measured on MI355X (profiles/r01_onesweep.md): the chained scan loses here.  A status word
+// crosses XCDs at ~1-2 us per hop and the ~770 tiles of the first wave all start together, so the
+// look-back chain costs more than the two small launches it removes (tile sort of 7.2M pairs:
+// 0.225 ms vs 0.181 ms).  Kept behind FG_SORT_ONESWEEP=1 for re-measurement on other sizes.
 static inline bool use_onesweep() {
   static const bool v = [] {
     const char* e = getenv("FG_SORT_ONESWEEP");
-    return !(e && e[0] == '0');
+    return e && e[0] == '1';
   }();
   return v;
 }
