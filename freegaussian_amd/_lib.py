@@ -53,6 +53,11 @@ SIGNATURES = {
                                       P]),
     "fg_preprocess_raw_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                       c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fg_densify_flags": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P,
+                                 P, P, P, P]),
+    "fg_densify_map": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
+    "fg_gather_rows": (c_int, [c_int64, c_int, P, P, c_int64, P, P]),
+    "fg_split_children": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -66,6 +66,18 @@ class FreeGaussianModelConfig:
     sh_degree_interval: int = 1000
     sh_degree: int = 3
     stop_split_at: int = 15000
+    # adaptive density control (:58-88), consumed by freegaussian_amd.densify.refinement_after
+    refine_start: int = 500
+    cull_alpha_thresh: float = 0.1
+    cull_scale_thresh: float = 0.5
+    continue_cull_post_densification: bool = True
+    reset_alpha_every: int = 30
+    densify_grad_thresh: float = 0.0008
+    densify_size_thresh: float = 0.01
+    n_split_samples: int = 2
+    cull_screen_size: float = 0.15
+    split_screen_size: float = 0.05
+    stop_screen_size_at: int = 4000
     output_depth_during_training: bool = False
     rasterize_mode: str = "classic"
     num_random: int = 50000

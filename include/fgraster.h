@@ -243,6 +243,43 @@ int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const f
                           float* v_features_dc, float* v_features_rest, float* v_extra,
                           fg_stream_t stream);
 
+/* ---- D: adaptive density control ---------------------------------
+ * The reference's refinement_after / split_gaussians / dup_gaussians / cull_gaussians and the
+ * Adam-state surgery around them (freegaussian_model.py:313-367, :404-571), as: one decision
+ * pass, prefix sums (the caller's), one map pass, ONE coalesced row copy per tensor into its final
+ * place, one fix-up pass over the new rows.
+ *
+ * fg_densify_flags: flags[N], bit 0 split, bit 1 duplicate, bit 2 old row survives, bit 3 its
+ * split children survive the cull, bit 4 its duplicate survives.  Thresholds as in the config
+ * (:68-88); pass split_screen_size / cull_scale_thresh / cull_screen_size < 0 to disable the
+ * step-dependent tests (:425, :505-511); do_densify = 0 is the cull-only branch (:466-467).
+ * max_dim = max(H, W) of the last render (:421).  max_2dsize nullable. */
+int fg_densify_flags(int N, int do_densify, float max_dim, float densify_grad_thresh,
+                     float densify_size_thresh, float split_screen_size, float cull_alpha_thresh,
+                     float cull_scale_thresh, float cull_screen_size, const float* xys_grad_norm,
+                     const float* vis_counts, const float* max_2dsize, const float* log_scales,
+                     const float* opacity_logits, uint8_t* flags, fg_stream_t stream);
+/* pos_old / pos_child / pos_dup [N]: EXCLUSIVE prefix sums of flag bits 2 / 3 / 4; rank_split[N]:
+ * of bit 0.  n_old, n_child: totals of bits 2, 3; n_split_total: of bit 0.  Row order of the new set
+ * (the reference's): surviving old rows, children sample-major, duplicates.  Outputs for every
+ * new-set row j: src_index[j] = the old row it copies; sample_index[j] = row of the
+ * randn((n_split_samples * n_split_total, 3)) draw (:530) for a child, -2 for the duplicate of a
+ * split parent (it carries the shrunk scales: `dups` is evaluated after the in-place shrink,
+ * :428-431), -1 otherwise. */
+int fg_densify_map(int N, const uint8_t* flags, const int32_t* pos_old, const int32_t* pos_child,
+                   const int32_t* pos_dup, const int32_t* rank_split, int n_old, int n_child,
+                   int n_split_total, int n_split_samples, int32_t* src_index, int32_t* sample_index,
+                   fg_stream_t stream);
+/* dst[j,:] = src[src_index[j],:] for rows of row_floats floats; rows j >= zero_from are zeroed
+ * instead (new rows of the Adam moments, :343-356). */
+int fg_gather_rows(int64_t n_rows, int row_floats, const float* src, const int32_t* src_index,
+                   int64_t zero_from, float* dst, fg_stream_t stream);
+/* In place on rows [first_row, first_row + n_rows) of the NEW set: children (sample_index >= 0):
+ * mean += R(q/|q|) (exp(s) * z), s = log(exp(s)/1.6) (:530-549); sample_index == -2: only the
+ * scales shrink. */
+int fg_split_children(int first_row, int n_rows, const int32_t* sample_index, const float* samples,
+                      float* means, float* log_scales, const float* quats, fg_stream_t stream);
+
 /* ---- F: flow derivative -------------------------------------------------------------------
  * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at
  * integer coordinates, infinite depth -> 0, :315-317).  depth[H,W], veloc[3], omega[3],
