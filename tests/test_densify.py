@@ -151,3 +151,37 @@ def test_hip_densify_matches_oracle(step, cfg_kw):
     for k in PARAM_NAMES:
         assert plain.gauss_params[k].shape == model.gauss_params[k].shape
         assert torch.allclose(plain.gauss_params[k], model.gauss_params[k], rtol=1e-5, atol=1e-6), k
+
+
+@pytest.mark.gpu
+def test_training_with_densification_through_the_harness():
+    """A short optimisation run with refinement every 10 steps: Gaussians are split / duplicated /
+    culled, every optimizer keeps tracking the replaced parameter, and the fit keeps improving."""
+    import sys, os
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _model_and_camera
+    from freegaussian_amd import harness as Hn
+
+    model, _, cam = _model_and_camera(n=3000, W=128, H=96, step=20, training=True)
+    c = model.config
+    c.warm_up, c.refine_start, c.refine_every, c.reset_alpha_every = 10**9, 20, 10, 3
+    c.densify_grad_thresh, c.stop_screen_size_at, c.sh_degree_interval = 2e-5, 0, 1
+    target = copy.deepcopy(model)
+    with torch.no_grad():
+        target.gauss_params["features_dc"].add_(0.3 * torch.randn_like(target.gauss_params["features_dc"]))
+        target.gauss_params["means"].add_(0.02 * torch.randn_like(target.gauss_params["means"]))
+    target.eval()
+    with torch.no_grad():
+        gt = target.get_outputs(copy.deepcopy(cam))["rgb"].clamp(0, 1)
+    opts = Hn.build_optimizers(model)
+    hist = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 20 + i, num_train_data=2) for i in range(45)]
+    counts = [h["gaussian_count"] for h in hist]
+    assert len(set(counts)) > 1 and counts[-1] != 3000  # densification happened
+    assert all(torch.isfinite(torch.tensor(h["loss"])) for h in hist)
+    assert hist[-1]["loss"] < 0.8 * hist[0]["loss"]
+    for k in PARAM_NAMES:
+        o = opts[k]
+        p = o.param_groups[0]["params"][0]
+        assert p is model.gauss_params[k] and p.shape[0] == counts[-1]
+        assert o.state[p]["exp_avg"].shape == p.shape
