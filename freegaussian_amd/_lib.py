@@ -58,6 +58,7 @@ SIGNATURES = {
     "fg_densify_map": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "fg_gather_rows": (c_int, [c_int64, c_int, P, P, c_int64, P, P]),
     "fg_split_children": (c_int, [c_int, c_int, P, P, P, P, P, P]),
+    "fg_mask_backproject": (c_int, [c_int, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
     "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),

@@ -280,6 +280,20 @@ int fg_gather_rows(int64_t n_rows, int row_floats, const float* src, const int32
 int fg_split_children(int first_row, int n_rows, const int32_t* sample_index, const float* samples,
                       float* means, float* log_scales, const float* quats, fg_stream_t stream);
 
+/* ---- M: attribute-mask back-projection -------------------------
+ * One key frame of preprocess/knn_gaussian.py:116-132: every visible Gaussian (radii > 0) whose
+ * centre, truncated toward zero, lies in the image and whose depth agrees with the rendered
+ * expected depth there (-0.1 d < d - depth_i < d) ORs that pixel's labels into its row:
+ *   gaussian_masks[i, j] |= atrb_masks[y, x, j] & mask_valids[j]      j < n_attributes
+ * atrb_masks[H,W,n_labels_stored] and mask_valids[n_labels_stored] are bool (1 byte), the last
+ * stored label (background) is dropped as the reference's `[..., :-1]` does: pass
+ * n_attributes = n_labels_stored - 1.  gaussian_masks[N,n_attributes] bool, caller-zeroed, is
+ * accumulated over frames and saved as gaussian_mask_NxM.npy (freegaussian_pipeline.py:45-47). */
+int fg_mask_backproject(int N, const float* means2d, const float* depths, const int32_t* radii,
+                        const float* depth_map, int width, int height, const uint8_t* atrb_masks,
+                        const uint8_t* mask_valids, int n_labels_stored, int n_attributes,
+                        uint8_t* gaussian_masks, fg_stream_t stream);
+
 /* ---- F: flow derivative -------------------------------------------------------------------
  * Per-pixel camera flow A v / Z + B w (preprocess/epipolar_flow.py:274-309; pixel centres at
  * integer coordinates, infinite depth -> 0, :315-317).  depth[H,W], veloc[3], omega[3],
