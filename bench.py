@@ -38,8 +38,8 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--n-gauss", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -119,8 +119,18 @@ def cpu_baseline(scene, view, crop, sh_degree):
                                  render_mode="RGB", packed=False)  # fmt: skip
     (r * vr).sum().backward()
     dt = time.perf_counter() - t0
+    # PSNR of the HIP render against the oracle render of the same crop
+    psnr_db = None
+    if torch.cuda.is_available():
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with torch.no_grad():
+            rg, _, _ = rasterization(*[t.detach().to(dev) for t in ins], scene.viewmats[view : view + 1].to(dev),
+                                     K[None].to(dev), cw, ch, sh_degree=sh_degree, render_mode="RGB", packed=False)  # fmt: skip
+        mse = float(((rg.cpu().double() - r.detach().double()) ** 2).mean())
+        psnr_db = 200.0 if mse == 0 else min(200.0, -10.0 * __import__("math").log10(mse))
     return {
         "value": cw * ch / dt / 1e6,
+        "psnr_hip_vs_oracle_db": psnr_db,
         "unit": "Mpix/s",
         "cores": cores,
         "host_cpus": os.cpu_count(),
@@ -160,15 +170,27 @@ def main():
     K = scene.Ks[view : view + 1].to(dev)
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
 
-    def step():
+    marks = []  # per step: HIP events at start / after forward / after backward / after the exchange
+
+    def step(timed=False):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
+        if ev:
+            ev[0].record()
         # gradients land directly in the flat all-reduce buffer (dense overwrite: no zeroing needed)
         with params.direct_grads():
             means, quats, scales, opac, colors = params.raster_inputs()
             r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
                                        render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+            if ev:
+                ev[1].record()
             r.backward(vr)  # upstream dL/d render = fixed N(0,1) image
+        if ev:
+            ev[2].record()
         if world > 1:
             params.all_reduce_grads()
+        if ev:
+            ev[3].record()
+            marks.append(ev)
         return info
 
     def fence():
@@ -182,7 +204,7 @@ def main():
     ops.stage_timer = ops.StageTimer()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        info = step()
+        info = step(timed=True)
     fence()
     dt = time.perf_counter() - t0
     stages = ops.stage_timer.summary()
@@ -215,6 +237,23 @@ def main():
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
     total_alg = 280 * N + (176 + 24 * k) * V + (100 + 24 * p) * I + 56 * P + 8 * T
+    # BASELINE.md section 3 protocol: per-step HIP-event times, median with p10 / p90
+    def pct(xs, q):
+        xs = sorted(xs)
+        return xs[min(len(xs) - 1, max(0, int(round(q * (len(xs) - 1)))))]
+
+    t_fwd = [e[0].elapsed_time(e[1]) for e in marks]
+    t_bwd = [e[1].elapsed_time(e[2]) for e in marks]
+    t_fb = [a + b for a, b in zip(t_fwd, t_bwd)]
+    t_xchg = [e[2].elapsed_time(e[3]) for e in marks]
+    event_times = {
+        "fwd_ms_median": pct(t_fwd, 0.5), "bwd_ms_median": pct(t_bwd, 0.5),
+        "fwd_plus_bwd_ms": {"median": pct(t_fb, 0.5), "p10": pct(t_fb, 0.1), "p90": pct(t_fb, 0.9)},
+        "mpix_per_s_per_gpu_from_median": P / (pct(t_fb, 0.5) * 1e-3) / 1e6,
+    }  # fmt: skip
+    if world > 1:
+        event_times["allreduce_ms_median"] = pct(t_xchg, 0.5)
+        event_times["allreduce_bytes"] = params.flat_grad.numel() * 4
     out = {
         "metric": "Mpixels/s fwd+bwd @ 1M Gaussians 1080p",
         "value": world * args.steps * P / dt / 1e6,
@@ -237,8 +276,10 @@ def main():
             "parallelism": f"view-dp{world}",
         },
         "roofline": roof,
+        "hip_event_times": event_times,
         "whole_step": {
             "algorithmic_bytes": total_alg,
+            "algorithmic_bytes_without_sort": total_alg - 24 * p * I,
             "achieved_GBs": total_alg / (dt / args.steps) / 1e9,
             "frac_of_hbm_peak": total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
         },
