@@ -15,6 +15,7 @@
 // unfused entry points.
 #include "project_math.h"
 #include "sh_math.h"
+#include "slab_io.h"
 
 namespace {
 using namespace fgp;
@@ -76,89 +77,6 @@ __device__ __forceinline__ Activated load_activated(const RawForm& raw, int i, c
   for (int c = 0; c < 3; ++c) a.s[c] = a.es[c] + (raw.d_scales ? raw.d_scales[3 * i + c] : 0.f);
   a.o = 1.f / (1.f + expf(-o));
   return a;
-}
-
-// Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows (stride STRIDE) at
-// column lds_col0, keeping the first use_floats columns of each row.  16-byte loads whenever the
-// slab is a whole number of float4, for ANY row length: all loads of a lane are issued first, the
-// (row, column) of an element comes from a multiply-shift division (exact for rows <= 48 floats
-// and slabs <= 2^14 elements), row wrap inside a float4 is branch-free and dropped columns land
-// in the row's last pad slot (column STRIDE-1), so there is no divergent code between load and store.
-constexpr int SLAB_MAX_Q = (BLOCK * 48 / 4 + BLOCK - 1) / BLOCK;  // float4 per lane of a full slab
-
-template <int STRIDE = ROW>
-__device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const float* __restrict__ src, int nrows,
-                                               int row_floats, int use_floats) {
-  const int total = nrows * row_floats;
-  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
-    const float4* src4 = reinterpret_cast<const float4*>(src);
-    const int total4 = total / 4;
-    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
-    float4 v[SLAB_MAX_Q];
-#pragma unroll
-    for (int t = 0; t < SLAB_MAX_Q; ++t) {
-      const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) v[t] = src4[q];
-    }
-#pragma unroll
-    for (int t = 0; t < SLAB_MAX_Q; ++t) {
-      const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) {
-        const int e = 4 * q;
-        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
-        const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const bool wrap = c + jj >= row_floats;
-          const int cc = wrap ? c + jj - row_floats : c + jj;
-          const int row_base = (wrap ? r + 1 : r) * STRIDE;
-          lds[row_base + (cc < use_floats ? lds_col0 + cc : STRIDE - 1)] = vv[jj];
-        }
-      }
-    }
-  } else {
-    const int tot = nrows * use_floats;
-    for (int e = threadIdx.x; e < tot; e += BLOCK) {
-      const int r = e / use_floats, c = e - r * use_floats;
-      lds[r * STRIDE + lds_col0 + c] = src[(size_t)r * row_floats + c];
-    }
-  }
-}
-
-// The inverse: padded LDS rows (from column lds_col0) out to a contiguous [nrows x row_floats]
-// slab; columns >= lds_cols are written as zero.
-template <int STRIDE = ROW>
-__device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_col0, int nrows,
-                                               int row_floats, int lds_cols) {
-  const int total = nrows * row_floats;
-  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
-    float4* dst4 = reinterpret_cast<float4*>(dst);
-    const int total4 = total / 4;
-    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
-#pragma unroll
-    for (int t = 0; t < SLAB_MAX_Q; ++t) {
-      const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) {
-        const int e = 4 * q;
-        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
-        float vv[4];
-#pragma unroll
-        for (int jj = 0; jj < 4; ++jj) {
-          const bool wrap = c + jj >= row_floats;
-          const int cc = wrap ? c + jj - row_floats : c + jj;
-          const int row_base = (wrap ? r + 1 : r) * STRIDE;
-          const float x = lds[row_base + (cc < lds_cols ? lds_col0 + cc : STRIDE - 1)];
-          vv[jj] = cc < lds_cols ? x : 0.f;
-        }
-        dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
-      }
-    }
-  } else {
-    for (int e = threadIdx.x; e < total; e += BLOCK) {
-      const int r = e / row_floats, c = e - r * row_floats;
-      dst[e] = (c < lds_cols) ? lds[r * STRIDE + lds_col0 + c] : 0.f;
-    }
-  }
 }
 
 // raw form: SH coefficient rows of a workgroup, split in two arrays -> LDS rows [dc | rest]
@@ -287,6 +205,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
 __global__ void __launch_bounds__(BLOCK)
 preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d_quats,
                       float* __restrict__ v_d_scales, float* __restrict__ v_features_rest,
+                      float* __restrict__ v_rgb,
                       const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
                       const float* __restrict__ colors, const float* __restrict__ viewmat,
@@ -431,8 +350,14 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       }
     }
   }
+  // factored SH gradient (view-DP exchange): the masked colour gradient itself, 12 B instead of the
+  // 192-B coefficient row it expands to (v_coeffs[k] = basis_k(dir) * v_rgb, rebuilt after the
+  // exchange by fg_sh_grad_accumulate)
+  if (v_rgb && i < N) {
+    v_rgb[3 * i] = vr; v_rgb[3 * i + 1] = vg; v_rgb[3 * i + 2] = vb;
+  }
   // ---- v_coeffs rows out through LDS -------------------------------------------------------------
-  if (kk > 0) {
+  if (kk > 0 && v_colors) {
     __syncthreads();  // everyone is done reading the coefficient slab
     float* row = lds + threadIdx.x * ROW;
 #pragma unroll
@@ -489,6 +414,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
 }
 
 int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scales, float* v_features_rest,
+                          float* v_rgb,
                           const float* means, const float* quats, const float* scales, const float* opacities,
                           const float* colors, int sh_degree, int k_stored, int n_color, int with_depth, int n_extra,
                           const float* viewmat, const float* K, int width, int height, float eps2d, int antialiased,
@@ -502,14 +428,17 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d ||
       !v_means || !v_quats || !v_scales || !v_opacities)
     return FG_ERR_INVALID_ARG;
-  if ((fl.n_color > 0 && (!colors || !v_colors)) || (n_extra > 0 && !v_extra)) return FG_ERR_INVALID_ARG;
+  // v_colors may be null only in the factored form (SH colours, v_rgb given instead)
+  if ((fl.n_color > 0 && (!colors || (!v_colors && !(v_rgb && sh_degree >= 0)))) || (n_extra > 0 && !v_extra))
+    return FG_ERR_INVALID_ARG;
+  if (v_rgb && (sh_degree < 0 || raw.enabled)) return FG_ERR_UNSUPPORTED;
   if (raw.enabled) {
     if (sh_degree < 0 || (k_stored > 1 && (!raw.features_rest || !v_features_rest))) return FG_ERR_INVALID_ARG;
     if ((raw.d_quats != nullptr) != (v_d_quats != nullptr) || (raw.d_scales != nullptr) != (v_d_scales != nullptr))
       return FG_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
-                     fl, raw, v_d_quats, v_d_scales, v_features_rest, means, quats, scales, opacities, colors,
+                     fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, means, quats, scales, opacities, colors,
                      viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                      v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra);
   FG_RETURN_IF_LAUNCH_FAILED();
@@ -540,7 +469,7 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
                                  const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                                  float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
                                  fg_stream_t stream) {
-  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, means, quats,
+  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr, means, quats,
                                scales, opacities, colors, sh_degree, k_stored, n_color, with_depth, n_extra, viewmat,
                                K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                                v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
@@ -575,8 +504,23 @@ extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* qua
                                      float* v_features_dc, float* v_features_rest, float* v_extra,
                                      fg_stream_t stream) {
   return launch_preprocess_bwd(N, RawForm{1, d_quats, d_scales, features_rest}, v_d_quats, v_d_scales,
-                               v_features_rest, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
+                               v_features_rest, nullptr, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
                                k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
                                v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats,
                                v_log_scales, v_opacity_logits, v_features_dc, v_extra, stream);
+}
+
+extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, const float* scales,
+                                          const float* opacities, const float* colors, int sh_degree, int k_stored,
+                                          int with_depth, int n_extra, const float* viewmat, const float* K,
+                                          int width, int height, float eps2d, int antialiased, const int32_t* radii,
+                                          const float* v_splats, const float* v_means2d, int v_means2d_stride,
+                                          const float* v_depths, const float* v_conics, float* v_means,
+                                          float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
+                                          float* v_extra, fg_stream_t stream) {
+  if (!v_rgb) return FG_ERR_INVALID_ARG;
+  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, v_rgb, means, quats,
+                               scales, opacities, colors, sh_degree, k_stored, 3, with_depth, n_extra, viewmat, K,
+                               width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
+                               v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, nullptr, v_extra, stream);
 }

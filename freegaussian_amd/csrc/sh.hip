@@ -7,6 +7,7 @@
 // coalesced loads (consecutive lanes -> consecutive dwords), padded to an odd row stride so
 // the per-lane row reads are bank-conflict free.  The backward writes v_coeffs the same way.
 #include "sh_math.h"
+#include "slab_io.h"
 
 namespace {
 using namespace fgsh;
@@ -132,7 +133,67 @@ sh_bwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, 
   }
 }
 
+// View-DP exchange, second half: every rank holds the masked colour gradients g_v[N,3] of ALL views
+// (all-gathered, 12 B per Gaussian per view) and rebuilds the summed coefficient gradient
+//   v_coeffs[i,k,:] = scale * sum_v basis_k(dir_v(i)) * g_v[i,:]
+// locally -- 192 B per Gaussian that never cross xGMI.  payload: n_views blocks of view_stride
+// floats, block v = [g_v (3N floats) | camera position of view v (3 floats)].
+__global__ void __launch_bounds__(BLOCK)
+sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const float* __restrict__ means,
+                          const float* __restrict__ payload, int64_t view_stride, float scale,
+                          float* __restrict__ v_coeffs) {
+  __shared__ float lds[BLOCK * ROW];
+  const int row0 = blockIdx.x * BLOCK;
+  const int nrows = min(BLOCK, N - row0);
+  const int i = row0 + threadIdx.x;
+  const int kk = (degree + 1) * (degree + 1);
+  float acc[48];
+#pragma unroll
+  for (int q = 0; q < 48; ++q) acc[q] = 0.f;
+  if (i < N) {
+    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    for (int v = 0; v < n_views; ++v) {
+      const float* blk = payload + (size_t)v * view_stride;
+      const float gr = blk[3 * i], gg = blk[3 * i + 1], gb = blk[3 * i + 2];
+      if (gr == 0.f && gg == 0.f && gb == 0.f) continue;  // culled or untouched in that view
+      const float* cam = blk + (size_t)3 * N;
+      float dx = mx - cam[0], dy = my - cam[1], dz = mz - cam[2];
+      const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+      dx *= inv; dy *= inv; dz *= inv;
+      float basis[16];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+      sh_basis(degree, dx, dy, dz, basis);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        if (k < kk) {
+          acc[3 * k] += basis[k] * gr; acc[3 * k + 1] += basis[k] * gg; acc[3 * k + 2] += basis[k] * gb;
+        }
+      }
+    }
+  }
+  float* row = lds + threadIdx.x * ROW;
+#pragma unroll
+  for (int q = 0; q < 48; ++q) row[q] = acc[q] * scale;
+  __syncthreads();
+  lds_to_slab_at(v_coeffs + (size_t)row0 * 3 * k_stored, lds, 0, nrows, 3 * k_stored, 48);
+}
+
 }  // namespace
+
+extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
+                                     const float* payload, int64_t view_stride, float scale, float* v_coeffs,
+                                     fg_stream_t stream) {
+  if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || k_stored < (sh_degree + 1) * (sh_degree + 1) ||
+      k_stored > 16 || view_stride < (int64_t)3 * N + 3)
+    return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !payload || !v_coeffs) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(sh_grad_accumulate_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream),
+                     N, n_views, sh_degree, k_stored, means, payload, view_stride, scale, v_coeffs);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
 
 extern "C" int fg_sh_fwd(int N, int degree, int k_stored, const float* means, const float* viewmat,
                          const float* coeffs, const int32_t* radii, float* colors, fg_stream_t stream) {

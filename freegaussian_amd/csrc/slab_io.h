@@ -1,0 +1,90 @@
+// Coalesced staging of row slabs through LDS, shared by preprocess.hip and sh.hip.
+#pragma once
+#include "sh_math.h"
+
+namespace fgsh {
+
+// Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows (stride STRIDE) at
+// column lds_col0, keeping the first use_floats columns of each row.  16-byte loads whenever the
+// slab is a whole number of float4, for ANY row length: all loads of a lane are issued first, the
+// (row, column) of an element comes from a multiply-shift division (exact for rows <= 48 floats
+// and slabs <= 2^14 elements), row wrap inside a float4 is branch-free and dropped columns land
+// in the row's last pad slot (column STRIDE-1), so there is no divergent code between load and store.
+constexpr int SLAB_MAX_Q = (BLOCK * 48 / 4 + BLOCK - 1) / BLOCK;  // float4 per lane of a full slab
+
+template <int STRIDE = ROW>
+__device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const float* __restrict__ src, int nrows,
+                                               int row_floats, int use_floats) {
+  const int total = nrows * row_floats;
+  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const float4* src4 = reinterpret_cast<const float4*>(src);
+    const int total4 = total / 4;
+    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
+    float4 v[SLAB_MAX_Q];
+#pragma unroll
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) v[t] = src4[q];
+    }
+#pragma unroll
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) {
+        const int e = 4 * q;
+        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
+        const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const bool wrap = c + jj >= row_floats;
+          const int cc = wrap ? c + jj - row_floats : c + jj;
+          const int row_base = (wrap ? r + 1 : r) * STRIDE;
+          lds[row_base + (cc < use_floats ? lds_col0 + cc : STRIDE - 1)] = vv[jj];
+        }
+      }
+    }
+  } else {
+    const int tot = nrows * use_floats;
+    for (int e = threadIdx.x; e < tot; e += BLOCK) {
+      const int r = e / use_floats, c = e - r * use_floats;
+      lds[r * STRIDE + lds_col0 + c] = src[(size_t)r * row_floats + c];
+    }
+  }
+}
+
+// The inverse: padded LDS rows (from column lds_col0) out to a contiguous [nrows x row_floats]
+// slab; columns >= lds_cols are written as zero.
+template <int STRIDE = ROW>
+__device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_col0, int nrows,
+                                               int row_floats, int lds_cols) {
+  const int total = nrows * row_floats;
+  if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    float4* dst4 = reinterpret_cast<float4*>(dst);
+    const int total4 = total / 4;
+    const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
+#pragma unroll
+    for (int t = 0; t < SLAB_MAX_Q; ++t) {
+      const int q = threadIdx.x + t * BLOCK;
+      if (q < total4) {
+        const int e = 4 * q;
+        const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
+        float vv[4];
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+          const bool wrap = c + jj >= row_floats;
+          const int cc = wrap ? c + jj - row_floats : c + jj;
+          const int row_base = (wrap ? r + 1 : r) * STRIDE;
+          const float x = lds[row_base + (cc < lds_cols ? lds_col0 + cc : STRIDE - 1)];
+          vv[jj] = cc < lds_cols ? x : 0.f;
+        }
+        dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+      }
+    }
+  } else {
+    for (int e = threadIdx.x; e < total; e += BLOCK) {
+      const int r = e / row_floats, c = e - r * row_floats;
+      dst[e] = (c < lds_cols) ? lds[r * STRIDE + lds_col0 + c] : 0.f;
+    }
+  }
+}
+
+}  // namespace fgsh

@@ -369,6 +369,13 @@ def rasterize_to_pixels(means2d, conics, features, opacities, width, height, til
 grad_alloc = None
 
 
+# Optional hook for the factored view-DP exchange (viewdp.FlatGaussianParams.factored_exchange):
+# when set, the fused backward of an SH-coloured view hands the clamp-masked colour gradient
+# g[N,3] (+ what is needed to rebuild the coefficient gradient) to the sink instead of writing the
+# dense [N,K,3] coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
+color_grad_sink = None
+
+
 def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
     if grad_alloc is not None:
         buf = grad_alloc(t)
@@ -418,7 +425,6 @@ class _Preprocess(torch.autograd.Function):
             v_means2d = torch.zeros(N, 2, dtype=torch.float32, device=dev)
         v_means, v_quats, v_scales = _alloc_grad(means), _alloc_grad(quats), _alloc_grad(scales)
         v_opac = _alloc_grad(opacities)
-        v_colors = _alloc_grad(colors) if colors is not None else None
         v_extra = torch.empty_like(extra) if extra is not None else None
         # the xy gradient usually IS the xy slots of a record array (strided view made by
         # _RasterSplats.backward): hand the kernel pointer + stride instead of compacting it
@@ -427,6 +433,18 @@ class _Preprocess(torch.autograd.Function):
             m2_stride = v_means2d.stride(0)
         else:
             v_means2d, m2_stride = v_means2d.contiguous(), 2
+        if color_grad_sink is not None and sh_degree >= 0 and colors is not None:
+            # factored form: 12 B of colour gradient per Gaussian instead of the 192-B coefficient row
+            v_rgb = color_grad_sink("alloc", N, means.device)
+            _call("fg_preprocess_bwd_factored", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
+                  _ptr(colors), sh_degree, k_stored, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height,
+                  eps2d, int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
+                  _ptr(None if v_depths is None else v_depths.contiguous()),
+                  _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
+                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), _ptr(v_extra), _stream())  # fmt: skip
+            color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, colors)
+            return v_means, v_quats, v_scales, v_opac, None, v_extra, None, None, None
+        v_colors = _alloc_grad(colors) if colors is not None else None
         _call("fg_preprocess_bwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
               sh_degree, k_stored, n_color, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d,
               int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,

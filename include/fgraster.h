@@ -243,6 +243,26 @@ int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const f
                           float* v_features_dc, float* v_features_rest, float* v_extra,
                           fg_stream_t stream);
 
+/* ---- X: factored SH-gradient exchange for view-sharded data parallelism (section 8e) ----------
+ * The SH coefficient gradient of one view is rank-1 per Gaussian: v_coeffs[i,k,:] =
+ * basis_k(dir_view(i)) * g[i,:] with g the clamp-masked colour gradient.  Instead of all-reducing
+ * 192 B per Gaussian, ranks all-gather g (12 B) and rebuild the sum locally.
+ * fg_preprocess_bwd_factored = fg_preprocess_bwd (SH colours) that writes v_rgb[N,3] = g instead
+ * of v_colors.  fg_sh_grad_accumulate: payload = n_views blocks of view_stride floats, block v =
+ * [g_v (3N floats) | camera position of view v (3 floats) | padding]; writes
+ * v_coeffs[N,k_stored,3] = scale * sum_v basis(normalize(means - cam_v)) (x) g_v densely. */
+int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, const float* scales,
+                               const float* opacities, const float* colors, int sh_degree, int k_stored,
+                               int with_depth, int n_extra, const float* viewmat, const float* K,
+                               int width, int height, float eps2d, int antialiased, const int32_t* radii,
+                               const float* v_splats, const float* v_means2d, int v_means2d_stride,
+                               const float* v_depths, const float* v_conics, float* v_means,
+                               float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
+                               float* v_extra, fg_stream_t stream);
+int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
+                          const float* payload, int64_t view_stride, float scale, float* v_coeffs,
+                          fg_stream_t stream);
+
 /* ---- D: adaptive density control ---------------------------------
  * The reference's refinement_after / split_gaussians / dup_gaussians / cull_gaussians and the
  * Adam-state surgery around them (freegaussian_model.py:313-367, :404-571), as: one decision
