@@ -170,23 +170,27 @@ def main():
     K = scene.Ks[view : view + 1].to(dev)
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
 
+    exchange = os.environ.get("FG_EXCHANGE", "factored")
     marks = []  # per step: HIP events at start / after forward / after backward / after the exchange
 
     def step(timed=False):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if ev:
             ev[0].record()
-        # gradients land directly in the flat all-reduce buffer (dense overwrite: no zeroing needed)
-        with params.direct_grads():
+        # gradients land directly in the flat gradient buffer (dense overwrite: no zeroing needed);
+        # N>1: factored exchange (all-gather of the colour gradient + 44 B/Gaussian all-reduce + local
+        # SH rebuild, viewdp.factored_exchange) unless FG_EXCHANGE=plain (one 236 B/Gaussian all-reduce)
+        factored = world > 1 and exchange == "factored"
+        with (params.factored_exchange() if factored else params.direct_grads()):
             means, quats, scales, opac, colors = params.raster_inputs()
             r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
                                        render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
             if ev:
                 ev[1].record()
             r.backward(vr)  # upstream dL/d render = fixed N(0,1) image
-        if ev:
-            ev[2].record()
-        if world > 1:
+            if ev:
+                ev[2].record()
+        if world > 1 and not factored:
             params.all_reduce_grads()
         if ev:
             ev[3].record()
@@ -252,8 +256,12 @@ def main():
         "mpix_per_s_per_gpu_from_median": P / (pct(t_fb, 0.5) * 1e-3) / 1e6,
     }  # fmt: skip
     if world > 1:
-        event_times["allreduce_ms_median"] = pct(t_xchg, 0.5)
-        event_times["allreduce_bytes"] = params.flat_grad.numel() * 4
+        event_times["exchange_ms_median_after_backward"] = pct(t_xchg, 0.5)
+        if exchange == "factored":
+            event_times["exchange"] = (f"factored: all-gather {12 * (N + 1)} B per rank (issued inside the backward), "
+                                       f"all-reduce {44 * N} B, local SH rebuild of {192 * N} B")  # fmt: skip
+        else:
+            event_times["exchange"] = f"plain: one all-reduce of {params.flat_grad.numel() * 4} B"
     out = {
         "metric": "Mpixels/s fwd+bwd @ 1M Gaussians 1080p",
         "value": world * args.steps * P / dt / 1e6,
@@ -269,7 +277,7 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank "
-            f"per step (8-view ring), fwd+bwd, RGB, absgrad" + (", RCCL grad all-reduce" if world > 1 else ""),
+            f"per step (8-view ring), fwd+bwd, RGB, absgrad" + (f", RCCL gradient exchange ({exchange})" if world > 1 else ""),
             "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
             "binning": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I "
             f"(the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",

@@ -802,3 +802,19 @@ def test_edge_cases_zero_gaussians_and_short_sh_tables():
     with pytest.raises(ValueError):
         rasterization(*[t.to(DEV) for t in cpu[:4]], torch.rand(4000, 9, device=DEV), sc.viewmats[:1].to(DEV),
                       sc.Ks[:1].to(DEV), 96, 64, sh_degree=None, packed=False)  # 9 channels > 8
+
+
+def test_factored_view_dp_exchange_two_ranks_on_one_gpu():
+    """viewdp.FlatGaussianParams.factored_exchange (all-gather of the colour gradient + small
+    all-reduce + fg_sh_grad_accumulate) against the plain flat all-reduce, 2 ranks sharing this GPU
+    over gloo, real kernels, run as child processes."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "exchange_check.py")]  # fmt: skip
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
