@@ -574,7 +574,7 @@ unpack_grads_kernel(int N, int C, const float* __restrict__ v_splats, float* __r
 int env_ppt(const char* name, int dflt) {
   const char* e = getenv(name);
   const int v = e ? atoi(e) : dflt;
-  return (v == 1 || v == 2 || v == 4) ? v : dflt;
+  return (v == 1 || v == 2 || v == 4) ? v : dflt;  // dflt 0 = "not forced"
 }
 int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measured best: profiles/r01_tile_order.md)
   static int mode = [] {
@@ -593,13 +593,21 @@ int launch_grid(int mode, int tile_w, int tile_h) {
     default: return 8 * ((tile_h + 7) / 8) * tile_w;
   }
 }
-int raster_ppt_fwd() {
-  static int ppt = env_ppt("FG_RASTER_PPT_FWD", 2);
-  return ppt;
+// Pixels per lane by tile count (FG_RASTER_PPT_FWD / _BWD override).  A tile's list is walked
+// serially by each of its wavefronts, so with few tiles the launch is bound by the longest list,
+// not by throughput: more, smaller wavefronts per tile then win although they repeat the
+// per-entry work.  Measured (profiles/r01_ppt_by_tiles.md): 8160 tiles -> fwd 2 / bwd 4;
+// 2040 tiles (960x540) -> 1 / 1: fwd 0.178 -> 0.117 ms, bwd 0.420 -> 0.317 ms;
+// 510 tiles (480x270) -> 1 / 1: fwd 0.138 -> 0.071, bwd 0.357 -> 0.151.
+int raster_ppt_fwd(int n_tiles) {
+  static int forced = env_ppt("FG_RASTER_PPT_FWD", 0);
+  if (forced) return forced;
+  return n_tiles >= 6000 ? 2 : 1;
 }
-int raster_ppt_bwd() {
-  static int ppt = env_ppt("FG_RASTER_PPT_BWD", 4);
-  return ppt;
+int raster_ppt_bwd(int n_tiles) {
+  static int forced = env_ppt("FG_RASTER_PPT_BWD", 0);
+  if (forced) return forced;
+  return n_tiles >= 6000 ? 4 : (n_tiles >= 3000 ? 2 : 1);
 }
 
 template <int C, int PPT>
@@ -681,7 +689,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt_fwd();
+  const int ppt = raster_ppt_fwd(((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
 #define CALL(CC)                                                                                                    \
   rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
@@ -705,7 +713,7 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt_bwd();
+  const int ppt = raster_ppt_bwd(((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
 #define CALL(CC)                                                                                            \
   rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
