@@ -24,7 +24,9 @@ def _ptr(t: Optional[torch.Tensor]):
 
 
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    # raw handle of the current stream of the current device; the public
+    # torch.cuda.current_stream() builds a Stream object (~13 us, five times per step)
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 class StageTimer:
@@ -213,10 +215,18 @@ def _count_buffer(dev) -> torch.Tensor:
 
 
 @torch.no_grad()
-def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h):
+def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False):
     """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
     -> (tile_keys[I] uint32-as-int32, flatten_ids[I] int32, tile_offsets[T+1] int32); the lists are
-    bit-identical to ``isect_tiles`` (same (tile, depth, id) order)."""
+    bit-identical to ``isect_tiles`` (same (tile, depth, id) order).
+
+    ``defer=True`` -> (tile_keys, flatten_ids, tile_offsets, finish): when the lists were enqueued
+    speculatively, ``finish`` is a callable and the first two tensors are still the capacity-sized
+    buffers (valid up to the count, which the kernels read on the device); the caller may enqueue
+    the kernels that consume them and THEN call ``finish() -> (tile_keys, flatten_ids, redone)``,
+    which waits for the count, slices, and -- if the guess was too small -- re-runs emission + sort
+    on exact buffers (``redone=True``: consumers must be re-run too).  ``finish`` is None when
+    nothing was deferred."""
     lib = _lib.load()
     N = means2d.shape[0]
     dev = means2d.device
@@ -248,19 +258,25 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h):
         ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(capacity)), dtype=torch.uint8, device=dev)
         _call("fg_bin_emit_sort_capacity", N, capacity, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
               tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
-    ready.synchronize()
-    n_isects = int(count_host[0])
-    if n_isects >= 2**31:
-        raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
-    _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
-    if capacity is not None and n_isects <= capacity:
-        return tile_keys[:n_isects], flatten_ids[:n_isects], offsets
-    tile_keys = torch.empty(n_isects, dtype=torch.int32, device=dev)
-    flatten_ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
-    ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
-    _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size, tile_w,
-          tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
-    return tile_keys, flatten_ids, offsets
+    def finish():
+        ready.synchronize()
+        n_isects = int(count_host[0])
+        if n_isects >= 2**31:
+            raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+        _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
+        if capacity is not None and n_isects <= capacity:
+            return tile_keys[:n_isects], flatten_ids[:n_isects], False
+        tk = torch.empty(n_isects, dtype=torch.int32, device=dev)
+        ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
+        ws3 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
+        _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size, tile_w,
+              tile_h, _ptr(tk), _ptr(ids), _ptr(offsets), _ptr(ws3), ws3.numel(), _stream())  # fmt: skip
+        return tk, ids, True
+
+    if defer and capacity is not None:
+        return tile_keys, flatten_ids, offsets, finish
+    tk, ids, _ = finish()
+    return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
 @torch.no_grad()

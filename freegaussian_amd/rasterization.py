@@ -182,8 +182,9 @@ def rasterization(
             chans.append(extra_channels.float())
         feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
 
-    tile_keys, flatten_ids, offsets = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
+    # speculative lists: the raster forward is enqueued before the host waits for the list length
+    tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True
     )
 
     if packed:
@@ -195,14 +196,18 @@ def rasterization(
         means2d_info = means2d_n.unsqueeze(0)  # [1,N,2]: the tensor that is retain_grad()'ed
         means2d_in = means2d_info
 
-    if fused:
-        render, alpha, last_ids = ops.rasterize_splats(
-            splats, means2d_in, channels, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
-        )
-    else:
-        render, alpha, last_ids = ops.rasterize_to_pixels(
-            means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad
-        )
+    def composite():
+        if fused:
+            return ops.rasterize_splats(splats, means2d_in, channels, width, height, tile_size, offsets, flatten_ids,
+                                        absgrad=absgrad)  # fmt: skip
+        return ops.rasterize_to_pixels(means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids,
+                                       absgrad=absgrad)  # fmt: skip
+
+    render, alpha, last_ids = composite()
+    if finish_lists is not None:
+        tile_keys, flatten_ids, redone = finish_lists()
+        if redone:  # the capacity guess was too small: lists were rebuilt exactly, composite again
+            render, alpha, last_ids = composite()
     if backgrounds is not None:
         render = render + (1.0 - alpha) * backgrounds.reshape(1, 1, -1)
     if render_mode in ("ED", "RGB+ED"):
@@ -304,18 +309,24 @@ def rasterize_gauss_params(
         far_plane=far_plane, radius_clip=radius_clip, tile_size=tile_size,
         antialiased=(rasterize_mode == "antialiased"), with_depth=with_depth,
     )  # fmt: skip
-    tile_keys, flatten_ids, offsets = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h
+    tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True
     )
     means2d_info = means2d_n.unsqueeze(0)
     bg = None
     if background is not None:
         bg = torch.zeros(channels, device=means.device, dtype=torch.float32)
         bg[:3] = background.detach().reshape(-1).to(means.device, torch.float32)
-    render, alpha, last_ids = ops.rasterize_splats(
-        splats, means2d_info, channels, width, height, tile_size, offsets, flatten_ids, absgrad=absgrad,
-        background=bg, n_clamp=(3 if clamp else 0),
-    )  # fmt: skip
+
+    def composite():
+        return ops.rasterize_splats(splats, means2d_info, channels, width, height, tile_size, offsets, flatten_ids,
+                                    absgrad=absgrad, background=bg, n_clamp=(3 if clamp else 0))  # fmt: skip
+
+    render, alpha, last_ids = composite()
+    if finish_lists is not None:
+        tile_keys, flatten_ids, redone = finish_lists()
+        if redone:
+            render, alpha, last_ids = composite()
     if with_depth:
         d = render[..., 3:4] / alpha.clamp(min=1e-10)
         render = torch.cat([render[..., :3], d, render[..., 4:]], dim=-1)

@@ -172,6 +172,22 @@ def test_speculative_binning_capacity_and_overflow():
     ops.speculative_binning = was
 
 
+def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
+    sc = _scene(n=20000, w=256, h=160, seed=17)
+    t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    ops._isect_capacity.clear()
+    r0, a0, i0 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)  # exact (no guess yet)
+    r1, a1, i1 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)  # speculative
+    for key in list(ops._isect_capacity):
+        ops._isect_capacity[key] = 1000  # force the overflow path
+    r2, a2, i2 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
+    for r, a, i in ((r1, a1, i1), (r2, a2, i2)):
+        assert torch.equal(r, r0) and torch.equal(a, a0)
+        assert torch.equal(i["flatten_ids"], i0["flatten_ids"]) and torch.equal(i["isect_offsets"], i0["isect_offsets"])
+        assert torch.equal(i["tile_keys"], i0["tile_keys"])
+
+
 def test_isect_empty_scene():
     """All Gaussians behind the camera: I = 0, every range empty, render = 0."""
     sc = plumbing_scene()
