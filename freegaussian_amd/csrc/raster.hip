@@ -494,19 +494,28 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
           bsum[k] += cdot * fac;
           const bool open = valid && (ov <= FG_ALPHA_MAX);  // alpha not clamped: gradient flows
-          const float v_sigma = open ? -ov * v_alpha : 0.f;
-          g[3] += 0.5f * v_sigma * dx * dx;
-          g[4] += v_sigma * dx * dy;
-          g[5] += 0.5f * v_sigma * dy * dy;
+          const float v_o = open ? vis * v_alpha : 0.f;       // d/d opacity
+          const float v_sigma = -s.o * v_o;
+          g[2] += v_o;
+          // dx is the same for all pixel slots of a lane: the conic gradient needs only the moments
+          // S0 = sum v_sigma, S1 = sum v_sigma dy, S2 = sum v_sigma dy^2 per entry (kept in g[3..5],
+          // which are zero at the start of every contributing entry) -- finished below
+          const float vsdy = v_sigma * dy;
+          g[3] += v_sigma;
+          g[4] += vsdy;
+          g[5] = fmaf(vsdy, dy, g[5]);
           const float gx = v_sigma * (s.a * dx + s.b * dy);
           const float gy = v_sigma * (s.b * dx + s.c * dy);
           g[0] += gx;
           g[1] += gy;
-          g[6] += fabsf(gx);
+          g[6] += fabsf(gx);  // absgrad sums |.| per pixel: not a moment
           g[7] += fabsf(gy);
-          g[2] += open ? vis * v_alpha : 0.f;
         }
         if (!__any(contributed)) continue;
+        // v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
+        g[5] *= 0.5f;
+        g[4] *= dx;
+        g[3] *= 0.5f * dx * dx;
         FG_STAT(4, 1);
         if (C <= 4) {  // only record slots 0..11 are in use: the cheaper 12-value butterfly
           const float total = fg::wave_reduce12_transposed(g);
