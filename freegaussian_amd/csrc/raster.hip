@@ -125,6 +125,10 @@ __device__ unsigned long long fg_raster_stats[16];
 #define FG_STAT(i, n) do { } while (0)
 #endif
 
+#ifndef FG_FWD_STRIP_TEST_MIN_PPT
+#define FG_FWD_STRIP_TEST_MIN_PPT 2
+#endif
+
 struct SigmaTerms {
   float hc, bdx, hadx2;
 };
@@ -288,7 +292,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       for (int k = 0; k < PPT; ++k) {
         // PPT == 4: skip the strips the splat cannot reach; with 1-2 slots per lane the test
         // costs more scalar work than it saves
-        if (PPT == 4 && !((packed >> (8 + k)) & 1u)) continue;
+        if (PPT >= FG_FWD_STRIP_TEST_MIN_PPT && !((packed >> (8 + wave + k * (4 / PPT))) & 1u)) continue;
         // one wave-uniform branch, then select-predicated straight-line code (no nested
         // divergent ifs: each costs exec save/restore and merge copies)
         const float dy = s.y - py[k];
