@@ -102,3 +102,70 @@ def test_mask_backprojection_matches_reference_expressions():
                       depth_map, atrb, torch.ones(M + 1, dtype=torch.bool))  # fmt: skip
     # row 0: inside after truncation, |delta| small -> labelled; row 1: delta = -2.5 < -0.2 -> rejected; row 2: outside
     assert gm.cpu().tolist() == [[True] * M, [False] * M, [False] * M]
+
+
+@pytest.mark.gpu
+def test_stage1_to_stage2_end_to_end(tmp_path):
+    """The whole hand-off on a synthetic scene: stage-1 training steps with the
+    deform net -> step-%09d.ckpt -> key-frame mask back-projection -> gaussian_mask_NxM.npy ->
+    FreeGaussianControlModel initialised from both files -> stage-2 training steps that only move
+    the control net."""
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (no CPU fallback exists)")
+    import copy
+    import sys
+
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_gpu_parity import _model_and_camera
+
+    from freegaussian_amd import harness as Hn
+    from freegaussian_amd.masks import build_gaussian_masks
+    from freegaussian_amd.method_config import STAGE2_OPTIMIZERS
+    from freegaussian_amd.model import FreeGaussianControlModel
+    from freegaussian_amd.utils import get_viewmat
+
+    dev = "cuda"
+    model, _, cam = _model_and_camera(n=3000, W=128, H=96, step=3000, training=True)  # after warm-up: deform active
+    target = copy.deepcopy(model).eval()
+    with torch.no_grad():
+        target.gauss_params["features_dc"].add_(0.2)
+        gt = target.get_outputs(copy.deepcopy(cam))["rgb"].clamp(0, 1)
+    opts = Hn.build_optimizers(model)
+    h1 = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 3000 + i) for i in range(8)]
+    assert h1[-1]["loss"] < h1[0]["loss"]
+    ckpt = fio.save_checkpoint(str(tmp_path / "ckpt"), 3007, model, opts)
+
+    # key frame: label the left and right halves of the image as two attributes (+ background)
+    H, W = cam.height, cam.width
+    atrb = torch.zeros(H, W, 3, dtype=torch.bool)
+    atrb[:, : W // 2, 0] = True
+    atrb[:, W // 2 :, 1] = True
+    valids = torch.ones(3, dtype=torch.bool)
+    gp = {k: v.detach() for k, v in model.gauss_params.items()}
+    colors = torch.cat([gp["features_dc"][:, None], gp["features_rest"]], 1)
+    frame = (get_viewmat(cam.camera_to_worlds), cam.get_intrinsics_matrices(), W, H, atrb, valids)
+    masks = build_gaussian_masks(gp["means"], gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True), gp["scales"].exp(),
+                                 torch.sigmoid(gp["opacities"]).squeeze(-1), colors, 3, [frame])  # fmt: skip
+    assert masks.shape == (3000, 2) and 50 < int(masks.any(-1).sum()) < 3000
+    assert not bool((masks[:, 0] & masks[:, 1]).any())  # a centre lies in one half only
+    fio.save_gaussian_mask(str(tmp_path), masks)
+
+    # stage 2 from the two files
+    init_cam = type(cam)(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx, cam.cy, W, H, times=torch.tensor([[0.0]]))
+    stage2 = FreeGaussianControlModel(fio.load_gaussian_mask(str(tmp_path)), init_cam, config=copy.deepcopy(model.config),
+                                      num_points=10)  # fmt: skip
+    assert fio.load_deformable_checkpoint(stage2, ckpt) == 3007 and stage2.num_points == 3000
+    stage2 = stage2.to(dev).train()
+    for k in model.gauss_params:
+        assert torch.equal(stage2.gauss_params[k], model.gauss_params[k])
+    opts2 = Hn.build_optimizers(stage2, STAGE2_OPTIMIZERS)
+    assert "deform" not in opts2 and "control" in opts2
+    before = [p.detach().clone() for p in stage2.deform.parameters()]
+    ctrl0 = torch.cat([p.detach().flatten().clone() for p in stage2.control.parameters()])
+    cam2 = copy.deepcopy(cam)
+    cam2.metadata["cameras0"] = init_cam
+    h2 = [Hn.train_step(stage2, opts2, copy.deepcopy(cam2), gt, 30000 + i, table=STAGE2_OPTIMIZERS) for i in range(6)]
+    assert all(torch.isfinite(torch.tensor(h["loss"])) for h in h2)
+    assert all(torch.equal(a, b) for a, b in zip(before, stage2.deform.parameters()))  # frozen in stage 2
+    ctrl1 = torch.cat([p.detach().flatten() for p in stage2.control.parameters()])
+    assert float((ctrl1 - ctrl0).abs().max()) > 0  # the control net is what trains
