@@ -58,6 +58,7 @@ def algorithmic_bytes(N, V, I, P, T, k, p):
         "fg_bin_emit_sort": 8 * I + 2 * 16 * I + 4 * I,
         "fg_bin_emit_sort_capacity": 8 * I + 2 * 16 * I + 4 * I,
         "fg_project_fwd": 44 * N + 32 * V,
+        "fg_sh_pack_fwd": 16 * N + (12 * k + 32) * V + 64 * N,
         "fg_sh_fwd": 12 * k * V + 12 * V,
         "fg_tile_bin": 12 * I,
         "fg_sort_pairs": 24 * p * I,

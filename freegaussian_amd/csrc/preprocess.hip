@@ -88,6 +88,10 @@ __device__ __forceinline__ void coeffs_to_lds(float* lds, const RawForm& raw, co
                    3 * (kk - 1));
 }
 
+// PACK_ONLY: the projection outputs (radii, means2d, depths, conics, compensations) are INPUTS
+// (written by fg_project_fwd); only the colour + record part runs -- the half of the forward that
+// can overlap the latency-bound binning on a second stream (fg_sh_pack_fwd).
+template <bool PACK_ONLY>
 __global__ void __launch_bounds__(BLOCK)
 preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
@@ -111,7 +115,18 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   bool ok = false;
   Fwd f;
   float mx = 0.f, my = 0.f, mz = 0.f, opac = 0.f;
-  if (i < N) {
+  if (PACK_ONLY) {
+    if (i < N) {
+      mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
+      opac = opacities[i];
+      ok = radii[i] > 0;
+      f.m2x = means2d[2 * i]; f.m2y = means2d[2 * i + 1];
+      f.pz = depths[i];
+      f.conic_a = conics[3 * i]; f.conic_b = conics[3 * i + 1]; f.conic_c = conics[3 * i + 2];
+      f.comp = compensations ? compensations[i] : 1.f;
+      f.radius_f = 0.f;
+    }
+  } else if (i < N) {
     const Cam cam = load_cam(viewmat, K);
     mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2];
     const Activated a = load_activated(raw, i, quats, scales, opacities);
@@ -142,7 +157,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
     rec[2] = antialiased ? opac * f.comp : opac;
     rec[3] = f.conic_a; rec[4] = f.conic_b; rec[5] = f.conic_c;
   }
-  if (i < N) {
+  if (!PACK_ONLY && i < N) {
     radii[i] = radius;
     means2d[2 * i] = rec[0];
     means2d[2 * i + 1] = rec[1];
@@ -405,7 +420,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
   if ((fl.n_color > 0 && !colors) || (n_extra > 0 && !extra)) return FG_ERR_INVALID_ARG;
   if (raw.enabled && (sh_degree < 0 || (k_stored > 1 && !raw.features_rest))) return FG_ERR_INVALID_ARG;
   const int tile_w = (width + tile_size - 1) / tile_size, tile_h = (height + tile_size - 1) / tile_size;
-  hipLaunchKernelGGL(preprocess_fwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
+  hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
                      fl, raw, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
                      near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
                      depths, conics, compensations, tiles_touched, splats);
@@ -523,4 +538,23 @@ extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float
                                scales, opacities, colors, sh_degree, k_stored, 3, with_depth, n_extra, viewmat, K,
                                width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                                v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, nullptr, v_extra, stream);
+}
+
+extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities, const float* colors, int sh_degree,
+                              int k_stored, int n_color, int with_depth, const float* extra, int n_extra,
+                              const float* viewmat, int antialiased, const int32_t* radii, const float* means2d,
+                              const float* depths, const float* conics, const float* compensations, float* splats,
+                              fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!means || !opacities || !viewmat || !radii || !means2d || !depths || !conics || !splats) return FG_ERR_INVALID_ARG;
+  if ((fl.n_color > 0 && !colors) || (n_extra > 0 && !extra) || (antialiased && !compensations)) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(preprocess_fwd_kernel<true>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream),
+                     N, fl, RawForm{0, nullptr, nullptr, nullptr}, means, nullptr, nullptr, opacities, colors, extra,
+                     viewmat, nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 16, 0, 0, antialiased, const_cast<int32_t*>(radii),
+                     const_cast<float*>(means2d), const_cast<float*>(depths), const_cast<float*>(conics),
+                     const_cast<float*>(compensations), nullptr, splats);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
 }

@@ -20,7 +20,10 @@ constexpr int RADIX_BITS = 8;
 constexpr int RADIX = 1 << RADIX_BITS;
 constexpr int BLOCK = 256;
 constexpr int WAVES = BLOCK / 64;
-constexpr int KEYS_PER_THREAD = 16;
+#ifndef FG_SORT_KPT
+#define FG_SORT_KPT 16
+#endif
+constexpr int KEYS_PER_THREAD = FG_SORT_KPT;
 constexpr int TILE = BLOCK * KEYS_PER_THREAD;  // 4096 keys per workgroup
 constexpr int WAVE_SPAN = 64 * KEYS_PER_THREAD;
 

@@ -50,15 +50,17 @@ class StageTimer:
 stage_timer: Optional[StageTimer] = None
 
 
-def _call(name: str, *args) -> None:
-    """Invoke one C-ABI entry point on the current stream, optionally bracketed by HIP events."""
+def _call(name: str, *args, on=None) -> None:
+    """Invoke one C-ABI entry point, optionally bracketed by HIP events recorded on the stream the
+    kernels go to (``on``: a torch stream other than the current one; the caller passes its raw
+    handle as the entry point's stream argument)."""
     fn = getattr(_lib.load(), name)
     ev = stage_timer.record(name) if stage_timer is not None else None
     if ev:
-        ev[0].record()
+        ev[0].record(on) if on is not None else ev[0].record()
     rc = fn(*args)
     if ev:
-        ev[1].record()
+        ev[1].record(on) if on is not None else ev[1].record()
     _lib.check(rc, name)
 
 
@@ -400,10 +402,32 @@ def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
     return torch.empty_like(t)
 
 
+# Two-stream forward: the projection (whose outputs the binning needs) runs on the current stream,
+# the colour + record half (HBM-bound, 300 B per Gaussian) on a side stream, concurrently with the
+# binning kernels, which are small and latency-bound and leave most of the GPU idle.  The records
+# carry the event their consumer (the raster forward) must wait for.  FG_OVERLAP_PACK=0 turns it off.
+overlap_pack = os.environ.get("FG_OVERLAP_PACK", "1") != "0"
+_side_streams: dict = {}
+
+
+def _side_stream(dev) -> torch.cuda.Stream:
+    s = _side_streams.get(dev)
+    if s is None:
+        s = _side_streams[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def _wait_ready(t: torch.Tensor) -> None:
+    """Make the current stream wait for the side-stream kernel that produces ``t`` (if any)."""
+    ev = getattr(t, "_fg_ready", None)
+    if ev is not None:
+        torch.cuda.current_stream().wait_event(ev)
+
+
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, extra, viewmat, K, cfg):
-        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg[:10]
         N = means.shape[0]
         dev = means.device
         if sh_degree >= 0:
@@ -418,10 +442,29 @@ class _Preprocess(torch.autograd.Function):
         comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
-        _call("fg_preprocess_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
-              sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
-              height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
-              _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _stream())  # fmt: skip
+        if overlap_pack and len(cfg) > 10 and cfg[10]:
+            main = torch.cuda.current_stream()
+            side = _side_stream(dev)
+            _call("fg_project_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmat), _ptr(K), width, height,
+                  eps2d, near, far, radius_clip, tile_size, _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics),
+                  _ptr(comp), _ptr(tiles), _stream())  # fmt: skip
+            projected = torch.cuda.Event()
+            projected.record(main)
+            side.wait_event(projected)
+            _call("fg_sh_pack_fwd", N, _ptr(means), _ptr(opacities), _ptr(colors), sh_degree, k_stored, n_color,
+                  int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), int(antialiased), _ptr(radii), _ptr(means2d),
+                  _ptr(depths), _ptr(conics), _ptr(comp), _ptr(splats), side.cuda_stream, on=side)  # fmt: skip
+            ready = torch.cuda.Event()
+            ready.record(side)
+            for t in (splats, means, opacities, colors, extra, viewmat, radii, means2d, depths, conics, comp):
+                if t is not None:
+                    t.record_stream(side)  # the caching allocator must not recycle them under the side kernel
+            splats._fg_ready = ready
+        else:
+            _call("fg_preprocess_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
+                  sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
+                  height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
+                  _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _stream())  # fmt: skip
         ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii)
         ctx.cfg = cfg
         ctx.layout = (k_stored, n_color, n_extra)
@@ -431,7 +474,7 @@ class _Preprocess(torch.autograd.Function):
     @staticmethod
     def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
         means, quats, scales, opacities, colors, extra, viewmat, K, radii = ctx.saved_tensors
-        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg
+        (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg[:10]
         k_stored, n_color, n_extra = ctx.layout
         N = means.shape[0]
         dev = means.device
@@ -472,15 +515,18 @@ class _Preprocess(torch.autograd.Function):
 
 def preprocess(means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d=0.3,
                near_plane=0.01, far_plane=1e10, radius_clip=0.0, tile_size=TILE_SIZE, antialiased=False,
-               sh_degree=-1, with_depth=False):  # fmt: skip
+               sh_degree=-1, with_depth=False, overlap=False):  # fmt: skip
     """Fused projection + colour + record packing.
-    -> radii[N], means2d[N,2], depths[N], conics[N,3], tiles_touched[N], splats[N,16]."""
+    -> radii[N], means2d[N,2], depths[N], conics[N,3], tiles_touched[N], splats[N,16].
+    ``overlap=True``: the records are produced on a side stream (concurrently with whatever the
+    caller enqueues next on the current stream, i.e. the binning); they carry the event
+    ``rasterize_splats`` waits for -- any other reader must call ``ops._wait_ready(splats)`` first."""
     means, quats, scales = _f32(means, "means"), _f32(quats, "quats"), _f32(scales, "scales")
     opacities, viewmat, K = _f32(opacities, "opacities"), _f32(viewmat, "viewmat"), _f32(K, "K")
     colors = None if colors is None else _f32(colors, "colors")
     extra = None if extra is None else _f32(extra, "extra_channels")
     cfg = (int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-           int(tile_size), bool(antialiased), int(sh_degree), bool(with_depth))  # fmt: skip
+           int(tile_size), bool(antialiased), int(sh_degree), bool(with_depth), bool(overlap))  # fmt: skip
     return _Preprocess.apply(means, quats, scales, opacities, colors, extra, viewmat, K, cfg)
 
 
@@ -583,6 +629,7 @@ class _RasterSplats(torch.autograd.Function):
     def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad,
                 background=None, n_clamp=0):  # fmt: skip
         dev = splats.device
+        _wait_ready(splats)
         render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
         alphas = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)

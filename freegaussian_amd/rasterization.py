@@ -158,7 +158,7 @@ def rasterization(
         radii, means2d_n, depths, conics, tiles, splats = ops.preprocess(
             means, quats, scales, opacities, colors if with_rgb else None, extra_channels, viewmat, K, width,
             height, eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased,
-            (sh_degree if (sh_degree is not None and with_rgb) else -1), with_depth,
+            (sh_degree if (sh_degree is not None and with_rgb) else -1), with_depth, overlap=True,
         )  # fmt: skip
         opac = splats[:, 2]
     else:

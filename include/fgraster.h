@@ -194,6 +194,16 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                       float* compensations, int32_t* tiles_touched, float* splats,
                       fg_stream_t stream);
+/* The colour + record half of fg_preprocess_fwd on its own: inputs are the projection outputs of
+ * fg_project_fwd (radii, means2d, depths, conics; compensations when antialiased).  Splitting the
+ * forward this way lets a host run this HBM-bound half on a second stream while the
+ * latency-bound binning (fg_bin_prepare / fg_bin_emit_sort) runs on the first; records are
+ * bit-identical to fg_preprocess_fwd's. */
+int fg_sh_pack_fwd(int N, const float* means, const float* opacities, const float* colors, int sh_degree,
+                   int k_stored, int n_color, int with_depth, const float* extra, int n_extra,
+                   const float* viewmat, int antialiased, const int32_t* radii, const float* means2d,
+                   const float* depths, const float* conics, const float* compensations, float* splats,
+                   fg_stream_t stream);
 /* fg_preprocess_bwd = fg_unpack_grads + fg_sh_bwd + fg_project_bwd in one pass.  v_splats[N,16]
  * is the record fg_raster_bwd accumulated; its xy slots are IGNORED and v_means2d is used
  * instead (autograd routes that gradient through info["means2d"] so .grad exists there): row i
