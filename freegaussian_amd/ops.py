@@ -402,11 +402,13 @@ def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
     return torch.empty_like(t)
 
 
-# Two-stream forward: the projection (whose outputs the binning needs) runs on the current stream,
-# the colour + record half (HBM-bound, 300 B per Gaussian) on a side stream, concurrently with the
-# binning kernels, which are small and latency-bound and leave most of the GPU idle.  The records
-# carry the event their consumer (the raster forward) must wait for.  FG_OVERLAP_PACK=0 turns it off.
-overlap_pack = os.environ.get("FG_OVERLAP_PACK", "1") != "0"
+# Optional two-stream forward (FG_OVERLAP_PACK=1, off by default): the projection (whose outputs the
+# binning needs) runs on the current stream, the colour + record half (HBM-bound, 300 B per
+# Gaussian) on a side stream, concurrently with the binning kernels.  The records carry the event
+# their consumer (the raster forward) must wait for.  Measured on MI355X at 1M / 1080p
+# (profiles/r01_two_stream_forward.md): no gain -- the 3900-workgroup colour kernel crowds the small
+# sort kernels out (fg_bin_prepare 0.114 -> 0.153 ms) by as much as it hides.
+overlap_pack = os.environ.get("FG_OVERLAP_PACK", "0") == "1"
 _side_streams: dict = {}
 
 

@@ -188,6 +188,29 @@ def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
         assert torch.equal(i["tile_keys"], i0["tile_keys"])
 
 
+def test_two_stream_forward_gives_identical_results():
+    """ops.overlap_pack: projection on the current stream, colour + record packing (fg_sh_pack_fwd)
+    on a side stream overlapping the binning; the raster forward waits for the records' event."""
+    sc = _scene(n=15000, w=240, h=144, seed=23)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    outs = []
+    was = ops.overlap_pack
+    try:
+        for flag in (False, True):
+            ops.overlap_pack = flag
+            t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+            r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, render_mode="RGB+ED",
+                                       packed=False, absgrad=True, rasterize_mode="antialiased")  # fmt: skip
+            (r.sum() + a.sum()).backward()
+            outs.append((r.detach(), a.detach(), info["radii"], [x.grad for x in t]))
+    finally:
+        ops.overlap_pack = was
+    (r0, a0, rad0, g0), (r1, a1, rad1, g1) = outs
+    assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(rad0, rad1)
+    for x, y in zip(g0, g1):
+        assert rel_l2(y, x) < 1e-5
+
+
 def test_isect_empty_scene():
     """All Gaussians behind the camera: I = 0, every range empty, render = 0."""
     sc = plumbing_scene()
