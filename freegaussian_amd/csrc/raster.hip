@@ -140,6 +140,17 @@ __device__ __forceinline__ SigmaTerms sigma_terms(const Splat& s, float dx) {
   t.hadx2 = ((0.5f * NL) * s.a) * dx * dx;
   return t;
 }
+// The same terms from conic coefficients the loader lane already scaled while staging the record
+// in LDS (a' = -log2(e)/2 a, b' = -log2(e) b, c' = -log2(e)/2 c): identical products, three
+// multiplies per (entry, wavefront) fewer.
+constexpr float FG_NEG_LOG2E = -1.4426950408889634f;
+__device__ __forceinline__ SigmaTerms sigma_terms_prescaled(float a_s, float b_s, float c_s, float dx) {
+  SigmaTerms t;
+  t.hc = c_s;
+  t.bdx = b_s * dx;
+  t.hadx2 = a_s * dx * dx;
+  return t;
+}
 __device__ __forceinline__ float neg_sigma_log2e(const SigmaTerms& t, float dy) {
   return fmaf(fmaf(t.hc, dy, t.bdx), dy, t.hadx2);
 }
@@ -253,11 +264,14 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        v[q] = rec[q];
-        lds[threadIdx.x][q] = v[q];
-      }
+      for (int q = 0; q < NV; ++q) v[q] = rec[q];
       mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+      // the forward only ever uses the conic inside the exponent: stage it pre-scaled
+      v[0].w *= 0.5f * FG_NEG_LOG2E;
+      v[1].x *= FG_NEG_LOG2E;
+      v[1].y *= 0.5f * FG_NEG_LOG2E;
+#pragma unroll
+      for (int q = 0; q < NV; ++q) lds[threadIdx.x][q] = v[q];
     }
     lds_mask[threadIdx.x] = mask;
     __syncthreads();
@@ -287,7 +301,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       float f[C];
       read_record<C>(lds[j], s, f);
       const float dx = s.x - px;
-      const SigmaTerms st = sigma_terms(s, dx);
+      const SigmaTerms st = sigma_terms_prescaled(s.a, s.b, s.c, dx);
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         // PPT == 4: skip the strips the splat cannot reach; with 1-2 slots per lane the test
@@ -428,11 +442,15 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
 #pragma unroll
-      for (int q = 0; q < NV; ++q) {
-        v[q] = rec[q];
-        lds[threadIdx.x][q] = v[q];
-      }
+      for (int q = 0; q < NV; ++q) v[q] = rec[q];
       mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+      if (C == 3) {  // three spare floats in the 48-byte LDS copy: the pre-scaled conic rides along
+        v[2].y = v[0].w * (0.5f * FG_NEG_LOG2E);
+        v[2].z = v[1].x * FG_NEG_LOG2E;
+        v[2].w = v[1].y * (0.5f * FG_NEG_LOG2E);
+      }
+#pragma unroll
+      for (int q = 0; q < NV; ++q) lds[threadIdx.x][q] = v[q];
     }
     lds_mask[threadIdx.x] = mask;
     __syncthreads();
@@ -459,7 +477,13 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         float f[C];
         read_record<C>(lds[j], s, f);
         const float dx = s.x - px;
-        const SigmaTerms st = sigma_terms(s, dx);
+        SigmaTerms st;
+        if (C == 3) {
+          const float4 tail = lds[j][2];  // (f2, a', b', c'): the load read_record already issued
+          st = sigma_terms_prescaled(tail.y, tail.z, tail.w, dx);
+        } else {
+          st = sigma_terms(s, dx);
+        }
         // Per pixel slot: one wave-uniform branch ("does any lane contribute?"), then straight-line
         // select-predicated arithmetic.  Nested divergent ifs made the compiler re-materialise
         // the 11 accumulators at every merge point (~30 v_mov per slot in the ISA).
