@@ -72,11 +72,12 @@ def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = Non
 
 
 def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
-               grad_sync=None, num_train_data: Optional[int] = None) -> Dict[str, float]:  # fmt: skip
+               grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None) -> Dict[str, float]:  # fmt: skip
     """One iteration in the reference's callback order: step_cb -> get_outputs ->
     loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter ->
     refinement_after every ``refine_every`` steps (freegaussian_model.py:575-590; needs
-    ``num_train_data``, the number of training cameras, :416)."""
+    ``num_train_data``, the number of training cameras, :416).  View-sharded DP: pass
+    ``grad_sync=viewdp.all_reduce_model_grads`` and ``stats_sync=viewdp.sync_densify_stats``."""
     model.step_cb(step)
     for o in opts.values():
         o.zero_grad(set_to_none=True)
@@ -93,6 +94,8 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     if num_train_data is not None and step % model.config.refine_every == 0:
         from .densify import refinement_after
 
+        if stats_sync is not None:  # view-DP: identical statistics and split samples on every rank
+            stats_sync(model)
         refinement_after(model, opts, step, num_train_data)
     with torch.no_grad():
         return {"loss": float(loss), "psnr": float(psnr(out["rgb"], gt)), "gaussian_count": model.num_points}

@@ -219,3 +219,38 @@ def shared_seed(seed: Optional[int] = None, group=None) -> int:
 def views_for_rank(n_views: int, rank: int, world: int):
     """Round-robin shard of camera views: rank r renders views r, r+world, ..."""
     return list(range(rank, n_views, world))
+
+
+def all_reduce_model_grads(model: torch.nn.Module, average: bool = True, group=None) -> None:
+    """View-DP gradient exchange for a model whose parameters are NOT views of one flat buffer
+    (``FreeGaussianModel``: densification re-allocates its ParameterDict): every existing ``.grad``
+    -- Gaussian parameters and the deform / control MLPs -- goes through ONE all-reduce of a
+    flattened copy.  Parameters without a gradient on this rank (e.g. nothing visible) are
+    treated as zeros so that all ranks reduce the same layout."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    params = [p for p in model.parameters() if p.requires_grad]
+    for p in params:
+        if p.grad is None:
+            p.grad = torch.zeros_like(p)
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    if average:
+        flat.div_(dist.get_world_size(group))
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off : off + n].view_as(p.grad))
+        off += n
+
+
+def sync_densify_stats(model, group=None) -> None:
+    """Before ``refinement_after`` on every rank: make the accumulated statistics identical
+    (``all_reduce_densify_stats``) and re-seed the generator that draws the split samples."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    if model.xys_grad_norm is not None:
+        all_reduce_densify_stats(model.xys_grad_norm, model.vis_counts, model.max_2Dsize, group=group)
+        # every rank added its own "+1" start value to vis_counts (model.after_train_iter): keep one
+        model.vis_counts.sub_(dist.get_world_size(group) - 1)
+    shared_seed(group=group)

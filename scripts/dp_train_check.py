@@ -1,0 +1,73 @@
+"""View-sharded DP training of FreeGaussianModel, W ranks (torchrun): ranks render different views,
+exchange gradients (viewdp.all_reduce_model_grads) and densification statistics
+(viewdp.sync_densify_stats) and must stay in lockstep -- same Gaussian count and bit-identical
+parameters after a run that includes refinements.  On a 1-GPU box: FG_BENCH_BACKEND=gloo."""
+import copy
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from freegaussian_amd import harness as Hn  # noqa: E402
+from freegaussian_amd import viewdp  # noqa: E402
+from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig  # noqa: E402
+from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
+
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+dev = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+torch.cuda.set_device(dev)
+backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else {}))
+
+W, H, n = 160, 96, 4000
+sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=7)
+torch.manual_seed(0)
+cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=10**9, refine_start=10,
+                              refine_every=10, reset_alpha_every=30, densify_grad_thresh=1e-4, stop_screen_size_at=0,
+                              sh_degree_interval=1)
+model = FreeGaussianModel(cfg, seed_points=sc.means)
+with torch.no_grad():
+    gp = model.gauss_params
+    gp["scales"].copy_(sc.scales.log())
+    gp["quats"].copy_(sc.quats)
+    gp["opacities"].copy_(torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4))[:, None])
+    gp["features_dc"].copy_(sc.colors[:, 0])
+    gp["features_rest"].copy_(sc.colors[:, 1:])
+model = model.to(dev).train()
+
+
+def camera(v):
+    c2w = torch.linalg.inv(sc.viewmats[v])
+    c2w[:3, 1:3] *= -1
+    K = sc.Ks[v]
+    return Camera(c2w[None, :3], float(K[0, 0]), float(K[1, 1]), float(K[0, 2]), float(K[1, 2]), W, H,
+                  times=torch.zeros(1, 1))
+
+
+target = copy.deepcopy(model).eval()
+with torch.no_grad():
+    target.gauss_params["features_dc"].add_(0.25)
+    gts = {v: target.get_outputs(camera(v))["rgb"].clamp(0, 1) for v in range(8)}
+opts = Hn.build_optimizers(model)
+hist = []
+for i in range(25):
+    v = (i * world + rank) % 8  # this rank's view of the step
+    hist.append(Hn.train_step(model, opts, camera(v), gts[v], 10 + i, num_train_data=2,
+                              grad_sync=viewdp.all_reduce_model_grads, stats_sync=viewdp.sync_densify_stats))
+torch.cuda.synchronize()
+sig = torch.cat([torch.tensor([float(model.num_points)], device=dev)] +
+                [p.detach().double().sum().float().reshape(1) for p in model.parameters()])
+sigs = [torch.empty_like(sig) for _ in range(world)]
+dist.all_gather(sigs, sig)
+same = all(torch.equal(s, sigs[0]) for s in sigs)
+counts = [h["gaussian_count"] for h in hist]
+if rank == 0:
+    print(f"world={world} gaussian counts {counts[0]} -> {counts[-1]} ({len(set(counts))} distinct), "
+          f"loss {hist[0]['loss']:.4f} -> {hist[-1]['loss']:.4f}")
+    print("dp lockstep ok" if same and len(set(counts)) > 1 else "dp lockstep MISMATCH")
+dist.barrier()
+dist.destroy_process_group()
+sys.exit(0 if same else 1)

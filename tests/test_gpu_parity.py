@@ -857,3 +857,19 @@ def test_factored_view_dp_exchange_two_ranks_on_one_gpu():
            "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "exchange_check.py")]  # fmt: skip
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_view_dp_training_keeps_two_ranks_in_lockstep():
+    """FreeGaussianModel trained view-sharded on 2 ranks sharing this GPU (gloo): gradient exchange,
+    densification-statistics exchange and shared split samples keep the replicas bit-identical
+    through refinements (scripts/dp_train_check.py, child processes)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, FG_BENCH_BACKEND="gloo")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", "29534", os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    assert out.returncode == 0 and "dp lockstep ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
