@@ -203,17 +203,15 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
     return isect_ids, flatten_ids, offsets
 
 
-# bin_tiles: capacity guesses per (device, N, tile grid) and pinned readback buffers per device
+# bin_tiles: capacity guesses per (device, N, tile grid)
 speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
 _isect_capacity: dict = {}
-_count_buffers: dict = {}
 
 
 def _count_buffer(dev) -> torch.Tensor:
-    buf = _count_buffers.get(dev)
-    if buf is None:
-        buf = _count_buffers[dev] = torch.empty(1, dtype=torch.int64).pin_memory()
-    return buf
+    # one pinned 8-byte buffer per call (torch's caching host allocator makes this cheap): a shared
+    # one would be overwritten by a second in-flight call on the same device
+    return torch.empty(1, dtype=torch.int64, pin_memory=True)
 
 
 @torch.no_grad()
