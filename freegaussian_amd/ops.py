@@ -205,6 +205,8 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
 
 # bin_tiles: capacity guesses per (device, N, tile grid)
 speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
+static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
+last_overflow: Optional[torch.Tensor] = None
 _isect_capacity: dict = {}
 
 
@@ -245,6 +247,18 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     # (fg_bin_emit_sort_capacity reads the count on the device); the host then waits only for an
     # asynchronous readback -- the GPU keeps working meanwhile -- and repeats the call with exact
     # buffers in the rare case the guess was too small.
+    if static_capacity is not None:
+        # static-shape mode (graphed.GraphedRaster): fixed-size lists, no readback, no host wait at
+        # all -- capturable in a hipGraph.  The lists are valid iff the device-side count fits; the
+        # flag is left in `last_overflow` for the caller to check after the replay.
+        cap = int(static_capacity)
+        tile_keys = torch.empty(cap, dtype=torch.int32, device=dev)
+        flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
+        _call("fg_bin_emit_sort_capacity", N, cap, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
+              tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
+        globals()["last_overflow"] = cum[N - 1 :] > cap
+        return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h)
     count_host = _count_buffer(dev)
     count_host.copy_(cum[N - 1 :], non_blocking=True)

@@ -873,3 +873,32 @@ def test_view_dp_training_keeps_two_ranks_in_lockstep():
            "127.0.0.1", "--master-port", "29534", os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
     assert out.returncode == 0 and "dp lockstep ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_graphed_raster_replays_equal_eager_steps_and_recovers_from_overflow():
+    """graphed.GraphedRaster: forward + backward captured in one hipGraph with fixed-capacity lists
+    (count read on the device, no host wait); replays for other views equal the eager path; a view
+    whose list does not fit is detected, redone eagerly and the graph re-captured."""
+    from freegaussian_amd.graphed import GraphedRaster
+    from freegaussian_amd.viewdp import FlatGaussianParams
+
+    sc = synthetic_scene(30000, 320, 192, n_views=4, seed=31)
+    fp = FlatGaussianParams.from_scene(sc, DEV)
+    ref = FlatGaussianParams.from_scene(sc, DEV)
+    g = GraphedRaster(fp, sc.width, sc.height, sh_degree=3)
+    gen = torch.Generator().manual_seed(2)
+    for it, v in enumerate([0, 1, 2, 1, 3]):
+        vm, K = sc.viewmats[v : v + 1].to(DEV), sc.Ks[v : v + 1].to(DEV)
+        vr = torch.randn(1, sc.height, sc.width, 3, generator=gen).to(DEV)
+        if it == 3:
+            g.capacity = 2000  # far too small for any view: next replay must overflow
+            g._capture()
+        r, a, overflow = g.step(vm, K, vr)
+        assert overflow == (it == 3)
+        with ref.direct_grads():
+            r0, a0, _ = rasterization(*ref.raster_inputs(), vm, K, sc.width, sc.height, sh_degree=3, packed=False,
+                                      absgrad=True)  # fmt: skip
+            r0.backward(vr)
+        assert torch.equal(r, r0.detach()) and torch.equal(a, a0.detach())
+        assert rel_l2(fp.flat_grad, ref.flat_grad) < 1e-5  # float atomics: not bit-identical
+    assert g.graph is not None and g.capacity > 2000
