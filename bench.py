@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-crop", type=str, default="960x544")  # ~15 s of oracle time on the GPU box
     return ap.parse_args()
 
@@ -294,6 +295,27 @@ def main():
         },
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
     }  # fmt: skip
+    if world == 1 and not args.no_graph:
+        # the same step captured in one hipGraph (graphed.GraphedRaster): informational -- the
+        # headline above is the eager path, whose kernels can be timed individually
+        try:
+            from freegaussian_amd.graphed import GraphedRaster
+
+            gr = GraphedRaster(params, W, H, sh_degree=args.sh_degree)
+            for _ in range(3):
+                gr.step(vm, K, vr)
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            overflows = 0
+            for _ in range(args.steps):
+                overflows += int(gr.step(vm, K, vr)[2])
+            torch.cuda.synchronize()
+            dtg = time.perf_counter() - tg
+            out["graphed"] = {"ms_per_step": dtg / args.steps * 1e3, "value": args.steps * P / dtg / 1e6,
+                              "unit": "Mpix/s", "list_capacity": gr.capacity, "overflows": overflows,
+                              "note": "fwd+bwd replayed as one hipGraph, overflow flag read back every step"}  # fmt: skip
+        except Exception as e:  # never lose the headline line to the optional measurement
+            out["graphed"] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree)
