@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--sh-degree", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-crop", type=str, default="960x544")  # ~15 s of oracle time on the GPU box
     return ap.parse_args()
 
@@ -143,8 +144,36 @@ def cpu_baseline(scene, view, crop, sh_degree):
     }
 
 
+def graph_only(args):
+    """Child-process leg: the step replayed as one hipGraph; prints one JSON object."""
+    from freegaussian_amd.graphed import GraphedRaster
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=8, sh_degree=args.sh_degree, seed=42)
+    W, H = scene.width, scene.height
+    params = FlatGaussianParams.from_scene(scene, dev)
+    vm, K = scene.viewmats[:1].to(dev), scene.Ks[:1].to(dev)
+    vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    gr = GraphedRaster(params, W, H, sh_degree=args.sh_degree)
+    for _ in range(5):
+        gr.step(vm, K, vr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    overflows = 0
+    for _ in range(args.steps):
+        overflows += int(gr.step(vm, K, vr)[2])
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": args.steps * W * H / dt / 1e6, "unit": "Mpix/s",
+                      "list_capacity": gr.capacity, "overflows": overflows,
+                      "note": "fwd+bwd replayed as one hipGraph; the overflow flag is read back every step"}))  # fmt: skip
+
+
 def main():
     args = parse()
+    if args.graph_only:
+        return graph_only(args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -295,26 +324,19 @@ def main():
         },
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
     }  # fmt: skip
-    if world == 1 and not args.no_graph:
-        # the same step captured in one hipGraph (graphed.GraphedRaster): informational -- the
-        # headline above is the eager path, whose kernels can be timed individually
-        try:
-            from freegaussian_amd.graphed import GraphedRaster
+    if world == 1 and not args.no_graph and rank == 0:
+        # the same step captured in one hipGraph (graphed.GraphedRaster), measured in a CHILD process
+        # (a failed capture aborts the process; the headline line must survive).  Informational:
+        # the headline above is the eager path, whose kernels can be timed individually.
+        import subprocess
 
-            gr = GraphedRaster(params, W, H, sh_degree=args.sh_degree)
-            for _ in range(3):
-                gr.step(vm, K, vr)
-            torch.cuda.synchronize()
-            tg = time.perf_counter()
-            overflows = 0
-            for _ in range(args.steps):
-                overflows += int(gr.step(vm, K, vr)[2])
-            torch.cuda.synchronize()
-            dtg = time.perf_counter() - tg
-            out["graphed"] = {"ms_per_step": dtg / args.steps * 1e3, "value": args.steps * P / dtg / 1e6,
-                              "unit": "Mpix/s", "list_capacity": gr.capacity, "overflows": overflows,
-                              "note": "fwd+bwd replayed as one hipGraph, overflow flag read back every step"}  # fmt: skip
-        except Exception as e:  # never lose the headline line to the optional measurement
+        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--n-gauss",
+               str(args.n_gauss), "--width", str(args.width), "--height", str(args.height), "--sh-degree",
+               str(args.sh_degree)]  # fmt: skip
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+            out["graphed"] = json.loads(res.stdout.strip().splitlines()[-1])
+        except Exception as e:
             out["graphed"] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
