@@ -8,6 +8,11 @@ host side -- the intersection lists get a fixed capacity, the count stays on the
 graph per step: one launch, no host wait.  Gradients land in the flat buffer of a
 ``viewdp.FlatGaussianParams`` exactly as in the eager path.
 
+Caller's duty (a PyTorch rule for capturing a backward): no autograd graph built OUTSIDE the capture
+may still reference the parameters when the capture starts (drop old ``render`` / ``info``
+objects first) -- their AccumulateGrad nodes would run on the stream they were created on, not on
+the capture stream, and the capture aborts.
+
 If a replay finds more intersections than the capacity, its lists were truncated: ``step`` then
 reports ``overflow=True``, re-runs the step eagerly (exact) and re-captures with a larger capacity."""
 from __future__ import annotations
