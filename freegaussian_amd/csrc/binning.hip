@@ -220,22 +220,34 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
 __global__ void __launch_bounds__(256)
 tile_ranges32_kernel(int64_t n, const int64_t* __restrict__ n_dev, const uint32_t* __restrict__ keys, int n_tiles,
                      int32_t* __restrict__ offsets) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // four consecutive keys per thread (one 16-byte load + the predecessor's last key)
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n_dev) n = min(n, *n_dev);
   if (n == 0) {
-    if (i <= n_tiles) offsets[i] = 0;
+    for (int64_t t = 4 * q; t < 4 * q + 4; ++t)
+      if (t <= n_tiles) offsets[t] = 0;
     return;
   }
-  if (i >= n) return;
-  const int cur = (int)keys[i];
-  if (i == 0) {
-    for (int t = 0; t <= cur; ++t) offsets[t] = 0;
+  const int64_t i0 = 4 * q;
+  if (i0 >= n) return;
+  uint32_t k[4];
+  if (i0 + 4 <= n) {
+    const uint4 v = reinterpret_cast<const uint4*>(keys)[q];
+    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
   } else {
-    const int prev = (int)keys[i - 1];
-    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = i0 + j < n ? keys[i0 + j] : 0u;
   }
-  if (i == n - 1) {
-    for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
+  int prev = i0 == 0 ? -1 : (int)keys[i0 - 1];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t i = i0 + j;
+    if (i >= n) break;
+    const int cur = (int)k[j];
+    for (int t = prev + 1; t <= cur; ++t) offsets[t] = (int32_t)i;  // i == 0: t = 0..cur get 0
+    prev = cur;
+    if (i == n - 1)
+      for (int t = cur + 1; t <= n_tiles; ++t) offsets[t] = (int32_t)n;
   }
 }
 
@@ -357,7 +369,7 @@ int bin_emit_sort_any(int N, int64_t n_isects, const int64_t* n_dev, const float
                                                  workspace, workspace_bytes, s, n_dev);
     if (rc != FG_OK) return rc;
   }
-  const int64_t work = n_isects > (int64_t)n_tiles + 1 ? n_isects : (int64_t)n_tiles + 1;
+  const int64_t work = ((n_isects > (int64_t)n_tiles + 1 ? n_isects : (int64_t)n_tiles + 1) + 3) / 4;
   hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, n_dev,
                      tile_keys, n_tiles, tile_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
