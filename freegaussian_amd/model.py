@@ -133,6 +133,23 @@ class FreeGaussianModel(nn.Module):
     num_points = property(lambda self: self.gauss_params["means"].shape[0])
     device = property(lambda self: self.gauss_params["means"].device)
 
+    def load_state_dict(self, state_dict, **kwargs):  # type: ignore[override]
+        """(:278-291) the Gaussian parameters are re-allocated to the checkpoint's count, legacy
+        un-prefixed names are remapped, and -- as in the reference -- the step jumps to 30000 (SH
+        degree maxed, warm-up over)."""
+        self.step = 30000
+        state_dict = dict(state_dict)
+        if "means" in state_dict:
+            for p in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
+                state_dict[f"gauss_params.{p}"] = state_dict.pop(p)
+        if "gauss_params.means" in state_dict:
+            newp = state_dict["gauss_params.means"].shape[0]
+            for name, param in self.gauss_params.items():
+                new_shape = (newp,) + tuple(param.shape[1:])
+                if tuple(param.shape) != new_shape:
+                    self.gauss_params[name] = nn.Parameter(torch.zeros(new_shape, device=param.device))
+        return super().load_state_dict(state_dict, **kwargs)
+
     # -- H3 ---------------------------------------------------------------------------------------
     def _get_downscale_factor(self) -> int:
         """2^max(num_downscales - step // resolution_schedule, 0) while training, else 1 (:626-633)."""

@@ -293,8 +293,15 @@ def rasterize_gauss_params(
     if not render_mode.startswith("RGB"):
         raise ValueError("the raw-parameter path renders colour: use rasterization() for depth-only modes")
     N = means.shape[0]
-    if N == 0:
-        raise ValueError("empty Gaussian set")
+    if N == 0:  # nothing to draw (everything culled away): the background, empty lists
+        render, alpha, info = _empty_result(means, width, height, tile_size, render_mode, sh_degree, None,
+                                            extra_channels, False)  # fmt: skip
+        if background is not None:
+            render = render.clone()
+            render[..., :3] = background.detach().reshape(1, 1, 1, 3).to(render)
+        if clamp:
+            render = torch.cat([render[..., :3].clamp(0.0, 1.0), render[..., 3:]], dim=-1)
+        return render, alpha, info
     with_depth = render_mode.endswith("D")
     n_extra = 0 if extra_channels is None else extra_channels.shape[1]
     channels = 3 + int(with_depth) + n_extra

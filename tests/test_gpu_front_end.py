@@ -173,3 +173,15 @@ def test_model_fused_front_end_equals_torch_front_end(step, training):
     fused.after_train_iter(step)
     plain.after_train_iter(step)
     assert rel_l2(fused.xys_grad_norm, plain.xys_grad_norm) < 3 * REL_TOL
+
+
+def test_raw_front_end_with_no_gaussians_returns_the_background():
+    z = lambda *sh: torch.zeros(*sh, device=DEV)  # noqa: E731
+    vm = torch.eye(4, device=DEV)[None]
+    K = torch.tensor([[[50.0, 0, 16], [0, 50.0, 12], [0, 0, 1]]], device=DEV)
+    r, a, info = rasterize_gauss_params(z(0, 3), z(0, 4), z(0, 3), z(0, 1), z(0, 3), z(0, 15, 3), vm, K, 32, 24, 3,
+                                        background=torch.tensor([0.2, 1.5, -1.0], device=DEV), clamp=True,
+                                        render_mode="RGB+ED")  # fmt: skip
+    assert r.shape == (1, 24, 32, 4) and a.shape == (1, 24, 32, 1) and float(a.abs().max()) == 0.0
+    assert torch.allclose(r[0, 0, 0], torch.tensor([0.2, 1.0, 0.0, 0.0], device=DEV))
+    assert info["radii"].shape == (1, 0) and info["flatten_ids"].numel() == 0

@@ -154,3 +154,22 @@ def test_harness_loss_ssim_and_schedule():
     Hn.apply_schedules(opts, 15000)
     assert opts["means"].param_groups[0]["lr"] == pytest.approx((8e-4 * 8e-6) ** 0.5, rel=1e-6)
     assert opts["opacities"].param_groups[0]["lr"] == 0.05
+
+
+def test_model_load_state_dict_resizes_and_remaps_like_the_reference():
+    """freegaussian_model.py:278-291: parameters re-allocated to the checkpoint's count, legacy
+    names remapped, step forced to 30000."""
+    from freegaussian_amd.model import FreeGaussianModel, FreeGaussianModelConfig
+
+    torch.manual_seed(0)
+    src = FreeGaussianModel(FreeGaussianModelConfig(), num_points=70)
+    dst = FreeGaussianModel(FreeGaussianModelConfig(), num_points=5)
+    dst.step = 12
+    dst.load_state_dict(src.state_dict())
+    assert dst.num_points == 70 and dst.step == 30000
+    for k, v in src.state_dict().items():
+        assert torch.equal(dst.state_dict()[k], v), k
+    legacy = {k.replace("gauss_params.", ""): v for k, v in src.state_dict().items()}
+    dst2 = FreeGaussianModel(FreeGaussianModelConfig(), num_points=9)
+    dst2.load_state_dict(legacy)
+    assert dst2.num_points == 70 and torch.equal(dst2.means, src.means)
