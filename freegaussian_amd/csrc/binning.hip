@@ -156,57 +156,6 @@ depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __rest
   order[i] = i;
 }
 
-// depth_keys_kernel + the sort's pass-0 histogram in one launch (same workgroup -> key mapping as
-// fg_sort::hist_kernel: workgroup b owns keys [b*TILE, (b+1)*TILE), thread t the keys t + k*BLOCK).
-__global__ void __launch_bounds__(fg_sort::BLOCK)
-depth_keys_hist_kernel(int N, const float* __restrict__ depths, const int32_t* __restrict__ radii,
-                       uint32_t* __restrict__ keys, int32_t* __restrict__ order, uint32_t* __restrict__ block_hist) {
-  __shared__ uint32_t hist[fg_sort::RADIX];
-  hist[threadIdx.x] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * fg_sort::TILE;
-#pragma unroll 4
-  for (int k = 0; k < fg_sort::KEYS_PER_THREAD; ++k) {
-    const int64_t i = base + k * fg_sort::BLOCK + threadIdx.x;
-    if (i < N) {
-      const uint32_t key = radii[i] > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
-      keys[i] = key;
-      order[i] = (int32_t)i;
-      atomicAdd(&hist[key & (fg_sort::RADIX - 1)], 1u);
-    }
-  }
-  __syncthreads();
-  block_hist[(size_t)blockIdx.x * fg_sort::RADIX + threadIdx.x] = hist[threadIdx.x];
-}
-
-// scan_apply_kernel that folds the scan of the workgroup totals in: workgroup b sums the raw totals
-// of workgroups 0..b-1 itself (a few KB from L2) -- one launch fewer than reduce / scan / apply.
-__global__ void __launch_bounds__(SCAN_BLOCK)
-scan_apply_selfbase_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
-                           const int64_t* __restrict__ block_totals, int64_t* __restrict__ out) {
-  __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
-  int64_t part = 0;
-  for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += block_totals[b];
-  int64_t base_total;
-  block_inclusive_scan(part, wave_sums, base_total);  // only the total is used
-  const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
-  int32_t v[SCAN_ITEMS];
-  int64_t s = 0;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    v[k] = (base + k < N) ? in[order ? order[base + k] : base + k] : 0;
-    s += v[k];
-  }
-  int64_t total;
-  const int64_t incl = block_inclusive_scan(s, wave_sums, total);
-  int64_t run = base_total + incl - s;
-#pragma unroll
-  for (int k = 0; k < SCAN_ITEMS; ++k) {
-    run += v[k];
-    if (base + k < N) out[base + k] = run;
-  }
-}
-
 // Emission in depth order, wave-cooperative: the 64 Gaussians of a wavefront own ONE contiguous
 // output range [cum[k0-1], cum[k0+63]) (cum is the ordered inclusive scan), so the wave walks that
 // range 64 slots at a time -- every store instruction writes 64 consecutive (tile, id) pairs --
@@ -381,20 +330,14 @@ extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, 
   const size_t sort_bytes = fg_sort::workspace_bytes<uint32_t>(N);
   ws += sort_bytes;
   int64_t* block_sums = reinterpret_cast<int64_t*>(ws);
-  const bool fuse_hist = N > 1 && !fg_sort::use_onesweep();
-  if (fuse_hist) {
-    hipLaunchKernelGGL(depth_keys_hist_kernel, dim3(fg_sort::num_blocks(N)), dim3(fg_sort::BLOCK), 0, s, N, depths, radii,
-                       keys, order, fg_sort::block_hist_of<uint32_t>(N, sort_ws));
-  } else {
-    hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
-  }
-  const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s,
-                                               nullptr, fuse_hist);
+  hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
+  const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s);
   if (rc != FG_OK) return rc;
   const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
                      (const int32_t*)order, block_sums);
-  hipLaunchKernelGGL(scan_apply_selfbase_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
+  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
+  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
                      (const int32_t*)order, block_sums, cum_tiles);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;

@@ -437,18 +437,9 @@ static inline bool use_onesweep() {
 // Sorts in place (result copied back into keys/vals if it ends in the scratch copy).
 // With n_dev != nullptr the element count is min(n, *n_dev), read on the device: n is then only the
 // capacity the launch grids and the scratch are sized for (no host round trip for the count).
-// where the 3-kernel passes keep their per-workgroup histograms inside `workspace`: a caller that
-// produces the keys itself can fill the pass-0 histogram in the same kernel (first_hist_ready)
-template <typename KeyT>
-static inline uint32_t* block_hist_of(int64_t n, void* workspace) {
-  return reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + align256((size_t)n * sizeof(KeyT)) +
-                                     align256((size_t)n * 4));
-}
-
 template <typename KeyT>
 static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit, void* workspace,
-                             size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr,
-                             bool first_hist_ready = false) {
+                             size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr) {
   if (n <= 1 || end_bit <= 0) return FG_OK;
   if (n > 0xFFFFFFFFll) return FG_ERR_UNSUPPORTED;
   if (ws_bytes < workspace_bytes<KeyT>(n)) return FG_ERR_WORKSPACE;
@@ -482,8 +473,7 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
     uint32_t* digit_total = control + ((size_t)nb + 1) * RADIX;
     for (int p = 0; p < passes; ++p) {
       const int shift = p * RADIX_BITS;
-      if (!(p == 0 && first_hist_ready))
-        hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
+      hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
       hipLaunchKernelGGL(digit_scan_kernel, dim3(RADIX), dim3(BLOCK), 0, s, nb, block_hist, digit_total);
       hipLaunchKernelGGL(scatter_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, vin, kout, vout, shift,
                          block_hist, digit_total);
