@@ -162,10 +162,11 @@ depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __rest
 // and each lane finds the splat that owns its slot by a 6-step binary search over the wave's
 // exclusive offsets (kept in LDS).  A lane-per-Gaussian loop wrote 8-byte pieces at 64 unrelated
 // addresses per instruction instead.
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
 tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
                         const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
-                        int tile_w, int tile_h, uint32_t* __restrict__ tile_keys,
+                        int tile_w, int tile_h, KeyT* __restrict__ tile_keys,
                         int32_t* __restrict__ flatten_ids, int64_t capacity) {
   __shared__ int32_t s_excl[4][64];  // exclusive slot offset of each lane's splat inside the wave's range
   __shared__ int32_t s_gid[4][64];
@@ -211,36 +212,38 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
       const int ty = t / w, tx = t - ty * w;
       const int64_t out = base + slot;
       if (out >= capacity) continue;  // capacity launch that guessed too low: the host redoes it
-      tile_keys[out] = (uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx);
+      tile_keys[out] = (KeyT)((uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx));
       flatten_ids[out] = s_gid[wave][lo];
     }
   }
 }
 
+// tile_offsets from the sorted tile keys; 16 bytes of consecutive keys per thread (4 x u32 or 8 x u16)
+// + the predecessor's last key.
+template <typename KeyT>
 __global__ void __launch_bounds__(256)
-tile_ranges32_kernel(int64_t n, const int64_t* __restrict__ n_dev, const uint32_t* __restrict__ keys, int n_tiles,
+tile_ranges32_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys, int n_tiles,
                      int32_t* __restrict__ offsets) {
-  // four consecutive keys per thread (one 16-byte load + the predecessor's last key)
+  constexpr int KPT = 16 / sizeof(KeyT);
   const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (n_dev) n = min(n, *n_dev);
   if (n == 0) {
-    for (int64_t t = 4 * q; t < 4 * q + 4; ++t)
+    for (int64_t t = KPT * q; t < KPT * q + KPT; ++t)
       if (t <= n_tiles) offsets[t] = 0;
     return;
   }
-  const int64_t i0 = 4 * q;
+  const int64_t i0 = KPT * q;
   if (i0 >= n) return;
-  uint32_t k[4];
-  if (i0 + 4 <= n) {
-    const uint4 v = reinterpret_cast<const uint4*>(keys)[q];
-    k[0] = v.x; k[1] = v.y; k[2] = v.z; k[3] = v.w;
+  KeyT k[KPT];
+  if (i0 + KPT <= n) {
+    *reinterpret_cast<uint4*>(k) = reinterpret_cast<const uint4*>(keys)[q];
   } else {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) k[j] = i0 + j < n ? keys[i0 + j] : 0u;
+    for (int j = 0; j < KPT; ++j) k[j] = i0 + j < n ? keys[i0 + j] : (KeyT)0;
   }
   int prev = i0 == 0 ? -1 : (int)keys[i0 - 1];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
+  for (int j = 0; j < KPT; ++j) {
     const int64_t i = i0 + j;
     if (i >= n) break;
     const int cur = (int)k[j];
@@ -344,13 +347,40 @@ extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, 
 }
 
 extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
-  return fg_sort::workspace_bytes<uint32_t>(n_isects > 0 ? n_isects : 1);
+  // covers both layouts: 32-bit keys in the caller's buffer, or 16-bit keys + their sort scratch
+  // in here (same byte count up to alignment padding)
+  return fg_sort::workspace_bytes<uint32_t>(n_isects > 0 ? n_isects : 1) + 1024;
 }
 
 namespace {
 
 // n_dev == nullptr: exactly n_isects intersections.  Otherwise n_isects is a capacity and the
 // count is read on the device from *n_dev (clamped to the capacity).
+template <typename KeyT>
+int bin_emit_sort_keys(int N, int64_t n_isects, const int64_t* n_dev, const float* means2d, const int32_t* radii,
+                       const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
+                       KeyT* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets, void* sort_ws, size_t sort_bytes,
+                       hipStream_t s) {
+  const int n_tiles = tile_w * tile_h;
+  if (n_isects > 0) {
+    hipLaunchKernelGGL(tile_bin_ordered_kernel<KeyT>, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
+                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
+    int bits = 1;
+    while ((1 << bits) < n_tiles) ++bits;
+    const int rc = fg_sort::sort_pairs<KeyT>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits, sort_ws,
+                                             sort_bytes, s, n_dev);
+    if (rc != FG_OK) return rc;
+  }
+  constexpr int KPT = 16 / sizeof(KeyT);
+  const int64_t work = ((n_isects > (int64_t)n_tiles + 1 ? n_isects : (int64_t)n_tiles + 1) + KPT - 1) / KPT;
+  hipLaunchKernelGGL(tile_ranges32_kernel<KeyT>, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, n_dev,
+                     tile_keys, n_tiles, tile_offsets);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
+// tile_keys == nullptr: the caller does not want the keys; they then live in the workspace as
+// 16-bit values (tile ids < 65536), which cuts the traffic of emission + two sort passes from 48
+// to 34 bytes per intersection.
 int bin_emit_sort_any(int N, int64_t n_isects, const int64_t* n_dev, const float* means2d, const int32_t* radii,
                       const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
                       uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets, void* workspace,
@@ -358,22 +388,18 @@ int bin_emit_sort_any(int N, int64_t n_isects, const int64_t* n_dev, const float
   if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
   if (tile_w > 1023 || tile_h > 1023) return FG_ERR_UNSUPPORTED;  // rectangle packing of the emit kernel
   hipStream_t s = fg_hip_stream(stream);
-  const int n_tiles = tile_w * tile_h;
-  if (n_isects > 0) {
-    if (!means2d || !radii || !order || !cum_tiles || !tile_keys || !flatten_ids || !workspace) return FG_ERR_INVALID_ARG;
-    hipLaunchKernelGGL(tile_bin_ordered_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
-                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
-    int bits = 1;
-    while ((1 << bits) < n_tiles) ++bits;
-    const int rc = fg_sort::sort_pairs<uint32_t>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits,
-                                                 workspace, workspace_bytes, s, n_dev);
-    if (rc != FG_OK) return rc;
+  if (n_isects > 0 && (!means2d || !radii || !order || !cum_tiles || !flatten_ids || !workspace)) return FG_ERR_INVALID_ARG;
+  if (workspace_bytes < fg_bin_emit_workspace_bytes(n_isects)) return FG_ERR_WORKSPACE;
+  if (tile_keys || tile_w * tile_h > 65536) {
+    if (n_isects > 0 && !tile_keys) return FG_ERR_INVALID_ARG;  // > 65536 tiles: 32-bit keys, caller's buffer
+    return bin_emit_sort_keys<uint32_t>(N, n_isects, n_dev, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
+                                        tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, s);
   }
-  const int64_t work = ((n_isects > (int64_t)n_tiles + 1 ? n_isects : (int64_t)n_tiles + 1) + 3) / 4;
-  hipLaunchKernelGGL(tile_ranges32_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, s, n_isects, n_dev,
-                     tile_keys, n_tiles, tile_offsets);
-  FG_RETURN_IF_LAUNCH_FAILED();
-  return FG_OK;
+  char* ws = static_cast<char*>(workspace);
+  uint16_t* keys16 = reinterpret_cast<uint16_t*>(ws);
+  const size_t head = al256((size_t)(n_isects > 0 ? n_isects : 1) * 2);
+  return bin_emit_sort_keys<uint16_t>(N, n_isects, n_dev, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
+                                      keys16, flatten_ids, tile_offsets, ws + head, workspace_bytes - head, s);
 }
 
 }  // namespace

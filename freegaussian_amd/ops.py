@@ -217,7 +217,15 @@ def _count_buffer(dev) -> torch.Tensor:
 
 
 @torch.no_grad()
-def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False):
+def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
+    """The sorted list's tile ids [n] int32, rebuilt from the tile ranges (the product path does
+    not materialise them: fg_bin_emit_sort keeps 16-bit keys in its workspace)."""
+    counts = (offsets[1:] - offsets[:-1]).long()
+    tiles = torch.arange(counts.numel(), dtype=torch.int32, device=offsets.device)
+    return torch.repeat_interleave(tiles, counts, output_size=int(n))
+
+
+def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False, want_keys=True):
     """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
     -> (tile_keys[I] uint32-as-int32, flatten_ids[I] int32, tile_offsets[T+1] int32); the lists are
     bit-identical to ``isect_tiles`` (same (tile, depth, id) order).
@@ -228,7 +236,9 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     the kernels that consume them and THEN call ``finish() -> (tile_keys, flatten_ids, redone)``,
     which waits for the count, slices, and -- if the guess was too small -- re-runs emission + sort
     on exact buffers (``redone=True``: consumers must be re-run too).  ``finish`` is None when
-    nothing was deferred."""
+    nothing was deferred.  ``want_keys=False``: tile_keys comes back as None (16-bit keys stay inside
+    the kernels' workspace; ``tile_keys_from_offsets`` rebuilds them on demand)."""
+    want_keys = want_keys or tile_w * tile_h > 65536
     lib = _lib.load()
     N = means2d.shape[0]
     dev = means2d.device
@@ -252,7 +262,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         # all -- capturable in a hipGraph.  The lists are valid iff the device-side count fits; the
         # flag is left in `last_overflow` for the caller to check after the replay.
         cap = int(static_capacity)
-        tile_keys = torch.empty(cap, dtype=torch.int32, device=dev)
+        tile_keys = torch.empty(cap, dtype=torch.int32, device=dev) if want_keys else None
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
         _call("fg_bin_emit_sort_capacity", N, cap, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
@@ -267,7 +277,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     capacity = _isect_capacity.get(key) if speculative_binning else None
     tile_keys = flatten_ids = None
     if capacity is not None:
-        tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev)
+        tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev) if want_keys else None
         flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(capacity)), dtype=torch.uint8, device=dev)
         _call("fg_bin_emit_sort_capacity", N, capacity, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
@@ -279,8 +289,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
             raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
         _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
         if capacity is not None and n_isects <= capacity:
-            return tile_keys[:n_isects], flatten_ids[:n_isects], False
-        tk = torch.empty(n_isects, dtype=torch.int32, device=dev)
+            return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
+        tk = torch.empty(n_isects, dtype=torch.int32, device=dev) if want_keys else None
         ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         ws3 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
         _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size, tile_w,

@@ -184,7 +184,7 @@ def rasterization(
 
     # speculative lists: the raster forward is enqueued before the host waits for the list length
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False
     )
 
     if packed:
@@ -224,7 +224,6 @@ def rasterization(
         "tile_width": tile_w,
         "tile_height": tile_h,
         "tiles_per_gauss": tiles[None],
-        "tile_keys": tile_keys,
         "flatten_ids": flatten_ids,
         "isect_offsets": offsets,
         "last_ids": last_ids,
@@ -233,8 +232,11 @@ def rasterization(
         "tile_size": tile_size,
         "n_cameras": 1,
     })
-    # the 64-bit (tile | depth) keys of the sorted list are only materialised if somebody asks
-    info.lazy("isect_ids", lambda: ops.isect_keys(tile_keys, flatten_ids, depths.detach()))
+    # the tile ids and the 64-bit (tile | depth) keys of the sorted list are only materialised if
+    # somebody asks
+    info.lazy("tile_keys", lambda: tile_keys if tile_keys is not None
+              else ops.tile_keys_from_offsets(offsets, flatten_ids.numel()))  # fmt: skip
+    info.lazy("isect_ids", lambda: ops.isect_keys(info["tile_keys"], flatten_ids, depths.detach()))
     if packed:
         info.update(
             camera_ids=torch.zeros_like(gids),
@@ -317,7 +319,7 @@ def rasterize_gauss_params(
         antialiased=(rasterize_mode == "antialiased"), with_depth=with_depth,
     )  # fmt: skip
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False
     )
     means2d_info = means2d_n.unsqueeze(0)
     bg = None
@@ -340,9 +342,11 @@ def rasterize_gauss_params(
     info = _Info({
         "radii": radii[None], "means2d": means2d_info, "depths": depths[None], "conics": conics[None],
         "opacities": splats[:, 2][None], "tile_width": tile_w, "tile_height": tile_h,
-        "tiles_per_gauss": tiles[None], "tile_keys": tile_keys, "flatten_ids": flatten_ids,
+        "tiles_per_gauss": tiles[None], "flatten_ids": flatten_ids,
         "isect_offsets": offsets, "last_ids": last_ids, "width": width, "height": height,
         "tile_size": tile_size, "n_cameras": 1,
     })  # fmt: skip
-    info.lazy("isect_ids", lambda: ops.isect_keys(tile_keys, flatten_ids, depths.detach()))
+    info.lazy("tile_keys", lambda: tile_keys if tile_keys is not None
+              else ops.tile_keys_from_offsets(offsets, flatten_ids.numel()))  # fmt: skip
+    info.lazy("isect_ids", lambda: ops.isect_keys(info["tile_keys"], flatten_ids, depths.detach()))
     return render[None], alpha[None], info
