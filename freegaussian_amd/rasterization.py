@@ -234,9 +234,13 @@ def rasterization(
     })
     # the tile ids and the 64-bit (tile | depth) keys of the sorted list are only materialised if
     # somebody asks
-    info.lazy("tile_keys", lambda: tile_keys if tile_keys is not None
-              else ops.tile_keys_from_offsets(offsets, flatten_ids.numel()))  # fmt: skip
-    info.lazy("isect_ids", lambda: ops.isect_keys(info["tile_keys"], flatten_ids, depths.detach()))
+    # (the thunks must not refer to `info` itself: a reference cycle would keep its tensors -- and the
+    # autograd graph behind them -- alive until the cyclic collector runs)
+    def _tile_keys():
+        return tile_keys if tile_keys is not None else ops.tile_keys_from_offsets(offsets, flatten_ids.numel())
+
+    info.lazy("tile_keys", _tile_keys)
+    info.lazy("isect_ids", lambda: ops.isect_keys(_tile_keys(), flatten_ids, depths.detach()))
     if packed:
         info.update(
             camera_ids=torch.zeros_like(gids),
@@ -346,7 +350,11 @@ def rasterize_gauss_params(
         "isect_offsets": offsets, "last_ids": last_ids, "width": width, "height": height,
         "tile_size": tile_size, "n_cameras": 1,
     })  # fmt: skip
-    info.lazy("tile_keys", lambda: tile_keys if tile_keys is not None
-              else ops.tile_keys_from_offsets(offsets, flatten_ids.numel()))  # fmt: skip
-    info.lazy("isect_ids", lambda: ops.isect_keys(info["tile_keys"], flatten_ids, depths.detach()))
+    # (the thunks must not refer to `info` itself: a reference cycle would keep its tensors -- and the
+    # autograd graph behind them -- alive until the cyclic collector runs)
+    def _tile_keys():
+        return tile_keys if tile_keys is not None else ops.tile_keys_from_offsets(offsets, flatten_ids.numel())
+
+    info.lazy("tile_keys", _tile_keys)
+    info.lazy("isect_ids", lambda: ops.isect_keys(_tile_keys(), flatten_ids, depths.detach()))
     return render[None], alpha[None], info
