@@ -50,6 +50,9 @@ class GraphedRaster:
         return r.detach(), a.detach(), int(info["flatten_ids"].numel())
 
     def _capture(self):
+        import gc
+
+        gc.collect()  # drop unreachable autograd graphs (reference cycles) that still hold the parameters
         ops.static_capacity = self.capacity
         try:
             side = torch.cuda.Stream()
