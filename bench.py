@@ -271,6 +271,14 @@ def main():
         "avg_ms": stages[dom],
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # the HBM-bound stages next to it: measured traffic (same PMC file) over their HIP-event time
+    hbm_stages = {}
+    for st_name in ("fg_preprocess_fwd", "fg_preprocess_bwd", "fg_raster_fwd", "fg_raster_bwd"):
+        tr = pmc_traffic(st_name, f"{N}x{W}x{H}xsh{args.sh_degree}")
+        if tr is not None and st_name in stages:
+            gbs = tr / (stages[st_name] * 1e-3) / 1e9
+            hbm_stages[st_name] = {"traffic": tr, "avg_ms": stages[st_name], "achieved_GBs": gbs,
+                                   "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}  # fmt: skip
     total_alg = 280 * N + (176 + 24 * k) * V + (100 + 24 * p) * I + 56 * P + 8 * T
     # BASELINE.md section 3 protocol: per-step HIP-event times, median with p10 / p90
     def pct(xs, q):
@@ -315,6 +323,7 @@ def main():
             "parallelism": f"view-dp{world}",
         },
         "roofline": roof,
+        "measured_hbm_traffic_by_stage": hbm_stages,
         "hip_event_times": event_times,
         "whole_step": {
             "algorithmic_bytes": total_alg,
