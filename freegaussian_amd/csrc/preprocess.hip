@@ -220,7 +220,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
 __global__ void __launch_bounds__(BLOCK)
 preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d_quats,
                       float* __restrict__ v_d_scales, float* __restrict__ v_features_rest,
-                      float* __restrict__ v_rgb,
+                      float* __restrict__ v_rgb, int v_rgb_floats,
                       const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
                       const float* __restrict__ colors, const float* __restrict__ viewmat,
@@ -244,6 +244,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   float g_m[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f}, g_s[3] = {0.f, 0.f, 0.f};
   float g_o = 0.f;
   float vr = 0.f, vg = 0.f, vb = 0.f;
+  float sh_dx = 0.f, sh_dy = 0.f, sh_dz = 0.f;  // unit view direction the SH basis was evaluated at
   float basis[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) basis[k] = 0.f;
@@ -283,6 +284,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       const float ux = mx - cx, uy = my - cy, uz = mz - cz;
       const float inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
       const float dx = ux * inv, dy = uy * inv, dz = uz * inv;
+      sh_dx = dx; sh_dy = dy; sh_dz = dz;
       sh_basis(fl.sh_degree, dx, dy, dz, basis);
       const float* crow = lds + threadIdx.x * ROW;
       // recompute the clamp mask: colour = max(sh + 0.5, 0)
@@ -369,7 +371,11 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   // 192-B coefficient row it expands to (v_coeffs[k] = basis_k(dir) * v_rgb, rebuilt after the
   // exchange by fg_sh_grad_accumulate)
   if (v_rgb && i < N) {
-    v_rgb[3 * i] = vr; v_rgb[3 * i + 1] = vg; v_rgb[3 * i + 2] = vb;
+    float* o = v_rgb + (size_t)v_rgb_floats * i;
+    o[0] = vr; o[1] = vg; o[2] = vb;
+    if (v_rgb_floats == 6) {  // per-view (deformed) means: the direction travels with the gradient
+      o[3] = sh_dx; o[4] = sh_dy; o[5] = sh_dz;
+    }
   }
   // ---- v_coeffs rows out through LDS -------------------------------------------------------------
   if (kk > 0 && v_colors) {
@@ -429,7 +435,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
 }
 
 int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scales, float* v_features_rest,
-                          float* v_rgb,
+                          float* v_rgb, int v_rgb_floats,
                           const float* means, const float* quats, const float* scales, const float* opacities,
                           const float* colors, int sh_degree, int k_stored, int n_color, int with_depth, int n_extra,
                           const float* viewmat, const float* K, int width, int height, float eps2d, int antialiased,
@@ -447,13 +453,14 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
   if ((fl.n_color > 0 && (!colors || (!v_colors && !(v_rgb && sh_degree >= 0)))) || (n_extra > 0 && !v_extra))
     return FG_ERR_INVALID_ARG;
   if (v_rgb && (sh_degree < 0 || raw.enabled)) return FG_ERR_UNSUPPORTED;
+  if (v_rgb && v_rgb_floats != 3 && v_rgb_floats != 6) return FG_ERR_INVALID_ARG;
   if (raw.enabled) {
     if (sh_degree < 0 || (k_stored > 1 && (!raw.features_rest || !v_features_rest))) return FG_ERR_INVALID_ARG;
     if ((raw.d_quats != nullptr) != (v_d_quats != nullptr) || (raw.d_scales != nullptr) != (v_d_scales != nullptr))
       return FG_ERR_INVALID_ARG;
   }
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
-                     fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, means, quats, scales, opacities, colors,
+                     fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, v_rgb_floats, means, quats, scales, opacities, colors,
                      viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                      v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra);
   FG_RETURN_IF_LAUNCH_FAILED();
@@ -484,7 +491,7 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
                                  const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                                  float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
                                  fg_stream_t stream) {
-  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr, means, quats,
+  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr, 3, means, quats,
                                scales, opacities, colors, sh_degree, k_stored, n_color, with_depth, n_extra, viewmat,
                                K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                                v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
@@ -519,7 +526,7 @@ extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* qua
                                      float* v_features_dc, float* v_features_rest, float* v_extra,
                                      fg_stream_t stream) {
   return launch_preprocess_bwd(N, RawForm{1, d_quats, d_scales, features_rest}, v_d_quats, v_d_scales,
-                               v_features_rest, nullptr, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
+                               v_features_rest, nullptr, 3, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
                                k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
                                v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats,
                                v_log_scales, v_opacity_logits, v_features_dc, v_extra, stream);
@@ -532,9 +539,9 @@ extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float
                                           const float* v_splats, const float* v_means2d, int v_means2d_stride,
                                           const float* v_depths, const float* v_conics, float* v_means,
                                           float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
-                                          float* v_extra, fg_stream_t stream) {
+                                          int v_rgb_floats, float* v_extra, fg_stream_t stream) {
   if (!v_rgb) return FG_ERR_INVALID_ARG;
-  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, v_rgb, means, quats,
+  return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, v_rgb, v_rgb_floats, means, quats,
                                scales, opacities, colors, sh_degree, k_stored, 3, with_depth, n_extra, viewmat, K,
                                width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                                v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, nullptr, v_extra, stream);

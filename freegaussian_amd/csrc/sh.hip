@@ -137,10 +137,12 @@ sh_bwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, 
 // (all-gathered, 12 B per Gaussian per view) and rebuilds the summed coefficient gradient
 //   v_coeffs[i,k,:] = scale * sum_v basis_k(dir_v(i)) * g_v[i,:]
 // locally -- 192 B per Gaussian that never cross xGMI.  payload: n_views blocks of view_stride
-// floats, block v = [g_v (3N floats) | camera position of view v (3 floats)].
+// floats; payload_floats == 3: block v = [g_v (3N floats) | camera position of view v (3 floats)]
+// and the direction is normalize(means - camera); payload_floats == 6: block v = N rows of
+// [g_v (3) | unit direction (3)] (per-view deformed means: every rank saw different positions).
 __global__ void __launch_bounds__(BLOCK)
 sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const float* __restrict__ means,
-                          const float* __restrict__ payload, int64_t view_stride, float scale,
+                          const float* __restrict__ payload, int64_t view_stride, int payload_floats, float scale,
                           float* __restrict__ v_coeffs) {
   __shared__ float lds[BLOCK * ROW];
   const int row0 = blockIdx.x * BLOCK;
@@ -151,15 +153,22 @@ sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const fl
 #pragma unroll
   for (int q = 0; q < 48; ++q) acc[q] = 0.f;
   if (i < N) {
-    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+    float mx = 0.f, my = 0.f, mz = 0.f;
+    if (payload_floats == 3) { mx = means[3 * i]; my = means[3 * i + 1]; mz = means[3 * i + 2]; }
     for (int v = 0; v < n_views; ++v) {
       const float* blk = payload + (size_t)v * view_stride;
-      const float gr = blk[3 * i], gg = blk[3 * i + 1], gb = blk[3 * i + 2];
+      const float* row = blk + (size_t)payload_floats * i;
+      const float gr = row[0], gg = row[1], gb = row[2];
       if (gr == 0.f && gg == 0.f && gb == 0.f) continue;  // culled or untouched in that view
-      const float* cam = blk + (size_t)3 * N;
-      float dx = mx - cam[0], dy = my - cam[1], dz = mz - cam[2];
-      const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-      dx *= inv; dy *= inv; dz *= inv;
+      float dx, dy, dz;
+      if (payload_floats == 6) {
+        dx = row[3]; dy = row[4]; dz = row[5];
+      } else {
+        const float* cam = blk + (size_t)3 * N;
+        dx = mx - cam[0]; dy = my - cam[1]; dz = mz - cam[2];
+        const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
+        dx *= inv; dy *= inv; dz *= inv;
+      }
       float basis[16];
 #pragma unroll
       for (int k = 0; k < 16; ++k) basis[k] = 0.f;
@@ -182,15 +191,16 @@ sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const fl
 }  // namespace
 
 extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
-                                     const float* payload, int64_t view_stride, float scale, float* v_coeffs,
-                                     fg_stream_t stream) {
+                                     const float* payload, int64_t view_stride, int payload_floats, float scale,
+                                     float* v_coeffs, fg_stream_t stream) {
   if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || k_stored < (sh_degree + 1) * (sh_degree + 1) ||
-      k_stored > 16 || view_stride < (int64_t)3 * N + 3)
+      k_stored > 16 || (payload_floats != 3 && payload_floats != 6) ||
+      view_stride < (payload_floats == 3 ? (int64_t)3 * N + 3 : (int64_t)6 * N))
     return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
-  if (!means || !payload || !v_coeffs) return FG_ERR_INVALID_ARG;
+  if ((payload_floats == 3 && !means) || !payload || !v_coeffs) return FG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(sh_grad_accumulate_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream),
-                     N, n_views, sh_degree, k_stored, means, payload, view_stride, scale, v_coeffs);
+                     N, n_views, sh_degree, k_stored, means, payload, view_stride, payload_floats, scale, v_coeffs);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

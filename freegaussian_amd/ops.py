@@ -518,13 +518,13 @@ class _Preprocess(torch.autograd.Function):
             v_means2d, m2_stride = v_means2d.contiguous(), 2
         if color_grad_sink is not None and sh_degree >= 0 and colors is not None:
             # factored form: 12 B of colour gradient per Gaussian instead of the 192-B coefficient row
-            v_rgb = color_grad_sink("alloc", N, means.device)
+            v_rgb = color_grad_sink("alloc", N, means.device)  # [N,3] or [N,6] (g | unit view direction)
             _call("fg_preprocess_bwd_factored", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
                   _ptr(colors), sh_degree, k_stored, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height,
                   eps2d, int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
                   _ptr(None if v_depths is None else v_depths.contiguous()),
                   _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
-                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), _ptr(v_extra), _stream())  # fmt: skip
+                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _stream())  # fmt: skip
             color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, colors)
             return v_means, v_quats, v_scales, v_opac, None, v_extra, None, None, None
         v_colors = _alloc_grad(colors) if colors is not None else None

@@ -104,7 +104,7 @@ class FlatGaussianParams:
 
         return cm()
 
-    def factored_exchange(self, average: bool = True, group=None):
+    def factored_exchange(self, average: bool = True, group=None, per_view_means: bool = False):
         """Context manager for one view-sharded step with the FACTORED gradient exchange
         (use instead of ``direct_grads()`` + ``all_reduce_grads()``; one ``rasterization`` call
         with SH colours per step per rank, like ``direct_grads``).
@@ -118,7 +118,12 @@ class FlatGaussianParams:
         Gaussians that is 84 MB received + a 44 MB all-reduce instead of a 236 MB all-reduce.
         The all-gather is issued from inside the backward (as soon as ``g`` exists) and the
         local rebuild overlaps the small all-reduce.  On exit every ``.grad`` holds the (averaged)
-        sum over ranks, exactly as after ``all_reduce_grads`` up to fp32 summation order."""
+        sum over ranks, exactly as after ``all_reduce_grads`` up to fp32 summation order.
+
+        ``per_view_means=True``: the ranks render different positions of the same Gaussians
+        (per-view deformation, freegaussian_model.py:832-845), so a direction cannot be rebuilt
+        from shared means + a camera position; the unit view direction then travels with the colour
+        gradient (24 B instead of 12 B per Gaussian per rank)."""
         import contextlib
 
         from . import _lib, ops
@@ -127,17 +132,21 @@ class FlatGaussianParams:
         n = self.n
         state = {}
 
+        pf = 6 if per_view_means else 3
+        stride = n * 6 if per_view_means else (n + 1) * 3
+
         def sink(what, *a):
             if what == "alloc":
-                state["payload"] = torch.empty((n + 1) * 3, device=self.flat.device, dtype=torch.float32)
-                return state["payload"][: 3 * n].view(n, 3)
+                state["payload"] = torch.empty(stride, device=self.flat.device, dtype=torch.float32)
+                return state["payload"][: pf * n].view(n, pf)
             _v_rgb, means, viewmat, sh_degree, colors = a
             payload = state["payload"]
-            vm = viewmat.reshape(-1, 4)[:3]
-            payload[3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
+            if not per_view_means:
+                vm = viewmat.reshape(-1, 4)[:3]
+                payload[3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
             state.update(means=means, sh_degree=int(sh_degree), k_stored=int(colors.shape[1]))
             if world > 1:
-                gathered = torch.empty(world * (n + 1) * 3, device=payload.device, dtype=torch.float32)
+                gathered = torch.empty(world * stride, device=payload.device, dtype=torch.float32)
                 if dist.get_backend(group) == "nccl":
                     state["work"] = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
                 else:
@@ -152,7 +161,10 @@ class FlatGaussianParams:
             prev_sink = ops.color_grad_sink
             ops.color_grad_sink = sink
             try:
-                with self.direct_grads():
+                # shared means: the raster inputs ARE the parameters, gradients land directly in the flat
+                # buffer.  Per-view means are computed from the parameters (deformation): ordinary
+                # accumulation into the pre-bound .grad views -- the caller zero_grad()s first.
+                with (contextlib.nullcontext(self) if per_view_means else self.direct_grads()):
                     yield self
             finally:
                 ops.color_grad_sink = prev_sink
@@ -167,7 +179,7 @@ class FlatGaussianParams:
             vc = self.grad_views["colors"]
             _lib.check(lib.fg_sh_grad_accumulate(
                 n, world, state["sh_degree"], state["k_stored"], state["means"].detach().contiguous().data_ptr(),
-                state["gathered"].data_ptr(), (n + 1) * 3, scale, vc.data_ptr(),
+                state["gathered"].data_ptr(), stride, pf, scale, vc.data_ptr(),
                 torch.cuda.current_stream().cuda_stream), "fg_sh_grad_accumulate")  # fmt: skip
             self.params["colors"].grad = vc
             if work is not None:

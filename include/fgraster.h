@@ -260,10 +260,13 @@ int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const f
  * The SH coefficient gradient of one view is rank-1 per Gaussian: v_coeffs[i,k,:] =
  * basis_k(dir_view(i)) * g[i,:] with g the clamp-masked colour gradient.  Instead of all-reducing
  * 192 B per Gaussian, ranks all-gather g (12 B) and rebuild the sum locally.
- * fg_preprocess_bwd_factored = fg_preprocess_bwd (SH colours) that writes v_rgb[N,3] = g instead
- * of v_colors.  fg_sh_grad_accumulate: payload = n_views blocks of view_stride floats, block v =
- * [g_v (3N floats) | camera position of view v (3 floats) | padding]; writes
- * v_coeffs[N,k_stored,3] = scale * sum_v basis(normalize(means - cam_v)) (x) g_v densely. */
+ * fg_preprocess_bwd_factored = fg_preprocess_bwd (SH colours) that writes v_rgb[N,v_rgb_floats]
+ * instead of v_colors: g (3 floats), or g + the unit view direction the basis was evaluated at
+ * (6 floats) when every rank renders its own deformed means.  fg_sh_grad_accumulate: payload =
+ * n_views blocks of view_stride floats; payload_floats = 3: block v = [g_v (3N floats) | camera
+ * position of view v (3 floats) | padding] and the direction is normalize(means - cam_v);
+ * payload_floats = 6: block v = N rows [g_v | direction] (means unused, may be NULL).  Writes
+ * v_coeffs[N,k_stored,3] = scale * sum_v basis(direction_v) (x) g_v densely. */
 int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, const float* scales,
                                const float* opacities, const float* colors, int sh_degree, int k_stored,
                                int with_depth, int n_extra, const float* viewmat, const float* K,
@@ -271,10 +274,10 @@ int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, co
                                const float* v_splats, const float* v_means2d, int v_means2d_stride,
                                const float* v_depths, const float* v_conics, float* v_means,
                                float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
-                               float* v_extra, fg_stream_t stream);
+                               int v_rgb_floats, float* v_extra, fg_stream_t stream);
 int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
-                          const float* payload, int64_t view_stride, float scale, float* v_coeffs,
-                          fg_stream_t stream);
+                          const float* payload, int64_t view_stride, int payload_floats, float scale,
+                          float* v_coeffs, fg_stream_t stream);
 
 /* ---- D: adaptive density control ---------------------------------
  * The reference's refinement_after / split_gaussians / dup_gaussians / cull_gaussians and the

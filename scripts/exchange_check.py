@@ -21,19 +21,36 @@ dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else
 sc = synthetic_scene(60000, 320, 192, n_views=8, sh_degree=3, seed=42)
 vm, K = sc.viewmats[rank % 8 : rank % 8 + 1].to(dev), sc.Ks[rank % 8 : rank % 8 + 1].to(dev)
 vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+per_view = os.environ.get("FG_PER_VIEW_MEANS") == "1"  # every rank renders its own displaced means
+shift = 0.01 * (rank + 1) * torch.sin(torch.arange(sc.means.shape[0] * 3, device=dev).float()).view(-1, 3)
+
+
+def render(p):
+    means, quats, scales, opac, colors = p.raster_inputs()
+    if per_view:
+        means = means + shift  # stands in for the per-view deformation (:832-845)
+    r, _, _ = rasterization(means, quats, scales, opac, colors, vm, K, sc.width, sc.height, sh_degree=3,
+                            packed=False, absgrad=True)
+    r.backward(vr)
+
+
 grads = []
 for mode in ("plain", "factored"):
     p = FlatGaussianParams.from_scene(sc, dev)
     p.flat_grad.fill_(float("nan"))
     if mode == "plain":
-        with p.direct_grads():
-            r, _, _ = rasterization(*p.raster_inputs(), vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True)
-            r.backward(vr)
+        if per_view:  # the displaced means are not a leaf: ordinary accumulation into the flat buffer
+            p.zero_grad()
+            render(p)
+        else:
+            with p.direct_grads():
+                render(p)
         p.all_reduce_grads()
     else:
-        with p.factored_exchange():
-            r, _, _ = rasterization(*p.raster_inputs(), vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True)
-            r.backward(vr)
+        if per_view:
+            p.zero_grad()
+        with p.factored_exchange(per_view_means=per_view):
+            render(p)
     torch.cuda.synchronize()
     assert bool(torch.isfinite(p.flat_grad).all()), mode
     assert all(q.grad is not None for q in p.raster_inputs()), mode
