@@ -852,11 +852,12 @@ def test_factored_view_dp_exchange_two_ranks_on_one_gpu():
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FG_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29533", os.path.join(root, "scripts", "exchange_check.py")]  # fmt: skip
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
-    assert out.returncode == 0 and "exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    for per_view, port in (("0", "29533"), ("1", "29535")):  # shared means / per-view (deformed) means
+        env = dict(os.environ, FG_BENCH_BACKEND="gloo", FG_PER_VIEW_MEANS=per_view)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(root, "scripts", "exchange_check.py")]  # fmt: skip
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0 and "exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
 def test_view_dp_training_keeps_two_ranks_in_lockstep():
