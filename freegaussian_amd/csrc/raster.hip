@@ -307,7 +307,6 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         // PPT == 4: skip the strips the splat cannot reach; with 1-2 slots per lane the test
         // costs more scalar work than it saves
         if (PPT >= FG_FWD_STRIP_TEST_MIN_PPT && !((packed >> (8 + wave + k * (4 / PPT))) & 1u)) continue;
-        if (PPT > 1 && done[k] == full) continue;  // every pixel of this slot has terminated (scalar test)
         // one wave-uniform branch, then select-predicated straight-line code (no nested
         // divergent ifs: each costs exec save/restore and merge copies)
         const float dy = s.y - py[k];
@@ -426,11 +425,6 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   }
   const int n_used = bin_final - start + 1;
   if (n_used <= 0) return;
-  // last list entry any pixel of each SLOT used (wave-uniform): entries behind it are dead for the
-  // whole slot and are skipped by a scalar compare before any vector work
-  int slot_last[PPT];
-#pragma unroll
-  for (int k = 0; k < PPT; ++k) slot_last[k] = __builtin_amdgcn_readfirstlane(fg::wave_max_i32(last[k]));
   const int n_batches = (n_used + NT - 1) / NT;
   if (threadIdx.x == 0) { FG_STAT(5, n_used); FG_STAT(6, end - start); }
   float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
@@ -503,7 +497,6 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-          if (idx_j > slot_last[k]) continue;                                  // wave-uniform
           const float dy = s.y - py[k];
           const float e2 = neg_sigma_log2e(st, dy);
           const float vis = __builtin_amdgcn_exp2f(e2);
