@@ -100,6 +100,21 @@ def pmc_traffic(stage, workload_key):
     return None
 
 
+def pmc_valu(stage, workload_key):
+    """Vector wave-instructions per launch of `stage`'s kernel (SQ_INSTS_VALU of the same PMC file)."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    kern = STAGE_KERNEL.get(stage)
+    if kern is None or not os.path.exists(path):
+        return None
+    rec = json.load(open(path))
+    if rec.get("workload_key") != workload_key:
+        return None
+    for name, v in rec["kernels"].items():
+        if name.startswith(kern):
+            return v.get("valu_wave_instr_per_launch")
+    return None
+
+
 def cpu_baseline(scene, view, crop, sh_degree):
     """The CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is the absent
     CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd."""
@@ -271,6 +286,16 @@ def main():
         "avg_ms": stages[dom],
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
+    # the roof that actually binds the raster kernels: vector issue.  A wave64 fp32 instruction occupies
+    # a SIMD16 for 4 clocks; 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+    issue = {}
+    for st_name in ("fg_raster_bwd", "fg_raster_fwd"):
+        vi = pmc_valu(st_name, f"{N}x{W}x{H}xsh{args.sh_degree}")
+        if vi is not None and st_name in stages:
+            peak = 1024 * 2.4e9 / 4  # wave-instructions per second
+            issue[st_name] = {"valu_wave_instr": vi, "avg_ms": stages[st_name],
+                              "achieved_G_instr_per_s": vi / (stages[st_name] * 1e-3) / 1e9,
+                              "peak_G_instr_per_s": peak / 1e9, "frac": vi / (stages[st_name] * 1e-3) / peak}  # fmt: skip
     # the HBM-bound stages next to it: measured traffic (same PMC file) over their HIP-event time
     hbm_stages = {}
     for st_name in ("fg_preprocess_fwd", "fg_preprocess_bwd", "fg_raster_fwd", "fg_raster_bwd"):
@@ -323,6 +348,7 @@ def main():
             "parallelism": f"view-dp{world}",
         },
         "roofline": roof,
+        "vector_issue_roofline": issue,
         "measured_hbm_traffic_by_stage": hbm_stages,
         "hip_event_times": event_times,
         "whole_step": {
