@@ -903,3 +903,31 @@ def test_graphed_raster_replays_equal_eager_steps_and_recovers_from_overflow():
         assert torch.equal(r, r0.detach()) and torch.equal(a, a0.detach())
         assert rel_l2(fp.flat_grad, ref.flat_grad) < 1e-5  # float atomics: not bit-identical
     assert g.graph is not None and g.capacity > 2000
+
+
+def test_partial_requires_grad_noncontiguous_and_half_inputs():
+    """Boundary hygiene: inputs that are non-contiguous views, lower precision, or only partly
+    differentiable behave like their contiguous fp32 counterparts."""
+    sc = _scene(n=5000, w=160, h=96, seed=41)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    base = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    ref = [x.clone().requires_grad_(True) for x in base]
+    r0, a0, _ = rasterization(*ref, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
+    (r0.sum() + a0.sum()).backward()
+    # (1) non-contiguous: every input is a strided slice of a wider buffer
+    wide = [torch.cat([x, x], dim=-1) if x.dim() > 1 else torch.stack([x, x], dim=-1) for x in base]
+    nc = [w[..., : b.shape[-1]] if b.dim() > 1 else w[..., 0] for w, b in zip(wide, base)]
+    assert not nc[0].is_contiguous() and not nc[3].is_contiguous()
+    r1, a1, _ = rasterization(*nc, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
+    assert torch.equal(r1, r0.detach()) and torch.equal(a1, a0.detach())
+    # (2) only the means are differentiable
+    part = [base[0].clone().requires_grad_(True)] + [x.clone() for x in base[1:]]
+    r2, a2, _ = rasterization(*part, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
+    (r2.sum() + a2.sum()).backward()
+    assert rel_l2(part[0].grad, ref[0].grad) < 1e-5 and all(x.grad is None for x in part[1:])
+    # (3) bf16 colours / fp16 opacities are promoted to fp32 at the boundary
+    lo = [base[0], base[1], base[2], base[3].half(), base[4].bfloat16()]
+    r3, a3, _ = rasterization(*lo, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
+    r4, a4, _ = rasterization(base[0], base[1], base[2], base[3].half().float(), base[4].bfloat16().float(), vm, K,
+                              sc.width, sc.height, sh_degree=3, packed=False)  # fmt: skip
+    assert torch.equal(r3, r4) and torch.equal(a3, a4)
