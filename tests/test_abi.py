@@ -54,6 +54,29 @@ def test_argument_validation_without_gpu():
     assert lib.fg_sort_pairs(10, None, None, 70, None, 0, None) == -1
 
 
+def test_argument_validation_of_the_newer_entry_points_without_gpu():
+    lib = _lib.load()
+    n = [None]
+    # densify / gather / children / back-projection: negative sizes and missing buffers
+    assert lib.fg_densify_flags(-1, 1, 100.0, 1e-3, 0.01, 0.05, 0.1, 0.5, 0.15, *(n * 7)) == -1
+    assert lib.fg_densify_flags(8, 1, 100.0, 1e-3, 0.01, 0.05, 0.1, 0.5, 0.15, *(n * 7)) == -1
+    assert lib.fg_densify_map(8, *(n * 5), 1, 1, 1, 2, None, None, None) == -1
+    assert lib.fg_gather_rows(4, 0, None, None, 0, None, None) == -1
+    assert lib.fg_gather_rows(0, 3, None, None, 0, None, None) == 0  # nothing to do
+    assert lib.fg_split_children(0, 4, *(n * 6)) == -1
+    assert lib.fg_mask_backproject(4, None, None, None, None, 8, 8, None, None, 2, 3, None, None) == -1  # M > stored
+    # factored exchange: payload layout must be 3 or 6 floats
+    assert lib.fg_sh_grad_accumulate(4, 2, 3, 16, None, None, 100, 4, 1.0, None, None) == -1
+    assert lib.fg_sh_grad_accumulate(4, 2, 3, 16, None, None, 5, 3, 1.0, None, None) == -1  # stride < 3N+3
+    # capacity emission needs a positive capacity and the count array
+    assert lib.fg_bin_emit_sort_capacity(4, 0, *(n * 4), 16, 4, 4, *(n * 4), 0, None) == -1
+    # raw preprocess is SH-only
+    assert lib.fg_preprocess_raw_fwd(4, *(n * 8), -1, 16, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
+                                     *(n * 8)) == -1  # fmt: skip
+    # composite raster: clamp count within the channels, mask required
+    assert lib.fg_raster_composite_fwd(3, 32, 32, 16, *(n * 4), 4, *(n * 5)) == -1
+
+
 def test_product_does_not_import_oracle():
     """The product path must never route through the CPU oracle."""
     pkg = os.path.join(ROOT, "freegaussian_amd")
