@@ -203,6 +203,8 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
     return isect_ids, flatten_ids, offsets
 
 
+# Module-level state below (hooks, caches, timers) is per process and not synchronised: drive one
+# device from one Python thread (autograd's own backward thread only ever reads the hooks).
 # bin_tiles: capacity guesses per (device, N, tile grid)
 speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
 static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
@@ -287,6 +289,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         n_isects = int(count_host[0])
         if n_isects >= 2**31:
             raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+        if key not in _isect_capacity and len(_isect_capacity) >= 256:
+            _isect_capacity.pop(next(iter(_isect_capacity)))  # densification changes N: do not grow for ever
         _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
