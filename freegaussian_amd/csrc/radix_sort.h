@@ -2,8 +2,8 @@
 // 8-bit digits, keys of 32 or 64 bits, only bits [0, end_bit) sorted.
 //
 // Per pass (3 launches):
-//   hist    : each workgroup histograms its key tile in LDS               -> block_hist[block][256]
-//   scan    : workgroup d turns column d of block_hist into an exclusive prefix over workgroups
+//   hist    : each workgroup histograms its key tile in LDS               -> block_hist[256][block]
+//   scan    : workgroup d turns row d of block_hist into an exclusive prefix over workgroups
 //             and writes the digit total
 //   scatter : each workgroup scans the 256 digit totals, recomputes stable ranks for its tile
 //             with wave-ballot match masks and writes keys+values to their final slots
@@ -55,11 +55,12 @@ hist_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict
     if (i < n) atomicAdd(&hist[digit_of(key[k], shift)], 1u);
   }
   __syncthreads();
-  block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x] = hist[threadIdx.x];
+  // digit-major layout [RADIX][nblocks]: the per-digit scan below then walks contiguous memory
+  block_hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x] = hist[threadIdx.x];
 }
 
-// workgroup d: exclusive prefix over workgroups of column d of block_hist (in place) and the
-// column total.  Thread t owns a contiguous chunk of the column.
+// workgroup d: exclusive prefix over workgroups of row d of block_hist (in place) and the
+// row total.  Thread t owns a contiguous chunk of the row.
 static __global__ void __launch_bounds__(BLOCK)
 digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wave_tot[WAVES];
@@ -67,7 +68,8 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
   const int chunk = (nblocks + BLOCK - 1) / BLOCK;
   const int b0 = min(nblocks, (int)threadIdx.x * chunk), b1 = min(nblocks, b0 + chunk);
   uint32_t sum = 0;
-  for (int b = b0; b < b1; ++b) sum += block_hist[(size_t)b * RADIX + d];
+  uint32_t* row = block_hist + (size_t)d * nblocks;
+  for (int b = b0; b < b1; ++b) sum += row[b];
   uint32_t incl = sum;
 #pragma unroll
   for (int k = 1; k < 64; k <<= 1) {
@@ -83,9 +85,8 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
     total += wave_tot[w];
   }
   for (int b = b0; b < b1; ++b) {
-    uint32_t* p = block_hist + (size_t)b * RADIX + d;
-    const uint32_t c = *p;
-    *p = run;
+    const uint32_t c = row[b];
+    row[b] = run;
     run += c;
   }
   if (threadIdx.x == 0) digit_total[d] = total;
@@ -122,7 +123,7 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
 #pragma unroll
     for (int w = 0; w < WAVES; ++w)
       if (w < wave) base += scan_tmp[w];
-    digit_start = base + block_hist[(size_t)blockIdx.x * RADIX + threadIdx.x];
+    digit_start = base + block_hist[(size_t)threadIdx.x * gridDim.x + blockIdx.x];
   }
   __syncthreads();
 
