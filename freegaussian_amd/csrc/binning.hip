@@ -3,8 +3,6 @@
 //
 // Replaces the binning stage implied by tile_size=16 at
 // /root/reference freegaussian/freegaussian_model.py:806,857.
-#include <cstdlib>
-
 #include "fg_common.h"
 #include "radix_sort.h"
 
@@ -164,88 +162,6 @@ depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __rest
 // and each lane finds the splat that owns its slot by a 6-step binary search over the wave's
 // exclusive offsets (kept in LDS).  A lane-per-Gaussian loop wrote 8-byte pieces at 64 unrelated
 // addresses per instruction instead.
-// Load-balanced emission.  In depth order the nearest -- largest -- Gaussians all sit in the first
-// wavefronts of tile_bin_ordered_kernel (64 consecutive Gaussians per wavefront): one wavefront
-// writes thousands of slots while most write a few dozen, and the launch lasts as long as that one.
-// Here every wavefront owns a fixed range of SLOTS_PER_WAVE output slots instead; it finds the first
-// Gaussian of its range by a scalar binary search over the ordered inclusive scan and then walks
-// 64 Gaussians at a time exactly as above, clipped to its range (a big Gaussian is shared by
-// several wavefronts).  Same output.
-constexpr int SLOTS_PER_WAVE = 1024;
-
-template <typename KeyT>
-__global__ void __launch_bounds__(256)
-tile_bin_balanced_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
-                         const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
-                         int tile_w, int tile_h, KeyT* __restrict__ tile_keys, int32_t* __restrict__ flatten_ids,
-                         int64_t capacity) {
-  __shared__ int32_t s_excl[4][64];
-  __shared__ int32_t s_gid[4][64];
-  __shared__ int32_t s_rect[4][64];
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const int64_t total_slots = min(cum_tiles[N - 1], capacity);
-  const int64_t s_begin = ((int64_t)blockIdx.x * 4 + wave) * SLOTS_PER_WAVE;
-  if (s_begin >= total_slots) return;
-  const int64_t s_end = min(s_begin + SLOTS_PER_WAVE, total_slots);
-  // first Gaussian (in depth order) that owns a slot > s_begin - 1: smallest k with cum[k] > s_begin
-  int lo = 0, hi = N - 1;
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (cum_tiles[mid] > s_begin) hi = mid; else lo = mid + 1;
-  }
-  for (int k0 = lo; k0 < N; k0 += 64) {
-    const int64_t base = (k0 == 0) ? 0 : cum_tiles[k0 - 1];  // first slot of Gaussian k0
-    if (base >= s_end) break;
-    const int k = k0 + lane;
-    const int klast = min(k0 + 63, N - 1);
-    const int64_t group_end = cum_tiles[klast];
-    int gid = 0, rect = 0;
-    int64_t excl64 = group_end - base;  // lanes past N own nothing
-    if (k < N) {
-      gid = order[k];
-      excl64 = ((k == 0) ? 0 : cum_tiles[k - 1]) - base;
-      const int radius = radii[gid];
-      if (radius > 0) {
-        const float ts = (float)tile_size;
-        const float r = (float)radius / ts;
-        const float tx = means2d[2 * gid] / ts, ty = means2d[2 * gid + 1] / ts;
-        const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
-        const int y0 = min(max((int)floorf(ty - r), 0), tile_h);
-        rect = x0 | (y0 << 10) | ((x1 - x0) << 20);
-      }
-    }
-    __builtin_amdgcn_wave_barrier();  // the previous batch's LDS reads are done (same wave: program order)
-    s_excl[wave][lane] = (int)min(excl64, (int64_t)0x7fffffff);  // 64 Gaussians cover < 2^31 slots (<= 64 * 2^20)
-    s_gid[wave][lane] = gid;
-    s_rect[wave][lane] = rect;
-    __builtin_amdgcn_wave_barrier();
-    // slots of this batch inside my range, relative to `base`
-    const int rel_begin = (int)max((int64_t)0, s_begin - base);
-    const int rel_end = (int)min(group_end - base, s_end - base);
-    for (int s0 = rel_begin; s0 < rel_end; s0 += 64) {
-      const int slot = s0 + lane;
-      if (slot < rel_end) {
-        int own = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (s_excl[wave][own + step] <= slot) own += step;
-        const int t = slot - s_excl[wave][own];
-        const int rc = s_rect[wave][own];
-        const int w = rc >> 20;
-        // t / w without the integer-division sequence: t < 2^20 is exact in fp32, one fix-up step
-        int ty = (int)((float)t * __builtin_amdgcn_rcpf((float)w));
-        ty -= (ty * w > t);
-        ty += ((ty + 1) * w <= t);
-        const int tx = t - ty * w;
-        const int64_t out = base + slot;
-        tile_keys[out] = (KeyT)((uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx));
-        flatten_ids[out] = s_gid[wave][own];
-      }
-    }
-    if (group_end >= s_end) break;
-  }
-}
-
 template <typename KeyT>
 __global__ void __launch_bounds__(256)
 tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
@@ -438,14 +354,6 @@ extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
 
 namespace {
 
-bool emit_balanced() {  // FG_EMIT=grouped: the 64-Gaussians-per-wavefront emission
-  static const bool v = [] {
-    const char* e = getenv("FG_EMIT");
-    return !(e && e[0] == 'g');
-  }();
-  return v;
-}
-
 // n_dev == nullptr: exactly n_isects intersections.  Otherwise n_isects is a capacity and the
 // count is read on the device from *n_dev (clamped to the capacity).
 template <typename KeyT>
@@ -455,14 +363,8 @@ int bin_emit_sort_keys(int N, int64_t n_isects, const int64_t* n_dev, const floa
                        hipStream_t s) {
   const int n_tiles = tile_w * tile_h;
   if (n_isects > 0) {
-    if (emit_balanced()) {  // n_isects is the exact count or the capacity: one wavefront per 1024 slots of it
-      const int64_t waves = (n_isects + SLOTS_PER_WAVE - 1) / SLOTS_PER_WAVE;
-      hipLaunchKernelGGL(tile_bin_balanced_kernel<KeyT>, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, N, means2d,
-                         radii, order, cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
-    } else {
-      hipLaunchKernelGGL(tile_bin_ordered_kernel<KeyT>, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
-                         cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
-    }
+    hipLaunchKernelGGL(tile_bin_ordered_kernel<KeyT>, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
+                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
     int bits = 1;
     while ((1 << bits) < n_tiles) ++bits;
     const int rc = fg_sort::sort_pairs<KeyT>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits, sort_ws,
