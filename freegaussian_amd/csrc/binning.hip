@@ -209,7 +209,11 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
       const int t = slot - s_excl[wave][lo];
       const int rc = s_rect[wave][lo];
       const int w = rc >> 20;
-      const int ty = t / w, tx = t - ty * w;
+      // t / w without the ~30-instruction integer division: t < 2^20 is exact in fp32, one fix-up each way
+      int ty = (int)((float)t * __builtin_amdgcn_rcpf((float)w));
+      ty -= (ty * w > t);
+      ty += ((ty + 1) * w <= t);
+      const int tx = t - ty * w;
       const int64_t out = base + slot;
       if (out >= capacity) continue;  // capacity launch that guessed too low: the host redoes it
       tile_keys[out] = (KeyT)((uint32_t)(((rc >> 10) & 1023) + ty) * (uint32_t)tile_w + (uint32_t)((rc & 1023) + tx));
