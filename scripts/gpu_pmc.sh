@@ -7,7 +7,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 run() {  # name, counters...
   name=$1; shift
-  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/$name.json 2> $out/$name.err
+  timeout 300 rocprofv3 --pmc "$@" --output-format csv -d $out/$name -o c -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph > $out/$name.json 2> $out/$name.err
 }
 run sq1 SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU
 run sq2 SQ_WAIT_ANY SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INST_CYCLES_VMEM SQ_ACTIVE_INST_ANY SQ_INSTS_SMEM
@@ -34,7 +34,7 @@ for k,c in agg.items():
         traffic[k.replace("void ","")]={"FETCH_SIZE_KiB":f,"WRITE_SIZE_KiB":w,"hbm_bytes_per_launch":(2*f+w)*1024}
         if "SQ_INSTS_VALU" in c:
             traffic[k.replace("void ","")]["valu_wave_instr_per_launch"]=sum(c["SQ_INSTS_VALU"])/len(c["SQ_INSTS_VALU"])
-json.dump({"workload_key":"1000000x1920x1080xsh3","source":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline",
+json.dump({"workload_key":"1000000x1920x1080xsh3","source":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph",
            "correction":"bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024","kernels":traffic}, open(out+"/pmc_traffic.json","w"), indent=1)
 with open(out+"/pmc_summary.txt","w") as fo:
     for k in sorted(agg):
