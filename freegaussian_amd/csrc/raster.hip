@@ -402,7 +402,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
     const size_t pix = (size_t)iy * width + ix;
     T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
     last[k] = inside ? last_ids[pix] : start - 1;
-    float va = inside ? v_alphas[pix] : 0.f;
+    float va = (inside && v_alphas) ? v_alphas[pix] : 0.f;  // v_alphas == nullptr: no gradient on alpha
     const unsigned blocked = (inside && comp.n_clamp > 0) ? comp.clamp_mask[pix] : 0u;
     bsum[k] = 0.f;
 #pragma unroll
@@ -745,8 +745,7 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
                    Composite comp, fg_stream_t stream) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
-  if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_alphas || !v_splats)
-    return FG_ERR_INVALID_ARG;
+  if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_splats) return FG_ERR_INVALID_ARG;
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;

@@ -494,6 +494,7 @@ class _Preprocess(torch.autograd.Function):
                   height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
                   _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _stream())  # fmt: skip
         ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii)
+        ctx.set_materialize_grads(False)  # unused depths / conics gradients arrive as None, not as zero tensors
         ctx.cfg = cfg
         ctx.layout = (k_stored, n_color, n_extra)
         ctx.mark_non_differentiable(radii, tiles)
@@ -585,6 +586,7 @@ class _PreprocessRaw(torch.autograd.Function):
               _ptr(splats), _stream())  # fmt: skip
         ctx.save_for_backward(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
                               features_rest, extra, viewmat, K, radii)  # fmt: skip
+        ctx.set_materialize_grads(False)
         ctx.cfg = cfg
         ctx.mark_non_differentiable(radii, tiles)
         return radii, means2d, depths, conics, tiles, splats
@@ -671,6 +673,7 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask)
+        ctx.set_materialize_grads(False)  # an unused alpha / render must not cost a zero-fill launch
         ctx.composite = (composite, int(n_clamp))
         ctx.geom = (channels, width, height, tile_size, absgrad, tuple(means2d.shape))
         ctx.means2d_ref = means2d if absgrad else None
@@ -684,15 +687,15 @@ class _RasterSplats(torch.autograd.Function):
         composite, n_clamp = ctx.composite
         N = splats.shape[0]
         v_render = torch.zeros(height, width, C, device=splats.device) if v_render is None else v_render
-        v_alphas = torch.zeros_like(alphas) if v_alphas is None else v_alphas
+        v_alphas = None if v_alphas is None else v_alphas.contiguous()  # NULL = no gradient on alpha
         v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
         if composite:
             _call("fg_raster_composite_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas), _ptr(last_ids),
-                  _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()), _ptr(v_splats), _stream())  # fmt: skip
+                  _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _stream())  # fmt: skip
         else:
             _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
-                  _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas.contiguous()),
+                  _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas),
                   _ptr(v_splats), _stream())  # fmt: skip
         # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
         v_means2d = v_splats[:, 0:2].view(m2_shape)

@@ -154,7 +154,8 @@ int fg_pack_splats(int N, int channels, const float* means2d, const float* conic
 int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
                   const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
                   float* alphas, int32_t* last_ids, fg_stream_t stream);
-/* v_splats[N,16] must be ZEROED by the caller; per-Gaussian gradients are accumulated as
+/* v_alphas may be NULL (no gradient on alpha).
+ * v_splats[N,16] must be ZEROED by the caller; per-Gaussian gradients are accumulated as
  *   [v_x, v_y, v_opacity, v_conic_a, v_conic_b, v_conic_c, |v_x|, |v_y|, v_f0..v_f(C-1)]
  * (|v_x|,|v_y| = absgrad, freegaussian_model.py:864 / :377). */
 int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
