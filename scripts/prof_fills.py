@@ -15,9 +15,8 @@ def step():
         r.backward(vr)
 for _ in range(5): step()
 torch.cuda.synchronize()
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     step(); torch.cuda.synchronize()
 for e in prof.events():
     if e.name in ("aten::fill_", "aten::zero_", "aten::zeros", "aten::zeros_like", "aten::copy_", "aten::full"):
-        st = [s for s in (e.stack or []) if "repo" in s][:2]
-        print(e.name, e.input_shapes if hasattr(e,'input_shapes') else '', round(e.device_time_total,1), st)
+        print(e.name, e.input_shapes, round(e.device_time_total, 1))
