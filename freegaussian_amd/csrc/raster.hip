@@ -558,8 +558,9 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
+        // only the accumulators this channel count ever writes need clearing (8 + C of the 16)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
+        for (int q = 0; q < 8 + C; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
       }
     }
   }
