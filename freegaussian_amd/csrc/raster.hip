@@ -558,9 +558,18 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        // only the accumulators this channel count ever writes need clearing (8 + C of the 16)
+        // only the accumulators this channel count ever writes need clearing (8 + C of the 16);
+        // two at a time with v_mov_b64 where they pair up
 #pragma unroll
-        for (int q = 0; q < 8 + C; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
+        for (int q = 0; q + 1 < 8 + C; q += 2) {
+          struct F2 { float a, b; };
+          double z;
+          asm volatile("v_mov_b64 %0, 0" : "=v"(z));
+          const F2 h = __builtin_bit_cast(F2, z);
+          g[q] = h.a;
+          g[q + 1] = h.b;
+        }
+        if ((8 + C) & 1) asm volatile("v_mov_b32 %0, 0" : "=v"(g[8 + C - 1]));
       }
     }
   }
