@@ -539,7 +539,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           g[6] += fabsf(gx);  // absgrad sums |.| per pixel: not a moment
           g[7] += fabsf(gy);
         }
-        if (!__any(contributed)) continue;
+        if (!contributed) continue;  // wave-uniform: only ever set under the uniform any-valid branches
         // v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
         g[5] *= 0.5f;
         g[4] *= dx;
