@@ -548,13 +548,16 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         if (C <= 4) {  // only record slots 0..11 are in use: the cheaper 12-value butterfly
           const float total = fg::wave_reduce12_transposed(g);
           if (fg::wave_reduce12_owner(lane)) {
-            float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + fg::wave_reduce12_index(lane);
+            // the Gaussian id is wave-uniform: scalar base address + per-lane slot offset
+            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + fg::wave_reduce12_index(lane);
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         } else {
           const float total = fg::wave_reduce16_transposed(g);
           if ((lane & 3) == 0) {
-            float* dst = v_splats + (size_t)lds_gid[j] * FG_SPLAT_FLOATS + (lane >> 2);
+            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
