@@ -159,6 +159,19 @@ def cpu_baseline(scene, view, crop, sh_degree):
     }
 
 
+def gpu_clocks():
+    """Engine / memory clock levels as rocm-smi reports them right after the timed region (BASELINE.md
+    section 3 asks for the clocks to be noted); a child process, best effort."""
+    import subprocess
+
+    try:
+        res = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=30)
+        card = next(iter(json.loads(res.stdout).values()))
+        return {k: v for k, v in card.items() if any(c in k.lower() for c in ("sclk", "mclk", "fclk"))}
+    except Exception as e:
+        return {"error": repr(e)[:120]}
+
+
 def graph_only(args):
     """Child-process leg: the step replayed as one hipGraph; prints one JSON object."""
     from freegaussian_amd.graphed import GraphedRaster
@@ -359,6 +372,8 @@ def main():
         },
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
     }  # fmt: skip
+    if rank == 0:
+        out["clocks_after_timed_region"] = gpu_clocks()
     if world == 1 and not args.no_graph and rank == 0:
         # the same step captured in one hipGraph (graphed.GraphedRaster), measured in a CHILD process
         # (a failed capture aborts the process; the headline line must survive).  Informational:

@@ -132,6 +132,34 @@ def test_depth_first_binning_equals_full_key_sort():
     assert torch.equal(ops.isect_keys(tk, ids, d).cpu(), keys_s)
 
 
+def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
+    """257 x 257 = 66049 tiles: tile ids no longer fit the 16-bit in-workspace keys.  The lists must
+    still equal the oracle's 64-bit-key sort, and a tile-aligned crop rendered through the 16-bit
+    path must equal the same pixels of the full render (up to the rounding of cx - x0)."""
+    W, H = 4112, 4100
+    sc = _scene(n=8000, w=W, h=H, seed=5)
+    vm, K = sc.viewmats[0], sc.Ks[0]
+    ref = O.project(sc.means, sc.quats, sc.scales, vm, K, W, H)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    assert tw * th > 65536
+    _, keys_s, vals_s = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=True)
+    offs_s = O.isect_offsets(keys_s, tw * th)
+    gpu_in = [t.to(DEV) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    r, a, info = rasterization(*gpu_in, vm[None].to(DEV), K[None].to(DEV), W, H, sh_degree=3)
+    assert torch.equal(info["flatten_ids"].cpu(), vals_s)
+    assert torch.equal(info["isect_offsets"].cpu().reshape(-1), offs_s.reshape(-1))
+    assert torch.equal(info["isect_ids"].cpu(), keys_s)
+    x0, y0, cw, ch = 2048, 2048, 512, 512
+    Kc = K.clone()
+    Kc[0, 2] -= x0
+    Kc[1, 2] -= y0
+    rc, ac, _ = rasterization(*gpu_in, vm[None].to(DEV), Kc[None].to(DEV), cw, ch, sh_degree=3)
+    assert close_except_knife_edge(rc[0], r[0, y0 : y0 + ch, x0 : x0 + cw], 3 * REL_TOL, max_frac=3e-3)
+    assert close_except_knife_edge(ac[0], a[0, y0 : y0 + ch, x0 : x0 + cw], 3 * REL_TOL, max_frac=3e-3)
+    r0, a0, _ = O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, vm[None], Kc[None], cw, ch, sh_degree=3)
+    assert close_except_knife_edge(rc, r0, 3 * REL_TOL, max_frac=3e-3) and close_except_knife_edge(ac, a0, 3 * REL_TOL, max_frac=3e-3)
+
+
 @pytest.mark.parametrize("n,end_bit", [(5, 32), (4097, 13), (250_001, 32), (3_000_000, 13)])
 def test_sort_pairs32_bit_exact_and_stable(n, end_bit):
     g = torch.Generator().manual_seed(n)
