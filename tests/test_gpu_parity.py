@@ -134,10 +134,10 @@ def test_depth_first_binning_equals_full_key_sort():
 
 def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
     """257 x 257 = 66049 tiles: tile ids no longer fit the 16-bit in-workspace keys.  The lists must
-    still equal the oracle's 64-bit-key sort, and a tile-aligned crop rendered through the 16-bit
-    path must equal the same pixels of the full render (up to the rounding of cx - x0)."""
+    still equal the oracle's 64-bit-key sort, and the pixels of tiles with ids beyond 65535 the C
+    oracle's."""
     W, H = 4112, 4100
-    sc = _scene(n=8000, w=W, h=H, seed=5)
+    sc = _scene(n=8000, w=W, h=H, seed=5, cam_radius=3.0)
     vm, K = sc.viewmats[0], sc.Ks[0]
     ref = O.project(sc.means, sc.quats, sc.scales, vm, K, W, H)
     tw, th = (W + 15) // 16, (H + 15) // 16
@@ -145,19 +145,30 @@ def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
     _, keys_s, vals_s = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=True)
     offs_s = O.isect_offsets(keys_s, tw * th)
     gpu_in = [t.to(DEV) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
-    r, a, info = rasterization(*gpu_in, vm[None].to(DEV), K[None].to(DEV), W, H, sh_degree=3)
+    r, a, info = rasterization(*gpu_in, vm[None].to(DEV), K[None].to(DEV), W, H, sh_degree=3, packed=False)
     assert torch.equal(info["flatten_ids"].cpu(), vals_s)
     assert torch.equal(info["isect_offsets"].cpu().reshape(-1), offs_s.reshape(-1))
     assert torch.equal(info["isect_ids"].cpu(), keys_s)
-    x0, y0, cw, ch = 2048, 2048, 512, 512
-    Kc = K.clone()
-    Kc[0, 2] -= x0
-    Kc[1, 2] -= y0
-    rc, ac, _ = rasterization(*gpu_in, vm[None].to(DEV), Kc[None].to(DEV), cw, ch, sh_degree=3)
-    assert close_except_knife_edge(rc[0], r[0, y0 : y0 + ch, x0 : x0 + cw], 3 * REL_TOL, max_frac=3e-3)
-    assert close_except_knife_edge(ac[0], a[0, y0 : y0 + ch, x0 : x0 + cw], 3 * REL_TOL, max_frac=3e-3)
-    r0, a0, _ = O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, vm[None], Kc[None], cw, ch, sh_degree=3)
-    assert close_except_knife_edge(rc, r0, 3 * REL_TOL, max_frac=3e-3) and close_except_knife_edge(ac, a0, 3 * REL_TOL, max_frac=3e-3)
+    # a crop whose tiles have ids beyond 65535, pixel by pixel against the scalar C oracle fed with
+    # the (validated) lists of those tiles
+    from oracle import c_oracle as CO
+
+    cw, ch, x0, y0 = 640, 48, 16 * 100, 16 * 253
+    offs_c, ids_c = info["isect_offsets"].cpu().reshape(-1), info["flatten_ids"].cpu()
+    lists, coffs = [], [0]
+    for ty in range(ch // 16):
+        for tx in range(cw // 16):
+            tt = (y0 // 16 + ty) * tw + (x0 // 16 + tx)
+            lists.append(ids_c[int(offs_c[tt]) : int(offs_c[tt + 1])])
+            coffs.append(coffs[-1] + lists[-1].numel())
+    assert (y0 // 16 + 2) * tw + x0 // 16 > 65535 and coffs[-1] > 100
+    cv, coffs = torch.cat(lists), torch.tensor(coffs, dtype=torch.int32)
+    m2 = info["means2d"][0].cpu() - torch.tensor([float(x0), float(y0)])
+    campos = torch.linalg.inv(vm)[:3, 3]
+    rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
+    rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
+    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
+    assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
 @pytest.mark.parametrize("n,end_bit", [(5, 32), (4097, 13), (250_001, 32), (3_000_000, 13)])
