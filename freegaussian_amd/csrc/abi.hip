@@ -31,10 +31,17 @@ __global__ void __launch_bounds__(64) debug_reduce16_kernel(const float* __restr
   for (int i = 0; i < 16; ++i) w[i] = in[threadIdx.x * 16 + i];
   const float r12 = fg::wave_reduce12_transposed(w);
   if (fg::wave_reduce12_owner(threadIdx.x)) out[144 + fg::wave_reduce12_index(threadIdx.x)] = r12;
+  // LDS-transposing variant: 11 rows (8 + 3 channels), every lane of the owning quads reports
+  __shared__ float red[16 * fg::FG_RED_STRIDE];
+  float u[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) u[i] = in[threadIdx.x * 16 + i];
+  const float r11 = fg::wave_reduce_rows_lds<11>(u, red, threadIdx.x);
+  out[156 + threadIdx.x] = (threadIdx.x >> 2) < 11 ? r11 : -1.f;
 }
 }  // namespace
 
-// Test hook (not part of the drop-in surface): in[64*16] floats, out[156] floats.
+// Test hook (not part of the drop-in surface): in[64*16] floats, out[220] floats.
 extern "C" int fg_debug_wave_reduce16(const float* in, float* out, fg_stream_t stream) {
   if (!in || !out) return FG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(debug_reduce16_kernel, dim3(1), dim3(64), 0, fg_hip_stream(stream), in, out);

@@ -142,4 +142,35 @@ __device__ __forceinline__ int wave_reduce12_index(int lane) {
 }
 __device__ __forceinline__ bool wave_reduce12_owner(int lane) { return (lane & 3) == 0 && (lane & 12) != 12; }
 
+// LDS-transposing wave reduction of ROWS per-lane values (ROWS <= 16).  Measured on gfx950
+// (scripts/micro/valu_rate.hip, profiles/r01_valu_issue_rates.md): a v_permlane*_swap holds a
+// SIMD's vector issue for 8 clocks and every DPP operation for 4 (neither overlaps with other
+// vector work), while a plain v_add_f32 costs 2 -- the register-only butterflies above spend
+// ~130-170 issue clocks per reduction.  Here every lane stores its ROWS values column-wise
+// (row q at buf[q * FG_RED_STRIDE + lane]: conflict-free), then lane l = 4q + part sums 16
+// consecutive floats of row q with four ds_read_b128 (stride 68 floats keeps the four b128
+// phases on disjoint banks) and 15 full-rate adds; two quad DPP adds finish.  The LDS pipe does
+// the data movement beside the vector ALU.  After the call lane l holds the 64-lane sum of value
+// (l >> 2) when (l >> 2) < ROWS; one wavefront per buffer, no barrier (a wavefront's LDS
+// operations execute in order).
+constexpr int FG_RED_STRIDE = 68;
+template <int ROWS>
+__device__ __forceinline__ float wave_reduce_rows_lds(const float (&v)[16], float* buf, int lane) {
+#pragma unroll
+  for (int q = 0; q < ROWS; ++q) buf[q * FG_RED_STRIDE + lane] = v[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float r = 0.f;
+  if ((lane >> 2) < ROWS) {
+    const float4* src = reinterpret_cast<const float4*>(buf + (lane >> 2) * FG_RED_STRIDE + (lane & 3) * 16);
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+    r = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+        (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    r += dpp_mov<FG_DPP_QUAD_XOR1>(r);
+    r += dpp_mov<FG_DPP_QUAD_XOR2>(r);
+  }
+  return r;
+}
+
 }  // namespace fg

@@ -125,6 +125,11 @@ __device__ unsigned long long fg_raster_stats[16];
 #define FG_STAT(i, n) do { } while (0)
 #endif
 
+// 1: the backward sums its per-splat accumulators through LDS; 0: register butterfly (A/B switch)
+#ifndef FG_BWD_LDS_REDUCE
+#define FG_BWD_LDS_REDUCE 1
+#endif
+
 #ifndef FG_FWD_STRIP_TEST_MIN_PPT
 #define FG_FWD_STRIP_TEST_MIN_PPT 2
 #endif
@@ -378,6 +383,9 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   __shared__ int32_t lds_gid[NT];
   __shared__ uint32_t lds_mask[NT];
   __shared__ int32_t lds_max[NW];
+#if FG_BWD_LDS_REDUCE
+  __shared__ float lds_red[NW][(8 + (C <= 4 ? C : 0)) * fg::FG_RED_STRIDE];  // per-wavefront reduction buffer
+#endif
 
   const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
   if (tile < 0) return;
@@ -545,6 +553,17 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         g[4] *= dx;
         g[3] *= 0.5f * dx * dx;
         FG_STAT(4, 1);
+#if FG_BWD_LDS_REDUCE
+        if (C <= 4) {  // 8 + C live accumulators: summed through LDS (the butterflies' swaps and DPP
+                       // operations cost 4-8 issue clocks each, fg_common.h)
+          const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wave], lane);
+          if ((lane & 3) == 0 && (lane >> 2) < 8 + C) {
+            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
+            __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        } else
+#endif
         if (C <= 4) {  // only record slots 0..11 are in use: the cheaper 12-value butterfly
           const float total = fg::wave_reduce12_transposed(g);
           if (fg::wave_reduce12_owner(lane)) {

@@ -33,7 +33,7 @@ def test_wave_reduce16_transposed():
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
     x = torch.randint(-8, 9, (64, 16), generator=g).float()  # integers: exact sums
-    out = torch.zeros(156, device=DEV)
+    out = torch.zeros(220, device=DEV)
     _lib.check(lib.fg_debug_wave_reduce16(x.to(DEV).data_ptr(), out.data_ptr(), None), "dbg")
     torch.cuda.synchronize()
     out = out.cpu()
@@ -41,6 +41,8 @@ def test_wave_reduce16_transposed():
     assert torch.equal(out[16:80], x.sum(0).repeat_interleave(4))
     assert torch.equal(out[80:144], x[:, 0].sum().expand(64))
     assert torch.equal(out[144:156], x.sum(0)[:12])  # 12-value butterfly
+    assert torch.equal(out[156:200], x.sum(0)[:11].repeat_interleave(4))  # LDS-transposing reduction, 11 rows
+    assert bool((out[200:220] == -1).all())
 
 
 @pytest.mark.parametrize("n,end_bit", [(1, 64), (63, 64), (4096, 40), (4097, 45), (100_003, 45), (1_000_000, 45)])
