@@ -42,6 +42,12 @@ __host__ __device__ constexpr int rec_vec4(int C) { return (6 + C + 3) / 4; }
 //                  its vertical neighbours (which share most of their splats) run back to back.
 __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_h, int mode) {
   const int xcd = b & 7, k = b >> 3;
+  // measurement hook (FG_DEBUG_ONLY_XCD=x): only the workgroups of XCD x do their tile, so that a
+  // launch's duration is that XCD's share of the work
+  const int only = ((mode >> 8) & 15) - 1, kmod = mode >> 12;
+  mode &= 255;
+  if (only >= 0 && xcd != only) return -1;
+  if (kmod > 1 && k % kmod != 0) return -1;  // FG_DEBUG_K_MOD=m: every m-th tile of each XCD only
   if (mode == 0) {
     const int row = (k / tile_w) * 8 + xcd;
     return row < tile_h ? row * tile_w + (k % tile_w) : -1;
@@ -95,6 +101,8 @@ struct Splat {
 __device__ __forceinline__ uint64_t lanes_oge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 3); }
 __device__ __forceinline__ uint64_t lanes_ole(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 5); }
 __device__ __forceinline__ uint64_t lanes_ule(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 13); }
+__device__ __forceinline__ uint64_t lanes_uge(float a, float b) { return __builtin_amdgcn_fcmpf(a, b, 11); }
+__device__ __forceinline__ uint64_t lanes_sle(int a, int b) { return __builtin_amdgcn_sicmp(a, b, 41); }  // ICMP_SLE
 __device__ __forceinline__ float lane_select(uint64_t m, float if_set, float if_clear) {
   float r;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
@@ -128,6 +136,12 @@ __device__ unsigned long long fg_raster_stats[16];
 // 1: the backward sums its per-splat accumulators through LDS; 0: register butterfly (A/B switch)
 #ifndef FG_BWD_LDS_REDUCE
 #define FG_BWD_LDS_REDUCE 1
+#endif
+
+// 1: the backward evaluates the alpha pre-test of all pixel slots of an entry as independent chains
+// before any per-slot branch; 0: slot by slot (A/B switch)
+#ifndef FG_BWD_BATCHED_PRETEST
+#define FG_BWD_BATCHED_PRETEST 1
 #endif
 
 #ifndef FG_FWD_STRIP_TEST_MIN_PPT
@@ -501,6 +515,62 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         // They are zeroed once per tile and again after each reduction that consumed them: an
         // entry to which no lane contributes leaves them untouched (all updates sit behind the
         // uniform any-valid branches).
+#if FG_BWD_BATCHED_PRETEST
+        // Pre-test of all pixel slots first, as PPT independent instruction chains with no branch
+        // between them: one wavefront issues a DEPENDENT vector instruction only every ~8 clocks
+        // (scripts/micro/valu_rate.hip) and a tile has few wavefronts, so the serial
+        // sub-fma-fma-exp-mul-min-cmp-branch chain per slot was latency-bound.  Slots the strip
+        // mask rules out are evaluated too (their masks come out empty: the culling is
+        // result-preserving), which costs less than the branches did.
+        float vis_k[PPT], alpha_k[PPT];
+        uint64_t valid_k[PPT];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const float e2 = neg_sigma_log2e(st, s.y - py[k]);
+          vis_k[k] = __builtin_amdgcn_exp2f(e2);
+          alpha_k[k] = fminf(FG_ALPHA_MAX, s.o * vis_k[k]);
+          valid_k[k] = lanes_sle(idx_j, last[k]) & lanes_ule(e2, 0.f) & lanes_uge(alpha_k[k], FG_ALPHA_SKIP);
+          FG_STAT(1, 1);
+        }
+        bool contributed = false;
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const uint64_t valid = valid_k[k];
+          if (valid == 0ull) continue;  // scalar
+          FG_STAT(2, 1);
+          FG_STAT(3, __popcll(valid));
+          contributed = true;
+          const float dy = s.y - py[k];
+          const float vis = vis_k[k];
+          const float ov = s.o * vis;
+          const float a_eff = lane_select(valid, alpha_k[k], 0.f);
+          const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
+          T[k] *= ra;
+          const float fac = a_eff * T[k];
+          float cdot = 0.f;
+#pragma unroll
+          for (int c = 0; c < C; ++c) {
+            g[8 + c] += fac * vr[k][c];
+            cdot += f[c] * vr[k][c];
+          }
+          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
+          bsum[k] += cdot * fac;
+          const uint64_t open = valid & lanes_ole(ov, FG_ALPHA_MAX);  // alpha not clamped: gradient flows
+          const float v_o = lane_select(open, vis * v_alpha, 0.f);     // d/d opacity
+          const float v_sigma = -s.o * v_o;
+          g[2] += v_o;
+          const float vsdy = v_sigma * dy;
+          g[3] += v_sigma;
+          g[4] += vsdy;
+          g[5] = fmaf(vsdy, dy, g[5]);
+          const float gx = v_sigma * (s.a * dx + s.b * dy);
+          const float gy = v_sigma * (s.b * dx + s.c * dy);
+          g[0] += gx;
+          g[1] += gy;
+          g[6] += fabsf(gx);
+          g[7] += fabsf(gy);
+        }
+#else
         bool contributed = false;
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
@@ -547,6 +617,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
           g[6] += fabsf(gx);  // absgrad sums |.| per pixel: not a moment
           g[7] += fabsf(gy);
         }
+#endif
         if (!contributed) continue;  // wave-uniform: only ever set under the uniform any-valid branches
         // v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
         g[5] *= 0.5f;
@@ -648,8 +719,12 @@ int env_ppt(const char* name, int dflt) {
 int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measured best: profiles/r01_tile_order.md)
   static int mode = [] {
     const char* e = getenv("FG_TILE_ORDER");
-    if (!e) return 2;
-    return e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : e[0] == 'x' ? 4 : e[0] == 'y' ? 5 : 1;
+    const char* x = getenv("FG_DEBUG_ONLY_XCD");
+    const int only = (x && x[0] >= '0' && x[0] <= '7') ? ((x[0] - '0' + 1) << 8) : 0;
+    const char* km = getenv("FG_DEBUG_K_MOD");
+    const int dbg = only | ((km ? atoi(km) : 0) << 12);
+    if (!e) return 2 | dbg;
+    return (e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : e[0] == 'x' ? 4 : e[0] == 'y' ? 5 : 1) | dbg;
   }();
   return mode;
 }
@@ -685,7 +760,7 @@ int launch_fwd(int width, int height, const float* splats, const int32_t* tile_o
                hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = launch_grid(mode, tile_w, tile_h);
+  const int grid = launch_grid(mode & 255, tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
                      alphas, last_ids, comp);
@@ -698,7 +773,7 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
                const float* v_alphas, float* v_splats, Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int mode = tile_order_mode();
-  const int grid = launch_grid(mode, tile_w, tile_h);
+  const int grid = launch_grid(mode & 255, tile_w, tile_h);
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
                      last_ids, v_render, v_alphas, v_splats, comp);

@@ -125,7 +125,7 @@ void run(const char* name, kern_t k, float* d_out, int n_cu) {
   printf("\n");
 }
 
-int main() {
+int main(int argc, char** argv) {
   setvbuf(stdout, nullptr, _IONBF, 0);
   hipDeviceProp_t prop;
   (void)hipGetDeviceProperties(&prop, 0);
@@ -134,6 +134,11 @@ int main() {
   float* d_out;
   (void)hipMalloc(&d_out, 4096);
   printf("ns per wave64 instruction per SIMD (all SIMDs busy), by wavefronts resident per SIMD; 2 clk @2.4 GHz = 0.833 ns\n");
+  if (argc > 1) {  // counter-calibration mode for rocprofv3 --pmc: one launch each at 8 wavefronts per SIMD
+#define ONE(k) hipLaunchKernelGGL(k, dim3(n_cu * 8), dim3(256), 0, 0, d_out, 1.0f, 2.0f); (void)hipDeviceSynchronize();
+    ONE(k_fma) ONE(k_max) ONE(k_exp) ONE(k_swap32) ONE(k_mix_max) ONE(k_cnd_sgpr) ONE(k_dpp_add) ONE(k_fma_dep)
+    return 0;
+  }
 #define RUN(k) run(#k, k, d_out, n_cu);
   RUN(k_fma) RUN(k_fma_dep) RUN(k_fmac) RUN(k_fma_sgpr) RUN(k_fma_neg) RUN(k_fmaak) RUN(k_add) RUN(k_add_sgpr) RUN(k_sub)
   RUN(k_mul) RUN(k_mul_e64) RUN(k_mul_lit) RUN(k_mul_inl) RUN(k_max) RUN(k_min) RUN(k_max3) RUN(k_mov) RUN(k_mov64) RUN(k_and) RUN(k_addu) RUN(k_lshl)
