@@ -88,6 +88,33 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
   return first + k;
 }
 
+// Mixed launch: job k of XCD x.  The XCD's tiles are those of tile_of_block mode 2 (a band of whole
+// tile rows, column-major); the first n - tail of them are whole-tile jobs (strip = -1), each of
+// the last `tail` is four single-strip jobs.  Why: a tile's list is walked serially by its
+// wavefront, and a launch ends with wavefronts that run alone on their SIMDs; measured
+// (FG_DEBUG_K_MOD hook), 1/5 of the tiles of the 1M / 1080p scene take half the time of all of
+// them.  Shorter jobs at the end of every XCD's sequence shorten that tail; splitting every tile
+// would repeat the per-entry work everywhere (slower: profiles/r01_ppt_by_tiles.md).
+__device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int tail_tiles, int& strip) {
+  const int xcd = b & 7, k = b >> 3;
+  const int q = tile_h >> 3, r = tile_h & 7;
+  const int rows = q + (xcd < r ? 1 : 0);
+  const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int n = rows * tile_w;
+  const int tail = min(tail_tiles, n), n_main = n - tail;
+  int idx;
+  if (k < n_main) {
+    idx = k;
+    strip = -1;
+  } else {
+    idx = n_main + ((k - n_main) >> 2);
+    strip = (k - n_main) & 3;
+  }
+  if (idx >= n) return -1;
+  const int col = idx / rows;
+  return (row0 + idx - col * rows) * tile_w + col;
+}
+
 struct Splat {
   float x, y, o, a, b, c;
 };
@@ -226,26 +253,35 @@ __device__ __forceinline__ unsigned wave_strips(int wave) {
   return PPT == 1 ? (1u << wave) : PPT == 2 ? ((1u << wave) | (1u << (wave + 2))) : 0xFu;
 }
 
-template <int C, int PPT>
-__global__ void __launch_bounds__(256 / PPT)
-raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
-                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                  Composite comp) {
-  constexpr int NT = 256 / PPT;
+// Shared staging of one tile job: NT = 64 * (cooperating wavefronts).
+template <int C, int NT>
+struct FwdShared {
+  float4 rec[NT][rec_vec4(C)];
+  uint32_t mask[NT];
+  uint16_t list[NT / 64][NT];  // per-wavefront compacted (entry | strips << 8)
+};
+
+// One tile job: NW cooperating wavefronts (threadIdx.x in [0, 64 NW)), PPT pixels per lane; the
+// job's first wavefront owns strip group `wave_base` (0 for a whole tile; the strip index for a
+// single-strip job of the mixed launch, PPT == 1 / NW == 1).
+template <int C, int PPT, int NW>
+__device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int tile, int wave_base, int width,
+                                                int height, int tile_w, const float4* __restrict__ splats,
+                                                const int32_t* __restrict__ tile_offsets,
+                                                const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
+                                                float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                                                const Composite& comp) {
+  constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
-  __shared__ float4 lds[NT][NV];
-  __shared__ uint32_t lds_mask[NT];
-  __shared__ uint16_t lds_list[NT / 64][NT];  // per-wavefront compacted (entry | strips << 8)
-
-  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
-  if (tile < 0) return;
+  auto& lds = sh.rec;
+  auto& lds_mask = sh.mask;
+  auto& lds_list = sh.list;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
-  const int lane = fg::lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = fg::lane_id(), wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave_base + wl;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
+  const int col = threadIdx.x & 15, row0 = 4 * wave_base + (threadIdx.x >> 4);
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
@@ -304,7 +340,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       const unsigned m = lds_mask[64 * i + lane];
       const bool rel = (m & my_strips) != 0u;
       const uint64_t bal = __ballot(rel);
-      if (rel) lds_list[wave][cnt + __popcll(bal & lt_mask)] = (uint16_t)((64 * i + lane) | (m << 8));
+      if (rel) lds_list[wl][cnt + __popcll(bal & lt_mask)] = (uint16_t)((64 * i + lane) | (m << 8));
       cnt += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();  // the list is private to this wavefront
@@ -314,7 +350,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       // the list index are scalar arithmetic (as a vector value the compiler spent a quarter-rate
       // v_mul_lo_u32 per entry on the address)
       FG_STAT(8, 1);
-      const unsigned packed = __builtin_amdgcn_readfirstlane((unsigned)lds_list[wave][n]);
+      const unsigned packed = __builtin_amdgcn_readfirstlane((unsigned)lds_list[wl][n]);
       const int j = packed & 255u;
       Splat s;
       float f[C];
@@ -382,32 +418,76 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   }
 }
 
+
 template <int C, int PPT>
 __global__ void __launch_bounds__(256 / PPT)
-raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
+raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
-                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
-                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
-                  float* __restrict__ v_splats, Composite comp) {
-  constexpr int NT = 256 / PPT;
-  constexpr int NW = NT / 64;
-  constexpr int RSTEP = TILE / PPT;
-  constexpr int NV = rec_vec4(C);
-  __shared__ float4 lds[NT][NV];
-  __shared__ int32_t lds_gid[NT];
-  __shared__ uint32_t lds_mask[NT];
-  __shared__ int32_t lds_max[NW];
-#if FG_BWD_LDS_REDUCE
-  __shared__ float lds_red[NW][(8 + (C <= 4 ? C : 0)) * fg::FG_RED_STRIDE];  // per-wavefront reduction buffer
-#endif
-
+                  float* __restrict__ render, float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                  Composite comp) {
+  constexpr int NW = 256 / PPT / 64;
+  __shared__ FwdShared<C, 64 * NW> sh;
   const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
   if (tile < 0) return;
+  raster_fwd_body<C, PPT, NW>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
+                              last_ids, comp);
+}
+
+// Mixed launch (one wavefront per workgroup): every XCD walks its band column-major as above; the
+// first tiles of its sequence are whole-tile jobs (4 pixels per lane), the last `tail_tiles` are
+// split into four single-strip jobs (1 pixel per lane) -- see launch_fwd_mixed.
+template <int C>
+__global__ void __launch_bounds__(64)
+raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+                        const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+                        const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
+                        float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp) {
+  __shared__ FwdShared<C, 64> sh;
+  int strip;
+  const int tile = job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+  if (tile < 0) return;
+  if (strip < 0)
+    raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
+                             last_ids, comp);
+  else
+    raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
+                             alphas, last_ids, comp);
+}
+
+template <int C, int NT>
+struct BwdShared {
+  float4 rec[NT][rec_vec4(C)];
+  // per-wavefront reduction buffer; read with ds_read_b128: keep it 16-byte aligned (unaligned it
+  // cost 0.46 -> 0.70 ms)
+  alignas(16) float red[NT / 64][(8 + (C <= 4 ? C : 0)) * fg::FG_RED_STRIDE];
+  int32_t gid[NT];
+  uint32_t mask[NT];
+  int32_t mx[NT / 64];
+};
+
+template <int C, int PPT, int NW>
+__device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int tile, int wave_base, int width,
+                                                int height, int tile_w, const float4* __restrict__ splats,
+                                                const int32_t* __restrict__ tile_offsets,
+                                                const int32_t* __restrict__ flatten_ids,
+                                                const float* __restrict__ alphas,
+                                                const int32_t* __restrict__ last_ids,
+                                                const float* __restrict__ v_render,
+                                                const float* __restrict__ v_alphas, float* __restrict__ v_splats,
+                                                const Composite& comp) {
+  constexpr int NT = 64 * NW;
+  constexpr int RSTEP = TILE / PPT;
+  constexpr int NV = rec_vec4(C);
+  auto& lds = sh.rec;
+  auto& lds_gid = sh.gid;
+  auto& lds_mask = sh.mask;
+  auto& lds_max = sh.mx;
+  auto& lds_red = sh.red;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
-  const int lane = fg::lane_id(), wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int col = threadIdx.x & 15, row0 = threadIdx.x >> 4;
+  const int lane = fg::lane_id(), wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave_base + wl;
+  const int col = threadIdx.x & 15, row0 = 4 * wave_base + (threadIdx.x >> 4);
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
   const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
@@ -440,7 +520,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
   // last list entry any pixel of the tile used
   int bin_final = fg::wave_max_i32(my_max);
   if (NW > 1) {
-    if (lane == 0) lds_max[threadIdx.x >> 6] = bin_final;
+    if (lane == 0) lds_max[wl] = bin_final;
     __syncthreads();
 #pragma unroll
     for (int w = 0; w < NW; ++w) bin_final = max(bin_final, lds_max[w]);
@@ -484,7 +564,9 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         todo &= ~(1ull << bit);
         const int j = 64 * i + bit;
         const int idx_j = batch + j;
+#if !FG_BWD_BATCHED_PRETEST
         const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
+#endif
         if (NW > 1) {
           // wave-uniform skip: no pixel of THIS wavefront reaches the entry (with one wavefront per
           // tile every staged entry is <= bin_final = max(last), i.e. always reached by some pixel)
@@ -625,9 +707,10 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
         g[3] *= 0.5f * dx * dx;
         FG_STAT(4, 1);
 #if FG_BWD_LDS_REDUCE
+        (void)lds_red;
         if (C <= 4) {  // 8 + C live accumulators: summed through LDS (the butterflies' swaps and DPP
                        // operations cost 4-8 issue clocks each, fg_common.h)
-          const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wave], lane);
+          const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wl], lane);
           if ((lane & 3) == 0 && (lane >> 2) < 8 + C) {
             const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
             float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
@@ -666,6 +749,40 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
       }
     }
   }
+}
+
+template <int C, int PPT>
+__global__ void __launch_bounds__(256 / PPT)
+raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode, const float4* __restrict__ splats,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ flatten_ids,
+                  const float* __restrict__ alphas, const int32_t* __restrict__ last_ids,
+                  const float* __restrict__ v_render, const float* __restrict__ v_alphas,
+                  float* __restrict__ v_splats, Composite comp) {
+  constexpr int NW = 256 / PPT / 64;
+  __shared__ BwdShared<C, 64 * NW> sh;
+  const int tile = tile_of_block(blockIdx.x, tile_w * tile_h, tile_w, tile_h, order_mode);
+  if (tile < 0) return;
+  raster_bwd_body<C, PPT, NW>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                              v_render, v_alphas, v_splats, comp);
+}
+
+template <int C>
+__global__ void __launch_bounds__(64)
+raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+                        const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+                        const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
+                        const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
+                        const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp) {
+  __shared__ BwdShared<C, 64> sh;
+  int strip;
+  const int tile = job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+  if (tile < 0) return;
+  if (strip < 0)
+    raster_bwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                             v_render, v_alphas, v_splats, comp);
+  else
+    raster_bwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
+                             last_ids, v_render, v_alphas, v_splats, comp);
 }
 
 __global__ void __launch_bounds__(256)
@@ -780,6 +897,47 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
+#ifndef FG_TAIL_PERMILLE_FWD
+#define FG_TAIL_PERMILLE_FWD 500
+#endif
+#ifndef FG_TAIL_PERMILLE_BWD
+#define FG_TAIL_PERMILLE_BWD 0
+#endif
+// Tiles per XCD that the mixed launch splits into single-strip jobs (0 = classic launch).
+// FG_RASTER_TAIL_FWD / _BWD override; measured in profiles/r01_tail_split.md.
+int raster_tail(const char* name, int n_tiles, int dflt_permille) {
+  const char* e = getenv(name);
+  if (e) return atoi(e);
+  if (n_tiles < 6000 || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
+  return (int)((int64_t)(n_tiles / 8) * dflt_permille / 1000);
+}
+int mixed_grid(int tile_w, int tile_h, int tail) {
+  const int n_max = ((tile_h >> 3) + ((tile_h & 7) ? 1 : 0)) * tile_w;
+  return 8 * (n_max + 3 * (tail < n_max ? tail : n_max));
+}
+
+template <int C>
+int launch_fwd_mixed(int width, int height, int tail, const float* splats, const int32_t* tile_offsets,
+                     const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, Composite comp,
+                     hipStream_t s) {
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(mixed_grid(tile_w, tile_h, tail)), dim3(64), 0, s, width,
+                     height, tile_w, tile_h, tail, reinterpret_cast<const float4*>(splats), tile_offsets,
+                     flatten_ids, render, alphas, last_ids, comp);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
+template <int C>
+int launch_bwd_mixed(int width, int height, int tail, const float* splats, const int32_t* tile_offsets,
+                     const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids,
+                     const float* v_render, const float* v_alphas, float* v_splats, Composite comp, hipStream_t s) {
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(mixed_grid(tile_w, tile_h, tail)), dim3(64), 0, s, width,
+                     height, tile_w, tile_h, tail, reinterpret_cast<const float4*>(splats), tile_offsets,
+                     flatten_ids, alphas, last_ids, v_render, v_alphas, v_splats, comp);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
 #define FG_DISPATCH_C(CALL)                  \
   switch (channels) {                        \
     case 1: CALL(1); break;                  \
@@ -833,9 +991,13 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt_fwd(((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
+  const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  const int ppt = raster_ppt_fwd(n_tiles);
+  const int tail = getenv("FG_RASTER_PPT_FWD") ? 0 : raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL_PERMILLE_FWD);
 #define CALL(CC)                                                                                                    \
-  rc = (ppt == 4)   ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+  rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, render, alphas,  \
+                                         last_ids, comp, s)                                                         \
+       : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
@@ -856,9 +1018,13 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
-  const int ppt = raster_ppt_bwd(((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE));
+  const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  const int ppt = raster_ppt_bwd(n_tiles);
+  const int tail = getenv("FG_RASTER_PPT_BWD") ? 0 : raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL_PERMILLE_BWD);
 #define CALL(CC)                                                                                            \
-  rc = (ppt == 4)   ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+  rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, alphas,  \
+                                         last_ids, v_render, v_alphas, v_splats, comp, s)                   \
+       : (ppt == 4) ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
        : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
