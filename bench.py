@@ -299,16 +299,19 @@ def main():
         "avg_ms": stages[dom],
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
-    # the roof that actually binds the raster kernels: vector issue.  A wave64 fp32 instruction occupies
-    # a SIMD16 for 4 clocks; 256 CUs x 4 SIMDs at the 2.4 GHz peak engine clock (MI355X_MICROARCH.md)
+    # Vector issue of the raster kernels (profiles/r01_valu_issue_rates.md): a SIMD issues one
+    # full-rate wave64 fp32 instruction per 2 clocks (256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1229 G/s) but
+    # only with ~4 ready wavefronts of dependent code; half-rate instructions (compare, select,
+    # min/max, DPP) cost 4 clocks, exp / rcp / permlane swaps 8.  `frac` is against the 2-clock peak.
     issue = {}
     for st_name in ("fg_raster_bwd", "fg_raster_fwd"):
         vi = pmc_valu(st_name, f"{N}x{W}x{H}xsh{args.sh_degree}")
         if vi is not None and st_name in stages:
-            peak = 1024 * 2.4e9 / 4  # wave-instructions per second
+            peak = 1024 * 2.4e9 / 2  # wave-instructions per second, full-rate instructions
+            rate = vi / (stages[st_name] * 1e-3)
             issue[st_name] = {"valu_wave_instr": vi, "avg_ms": stages[st_name],
-                              "achieved_G_instr_per_s": vi / (stages[st_name] * 1e-3) / 1e9,
-                              "peak_G_instr_per_s": peak / 1e9, "frac": vi / (stages[st_name] * 1e-3) / peak}  # fmt: skip
+                              "achieved_G_instr_per_s": rate / 1e9, "peak_G_instr_per_s": peak / 1e9,
+                              "frac": rate / peak, "clocks_per_instr_per_simd": 1024 * 2.4e9 / rate}  # fmt: skip
     # the HBM-bound stages next to it: measured traffic (same PMC file) over their HIP-event time
     hbm_stages = {}
     for st_name in ("fg_preprocess_fwd", "fg_preprocess_bwd", "fg_raster_fwd", "fg_raster_bwd"):

@@ -459,7 +459,7 @@ struct BwdShared {
   float4 rec[NT][rec_vec4(C)];
   // per-wavefront reduction buffer; read with ds_read_b128: keep it 16-byte aligned (unaligned it
   // cost 0.46 -> 0.70 ms)
-  alignas(16) float red[NT / 64][(8 + (C <= 4 ? C : 0)) * fg::FG_RED_STRIDE];
+  alignas(16) float red[NT / 64][(8 + C) * fg::FG_RED_STRIDE];
   int32_t gid[NT];
   uint32_t mask[NT];
   int32_t mx[NT / 64];
@@ -708,8 +708,8 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         FG_STAT(4, 1);
 #if FG_BWD_LDS_REDUCE
         (void)lds_red;
-        if (C <= 4) {  // 8 + C live accumulators: summed through LDS (the butterflies' swaps and DPP
-                       // operations cost 4-8 issue clocks each, fg_common.h)
+        if (true) {  // 8 + C live accumulators: summed through LDS (the butterflies' swaps and DPP
+                     // operations cost 4-8 issue clocks each, fg_common.h)
           const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wl], lane);
           if ((lane & 3) == 0 && (lane >> 2) < 8 + C) {
             const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
