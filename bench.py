@@ -74,10 +74,10 @@ def algorithmic_bytes(N, V, I, P, T, k, p):
 
 # stage (C-ABI entry point) -> the single kernel it launches, for the PMC traffic lookup
 STAGE_KERNEL = {
-    "fg_raster_bwd": "raster_bwd_kernel",
-    "fg_raster_fwd": "raster_fwd_kernel",
-    "fg_preprocess_fwd": "preprocess_fwd_kernel",
-    "fg_preprocess_bwd": "preprocess_bwd_kernel",
+    "fg_raster_bwd": ("raster_bwd_kernel", "raster_bwd_mixed_kernel"),
+    "fg_raster_fwd": ("raster_fwd_mixed_kernel", "raster_fwd_kernel"),
+    "fg_preprocess_fwd": ("preprocess_fwd_kernel",),
+    "fg_preprocess_bwd": ("preprocess_bwd_kernel",),
 }
 
 
@@ -95,7 +95,7 @@ def pmc_traffic(stage, workload_key):
     if rec.get("workload_key") != workload_key:
         return None
     for name, v in rec["kernels"].items():
-        if name.startswith(kern):
+        if name.startswith(kern):  # str.startswith takes the tuple of candidate kernel names
             return v["hbm_bytes_per_launch"]
     return None
 
