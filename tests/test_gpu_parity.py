@@ -173,6 +173,29 @@ def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
+def test_mixed_launch_equals_classic_launch(monkeypatch):
+    """Whole-tile jobs + single-strip tail jobs (raster_*_mixed_kernel) against one launch shape for
+    all tiles: the forward is bit-identical (a pixel's compositing does not depend on which
+    wavefront owns it), the backward equal up to the order of its float atomics."""
+    sc = _scene(n=20000, w=400, h=300, seed=23)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    outs = []
+    for tail in ("0", "7", "100000"):
+        monkeypatch.setenv("FG_RASTER_TAIL_FWD", tail)
+        monkeypatch.setenv("FG_RASTER_TAIL_BWD", tail)
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, render_mode="RGB+ED", absgrad=True, packed=False)
+        g = torch.Generator().manual_seed(0)
+        info["means2d"].retain_grad()
+        (r * torch.randn(r.shape, generator=g).to(DEV)).sum().backward()
+        outs.append((r.detach(), a.detach(), [x.grad for x in t], info["means2d"].absgrad))
+    for r, a, grads, absg in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(a, outs[0][1])
+        for x, y in zip(grads, outs[0][2]):
+            assert rel_l2(x, y) < 1e-5
+        assert rel_l2(absg, outs[0][3]) < 1e-5
+
+
 @pytest.mark.parametrize("n,end_bit", [(5, 32), (4097, 13), (250_001, 32), (3_000_000, 13)])
 def test_sort_pairs32_bit_exact_and_stable(n, end_bit):
     g = torch.Generator().manual_seed(n)
