@@ -214,7 +214,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
     for (int c = 0; c < REC; ++c) row[c] = rec[c];
   }
   __syncthreads();
-  lds_to_slab_at<RSTRIDE>(splats + (size_t)row0 * REC, lds, 0, nrows, REC, REC);
+  lds_to_slab_at<RSTRIDE, false>(splats + (size_t)row0 * REC, lds, 0, nrows, REC, REC);
 }
 
 __global__ void __launch_bounds__(BLOCK)

@@ -2,6 +2,28 @@
 #pragma once
 #include "sh_math.h"
 
+// Slabs are read once / written once per launch: non-temporal accesses keep them from evicting
+// the record arrays the raster kernels re-read from L2 (FG_SLAB_NT=0 for the A/B).
+#ifndef FG_SLAB_NT
+#define FG_SLAB_NT 1
+#endif
+#if FG_SLAB_NT
+typedef float fg_f4_native __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 fg_slab_load_nt(const float4* p) {
+  const fg_f4_native v = __builtin_nontemporal_load(reinterpret_cast<const fg_f4_native*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void fg_slab_store_nt(float4* p, float4 v) {
+  fg_f4_native n = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(n, reinterpret_cast<fg_f4_native*>(p));
+}
+#define FG_SLAB_LOAD(p) fg_slab_load_nt(p)
+#define FG_SLAB_STORE(p, v) fg_slab_store_nt((p), (v))
+#else
+#define FG_SLAB_LOAD(p) (*(p))
+#define FG_SLAB_STORE(p, v) (*(p) = (v))
+#endif
+
 namespace fgsh {
 
 // Coalesced copy of a contiguous [nrows x row_floats] slab into padded LDS rows (stride STRIDE) at
@@ -24,7 +46,7 @@ __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const f
 #pragma unroll
     for (int t = 0; t < SLAB_MAX_Q; ++t) {
       const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) v[t] = src4[q];
+      if (q < total4) v[t] = FG_SLAB_LOAD(&src4[q]);
     }
 #pragma unroll
     for (int t = 0; t < SLAB_MAX_Q; ++t) {
@@ -53,7 +75,9 @@ __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const f
 
 // The inverse: padded LDS rows (from column lds_col0) out to a contiguous [nrows x row_floats]
 // slab; columns >= lds_cols are written as zero.
-template <int STRIDE = ROW>
+// NT: the slab is not read again on the GPU soon (gradient outputs) -> non-temporal stores; the
+// splat records, which the raster kernels gather right afterwards, keep the default policy.
+template <int STRIDE = ROW, bool NT = true>
 __device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_col0, int nrows,
                                                int row_floats, int lds_cols) {
   const int total = nrows * row_floats;
@@ -76,7 +100,8 @@ __device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const fl
           const float x = lds[row_base + (cc < lds_cols ? lds_col0 + cc : STRIDE - 1)];
           vv[jj] = cc < lds_cols ? x : 0.f;
         }
-        dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+        if (NT) FG_SLAB_STORE(&dst4[q], make_float4(vv[0], vv[1], vv[2], vv[3]));
+        else dst4[q] = make_float4(vv[0], vv[1], vv[2], vv[3]);
       }
     }
   } else {
