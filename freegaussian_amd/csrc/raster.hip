@@ -22,6 +22,7 @@
 #include "fg_common.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -96,19 +97,26 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
 // them.  Shorter jobs at the end of every XCD's sequence shorten that tail; splitting every tile
 // would repeat the per-entry work everywhere (slower: profiles/r01_ppt_by_tiles.md).
 __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int tail_tiles, int& strip) {
+  // tail_tiles = tail4 | tail2 << 16: the last tail4 tiles of the sequence are four single-strip
+  // jobs (strip = 0..3), the tail2 tiles before them two two-strip jobs (strip = 4 + half)
+  const int tail4_req = tail_tiles & 0xFFFF, tail2_req = tail_tiles >> 16;
   const int xcd = b & 7, k = b >> 3;
   const int q = tile_h >> 3, r = tile_h & 7;
   const int rows = q + (xcd < r ? 1 : 0);
   const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int n = rows * tile_w;
-  const int tail = min(tail_tiles, n), n_main = n - tail;
+  const int tail4 = min(tail4_req, n), tail2 = min(tail2_req, n - tail4), n_main = n - tail4 - tail2;
   int idx;
   if (k < n_main) {
     idx = k;
     strip = -1;
+  } else if (k < n_main + 2 * tail2) {
+    idx = n_main + ((k - n_main) >> 1);
+    strip = 4 + ((k - n_main) & 1);
   } else {
-    idx = n_main + ((k - n_main) >> 2);
-    strip = (k - n_main) & 3;
+    const int t = k - n_main - 2 * tail2;
+    idx = n_main + tail2 + (t >> 2);
+    strip = t & 3;
   }
   if (idx >= n) return -1;
   const int col = idx / rows;
@@ -449,6 +457,9 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
                              last_ids, comp);
+  else if (strip >= 4)
+    raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
+                             alphas, last_ids, comp);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
                              alphas, last_ids, comp);
@@ -546,7 +557,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
 #pragma unroll
       for (int q = 0; q < NV; ++q) v[q] = rec[q];
       mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
-      if (C == 3) {  // three spare floats in the 48-byte LDS copy: the pre-scaled conic rides along
+      if constexpr (C == 3) {  // three spare floats in the 48-byte LDS copy: the pre-scaled conic rides along
         v[2].y = v[0].w * (0.5f * FG_NEG_LOG2E);
         v[2].z = v[1].x * FG_NEG_LOG2E;
         v[2].w = v[1].y * (0.5f * FG_NEG_LOG2E);
@@ -582,7 +593,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         read_record<C>(lds[j], s, f);
         const float dx = s.x - px;
         SigmaTerms st;
-        if (C == 3) {
+        if constexpr (C == 3) {
           const float4 tail = lds[j][2];  // (f2, a', b', c'): the load read_record already issued
           st = sigma_terms_prescaled(tail.y, tail.z, tail.w, dx);
         } else {
@@ -780,6 +791,9 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   if (strip < 0)
     raster_bwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
                              v_render, v_alphas, v_splats, comp);
+  else if (strip >= 4)
+    raster_bwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
+                             last_ids, v_render, v_alphas, v_splats, comp);
   else
     raster_bwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
                              last_ids, v_render, v_alphas, v_splats, comp);
@@ -897,23 +911,48 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
-#ifndef FG_TAIL_PERMILLE_FWD
-#define FG_TAIL_PERMILLE_FWD 500
+// Tiles per XCD at the end of its sequence that the mixed launch splits into four single-strip
+// jobs (TAIL4) / into two two-strip jobs placed before those (TAIL2).  Absolute counts: the tail
+// of a launch is about one job per wavefront slot of the XCD (128 SIMDs x 4-8 slots), whatever the
+// image size -- 510 / 300 were the best settings at 1080p, 1440p and 2160p alike
+// (profiles/r01_tail_split.md); at most half / 30% of the XCD's tiles.  0 = classic launch.
+// FG_RASTER_TAIL_FWD / _BWD = "t4" or "t4,t2" override.
+#ifndef FG_TAIL4_TILES_FWD
+#define FG_TAIL4_TILES_FWD 510
 #endif
-#ifndef FG_TAIL_PERMILLE_BWD
-#define FG_TAIL_PERMILLE_BWD 0
+#ifndef FG_TAIL2_TILES_FWD
+#define FG_TAIL2_TILES_FWD 0
 #endif
-// Tiles per XCD that the mixed launch splits into single-strip jobs (0 = classic launch).
-// FG_RASTER_TAIL_FWD / _BWD override; measured in profiles/r01_tail_split.md.
-int raster_tail(const char* name, int n_tiles, int dflt_permille) {
+#ifndef FG_TAIL4_TILES_BWD
+#define FG_TAIL4_TILES_BWD 0
+#endif
+#ifndef FG_TAIL2_TILES_BWD
+#define FG_TAIL2_TILES_BWD 300
+#endif
+// Returns tail4 | tail2 << 16 (both clamped to 16 bits); the variables take "t4" or "t4,t2".
+int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
   const char* e = getenv(name);
-  if (e) return atoi(e);
-  if (n_tiles < 6000 || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
-  return (int)((int64_t)(n_tiles / 8) * dflt_permille / 1000);
+  int t4, t2 = 0;
+  if (e) {
+    t4 = atoi(e);
+    const char* c = strchr(e, ',');
+    if (c) t2 = atoi(c + 1);
+  } else {
+    if (n_tiles < 5000 || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
+    const int per_xcd = n_tiles / 8;
+    t4 = dflt4 < per_xcd / 2 ? dflt4 : per_xcd / 2;
+    t2 = dflt2 < per_xcd * 3 / 10 ? dflt2 : per_xcd * 3 / 10;
+  }
+  t4 = t4 < 0 ? 0 : (t4 > 0xFFFF ? 0xFFFF : t4);
+  t2 = t2 < 0 ? 0 : (t2 > 0x7FFF ? 0x7FFF : t2);
+  return t4 | (t2 << 16);
 }
 int mixed_grid(int tile_w, int tile_h, int tail) {
   const int n_max = ((tile_h >> 3) + ((tile_h & 7) ? 1 : 0)) * tile_w;
-  return 8 * (n_max + 3 * (tail < n_max ? tail : n_max));
+  int t4 = tail & 0xFFFF, t2 = tail >> 16;
+  t4 = t4 < n_max ? t4 : n_max;
+  t2 = t2 < n_max - t4 ? t2 : n_max - t4;
+  return 8 * (n_max + 3 * t4 + t2);
 }
 
 template <int C>
@@ -993,7 +1032,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const int ppt = raster_ppt_fwd(n_tiles);
-  const int tail = getenv("FG_RASTER_PPT_FWD") ? 0 : raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL_PERMILLE_FWD);
+  const int tail = getenv("FG_RASTER_PPT_FWD") ? 0 : raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL4_TILES_FWD, FG_TAIL2_TILES_FWD);
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, render, alphas,  \
                                          last_ids, comp, s)                                                         \
@@ -1020,7 +1059,7 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const int ppt = raster_ppt_bwd(n_tiles);
-  const int tail = getenv("FG_RASTER_PPT_BWD") ? 0 : raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL_PERMILLE_BWD);
+  const int tail = getenv("FG_RASTER_PPT_BWD") ? 0 : raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, alphas,  \
                                          last_ids, v_render, v_alphas, v_splats, comp, s)                   \
