@@ -180,7 +180,7 @@ def test_mixed_launch_equals_classic_launch(monkeypatch):
     sc = _scene(n=20000, w=400, h=300, seed=23)
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     outs = []
-    for tail in ("0", "7", "100000"):
+    for tail in ("0", "7", "3,5", "100000"):
         monkeypatch.setenv("FG_RASTER_TAIL_FWD", tail)
         monkeypatch.setenv("FG_RASTER_TAIL_BWD", tail)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
