@@ -123,6 +123,85 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
   return (row0 + idx - col * rows) * tile_w + col;
 }
 
+// Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
+// whose list is longer than total / 2^s4 becomes four single-strip jobs, longer than total / 2^s2
+// two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
+// mean, scripts/clustered_check.py) whole-tile jobs for those tiles made the forward 0.81 ms; every
+// tile in quarters 0.39 ms.  Layout of a list (int32): [0..7] jobs per XCD, then 8 segments of
+// `cap` = 4 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
+// column-major order.  (Giving every tile four workgroups and letting the unused ones return was
+// tried first: the empty workgroups in front of live ones cost the forward 0.218 -> 0.275 ms, and
+// with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
+struct JobParams {
+  int tail4, tail2, s4, s2;
+};
+__global__ void __launch_bounds__(1024)
+build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
+                  JobParams pb, int32_t* __restrict__ jobs_fwd, int32_t* __restrict__ jobs_bwd) {
+  constexpr int NTH = 1024, NWV = NTH / 64;
+  __shared__ int wave_tot[NWV];
+  __shared__ int carry;
+  const int xcd = blockIdx.x & 7;
+  const bool bwd = blockIdx.x >= 8;
+  int32_t* jobs = bwd ? jobs_bwd : jobs_fwd;
+  if (!jobs) return;
+  const JobParams p = bwd ? pb : pf;
+  const int q = tile_h >> 3, r = tile_h & 7;
+  const int rows = q + (xcd < r ? 1 : 0);
+  const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int n = rows * tile_w;
+  const int total = tile_offsets[tile_w * tile_h];
+  const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
+  const int thr4 = p.s4 ? (total >> p.s4) : 0x7fffffff, thr2 = p.s2 ? (total >> p.s2) : 0x7fffffff;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  int32_t* seg = jobs + 8 + (size_t)xcd * cap;
+  for (int base = 0; base < n; base += NTH) {
+    const int idx = base + (int)threadIdx.x;
+    int cnt = 0, tile = 0;
+    if (idx < n) {
+      const int col = idx / rows;
+      tile = (row0 + idx - col * rows) * tile_w + col;
+      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+      int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
+      level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
+      cnt = 1 << level;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const int o = __shfl_up(incl, k);
+      if (lane >= k) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pos = carry + incl - cnt;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w)
+      if (w < wave) pos += wave_tot[w];
+    if (cnt == 1) seg[pos] = tile << 3;  // strip -1
+    else if (cnt == 2) { seg[pos] = tile << 3 | 5; seg[pos + 1] = tile << 3 | 6; }  // strip 4, 5
+    else if (cnt == 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1);  // strip 0..3
+    }
+    __syncthreads();
+    if (threadIdx.x == NTH - 1) carry = pos + cnt;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) jobs[xcd] = carry;
+}
+
+// job k of XCD (b & 7) from a list; tile or -1
+__device__ __forceinline__ int job_from_list(int b, const int32_t* __restrict__ jobs, int cap, int& strip) {
+  const int xcd = b & 7, k = b >> 3;
+  if (k >= jobs[xcd]) return -1;
+  const int e = jobs[8 + (size_t)xcd * cap + k];
+  strip = (e & 7) - 1;
+  return e >> 3;
+}
+
 struct Splat {
   float x, y, o, a, b, c;
 };
@@ -447,12 +526,14 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 template <int C>
 __global__ void __launch_bounds__(64)
 raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+                        const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp) {
   __shared__ FwdShared<C, 64> sh;
   int strip;
-  const int tile = job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
+                        : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
@@ -780,13 +861,15 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 template <int C>
 __global__ void __launch_bounds__(64)
 raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+                        const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
                         const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
                         const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp) {
   __shared__ BwdShared<C, 64> sh;
   int strip;
-  const int tile = job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
+                        : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
   if (strip < 0)
     raster_bwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
@@ -917,6 +1000,18 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
 // image size -- 510 / 300 were the best settings at 1080p, 1440p and 2160p alike
 // (profiles/r01_tail_split.md); at most half / 30% of the XCD's tiles.  0 = classic launch.
 // FG_RASTER_TAIL_FWD / _BWD = "t4" or "t4,t2" override.
+#ifndef FG_SPLIT4_FWD
+#define FG_SPLIT4_FWD 11
+#endif
+#ifndef FG_SPLIT2_FWD
+#define FG_SPLIT2_FWD 12
+#endif
+#ifndef FG_SPLIT4_BWD
+#define FG_SPLIT4_BWD 11
+#endif
+#ifndef FG_SPLIT2_BWD
+#define FG_SPLIT2_BWD 12
+#endif
 #ifndef FG_TAIL4_TILES_FWD
 #define FG_TAIL4_TILES_FWD 510
 #endif
@@ -947,33 +1042,61 @@ int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
   t2 = t2 < 0 ? 0 : (t2 > 0x7FFF ? 0x7FFF : t2);
   return t4 | (t2 << 16);
 }
-int mixed_grid(int tile_w, int tile_h, int tail) {
-  const int n_max = ((tile_h >> 3) + ((tile_h & 7) ? 1 : 0)) * tile_w;
+// tail4 | tail2 << 16 of the mixed launch, or 0 = classic launch for this image size / environment
+int mixed_tail_fwd(int n_tiles) {
+  if (getenv("FG_RASTER_PPT_FWD")) return 0;
+  return raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL4_TILES_FWD, FG_TAIL2_TILES_FWD);
+}
+int mixed_tail_bwd(int n_tiles) {
+  if (getenv("FG_RASTER_PPT_BWD")) return 0;
+  return raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
+}
+int band_tiles_max(int tile_w, int tile_h) { return ((tile_h >> 3) + ((tile_h & 7) ? 1 : 0)) * tile_w; }
+int mixed_grid(int tile_w, int tile_h, int tail) {  // positional jobs only
+  const int n_max = band_tiles_max(tile_w, tile_h);
   int t4 = tail & 0xFFFF, t2 = tail >> 16;
   t4 = t4 < n_max ? t4 : n_max;
   t2 = t2 < n_max - t4 ? t2 : n_max - t4;
   return 8 * (n_max + 3 * t4 + t2);
 }
+int jobs_cap(int tile_w, int tile_h) { return 4 * band_tiles_max(tile_w, tile_h); }
+// Content thresholds of the mixed launch: "s4,s2" = split a tile in four when its list is longer than
+// total / 2^s4, in two when longer than total / 2^s2 (FG_RASTER_SPLIT_FWD / _BWD; "0" = off).
+int raster_split(const char* name, int dflt4, int dflt2) {
+  const char* e = getenv(name);
+  int s4 = dflt4, s2 = dflt2;
+  if (e) {
+    s4 = atoi(e);
+    const char* c = strchr(e, ',');
+    s2 = c ? atoi(c + 1) : 0;
+  }
+  s4 = s4 < 0 ? 0 : (s4 > 30 ? 30 : s4);
+  s2 = s2 < 0 ? 0 : (s2 > 30 ? 30 : s2);
+  return s4 | (s2 << 8);
+}
 
 template <int C>
-int launch_fwd_mixed(int width, int height, int tail, const float* splats, const int32_t* tile_offsets,
-                     const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, Composite comp,
-                     hipStream_t s) {
+int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
+                     const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
+                     int32_t* last_ids, Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(mixed_grid(tile_w, tile_h, tail)), dim3(64), 0, s, width,
-                     height, tile_w, tile_h, tail, reinterpret_cast<const float4*>(splats), tile_offsets,
-                     flatten_ids, render, alphas, last_ids, comp);
+  const int cap = jobs_cap(tile_w, tile_h);
+  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? 8 * cap : mixed_grid(tile_w, tile_h, tail)), dim3(64),
+                     0, s, width, height, tile_w, tile_h, tail, jobs, cap, reinterpret_cast<const float4*>(splats),
+                     tile_offsets, flatten_ids, render, alphas, last_ids, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
 template <int C>
-int launch_bwd_mixed(int width, int height, int tail, const float* splats, const int32_t* tile_offsets,
-                     const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids,
-                     const float* v_render, const float* v_alphas, float* v_splats, Composite comp, hipStream_t s) {
+int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
+                     const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
+                     const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
+                     Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(mixed_grid(tile_w, tile_h, tail)), dim3(64), 0, s, width,
-                     height, tile_w, tile_h, tail, reinterpret_cast<const float4*>(splats), tile_offsets,
-                     flatten_ids, alphas, last_ids, v_render, v_alphas, v_splats, comp);
+  const int cap = jobs_cap(tile_w, tile_h);
+  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(jobs ? 8 * cap : mixed_grid(tile_w, tile_h, tail)), dim3(64),
+                     0, s, width, height, tile_w, tile_h, tail, jobs, cap, reinterpret_cast<const float4*>(splats),
+                     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_splats, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1023,7 +1146,7 @@ namespace {
 
 int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
-                   int32_t* last_ids, Composite comp, fg_stream_t stream) {
+                   int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
@@ -1032,10 +1155,12 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const int ppt = raster_ppt_fwd(n_tiles);
-  const int tail = getenv("FG_RASTER_PPT_FWD") ? 0 : raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL4_TILES_FWD, FG_TAIL2_TILES_FWD);
+  int tail = mixed_tail_fwd(n_tiles);
+  if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
+  else if (jobs) tail |= 1;       // the list carries the tails; only "mixed" matters below
 #define CALL(CC)                                                                                                    \
-  rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, render, alphas,  \
-                                         last_ids, comp, s)                                                         \
+  rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
+                                         alphas, last_ids, comp, s)                                                 \
        : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
@@ -1050,7 +1175,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
 int raster_bwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                    const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                   Composite comp, fg_stream_t stream) {
+                   Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_splats) return FG_ERR_INVALID_ARG;
@@ -1059,10 +1184,12 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const int ppt = raster_ppt_bwd(n_tiles);
-  const int tail = getenv("FG_RASTER_PPT_BWD") ? 0 : raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
+  int tail = mixed_tail_bwd(n_tiles);
+  if (tail == 0) jobs = nullptr;
+  else if (jobs) tail |= 1;
 #define CALL(CC)                                                                                            \
-  rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, splats, tile_offsets, flatten_ids, alphas,  \
-                                         last_ids, v_render, v_alphas, v_splats, comp, s)                   \
+  rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
+                                         alphas, last_ids, v_render, v_alphas, v_splats, comp, s)           \
        : (ppt == 4) ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
        : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
@@ -1107,6 +1234,53 @@ extern "C" int fg_raster_composite_bwd(int channels, int width, int height, int 
   return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
                         stream);
+}
+
+// ---- job lists ---------------------------------------------------------------------------------
+extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size) {
+  if (width <= 0 || height <= 0 || tile_size != TILE) return 0;
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  const int n_tiles = tile_w * tile_h;
+  if ((tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
+  if (mixed_tail_fwd(n_tiles) == 0 && mixed_tail_bwd(n_tiles) == 0) return 0;  // classic launches: no lists
+  return 8 + 8 * (int64_t)jobs_cap(tile_w, tile_h);
+}
+
+extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
+                                    int32_t* jobs_fwd, int32_t* jobs_bwd, fg_stream_t stream) {
+  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
+  if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
+  if (!tile_offsets) return FG_ERR_INVALID_ARG;
+  if (!jobs_fwd && !jobs_bwd) return FG_OK;
+  const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
+  const int n_tiles = tile_w * tile_h;
+  const int tf = mixed_tail_fwd(n_tiles), tb = mixed_tail_bwd(n_tiles);
+  const int sf = raster_split("FG_RASTER_SPLIT_FWD", FG_SPLIT4_FWD, FG_SPLIT2_FWD);
+  const int sb = raster_split("FG_RASTER_SPLIT_BWD", FG_SPLIT4_BWD, FG_SPLIT2_BWD);
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 255, (sf >> 8) & 255};
+  const JobParams pb{tb & 0xFFFF, tb >> 16, sb & 255, (sb >> 8) & 255};
+  hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
+                     jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                                  const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
+                                  const float* background, int n_clamp, float* image, float* alphas,
+                                  int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream) {
+  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
+                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs);
+}
+
+extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                                  const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
+                                  const float* background, int n_clamp, const uint8_t* clamp_mask,
+                                  const float* alphas, const int32_t* last_ids, const float* v_image,
+                                  const float* v_alphas, float* v_splats, fg_stream_t stream) {
+  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                        v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
+                        stream, jobs);
 }
 
 #ifdef FG_RASTER_STATS

@@ -50,12 +50,12 @@ class StageTimer:
 stage_timer: Optional[StageTimer] = None
 
 
-def _call(name: str, *args, on=None) -> None:
+def _call(name: str, *args, on=None, stage=None) -> None:
     """Invoke one C-ABI entry point, optionally bracketed by HIP events recorded on the stream the
     kernels go to (``on``: a torch stream other than the current one; the caller passes its raw
-    handle as the entry point's stream argument)."""
+    handle as the entry point's stream argument).  ``stage``: name the time is booked under."""
     fn = getattr(_lib.load(), name)
-    ev = stage_timer.record(name) if stage_timer is not None else None
+    ev = stage_timer.record(stage or name) if stage_timer is not None else None
     if ev:
         ev[0].record(on) if on is not None else ev[0].record()
     rc = fn(*args)
@@ -665,7 +665,18 @@ class _RasterSplats(torch.autograd.Function):
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
         composite = background is not None or n_clamp > 0
         clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
-        if composite:  # O1 folded into the kernel epilogue: render is the finished image
+        # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches
+        words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size)))
+        jobs = None
+        if words > 0:
+            jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
+            _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
+                  _stream())  # fmt: skip
+            _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+                  _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
+                  _ptr(last_ids), _ptr(clamp_mask), _stream(),
+                  stage="fg_raster_composite_fwd" if composite else "fg_raster_fwd")  # fmt: skip
+        elif composite:  # O1 folded into the kernel epilogue: render is the finished image
             _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas), _ptr(last_ids),
                   _ptr(clamp_mask), _stream())  # fmt: skip
@@ -673,6 +684,7 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask)
+        ctx.jobs_bwd = jobs[1] if jobs is not None else None
         ctx.set_materialize_grads(False)  # an unused alpha / render must not cost a zero-fill launch
         ctx.composite = (composite, int(n_clamp))
         ctx.geom = (channels, width, height, tile_size, absgrad, tuple(means2d.shape))
@@ -689,7 +701,13 @@ class _RasterSplats(torch.autograd.Function):
         v_render = torch.zeros(height, width, C, device=splats.device) if v_render is None else v_render
         v_alphas = None if v_alphas is None else v_alphas.contiguous()  # NULL = no gradient on alpha
         v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
-        if composite:
+        if ctx.jobs_bwd is not None:
+            _call("fg_raster_jobs_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
+                  _ptr(flatten_ids), _ptr(ctx.jobs_bwd), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas),
+                  _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _stream(),
+                  stage="fg_raster_composite_bwd" if composite else "fg_raster_bwd")  # fmt: skip
+            ctx.jobs_bwd = None
+        elif composite:
             _call("fg_raster_composite_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas), _ptr(last_ids),
                   _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _stream())  # fmt: skip

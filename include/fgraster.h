@@ -178,6 +178,29 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
                             const float* background, int n_clamp, const uint8_t* clamp_mask,
                             const float* alphas, const int32_t* last_ids, const float* v_image,
                             const float* v_alphas, float* v_splats, fg_stream_t stream);
+/* ---- Job lists for the raster launches ---------------------------------------------------------
+ * At 5000 tiles and more the library runs the raster kernels as one wavefront per JOB: a whole tile
+ * (4 pixels per lane), half a tile or a quarter.  Without a list the job sizes depend on the tile's
+ * position only (the end of every XCD's tile sequence is split); with a list they also depend on
+ * the tile's list length (tiles far longer than the mean are split wherever they are), which is
+ * what non-uniform scenes need (scripts/clustered_check.py).  Caller-allocated like everything else:
+ *   words = fg_raster_jobs_words(...)   int32 words of ONE list; 0 = the library would not use lists
+ *                                        for this size / environment (call the plain entry points)
+ *   fg_raster_build_jobs(...)            one small launch, after tile_offsets exist; either list nullable
+ *   fg_raster_jobs_fwd / _bwd            fg_raster_composite_fwd / _bwd with a list (jobs == NULL:
+ *                                        identical to those) */
+int64_t fg_raster_jobs_words(int width, int height, int tile_size);
+int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
+                         int32_t* jobs_fwd, int32_t* jobs_bwd, fg_stream_t stream);
+int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
+                       const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
+                       const float* background, int n_clamp, float* image, float* alphas,
+                       int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream);
+int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
+                       const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
+                       const float* background, int n_clamp, const uint8_t* clamp_mask,
+                       const float* alphas, const int32_t* last_ids, const float* v_image,
+                       const float* v_alphas, float* v_splats, fg_stream_t stream);
 /* Split v_splats back into per-tensor gradients (any output nullable). */
 int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
                     float* v_means2d_abs, float* v_conics, float* v_opacities,

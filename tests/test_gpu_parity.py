@@ -174,15 +174,17 @@ def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
 
 
 def test_mixed_launch_equals_classic_launch(monkeypatch):
-    """Whole-tile jobs + single-strip tail jobs (raster_*_mixed_kernel) against one launch shape for
-    all tiles: the forward is bit-identical (a pixel's compositing does not depend on which
+    """Whole-tile, two-strip and single-strip jobs chosen by position and by list length
+    (raster_*_mixed_kernel + fg_raster_build_jobs) against one launch shape for all tiles: the forward is bit-identical (a pixel's compositing does not depend on which
     wavefront owns it), the backward equal up to the order of its float atomics."""
     sc = _scene(n=20000, w=400, h=300, seed=23)
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     outs = []
-    for tail in ("0", "7", "3,5", "100000"):
+    for tail, split in (("0", "0"), ("7", "11,12"), ("3,5", "15,17"), ("2,2", "13,0"), ("100000", "0")):
         monkeypatch.setenv("FG_RASTER_TAIL_FWD", tail)
         monkeypatch.setenv("FG_RASTER_TAIL_BWD", tail)
+        monkeypatch.setenv("FG_RASTER_SPLIT_FWD", split)  # content-aware job sizes (job lists)
+        monkeypatch.setenv("FG_RASTER_SPLIT_BWD", split)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, render_mode="RGB+ED", absgrad=True, packed=False)
         g = torch.Generator().manual_seed(0)
