@@ -261,6 +261,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if world > 1 and exchange == "factored":
+        # insurance for a path no 1-GPU box can exercise over RCCL: a host-side failure of the factored
+        # exchange (deterministic, hence on every rank alike) falls back to the plain all-reduce
+        try:
+            info = step()
+            fence()
+        except Exception as e:  # noqa: BLE001
+            if rank == 0:
+                print(f"[bench] factored exchange failed ({e!r}); falling back to FG_EXCHANGE=plain", file=sys.stderr)
+            exchange = "plain"
     for _ in range(args.warmup):
         info = step()
     fence()
