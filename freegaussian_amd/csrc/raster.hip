@@ -124,8 +124,8 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
 }
 
 // Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
-// whose list is longer than total / 2^s4 becomes four single-strip jobs, longer than total / 2^s2
-// two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
+// whose list is longer than total * a4 / 65536 becomes four single-strip jobs, longer than
+// total * a2 / 65536 two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
 // mean, scripts/clustered_check.py) whole-tile jobs for those tiles made the forward 0.81 ms; every
 // tile in quarters 0.39 ms.  Layout of a list (int32): [0..7] jobs per XCD, then 8 segments of
 // `cap` = 4 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
@@ -134,6 +134,7 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
 // with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
 struct JobParams {
   int tail4, tail2, s4, s2;
+  int max_jobs;  // workgroups per XCD of the launch that will read the list
 };
 __global__ void __launch_bounds__(1024)
 build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
@@ -152,8 +153,35 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
   const int n = rows * tile_w;
   const int total = tile_offsets[tile_w * tile_h];
   const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
-  const int thr4 = p.s4 ? (total >> p.s4) : 0x7fffffff, thr2 = p.s2 ? (total >> p.s2) : 0x7fffffff;
+  // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
+  int thr4 = p.s4 ? (int)(((int64_t)total * p.s4) >> 16) : 0x7fffffff;
+  int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
+  // it does; the positional jobs alone always fit
+  for (int round = 0; round < 12; ++round) {
+    int mine = 0;
+    for (int idx = threadIdx.x; idx < n; idx += NTH) {
+      const int col = idx / rows;
+      const int tile = (row0 + idx - col * rows) * tile_w + col;
+      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+      int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
+      level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
+      mine += 1 << level;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
+    __syncthreads();
+    if (lane == 0) wave_tot[wave] = mine;
+    __syncthreads();
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) all += wave_tot[w];
+    if (all <= p.max_jobs) break;  // uniform across the workgroup
+    thr4 = thr4 > 0x50000000 ? 0x7fffffff : thr4 + (thr4 >> 1) + 1;
+    thr2 = thr2 > 0x50000000 ? 0x7fffffff : thr2 + (thr2 >> 1) + 1;
+    if (round == 10) thr4 = thr2 = 0x7fffffff;
+  }
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   int32_t* seg = jobs + 8 + (size_t)xcd * cap;
@@ -531,6 +559,10 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp) {
   __shared__ FwdShared<C, 64> sh;
+  // With a list the grid covers the positional job count plus a margin; fg_raster_build_jobs
+  // makes the list fit it (build_jobs_kernel).  (A grid of the list's full capacity -- 4 jobs per
+  // tile -- left tens of thousands of empty workgroups to dispatch: 2160p forward 0.52 -> 0.64 ms;
+  // workgroups walking on through a longer list cost 12-19 registers in both kernels.)
   int strip;
   const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
                         : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
@@ -1000,17 +1032,20 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
 // image size -- 510 / 300 were the best settings at 1080p, 1440p and 2160p alike
 // (profiles/r01_tail_split.md); at most half / 30% of the XCD's tiles.  0 = classic launch.
 // FG_RASTER_TAIL_FWD / _BWD = "t4" or "t4,t2" override.
+// content thresholds in 1/65536 of the total list length (16 = total / 2^12): measured on the
+// uniform and on the clustered scene (profiles/r01_tail_split.md); at 8160 tiles 16 / 20 are 2.0x /
+// 2.5x the mean list length
 #ifndef FG_SPLIT4_FWD
-#define FG_SPLIT4_FWD 11
+#define FG_SPLIT4_FWD 20
 #endif
 #ifndef FG_SPLIT2_FWD
-#define FG_SPLIT2_FWD 12
+#define FG_SPLIT2_FWD 16
 #endif
 #ifndef FG_SPLIT4_BWD
-#define FG_SPLIT4_BWD 11
+#define FG_SPLIT4_BWD 20
 #endif
 #ifndef FG_SPLIT2_BWD
-#define FG_SPLIT2_BWD 12
+#define FG_SPLIT2_BWD 16
 #endif
 #ifndef FG_TAIL4_TILES_FWD
 #define FG_TAIL4_TILES_FWD 510
@@ -1060,8 +1095,16 @@ int mixed_grid(int tile_w, int tile_h, int tail) {  // positional jobs only
   return 8 * (n_max + 3 * t4 + t2);
 }
 int jobs_cap(int tile_w, int tile_h) { return 4 * band_tiles_max(tile_w, tile_h); }
-// Content thresholds of the mixed launch: "s4,s2" = split a tile in four when its list is longer than
-// total / 2^s4, in two when longer than total / 2^s2 (FG_RASTER_SPLIT_FWD / _BWD; "0" = off).
+// grid of a launch that reads job lists: the positional job count + half a job per tile for the
+// content splits (the builder fits the list into it)
+int listed_grid(int tile_w, int tile_h, int tail) {
+  const int g = mixed_grid(tile_w, tile_h, tail) / 8;
+  const int cap = jobs_cap(tile_w, tile_h);
+  const int want = g + band_tiles_max(tile_w, tile_h) / 2;
+  return 8 * (want < cap ? want : cap);
+}
+// Content thresholds of the mixed launch: "a4,a2" = split a tile in four when its list is longer than
+// total * a4 / 65536, in two when longer than total * a2 / 65536 (FG_RASTER_SPLIT_FWD / _BWD; "0" = off).
 int raster_split(const char* name, int dflt4, int dflt2) {
   const char* e = getenv(name);
   int s4 = dflt4, s2 = dflt2;
@@ -1070,9 +1113,9 @@ int raster_split(const char* name, int dflt4, int dflt2) {
     const char* c = strchr(e, ',');
     s2 = c ? atoi(c + 1) : 0;
   }
-  s4 = s4 < 0 ? 0 : (s4 > 30 ? 30 : s4);
-  s2 = s2 < 0 ? 0 : (s2 > 30 ? 30 : s2);
-  return s4 | (s2 << 8);
+  s4 = s4 < 0 ? 0 : (s4 > 0x7FFF ? 0x7FFF : s4);
+  s2 = s2 < 0 ? 0 : (s2 > 0x7FFF ? 0x7FFF : s2);
+  return s4 | (s2 << 16);
 }
 
 template <int C>
@@ -1081,9 +1124,9 @@ int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const
                      int32_t* last_ids, Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
-  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? 8 * cap : mixed_grid(tile_w, tile_h, tail)), dim3(64),
-                     0, s, width, height, tile_w, tile_h, tail, jobs, cap, reinterpret_cast<const float4*>(splats),
-                     tile_offsets, flatten_ids, render, alphas, last_ids, comp);
+  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
+                     dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
+                     reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1094,9 +1137,10 @@ int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const
                      Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
-  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(jobs ? 8 * cap : mixed_grid(tile_w, tile_h, tail)), dim3(64),
-                     0, s, width, height, tile_w, tile_h, tail, jobs, cap, reinterpret_cast<const float4*>(splats),
-                     tile_offsets, flatten_ids, alphas, last_ids, v_render, v_alphas, v_splats, comp);
+  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
+                     dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
+                     reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids, v_render,
+                     v_alphas, v_splats, comp);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1157,7 +1201,6 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   const int ppt = raster_ppt_fwd(n_tiles);
   int tail = mixed_tail_fwd(n_tiles);
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
-  else if (jobs) tail |= 1;       // the list carries the tails; only "mixed" matters below
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
                                          alphas, last_ids, comp, s)                                                 \
@@ -1186,7 +1229,6 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   const int ppt = raster_ppt_bwd(n_tiles);
   int tail = mixed_tail_bwd(n_tiles);
   if (tail == 0) jobs = nullptr;
-  else if (jobs) tail |= 1;
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s)           \
@@ -1257,8 +1299,8 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   const int tf = mixed_tail_fwd(n_tiles), tb = mixed_tail_bwd(n_tiles);
   const int sf = raster_split("FG_RASTER_SPLIT_FWD", FG_SPLIT4_FWD, FG_SPLIT2_FWD);
   const int sb = raster_split("FG_RASTER_SPLIT_BWD", FG_SPLIT4_BWD, FG_SPLIT2_BWD);
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 255, (sf >> 8) & 255};
-  const JobParams pb{tb & 0xFFFF, tb >> 16, sb & 255, (sb >> 8) & 255};
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8};
+  const JobParams pb{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
                      jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
   FG_RETURN_IF_LAUNCH_FAILED();

@@ -180,7 +180,7 @@ def test_mixed_launch_equals_classic_launch(monkeypatch):
     sc = _scene(n=20000, w=400, h=300, seed=23)
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     outs = []
-    for tail, split in (("0", "0"), ("7", "11,12"), ("3,5", "15,17"), ("2,2", "13,0"), ("100000", "0")):
+    for tail, split in (("0", "0"), ("7", "20,16"), ("3,5", "2,1"), ("2,2", "8,0"), ("100000", "0")):
         monkeypatch.setenv("FG_RASTER_TAIL_FWD", tail)
         monkeypatch.setenv("FG_RASTER_TAIL_BWD", tail)
         monkeypatch.setenv("FG_RASTER_SPLIT_FWD", split)  # content-aware job sizes (job lists)
