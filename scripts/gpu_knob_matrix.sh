@@ -2,7 +2,7 @@
 # Run the GPU parity suite under the non-default runtime knobs (every template instantiation and
 # optional path must give the same results).  Usage: gpurun -- 'bash scripts/gpu_knob_matrix.sh'
 for env in "FG_RASTER_PPT_FWD=1 FG_RASTER_PPT_BWD=1" "FG_RASTER_PPT_FWD=4 FG_RASTER_PPT_BWD=2" "FG_RASTER_PPT_FWD=2 FG_RASTER_PPT_BWD=4" \
-           "FG_RASTER_TAIL_FWD=3,4 FG_RASTER_TAIL_BWD=5,2" "FG_RASTER_TAIL_FWD=100000 FG_RASTER_TAIL_BWD=100000" \
+           "FG_RASTER_TAIL_FWD=3,4 FG_RASTER_TAIL_BWD=5,2 FG_RASTER_SPLIT_FWD=3,2 FG_RASTER_SPLIT_BWD=2,1" "FG_RASTER_TAIL_FWD=100000 FG_RASTER_TAIL_BWD=100000" \
            "FG_TILE_ORDER=rows" "FG_TILE_ORDER=split" "FG_TILE_ORDER=x" "FG_SPECULATIVE_BINNING=0" "FG_OVERLAP_PACK=1"; do
   res=$(env $env timeout 900 python -m pytest tests -m gpu -q -x -k "not two_ranks and not lockstep" 2>&1 | tail -1)
   echo "$env | $res"
