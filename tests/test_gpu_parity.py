@@ -722,6 +722,56 @@ def test_full_size_cfg4_properties_and_oracle_crop():
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
+def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monkeypatch):
+    """A non-uniform scene at 1920x1080 (8160 tiles: job lists are active by default): half of the
+    Gaussians sit in a small ball, so the centre tiles hold lists many times the mean and are split
+    by CONTENT.  Forward must equal the classic launch bit for bit, backward up to atomic order, and
+    a crop over the heavy tiles the scalar C oracle."""
+    from oracle import c_oracle as CO
+
+    sc = synthetic_scene(200_000, 1920, 1080, n_views=1, sh_degree=3, seed=9)
+    sc.means[:100_000] *= 0.2
+    W, H = sc.width, sc.height
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    g = torch.Generator().manual_seed(0)
+    vr = torch.randn(1, H, W, 3, generator=g).to(DEV)
+    outs = []
+    for classic in (False, True):
+        if classic:
+            monkeypatch.setenv("FG_RASTER_TAIL_FWD", "0")
+            monkeypatch.setenv("FG_RASTER_TAIL_BWD", "0")
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, info = rasterization(*t, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
+        (r * vr).sum().backward()
+        outs.append((r.detach(), a.detach(), [x.grad for x in t], info))
+    (r, a, grads, info), (r_c, a_c, grads_c, _) = outs
+    offs, ids = info["isect_offsets"].reshape(-1), info["flatten_ids"]
+    lens = torch.diff(torch.cat([offs, offs.new_tensor([ids.numel()])])) if offs.numel() == 8160 else torch.diff(offs)
+    assert int(lens.max()) > 20 * ids.numel() // 65536  # some tiles really are above the quarter threshold
+    assert torch.equal(r, r_c) and torch.equal(a, a_c)
+    for x, y in zip(grads, grads_c):
+        assert rel_l2(x, y) < 1e-5
+    # centre crop (the heavy tiles) against the C oracle, as in the cfg4 test
+    cw, ch = 160, 96
+    x0, y0 = (W - cw) // 2 // 16 * 16, (H - ch) // 2 // 16 * 16
+    tw = info["tile_width"]
+    offs_c, ids_c = offs.cpu(), ids.cpu()
+    ends = torch.cat([offs_c[1:], torch.tensor([ids_c.numel()], dtype=offs_c.dtype)]) if offs_c.numel() == 8160 else offs_c[1:]
+    lists, coffs = [], [0]
+    for ty in range(ch // 16):
+        for tx in range(cw // 16):
+            tt = (y0 // 16 + ty) * tw + (x0 // 16 + tx)
+            lists.append(ids_c[int(offs_c[tt]) : int(ends[tt])])
+            coffs.append(coffs[-1] + lists[-1].numel())
+    cv, coffs = torch.cat(lists), torch.tensor(coffs, dtype=torch.int32)
+    m2 = info["means2d"][0].detach().cpu() - torch.tensor([float(x0), float(y0)])
+    campos = torch.linalg.inv(sc.viewmats[0])[:3, 3]
+    rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
+    rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
+    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
+    assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
+
+
 # ------------------------------------------------------------------------------------------
 # BASELINE.json configs[1], [2], [4] at (or near) their stated sizes
 def test_cfg2_conerf_like_300k_psnr_and_gradients():
