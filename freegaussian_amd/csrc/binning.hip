@@ -76,10 +76,23 @@ scan_blocksums_kernel(int nblocks, int64_t* __restrict__ block_sums) {
 
 // pass 3: inclusive scan inside each workgroup, offset by the scanned totals.  Thread t owns
 // SCAN_ITEMS consecutive elements so the sequential order matches the array order.
+// RAW_TOTALS: block_sums holds the per-workgroup totals of pass 1 as they are and every workgroup
+// sums its predecessors itself (up to FG_SCAN_FUSED_MAX of them): one launch fewer.
+template <bool RAW_TOTALS>
 __global__ void __launch_bounds__(SCAN_BLOCK)
 scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
                   const int64_t* __restrict__ block_sums, int64_t* __restrict__ out) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
+  int64_t before = 0;
+  if (RAW_TOTALS) {
+    int64_t part = 0;
+    for (int b = threadIdx.x; b < (int)blockIdx.x; b += SCAN_BLOCK) part += block_sums[b];
+    int64_t tot;
+    block_inclusive_scan(part, wave_sums, tot);
+    before = tot;
+  } else {
+    before = block_sums[blockIdx.x];
+  }
   const int base = blockIdx.x * SCAN_TILE + threadIdx.x * SCAN_ITEMS;
   int32_t v[SCAN_ITEMS];
   int64_t s = 0;
@@ -90,11 +103,22 @@ scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restri
   }
   int64_t total;
   const int64_t incl = block_inclusive_scan(s, wave_sums, total);
-  int64_t run = block_sums[blockIdx.x] + incl - s;
+  int64_t run = before + incl - s;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     run += v[k];
     if (base + k < N) out[base + k] = run;
+  }
+}
+constexpr int FG_SCAN_FUSED_MAX = 2048;  // workgroups; beyond that the one-workgroup middle pass is cheaper
+void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_sums, int64_t* out, hipStream_t s) {
+  const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums);
+  if (nblocks <= FG_SCAN_FUSED_MAX) {
+    hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out);
+  } else {
+    hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
+    hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out);
   }
 }
 
@@ -279,14 +303,9 @@ extern "C" int fg_scan_tiles(int N, const int32_t* tiles_touched, int64_t* cum_t
   if (N == 0) return FG_OK;
   if (!tiles_touched || !cum_tiles || !workspace) return FG_ERR_INVALID_ARG;
   if (workspace_bytes < fg_scan_workspace_bytes(N)) return FG_ERR_WORKSPACE;
-  const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
   int64_t* block_sums = static_cast<int64_t*>(workspace);
   hipStream_t s = fg_hip_stream(stream);
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
-                     (const int32_t*)nullptr, block_sums);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
-                     (const int32_t*)nullptr, block_sums, cum_tiles);
+  launch_scan(N, tiles_touched, nullptr, block_sums, cum_tiles, s);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -340,12 +359,7 @@ extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, 
   hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
   const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s);
   if (rc != FG_OK) return rc;
-  const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
-                     (const int32_t*)order, block_sums);
-  hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
-  hipLaunchKernelGGL(scan_apply_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, tiles_touched,
-                     (const int32_t*)order, block_sums, cum_tiles);
+  launch_scan(N, tiles_touched, (const int32_t*)order, block_sums, cum_tiles, s);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
