@@ -27,9 +27,13 @@ constexpr int KEYS_PER_THREAD = FG_SORT_KPT;
 constexpr int TILE = BLOCK * KEYS_PER_THREAD;  // 4096 keys per workgroup
 constexpr int WAVE_SPAN = 64 * KEYS_PER_THREAD;
 
+// `shift` of the kernels below packs the pass's digit: bits 0-7 = bit position, bits 8-11 = digit
+// width (<= RADIX_BITS).  Passes share the key bits evenly (13 tile bits = 7 + 6, not 8 + 5): the
+// ranking costs one ballot round per digit bit.
+
 template <typename KeyT>
 __device__ __forceinline__ unsigned digit_of(KeyT key, int shift) {
-  return (unsigned)(key >> shift) & (RADIX - 1);
+  return (unsigned)(key >> (shift & 255)) & ((1u << (shift >> 8)) - 1u);
 }
 
 template <typename KeyT>
@@ -92,7 +96,8 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
   if (threadIdx.x == 0) digit_total[d] = total;
 }
 
-template <typename KeyT>
+// NBITS: digit width known at compile time (5..8), or 0 = read it from `shift` (narrow digits)
+template <typename KeyT, int NBITS>
 __global__ void __launch_bounds__(BLOCK, 3)
 scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys_in,
                const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -156,6 +161,7 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
     uint64_t peers = __ballot(in);  // lanes holding the same digit
 #pragma unroll
     for (int b = 0; b < RADIX_BITS; ++b) {
+      if (NBITS ? b >= NBITS : b >= (shift >> 8)) break;  // narrower digits need fewer rounds
       const uint64_t m = __ballot((d >> b) & 1u);
       peers &= ((d >> b) & 1u) ? m : ~m;
     }
@@ -262,12 +268,24 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   const int passes = (end_bit + RADIX_BITS - 1) / RADIX_BITS;
   uint32_t* block_hist = control;
   uint32_t* digit_total = control + ((size_t)nb + 1) * RADIX;
+  int first_bit = 0;
   for (int p = 0; p < passes; ++p) {
-    const int shift = p * RADIX_BITS;
+    const int nbits = (end_bit - first_bit + (passes - p) - 1) / (passes - p);  // even split of what is left
+    const int shift = first_bit | (nbits << 8);
+    first_bit += nbits;
     hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(RADIX), dim3(BLOCK), 0, s, nb, block_hist, digit_total);
-    hipLaunchKernelGGL(scatter_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, vin, kout, vout, shift,
-                       block_hist, digit_total);
+#define FG_SCATTER(NB)                                                                                       \
+  hipLaunchKernelGGL((scatter_kernel<KeyT, NB>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, vin, kout, vout, \
+                     shift, block_hist, digit_total)
+    switch (nbits) {
+      case 8: FG_SCATTER(8); break;
+      case 7: FG_SCATTER(7); break;
+      case 6: FG_SCATTER(6); break;
+      case 5: FG_SCATTER(5); break;
+      default: FG_SCATTER(0); break;
+    }
+#undef FG_SCATTER
     KeyT* tk = kin; kin = kout; kout = tk;
     uint32_t* tv = vin; vin = vout; vout = tv;
   }
