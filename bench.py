@@ -159,10 +159,19 @@ def cpu_baseline(scene, view, crop, sh_degree):
     }
 
 
+def under_profiler():
+    """rocprofv3 preloads a library that initialises the GPU in every process it starts: child
+    programs (rocm-smi, the graph leg) must then not be spawned -- the GPU boxes refuse that exec."""
+    return "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ)
+
+
 def gpu_clocks():
     """Engine / memory clock levels as rocm-smi reports them right after the timed region (BASELINE.md
     section 3 asks for the clocks to be noted); a child process, best effort."""
     import subprocess
+
+    if under_profiler():
+        return {"skipped": "running under a profiler"}
 
     try:
         res = subprocess.run(["rocm-smi", "-d", "0", "--showclocks", "--json"], capture_output=True, text=True, timeout=30)
@@ -387,7 +396,7 @@ def main():
     }  # fmt: skip
     if rank == 0:
         out["clocks_after_timed_region"] = gpu_clocks()
-    if world == 1 and not args.no_graph and rank == 0:
+    if world == 1 and not args.no_graph and rank == 0 and not under_profiler():
         # the same step captured in one hipGraph (graphed.GraphedRaster), measured in a CHILD process
         # (a failed capture aborts the process; the headline line must survive).  Informational:
         # the headline above is the eager path, whose kernels can be timed individually.
