@@ -45,14 +45,18 @@ __device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t* wave
 // pass 1: per-workgroup totals
 __global__ void __launch_bounds__(SCAN_BLOCK)
 scan_reduce_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
-                   int64_t* __restrict__ block_sums) {
+                   int64_t* __restrict__ block_sums, int32_t* __restrict__ gathered) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
   const int base = blockIdx.x * SCAN_TILE;
   int64_t s = 0;
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     const int i = base + k * SCAN_BLOCK + threadIdx.x;
-    if (i < N) s += in[order ? order[i] : i];
+    if (i < N) {
+      const int32_t v = in[order ? order[i] : i];
+      s += v;
+      if (gathered) gathered[i] = v;  // the second pass then reads in order instead of gathering again
+    }
   }
   int64_t total;
   block_inclusive_scan(s, wave_sums, total);
@@ -111,9 +115,17 @@ scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restri
   }
 }
 constexpr int FG_SCAN_FUSED_MAX = 2048;  // workgroups; beyond that the one-workgroup middle pass is cheaper
-void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_sums, int64_t* out, hipStream_t s) {
+// gathered (optional, N int32 of scratch): with an `order`, pass 1 leaves the gathered values there
+// and pass 2 reads them back coalesced instead of repeating the random gather
+void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_sums, int64_t* out, hipStream_t s,
+                 int32_t* gathered = nullptr) {
   const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums);
+  if (!order) gathered = nullptr;
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, gathered);
+  if (gathered) {
+    in = gathered;
+    order = nullptr;
+  }
   if (nblocks <= FG_SCAN_FUSED_MAX) {
     hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out);
   } else {
@@ -359,7 +371,8 @@ extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, 
   hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
   const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s);
   if (rc != FG_OK) return rc;
-  launch_scan(N, tiles_touched, (const int32_t*)order, block_sums, cum_tiles, s);
+  // the sort's alternate value buffer is free again: scratch for the gathered tile counts
+  launch_scan(N, tiles_touched, (const int32_t*)order, block_sums, cum_tiles, s, reinterpret_cast<int32_t*>(sort_ws));
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
