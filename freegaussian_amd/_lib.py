@@ -33,9 +33,10 @@ SIGNATURES = {
     "fg_sort_pairs32": (c_int, [c_int64, P, P, c_int, P, c_size_t, P]),
     "fg_bin_prepare_workspace_bytes": (c_size_t, [c_int]),
     "fg_bin_prepare": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
+    "fg_bin_prepare_rects": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_workspace_bytes": (c_size_t, [c_int64]),
-    "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
-    "fg_bin_emit_sort_capacity": (c_int, [c_int, c_int64, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t,
+    "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "fg_bin_emit_sort_capacity": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t,
                                           P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),

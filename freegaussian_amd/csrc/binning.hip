@@ -45,7 +45,8 @@ __device__ __forceinline__ int64_t block_inclusive_scan(int64_t v, int64_t* wave
 // pass 1: per-workgroup totals
 __global__ void __launch_bounds__(SCAN_BLOCK)
 scan_reduce_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
-                   int64_t* __restrict__ block_sums, int32_t* __restrict__ gathered) {
+                   int64_t* __restrict__ block_sums, int32_t* __restrict__ gathered,
+                   const int2* __restrict__ rect2, int32_t* __restrict__ rects_sorted) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
   const int base = blockIdx.x * SCAN_TILE;
   int64_t s = 0;
@@ -53,7 +54,18 @@ scan_reduce_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restr
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     const int i = base + k * SCAN_BLOCK + threadIdx.x;
     if (i < N) {
-      const int32_t v = in[order ? order[i] : i];
+      int32_t v;
+      if (rect2) {
+        // ONE 8-byte gather per Gaussian yields its tile rectangle: the count is width x height
+        // and the emission kernel later reads the rectangle in depth order, coalesced (its own
+        // gathers of radii / means2d by id were 15 of its 35 us)
+        const int2 r = rect2[order[i]];  // {x0 | y0 << 16, w | h << 16}
+        const int w = r.y & 0xFFFF, h = r.y >> 16;
+        v = w * h;
+        rects_sorted[i] = (r.x & 0xFFFF) | ((r.x >> 16) << 10) | (w << 20);
+      } else {
+        v = in[order ? order[i] : i];
+      }
       s += v;
       if (gathered) gathered[i] = v;  // the second pass then reads in order instead of gathering again
     }
@@ -118,10 +130,11 @@ constexpr int FG_SCAN_FUSED_MAX = 2048;  // workgroups; beyond that the one-work
 // gathered (optional, N int32 of scratch): with an `order`, pass 1 leaves the gathered values there
 // and pass 2 reads them back coalesced instead of repeating the random gather
 void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_sums, int64_t* out, hipStream_t s,
-                 int32_t* gathered = nullptr) {
+                 int32_t* gathered = nullptr, const int2* rect2 = nullptr, int32_t* rects_sorted = nullptr) {
   const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
   if (!order) gathered = nullptr;
-  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, gathered);
+  hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, gathered,
+                     rect2, rects_sorted);
   if (gathered) {
     in = gathered;
     order = nullptr;
@@ -192,6 +205,29 @@ depth_keys_kernel(int N, const float* __restrict__ depths, const int32_t* __rest
   order[i] = i;
 }
 
+// The same plus the tile rectangle of every Gaussian as {x0 | y0 << 16, w | h << 16} (zeros when
+// culled); the arithmetic is that of the preprocess pass, so w * h == tiles_touched.
+__global__ void __launch_bounds__(256)
+depth_keys_rects_kernel(int N, const float* __restrict__ depths, const int32_t* __restrict__ radii,
+                        const float* __restrict__ means2d, int tile_size, int tile_w, int tile_h,
+                        uint32_t* __restrict__ keys, int32_t* __restrict__ order, int2* __restrict__ rect2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const int radius = radii[i];
+  keys[i] = radius > 0 ? (uint32_t)__float_as_int(depths[i]) : 0xFFFFFFFFu;
+  order[i] = i;
+  int2 r = make_int2(0, 0);
+  if (radius > 0) {
+    const float ts = (float)tile_size;
+    const float rr = (float)radius / ts;
+    const float tx = means2d[2 * i] / ts, ty = means2d[2 * i + 1] / ts;
+    const int x0 = min(max((int)floorf(tx - rr), 0), tile_w), x1 = min(max((int)ceilf(tx + rr), 0), tile_w);
+    const int y0 = min(max((int)floorf(ty - rr), 0), tile_h), y1 = min(max((int)ceilf(ty + rr), 0), tile_h);
+    r = make_int2(x0 | (y0 << 16), (x1 - x0) | ((y1 - y0) << 16));
+  }
+  rect2[i] = r;
+}
+
 // Emission in depth order, wave-cooperative: the 64 Gaussians of a wavefront own ONE contiguous
 // output range [cum[k0-1], cum[k0+63]) (cum is the ordered inclusive scan), so the wave walks that
 // range 64 slots at a time -- every store instruction writes 64 consecutive (tile, id) pairs --
@@ -203,7 +239,8 @@ __global__ void __launch_bounds__(256)
 tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t* __restrict__ radii,
                         const int32_t* __restrict__ order, const int64_t* __restrict__ cum_tiles, int tile_size,
                         int tile_w, int tile_h, KeyT* __restrict__ tile_keys,
-                        int32_t* __restrict__ flatten_ids, int64_t capacity) {
+                        int32_t* __restrict__ flatten_ids, int64_t capacity,
+                        const int32_t* __restrict__ rects_sorted) {
   __shared__ int32_t s_excl[4][64];  // exclusive slot offset of each lane's splat inside the wave's range
   __shared__ int32_t s_gid[4][64];
   __shared__ int32_t s_rect[4][64];  // x0 | y0 << 10 | width << 20
@@ -219,8 +256,9 @@ tile_bin_ordered_kernel(int N, const float* __restrict__ means2d, const int32_t*
   if (k < N) {
     gid = order[k];
     excl = (int)(((k == 0) ? 0 : cum_tiles[k - 1]) - base);
-    const int radius = radii[gid];
-    if (radius > 0) {
+    if (rects_sorted) {
+      rect = rects_sorted[k];  // in depth order from fg_bin_prepare_rects: no gather by id
+    } else if (const int radius = radii[gid]; radius > 0) {
       const float ts = (float)tile_size;
       const float r = (float)radius / ts;
       const float tx = means2d[2 * gid] / ts, ty = means2d[2 * gid + 1] / ts;
@@ -350,15 +388,21 @@ static inline size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 
 extern "C" size_t fg_bin_prepare_workspace_bytes(int N) {
   const size_t n = (size_t)(N > 0 ? N : 1);
-  return al256(n * 4) + fg_sort::workspace_bytes<uint32_t>((int64_t)n) + al256(fg_scan_workspace_bytes(N));
+  return al256(n * 4) + fg_sort::workspace_bytes<uint32_t>((int64_t)n) + al256(fg_scan_workspace_bytes(N)) +
+         al256(n * 8);  // + the rectangle pairs of fg_bin_prepare_rects
 }
 
-extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, const int32_t* tiles_touched,
-                              int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes,
-                              fg_stream_t stream) {
+namespace {
+// rects_sorted == nullptr: counts come from tiles_touched (fg_bin_prepare); otherwise from the
+// rectangles computed here, which also go out in depth order for the emission kernel.
+int bin_prepare_any(int N, const float* depths, const int32_t* radii, const int32_t* tiles_touched,
+                    const float* means2d, int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles,
+                    int32_t* rects_sorted, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
   if (N < 0) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
-  if (!depths || !radii || !tiles_touched || !order || !cum_tiles || !workspace) return FG_ERR_INVALID_ARG;
+  if (!depths || !radii || !order || !cum_tiles || !workspace) return FG_ERR_INVALID_ARG;
+  if (rects_sorted ? (!means2d || tile_size <= 0 || tile_w <= 0 || tile_h <= 0) : !tiles_touched) return FG_ERR_INVALID_ARG;
+  if (rects_sorted && (tile_w > 1023 || tile_h > 1023)) return FG_ERR_UNSUPPORTED;  // rectangle packing
   if (workspace_bytes < fg_bin_prepare_workspace_bytes(N)) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
   char* ws = static_cast<char*>(workspace);
@@ -368,13 +412,37 @@ extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, 
   const size_t sort_bytes = fg_sort::workspace_bytes<uint32_t>(N);
   ws += sort_bytes;
   int64_t* block_sums = reinterpret_cast<int64_t*>(ws);
-  hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
+  ws += al256(fg_scan_workspace_bytes(N));
+  int2* rect2 = reinterpret_cast<int2*>(ws);
+  if (rects_sorted)
+    hipLaunchKernelGGL(depth_keys_rects_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, means2d,
+                       tile_size, tile_w, tile_h, keys, order, rect2);
+  else
+    hipLaunchKernelGGL(depth_keys_kernel, dim3((N + 255) / 256), dim3(256), 0, s, N, depths, radii, keys, order);
   const int rc = fg_sort::sort_pairs<uint32_t>(N, keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws, sort_bytes, s);
   if (rc != FG_OK) return rc;
-  // the sort's alternate value buffer is free again: scratch for the gathered tile counts
-  launch_scan(N, tiles_touched, (const int32_t*)order, block_sums, cum_tiles, s, reinterpret_cast<int32_t*>(sort_ws));
+  // the sort's alternate key buffer is free again: scratch for the gathered tile counts
+  launch_scan(N, tiles_touched, (const int32_t*)order, block_sums, cum_tiles, s, reinterpret_cast<int32_t*>(sort_ws),
+              rects_sorted ? rect2 : nullptr, rects_sorted);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
+}
+}  // namespace
+
+extern "C" int fg_bin_prepare(int N, const float* depths, const int32_t* radii, const int32_t* tiles_touched,
+                              int32_t* order, int64_t* cum_tiles, void* workspace, size_t workspace_bytes,
+                              fg_stream_t stream) {
+  return bin_prepare_any(N, depths, radii, tiles_touched, nullptr, 0, 0, 0, order, cum_tiles, nullptr, workspace,
+                         workspace_bytes, stream);
+}
+
+extern "C" int fg_bin_prepare_rects(int N, const float* depths, const int32_t* radii, const float* means2d,
+                                    int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles,
+                                    int32_t* rects_sorted, void* workspace, size_t workspace_bytes,
+                                    fg_stream_t stream) {
+  if (!rects_sorted) return FG_ERR_INVALID_ARG;
+  return bin_prepare_any(N, depths, radii, nullptr, means2d, tile_size, tile_w, tile_h, order, cum_tiles, rects_sorted,
+                         workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
@@ -391,11 +459,11 @@ template <typename KeyT>
 int bin_emit_sort_keys(int N, int64_t n_isects, const int64_t* n_dev, const float* means2d, const int32_t* radii,
                        const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
                        KeyT* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets, void* sort_ws, size_t sort_bytes,
-                       hipStream_t s) {
+                       hipStream_t s, const int32_t* rects_sorted) {
   const int n_tiles = tile_w * tile_h;
   if (n_isects > 0) {
     hipLaunchKernelGGL(tile_bin_ordered_kernel<KeyT>, dim3((N + 255) / 256), dim3(256), 0, s, N, means2d, radii, order,
-                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects);
+                       cum_tiles, tile_size, tile_w, tile_h, tile_keys, flatten_ids, n_isects, rects_sorted);
     int bits = 1;
     while ((1 << bits) < n_tiles) ++bits;
     const int rc = fg_sort::sort_pairs<KeyT>(n_isects, tile_keys, reinterpret_cast<uint32_t*>(flatten_ids), bits, sort_ws,
@@ -415,42 +483,44 @@ int bin_emit_sort_keys(int N, int64_t n_isects, const int64_t* n_dev, const floa
 int bin_emit_sort_any(int N, int64_t n_isects, const int64_t* n_dev, const float* means2d, const int32_t* radii,
                       const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w, int tile_h,
                       uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets, void* workspace,
-                      size_t workspace_bytes, fg_stream_t stream) {
+                      size_t workspace_bytes, fg_stream_t stream, const int32_t* rects_sorted) {
   if (N < 0 || n_isects < 0 || tile_size <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_offsets) return FG_ERR_INVALID_ARG;
   if (tile_w > 1023 || tile_h > 1023) return FG_ERR_UNSUPPORTED;  // rectangle packing of the emit kernel
   hipStream_t s = fg_hip_stream(stream);
-  if (n_isects > 0 && (!means2d || !radii || !order || !cum_tiles || !flatten_ids || !workspace)) return FG_ERR_INVALID_ARG;
+  if (n_isects > 0 && (!order || !cum_tiles || !flatten_ids || !workspace)) return FG_ERR_INVALID_ARG;
+  if (n_isects > 0 && !rects_sorted && (!means2d || !radii)) return FG_ERR_INVALID_ARG;
   if (workspace_bytes < fg_bin_emit_workspace_bytes(n_isects)) return FG_ERR_WORKSPACE;
   if (tile_keys || tile_w * tile_h > 65536) {
     if (n_isects > 0 && !tile_keys) return FG_ERR_INVALID_ARG;  // > 65536 tiles: 32-bit keys, caller's buffer
     return bin_emit_sort_keys<uint32_t>(N, n_isects, n_dev, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
-                                        tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, s);
+                                        tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, s, rects_sorted);
   }
   char* ws = static_cast<char*>(workspace);
   uint16_t* keys16 = reinterpret_cast<uint16_t*>(ws);
   const size_t head = al256((size_t)(n_isects > 0 ? n_isects : 1) * 2);
   return bin_emit_sort_keys<uint16_t>(N, n_isects, n_dev, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
-                                      keys16, flatten_ids, tile_offsets, ws + head, workspace_bytes - head, s);
+                                      keys16, flatten_ids, tile_offsets, ws + head, workspace_bytes - head, s, rects_sorted);
 }
 
 }  // namespace
 
 extern "C" int fg_bin_emit_sort(int N, int64_t n_isects, const float* means2d, const int32_t* radii,
-                                const int32_t* order, const int64_t* cum_tiles, int tile_size, int tile_w,
-                                int tile_h, uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
-                                void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+                                const int32_t* order, const int64_t* cum_tiles, const int32_t* rects_sorted,
+                                int tile_size, int tile_w, int tile_h, uint32_t* tile_keys, int32_t* flatten_ids,
+                                int32_t* tile_offsets, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
   return bin_emit_sort_any(N, n_isects, nullptr, means2d, radii, order, cum_tiles, tile_size, tile_w, tile_h,
-                           tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream);
+                           tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream, rects_sorted);
 }
 
 extern "C" int fg_bin_emit_sort_capacity(int N, int64_t capacity, const float* means2d, const int32_t* radii,
-                                         const int32_t* order, const int64_t* cum_tiles, int tile_size,
-                                         int tile_w, int tile_h, uint32_t* tile_keys, int32_t* flatten_ids,
-                                         int32_t* tile_offsets, void* workspace, size_t workspace_bytes,
-                                         fg_stream_t stream) {
+                                         const int32_t* order, const int64_t* cum_tiles,
+                                         const int32_t* rects_sorted, int tile_size, int tile_w, int tile_h,
+                                         uint32_t* tile_keys, int32_t* flatten_ids, int32_t* tile_offsets,
+                                         void* workspace, size_t workspace_bytes, fg_stream_t stream) {
   if (N <= 0 || capacity <= 0 || !cum_tiles) return FG_ERR_INVALID_ARG;
   return bin_emit_sort_any(N, capacity, cum_tiles + (N - 1), means2d, radii, order, cum_tiles, tile_size, tile_w,
-                           tile_h, tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream);
+                           tile_h, tile_keys, flatten_ids, tile_offsets, workspace, workspace_bytes, stream,
+                           rects_sorted);
 }
 
 extern "C" int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* flatten_ids,

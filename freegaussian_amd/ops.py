@@ -252,8 +252,15 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
-    _call("fg_bin_prepare", N, _ptr(depths), _ptr(radii), _ptr(tiles_touched), _ptr(order), _ptr(cum), _ptr(ws),
-          ws.numel(), _stream())  # fmt: skip
+    # rectangles in depth order for the emission kernel (no gathers by id there); the counts then
+    # come from the rectangles, tiles_touched is only the `info` output
+    rects = torch.empty(N, dtype=torch.int32, device=dev) if (tile_w <= 1023 and tile_h <= 1023) else None
+    if rects is not None:
+        _call("fg_bin_prepare_rects", N, _ptr(depths), _ptr(radii), _ptr(means2d), tile_size, tile_w, tile_h,
+              _ptr(order), _ptr(cum), _ptr(rects), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
+    else:
+        _call("fg_bin_prepare", N, _ptr(depths), _ptr(radii), _ptr(tiles_touched), _ptr(order), _ptr(cum), _ptr(ws),
+              ws.numel(), _stream())  # fmt: skip
     # The list length lives on the device.  Instead of stalling the queue on it, the emit + tile
     # sort are enqueued right away on buffers sized from the previous call of the same shape
     # (fg_bin_emit_sort_capacity reads the count on the device); the host then waits only for an
@@ -267,8 +274,9 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         tile_keys = torch.empty(cap, dtype=torch.int32, device=dev) if want_keys else None
         flatten_ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
-        _call("fg_bin_emit_sort_capacity", N, cap, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
-              tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
+        _call("fg_bin_emit_sort_capacity", N, cap, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), _ptr(rects),
+              tile_size, tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(),
+              _stream())  # fmt: skip
         globals()["last_overflow"] = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h)
@@ -282,8 +290,9 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev) if want_keys else None
         flatten_ids = torch.empty(capacity, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(capacity)), dtype=torch.uint8, device=dev)
-        _call("fg_bin_emit_sort_capacity", N, capacity, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size,
-              tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream())  # fmt: skip
+        _call("fg_bin_emit_sort_capacity", N, capacity, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum),
+              _ptr(rects), tile_size, tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2),
+              ws2.numel(), _stream())  # fmt: skip
     def finish():
         ready.synchronize()
         n_isects = int(count_host[0])
@@ -297,8 +306,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         tk = torch.empty(n_isects, dtype=torch.int32, device=dev) if want_keys else None
         ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         ws3 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
-        _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), tile_size, tile_w,
-              tile_h, _ptr(tk), _ptr(ids), _ptr(offsets), _ptr(ws3), ws3.numel(), _stream())  # fmt: skip
+        _call("fg_bin_emit_sort", N, n_isects, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), _ptr(rects),
+              tile_size, tile_w, tile_h, _ptr(tk), _ptr(ids), _ptr(offsets), _ptr(ws3), ws3.numel(), _stream())  # fmt: skip
         return tk, ids, True
 
     if defer and capacity is not None:

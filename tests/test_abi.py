@@ -75,7 +75,8 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_sh_grad_accumulate(4, 2, 3, 16, None, None, 100, 4, 1.0, None, None) == -1
     assert lib.fg_sh_grad_accumulate(4, 2, 3, 16, None, None, 5, 3, 1.0, None, None) == -1  # stride < 3N+3
     # capacity emission needs a positive capacity and the count array
-    assert lib.fg_bin_emit_sort_capacity(4, 0, *(n * 4), 16, 4, 4, *(n * 4), 0, None) == -1
+    assert lib.fg_bin_emit_sort_capacity(4, 0, *(n * 5), 16, 4, 4, *(n * 4), 0, None) == -1
+    assert lib.fg_bin_prepare_rects(4, *(n * 3), 16, 4, 4, *(n * 4), 0, None) == -1
     # raw preprocess is SH-only
     assert lib.fg_preprocess_raw_fwd(4, *(n * 8), -1, 16, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
                                      *(n * 8)) == -1  # fmt: skip
