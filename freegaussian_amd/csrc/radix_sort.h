@@ -26,6 +26,16 @@ constexpr int WAVES = BLOCK / 64;
 constexpr int KEYS_PER_THREAD = FG_SORT_KPT;
 constexpr int TILE = BLOCK * KEYS_PER_THREAD;  // 4096 keys per workgroup
 constexpr int WAVE_SPAN = 64 * KEYS_PER_THREAD;
+// Small arrays (the depth sort of ~1M Gaussians is 245 workgroups of 4096 keys on 256 CUs) are
+// sorted with fewer keys per thread, i.e. more, shorter workgroups.  The kernels take the keys
+// per thread as a template parameter and shadow the three constants above.
+#ifndef FG_SORT_KPT_SMALL
+#define FG_SORT_KPT_SMALL 8
+#endif
+#ifndef FG_SORT_SMALL_N
+#define FG_SORT_SMALL_N (3 << 20)
+#endif
+static inline int keys_per_thread_for(int64_t n) { return n < FG_SORT_SMALL_N ? FG_SORT_KPT_SMALL : FG_SORT_KPT; }
 
 // `shift` of the kernels below packs the pass's digit: bits 0-7 = bit position, bits 8-11 = digit
 // width (<= RADIX_BITS).  Passes share the key bits evenly (13 tile bits = 7 + 6, not 8 + 5): the
@@ -36,10 +46,11 @@ __device__ __forceinline__ unsigned digit_of(KeyT key, int shift) {
   return (unsigned)(key >> (shift & 255)) & ((1u << (shift >> 8)) - 1u);
 }
 
-template <typename KeyT>
+template <typename KeyT, int KPT>
 __global__ void __launch_bounds__(BLOCK)
 hist_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys, int shift,
             uint32_t* __restrict__ block_hist) {
+  constexpr int KEYS_PER_THREAD = KPT, TILE = BLOCK * KPT;
   __shared__ uint32_t hist[RADIX];
   hist[threadIdx.x] = 0;
   __syncthreads();
@@ -97,11 +108,12 @@ digit_scan_kernel(int nblocks, uint32_t* __restrict__ block_hist, uint32_t* __re
 }
 
 // NBITS: digit width known at compile time (5..8), or 0 = read it from `shift` (narrow digits)
-template <typename KeyT, int NBITS>
+template <typename KeyT, int NBITS, int KPT>
 __global__ void __launch_bounds__(BLOCK, 3)
 scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restrict__ keys_in,
                const uint32_t* __restrict__ vals_in, KeyT* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                int shift, const uint32_t* __restrict__ block_hist, const uint32_t* __restrict__ digit_total) {
+  constexpr int KEYS_PER_THREAD = KPT, TILE = BLOCK * KPT, WAVE_SPAN = 64 * KPT;
   const int64_t cap = n;
   __shared__ uint32_t wave_cnt[WAVES][RADIX];
   __shared__ uint32_t scan_tmp[WAVES];
@@ -242,7 +254,10 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-static inline int num_blocks(int64_t n) { return (int)((n + TILE - 1) / TILE); }
+static inline int num_blocks(int64_t n) {
+  const int64_t tile = (int64_t)BLOCK * keys_per_thread_for(n);
+  return (int)((n + tile - 1) / tile);
+}
 
 // bytes of the histogram region: per-workgroup digit histograms + the digit totals
 static inline size_t control_bytes(int64_t n) { return align256(((size_t)num_blocks(n) + 2) * RADIX * 4); }
@@ -264,6 +279,7 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
   if (n > 0xFFFFFFFFll) return FG_ERR_UNSUPPORTED;
   if (ws_bytes < workspace_bytes<KeyT>(n)) return FG_ERR_WORKSPACE;
   const int nb = num_blocks(n);
+  const bool small = keys_per_thread_for(n) != FG_SORT_KPT;
   char* ws = static_cast<char*>(workspace);
   KeyT* keys_alt = reinterpret_cast<KeyT*>(ws);
   ws += align256((size_t)n * sizeof(KeyT));
@@ -281,11 +297,16 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
     const int nbits = (end_bit - first_bit + (passes - p) - 1) / (passes - p);  // even split of what is left
     const int shift = first_bit | (nbits << 8);
     first_bit += nbits;
-    hipLaunchKernelGGL(hist_kernel<KeyT>, dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
+    if (small) hipLaunchKernelGGL((hist_kernel<KeyT, FG_SORT_KPT_SMALL>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
+    else hipLaunchKernelGGL((hist_kernel<KeyT, FG_SORT_KPT>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, shift, block_hist);
     hipLaunchKernelGGL(digit_scan_kernel, dim3(RADIX), dim3(BLOCK), 0, s, nb, block_hist, digit_total);
-#define FG_SCATTER(NB)                                                                                       \
-  hipLaunchKernelGGL((scatter_kernel<KeyT, NB>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin, vin, kout, vout, \
-                     shift, block_hist, digit_total)
+#define FG_SCATTER(NB)                                                                                         \
+  if (small)                                                                                                    \
+    hipLaunchKernelGGL((scatter_kernel<KeyT, NB, FG_SORT_KPT_SMALL>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev,    \
+                       kin, vin, kout, vout, shift, block_hist, digit_total);                                   \
+  else                                                                                                          \
+    hipLaunchKernelGGL((scatter_kernel<KeyT, NB, FG_SORT_KPT>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin,     \
+                       vin, kout, vout, shift, block_hist, digit_total)
     switch (nbits) {
       case 8: FG_SCATTER(8); break;
       case 7: FG_SCATTER(7); break;
