@@ -3,14 +3,20 @@
 synthetic 1M-Gaussian 1920x1080 scene of BASELINE.json (configs "DyNeRF multi-view 1080p,
 ~1M Gaussians"; generator: freegaussian_amd/scenes.py north_star_scene).
 
-One process per GPU; each rank renders its own camera view of the shared scene (view = rank
-mod 8) through ``freegaussian_amd.rasterization`` -- the drop-in for the call at reference
-freegaussian_model.py:847 -- and back-propagates a fixed N(0,1) image gradient.  For N > 1 the
-flat Gaussian-parameter gradient buffer (59 floats per Gaussian) is all-reduced over RCCL
-inside the timed region, as view-sharded training does every step.
+One process per GPU.  Step s of rank r renders camera view (r + s) mod 8 of the shared scene (the
+8-view ring of cfg4, all poses resident on the device) through ``freegaussian_amd.rasterization``
+-- the drop-in for the call at reference freegaussian_model.py:847 -- and back-propagates a fixed
+N(0,1) image gradient.  For N > 1 the Gaussian-parameter gradient (59 floats per Gaussian) is
+exchanged over RCCL inside the timed region, as view-sharded training does every step.
 
-A step = one view per rank, forward + backward (+ all-reduce).  value = total pixels rendered
-by all ranks / max-over-ranks wall time.  Inputs are resident in HBM before the timed region.
+Launching N ranks: either the caller does (``python -m torch.distributed.run --nproc-per-node N
+bench.py --gpus N``: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in the environment) or, when
+``--gpus N`` > 1 is given WITHOUT ``WORLD_SIZE``, this process starts the N rank processes itself
+-- before it has imported the package or made any GPU call -- relays rank 0's JSON line and
+exits with the worst rank's code.
+
+A step = one view per rank, forward + backward (+ exchange).  value = total pixels rendered by
+all ranks / max-over-ranks wall time.  Inputs are resident in HBM before the timed region.
 
 Prints ONE JSON line (rank 0) with the contract keys plus "roofline" (dominant kernel) and
 "cpu_baseline" (the CPU oracle timed on a bounded crop of the same view, N=1 only)."""
@@ -22,20 +28,19 @@ import os
 import sys
 import time
 
-import torch
-import torch.distributed as dist
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-from freegaussian_amd import ops, rasterization  # noqa: E402
-from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
-from freegaussian_amd.viewdp import FlatGaussianParams  # noqa: E402
+# torch and the package (which maps libfgraster.so) are imported inside the functions that need
+# them: the launcher branch of main() must start its rank processes before anything in this
+# process can have touched the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
+N_VIEWS = 8
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -47,8 +52,79 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
-    ap.add_argument("--cpu-crop", type=str, default="960x544")  # ~15 s of oracle time on the GPU box
-    return ap.parse_args()
+    ap.add_argument("--fixed-view", action="store_true", help="render view `rank` every step instead of cycling the ring")
+    ap.add_argument("--cpu-crop", type=str, default="480x272")  # ~4 s of oracle time per run on the GPU box
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the faster of 8 and all host threads")
+    return ap.parse_args(argv)
+
+
+# ------------------------------------------------------------------------------------------------
+# launcher: --gpus N without WORLD_SIZE
+
+
+def rank_environments(n, port, base=None):
+    """The environment of each of the n rank processes (torch.distributed's env:// contract)."""
+    envs = []
+    for r in range(n):
+        e = dict(os.environ if base is None else base)
+        e.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                 MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))  # fmt: skip
+        e.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on these hosts
+        e.setdefault("OMP_NUM_THREADS", "8")
+        envs.append(e)
+    return envs
+
+
+def free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start args.gpus rank processes of this script, relay rank 0's stdout, return the exit code.
+    Runs before this process has imported freegaussian_amd or touched the GPU (counting devices
+    does not initialise it); the children are fresh interpreters, never an exec of this one."""
+    import subprocess
+
+    n = args.gpus
+    backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and not os.environ.get("FG_BENCH_ECHO"):
+        import torch
+
+        have = torch.cuda.device_count()
+        if have < n:
+            print(f"[bench] --gpus {n} but only {have} GPU(s) visible: one rank per GPU over RCCL, devices are "
+                  "never shared (FG_BENCH_BACKEND=gloo exercises the N-rank control flow on fewer GPUs)",
+                  file=sys.stderr)  # fmt: skip
+            return 2
+    envs = rank_environments(n, free_port())
+    cmd = [sys.executable, os.path.abspath(__file__)] + list(argv)
+    procs = []
+    for r, e in enumerate(envs):
+        # rank 0's stdout is the result line; the other ranks' stdout joins stderr
+        procs.append(subprocess.Popen(cmd, env=e, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    out0, _ = procs[0].communicate()
+    codes = [procs[0].returncode]
+    deadline = time.time() + 120
+    for p in procs[1:]:
+        try:
+            codes.append(p.wait(timeout=max(1.0, deadline - time.time())))
+        except subprocess.TimeoutExpired:
+            p.kill()  # the exact process started above
+            codes.append(p.wait())
+    sys.stdout.write(out0 or "")
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        print(f"[bench] rank exit codes (rank, code): {bad}", file=sys.stderr)
+        return 1
+    return 0
+
+
+# ------------------------------------------------------------------------------------------------
 
 
 def algorithmic_bytes(N, V, I, P, T, k, p):
@@ -81,43 +157,53 @@ STAGE_KERNEL = {
 }
 
 
-def pmc_traffic(stage, workload_key):
-    """HBM bytes per launch of `stage`'s kernel from the committed rocprofv3 PMC passes of this same
-    command (profiles/r01_pmc_traffic.json, produced by scripts/gpu_pmc.sh: separate FETCH_SIZE and
-    WRITE_SIZE passes, corrected as MI355X_MICROARCH.md prescribes).  PMC collection cannot run inside
-    the timed process, so this is a recorded figure; None when the file is absent or was recorded
-    for another workload."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+def _pmc_record(stage, workload_key):
+    """The committed rocprofv3 PMC passes of this same command (profiles/rNN_pmc_traffic.json,
+    produced by scripts/gpu_pmc.sh: separate FETCH_SIZE and WRITE_SIZE passes, corrected as
+    MI355X_MICROARCH.md prescribes).  PMC collection cannot run inside the timed process, so these
+    are recorded figures; None when absent or recorded for another workload."""
     kern = STAGE_KERNEL.get(stage)
-    if kern is None or not os.path.exists(path):
+    if kern is None:
         return None
-    rec = json.load(open(path))
-    if rec.get("workload_key") != workload_key:
-        return None
-    for name, v in rec["kernels"].items():
-        if name.startswith(kern):  # str.startswith takes the tuple of candidate kernel names
-            return v["hbm_bytes_per_launch"]
+    for fname in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", fname)
+        if not os.path.exists(path):
+            continue
+        rec = json.load(open(path))
+        if rec.get("workload_key") != workload_key:
+            continue
+        for name, v in rec["kernels"].items():
+            if name.startswith(kern):  # str.startswith takes the tuple of candidate kernel names
+                return dict(v, source=f"profiles/{fname}")
     return None
+
+
+def pmc_traffic(stage, workload_key):
+    rec = _pmc_record(stage, workload_key)
+    return None if rec is None else rec["hbm_bytes_per_launch"]
 
 
 def pmc_valu(stage, workload_key):
     """Vector wave-instructions per launch of `stage`'s kernel (SQ_INSTS_VALU of the same PMC file)."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    kern = STAGE_KERNEL.get(stage)
-    if kern is None or not os.path.exists(path):
-        return None
-    rec = json.load(open(path))
-    if rec.get("workload_key") != workload_key:
-        return None
-    for name, v in rec["kernels"].items():
-        if name.startswith(kern):
-            return v.get("valu_wave_instr_per_launch")
-    return None
+    rec = _pmc_record(stage, workload_key)
+    return None if rec is None else rec.get("valu_wave_instr_per_launch")
 
 
-def cpu_baseline(scene, view, crop, sh_degree):
+def _rel_l2(a, b):
+    return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
+
+
+def cpu_baseline(scene, view, crop, sh_degree, threads=0):
     """The CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is the absent
-    CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd."""
+    CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd.
+    Protocol of BASELINE.md section 2: 1 warm-up + 3 timed runs, median; the thread count is the
+    faster of 8 and all host threads in the warm-ups (the oracle is thousands of small tensor
+    ops: beyond a few threads they mostly add synchronisation cost), both warm-up times reported.
+    The same crop is rendered and differentiated by the HIP path: PSNR and the relative L2 error of
+    every gradient against the oracle's are part of the line."""
+    import torch
+
+    from freegaussian_amd import rasterization
     from oracle import raster_oracle as O
 
     cw, ch = (int(x) for x in crop.split("x"))
@@ -125,37 +211,61 @@ def cpu_baseline(scene, view, crop, sh_degree):
     x0, y0 = (scene.width - cw) // 2, (scene.height - ch) // 2
     K[0, 2] -= x0
     K[1, 2] -= y0
-    # the oracle is thousands of small tensor ops: beyond a few threads they only add
-    # synchronisation cost, so it is run on (and reported for) at most 8 threads
-    cores = min(os.cpu_count() or 1, 8)
+    host = os.cpu_count() or 1
+    vr = torch.randn(1, ch, cw, 3, generator=torch.Generator().manual_seed(1))
+    names = ("means", "quats", "scales", "opacities", "colors")
+
+    def run():
+        ins = [getattr(scene, n).clone().requires_grad_(True) for n in names]
+        t0 = time.perf_counter()
+        r, a, info = O.rasterization(*ins, scene.viewmats[view : view + 1], K[None], cw, ch, sh_degree=sh_degree,
+                                     render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+        info["means2d"].retain_grad()
+        (r * vr).sum().backward()
+        return time.perf_counter() - t0, r.detach(), ins, info
+
+    candidates = [threads] if threads > 0 else sorted({min(host, 8), host})
+    warm = {}
+    for c in candidates:
+        torch.set_num_threads(c)
+        warm[c] = run()[0]
+    cores = min(warm, key=warm.get)
     torch.set_num_threads(cores)
-    ins = [t.clone().requires_grad_(True) for t in (scene.means, scene.quats, scene.scales, scene.opacities, scene.colors)]
-    g = torch.Generator().manual_seed(1)
-    vr = torch.randn(1, ch, cw, 3, generator=g)
-    t0 = time.perf_counter()
-    r, a, info = O.rasterization(*ins, scene.viewmats[view : view + 1], K[None], cw, ch, sh_degree=sh_degree,
-                                 render_mode="RGB", packed=False)  # fmt: skip
-    (r * vr).sum().backward()
-    dt = time.perf_counter() - t0
-    # PSNR of the HIP render against the oracle render of the same crop
-    psnr_db = None
+    timed = []
+    for _ in range(3):
+        dt, r, ins, info = run()
+        timed.append(dt)
+    dt = sorted(timed)[1]
+    # the HIP path on the same crop: PSNR of the render, relative L2 of the gradients
+    parity = {}
     if torch.cuda.is_available():
         dev = torch.device("cuda", torch.cuda.current_device())
-        with torch.no_grad():
-            rg, _, _ = rasterization(*[t.detach().to(dev) for t in ins], scene.viewmats[view : view + 1].to(dev),
-                                     K[None].to(dev), cw, ch, sh_degree=sh_degree, render_mode="RGB", packed=False)  # fmt: skip
-        mse = float(((rg.cpu().double() - r.detach().double()) ** 2).mean())
-        psnr_db = 200.0 if mse == 0 else min(200.0, -10.0 * __import__("math").log10(mse))
+        gin = [getattr(scene, n).to(dev).requires_grad_(True) for n in names]
+        rg, _, ginfo = rasterization(*gin, scene.viewmats[view : view + 1].to(dev), K[None].to(dev), cw, ch,
+                                     sh_degree=sh_degree, render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+        ginfo["means2d"].retain_grad()
+        (rg * vr.to(dev)).sum().backward()
+        mse = float(((rg.detach().cpu().double() - r.double()) ** 2).mean())
+        import math
+
+        parity["psnr_hip_vs_oracle_db"] = 200.0 if mse == 0 else min(200.0, -10.0 * math.log10(mse))
+        rel = {n: _rel_l2(g.grad.cpu(), o.grad) for n, g, o in zip(names, gin, ins)}
+        rel["means2d"] = _rel_l2(ginfo["means2d"].grad.cpu(), info["means2d"].grad)
+        rel["absgrad"] = _rel_l2(ginfo["means2d"].absgrad.cpu(), info["means2d"].absgrad)
+        parity["grad_rel_l2_hip_vs_oracle"] = rel
+        parity["grad_rel_l2_hip_vs_oracle_max"] = max(rel.values())
     return {
         "value": cw * ch / dt / 1e6,
-        "psnr_hip_vs_oracle_db": psnr_db,
+        **parity,
         "unit": "Mpix/s",
         "cores": cores,
-        "host_cpus": os.cpu_count(),
+        "host_cpus": host,
         "kind": "port",
+        "runs_s": [round(x, 2) for x in timed],
+        "warmup_s_by_threads": {str(k): round(v, 2) for k, v in warm.items()},
         "sample": f"centre {cw}x{ch} crop of view {view} of the same scene (all {scene.means.shape[0]} Gaussians "
-        f"projected, {info['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 run, {dt:.1f} s; "
-        "pure-PyTorch CPU oracle (extrapolates by pixel count)",
+        f"projected, {info['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 warm-up per thread count + 3 timed "
+        f"runs, median {dt:.1f} s on {cores} of {host} host threads; pure-PyTorch CPU oracle (extrapolates by pixel count)",
     }
 
 
@@ -183,23 +293,29 @@ def gpu_clocks():
 
 def graph_only(args):
     """Child-process leg: the step replayed as one hipGraph; prints one JSON object."""
+    import torch
+
     from freegaussian_amd.graphed import GraphedRaster
+    from freegaussian_amd.scenes import synthetic_scene
+    from freegaussian_amd.viewdp import FlatGaussianParams
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
-    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=8, sh_degree=args.sh_degree, seed=42)
+    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)
-    vm, K = scene.viewmats[:1].to(dev), scene.Ks[:1].to(dev)
+    vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
     gr = GraphedRaster(params, W, H, sh_degree=args.sh_degree)
-    for _ in range(5):
-        gr.step(vm, K, vr)
+    for s in range(N_VIEWS + 2):  # every view once: the list capacity settles on the largest
+        v = 0 if args.fixed_view else s % N_VIEWS
+        gr.step(vms[v : v + 1], Ks[v : v + 1], vr)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     overflows = 0
-    for _ in range(args.steps):
-        overflows += int(gr.step(vm, K, vr)[2])
+    for s in range(args.steps):
+        v = 0 if args.fixed_view else s % N_VIEWS
+        overflows += int(gr.step(vms[v : v + 1], Ks[v : v + 1], vr)[2])
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print(json.dumps({"ms_per_step": dt / args.steps * 1e3, "value": args.steps * W * H / dt / 1e6, "unit": "Mpix/s",
@@ -207,48 +323,72 @@ def graph_only(args):
                       "note": "fwd+bwd replayed as one hipGraph; the overflow flag is read back every step"}))  # fmt: skip
 
 
-def main():
-    args = parse()
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    args = parse(argv)
     if args.graph_only:
         return graph_only(args)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args, argv))
+    if os.environ.get("FG_BENCH_ECHO"):
+        # launcher self-test (tests/test_bench_launch.py): report the rank environment, touch nothing else
+        print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+                         | {"n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "gpus_arg": args.gpus}), flush=True)  # fmt: skip
+        return
+
+    import datetime
+
+    import torch
+    import torch.distributed as dist
+
+    from freegaussian_amd import ops, rasterization
+    from freegaussian_amd.scenes import synthetic_scene
+    from freegaussian_amd.viewdp import FlatGaussianParams
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but WORLD_SIZE={world}: the launcher's world size is used", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the raster path has no CPU fallback")
     ndev = torch.cuda.device_count()
+    backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+    if world > 1 and backend == "nccl" and local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible; RCCL ranks never share a device")
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
     if world > 1:
         # RCCL ("nccl") over xGMI is the product path; FG_BENCH_BACKEND=gloo only exists so that the
-        # N>1 control flow can be exercised on a 1-GPU box (ranks then share the device)
-        backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
+        # N>1 control flow can be exercised on a 1-GPU box (ranks then share the device).  A bounded
+        # timeout turns a desynchronised collective into an error instead of a hung box.
+        tmo = datetime.timedelta(seconds=int(os.environ.get("FG_BENCH_TIMEOUT_S", "300")))
         if backend == "nccl":
-            if local_rank >= ndev:
-                raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPUs visible")
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, timeout=tmo)
 
-    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=8, sh_degree=args.sh_degree, seed=42)
-    view = rank % 8
+    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)  # flat parameter + flat gradient buffers
-    vm = scene.viewmats[view : view + 1].to(dev)
-    K = scene.Ks[view : view + 1].to(dev)
+    vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)  # all 8 poses resident
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
 
-    exchange = os.environ.get("FG_EXCHANGE", "factored")
+    exchange = os.environ.get("FG_EXCHANGE", "factored") if world > 1 else "none"
     marks = []  # per step: HIP events at start / after forward / after backward / after the exchange
+    counter = [0]
 
     def step(timed=False):
+        view = rank % N_VIEWS if args.fixed_view else (rank + counter[0]) % N_VIEWS
+        counter[0] += 1
+        vm, K = vms[view : view + 1], Ks[view : view + 1]
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if timed else None
         if ev:
             ev[0].record()
         # gradients land directly in the flat gradient buffer (dense overwrite: no zeroing needed);
         # N>1: factored exchange (all-gather of the colour gradient + 44 B/Gaussian all-reduce + local
         # SH rebuild, viewdp.factored_exchange) unless FG_EXCHANGE=plain (one 236 B/Gaussian all-reduce)
-        factored = world > 1 and exchange == "factored"
+        factored = exchange == "factored"
         with (params.factored_exchange() if factored else params.direct_grads()):
             means, quats, scales, opac, colors = params.raster_inputs()
             r, a, info = rasterization(means, quats, scales, opac, colors, vm, K, W, H, sh_degree=args.sh_degree,
@@ -258,41 +398,58 @@ def main():
             r.backward(vr)  # upstream dL/d render = fixed N(0,1) image
             if ev:
                 ev[2].record()
-        if world > 1 and not factored:
+        if exchange == "plain":
             params.all_reduce_grads()
         if ev:
             ev[3].record()
             marks.append(ev)
-        return info
+        return info, view
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    if world > 1 and exchange == "factored":
-        # insurance for a path no 1-GPU box can exercise over RCCL: a host-side failure of the factored
-        # exchange (deterministic, hence on every rank alike) falls back to the plain all-reduce
+    fallback_note = None
+    if exchange == "factored":
+        # The factored exchange has only ever run on gloo and on one GPU.  Every rank tries one step;
+        # the outcome is agreed on with a MIN all-reduce of a flag, so either all ranks keep it or
+        # all fall back to the plain all-reduce together (a host-side failure is deterministic and
+        # hits every rank before its first collective; a rank that dies inside a collective ends the
+        # job through the process-group timeout).
+        ok, err = 1, None
         try:
-            info = step()
-            fence()
+            step()
+            torch.cuda.synchronize()
         except Exception as e:  # noqa: BLE001
+            ok, err = 0, repr(e)[:200]
+        flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            fallback_note = f"factored exchange failed on at least one rank ({err}); all ranks use the plain all-reduce"
             if rank == 0:
-                print(f"[bench] factored exchange failed ({e!r}); falling back to FG_EXCHANGE=plain", file=sys.stderr)
+                print(f"[bench] {fallback_note}", file=sys.stderr)
             exchange = "plain"
-    for _ in range(args.warmup):
-        info = step()
+    # warm-up: at least one pass over the whole ring, so that the speculative list capacity has seen every view
+    for _ in range(max(args.warmup, 0)):
+        step()
     fence()
+    redo0 = ops.capacity_redos
     ops.stage_timer = ops.StageTimer()
     t0 = time.perf_counter()
+    views_seen = []
     for _ in range(args.steps):
-        info = step(timed=True)
+        info, view = step(timed=True)
+        views_seen.append(view)
     fence()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     stages = ops.stage_timer.summary()
     ops.stage_timer = None
-    t = torch.tensor([dt], device=dev, dtype=torch.float64)
+    redos = ops.capacity_redos - redo0
+    t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
+    per_rank = [t.clone() for _ in range(world)]
     if world > 1:
+        dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -306,25 +463,34 @@ def main():
     p = (nbits + 7) // 8  # passes the reference-style 64-bit-key sort would need (SURVEY.md §8d formula)
     tile_passes = (max(T - 1, 1).bit_length() + 7) // 8
     alg = algorithmic_bytes(N, V, I, P, T, k, p)
-    dom = max(stages, key=lambda s: stages[s])
+    wkey = f"{N}x{W}x{H}xsh{args.sh_degree}"
+    # the dominant KERNEL: exchange / host-composed stages are not kernels of the path
+    kernel_stages = {s: v for s, v in stages.items() if s in alg}
+    dom = max(kernel_stages, key=lambda s: kernel_stages[s])
     roof = {
+        # the contract prices this path against HBM (no dense contraction, no MFMA);
+        # `measured_limiter` says what the counters show actually bounds the kernel
         "bound": "hbm",
         "kernel": dom,
         "achieved": alg.get(dom, 0) / (stages[dom] * 1e-3) / 1e9,
         "peak": HBM_PEAK_GBS,
         "unit": "GB/s",
-        "traffic": pmc_traffic(dom, f"{N}x{W}x{H}xsh{args.sh_degree}"),
+        "traffic": pmc_traffic(dom, wkey),
         "algorithmic_bytes": alg.get(dom, 0),
         "avg_ms": stages[dom],
+        "launch_counts": "I, V of the last timed step's view; duration averaged over the views of the timed region",
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
+    if dom in ("fg_raster_bwd", "fg_raster_fwd"):
+        roof["measured_limiter"] = ("vector issue + dependent-issue latency (VALU), not HBM: measured traffic is below "
+                                    "the algorithmic bytes (L2 / Infinity Cache hits) -- see vector_issue_roofline")  # fmt: skip
     # Vector issue of the raster kernels (profiles/r01_valu_issue_rates.md): a SIMD issues one
     # full-rate wave64 fp32 instruction per 2 clocks (256 CUs x 4 SIMDs x 2.4 GHz / 2 = 1229 G/s) but
     # only with ~4 ready wavefronts of dependent code; half-rate instructions (compare, select,
     # min/max, DPP) cost 4 clocks, exp / rcp / permlane swaps 8.  `frac` is against the 2-clock peak.
     issue = {}
     for st_name in ("fg_raster_bwd", "fg_raster_fwd"):
-        vi = pmc_valu(st_name, f"{N}x{W}x{H}xsh{args.sh_degree}")
+        vi = pmc_valu(st_name, wkey)
         if vi is not None and st_name in stages:
             peak = 1024 * 2.4e9 / 2  # wave-instructions per second, full-rate instructions
             rate = vi / (stages[st_name] * 1e-3)
@@ -334,12 +500,14 @@ def main():
     # the HBM-bound stages next to it: measured traffic (same PMC file) over their HIP-event time
     hbm_stages = {}
     for st_name in ("fg_preprocess_fwd", "fg_preprocess_bwd", "fg_raster_fwd", "fg_raster_bwd"):
-        tr = pmc_traffic(st_name, f"{N}x{W}x{H}xsh{args.sh_degree}")
+        tr = pmc_traffic(st_name, wkey)
         if tr is not None and st_name in stages:
             gbs = tr / (stages[st_name] * 1e-3) / 1e9
-            hbm_stages[st_name] = {"traffic": tr, "avg_ms": stages[st_name], "achieved_GBs": gbs,
-                                   "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}  # fmt: skip
-    total_alg = 280 * N + (176 + 24 * k) * V + (100 + 24 * p) * I + 56 * P + 8 * T
+            hbm_stages[st_name] = {"traffic": tr, "algorithmic_bytes": alg[st_name], "avg_ms": stages[st_name],
+                                   "achieved_GBs": gbs, "frac_of_hbm_peak": gbs / HBM_PEAK_GBS}  # fmt: skip
+    survey_total = 280 * N + (176 + 24 * k) * V + (100 + 24 * p) * I + 56 * P + 8 * T
+    needed = survey_total - 24 * p * I  # the 64-bit-key sort of the formula is not what this path runs
+
     # BASELINE.md section 3 protocol: per-step HIP-event times, median with p10 / p90
     def pct(xs, q):
         xs = sorted(xs)
@@ -354,13 +522,7 @@ def main():
         "fwd_plus_bwd_ms": {"median": pct(t_fb, 0.5), "p10": pct(t_fb, 0.1), "p90": pct(t_fb, 0.9)},
         "mpix_per_s_per_gpu_from_median": P / (pct(t_fb, 0.5) * 1e-3) / 1e6,
     }  # fmt: skip
-    if world > 1:
-        event_times["exchange_ms_median_after_backward"] = pct(t_xchg, 0.5)
-        if exchange == "factored":
-            event_times["exchange"] = (f"factored: all-gather {12 * (N + 1)} B per rank (issued inside the backward), "
-                                       f"all-reduce {44 * N} B, local SH rebuild of {192 * N} B")  # fmt: skip
-        else:
-            event_times["exchange"] = f"plain: one all-reduce of {params.flat_grad.numel() * 4} B"
+    step_s = dt / args.steps
     out = {
         "metric": "Mpixels/s fwd+bwd @ 1M Gaussians 1080p",
         "value": world * args.steps * P / dt / 1e6,
@@ -368,32 +530,56 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step": step_s * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank "
-            f"per step (8-view ring), fwd+bwd, RGB, absgrad" + (f", RCCL gradient exchange ({exchange})" if world > 1 else ""),
+            "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank per step, "
+            + ("view = rank (fixed)" if args.fixed_view else f"view = (rank + step) mod {N_VIEWS} around the 8-view ring")
+            + ", fwd+bwd, RGB, absgrad" + (f", RCCL gradient exchange ({exchange})" if world > 1 else ""),
             "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
+            "counts_are_for_view": view,
             "binning": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I "
             f"(the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
+            "list_capacity_redos_in_timed_region": redos,
         },
         "roofline": roof,
         "vector_issue_roofline": issue,
         "measured_hbm_traffic_by_stage": hbm_stages,
         "hip_event_times": event_times,
         "whole_step": {
-            "algorithmic_bytes": total_alg,
-            "algorithmic_bytes_without_sort": total_alg - 24 * p * I,
-            "achieved_GBs": total_alg / (dt / args.steps) / 1e9,
-            "frac_of_hbm_peak": total_alg / (dt / args.steps) / 1e9 / HBM_PEAK_GBS,
+            # headline: the bytes THIS path needs (SURVEY §8d total without the 24 p I term of a
+            # 64-bit-key sort it does not run)
+            "algorithmic_bytes": needed,
+            "achieved_GBs": needed / step_s / 1e9,
+            "frac_of_hbm_peak": needed / step_s / 1e9 / HBM_PEAK_GBS,
+            "survey_formula_with_64bit_sort": {
+                "algorithmic_bytes": survey_total,
+                "achieved_GBs": survey_total / step_s / 1e9,
+                "frac_of_hbm_peak": survey_total / step_s / 1e9 / HBM_PEAK_GBS,
+                "note": f"includes 24*p*I = {24 * p * I} B of {p}-pass 64-bit-key sort traffic the depth-first binning avoids",
+            },
         },
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
     }  # fmt: skip
+    if world > 1:
+        xm = pct(t_xchg, 0.5)
+        out["exchange"] = {
+            "kind": exchange,
+            "backend": backend + (" (RCCL over xGMI)" if backend == "nccl" else " (host-staged; control-flow check only)"),
+            "exchange_ms": xm,
+            "exchange_ms_note": "median HIP-event time from the end of the backward to the end of the exchange on rank 0 "
+            "(the factored all-gather is issued inside the backward and is partly hidden there)",
+            "what": (f"factored: all-gather {12 * (N + 1)} B per rank (issued inside the backward), all-reduce {44 * N} B, "
+                     f"local SH rebuild of {192 * N} B") if exchange == "factored"
+            else f"plain: one all-reduce of {params.flat_grad.numel() * 4} B",
+            "fallback": fallback_note,
+        }  # fmt: skip
+        out["per_rank_mpix_per_s"] = [args.steps * P / float(x.item()) / 1e6 for x in per_rank]
     if rank == 0:
         out["clocks_after_timed_region"] = gpu_clocks()
     if world == 1 and not args.no_graph and rank == 0 and not under_profiler():
@@ -404,7 +590,7 @@ def main():
 
         cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--n-gauss",
                str(args.n_gauss), "--width", str(args.width), "--height", str(args.height), "--sh-degree",
-               str(args.sh_degree)]  # fmt: skip
+               str(args.sh_degree)] + (["--fixed-view"] if args.fixed_view else [])  # fmt: skip
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
             out["graphed"] = json.loads(res.stdout.strip().splitlines()[-1])
@@ -412,7 +598,7 @@ def main():
             out["graphed"] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree)
+            out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

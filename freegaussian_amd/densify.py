@@ -2,16 +2,13 @@
 cull steps and the Adam-state surgery (freegaussian/freegaussian_model.py:313-367, :404-571),
 SURVEY.md section 8f row 2.
 
-Two implementations with identical results:
+One implementation, HIP only (CPU tensors raise -- the torch restatement of the reference's op
+sequence is test infrastructure: ``tests/densify_torch_sequence.py``, ``oracle/densify_oracle.py``):
+``fg_densify_flags`` -> prefix sums -> ``fg_densify_map`` -> one ``fg_gather_rows`` per tensor
+(6 parameters + 12 Adam moment tensors) straight into the final arrays -> ``fg_split_children``.
+Every tensor is read once and written once; nothing is concatenated and re-masked.
 
-* ``fused=True`` (default on a GPU): ``fg_densify_flags`` -> prefix sums -> ``fg_densify_map`` ->
-  one ``fg_gather_rows`` per tensor (6 parameters + 12 Adam moment tensors) straight into the
-  final arrays -> ``fg_split_children``.  Every tensor is read once and written once; nothing is
-  concatenated and re-masked.
-* ``fused=False``: the reference's op sequence in torch (``cat`` everything, then boolean-mask
-  everything), kept for CPU tensors and as the in-product comparison.
-
-Both draw the split samples with ``torch.randn((n_split_samples * n_splits, 3))`` exactly where
+The split samples are drawn with ``torch.randn((n_split_samples * n_splits, 3))`` exactly where
 the reference does (:530), so replicas that share a seed (``viewdp.shared_seed``) stay identical."""
 from __future__ import annotations
 
@@ -21,7 +18,6 @@ import torch
 from torch import nn
 
 from . import _lib
-from .rasterization import quat_to_rotmat
 
 PARAM_NAMES = ("means", "scales", "quats", "features_dc", "features_rest", "opacities")
 
@@ -65,78 +61,6 @@ def _reset_opacities(model, optimizers) -> None:
         if "exp_avg" in state:
             state["exp_avg"] = torch.zeros_like(state["exp_avg"])
             state["exp_avg_sq"] = torch.zeros_like(state["exp_avg_sq"])
-
-
-# ------------------------------------------------------------------------------------------------
-# the reference's op sequence
-
-
-def _refine_torch(model, optimizers, step: int, do_densify: bool, samples: Optional[torch.Tensor]):
-    cfg = model.config
-    gp = model.gauss_params
-    dev = gp["means"].device
-    n0 = gp["means"].shape[0]
-    extra_cull = None
-    if do_densify:
-        avg = (model.xys_grad_norm / model.vis_counts) * 0.5 * max(model.last_size[0], model.last_size[1])
-        high = (avg > cfg.densify_grad_thresh).squeeze()
-        splits = (gp["scales"].exp().max(dim=-1).values > cfg.densify_size_thresh).squeeze() & high
-        if step < cfg.stop_screen_size_at:
-            splits = splits | (model.max_2Dsize > cfg.split_screen_size).squeeze()
-        nsamps = cfg.n_split_samples
-        n_splits = int(splits.sum().item())
-        # split_gaussians (:524-563)
-        z = torch.randn((nsamps * n_splits, 3), device=dev) if samples is None else samples.to(dev)
-        scaled = torch.exp(gp["scales"][splits].repeat(nsamps, 1)) * z
-        q = gp["quats"][splits] / gp["quats"][splits].norm(dim=-1, keepdim=True)
-        rots = quat_to_rotmat(q.repeat(nsamps, 1))
-        new_means = torch.bmm(rots, scaled[..., None]).squeeze(-1) + gp["means"][splits].repeat(nsamps, 1)
-        shrunk = torch.log(torch.exp(gp["scales"][splits]) / 1.6)
-        split_params = {
-            "means": new_means,
-            "features_dc": gp["features_dc"][splits].repeat(nsamps, 1),
-            "features_rest": gp["features_rest"][splits].repeat(nsamps, 1, 1),
-            "opacities": gp["opacities"][splits].repeat(nsamps, 1),
-            "scales": shrunk.repeat(nsamps, 1),
-            "quats": gp["quats"][splits].repeat(nsamps, 1),
-        }
-        gp["scales"].data[splits] = shrunk  # in place, BEFORE `dups` is evaluated (:549, :430)
-        dups = (gp["scales"].exp().max(dim=-1).values <= cfg.densify_size_thresh).squeeze() & high
-        dup_params = {k: gp[k][dups] for k in PARAM_NAMES}
-        for k in PARAM_NAMES:
-            gp[k] = nn.Parameter(torch.cat([gp[k].detach(), split_params[k], dup_params[k]], dim=0))
-        n_new = nsamps * n_splits + int(dups.sum().item())
-        model.max_2Dsize = torch.cat([model.max_2Dsize, torch.zeros(n_new, device=dev)], dim=0)
-        for k in PARAM_NAMES:  # dup_in_all_optim twice (:452-456)
-            opt = optimizers.get(k)
-            if opt is None:
-                continue
-            _, state = _adam_state(opt)
-            if "exp_avg" in state:
-                for m in ("exp_avg", "exp_avg_sq"):
-                    state[m] = torch.cat([state[m], torch.zeros((n_new,) + state[m].shape[1:], device=dev)], dim=0)
-            _swap_param(opt, gp[k], state)
-        extra_cull = torch.cat([splits, torch.zeros(n_new, device=dev, dtype=torch.bool)])
-    # cull_gaussians (:493-522)
-    culls = (torch.sigmoid(gp["opacities"]) < cfg.cull_alpha_thresh).squeeze(-1)
-    if extra_cull is not None:
-        culls = culls | extra_cull
-    if step > cfg.refine_every * cfg.reset_alpha_every:
-        toobigs = (torch.exp(gp["scales"]).max(dim=-1).values > cfg.cull_scale_thresh).squeeze()
-        if step < cfg.stop_screen_size_at and model.max_2Dsize is not None:
-            toobigs = toobigs | (model.max_2Dsize > cfg.cull_screen_size).squeeze()
-        culls = culls | toobigs
-    for k in PARAM_NAMES:
-        gp[k] = nn.Parameter(gp[k][~culls])
-        opt = optimizers.get(k)
-        if opt is None:
-            continue
-        _, state = _adam_state(opt)
-        if "exp_avg" in state:
-            state["exp_avg"] = state["exp_avg"][~culls]
-            state["exp_avg_sq"] = state["exp_avg_sq"][~culls]
-        _swap_param(opt, gp[k], state)
-    return n0, int(gp["means"].shape[0])
 
 
 # ------------------------------------------------------------------------------------------------
@@ -189,7 +113,9 @@ def _refine_fused(model, optimizers, step: int, do_densify: bool, samples: Optio
         dst = torch.empty((n_out,) + tuple(src.shape[1:]), dtype=src.dtype, device=dev)
         call("fg_gather_rows", n_out, D, ptr(src), ptr(src_index), n_out, ptr(dst), stream)
         new[k] = dst
-    if n_out > n_old:
+    # rows of split parents' children are moved and shrunk; with no split at all (duplicates only)
+    # every new row is a plain copy and there is no sample buffer to hand over
+    if n_out > n_old and n_split > 0:
         call("fg_split_children", n_old, n_out - n_old, ptr(sample_index), ptr(z), ptr(new["means"]),
              ptr(new["scales"]), ptr(new["quats"]), stream)  # fmt: skip
     for k in PARAM_NAMES:
@@ -213,24 +139,28 @@ def _refine_fused(model, optimizers, step: int, do_densify: bool, samples: Optio
 
 
 def refinement_after(model, optimizers: Dict[str, torch.optim.Optimizer], step: int, num_train_data: int,
-                     fused: Optional[bool] = None, samples: Optional[torch.Tensor] = None) -> Optional[Dict[str, int]]:  # fmt: skip
+                     samples: Optional[torch.Tensor] = None, refine=None) -> Optional[Dict[str, int]]:  # fmt: skip
     """Mirror of FreeGaussianModel.refinement_after (:404-491).  ``optimizers`` maps the parameter
     group names (``means``, ``scales``, ...) to their single-parameter Adam optimizers, as
-    nerfstudio's ``Optimizers.optimizers`` does.  ``samples`` overrides the randn draw (tests).
-    Returns counts, or None when nothing ran (before ``refine_start``)."""
+    nerfstudio's ``Optimizers.optimizers`` does.  ``samples`` overrides the randn draw (tests);
+    ``refine`` replaces the HIP passes by another implementation of the split / duplicate / cull
+    step with the same signature (tests and scripts/densify_bench.py time the reference's torch op
+    sequence that way).  Returns counts, or None when nothing ran (before ``refine_start``)."""
     assert step == model.step
     cfg = model.config
     if step < cfg.refine_start:
         return None
-    if fused is None:
-        fused = model.gauss_params["means"].is_cuda
+    if refine is None:
+        if not model.gauss_params["means"].is_cuda:
+            raise _lib.FgRasterError("refinement_after needs CUDA/HIP tensors: the densification passes have no CPU fallback")
+        refine = _refine_fused
     with torch.no_grad():
         do_densify, do_cull_only, do_reset = _schedule(model, step, num_train_data)
         before = after = model.num_points
         if do_densify:
             assert model.xys_grad_norm is not None and model.vis_counts is not None and model.max_2Dsize is not None
         if do_densify or do_cull_only:
-            before, after = (_refine_fused if fused else _refine_torch)(model, optimizers, step, do_densify, samples)
+            before, after = refine(model, optimizers, step, do_densify, samples)
         if do_reset:
             _reset_opacities(model, optimizers)
         model.xys_grad_norm = None

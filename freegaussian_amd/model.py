@@ -6,7 +6,7 @@ inputs of ``rasterization(...)`` and post-process its outputs -- and S1 (``after
 :369-392).  ``FreeGaussianControlModel.get_outputs`` mirrors the stage-2 variant
 (``freegaussian_control_model.py:52-209``).  nerfstudio is not a dependency: ``Camera`` is a
 minimal stand-in for the fields of ``nerfstudio.cameras.Cameras`` the reference touches, and
-``nerfstudio_adapter.py`` registers the method only if nerfstudio imports.
+``nerfstudio_adapter.py`` registers the methods only if nerfstudio imports.
 
 Everything here is plain torch (small elementwise ops and the MLP GEMMs); the raster itself is
 the HIP library behind ``freegaussian_amd.rasterization``."""
@@ -43,15 +43,36 @@ class Camera:
         return (self.camera_to_worlds.shape[0],)
 
     def rescale_output_resolution(self, s: float) -> None:
-        """In place, like nerfstudio's Cameras.rescale_output_resolution: intrinsics scale
-        linearly, the image size rounds half up.  (nerfstudio's source is not readable here:
-        SURVEY.md citation discipline -- this is the documented behaviour, re-stated.)"""
+        """In place, like nerfstudio's Cameras.rescale_output_resolution with its default
+        ``scale_rounding_mode="floor"``: intrinsics scale linearly, the image size is floored --
+        the same ``H // d`` the ground truth gets from ``resize_image`` (utils.py:248-261), so
+        render and target agree in shape at every size (1014 rows at d = 4 -> 253, not 254).
+        (nerfstudio's source is not readable here: SURVEY.md citation discipline -- the default is
+        recalled; the shape agreement with ``get_gt_img`` is what the tests pin.)"""
         self.fx, self.fy, self.cx, self.cy = self.fx * s, self.fy * s, self.cx * s, self.cy * s
-        self.width = int(self.width * s + 0.5)
-        self.height = int(self.height * s + 0.5)
+        # s is 1 / 2^k or 2^k: the product is exact in floating point, floor is safe
+        self.width = int(self.width * s)
+        self.height = int(self.height * s)
 
     def get_intrinsics_matrices(self) -> torch.Tensor:
         return torch.tensor([[[self.fx, 0.0, self.cx], [0.0, self.fy, self.cy], [0.0, 0.0, 1.0]]])
+
+
+@dataclass
+class OrientedBox:
+    """Stand-in for ``nerfstudio.data.scene_box.OrientedBox`` as ``set_crop`` / ``get_outputs`` use
+    it (:397-398, :779-783): any object with ``within(points[N,3]) -> bool[N] or [N,1]`` works.
+    R [3,3] rotation, T [3] centre, S [3] full side lengths (recalled layout; nerfstudio's source is
+    not readable here)."""
+
+    R: torch.Tensor
+    T: torch.Tensor
+    S: torch.Tensor
+
+    def within(self, pts: torch.Tensor) -> torch.Tensor:
+        R, T, S = (x.to(pts) for x in (self.R, self.T, self.S))
+        local = (pts - T) @ R  # = R^T (p - T) per row
+        return ((local > -S / 2) & (local < S / 2)).all(dim=-1, keepdim=True)
 
 
 @dataclass
@@ -122,14 +143,40 @@ class FreeGaussianModel(nn.Module):
         self.vis_counts: Optional[torch.Tensor] = None
         self.max_2Dsize: Optional[torch.Tensor] = None
         self.last_size = (1, 1)
+        self.crop_box = None  # (:220) set through set_crop by the viewer / render scripts
+        self._active_crop: Optional[torch.Tensor] = None
+
+    def set_crop(self, crop_box) -> None:
+        """(:397-398)"""
+        self.crop_box = crop_box
+
+    @staticmethod
+    def get_empty_outputs(width: int, height: int, background: torch.Tensor):
+        """(:641-646) what an eval render returns when the crop box holds no Gaussian."""
+        rgb = background.repeat(height, width, 1)
+        depth = background.new_ones(*rgb.shape[:2], 1) * 10
+        accumulation = background.new_zeros(*rgb.shape[:2], 1)
+        return {"rgb": rgb, "depth": depth, "accumulation": accumulation, "background": background}
+
+    def _crop_ids(self):
+        """Eval-only crop (:778-785): None = all Gaussians; an all-False mask = empty output."""
+        if self.crop_box is None or self.training:
+            return None
+        return self.crop_box.within(self.gauss_params["means"]).reshape(-1)
 
     # -- accessors with the reference's names -------------------------------------------------
-    means = property(lambda self: self.gauss_params["means"])
-    scales = property(lambda self: self.gauss_params["scales"])
-    quats = property(lambda self: self.gauss_params["quats"])
-    features_dc = property(lambda self: self.gauss_params["features_dc"])
-    features_rest = property(lambda self: self.gauss_params["features_rest"])
-    opacities = property(lambda self: self.gauss_params["opacities"])
+    def _p(self, name: str) -> torch.Tensor:
+        """A Gaussian parameter; inside a cropped eval render, its rows within the crop box (the
+        reference's ``*_crop`` tensors, :786-798)."""
+        t = self.gauss_params[name]
+        return t if self._active_crop is None else t[self._active_crop]
+
+    means = property(lambda self: self._p("means"))
+    scales = property(lambda self: self._p("scales"))
+    quats = property(lambda self: self._p("quats"))
+    features_dc = property(lambda self: self._p("features_dc"))
+    features_rest = property(lambda self: self._p("features_rest"))
+    opacities = property(lambda self: self._p("opacities"))
     num_points = property(lambda self: self.gauss_params["means"].shape[0])
     device = property(lambda self: self.gauss_params["means"].device)
 
@@ -178,8 +225,14 @@ class FreeGaussianModel(nn.Module):
     # -- the pieces of get_outputs shared by stage 1 and stage 2 ------------------------------------
     def _camera_setup(self, camera: Camera):
         """viewmat, K, W, H at the scheduled resolution (:806-815)."""
+        cam0 = camera.metadata.get("cameras0")
+        if cam0 is not None and cam0 is not camera:  # (:802-804)
+            assert bool((cam0.get_intrinsics_matrices() == camera.get_intrinsics_matrices()).all()), \
+                "Intrinsics matrices should be the same"
         s = self._get_downscale_factor()
         camera.rescale_output_resolution(1 / s)
+        if cam0 is not None and cam0 is not camera:  # (:808, :814) rescaled and restored alongside
+            cam0.rescale_output_resolution(1 / s)
         c2w = camera.camera_to_worlds
         if c2w.is_cuda or self.device.type != "cuda":
             viewmat = get_viewmat(c2w.to(self.device))
@@ -196,6 +249,8 @@ class FreeGaussianModel(nn.Module):
         W, H = int(camera.width), int(camera.height)
         self.last_size = (H, W)
         camera.rescale_output_resolution(s)
+        if cam0 is not None and cam0 is not camera:
+            cam0.rescale_output_resolution(s)
         return viewmat, K, W, H
 
     def _colors_and_degree(self):
@@ -296,14 +351,25 @@ class FreeGaussianModel(nn.Module):
             camera.metadata["cameras0"] = camera
         if self.training:
             assert camera.shape[0] == 1, "Only one camera at a time"
+        crop = self._crop_ids()
+        if crop is not None and int(crop.sum()) == 0:  # (:781-782)
+            return self.get_empty_outputs(int(camera.width), int(camera.height), self.background_color.to(self.device))
+        self._active_crop = crop
+        try:
+            return self._get_outputs_on_active_rows(camera)
+        finally:
+            self._active_crop = None
+
+    def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)
         if self.step < self.config.warm_up:
             means = self.means
             d_rotation, d_scaling = 0.0, 0.0
         else:
-            times = camera.times.to(self.device).expand(self.num_points, -1)
-            d_xyz, d_rotation, d_scaling = self.deform(self.means.detach(), times)
-            means = from_homogenous(torch.bmm(d_xyz, to_homogenous(self.means).unsqueeze(-1)).squeeze(-1))
+            pts = self.means
+            times = camera.times.to(self.device).expand(pts.shape[0], -1)
+            d_xyz, d_rotation, d_scaling = self.deform(pts.detach(), times)
+            means = from_homogenous(torch.bmm(d_xyz, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
         return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
 
     @torch.no_grad()
@@ -359,10 +425,22 @@ class FreeGaussianControlModel(FreeGaussianModel):
         if not isinstance(camera, Camera):
             print("Called get_outputs with not a camera")
             return {}
+        crop = self._crop_ids()  # (freegaussian_control_model.py:73-86: the mask is cropped alongside)
+        if crop is not None and int(crop.sum()) == 0:
+            return self.get_empty_outputs(int(camera.width), int(camera.height), self.background_color.to(self.device))
+        self._active_crop = crop
+        try:
+            return self._get_outputs_on_active_rows(camera)
+        finally:
+            self._active_crop = None
+
+    def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)
-        sel = self.gaussian_mask.any(-1)
-        pts = self.means[sel]
-        pmask = self.gaussian_mask[sel]  # [n,M]
+        gmask = self.gaussian_mask if self._active_crop is None else self.gaussian_mask[self._active_crop]
+        all_means, all_scales, all_quats = self.means, self.scales, self.quats
+        sel = gmask.any(-1)
+        pts = all_means[sel]
+        pmask = gmask[sel]  # [n,M]
         if not self.training and "cameras0" not in camera.metadata and self.control_values is not None:
             d_avg = self.control_values.to(self.device)
         else:
@@ -376,9 +454,9 @@ class FreeGaussianControlModel(FreeGaussianModel):
         value = pmask.float() @ d_avg / pmask.sum(-1, keepdim=True)  # (:140)
         d_xyz, d_rot, d_scale = self.control(pts, value)
         idx = (sel.nonzero().squeeze(-1),)
-        means = self.means + torch.zeros_like(self.means).index_put(idx, d_xyz)
-        d_scaling = torch.zeros_like(self.scales).index_put(idx, d_scale)
-        d_rotation = torch.zeros_like(self.quats).index_put(idx, d_rot)
+        means = all_means + torch.zeros_like(all_means).index_put(idx, d_xyz)
+        d_scaling = torch.zeros_like(all_scales).index_put(idx, d_scale)
+        d_rotation = torch.zeros_like(all_quats).index_put(idx, d_rot)
         return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
 
     def get_param_groups(self):

@@ -210,6 +210,7 @@ speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
 static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
 last_overflow: Optional[torch.Tensor] = None
 _isect_capacity: dict = {}
+capacity_redos = 0  # times a speculative list turned out too small and emission + sort were repeated
 
 
 def _count_buffer(dev) -> torch.Tensor:
@@ -300,9 +301,16 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
             raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
         if key not in _isect_capacity and len(_isect_capacity) >= 256:
             _isect_capacity.pop(next(iter(_isect_capacity)))  # densification changes N: do not grow for ever
-        _isect_capacity[key] = min(int(n_isects * 1.25) + 4096, 2**31 - 1)
+        # 25% headroom over this view; decays slowly (3% per call) from the largest view seen, so a
+        # camera that moves between light and heavy views does not overflow on every return
+        want = int(n_isects * 1.25) + 4096
+        if capacity is not None:
+            want = max(want, int(capacity * 0.97))
+        _isect_capacity[key] = min(want, 2**31 - 1)
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
+        if capacity is not None:
+            globals()["capacity_redos"] += 1
         tk = torch.empty(n_isects, dtype=torch.int32, device=dev) if want_keys else None
         ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         ws3 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)

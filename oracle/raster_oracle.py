@@ -443,6 +443,25 @@ def rasterize_backward(
     return v_xy, v_xy_abs, v_conic, v_col, v_op
 
 
+class _AbsgradTap(torch.autograd.Function):
+    """Identity on (render, alpha) whose backward sees both upstream gradients together and
+    evaluates the analytic K6 restatement once more to define ``means2d.absgrad`` (the gradients
+    themselves keep flowing through autograd untouched)."""
+
+    @staticmethod
+    def forward(ctx, render, alpha, state):
+        ctx.state = state
+        return render.view_as(render), alpha.view_as(alpha)
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha):
+        st = ctx.state
+        with torch.no_grad():
+            _, v_abs, _, _, _ = rasterize_backward(*st["args"], v_render, v_alpha[..., 0])
+        st["holder"].absgrad = v_abs[None]
+        return v_render, v_alpha, None
+
+
 @dataclass
 class RasterResult:
     render: torch.Tensor  # [1,H,W,C]
@@ -509,20 +528,28 @@ def rasterization(
 
     tile_w = (width + tile_size - 1) // tile_size
     tile_h = (height + tile_size - 1) // tile_size
+    # the [1,N,2] tensor handed out in `info` is the one the compositing consumes, so that
+    # `info["means2d"].retain_grad()` sees the screen-space gradient (freegaussian_model.py:869-870)
+    means2d_out = proj.means2d[None]
+    m2 = means2d_out[0]
     tiles_per_gauss, isect_ids, flatten_ids = isect_tiles(
         proj.means2d, proj.radii, proj.depths, tile_size, tile_w, tile_h
     )
     offsets = isect_offsets(isect_ids, tile_w * tile_h)
     render, alpha, last_ids = rasterize(
-        proj.means2d, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids
+        m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids
     )
+    if absgrad and torch.is_grad_enabled() and render.requires_grad:
+        args = tuple(t.detach() for t in (proj.means2d, proj.conics, feats, opac)) + (
+            width, height, tile_size, offsets, flatten_ids)  # fmt: skip
+        render, alpha = _AbsgradTap.apply(render, alpha, {"args": args, "holder": means2d_out})
     if render_mode in ("ED", "RGB+ED"):
         di = 3 if render_mode == "RGB+ED" else 0
         d = render[..., di : di + 1] / alpha.clamp(min=1e-10)
         render = torch.cat([render[..., :di], d, render[..., di + 1 :]], -1)
     info = {
         "radii": proj.radii[None],
-        "means2d": proj.means2d[None],
+        "means2d": means2d_out,
         "depths": proj.depths[None],
         "conics": proj.conics[None],
         "opacities": opac[None],

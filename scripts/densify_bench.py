@@ -9,6 +9,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 from test_densify import _setup  # noqa: E402
+from densify_torch_sequence import refine_torch  # noqa: E402
 from freegaussian_amd.densify import refinement_after  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
@@ -18,7 +19,7 @@ for fused in (True, False, True, False):
     torch.cuda.reset_peak_memory_stats()
     base = torch.cuda.memory_allocated()
     t0 = time.perf_counter()
-    out = refinement_after(model, opts, 3500, 60, fused=fused)
+    out = refinement_after(model, opts, 3500, 60, refine=None if fused else refine_torch)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) * 1e3
     print(f"fused={fused}: {dt:.2f} ms, {out['before']} -> {out['after']} Gaussians, "

@@ -1,9 +1,15 @@
-"""Adaptive density control: the product's two implementations
-(reference op sequence in torch; HIP passes) against the CPU restatement in oracle/."""
+"""Adaptive density control: the product's HIP passes, and the torch
+restatement of the reference's op sequence (tests/densify_torch_sequence.py), against the CPU
+restatement in oracle/ (itself pinned to the reference's own methods: tests/golden/g_densify.npz)."""
 import copy
+import os
+import sys
 
 import pytest
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from densify_torch_sequence import refine_torch  # noqa: E402
 
 from freegaussian_amd.densify import PARAM_NAMES, refinement_after
 from freegaussian_amd.model import FreeGaussianModel, FreeGaussianModelConfig
@@ -93,7 +99,7 @@ def test_reference_op_sequence_matches_oracle_on_cpu(step, cfg_kw):
     params, moments, stats = _oracle_inputs(model, opts)
     z = torch.randn(model.config.n_split_samples * _n_splits(model, step), 3, generator=torch.Generator().manual_seed(5))
     ref_p, ref_m, info = DO.refinement_after(params, moments, stats, model.config, step, 60, samples=z)
-    out = refinement_after(model, opts, step, 60, fused=False, samples=z)
+    out = refinement_after(model, opts, step, 60, samples=z, refine=refine_torch)
     if step < model.config.refine_start:
         assert out is None
     else:
@@ -122,7 +128,7 @@ def test_split_then_duplicate_quirk_is_reproduced():
     assert info["n_splits"] == 1 and info["n_dups"] == 1 and ref_p["means"].shape[0] == 63 + 2 + 1
     assert torch.allclose(ref_p["scales"][-1].exp(), torch.full((3,), 0.013 / 1.6))  # the duplicate is shrunk
     assert torch.equal(ref_p["means"][-1], params["means"][7])  # ... and not moved
-    refinement_after(model, opts, 3500, 60, fused=False, samples=z)
+    refinement_after(model, opts, 3500, 60, samples=z, refine=refine_torch)
     _check(model, opts, ref_p, ref_m, exact=True)
 
 
@@ -136,21 +142,66 @@ def test_hip_densify_matches_oracle(step, cfg_kw):
     params, moments, stats = _oracle_inputs(model, opts)
     z = torch.randn(model.config.n_split_samples * _n_splits(model, step), 3, generator=torch.Generator().manual_seed(5))
     ref_p, ref_m, info = DO.refinement_after(params, moments, stats, model.config, step, 60, samples=z)
-    out = refinement_after(model, opts, step, 60, fused=True, samples=z)
+    out = refinement_after(model, opts, step, 60, samples=z)
     assert out["after"] == ref_p["means"].shape[0] and out["densified"] == info["densified"]
     # expf / logf / the 3x3 product differ from torch's CPU kernels in the last bit: the rows a
     # threshold decides are compared exactly through the shapes, the values within 2e-6
     _check(model, opts, ref_p, ref_m, exact=False)
-    # and the product's own torch path on the GPU gives the same set
+    # and the torch op sequence on the GPU gives the same set
     plain_opts = {k: torch.optim.Adam([plain.gauss_params[k]], lr=1e-3) for k in PARAM_NAMES}
     for k, o in plain_opts.items():
         st = opts_state = moments[k]
         o.state[o.param_groups[0]["params"][0]] = {"step": torch.tensor(1.0), "exp_avg": st["exp_avg"].cuda(),
                                                     "exp_avg_sq": st["exp_avg_sq"].cuda()}  # fmt: skip
-    refinement_after(plain, plain_opts, step, 60, fused=False, samples=z)
+    refinement_after(plain, plain_opts, step, 60, samples=z, refine=refine_torch)
     for k in PARAM_NAMES:
         assert plain.gauss_params[k].shape == model.gauss_params[k].shape
         assert torch.allclose(plain.gauss_params[k], model.gauss_params[k], rtol=1e-5, atol=1e-6), k
+
+
+def _dup_only_setup(device):
+    """Every Gaussian small (no size split), past stop_screen_size_at (no screen-size split), some
+    with a high gradient: duplicates only -- n_split == 0, n_dup > 0 (the HIP path then
+    has no sample buffer to hand to fg_split_children)."""
+    model, opts = _setup(n=4000, step=4500, device=device)
+    with torch.no_grad():
+        model.gauss_params["scales"].fill_(-7.0)  # exp(-7) = 9e-4 < densify_size_thresh
+        model.gauss_params["opacities"].fill_(2.0)
+    model.xys_grad_norm = (torch.arange(4000) % 7 == 0).float().to(device)
+    model.vis_counts = torch.ones(4000, device=device)
+    model.max_2Dsize = torch.zeros(4000, device=device)
+    return model, opts
+
+
+def test_duplicates_only_refinement_oracle_and_torch_sequence():
+    model, opts = _dup_only_setup("cpu")
+    assert _n_splits(model, 4500) == 0
+    params, moments, stats = _oracle_inputs(model, opts)
+    z = torch.zeros(0, 3)
+    ref_p, ref_m, info = DO.refinement_after(params, moments, stats, model.config, 4500, 60, samples=z)
+    assert info["n_splits"] == 0 and info["n_dups"] == 572 and ref_p["means"].shape[0] == 4572
+    refinement_after(model, opts, 4500, 60, samples=z, refine=refine_torch)
+    _check(model, opts, ref_p, ref_m, exact=True)
+
+
+@pytest.mark.gpu
+def test_hip_duplicates_only_refinement():
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no GPU is visible (no CPU fallback exists)")
+    model, opts = _dup_only_setup("cuda")
+    params, moments, stats = _oracle_inputs(model, opts)
+    ref_p, ref_m, info = DO.refinement_after(params, moments, stats, model.config, 4500, 60, samples=torch.zeros(0, 3))
+    out = refinement_after(model, opts, 4500, 60)  # draws its own (empty) sample tensor, as training does
+    assert out["after"] == 4572 and info["n_splits"] == 0
+    _check(model, opts, ref_p, ref_m, exact=False)
+
+
+def test_product_refuses_cpu_tensors():
+    from freegaussian_amd._lib import FgRasterError
+
+    model, opts = _setup(n=100, step=3500)
+    with pytest.raises(FgRasterError):
+        refinement_after(model, opts, 3500, 60)
 
 
 @pytest.mark.gpu
@@ -169,7 +220,7 @@ def test_training_with_densification_through_the_harness():
     from freegaussian_amd import harness as Hn
 
     runs = []
-    for fused in (True, False):
+    for refine in (None, refine_torch):
         torch.manual_seed(123)
         model, _, cam = _model_and_camera(n=3000, W=128, H=96, step=20, training=True)
         c = model.config
@@ -185,7 +236,7 @@ def test_training_with_densification_through_the_harness():
             gt = target.get_outputs(copy.deepcopy(cam))["rgb"].clamp(0, 1)
         opts = Hn.build_optimizers(model)
         orig = D.refinement_after
-        D.refinement_after = lambda m, o, s, n, fused=fused: orig(m, o, s, n, fused=fused)
+        D.refinement_after = lambda m, o, s, n, refine=refine: orig(m, o, s, n, refine=refine)
         try:
             torch.manual_seed(7)
             hist = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 20 + i, num_train_data=2) for i in range(45)]

@@ -125,6 +125,50 @@ def test_model_schedules_and_camera_rescale():
         m._get_background_color()
 
 
+@pytest.mark.parametrize("W,H", [(1352, 1014), (1920, 1080), (1015, 677), (128, 128)])
+def test_rescaled_camera_size_equals_ground_truth_size(W, H):
+    """The render size at the scheduled resolution must be the size get_gt_img gives the target
+    (resize_image: H // d, reference utils.py:248-261) also when H % d >= d / 2 (ADVICE r1)."""
+    m = FreeGaussianModel(FreeGaussianModelConfig(), num_points=4)
+    m.train()
+    img = torch.rand(H, W, 3)
+    for m.step in (0, 3000, 6000):
+        d = m._get_downscale_factor()
+        cam = Camera(torch.eye(4)[None, :3], 800.0, 800.0, W / 2, H / 2, W, H)
+        cam.rescale_output_resolution(1 / d)
+        gt = m.get_gt_img(img)
+        assert (cam.height, cam.width) == tuple(gt.shape[:2]) == (H // d, W // d)
+        cam.rescale_output_resolution(d)
+        if W % d == 0 and H % d == 0:
+            assert (cam.width, cam.height) == (W, H)
+
+
+def test_crop_box_selection_and_empty_outputs():
+    """Eval-only crop (reference :778-798) and get_empty_outputs (:641-646); the raster call
+    itself needs a GPU (tests/test_gpu_parity.py::test_crop_box_render)."""
+    from freegaussian_amd.model import OrientedBox
+
+    m = FreeGaussianModel(FreeGaussianModelConfig(), seed_points=torch.tensor([[0.0, 0, 0], [0.4, 0, 0], [3.0, 0, 0]]))
+    box = OrientedBox(R=torch.eye(3), T=torch.zeros(3), S=torch.tensor([1.0, 1.0, 1.0]))
+    m.set_crop(box)
+    m.train()
+    assert m._crop_ids() is None  # training ignores the crop box
+    m.eval()
+    assert m._crop_ids().tolist() == [True, True, False]
+    m._active_crop = m._crop_ids()
+    assert m.means.shape == (2, 3) and m.features_rest.shape == (2, 15, 3) and m.num_points == 3
+    m._active_crop = None
+    m.set_crop(OrientedBox(R=torch.eye(3), T=torch.full((3,), 50.0), S=torch.ones(3)))
+    cam = Camera(torch.eye(4)[None, :3], 100.0, 100.0, 8.0, 6.0, 16, 12)
+    out = m.get_outputs(cam)  # nothing inside: no raster call, hence fine on CPU
+    assert out["rgb"].shape == (12, 16, 3) and float(out["depth"].min()) == 10.0 and float(out["accumulation"].max()) == 0.0
+    # a rotated box: 45 degrees about z, long axis along the world diagonal
+    c = 2**-0.5
+    rot = OrientedBox(R=torch.tensor([[c, -c, 0.0], [c, c, 0.0], [0.0, 0.0, 1.0]]), T=torch.zeros(3), S=torch.tensor([4.0, 0.2, 1.0]))
+    pts = torch.tensor([[1.0, 1.0, 0.0], [1.0, -1.0, 0.0]])
+    assert rot.within(pts).reshape(-1).tolist() == [True, False]
+
+
 def test_method_specs_mirror_reference_tables():
     from freegaussian_amd.method_config import METHODS, STAGE1_OPTIMIZERS, STAGE2_OPTIMIZERS, nerfstudio_method_specs
 
