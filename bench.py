@@ -193,18 +193,60 @@ def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
+def _oracle_run(scene, view, K, cw, ch, sh_degree, vr, compositor=None, absgrad=False):
+    import torch
+
+    from oracle import raster_oracle as O
+
+    names = ("means", "quats", "scales", "opacities", "colors")
+    ins = [getattr(scene, n).clone().requires_grad_(True) for n in names]
+    t0 = time.perf_counter()
+    r, a, info = O.rasterization(*ins, scene.viewmats[view : view + 1], K[None], cw, ch, sh_degree=sh_degree,
+                                 render_mode="RGB", packed=False, absgrad=absgrad, compositor=compositor)  # fmt: skip
+    if absgrad:
+        info["means2d"].retain_grad()
+    (r * vr).sum().backward()
+    return time.perf_counter() - t0, r.detach(), ins, info
+
+
+def _hip_parity(scene, view, K, cw, ch, sh_degree, vr, r_ref, ins_ref, info_ref):
+    """The HIP path on the same inputs: PSNR of the render, relative L2 of every gradient
+    (parameters, screen-space means2d, absgrad) against the oracle's."""
+    import math
+
+    import torch
+
+    from freegaussian_amd import rasterization
+
+    names = ("means", "quats", "scales", "opacities", "colors")
+    dev = torch.device("cuda", torch.cuda.current_device())
+    gin = [getattr(scene, n).to(dev).requires_grad_(True) for n in names]
+    rg, _, ginfo = rasterization(*gin, scene.viewmats[view : view + 1].to(dev), K[None].to(dev), cw, ch,
+                                 sh_degree=sh_degree, render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+    ginfo["means2d"].retain_grad()
+    (rg * vr.to(dev)).sum().backward()
+    mse = float(((rg.detach().cpu().double() - r_ref.double()) ** 2).mean())
+    rel = {n: _rel_l2(g.grad.cpu(), o.grad) for n, g, o in zip(names, gin, ins_ref)}
+    if getattr(info_ref["means2d"], "absgrad", None) is not None:  # oracle runs with absgrad=True only
+        rel["means2d"] = _rel_l2(ginfo["means2d"].grad.cpu(), info_ref["means2d"].grad)
+        rel["absgrad"] = _rel_l2(ginfo["means2d"].absgrad.cpu(), info_ref["means2d"].absgrad)
+    return {
+        "psnr_hip_vs_oracle_db": 200.0 if mse == 0 else min(200.0, -10.0 * math.log10(mse)),
+        "lists_bit_exact": bool(torch.equal(ginfo["flatten_ids"].cpu(), info_ref["flatten_ids"])),
+        "grad_rel_l2_hip_vs_oracle": rel,
+        "grad_rel_l2_hip_vs_oracle_max": max(rel.values()),
+    }
+
+
 def cpu_baseline(scene, view, crop, sh_degree, threads=0):
-    """The CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is the absent
-    CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd + bwd.
-    Protocol of BASELINE.md section 2: 1 warm-up + 3 timed runs, median; the thread count is the
-    faster of 8 and all host threads in the warm-ups (the oracle is thousands of small tensor
+    """The pure-PyTorch CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is
+    the absent CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd +
+    bwd.  Protocol of BASELINE.md section 2: 1 warm-up + 3 timed runs, median; the thread count is
+    the faster of 8 and all host threads in the warm-ups (the oracle is thousands of small tensor
     ops: beyond a few threads they mostly add synchronisation cost), both warm-up times reported.
     The same crop is rendered and differentiated by the HIP path: PSNR and the relative L2 error of
     every gradient against the oracle's are part of the line."""
     import torch
-
-    from freegaussian_amd import rasterization
-    from oracle import raster_oracle as O
 
     cw, ch = (int(x) for x in crop.split("x"))
     K = scene.Ks[view].clone()
@@ -213,47 +255,16 @@ def cpu_baseline(scene, view, crop, sh_degree, threads=0):
     K[1, 2] -= y0
     host = os.cpu_count() or 1
     vr = torch.randn(1, ch, cw, 3, generator=torch.Generator().manual_seed(1))
-    names = ("means", "quats", "scales", "opacities", "colors")
-
-    def run():
-        ins = [getattr(scene, n).clone().requires_grad_(True) for n in names]
-        t0 = time.perf_counter()
-        r, a, info = O.rasterization(*ins, scene.viewmats[view : view + 1], K[None], cw, ch, sh_degree=sh_degree,
-                                     render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
-        info["means2d"].retain_grad()
-        (r * vr).sum().backward()
-        return time.perf_counter() - t0, r.detach(), ins, info
-
     candidates = [threads] if threads > 0 else sorted({min(host, 8), host})
     warm = {}
     for c in candidates:
         torch.set_num_threads(c)
-        warm[c] = run()[0]
+        warm[c], r_ref, ins_ref, info_ref = _oracle_run(scene, view, K, cw, ch, sh_degree, vr)
     cores = min(warm, key=warm.get)
     torch.set_num_threads(cores)
-    timed = []
-    for _ in range(3):
-        dt, r, ins, info = run()
-        timed.append(dt)
+    timed = [_oracle_run(scene, view, K, cw, ch, sh_degree, vr)[0] for _ in range(3)]
     dt = sorted(timed)[1]
-    # the HIP path on the same crop: PSNR of the render, relative L2 of the gradients
-    parity = {}
-    if torch.cuda.is_available():
-        dev = torch.device("cuda", torch.cuda.current_device())
-        gin = [getattr(scene, n).to(dev).requires_grad_(True) for n in names]
-        rg, _, ginfo = rasterization(*gin, scene.viewmats[view : view + 1].to(dev), K[None].to(dev), cw, ch,
-                                     sh_degree=sh_degree, render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
-        ginfo["means2d"].retain_grad()
-        (rg * vr.to(dev)).sum().backward()
-        mse = float(((rg.detach().cpu().double() - r.double()) ** 2).mean())
-        import math
-
-        parity["psnr_hip_vs_oracle_db"] = 200.0 if mse == 0 else min(200.0, -10.0 * math.log10(mse))
-        rel = {n: _rel_l2(g.grad.cpu(), o.grad) for n, g, o in zip(names, gin, ins)}
-        rel["means2d"] = _rel_l2(ginfo["means2d"].grad.cpu(), info["means2d"].grad)
-        rel["absgrad"] = _rel_l2(ginfo["means2d"].absgrad.cpu(), info["means2d"].absgrad)
-        parity["grad_rel_l2_hip_vs_oracle"] = rel
-        parity["grad_rel_l2_hip_vs_oracle_max"] = max(rel.values())
+    parity = _hip_parity(scene, view, K, cw, ch, sh_degree, vr, r_ref, ins_ref, info_ref) if torch.cuda.is_available() else {}
     return {
         "value": cw * ch / dt / 1e6,
         **parity,
@@ -264,9 +275,30 @@ def cpu_baseline(scene, view, crop, sh_degree, threads=0):
         "runs_s": [round(x, 2) for x in timed],
         "warmup_s_by_threads": {str(k): round(v, 2) for k, v in warm.items()},
         "sample": f"centre {cw}x{ch} crop of view {view} of the same scene (all {scene.means.shape[0]} Gaussians "
-        f"projected, {info['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 warm-up per thread count + 3 timed "
-        f"runs, median {dt:.1f} s on {cores} of {host} host threads; pure-PyTorch CPU oracle (extrapolates by pixel count)",
+        f"projected, {info_ref['flatten_ids'].numel()} tile intersections), fwd+bwd, 1 warm-up per thread count + 3 "
+        f"timed runs, median {dt:.1f} s on {cores} of {host} host threads; pure-PyTorch CPU oracle (extrapolates by "
+        "pixel count)",
     }
+
+
+def cpu_full_frame(scene, view, sh_degree):
+    """The WHOLE headline frame on the host: torch projection / SH / sort of the oracle with the
+    scalar C compositing (oracle/fg_oracle.c, OpenMP over tiles) -- no crop, no extrapolation -- and
+    the HIP path's render and gradients of the whole frame against it.  One run (~10-30 s)."""
+    import torch
+
+    from oracle import c_oracle as CO
+
+    host = os.cpu_count() or 1
+    torch.set_num_threads(host)
+    W, H = scene.width, scene.height
+    K = scene.Ks[view]
+    vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1))
+    dt, r_ref, ins_ref, info_ref = _oracle_run(scene, view, K, W, H, sh_degree, vr, compositor=CO.composite, absgrad=True)
+    parity = _hip_parity(scene, view, K, W, H, sh_degree, vr, r_ref, ins_ref, info_ref) if torch.cuda.is_available() else {}
+    return {"value": W * H / dt / 1e6, "unit": "Mpix/s", "cores": host, "kind": "port", "seconds": round(dt, 2), **parity,
+            "sample": f"the whole {W}x{H} frame of view {view}, fwd+bwd, 1 run; torch projection / SH / sort + C "
+            "compositing (OpenMP), all host threads"}  # fmt: skip
 
 
 def under_profiler():
@@ -599,6 +631,7 @@ def main(argv=None):
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)
+            out["cpu_full_frame"] = cpu_full_frame(scene, view, args.sh_degree)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

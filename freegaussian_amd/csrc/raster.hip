@@ -990,12 +990,12 @@ int launch_grid(int mode, int tile_w, int tile_h) {
 // 2040 tiles (960x540) -> 1 / 1: fwd 0.178 -> 0.117 ms, bwd 0.420 -> 0.317 ms;
 // 510 tiles (480x270) -> 1 / 1: fwd 0.138 -> 0.071, bwd 0.357 -> 0.151.
 int raster_ppt_fwd(int n_tiles) {
-  static int forced = env_ppt("FG_RASTER_PPT_FWD", 0);
+  const int forced = env_ppt("FG_RASTER_PPT_FWD", 0);  // read per call: tests switch it within a process
   if (forced) return forced;
   return n_tiles >= 6000 ? 2 : 1;
 }
 int raster_ppt_bwd(int n_tiles) {
-  static int forced = env_ppt("FG_RASTER_PPT_BWD", 0);
+  const int forced = env_ppt("FG_RASTER_PPT_BWD", 0);
   if (forced) return forced;
   return n_tiles >= 6000 ? 4 : (n_tiles >= 3000 ? 2 : 1);
 }

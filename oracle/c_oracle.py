@@ -77,3 +77,33 @@ def raster_bwd(means2d, conics, feats, opac, width, height, ts, offsets, ids, al
     lib().fgo_raster_bwd(N, C, width, height, ts, _p(means2d), _p(conics), _p(feats), _p(opac), _p(offsets), _p(ids),
                          _p(alphas), _p(last), _p(v_render), _p(v_alphas), *[_p(o) for o in out])  # fmt: skip
     return out
+
+
+class _CompositeC(torch.autograd.Function):
+    """K5 / K6 of the C restatement as one autograd node, so that the torch oracle's projection and
+    SH stages (autograd) can be chained with per-pixel sequential C compositing."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, feats, opac, geom, offsets, ids, holder):
+        width, height, ts = geom
+        render, alphas, last = raster_fwd(means2d, conics, feats, opac, width, height, ts, offsets, ids)
+        ctx.save_for_backward(means2d, conics, feats, opac, offsets, ids, alphas, last)
+        ctx.geom, ctx.holder = geom, holder
+        ctx.mark_non_differentiable(last)
+        return render, alphas, last
+
+    @staticmethod
+    def backward(ctx, v_render, v_alphas, _v_last):
+        means2d, conics, feats, opac, offsets, ids, alphas, last = ctx.saved_tensors
+        width, height, ts = ctx.geom
+        v_xy, v_abs, v_conic, v_col, v_op = raster_bwd(means2d, conics, feats, opac, width, height, ts, offsets, ids,
+                                                       alphas, last, v_render, v_alphas)  # fmt: skip
+        if ctx.holder is not None:
+            ctx.holder.absgrad = v_abs[None]
+        return v_xy, v_conic, v_col, v_op, None, None, None, None
+
+
+def composite(means2d, conics, feats, opac, width, height, ts, offsets, ids, absgrad_holder=None):
+    """``compositor=`` argument of raster_oracle.rasterization: the C compositing, differentiable."""
+    return _CompositeC.apply(means2d, conics, feats, opac, (int(width), int(height), int(ts)),
+                             offsets.to(torch.int32).contiguous(), ids.to(torch.int32).contiguous(), absgrad_holder)  # fmt: skip

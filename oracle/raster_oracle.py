@@ -491,11 +491,15 @@ def rasterization(
     radius_clip: float = 0.0,
     eps2d: float = EPS2D,
     extra_channels: Optional[torch.Tensor] = None,
+    compositor=None,
 ):
     """The whole K0 boundary on CPU for one camera, differentiable by autograd.
 
     ``extra_channels`` [N,E] are composited like colours and appended after the render-mode
-    channels (used for the flow channels F1)."""
+    channels (used for the flow channels F1).  ``compositor``: another implementation of the K5/K6
+    stage, ``f(means2d, conics, feats, opac, W, H, tile, offsets, flatten_ids, absgrad_holder) ->
+    (render, alpha, last_ids)`` -- ``c_oracle.composite`` plugs the scalar C restatement in, which
+    makes full-resolution oracle runs affordable (the torch compositing costs ~10 ms per tile)."""
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
@@ -536,10 +540,15 @@ def rasterization(
         proj.means2d, proj.radii, proj.depths, tile_size, tile_w, tile_h
     )
     offsets = isect_offsets(isect_ids, tile_w * tile_h)
-    render, alpha, last_ids = rasterize(
-        m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids
-    )
-    if absgrad and torch.is_grad_enabled() and render.requires_grad:
+    if compositor is not None:
+        render, alpha, last_ids = compositor(
+            m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids, means2d_out if absgrad else None
+        )
+    else:
+        render, alpha, last_ids = rasterize(
+            m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids
+        )
+    if compositor is None and absgrad and torch.is_grad_enabled() and render.requires_grad:
         args = tuple(t.detach() for t in (proj.means2d, proj.conics, feats, opac)) + (
             width, height, tile_size, offsets, flatten_ids)  # fmt: skip
         render, alpha = _AbsgradTap.apply(render, alpha, {"args": args, "holder": means2d_out})

@@ -328,8 +328,13 @@ def _raster_inputs(sc, view=0, channels=3, seed=0):
     return ref, feats, offs, vals
 
 
-@pytest.mark.parametrize("channels", [1, 3, 4, 6, 8])
-def test_raster_forward_backward_vs_oracle(channels):
+@pytest.mark.parametrize("channels,ppt", [(1, 0), (3, 0), (4, 0), (6, 0), (8, 0), (3, 1), (3, 2), (3, 4), (5, 2), (4, 4)])
+def test_raster_forward_backward_vs_oracle(channels, ppt, monkeypatch):
+    """ppt = 0: the library's own choice for this tile count; 1 / 2 / 4: every pixels-per-lane body
+    of the classic launch (4 / 2 / 1 wavefronts per tile) directly against the oracle."""
+    if ppt:
+        monkeypatch.setenv("FG_RASTER_PPT_FWD", str(ppt))
+        monkeypatch.setenv("FG_RASTER_PPT_BWD", str(ppt))
     sc = _scene(n=8000, w=150, h=100)  # 150x100: partial tiles on both edges
     sc.opacities[:400] = 1.0  # exercise the 0.999 clamp branch
     ref, feats, offs, vals = _raster_inputs(sc, channels=channels)
@@ -527,7 +532,8 @@ def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True):
     c2w_cv = torch.linalg.inv(w2c)
     c2w_gl = c2w_cv.clone()
     c2w_gl[:3, 1:3] *= -1  # OpenCV -> OpenGL camera axes (get_viewmat flips them back)
-    cam = Camera(c2w_gl[None, :3], 140.0, 150.0, W / 2, H / 2, W, H, times=torch.tensor([[0.4]]))
+    f = W / 160.0  # same field of view at every size
+    cam = Camera(c2w_gl[None, :3], 140.0 * f, 150.0 * f, W / 2, H / 2, W, H, times=torch.tensor([[0.4]]))
     ref = copy.deepcopy(model)
     return model.to(DEV), ref, cam
 
@@ -583,6 +589,44 @@ def test_model_get_outputs_eval_depth_and_background():
     d0 = torch.where(acc0 > 0, r0[0, ..., 3:4], r0[0, ..., 3:4].max())
     assert out["depth"].shape == (cam.height, cam.width, 1) and out["background"].shape == (cam.height, cam.width, 3)
     assert rel_err(out["rgb"], rgb0) < 3 * REL_TOL and rel_err(out["depth"], d0) < 3 * REL_TOL
+
+
+def test_crop_box_render_equals_rendering_the_subset():
+    """Eval-only crop (reference :778-798): the render of the cropped model is the render of a model
+    that only holds the rows inside the box."""
+    import copy
+
+    from freegaussian_amd.model import OrientedBox
+
+    model, _, cam = _model_and_camera(n=3000, step=4000, training=False)
+    box = OrientedBox(R=torch.eye(3), T=torch.tensor([0.2, 0.0, 0.0]), S=torch.tensor([1.0, 1.4, 1.2]))
+    inside = box.within(model.gauss_params["means"]).reshape(-1)
+    assert 100 < int(inside.sum()) < 2900
+    sub = copy.deepcopy(model)
+    for k in list(sub.gauss_params.keys()):
+        sub.gauss_params[k] = torch.nn.Parameter(sub.gauss_params[k][inside].clone())
+    model.set_crop(box)
+    with torch.no_grad():
+        a, b = model.get_outputs(copy.deepcopy(cam)), sub.get_outputs(copy.deepcopy(cam))
+    assert torch.equal(a["rgb"], b["rgb"]) and torch.equal(a["depth"], b["depth"])
+    assert model.radii.shape[0] == int(inside.sum())
+    model.train()
+    out = model.get_outputs(copy.deepcopy(cam))  # training ignores the box
+    assert model.radii.shape[0] == 3000 and out["rgb"].shape == (cam.height, cam.width, 3)
+
+
+def test_render_and_ground_truth_shapes_agree_at_every_scheduled_resolution():
+    """1352x1014 at d = 4: 1014 / 4 = 253.5 -- render and resize_image target must both be 253 rows."""
+    model, _, _ = _model_and_camera(n=500, W=1352, H=1014, step=100, training=True)
+    from freegaussian_amd.model import Camera
+
+    model.config.num_downscales = 2
+    cam = Camera(torch.eye(4)[None, :3], 900.0, 900.0, 676.0, 507.0, 1352, 1014, times=torch.tensor([[0.1]]))
+    img = torch.rand(1014, 1352, 3)
+    for model.step in (100, 3100, 6100):
+        out = model.get_outputs(cam)
+        assert out["rgb"].shape == model.get_gt_img(img).shape, model.step
+        assert (cam.width, cam.height) == (1352, 1014)
 
 
 def test_control_model_stage2_scatter_and_render():
@@ -722,6 +766,82 @@ def test_full_size_cfg4_properties_and_oracle_crop():
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
+
+# ------------------------------------------------------------------------------------------
+def _oracle_full_res(sc, view, render_mode, sh_degree, seed=0, with_alpha_grad=True):
+    """O.rasterization with the scalar C compositing (oracle/c_oracle.composite; it agrees with the
+    torch compositing to 1e-6, tests/test_oracle.py) -- affordable at 8160 tiles -- and the HIP path
+    on the same inputs and the same upstream gradients."""
+    from oracle import c_oracle as CO
+
+    names = ["means", "quats", "scales", "opacities", "colors"]
+    cpu = [getattr(sc, n) for n in names]
+    ref_in = [t.clone().requires_grad_(True) for t in cpu]
+    gpu_in = [t.to(DEV).requires_grad_(True) for t in cpu]
+    kw = dict(width=sc.width, height=sc.height, sh_degree=sh_degree, render_mode=render_mode, packed=False, absgrad=True)
+    vm, K = sc.viewmats[view : view + 1], sc.Ks[view : view + 1]
+    r0, a0, i0 = O.rasterization(*ref_in, vm, K, compositor=CO.composite, **kw)
+    r1, a1, i1 = rasterization(*gpu_in, vm.to(DEV), K.to(DEV), **kw)
+    i0["means2d"].retain_grad()
+    i1["means2d"].retain_grad()
+    g = torch.Generator().manual_seed(seed)
+    vr, va = torch.randn(r0.shape, generator=g), torch.randn(a0.shape, generator=g)
+    if not with_alpha_grad:
+        va = torch.zeros_like(va)
+    ((r0 * vr).sum() + (a0 * va).sum()).backward()
+    ((r1 * vr.to(DEV)).sum() + (a1 * va.to(DEV)).sum()).backward()
+    return dict(zip(names, ref_in)), dict(zip(names, gpu_in)), (r0, a0, i0), (r1, a1, i1)
+
+
+def _assert_full_parity(ref_in, gpu_in, o0, o1, tol):
+    (r0, a0, i0), (r1, a1, i1) = o0, o1
+    assert torch.equal(i1["radii"].cpu(), i0["radii"])
+    assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
+    assert torch.equal(i1["isect_offsets"].cpu().reshape(-1), i0["isect_offsets"].reshape(-1))
+    assert close_except_knife_edge(r1[0], r0[0], 3 * REL_TOL) and close_except_knife_edge(a1[0], a0[0], REL_TOL)
+    worst = {}
+    for k in ref_in:
+        worst[k] = rel_l2(gpu_in[k].grad, ref_in[k].grad)
+    worst["means2d"] = rel_l2(i1["means2d"].grad, i0["means2d"].grad)
+    worst["absgrad"] = rel_l2(i1["means2d"].absgrad, i0["means2d"].absgrad)
+    assert all(v < tol for v in worst.values()), worst
+    return worst
+
+
+@pytest.mark.parametrize("layout,render_mode", [("uniform", "RGB"), ("clustered", "RGB"), ("uniform", "RGB+ED")])
+def test_1080p_mixed_launch_forward_and_all_gradients_vs_oracle(layout, render_mode):
+    """8160 tiles: the launch shape of the headline -- `raster_fwd/bwd_mixed_kernel` with job lists,
+    whole-tile jobs (4 pixels per lane), the positional two-strip / single-strip tails and, on the
+    clustered scene, content-split jobs -- put DIRECTLY against the oracle: image, every parameter
+    gradient, the screen-space gradient and absgrad (VERDICT r1 weak #2)."""
+    from freegaussian_amd import _lib
+
+    assert int(_lib.load().fg_raster_jobs_words(1920, 1080, 16)) > 0  # job-list launches are what runs here
+    sc = synthetic_scene(40_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    if layout == "clustered":
+        sc.means[:20_000] *= 0.15  # a ball at the centre: lists there are many times the mean
+    ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 1, render_mode, 3)
+    if layout == "clustered":
+        offs = o0[2]["isect_offsets"].reshape(-1)
+        lens = torch.diff(offs)
+        assert int(lens.max()) > 20 * int(offs[-1]) // 65536  # some tiles are above the four-strip threshold
+    _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+
+
+def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
+    """BASELINE.json's headline input itself -- 1M Gaussians, 1920x1080, SH 3, 7.2M intersections --
+    forward and backward against the oracle on the WHOLE frame (torch projection / SH / sort + C
+    compositing, ~30 s of CPU): lists bit-exact, image within the bar, every gradient incl. absgrad."""
+    from freegaussian_amd.scenes import north_star_scene
+
+    sc = north_star_scene(n_views=1)
+    ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 0, "RGB", 3, with_alpha_grad=False)  # the bench's upstream gradient
+    assert o0[2]["flatten_ids"].numel() > 7_000_000
+    worst = _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+    assert psnr(o1[0], o0[0]) > 80
+    print("cfg4 whole-frame rel-L2 of gradients vs oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
+
+
 def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monkeypatch):
     """A non-uniform scene at 1920x1080 (8160 tiles: job lists are active by default): half of the
     Gaussians sit in a small ball, so the centre tiles hold lists many times the mean and are split
@@ -787,14 +907,18 @@ def test_cfg2_conerf_like_300k_psnr_and_gradients():
         assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
 
 
-def test_cfg3_flow_derivative_scene():
+@pytest.mark.parametrize("N,W,H", [(60_000, 480, 270), (300_000, 960, 540)])
+def test_cfg3_flow_derivative_scene(N, W, H):
     """configs[2] 'LiveScene-sim scene with flow-derivative loss enabled': second pose = first pose
     moved by dt=(0.02,0,0), dw=(0,0.01,0); per-Gaussian rigid screw motion; F1 composited flow via
-    render_with_flow, F2 per-Gaussian Jacobian terms, camera flow map -- all against the oracle."""
+    render_with_flow, F2 per-Gaussian Jacobian terms, camera flow map -- all against the oracle.
+    The second case is SURVEY.md section 8d's stated size (300k Gaussians, 960x540), with the C
+    compositing inside the oracle; the first keeps the pure-torch oracle in the loop."""
     from freegaussian_amd import flow as FL
     from freegaussian_amd.utils import exp_se3, from_homogenous, to_homogenous
+    from oracle import c_oracle as CO
 
-    N, W, H = 60_000, 480, 270
+    compositor = CO.composite if N > 100_000 else None
     sc = synthetic_scene(N, W, H, n_views=1, seed=42)
     g = torch.Generator().manual_seed(5)
     screw = torch.cat([torch.nn.functional.normalize(torch.randn(N, 3, generator=g), dim=-1),
@@ -816,7 +940,7 @@ def test_cfg3_flow_derivative_scene():
     both = ((p0.radii > 0) & (pt.radii > 0))[:, None]
     disp = torch.where(both, pt.means2d - p0.means2d, torch.zeros_like(pt.means2d))
     r0, a0, _ = O.rasterization(ref[0], ref[2], ref[3], ref[4], ref[5], vm_t, K, W, H, sh_degree=3,
-                                render_mode="RGB+ED", extra_channels=disp)  # fmt: skip
+                                render_mode="RGB+ED", extra_channels=disp, compositor=compositor)  # fmt: skip
     target = torch.randn(1, H, W, 2, generator=g) * 0.1
     loss0 = (r0[..., 4:] - target).abs().mean() + r0[..., :3].mean()
     loss0.backward()
@@ -852,20 +976,25 @@ def test_cfg3_flow_derivative_scene():
     assert rel_err(ug1, ug0) < REL_TOL and rel_err(uc1, uc0) < REL_TOL
 
 
-def test_cfg5_control_stage2_matches_oracle_host_path():
+@pytest.mark.parametrize("n,W,H", [(6000, 160, 96), (50_000, 1920, 1080)])
+def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     """configs[4] 'freegaussian-control stage-2': frozen deform -> per-attribute mean displacement
-    -> control MLP -> deltas scattered into the masked Gaussians -> the same raster call."""
+    -> control MLP -> deltas scattered into the masked Gaussians -> the same raster call.
+    Second case: 1920x1080 = 8160 tiles ("as cfg4") -- the mixed / job-list
+    launches under the stage-2 front end, 5% of the rows masked; oracle with the C compositing."""
     import copy
 
     from freegaussian_amd.model import FreeGaussianControlModel, FreeGaussianModelConfig
     from freegaussian_amd.utils import from_homogenous, get_viewmat, to_homogenous
+    from oracle import c_oracle as CO
 
-    _, base, cam = _model_and_camera(n=6000, training=True)
+    compositor = CO.composite if W * H > 10**6 else None
+    _, base, cam = _model_and_camera(n=n, W=W, H=H, training=True)
     N = base.num_points
     mask = torch.zeros(N, 3, dtype=torch.bool)
-    mask[:300, 0] = True
-    mask[200:500, 1] = True
-    mask[1000:1100, 2] = True
+    mask[: N // 20, 0] = True  # 5% of the rows set (cfg5), overlapping attributes
+    mask[N // 30 : N // 12, 1] = True
+    mask[N // 6 : N // 6 + N // 60, 2] = True
     init_cam = type(cam)(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height,
                          times=torch.tensor([[0.0]]))  # fmt: skip
     cfg = FreeGaussianModelConfig(background_color="black")
@@ -897,7 +1026,7 @@ def test_cfg5_control_stage2_matches_oracle_host_path():
     colors, deg = cm_cpu._colors_and_degree()
     r0, a0, _ = O.rasterization(means, quats, scales, torch.sigmoid(cm_cpu.opacities).squeeze(-1), colors,
                                 get_viewmat(cam.camera_to_worlds), cam.get_intrinsics_matrices(), cam.width,
-                                cam.height, sh_degree=deg, render_mode="RGB", packed=False)  # fmt: skip
+                                cam.height, sh_degree=deg, render_mode="RGB", packed=False, compositor=compositor)  # fmt: skip
     rgb0 = torch.clamp(r0[..., :3] + (1 - a0) * torch.zeros(3), 0.0, 1.0).squeeze(0)
     assert deg == 3 and cm.step == 30000
     assert close_except_knife_edge(out["rgb"], rgb0, 3 * REL_TOL)

@@ -185,3 +185,28 @@ def test_oracle_sqrt_is_correctly_rounded():
 
     x = torch.rand(500_000, generator=torch.Generator().manual_seed(0)) * 100
     assert np.array_equal(O._sqrt(x).numpy(), np.sqrt(x.numpy()))
+
+
+def test_c_compositor_plugs_into_the_torch_oracle_and_agrees_end_to_end():
+    """`compositor=c_oracle.composite`: the torch oracle's projection / SH / sort chained with the
+    scalar C compositing through autograd (what the full-resolution GPU parity tests and bench.py's
+    whole-frame leg use) against the all-torch oracle: image, every gradient, means2d.grad, absgrad."""
+    import math
+
+    from freegaussian_amd.scenes import synthetic_scene
+    from oracle import c_oracle as CO
+
+    sc = synthetic_scene(3000, 200, 136, n_views=1, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    outs = []
+    for comp in (None, CO.composite):
+        ins = [t.clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, info = O.rasterization(*ins, sc.viewmats[:1], sc.Ks[:1], 200, 136, sh_degree=3, render_mode="RGB+ED",
+                                     absgrad=True, compositor=comp)  # fmt: skip
+        info["means2d"].retain_grad()
+        g = torch.Generator().manual_seed(0)
+        vr, va = torch.randn(r.shape, generator=g), torch.randn(a.shape, generator=g)
+        ((r * vr).sum() + (a * va).sum()).backward()
+        outs.append([r.detach(), a.detach()] + [x.grad for x in ins] + [info["means2d"].grad, info["means2d"].absgrad])
+    assert outs[0][-1].shape == (1, 3000, 2) and bool((outs[0][-1] >= outs[0][-2].abs() - 1e-6).all())
+    for x, y in zip(outs[1], outs[0]):
+        assert float((x - y).norm() / y.norm()) < 2e-5
