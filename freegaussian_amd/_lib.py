@@ -69,6 +69,7 @@ SIGNATURES = {
     "fg_split_children": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     "fg_mask_backproject": (c_int, [c_int, P, P, P, P, c_int, c_int, P, P, c_int, c_int, P, P]),
     "fg_camera_flow": (c_int, [c_int, c_int, P, P, P, P, P, P]),
+    "fg_reprojection_flow": (c_int, [c_int, c_int, P, P, P, P, c_float, P, P]),
     "fg_flow_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_flow_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
 }  # fmt: skip

@@ -3,6 +3,10 @@
 //  * fg_camera_flow : per-pixel camera flow  A(x,y) v / Z + B(x,y) w
 //        /root/reference preprocess/epipolar_flow.py:272-309 (pixel centres at integer
 //        coordinates, :272; infinite depth -> 0, :315-317).
+//  * fg_reprojection_flow : the exact-reprojection variant (F-spec')
+//        /root/reference preprocess/epipolar_flow_bp.py:268-295: lift the pixel with the depth of
+//        frame 0, map it by the 3x4 matrix M the host composed from the two poses, project with K,
+//        divide by the depth map of frame 1, subtract the pixel.
 //  * fg_flow_fwd/bwd : per-Gaussian projection-flow Jacobian (Lemma 1,
 //        /root/reference docs/index.html:256-273), with the CODE's sign convention
 //        A = [[fx,0,cx-x],[0,fy,cy-y]] (epipolar_flow.py:277-282), which is -1x the page's.
@@ -47,6 +51,32 @@ camera_flow_kernel(int width, int height, const float* __restrict__ depth, const
     const float w0 = omega[0], w1 = omega[1], w2 = omega[2];
     fu = (k.fx * v0 + (k.cx - x) * v2) / Z + (B[0][0] * w0 + B[0][1] * w1 + B[0][2] * w2);
     fv = (k.fy * v1 + (k.cy - y) * v2) / Z + (B[1][0] * w0 + B[1][1] * w1 + B[1][2] * w2);
+  }
+  reinterpret_cast<float2*>(flow)[p] = make_float2(fu, fv);
+}
+
+// uv - xy of epipolar_flow_bp.py:271-279; `sign` = -1 writes the reference's returned
+// "sceneflow" (:295), +1 the raw difference; infinite depth0 -> 0 (:285-287).
+__global__ void __launch_bounds__(256)
+reprojection_flow_kernel(int width, int height, const float* __restrict__ depth0,
+                         const float* __restrict__ depth1, const float* __restrict__ K,
+                         const float* __restrict__ M, float sign, float* __restrict__ flow) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= (int64_t)width * height) return;
+  const int iy = (int)(p / width), ix = (int)(p - (int64_t)iy * width);
+  const Intr k = load_intr(K);
+  const float x = (float)ix, y = (float)iy;
+  const float Z = depth0[p];
+  float fu = 0.f, fv = 0.f;
+  if (!isinf(Z)) {
+    // K^-1 (x, y, 1) Z
+    const float X = (x - k.cx) / k.fx * Z, Y = (y - k.cy) / k.fy * Z;
+    const float qx = M[0] * X + M[1] * Y + M[2] * Z + M[3];
+    const float qy = M[4] * X + M[5] * Y + M[6] * Z + M[7];
+    const float qz = M[8] * X + M[9] * Y + M[10] * Z + M[11];
+    const float iz1 = 1.f / depth1[p];
+    fu = sign * ((k.fx * qx + k.cx * qz) * iz1 - x);
+    fv = sign * ((k.fy * qy + k.cy * qz) * iz1 - y);
   }
   reinterpret_cast<float2*>(flow)[p] = make_float2(fu, fv);
 }
@@ -131,6 +161,17 @@ extern "C" int fg_camera_flow(int width, int height, const float* depth, const f
   const int64_t P = (int64_t)width * height;
   hipLaunchKernelGGL(camera_flow_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, fg_hip_stream(stream),
                      width, height, depth, K, veloc, omega, flow);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_reprojection_flow(int width, int height, const float* depth0, const float* depth1,
+                                    const float* K, const float* M, float sign, float* flow,
+                                    fg_stream_t stream) {
+  if (width <= 0 || height <= 0 || !depth0 || !depth1 || !K || !M || !flow) return FG_ERR_INVALID_ARG;
+  const int64_t P = (int64_t)width * height;
+  hipLaunchKernelGGL(reprojection_flow_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0,
+                     fg_hip_stream(stream), width, height, depth0, depth1, K, M, sign, flow);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

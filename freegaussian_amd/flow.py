@@ -6,6 +6,11 @@
   R0^-1 R1, v = t1 - t0.  Checked against the reference's own output (tests/golden/g_flow.npz).
 * ``camera_flow_map`` -- the per-pixel camera flow  A v / Z + B w  (epipolar_flow.py:272-317) on
   the GPU (HIP kernel ``fg_camera_flow``).
+* ``reprojection_motion`` / ``reprojection_flow_map`` -- F-spec', the exact-reprojection variant of
+  the camera flow (preprocess/epipolar_flow_bp.py:258-298) with that file's own conventions;
+  HIP kernel ``fg_reprojection_flow``.  To first order in the camera motion it equals
+  A v / Z + B w with (v, w) = (translation, rotation vector) of the same 3x4 matrix
+  (tests/test_host.py::test_reprojection_flow_agrees_with_the_AB_jacobian_to_first_order).
 * ``flow_channels`` / ``render_with_flow`` -- F1 of SURVEY.md §8a: the composited Gaussian flow
   of Corollary 1 (docs/index.html:293-299), sum_i T_i alpha_i (mu_{i,t} - mu_{i,0}), rendered as
   two extra channels of the same raster pass, plus F2 (Lemma 1) per-Gaussian Jacobian terms
@@ -50,6 +55,38 @@ def relative_camera_motion(c2w0: torch.Tensor, c2w1: torch.Tensor) -> Tuple[torc
 def camera_flow_map(depth: torch.Tensor, K: torch.Tensor, veloc: torch.Tensor, omega: torch.Tensor) -> torch.Tensor:
     """depth [H,W] or [H,W,1] (inf allowed) -> camera flow [H,W,2] (fp32, GPU)."""
     return ops.camera_flow(depth.reshape(depth.shape[0], depth.shape[1]), K, veloc, omega)
+
+
+def reprojection_motion(c2w0: torch.Tensor, c2w1: torch.Tensor) -> torch.Tensor:
+    """The 3x4 matrix the reference's reprojection applies to a camera-frame point of frame 0
+    (epipolar_flow_bp.py:265-266, :275-276): both nerfstudio poses get the OpenGL->OpenCV
+    camera-axis flip only (``manual2cv(keep_original_world_coordinate=True)``), then
+    M = c2w1 . c2w0^-1.  float64."""
+
+    def to_cv(c2w):
+        m = torch.eye(4, dtype=torch.float64)
+        m[: c2w.shape[0]] = c2w.double().cpu()
+        m[0:3, 1:3] = -m[0:3, 1:3]
+        return m
+
+    return (to_cv(c2w1) @ torch.linalg.inv(to_cv(c2w0)))[:3]
+
+
+def reprojection_flow_map(depth0: torch.Tensor, depth1: torch.Tensor, K: torch.Tensor, c2w0: torch.Tensor,
+                          c2w1: torch.Tensor, opticalflow: Optional[torch.Tensor] = None) -> Dict[str, torch.Tensor]:  # fmt: skip
+    """F-spec' on the GPU: ``sceneflow`` = -(uv - xy) and, with an optical-flow map,
+    ``interflow`` = opticalflow - (uv - xy), both 0 at infinite depth -- the dictionary
+    epipolar_flow_bp.diff_2d_epipolar_flow returns (:282-297).  depth maps [H,W] or [H,W,1]."""
+    dev = depth0.device
+    d0 = depth0.reshape(depth0.shape[0], depth0.shape[1])
+    d1 = depth1.reshape(depth1.shape[0], depth1.shape[1])
+    M = reprojection_motion(c2w0, c2w1).float().to(dev)
+    scene = ops.reprojection_flow(d0, d1, K.to(dev), M, sign=-1.0)
+    out = {"sceneflow": scene}
+    if opticalflow is not None:
+        inter = opticalflow.to(dev).float() + scene
+        out["interflow"] = torch.where(torch.isinf(d0)[..., None], torch.zeros_like(inter), inter)
+    return out
 
 
 def render_with_flow(

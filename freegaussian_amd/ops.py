@@ -775,6 +775,19 @@ def camera_flow(depth: torch.Tensor, K: torch.Tensor, veloc: torch.Tensor, omega
     return flow
 
 
+def reprojection_flow(depth0: torch.Tensor, depth1: torch.Tensor, K: torch.Tensor, M: torch.Tensor,
+                      sign: float = -1.0) -> torch.Tensor:  # fmt: skip
+    """Exact-reprojection camera flow (reference preprocess/epipolar_flow_bp.py:268-295): lift with
+    depth0 [H,W], map by M [3,4], project with K, divide by depth1 [H,W]; -> sign * (uv - xy) [H,W,2]."""
+    depth0, depth1, K, M = _f32(depth0, "depth0"), _f32(depth1, "depth1"), _f32(K, "K"), _f32(M, "M")
+    H, W = depth0.shape
+    if depth1.shape != depth0.shape or M.numel() != 12:
+        raise ValueError("depth maps of equal shape and a 3x4 matrix expected")
+    flow = torch.empty(H, W, 2, dtype=torch.float32, device=depth0.device)
+    _call("fg_reprojection_flow", W, H, _ptr(depth0), _ptr(depth1), _ptr(K), _ptr(M), float(sign), _ptr(flow), _stream())
+    return flow
+
+
 class _GaussianFlow(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, depths, vel, radii, K, veloc, omega):

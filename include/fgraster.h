@@ -371,6 +371,14 @@ int fg_mask_backproject(int N, const float* means2d, const float* depths, const 
  * flow[H,W,2]. */
 int fg_camera_flow(int width, int height, const float* depth, const float* K,
                    const float* veloc, const float* omega, float* flow, fg_stream_t stream);
+/* Exact-reprojection camera flow (preprocess/epipolar_flow_bp.py:268-295): per pixel, lift with
+ * depth0, map by M[3,4] (row-major; the host composes it from the two poses exactly as the
+ * reference does, c2w1 . c2w0^-1 after its OpenGL->OpenCV column flip, :265-266, :275-276), project
+ * with K, divide by depth1, subtract the pixel (pixel centres at integer coordinates, :268).
+ * flow[H,W,2] = sign * (uv - xy); sign = -1 is the "sceneflow" the reference returns (:295).
+ * Infinite depth0 -> 0 (:285-287). */
+int fg_reprojection_flow(int width, int height, const float* depth0, const float* depth1,
+                         const float* K, const float* M, float sign, float* flow, fg_stream_t stream);
 /* Per-Gaussian projection-flow Jacobian (Lemma 1, docs/index.html:256-273, code sign
  * convention of epipolar_flow.py:277-298): for visible Gaussian i at means2d mu_i, depth Z_i,
  * camera-frame velocity vel[i]:   u_gs[i] = A(mu_i) vel[i] / Z_i

@@ -6,9 +6,14 @@ Follows /root/reference freegaussian/freegaussian_model.py line by line:
 functions on dictionaries of CPU tensors (no nerfstudio, no optimizers objects: the Adam moments
 are passed as ``{name: {"exp_avg": t, "exp_avg_sq": t}}``).  Only ``tests/`` may import this.
 
-PARITY: pinned against the reference's own source text only (the module cannot be imported here:
-its nerfstudio / gsplat imports fail); the one external function it calls,
-gsplat's ``quat_to_rotmat``, is restated from its published formula (wxyz quaternion)."""
+PARITY: PINNED to the reference's own methods.  The module cannot be imported here (its
+nerfstudio / gsplat imports fail, SURVEY.md section 8c), so tests/golden/make_golden.py::gen_densify
+executes the bodies of ``refinement_after`` / ``split_gaussians`` / ``dup_gaussians`` /
+``cull_gaussians`` / ``dup_in_optim`` / ``remove_from_optim`` (AST slices, never stored) as methods
+of a stub ``self`` on 8 seeded cases and tests/test_densify.py checks this file against their
+outputs (tests/golden/g_densify.npz; all tensors exact, the rotated child offsets to 1e-6).  The
+one external function they call, gsplat's ``quat_to_rotmat``, is not on disk: the stub is handed
+the function below (its published formula, wxyz quaternion)."""
 from __future__ import annotations
 
 from typing import Dict, Optional

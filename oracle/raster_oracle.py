@@ -631,3 +631,39 @@ def gaussian_flow(means2d, depths, vel_cam, fx, fy, cx, cy, veloc, omega):
     u_gs = torch.einsum("nij,nj->ni", A, vel_cam) * iz
     u_cam = torch.einsum("nij,j->ni", A, veloc.to(A.dtype)) * iz + torch.einsum("nij,j->ni", B, omega.to(A.dtype))
     return u_gs, u_cam
+
+
+def camera_flow_reprojection(Z, Z1, c2w0, c2w1, K, opticalflow=None):
+    """F-spec': the exact-reprojection variant, ``preprocess/epipolar_flow_bp.py:258-298``, restated
+    line by line INCLUDING its conventions: poses go OpenGL->OpenCV by the camera-axis flip only
+    (``manual2cv(..., keep_original_world_coordinate=True)``, ``:229-241``); a pixel is lifted with the
+    depth of frame 0 (``:271-273``), mapped by ``inverse(c2w0)`` and then by ``c2w1`` (``:275-276`` --
+    i.e. by c2w1 . c2w0^-1, the camera-to-world matrices used where world-to-camera ones would give
+    the physical reprojection), divided by the depth map of frame 1 (``:276``) and compared with the
+    pixel: ``uv - xy`` (``:279``).  Returned as the reference returns it: ``sceneflow = -(uv - xy)``
+    (``:295``), ``interflow = opticalflow - (uv - xy)`` (``:282``), both 0 at infinite depth.
+    Z, Z1 [H,W,1]; c2w [3,4]; K [3,3]; pixel centres at integer coordinates (``:268``)."""
+    dt = Z.dtype
+
+    def to_cv(c2w):
+        m = torch.eye(4, dtype=dt)
+        m[:3] = c2w.to(dt)
+        m[0:3, 1:3] = -m[0:3, 1:3]
+        return m
+
+    m0, m1 = to_cv(c2w0), to_cv(c2w1)
+    H, W = Z.shape[:2]
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=dt), torch.arange(W, dtype=dt), indexing="ij")
+    pix = torch.stack([xx, yy, torch.ones_like(xx)], -1).unsqueeze(-1)  # [H,W,3,1]
+    Kd = K.to(dt)
+    p_cam = torch.linalg.inv(Kd) @ pix * Z.unsqueeze(-1)
+    p_h = torch.cat([p_cam, torch.ones_like(p_cam[..., :1, :])], -2)
+    p3d = torch.linalg.inv(m0) @ p_h
+    uvf = 1 / Z1.unsqueeze(-1) * (Kd @ (m1 @ p3d)[..., :3, :])
+    raw = uvf[..., :2, 0] - torch.stack([xx, yy], -1)  # uv - xy
+    inf = torch.isinf(Z).squeeze(-1)
+    out = {"sceneflow": torch.where(inf[..., None], torch.zeros_like(raw), -raw), "raw": raw}
+    if opticalflow is not None:
+        inter = opticalflow.to(dt) - raw
+        out["interflow"] = torch.where(inf[..., None], torch.zeros_like(inter), inter)
+    return out

@@ -83,6 +83,66 @@ def _check(model, opts, ref_params, ref_moments, exact):
             assert torch.equal(o.state[p][m].cpu(), ref_moments[k][m]), (k, m)
 
 
+# ------------------------------------------------------------------------------------------------
+# the oracle pinned to the reference's own methods (tests/golden/g_densify.npz: the reference's
+# refinement_after / split_gaussians / dup_gaussians / cull_gaussians / *_in_optim executed from AST
+# slices with a stub `self`, tests/golden/make_golden.py::gen_densify)
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+sys.path.insert(0, GOLD)
+from make_golden import DENSIFY_CASES, DENSIFY_CFG  # noqa: E402  (tables only; nothing reads /root/reference)
+
+
+@pytest.mark.parametrize("case", DENSIFY_CASES, ids=[c[0] for c in DENSIFY_CASES])
+def test_densify_oracle_matches_the_references_own_methods(case):
+    import types
+
+    import numpy as np
+
+    tag, step, over, n, k_rest, special = case
+    z = np.load(os.path.join(GOLD, "g_densify.npz"))
+    t = lambda k: torch.from_numpy(z[f"{tag}.{k}"])  # noqa: E731
+    params = {k: t(f"in.{k}") for k in PARAM_NAMES}
+    moments = {k: {m: t(f"in.{k}.{m}") for m in ("exp_avg", "exp_avg_sq")} for k in PARAM_NAMES}
+    stats = {"xys_grad_norm": t("in.xys_grad_norm"), "vis_counts": t("in.vis_counts"), "max_2Dsize": t("in.max_2Dsize"),
+             "last_size": (96, 160)}  # fmt: skip
+    cfg = types.SimpleNamespace(**{**DENSIFY_CFG, **over})
+    meta = t("meta").tolist()
+    assert meta[0] == step and meta[1] == n == params["means"].shape[0]
+    new_p, new_m, info = DO.refinement_after(params, moments, stats, cfg, step, 60, samples=t("samples"))
+    assert new_p["means"].shape[0] == meta[2]
+    assert t("samples").shape[0] == cfg.n_split_samples * info["n_splits"]
+    for k in PARAM_NAMES:
+        # same torch ops in the same order on the same values: exact, except the rotated offsets
+        if k == "means":
+            assert torch.allclose(new_p[k], t(f"out.{k}"), rtol=1e-6, atol=1e-7), k
+        else:
+            assert torch.equal(new_p[k], t(f"out.{k}")), k
+        for m in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(new_m[k][m], t(f"out.{k}.{m}")), (k, m)
+    if special == "quirk":
+        assert info["n_splits"] == 1 and info["n_dups"] == 1
+    if special == "dup_only":
+        assert info["n_splits"] == 0 and info["n_dups"] > 0
+
+
+def test_after_train_iter_matches_the_references_own_method():
+    """S1 (:369-392): the model's statistics update against the reference method run on a stub."""
+    import numpy as np
+
+    z = np.load(os.path.join(GOLD, "g_densify.npz"))
+    t = lambda k: torch.from_numpy(z[f"s1.{k}"])  # noqa: E731
+    m = FreeGaussianModel(FreeGaussianModelConfig(), num_points=40)
+    m.last_size = (96, 160)
+    for it in range(2):
+        m.step = 700 + it
+        m.radii = t(f"radii{it}")
+        m.xys = torch.zeros(1, 40, 2)
+        m.xys.absgrad = t(f"absgrad{it}")
+        m.after_train_iter(m.step)
+        assert torch.equal(m.xys_grad_norm, t(f"xys_grad_norm{it}"))
+        assert torch.equal(m.vis_counts, t(f"vis_counts{it}")) and torch.equal(m.max_2Dsize, t(f"max_2Dsize{it}"))
+
+
 CASES = [
     (3500, {}),  # densify, screen-size tests on, too-big culling on
     (4500, {}),  # densify, screen-size tests off

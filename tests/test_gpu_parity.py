@@ -71,13 +71,15 @@ def test_sort_full_64bit_random():
 
 
 # ------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("view", [0, 1])
-def test_project_bit_exact(view):
+@pytest.mark.parametrize("view,off_centre", [(0, False), (1, False), (0, True)])
+def test_project_bit_exact(view, off_centre):
     sc = _scene()
     # put some Gaussians behind / beside the camera and make a few huge
     sc.means[:50] *= 4.0
     sc.scales[50:60] *= 30.0
-    vm, K = sc.viewmats[view], sc.Ks[view]
+    vm, K = sc.viewmats[view], sc.Ks[view].clone()
+    if off_centre:  # principal point at 30% / 62%: the FOV clamp stays symmetric about the optical axis
+        K[0, 2], K[1, 2] = 0.3 * sc.width, 0.62 * sc.height  # (tests/test_oracle.py::test_fov_clamp_choice...)
     ref = O.project(sc.means, sc.quats, sc.scales, vm, K, sc.width, sc.height)
     radii, m2, d, con, comp, tiles = ops.project(
         sc.means.to(DEV), sc.quats.to(DEV), sc.scales.to(DEV), vm.to(DEV), K.to(DEV), sc.width, sc.height,
@@ -495,6 +497,39 @@ def test_flow_kernels_vs_oracle():
     f0 = O.camera_flow(Z, K[0, 0], K[1, 1], K[0, 2], K[1, 2], veloc, omega)
     f1 = ops.camera_flow(Z.to(DEV), K.to(DEV), veloc.to(DEV), omega.to(DEV))
     assert rel_err(f1, f0) < REL_TOL and float(f1[3, 5].abs().max()) == 0.0
+
+
+def test_reprojection_flow_kernel_vs_oracle_and_reference_golden():
+    """F-spec' on the GPU (fg_reprojection_flow through flow.reprojection_flow_map) against the oracle
+    restatement at 400x300 and against the reference's own output (g_flow_bp.npz)."""
+    import os
+
+    import numpy as np
+
+    from freegaussian_amd import flow as FL
+
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g_flow_bp.npz"))
+    t = lambda k: torch.from_numpy(z[k])  # noqa: E731
+    fx, fy, cx, cy = t("K").tolist()
+    K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+    for tag in ("trans", "rot"):
+        out = FL.reprojection_flow_map(t("Z").to(DEV), t("Z1").to(DEV), K, t(tag + ".c2w0"), t(tag + ".c2w1"),
+                                       t("opticalflow"))  # fmt: skip
+        assert torch.allclose(out["sceneflow"].cpu(), t(tag + ".sceneflow"), atol=1e-5)
+        assert torch.allclose(out["interflow"].cpu(), t(tag + ".interflow"), atol=1e-5)
+    g = torch.Generator().manual_seed(2)
+    H, W = 300, 400
+    Z = torch.rand(H, W, 1, generator=g) * 4 + 0.5
+    Z[10:20, 30:50] = float("inf")
+    Z1 = Z + torch.randn(H, W, 1, generator=g) * 0.01
+    Z1[torch.isinf(Z1)] = 3.0
+    K = torch.tensor([[310.0, 0.0, 201.5], [0.0, 305.0, 148.0], [0.0, 0.0, 1.0]])
+    of = torch.randn(H, W, 2, generator=g)
+    ref = O.camera_flow_reprojection(Z.double(), Z1.double(), t("rot.c2w0"), t("rot.c2w1"), K.double(), of.double())
+    out = FL.reprojection_flow_map(Z.to(DEV), Z1.to(DEV), K, t("rot.c2w0"), t("rot.c2w1"), of)
+    assert rel_err(out["sceneflow"], ref["sceneflow"].float()) < REL_TOL
+    assert rel_err(out["interflow"], ref["interflow"].float()) < REL_TOL
+    assert float(out["sceneflow"][10:20, 30:50].abs().max()) == 0.0
 
 
 def test_composited_flow_channels_f1():

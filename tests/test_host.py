@@ -91,6 +91,59 @@ def test_camera_flow_matches_reference_epipolar_flow(tag):
     assert float(sf[1, 2].abs().max()) == 0.0  # infinite depth -> 0
 
 
+@pytest.mark.parametrize("tag", ["trans", "rot", "small_trans", "small_rot"])
+def test_reprojection_flow_restatement_matches_reference_epipolar_flow_bp(tag):
+    """F-spec' (preprocess/epipolar_flow_bp.py:258-298): the oracle restatement against the output
+    of the reference's own function (tests/golden/g_flow_bp.npz)."""
+    t = _load("g_flow_bp.npz")
+    fx, fy, cx, cy = t("K").tolist()
+    K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+    out = O.camera_flow_reprojection(t("Z"), t("Z1"), t(tag + ".c2w0"), t(tag + ".c2w1"), K, t("opticalflow"))
+    assert torch.allclose(out["sceneflow"], t(tag + ".sceneflow"), atol=5e-6)
+    assert torch.allclose(out["interflow"], t(tag + ".interflow"), atol=5e-6)
+    assert float(out["sceneflow"][1, 2].abs().max()) == 0.0 and float(out["interflow"][1, 2].abs().max()) == 0.0
+    # the host-side matrix of the product is the one the restatement applies
+    M = FL.reprojection_motion(t(tag + ".c2w0"), t(tag + ".c2w1"))
+    if tag == "trans":  # a translated camera: identity rotation, the WORLD-frame offset as translation
+        assert torch.allclose(M[:, :3], torch.eye(3, dtype=torch.float64), atol=1e-6)
+        assert torch.allclose(M[:, 3], (t("trans.c2w1") - t("trans.c2w0"))[:, 3].double(), atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["small_trans", "small_rot", "both"])
+def test_reprojection_flow_agrees_with_the_AB_jacobian_to_first_order(tag):
+    """The second, independent check of the A/B Jacobian's sign and layout (SURVEY.md section 8a,
+    F-spec'): for a small camera motion the reprojection's `uv - xy` equals A v / Z + B w with
+    v = M[:, 3] and w = rotation vector of M[:, :3] (M = the 3x4 matrix the reprojection applies),
+    up to second order -- when the depth of frame 1 is the depth of the moved point."""
+    from scipy.spatial.transform import Rotation as R
+
+    t = _load("g_flow_bp.npz")
+    fx, fy, cx, cy = t("K").tolist()
+    K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    if tag == "both":
+        c0 = t("small_trans.c2w0")
+        c1 = t("small_rot.c2w1").clone()
+        c1[:, 3] = t("small_trans.c2w1")[:, 3]
+    else:
+        c0, c1 = t(tag + ".c2w0"), t(tag + ".c2w1")
+    Z = t("Z").double()
+    Z[torch.isinf(Z)] = 2.0
+    M = FL.reprojection_motion(c0, c1)
+    v = M[:, 3]
+    w = torch.from_numpy(R.from_matrix(M[:, :3].numpy()).as_rotvec())
+    # consistent frame-1 depth: z of the moved point
+    H, W = Z.shape[:2]
+    yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float64), torch.arange(W, dtype=torch.float64), indexing="ij")
+    p = torch.stack([(xx - cx) / fx, (yy - cy) / fy, torch.ones_like(xx)], -1) * Z
+    Z1 = (p @ M[:, :3].T + M[:, 3])[..., 2:3]
+    raw = O.camera_flow_reprojection(Z, Z1, c0, c1, K)["raw"]
+    ab = O.camera_flow(Z[..., 0], fx, fy, cx, cy, v, w)
+    scale = float(ab.abs().max())
+    assert scale > 1e-3
+    assert float((raw - ab).abs().max()) < 0.02 * scale  # second-order remainder at |motion| ~ 3e-3
+    assert float((raw + ab).abs().max()) > 1.5 * scale  # ... and the sign is not the other one
+
+
 def test_flow_AB_sign_convention_is_the_codes():
     A, B = O.camera_flow_AB(torch.tensor([3.0]), torch.tensor([1.0]), 7.0, 9.0, 2.5, 1.5)
     assert A[0].tolist() == [[7.0, 0.0, -0.5], [0.0, 9.0, 0.5]]  # +fx, cx - x: -1x the project page

@@ -210,3 +210,45 @@ def test_c_compositor_plugs_into_the_torch_oracle_and_agrees_end_to_end():
     assert outs[0][-1].shape == (1, 3000, 2) and bool((outs[0][-1] >= outs[0][-2].abs() - 1e-6).all())
     for x, y in zip(outs[1], outs[0]):
         assert float((x - y).norm() / y.norm()) < 2e-5
+
+
+def test_fov_clamp_choice_is_the_symmetric_gsplat_1_0_form_also_off_centre():
+    """The perspective Jacobian is evaluated at x/z clamped to +-1.3 * (W/2) / fx about the OPTICAL
+    AXIS, whatever the principal point (gsplat 1.0-1.3, the versions that certainly ship the
+    `gsplat.cuda_legacy` module the reference imports, freegaussian_model.py:15,21).  Later gsplat
+    clamps to [-(cx/fx + 0.3 tan), (W - cx)/fx + 0.3 tan], identical only for cx = W/2.  A build
+    constant, written down here and in DESIGN.md: with cx = 0.3 W a Gaussian at x/z = -0.55 W/fx is
+    inside the symmetric limit (0.65 W/fx) and outside the later one (0.45 W/fx)."""
+    W = H = 200
+    fx = fy = 200.0
+    cx, cy = 0.3 * W, 0.5 * H
+    K = torch.tensor([[fx, 0.0, cx], [0.0, fy, cy], [0.0, 0.0, 1.0]])
+    z, s = 2.0, 0.25
+    xr = -0.55 * W / fx
+    means = torch.tensor([[xr * z, 0.1, z]])
+    quats, scales = torch.tensor([[1.0, 0.0, 0.0, 0.0]]), torch.full((1, 3), s)
+    ref = O.project(means, quats, scales, torch.eye(4), K, W, H)
+    radii, m2, d, con, _ = CO.project(means, quats, scales, torch.eye(4), K, W, H)
+    assert int(ref.radii[0]) > 0 and torch.equal(radii, ref.radii) and torch.equal(con, ref.conics)
+    assert float(ref.means2d[0, 0]) == pytest.approx(fx * xr + cx)  # the mean itself is never clamped
+
+    def conic(tx_over_z):
+        ty_over_z = 0.1 / z
+        J = torch.tensor([[fx / z, 0.0, -fx * tx_over_z / z], [0.0, fy / z, -fy * ty_over_z / z]], dtype=torch.float64)
+        cov = s * s * (J @ J.T) + 0.3 * torch.eye(2, dtype=torch.float64)
+        inv = torch.linalg.inv(cov)
+        return torch.stack([inv[0, 0], inv[0, 1], inv[1, 1]])
+
+    symmetric = conic(max(-1.3 * 0.5 * W / fx, xr))  # = conic(xr): not clamped
+    later = conic(max(-(cx / fx + 0.3 * 0.5 * W / fx), xr))  # clamped at -0.45
+    assert torch.allclose(ref.conics[0].double(), symmetric, rtol=1e-5)
+    assert not torch.allclose(ref.conics[0].double(), later, rtol=1e-2)
+    # and beyond the symmetric limit the Jacobian point is clamped about the axis
+    means2 = torch.tensor([[-0.8 * W / fx * z, 0.1, z]])
+    big = torch.full((1, 3), 0.5)  # large enough to reach the image from -0.5 W
+    ref2 = O.project(means2, quats, big, torch.eye(4), K, W, H)
+    assert int(ref2.radii[0]) > 0
+    J = torch.tensor([[fx / z, 0.0, fx * 0.65 * W / fx / z], [0.0, fy / z, -fy * 0.05 / z]], dtype=torch.float64)
+    cov = 0.25 * (J @ J.T) + 0.3 * torch.eye(2, dtype=torch.float64)
+    inv = torch.linalg.inv(cov)
+    assert torch.allclose(ref2.conics[0].double(), torch.stack([inv[0, 0], inv[0, 1], inv[1, 1]]), rtol=1e-5)
