@@ -111,6 +111,57 @@ def render_with_flow(
     return {"render": render[..., :n], "flow_gs": render[..., n:], "alpha": alpha, "info": info}
 
 
+def _pose_inverse_4x4(c2w: torch.Tensor) -> torch.Tensor:
+    """to4x4(inverse(pose)) of nerfstudio.utils.poses for [...,3,4] poses."""
+    R, t = c2w[..., :3, :3], c2w[..., :3, 3:]
+    Rt = R.transpose(-1, -2)
+    top = torch.cat([Rt, -Rt @ t], -1)
+    bottom = torch.zeros_like(top[..., :1, :])
+    bottom[..., 0, 3] = 1.0
+    return torch.cat([top, bottom], -2)
+
+
+def query_3d_gaussian_flow(means2d, Z0, interflow, c2w1, K, grid_size: Optional[int] = None, step: int = 8,
+                           reference_quirk: bool = True) -> Dict[str, torch.Tensor]:  # fmt: skip
+    """F-dead of SURVEY.md section 8a: ``FreeGaussianModel.query_3d_gaussian_flow`` (``grid_size=None``,
+    freegaussian_model.py:662-696) and ``query_3d_gaussian_flow_grid`` (``grid_size`` given,
+    :698-751) -- never called upstream, kept for completeness of the flow surface.  Per on-screen
+    Gaussian: sample ``interflow`` [1,H,W,2] at its ``means2d`` [1,N,2], advect, sample the depth
+    map ``Z0`` [1,H,W,1] there, lift with K^-1 and map by ``inverse(c2w1)``; off-screen rows stay 0.
+    -> {"p1_3d2": [1,N,3]} or [1,N,3*(4*(grid_size//2//step)^2+1)] for the grid variant.
+
+    ``reference_quirk=True`` is the reference's arithmetic exactly: its floor/ceil ``bilinear_interp``
+    (0 at integer coordinates, utils.py:316-343) and, in the grid variant, the height/width swap of
+    ``_, w, h, _ = Z0.shape`` (:722: neighbour rows are clamped to W-1 and columns to H-1).  False:
+    true bilinear sampling and the clamps on the right axes.  Plain torch, any device."""
+    from .utils import bilinear_interp
+
+    device = means2d.device
+    _, H, W, _ = Z0.shape
+    m = ((means2d >= 0) & (means2d < torch.tensor([W, H], device=device))).all(-1)  # x < W, y < H (:677)
+    x, y = means2d[m][..., 0], means2d[m][..., 1]  # [n]
+    if grid_size is None:
+        x, y = x.unsqueeze(0), y.unsqueeze(0)  # [1,n]
+    else:
+        ylim, xlim = (W - 1, H - 1) if reference_quirk else (H - 1, W - 1)
+        g = torch.arange(step, grid_size // 2 + 1, step, device=device)
+        gy, gx = torch.meshgrid(torch.cat([-g, g]), torch.cat([-g, g]), indexing="ij")
+        gy = (gy.reshape(-1, 1) + y).clamp(0, ylim).long()
+        gx = (gx.reshape(-1, 1) + x).clamp(0, xlim).long()
+        x, y = torch.cat([gx, x.unsqueeze(0)], 0), torch.cat([gy, y.unsqueeze(0)], 0)  # [B,n]
+    B = x.shape[0]
+    flow = bilinear_interp(interflow.float().expand(B, -1, -1, -1), x, y, reference_quirk=reference_quirk)
+    x2, y2 = x + flow[..., 0], y + flow[..., 1]
+    Z = bilinear_interp(Z0.expand(B, -1, -1, -1), x2, y2, reference_quirk=reference_quirk).permute(0, 2, 1)  # [B,1,n]
+    p_cam1 = torch.linalg.inv(K) @ torch.stack([x2, y2, torch.ones_like(x2)], dim=1) * Z  # [B,3,n]
+    p_homo = torch.cat([p_cam1, torch.ones_like(p_cam1[:, :1])], dim=1)
+    p3d = (_pose_inverse_4x4(c2w1) @ p_homo)[:, :3]  # [B,3,n]
+    N = means2d.shape[1]
+    P1 = torch.zeros((1, N, 3 * B), device=device, dtype=p3d.dtype)
+    P1[m] = p3d.permute(2, 0, 1).reshape(-1, 3 * B)
+    return {"p1_3d2": P1}
+
+
 def flow_loss(flow_gs: torch.Tensor, interflow: torch.Tensor, depth: Optional[torch.Tensor] = None) -> torch.Tensor:
     """L1 between the composited Gaussian flow and a target ``interflow`` map on pixels with
     finite depth (build choice, see module docstring)."""

@@ -10,8 +10,9 @@
                              (freegaussian_pipeline.py:25,43-50).
 
 The tables are plain data so the build's own harness (harness.py) can use them without
-nerfstudio; ``nerfstudio_method_specs()`` wraps them in ``MethodSpecification`` objects when
-nerfstudio is importable (it is not in this image)."""
+nerfstudio; with nerfstudio installed the entry points resolve through ``nerfstudio_adapter``
+(pyproject.toml of this repo), which reuses the reference's own ``TrainerConfig`` -- pipeline,
+data manager and parser included -- and only rebinds the raster call."""
 from __future__ import annotations
 
 from dataclasses import dataclass
@@ -54,24 +55,10 @@ METHODS = {
 
 
 def nerfstudio_method_specs():
-    """MethodSpecification objects for both entry points; requires nerfstudio."""
-    try:
-        from nerfstudio.engine.optimizers import AdamOptimizerConfig
-        from nerfstudio.engine.schedulers import ExponentialDecaySchedulerConfig
-        from nerfstudio.engine.trainer import TrainerConfig
-        from nerfstudio.plugins.types import MethodSpecification
-    except ImportError as e:  # pragma: no cover - nerfstudio is absent in the build image
-        raise ImportError("nerfstudio is not installed: use freegaussian_amd.harness instead") from e
+    """MethodSpecification objects for both entry points -- complete ``TrainerConfig``s including
+    ``pipeline=`` (the reference's FreeGaussianPipelineConfig with its data manager / parser, the
+    model's raster call rebound to this package): ``nerfstudio_adapter`` builds them from the
+    reference's own spec.  Requires nerfstudio and the reference package to be importable."""
+    from . import nerfstudio_adapter as A
 
-    def optim_table(table):
-        out = {}
-        for name, o in table.items():
-            sched = None if o.lr_final is None else ExponentialDecaySchedulerConfig(lr_final=o.lr_final, max_steps=o.max_steps)
-            out[name] = {"optimizer": AdamOptimizerConfig(lr=o.lr, eps=o.eps), "scheduler": sched}
-        return out
-
-    return {
-        name: MethodSpecification(TrainerConfig(method_name=name, optimizers=optim_table(m["optimizers"]), **m["trainer"]),
-                                  description=m["description"])
-        for name, m in METHODS.items()
-    }  # fmt: skip
+    return {name: getattr(A, attr) for name, attr in A.METHOD_ENTRY_POINTS.items()}

@@ -14,6 +14,8 @@ What is captured -- data only, no reference source text 
                 rotation pair                               (preprocess/epipolar_flow.py:212-321)
   g_flow_bp.npz the exact-reprojection variant (F-spec') on the same pairs + small-motion pairs
                                                             (preprocess/epipolar_flow_bp.py:229-298)
+  g_flow_query.npz query_3d_gaussian_flow / query_3d_gaussian_flow_grid (dead code upstream)
+                                                            (freegaussian_model.py:662-751)
   g_densify.npz refinement_after / split_gaussians / dup_gaussians / cull_gaussians / the
                 optimizer surgery and after_train_iter, executed as methods of a stub ``self``
                                                             (freegaussian_model.py:313-392, :404-571)
@@ -433,6 +435,40 @@ def gen_densify():
     print("g_densify.npz", len(d))
 
 
+def gen_flow_query(U):
+    """query_3d_gaussian_flow / _grid (freegaussian_model.py:662-751, dead code upstream) as methods
+    of a stub; `inverse` / `to4x4` are the batched nerfstudio pose helpers they call."""
+    from torch.linalg import inv
+
+    def inverse(p):
+        R, t = p[..., :3, :3], p[..., :3, 3:]
+        return torch.cat([R.transpose(-1, -2), -R.transpose(-1, -2) @ t], -1)
+
+    def to4x4(p):
+        bottom = torch.zeros_like(p[..., :1, :])
+        bottom[..., 0, 3] = 1.0
+        return torch.cat([p, bottom], -2)
+
+    src = slice_methods(os.path.join(REF, "freegaussian", "freegaussian_model.py"), "FreeGaussianModel",
+                        ["query_3d_gaussian_flow", "query_3d_gaussian_flow_grid"])  # fmt: skip
+    ns = {"torch": torch, "inv": inv, "inverse": inverse, "to4x4": to4x4, "bilinear_interp": U.bilinear_interp}
+    exec(compile(src, "<reference flow query slice>", "exec"), ns)
+    g = torch.Generator().manual_seed(11)
+    H, W, N = 24, 40, 30
+    means2d = torch.rand(1, N, 2, generator=g) * torch.tensor([W + 8.0, H + 8.0]) - 4.0  # some off screen
+    means2d[0, 3] = torch.tensor([7.0, 5.0])  # integer coordinates: the bilinear quirk gives 0 there
+    Z0 = torch.rand(1, H, W, 1, generator=g) * 3 + 1
+    interflow = torch.randn(1, H, W, 2, generator=g) * 1.5
+    c2w1 = torch.cat([torch.linalg.qr(torch.randn(3, 3, generator=g)).Q, torch.randn(3, 1, generator=g)], -1)[None]
+    K = torch.tensor([[30.0, 0.0, 19.5], [0.0, 28.0, 11.5], [0.0, 0.0, 1.0]])
+    d = {"means2d": means2d, "Z0": Z0, "interflow": interflow, "c2w1": c2w1, "K": K}
+    d["plain"] = ns["query_3d_gaussian_flow"](None, means2d, Z0, interflow, c2w1, K)["p1_3d2"]
+    d["grid_16_8"] = ns["query_3d_gaussian_flow_grid"](None, means2d, Z0, interflow, c2w1, K)["p1_3d2"]
+    d["grid_8_2"] = ns["query_3d_gaussian_flow_grid"](None, means2d, Z0, interflow, c2w1, K, 8, 2)["p1_3d2"]
+    np.savez(os.path.join(OUT, "g_flow_query.npz"), **{k: t.numpy() for k, t in d.items()})
+    print("g_flow_query.npz", {k: tuple(v.shape) for k, v in d.items() if k in ("plain", "grid_16_8", "grid_8_2")})
+
+
 if __name__ == "__main__":
     U = load_utils()
     gen_utils(U)
@@ -440,3 +476,4 @@ if __name__ == "__main__":
     gen_flow()
     gen_flow_bp()
     gen_densify()
+    gen_flow_query(U)

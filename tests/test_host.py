@@ -144,6 +144,22 @@ def test_reprojection_flow_agrees_with_the_AB_jacobian_to_first_order(tag):
     assert float((raw + ab).abs().max()) > 1.5 * scale  # ... and the sign is not the other one
 
 
+def test_query_3d_gaussian_flow_matches_the_references_dead_code():
+    """F-dead (freegaussian_model.py:662-751; zero call sites upstream): both variants against the
+    output of the reference's own methods, quirks included; and the quirk-free mode differs exactly
+    where the quirks bite."""
+    t = _load("g_flow_query.npz")
+    args = (t("means2d"), t("Z0"), t("interflow"), t("c2w1"), t("K"))
+    assert torch.equal(FL.query_3d_gaussian_flow(*args)["p1_3d2"], t("plain"))
+    assert torch.equal(FL.query_3d_gaussian_flow(*args, grid_size=16, step=8)["p1_3d2"], t("grid_16_8"))
+    assert torch.equal(FL.query_3d_gaussian_flow(*args, grid_size=8, step=2)["p1_3d2"], t("grid_8_2"))
+    on = ((t("means2d") >= 0) & (t("means2d") < torch.tensor([40.0, 24.0]))).all(-1)[0]
+    assert 0 < int(on.sum()) < 30 and float(t("plain")[0][~on].abs().max()) == 0.0  # off-screen rows stay 0
+    fixed = FL.query_3d_gaussian_flow(*args, reference_quirk=False)["p1_3d2"]
+    assert float(fixed[0, 3].abs().max()) > 0.0  # integer coordinates: a real sample instead of the quirk's 0 weights
+    assert not torch.equal(fixed[0, 3], t("plain")[0, 3])
+
+
 def test_flow_AB_sign_convention_is_the_codes():
     A, B = O.camera_flow_AB(torch.tensor([3.0]), torch.tensor([1.0]), 7.0, 9.0, 2.5, 1.5)
     assert A[0].tolist() == [[7.0, 0.0, -0.5], [0.0, 9.0, 0.5]]  # +fx, cx - x: -1x the project page
