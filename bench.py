@@ -54,7 +54,7 @@ def parse(argv=None):
     ap.add_argument("--graph-only", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--fixed-view", action="store_true", help="render view `rank` every step instead of cycling the ring")
     ap.add_argument("--cpu-crop", type=str, default="480x272")  # ~4 s of oracle time per run on the GPU box
-    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the faster of 8 and all host threads")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the faster of 8 and 32 host threads")
     return ap.parse_args(argv)
 
 
@@ -242,8 +242,9 @@ def cpu_baseline(scene, view, crop, sh_degree, threads=0):
     """The pure-PyTorch CPU oracle (oracle/raster_oracle.py, a port: the reference's own raster is
     the absent CUDA-only gsplat) on a centre crop of the same view, all Gaussians projected; fwd +
     bwd.  Protocol of BASELINE.md section 2: 1 warm-up + 3 timed runs, median; the thread count is
-    the faster of 8 and all host threads in the warm-ups (the oracle is thousands of small tensor
-    ops: beyond a few threads they mostly add synchronisation cost), both warm-up times reported.
+    the faster of 8 and 32 in the warm-ups (the oracle is thousands of small tensor ops: every one
+    is a fork/join over the thread pool, and on the 256-thread GPU box a full-width pool made a run
+    take minutes instead of seconds), both warm-up times reported next to the host's thread count.
     The same crop is rendered and differentiated by the HIP path: PSNR and the relative L2 error of
     every gradient against the oracle's are part of the line."""
     import torch
@@ -255,7 +256,7 @@ def cpu_baseline(scene, view, crop, sh_degree, threads=0):
     K[1, 2] -= y0
     host = os.cpu_count() or 1
     vr = torch.randn(1, ch, cw, 3, generator=torch.Generator().manual_seed(1))
-    candidates = [threads] if threads > 0 else sorted({min(host, 8), host})
+    candidates = [threads] if threads > 0 else sorted({min(host, 8), min(host, 32)})
     warm = {}
     for c in candidates:
         torch.set_num_threads(c)
@@ -290,15 +291,16 @@ def cpu_full_frame(scene, view, sh_degree):
     from oracle import c_oracle as CO
 
     host = os.cpu_count() or 1
-    torch.set_num_threads(host)
+    torch.set_num_threads(min(host, 32))  # the torch stages (projection, SH, sort); the C compositing is OpenMP over all cores
     W, H = scene.width, scene.height
     K = scene.Ks[view]
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1))
     dt, r_ref, ins_ref, info_ref = _oracle_run(scene, view, K, W, H, sh_degree, vr, compositor=CO.composite, absgrad=True)
     parity = _hip_parity(scene, view, K, W, H, sh_degree, vr, r_ref, ins_ref, info_ref) if torch.cuda.is_available() else {}
     return {"value": W * H / dt / 1e6, "unit": "Mpix/s", "cores": host, "kind": "port", "seconds": round(dt, 2), **parity,
-            "sample": f"the whole {W}x{H} frame of view {view}, fwd+bwd, 1 run; torch projection / SH / sort + C "
-            "compositing (OpenMP), all host threads"}  # fmt: skip
+            "sample": f"the whole {W}x{H} frame of view {view}, fwd+bwd, 1 run; torch projection / SH / sort "
+            f"({min(host, 32)} threads) + C compositing (forward OpenMP over all {host} host threads; backward one "
+            "thread with double accumulators, so that its sums do not depend on scheduling)"}  # fmt: skip
 
 
 def under_profiler():
@@ -487,7 +489,8 @@ def main(argv=None):
 
     N = args.n_gauss
     V = int((info["radii"] > 0).sum())
-    I = int(info["flatten_ids"].numel())
+    I_raster = int(info["raster_flatten_ids"].numel())  # entries the compositing walks (footprint rectangles)
+    I = int(info["flatten_ids"].numel())  # the reference's list length (radius boxes): SURVEY section 8d's I
     P = W * H
     T = info["tile_width"] * info["tile_height"]
     k = (args.sh_degree + 1) ** 2
@@ -573,6 +576,10 @@ def main(argv=None):
             + ("view = rank (fixed)" if args.fixed_view else f"view = (rank + step) mod {N_VIEWS} around the 8-view ring")
             + ", fwd+bwd, RGB, absgrad" + (f", RCCL gradient exchange ({exchange})" if world > 1 else ""),
             "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
+            "I_raster": I_raster,
+            "I_note": "I = tile intersections of the reference algorithm (radius-box rectangles; the formulas of SURVEY "
+            "section 8d use it); I_raster = entries of the lists actually binned and composited: the footprint rectangles "
+            "drop (splat, tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
             "counts_are_for_view": view,
             "binning": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I "
             f"(the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",

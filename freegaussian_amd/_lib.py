@@ -34,6 +34,7 @@ SIGNATURES = {
     "fg_bin_prepare_workspace_bytes": (c_size_t, [c_int]),
     "fg_bin_prepare": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
     "fg_bin_prepare_rects": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
+    "fg_bin_prepare_keys": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_workspace_bytes": (c_size_t, [c_int64]),
     "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_sort_capacity": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t,
@@ -50,13 +51,13 @@ SIGNATURES = {
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
-                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P]),
+                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_sh_pack_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                   c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_raw_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P, P, c_int,
                                       c_int, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P,
-                                      P]),
+                                      P, P, P]),
     "fg_preprocess_raw_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                       c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
@@ -77,7 +78,7 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 _lib = None
 
 

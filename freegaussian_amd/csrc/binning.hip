@@ -445,6 +445,29 @@ extern "C" int fg_bin_prepare_rects(int N, const float* depths, const int32_t* r
                          workspace, workspace_bytes, stream);
 }
 
+extern "C" int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
+                                   int64_t* cum_tiles, int32_t* rects_sorted, void* workspace,
+                                   size_t workspace_bytes, fg_stream_t stream) {
+  if (N < 0) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!depth_keys || !tile_rects || !order || !cum_tiles || !rects_sorted || !workspace) return FG_ERR_INVALID_ARG;
+  if (workspace_bytes < fg_bin_prepare_workspace_bytes(N)) return FG_ERR_WORKSPACE;
+  hipStream_t s = fg_hip_stream(stream);
+  char* ws = static_cast<char*>(workspace);
+  ws += al256((size_t)N * 4);  // (the key array of the other entry points: unused here)
+  void* sort_ws = ws;
+  const size_t sort_bytes = fg_sort::workspace_bytes<uint32_t>(N);
+  ws += sort_bytes;
+  int64_t* block_sums = reinterpret_cast<int64_t*>(ws);
+  const int rc = fg_sort::sort_pairs<uint32_t>(N, depth_keys, reinterpret_cast<uint32_t*>(order), 32, sort_ws,
+                                               sort_bytes, s, nullptr, /*iota_vals=*/true);
+  if (rc != FG_OK) return rc;
+  launch_scan(N, nullptr, (const int32_t*)order, block_sums, cum_tiles, s, reinterpret_cast<int32_t*>(sort_ws),
+              reinterpret_cast<const int2*>(tile_rects), rects_sorted);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
 extern "C" size_t fg_bin_emit_workspace_bytes(int64_t n_isects) {
   // covers both layouts: 32-bit keys in the caller's buffer, or 16-bit keys + their sort scratch
   // in here (same byte count up to alignment padding)

@@ -24,6 +24,38 @@ namespace fg {
 
 __device__ __forceinline__ int lane_id() { return __lane_id(); }
 
+// ---- where can a splat reach alpha >= 1/255? ------------------------------------------------
+// alpha = o exp(-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o); the ellipse sigma <= tau of the conic
+// (a, b, c) has the axis-aligned half extents sqrt(2 tau c / det), sqrt(2 tau a / det).  The extents
+// are inflated (x1.0005 + 0.02 px) so that rounding -- of the 1-ulp hardware log / rcp / sqrt used
+// here and of the pixel test itself -- can only ever ADD work: whatever lies outside them would have
+// failed the per-pixel alpha test anyway, so culling by them never changes a result.  ONE function
+// for the two users (the strip masks of the raster kernels, the tight tile rectangles of the
+// binning), so both cull by identical numbers.
+//   returns 0: the splat reaches 1/255 nowhere;  1: ex / ey valid;  2: no culling possible (NaN
+//   opacity -- the reference behaviour is to propagate it --, degenerate conic)
+__device__ __forceinline__ int alpha_extent(float o, float a, float b, float c, float& ex, float& ey) {
+  ex = ey = 0.f;
+  if (!(o == o)) return 2;
+  const float t255 = 255.f * o;
+  if (!(t255 >= 1.f)) return 0;
+  const float det = a * c - b * b;
+  if (!(det > 0.f)) return 2;
+  const float tau2 = 2.f * __logf(t255) + 1e-4f;
+  const float rdet = __builtin_amdgcn_rcpf(det);
+  ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet);
+  ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
+  if (!(ex == ex) || !(ey == ey)) return 2;
+  ex = ex * 1.0005f + 0.02f;
+  ey = ey * 1.0005f + 0.02f;
+  return 1;
+}
+// does the extent [g - e, g + e] reach a pixel centre of [lo + 0.5, lo + span - 0.5]?  (the comparison
+// form both users share; span = 16 for a tile side, 4 for a strip)
+__device__ __forceinline__ bool extent_reaches(float g, float e, float lo, float span) {
+  return !(g + e < lo + 0.5f || g - e > lo + (span - 0.5f));
+}
+
 // ---- DPP / permlane cross-lane moves (no LDS traffic) ------------------------------------
 template <int CTRL, int ROW_MASK = 0xf, int BANK_MASK = 0xf, bool BOUND = true>
 __device__ __forceinline__ float dpp_mov(float v) {

@@ -17,6 +17,8 @@
 #include "sh_math.h"
 #include "slab_io.h"
 
+#include <stdlib.h>
+
 namespace {
 using namespace fgp;
 using namespace fgsh;
@@ -81,11 +83,35 @@ __device__ __forceinline__ Activated load_activated(const RawForm& raw, int i, c
 
 // raw form: SH coefficient rows of a workgroup, split in two arrays -> LDS rows [dc | rest]
 __device__ __forceinline__ void coeffs_to_lds(float* lds, const RawForm& raw, const float* __restrict__ colors,
-                                              int row0, int nrows, int k_stored, int kk) {
-  slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc
+                                              int row0, int nrows, int k_stored, int kk,
+                                              const uint8_t* row_live = nullptr) {
+  slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc: 12 B rows, always fetched
   if (kk > 1)
     slab_to_lds_at(lds, 3, raw.features_rest + (size_t)row0 * 3 * (k_stored - 1), nrows, 3 * (k_stored - 1),
-                   3 * (kk - 1));
+                   3 * (kk - 1), row_live);
+}
+// all coefficient rows of the workgroup -> LDS, skipping rows whose flag in row_live is 0
+__device__ __forceinline__ void stage_coeffs(float* lds, const FeatLayout& fl, const RawForm& raw,
+                                             const float* __restrict__ colors, int row0, int nrows, int kk,
+                                             const uint8_t* row_live) {
+  if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk, row_live);
+  else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk, row_live);
+}
+
+// Shrink the tile range [t0, t1) to the tiles whose pixel centres the extent [g - e, g + e] reaches
+// (fg::extent_reaches, the comparison the raster kernels' strip masks use): a closed-form guess,
+// then one fix-up step each way against that very comparison, so that the two can never disagree.
+__device__ __forceinline__ void tighten_tile_range(float g, float e, float ts, int& t0, int& t1) {
+  if (t1 <= t0) return;
+  const float lo_f = fminf(fmaxf(ceilf((g - e - (ts - 0.5f)) / ts), (float)t0), (float)t1);
+  const float hi_f = fminf(fmaxf(floorf((g + e - 0.5f) / ts), (float)t0 - 1.f), (float)(t1 - 1));
+  int lo = (int)lo_f, hi = (int)hi_f;  // first tile, last tile (inclusive)
+  if (lo > t0 && fg::extent_reaches(g, e, (float)(lo - 1) * ts, ts)) --lo;
+  else if (lo <= hi && !fg::extent_reaches(g, e, (float)lo * ts, ts)) ++lo;
+  if (hi < t1 - 1 && fg::extent_reaches(g, e, (float)(hi + 1) * ts, ts)) ++hi;
+  else if (hi >= lo && !fg::extent_reaches(g, e, (float)hi * ts, ts)) --hi;
+  t0 = lo;
+  t1 = hi + 1 > lo ? hi + 1 : lo;
 }
 
 // PACK_ONLY: the projection outputs (radii, means2d, depths, conics, compensations) are INPUTS
@@ -100,16 +126,17 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
                       float eps2d, float near_plane, float far_plane, float radius_clip, int tile_size, int tile_w,
                       int tile_h, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
                       float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ compensations,
-                      int32_t* __restrict__ tiles_touched, float* __restrict__ splats) {
+                      int32_t* __restrict__ tiles_touched, float* __restrict__ splats,
+                      uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects, int skip_culled) {
   __shared__ float lds[BLOCK * ROW];  // coefficient slab, then the record slab
+  __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
-  if (kk > 0) {
-    if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
-    else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
-  }
+  // skip_culled: the coefficient rows are fetched AFTER the projection, visible Gaussians only (a
+  // culled Gaussian's row is 192 of its 236 bytes); otherwise up front, under the projection
+  if (kk > 0 && !skip_culled) stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, nullptr);
 
   // ---- K1 -------------------------------------------------------------------------------------
   bool ok = false;
@@ -144,13 +171,14 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   for (int c = 0; c < REC; ++c) rec[c] = 0.f;
   int32_t radius = 0, touched = 0;
   float o_comp = 0.f;
+  int x0 = 0, x1 = 0, y0 = 0, y1 = 0;  // the reference's tile rectangle (radius box)
   if (ok) {
     radius = (int32_t)f.radius_f;
     const float ts = (float)tile_size;
     const float r = (float)radius / ts;
     const float tx = f.m2x / ts, ty = f.m2y / ts;
-    const int x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
-    const int y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
+    x0 = min(max((int)floorf(tx - r), 0), tile_w), x1 = min(max((int)ceilf(tx + r), 0), tile_w);
+    y0 = min(max((int)floorf(ty - r), 0), tile_h), y1 = min(max((int)ceilf(ty + r), 0), tile_h);
     touched = (x1 - x0) * (y1 - y0);
     o_comp = f.comp;
     rec[0] = f.m2x; rec[1] = f.m2y;
@@ -165,9 +193,35 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
     conics[3 * i] = rec[3]; conics[3 * i + 1] = rec[4]; conics[3 * i + 2] = rec[5];
     if (compensations) compensations[i] = o_comp;
     tiles_touched[i] = touched;
+    // Inputs of the depth-first binning, produced here because everything is in registers: the
+    // depth sort key and the FOOTPRINT rectangle -- the radius box shrunk to the tiles the splat can
+    // reach with alpha >= 1/255 (fg::alpha_extent; 31% fewer (splat, tile) pairs on the 1M / 1080p
+    // scene: a 3-sigma box ignores the opacity).  Lists built from it are the reference's lists
+    // minus entries that contribute to no pixel, in the same order.
+    if (depth_keys) depth_keys[i] = ok ? (uint32_t)__float_as_int(f.pz) : 0xFFFFFFFFu;
+    if (tile_rects) {
+      int2 rc = make_int2(0, 0);
+      if (ok) {
+        float ex, ey;
+        const int kind = fg::alpha_extent(rec[2], rec[3], rec[4], rec[5], ex, ey);
+        int a0 = x0, a1 = x1, b0 = y0, b1 = y1;
+        if (kind == 0) a1 = a0;
+        if (kind == 1) {
+          tighten_tile_range(rec[0], ex, (float)tile_size, a0, a1);
+          tighten_tile_range(rec[1], ey, (float)tile_size, b0, b1);
+        }
+        if (a1 > a0 && b1 > b0) rc = make_int2(a0 | (b0 << 16), (a1 - a0) | ((b1 - b0) << 16));
+      }
+      tile_rects[i] = rc;
+    }
   }
 
   // ---- K2 + features ----------------------------------------------------------------------------
+  if (kk > 0 && skip_culled) {
+    row_live[threadIdx.x] = ok;
+    __syncthreads();
+    stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, row_live);
+  }
   if (kk > 0) __syncthreads();
   if (ok) {
     int c0 = 6;
@@ -229,15 +283,20 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
                       const float* __restrict__ v_means2d, int m2_stride, const float* __restrict__ v_depths,
                       const float* __restrict__ v_conics, float* __restrict__ v_means, float* __restrict__ v_quats,
                       float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
-                      float* __restrict__ v_extra) {
+                      float* __restrict__ v_extra, int skip_culled) {
   __shared__ float lds[BLOCK * ROW];       // coefficient slab in, v_coeffs slab out
+  __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
+  const bool active = (i < N) && radii[i] > 0;
   if (kk > 1) {
-    if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk);
-    else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk);
+    if (skip_culled) {  // only the visible Gaussians' coefficient rows are read back
+      row_live[threadIdx.x] = active;
+      __syncthreads();
+    }
+    stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, skip_culled ? row_live : nullptr);
   }
   __syncthreads();
 
@@ -251,7 +310,6 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   float rec[REC];
 #pragma unroll
   for (int c = 0; c < REC; ++c) rec[c] = 0.f;
-  const bool active = (i < N) && radii[i] > 0;
   Activated a;
   if (active) {
     // the lane's own 64-byte gradient record, four 16-byte loads (the lines are shared by the four
@@ -398,6 +456,15 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   }
 }
 
+// FG_PREPROCESS_SKIP_CULLED=0: fetch every coefficient row up front (the round-1 behaviour; A/B)
+int skip_culled_rows() {
+  static const int v = [] {
+    const char* e = getenv("FG_PREPROCESS_SKIP_CULLED");
+    return (e && e[0] == '0') ? 0 : 1;
+  }();
+  return v;
+}
+
 bool layout_ok(const FeatLayout& fl) {
   if (fl.sh_degree > 3 || fl.n_extra < 0 || fl.n_color < 0) return false;
   if (fl.sh_degree >= 0 && (fl.k_stored < (fl.sh_degree + 1) * (fl.sh_degree + 1) || fl.k_stored > 16)) return false;
@@ -416,7 +483,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
                           int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                           int tile_size, int antialiased, int32_t* radii, float* means2d, float* depths,
                           float* conics, float* compensations, int32_t* tiles_touched, float* splats,
-                          fg_stream_t stream) {
+                          uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream) {
   FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
   if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
@@ -429,7 +496,8 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
   hipLaunchKernelGGL(preprocess_fwd_kernel<false>, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
                      fl, raw, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
                      near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
-                     depths, conics, compensations, tiles_touched, splats);
+                     depths, conics, compensations, tiles_touched, splats, depth_keys,
+                     reinterpret_cast<int2*>(tile_rects), skip_culled_rows());
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -462,7 +530,8 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
                      fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, v_rgb_floats, means, quats, scales, opacities, colors,
                      viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
-                     v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra);
+                     v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
+                     skip_culled_rows());
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -476,11 +545,11 @@ extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, 
                                  float near_plane, float far_plane, float radius_clip, int tile_size,
                                  int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                                  float* compensations, int32_t* tiles_touched, float* splats,
-                                 fg_stream_t stream) {
+                                 uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{0, nullptr, nullptr, nullptr}, means, quats, scales, opacities, colors,
                                sh_degree, k_stored, n_color, with_depth, extra, n_extra, viewmat, K, width, height,
                                eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased, radii, means2d,
-                               depths, conics, compensations, tiles_touched, splats, stream);
+                               depths, conics, compensations, tiles_touched, splats, depth_keys, tile_rects, stream);
 }
 
 extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
@@ -506,12 +575,13 @@ extern "C" int fg_preprocess_raw_fwd(int N, const float* means, const float* qua
                                      int width, int height, float eps2d, float near_plane, float far_plane,
                                      float radius_clip, int tile_size, int antialiased, int32_t* radii,
                                      float* means2d, float* depths, float* conics, float* compensations,
-                                     int32_t* tiles_touched, float* splats, fg_stream_t stream) {
+                                     int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
+                                     int32_t* tile_rects, fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{1, d_quats, d_scales, features_rest}, means, quats, log_scales,
                                opacity_logits, features_dc, sh_degree, k_stored, 3, with_depth, extra, n_extra,
                                viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
                                antialiased, radii, means2d, depths, conics, compensations, tiles_touched, splats,
-                               stream);
+                               depth_keys, tile_rects, stream);
 }
 
 extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
@@ -561,7 +631,7 @@ extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities,
                      N, fl, RawForm{0, nullptr, nullptr, nullptr}, means, nullptr, nullptr, opacities, colors, extra,
                      viewmat, nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 16, 0, 0, antialiased, const_cast<int32_t*>(radii),
                      const_cast<float*>(means2d), const_cast<float*>(depths), const_cast<float*>(conics),
-                     const_cast<float*>(compensations), nullptr, splats);
+                     const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, 0);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -163,7 +163,7 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
     const int64_t i = wave_base + k * 64 + lane;
     const bool in = i < cap;  // in bounds of the buffers; the count proper is applied below
     key[k] = in ? keys_in[i] : (KeyT)~(KeyT)0;
-    val[k] = in ? vals_in[i] : 0u;
+    val[k] = in ? (vals_in ? vals_in[i] : (uint32_t)i) : 0u;  // no input values: the element's index
   }
   if (n_dev) n = min(n, *n_dev);  // device-side count: read alongside the keys, not in front of them
 #pragma unroll
@@ -272,9 +272,15 @@ static inline size_t workspace_bytes(int64_t n) {
 // Sorts in place (result copied back into keys/vals if it ends in the scratch copy).
 // With n_dev != nullptr the element count is min(n, *n_dev), read on the device: n is then only the
 // capacity the launch grids and the scratch are sized for (no host round trip for the count).
+// iota_vals: the values are the element indices 0..n-1 and `vals` is output only (the first pass
+// numbers them itself instead of reading an array somebody had to fill).
 template <typename KeyT>
 static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit, void* workspace,
-                             size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr) {
+                             size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr, bool iota_vals = false) {
+  if (iota_vals && (n <= 1 || end_bit <= 0)) {
+    if (n == 1 && hipMemsetAsync(vals, 0, 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    return FG_OK;
+  }
   if (n <= 1 || end_bit <= 0) return FG_OK;
   if (n > 0xFFFFFFFFll) return FG_ERR_UNSUPPORTED;
   if (ws_bytes < workspace_bytes<KeyT>(n)) return FG_ERR_WORKSPACE;
@@ -303,10 +309,11 @@ static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit,
 #define FG_SCATTER(NB)                                                                                         \
   if (small)                                                                                                    \
     hipLaunchKernelGGL((scatter_kernel<KeyT, NB, FG_SORT_KPT_SMALL>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev,    \
-                       kin, vin, kout, vout, shift, block_hist, digit_total);                                   \
+                       kin, vsrc, kout, vout, shift, block_hist, digit_total);                                  \
   else                                                                                                          \
     hipLaunchKernelGGL((scatter_kernel<KeyT, NB, FG_SORT_KPT>), dim3(nb), dim3(BLOCK), 0, s, n, n_dev, kin,     \
-                       vin, kout, vout, shift, block_hist, digit_total)
+                       vsrc, kout, vout, shift, block_hist, digit_total)
+    const uint32_t* vsrc = (iota_vals && p == 0) ? nullptr : vin;
     switch (nbits) {
       case 8: FG_SCATTER(8); break;
       case 7: FG_SCATTER(7); break;

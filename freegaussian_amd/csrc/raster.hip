@@ -332,32 +332,18 @@ __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (
   for (int c = 0; c < C; ++c) f[c] = tmp[c];
 }
 
-// Which of the tile's four 4-row strips can this splat reach with alpha >= 1/255?
-// alpha = o exp(-sigma) >= 1/255  <=>  sigma <= tau = ln(255 o); the ellipse sigma <= tau has the
-// axis-aligned half extents sqrt(2 tau c / det), sqrt(2 tau a / det).  The extents are inflated
-// (x1.0005 + 0.02 px) so that rounding can only ever ADD work: a culled (splat, strip) pair would
-// have failed the per-pixel alpha test anyway, i.e. the culling never changes a result.
+// Which of the tile's four 4-row strips can this splat reach with alpha >= 1/255?  (fg::alpha_extent:
+// result-preserving by construction; shared with the binning's tight tile rectangles.)
 __device__ __forceinline__ unsigned strip_mask(float gx, float gy, float o, float a, float b, float c,
                                                float tile_x0, float tile_y0) {
-  if (!(o == o)) return 0xFu;           // NaN opacity: keep the reference behaviour (propagates)
-  const float t255 = 255.f * o;
-  if (!(t255 >= 1.f)) return 0u;        // can never reach 1/255
-  const float det = a * c - b * b;
-  if (!(det > 0.f)) return 0xFu;        // degenerate conic: no culling
-  // 1-ulp hardware log / rcp / sqrt: their error is orders of magnitude inside the inflation below
-  const float tau2 = 2.f * __logf(t255) + 1e-4f;
-  const float rdet = __builtin_amdgcn_rcpf(det);
-  float ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet), ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
-  if (!(ex == ex) || !(ey == ey)) return 0xFu;
-  ex = ex * 1.0005f + 0.02f;
-  ey = ey * 1.0005f + 0.02f;
-  if (gx + ex < tile_x0 + 0.5f || gx - ex > tile_x0 + (TILE - 0.5f)) return 0u;
+  float ex, ey;
+  const int kind = fg::alpha_extent(o, a, b, c, ex, ey);
+  if (kind != 1) return kind == 0 ? 0u : 0xFu;
+  if (!fg::extent_reaches(gx, ex, tile_x0, (float)TILE)) return 0u;
   unsigned m = 0;
 #pragma unroll
-  for (int s4 = 0; s4 < 4; ++s4) {
-    const float ylo = tile_y0 + 4.f * s4 + 0.5f;
-    if (!(gy + ey < ylo || gy - ey > ylo + 3.f)) m |= 1u << s4;
-  }
+  for (int s4 = 0; s4 < 4; ++s4)
+    if (fg::extent_reaches(gy, ey, tile_y0 + 4.f * s4, 4.f)) m |= 1u << s4;
   return m;
 }
 

@@ -34,24 +34,35 @@ namespace fgsh {
 // in the row's last pad slot (column STRIDE-1), so there is no divergent code between load and store.
 constexpr int SLAB_MAX_Q = (BLOCK * 48 / 4 + BLOCK - 1) / BLOCK;  // float4 per lane of a full slab
 
+// row_live (LDS, one byte per row, nullable): rows whose flag is 0 are not fetched (their LDS rows
+// keep whatever they held; nobody reads them) -- culled Gaussians' 192-byte coefficient rows are a
+// sixth of the forward's traffic on the 1M / 1080p scene.
 template <int STRIDE = ROW>
 __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const float* __restrict__ src, int nrows,
-                                               int row_floats, int use_floats) {
+                                               int row_floats, int use_floats, const uint8_t* row_live = nullptr) {
   const int total = nrows * row_floats;
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const float4* src4 = reinterpret_cast<const float4*>(src);
     const int total4 = total / 4;
     const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
     float4 v[SLAB_MAX_Q];
+    bool fetch[SLAB_MAX_Q];
 #pragma unroll
     for (int t = 0; t < SLAB_MAX_Q; ++t) {
       const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) v[t] = FG_SLAB_LOAD(&src4[q]);
+      fetch[t] = q < total4;
+      if (row_live && fetch[t]) {  // a float4 touches at most two rows (rows are >= 3 floats)
+        const int e = 4 * q;
+        const int r = (int)(((unsigned)e * magic) >> 20);
+        const int r2 = (int)(((unsigned)(e + 3) * magic) >> 20);
+        fetch[t] = row_live[r] | row_live[r2 < nrows ? r2 : r];
+      }
+      if (fetch[t]) v[t] = FG_SLAB_LOAD(&src4[q]);
     }
 #pragma unroll
     for (int t = 0; t < SLAB_MAX_Q; ++t) {
       const int q = threadIdx.x + t * BLOCK;
-      if (q < total4) {
+      if (fetch[t]) {
         const int e = 4 * q;
         const int r = (int)(((unsigned)e * magic) >> 20), c = e - r * row_floats;
         const float vv[4] = {v[t].x, v[t].y, v[t].z, v[t].w};
@@ -68,7 +79,7 @@ __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const f
     const int tot = nrows * use_floats;
     for (int e = threadIdx.x; e < tot; e += BLOCK) {
       const int r = e / use_floats, c = e - r * use_floats;
-      lds[r * STRIDE + lds_col0 + c] = src[(size_t)r * row_floats + c];
+      if (!row_live || row_live[r]) lds[r * STRIDE + lds_col0 + c] = src[(size_t)r * row_floats + c];
     }
   }
 }

@@ -47,7 +47,7 @@ class GraphedRaster:
                                        sh_degree=self.sh_degree, render_mode=self.render_mode, packed=False,
                                        absgrad=True)  # fmt: skip
             r.backward(self.v_render)
-        return r.detach(), a.detach(), int(info["flatten_ids"].numel())
+        return r.detach(), a.detach(), int(info["raster_flatten_ids"].numel())
 
     def _capture(self):
         import gc

@@ -230,6 +230,11 @@ class FreeGaussianModel(nn.Module):
             assert bool((cam0.get_intrinsics_matrices() == camera.get_intrinsics_matrices()).all()), \
                 "Intrinsics matrices should be the same"
         s = self._get_downscale_factor()
+        # The reference rescales by 1/s and later by s (:807-808, :813-814).  With floor rounding that
+        # does not restore a size that s does not divide (1014 -> 253 -> 1012): its camera objects
+        # shrink once and, one schedule step later, render 506 rows against a 507-row target.  Here the
+        # cameras get their own sizes back exactly, so render and get_gt_img agree at every step.
+        saved = [(c, (c.fx, c.fy, c.cx, c.cy, c.width, c.height)) for c in ((camera, cam0) if cam0 is not None and cam0 is not camera else (camera,))]
         camera.rescale_output_resolution(1 / s)
         if cam0 is not None and cam0 is not camera:  # (:808, :814) rescaled and restored alongside
             cam0.rescale_output_resolution(1 / s)
@@ -248,9 +253,8 @@ class FreeGaussianModel(nn.Module):
             viewmat, K = dev[:16].view(1, 4, 4), dev[16:].view(1, 3, 3)
         W, H = int(camera.width), int(camera.height)
         self.last_size = (H, W)
-        camera.rescale_output_resolution(s)
-        if cam0 is not None and cam0 is not camera:
-            cam0.rescale_output_resolution(s)
+        for c, (fx, fy, cx, cy, w, h) in saved:
+            c.fx, c.fy, c.cx, c.cy, c.width, c.height = fx, fy, cx, cy, w, h
         return viewmat, K, W, H
 
     def _colors_and_degree(self):

@@ -228,7 +228,24 @@ def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
     return torch.repeat_interleave(tiles, counts, output_size=int(n))
 
 
-def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False, want_keys=True):
+# Footprint rectangles (FG_TIGHT_RECTS=0 turns them off): the fused preprocess passes also write the
+# depth sort keys and, per Gaussian, the tile rectangle shrunk to the tiles where the splat can reach
+# alpha >= 1/255; the raster lists are then binned from those (fg_bin_prepare_keys).  Same images and
+# gradients, ~30% fewer list entries on the 1M / 1080p scene.  The reference-exact lists
+# (info["flatten_ids"] etc.) are rebuilt on demand from the radius boxes.
+tight_rects = os.environ.get("FG_TIGHT_RECTS", "1") != "0"
+
+
+def _binning_side_outputs(N, tile_size, width, height, dev):
+    """(depth_keys, tile_rects) buffers for the preprocess passes, or (None, None)."""
+    tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
+    if not tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
+        return None, None
+    return torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 2, dtype=torch.int32, device=dev)
+
+
+def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False, want_keys=True,
+              keys_rects=None):
     """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
     -> (tile_keys[I] uint32-as-int32, flatten_ids[I] int32, tile_offsets[T+1] int32); the lists are
     bit-identical to ``isect_tiles`` (same (tile, depth, id) order).
@@ -240,7 +257,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     which waits for the count, slices, and -- if the guess was too small -- re-runs emission + sort
     on exact buffers (``redone=True``: consumers must be re-run too).  ``finish`` is None when
     nothing was deferred.  ``want_keys=False``: tile_keys comes back as None (16-bit keys stay inside
-    the kernels' workspace; ``tile_keys_from_offsets`` rebuilds them on demand)."""
+    the kernels' workspace; ``tile_keys_from_offsets`` rebuilds them on demand).
+    ``keys_rects=(depth_keys[N], tile_rects[N,2])`` from the fused preprocess pass: the lists are binned
+    from those rectangles (footprint rectangles: a subsequence of the reference's lists); depth_keys
+    is consumed (sorted in place)."""
     want_keys = want_keys or tile_w * tile_h > 65536
     lib = _lib.load()
     N = means2d.shape[0]
@@ -256,7 +276,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     # rectangles in depth order for the emission kernel (no gathers by id there); the counts then
     # come from the rectangles, tiles_touched is only the `info` output
     rects = torch.empty(N, dtype=torch.int32, device=dev) if (tile_w <= 1023 and tile_h <= 1023) else None
-    if rects is not None:
+    if keys_rects is not None and rects is not None:
+        _call("fg_bin_prepare_keys", N, _ptr(keys_rects[0]), _ptr(keys_rects[1]), _ptr(order), _ptr(cum), _ptr(rects),
+              _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
+    elif rects is not None:
         _call("fg_bin_prepare_rects", N, _ptr(depths), _ptr(radii), _ptr(means2d), tile_size, tile_w, tile_h,
               _ptr(order), _ptr(cum), _ptr(rects), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
     else:
@@ -280,7 +303,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
               _stream())  # fmt: skip
         globals()["last_overflow"] = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
-    key = (dev, N, tile_w, tile_h)
+    key = (dev, N, tile_w, tile_h, keys_rects is not None)
     count_host = _count_buffer(dev)
     count_host.copy_(cum[N - 1 :], non_blocking=True)
     ready = torch.cuda.Event()
@@ -487,6 +510,7 @@ class _Preprocess(torch.autograd.Function):
         comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
         if overlap_pack and len(cfg) > 10 and cfg[10]:
             main = torch.cuda.current_stream()
             side = _side_stream(dev)
@@ -509,7 +533,10 @@ class _Preprocess(torch.autograd.Function):
             _call("fg_preprocess_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
                   sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
                   height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
-                  _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _stream())  # fmt: skip
+                  _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _ptr(depth_keys),
+                  _ptr(tile_rects), _stream())  # fmt: skip
+            if depth_keys is not None:
+                splats._fg_bin = (depth_keys, tile_rects)  # for ops.bin_tiles(keys_rects=...)
         ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii)
         ctx.set_materialize_grads(False)  # unused depths / conics gradients arrive as None, not as zero tensors
         ctx.cfg = cfg
@@ -596,11 +623,14 @@ class _PreprocessRaw(torch.autograd.Function):
         comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
+        depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
         _call("fg_preprocess_raw_fwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
               _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, near, far, radius_clip, tile_size,
               int(antialiased), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles),
-              _ptr(splats), _stream())  # fmt: skip
+              _ptr(splats), _ptr(depth_keys), _ptr(tile_rects), _stream())  # fmt: skip
+        if depth_keys is not None:
+            splats._fg_bin = (depth_keys, tile_rects)
         ctx.save_for_backward(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
                               features_rest, extra, viewmat, K, radii)  # fmt: skip
         ctx.set_materialize_grads(False)

@@ -59,6 +59,41 @@ class _Info(dict):
         return dict.__contains__(self, key) or key in self.__dict__.get("_thunks", {})
 
 
+def _attach_lists(info: "_Info", tile_keys, flatten_ids, offsets, reference_lists, means2d, radii, depths, tiles,
+                  tile_size, tile_w, tile_h) -> None:
+    """The list entries of ``info``.  ``raster_flatten_ids`` / ``raster_isect_offsets`` are the lists
+    the compositing walked (``last_ids`` indexes them).  ``flatten_ids`` / ``isect_offsets`` /
+    ``tile_keys`` / ``isect_ids`` are the REFERENCE's lists (radius-box tile rectangles, sorted by
+    tile | depth bits): the same objects when the lists were binned from the radius boxes, otherwise
+    rebuilt on first access (footprint rectangles drop entries that contribute to no pixel; nothing
+    on the hot path reads the full lists)."""
+    info["raster_flatten_ids"], info["raster_isect_offsets"] = flatten_ids, offsets
+    if reference_lists:
+        info["flatten_ids"], info["isect_offsets"] = flatten_ids, offsets
+
+        # (the thunks must not refer to `info` itself: a reference cycle would keep its tensors -- and
+        # the autograd graph behind them -- alive until the cyclic collector runs)
+        def _tile_keys():
+            return tile_keys if tile_keys is not None else ops.tile_keys_from_offsets(offsets, flatten_ids.numel())
+
+        info.lazy("tile_keys", _tile_keys)
+        info.lazy("isect_ids", lambda: ops.isect_keys(_tile_keys(), flatten_ids, depths.detach()))
+        return
+    cache = {}
+
+    def full():
+        if not cache:
+            tk, ids, offs = ops.bin_tiles(means2d.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h,
+                                          want_keys=True)  # fmt: skip
+            cache.update(tile_keys=tk, flatten_ids=ids, isect_offsets=offs)
+        return cache
+
+    info.lazy("flatten_ids", lambda: full()["flatten_ids"])
+    info.lazy("isect_offsets", lambda: full()["isect_offsets"])
+    info.lazy("tile_keys", lambda: full()["tile_keys"])
+    info.lazy("isect_ids", lambda: ops.isect_keys(full()["tile_keys"], full()["flatten_ids"], depths.detach()))
+
+
 def _empty_result(means, width, height, tile_size, render_mode, sh_degree, colors, extra, packed):
     dev = means.device
     n_rgb = (3 if sh_degree is not None else colors.shape[1]) if render_mode.startswith("RGB") else 0
@@ -72,6 +107,7 @@ def _empty_result(means, width, height, tile_size, render_mode, sh_degree, color
         "opacities": zf[None], "tile_width": tile_w, "tile_height": tile_h, "tiles_per_gauss": zi[None],
         "tile_keys": zi, "flatten_ids": zi, "isect_ids": torch.zeros(0, dtype=torch.int64, device=dev),
         "isect_offsets": torch.zeros(tile_w * tile_h + 1, dtype=torch.int32, device=dev),
+        "raster_flatten_ids": zi, "raster_isect_offsets": torch.zeros(tile_w * tile_h + 1, dtype=torch.int32, device=dev),
         "last_ids": torch.full((height, width), -1, dtype=torch.int32, device=dev),
         "width": width, "height": height, "tile_size": tile_size, "n_cameras": 1,
     })  # fmt: skip
@@ -183,8 +219,10 @@ def rasterization(
         feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
 
     # speculative lists: the raster forward is enqueued before the host waits for the list length
+    keys_rects = getattr(splats, "_fg_bin", None) if fused else None
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
+        keys_rects=keys_rects,
     )
 
     if packed:
@@ -224,23 +262,14 @@ def rasterization(
         "tile_width": tile_w,
         "tile_height": tile_h,
         "tiles_per_gauss": tiles[None],
-        "flatten_ids": flatten_ids,
-        "isect_offsets": offsets,
         "last_ids": last_ids,
         "width": width,
         "height": height,
         "tile_size": tile_size,
         "n_cameras": 1,
     })
-    # the tile ids and the 64-bit (tile | depth) keys of the sorted list are only materialised if
-    # somebody asks
-    # (the thunks must not refer to `info` itself: a reference cycle would keep its tensors -- and the
-    # autograd graph behind them -- alive until the cyclic collector runs)
-    def _tile_keys():
-        return tile_keys if tile_keys is not None else ops.tile_keys_from_offsets(offsets, flatten_ids.numel())
-
-    info.lazy("tile_keys", _tile_keys)
-    info.lazy("isect_ids", lambda: ops.isect_keys(_tile_keys(), flatten_ids, depths.detach()))
+    _attach_lists(info, tile_keys, flatten_ids, offsets, keys_rects is None, means2d_n, radii, depths, tiles, tile_size,
+                  tile_w, tile_h)  # fmt: skip
     if packed:
         info.update(
             camera_ids=torch.zeros_like(gids),
@@ -322,8 +351,10 @@ def rasterize_gauss_params(
         far_plane=far_plane, radius_clip=radius_clip, tile_size=tile_size,
         antialiased=(rasterize_mode == "antialiased"), with_depth=with_depth,
     )  # fmt: skip
+    keys_rects = getattr(splats, "_fg_bin", None)
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False
+        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
+        keys_rects=keys_rects,
     )
     means2d_info = means2d_n.unsqueeze(0)
     bg = None
@@ -346,15 +377,9 @@ def rasterize_gauss_params(
     info = _Info({
         "radii": radii[None], "means2d": means2d_info, "depths": depths[None], "conics": conics[None],
         "opacities": splats[:, 2][None], "tile_width": tile_w, "tile_height": tile_h,
-        "tiles_per_gauss": tiles[None], "flatten_ids": flatten_ids,
-        "isect_offsets": offsets, "last_ids": last_ids, "width": width, "height": height,
+        "tiles_per_gauss": tiles[None], "last_ids": last_ids, "width": width, "height": height,
         "tile_size": tile_size, "n_cameras": 1,
     })  # fmt: skip
-    # (the thunks must not refer to `info` itself: a reference cycle would keep its tensors -- and the
-    # autograd graph behind them -- alive until the cyclic collector runs)
-    def _tile_keys():
-        return tile_keys if tile_keys is not None else ops.tile_keys_from_offsets(offsets, flatten_ids.numel())
-
-    info.lazy("tile_keys", _tile_keys)
-    info.lazy("isect_ids", lambda: ops.isect_keys(_tile_keys(), flatten_ids, depths.detach()))
+    _attach_lists(info, tile_keys, flatten_ids, offsets, keys_rects is None, means2d_n, radii, depths, tiles, tile_size,
+                  tile_w, tile_h)  # fmt: skip
     return render[None], alpha[None], info

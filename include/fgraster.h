@@ -42,7 +42,7 @@ typedef void* fg_stream_t;
 
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
-#define FG_ABI_VERSION 1
+#define FG_ABI_VERSION 2
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -129,6 +129,14 @@ int fg_bin_prepare_rects(int N, const float* depths, const int32_t* radii, const
                          int tile_size, int tile_w, int tile_h, int32_t* order, int64_t* cum_tiles,
                          int32_t* rects_sorted, void* workspace, size_t workspace_bytes,
                          fg_stream_t stream);
+/* The same from what fg_preprocess_fwd / fg_preprocess_raw_fwd already wrote: depth_keys[N] (sorted
+ * IN PLACE here -- a scratch array from the caller's point of view) and tile_rects[N,2] (read
+ * only).  No key / rectangle kernel runs and the first radix pass numbers the values itself.  With
+ * the preprocess pass's FOOTPRINT rectangles the lists hold only (splat, tile) pairs in which the
+ * splat can reach alpha >= 1/255 -- the reference's lists minus dead entries, same order. */
+int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
+                        int64_t* cum_tiles, int32_t* rects_sorted, void* workspace,
+                        size_t workspace_bytes, fg_stream_t stream);
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
  * of traffic per intersection over emission + the two sort passes. */
@@ -223,7 +231,15 @@ int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d
  * with colors[N,k_stored,3]; or n_color direct channels colors[N,n_color] when sh_degree = -1;
  * n_color may be 0), camera depth if with_depth, then n_extra channels from extra[N,n_extra];
  * at most FG_MAX_CHANNELS in total.  antialiased != 0 multiplies the record's opacity by the
- * compensation (rasterize_mode="antialiased", freegaussian_model.py:110-119). */
+ * compensation (rasterize_mode="antialiased", freegaussian_model.py:110-119).
+ * Optional outputs for the depth-first binning (both nullable; fg_bin_prepare_keys consumes them):
+ *   depth_keys[N] u32  = float bits of the camera depth, 0xFFFFFFFF when culled;
+ *   tile_rects[N,2] i32 = the FOOTPRINT rectangle {x0 | y0 << 16, w | h << 16}: the reference's
+ *   radius-box tile rectangle (floor / ceil of (mean +- radius) / tile) shrunk to the tiles in which
+ *   the splat can reach alpha >= 1/255 at a pixel centre (opacity-aware extents of the ellipse
+ *   sigma <= ln(255 o), inflated so that rounding only ever keeps more).  Lists binned from it are
+ *   the reference's lists minus entries that contribute to no pixel, in the same order; images and
+ *   gradients are unchanged.  (0, 0) when culled or when nothing is reached. */
 int fg_preprocess_fwd(int N, const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* colors, int sh_degree, int k_stored,
                       int n_color, int with_depth, const float* extra, int n_extra,
@@ -231,7 +247,7 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       float near_plane, float far_plane, float radius_clip, int tile_size,
                       int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                       float* compensations, int32_t* tiles_touched, float* splats,
-                      fg_stream_t stream);
+                      uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream);
 /* The colour + record half of fg_preprocess_fwd on its own: inputs are the projection outputs of
  * fg_project_fwd (radii, means2d, depths, conics; compensations when antialiased).  Splitting the
  * forward this way lets a host run this HBM-bound half on a second stream while the
@@ -278,7 +294,8 @@ int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const f
                           int width, int height, float eps2d, float near_plane, float far_plane,
                           float radius_clip, int tile_size, int antialiased, int32_t* radii,
                           float* means2d, float* depths, float* conics, float* compensations,
-                          int32_t* tiles_touched, float* splats, fg_stream_t stream);
+                          int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
+                          int32_t* tile_rects, fg_stream_t stream);
 int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
                           const float* log_scales, const float* d_scales,
                           const float* opacity_logits, const float* features_dc,

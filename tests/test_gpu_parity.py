@@ -136,6 +136,59 @@ def test_depth_first_binning_equals_full_key_sort():
     assert torch.equal(ops.isect_keys(tk, ids, d).cpu(), keys_s)
 
 
+@pytest.mark.parametrize("mode", ["classic", "antialiased"])
+def test_footprint_rectangles_cull_only_dead_entries(mode, monkeypatch):
+    """The lists the compositing walks (binned from the preprocess pass's footprint rectangles) are
+    the reference's lists minus (splat, tile) pairs in which the splat reaches alpha >= 1/255 at no
+    pixel centre: a subsequence, tile by tile, of the radius-box lists; every dropped entry is dead
+    by the oracle's own alpha test; image bit-identical, gradients equal up to atomic order; and
+    info["flatten_ids"] / ["isect_offsets"] / ["isect_ids"] still are the reference's full lists."""
+    sc = _scene(n=30000, w=400, h=240, seed=13)
+    sc.opacities[::3] *= 0.05  # many faint splats: their 3-sigma boxes are mostly dead area
+    sc.scales[:40] *= 12.0
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
+    outs = []
+    for tight in (True, False):
+        monkeypatch.setattr(ops, "tight_rects", tight)
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True,
+                                   rasterize_mode=mode)  # fmt: skip
+        (r * vr).sum().backward()
+        outs.append((r.detach(), a.detach(), [x.grad for x in t], info))
+    (r1, a1, g1, i1), (r0, a0, g0, i0) = outs
+    assert torch.equal(r1, r0) and torch.equal(a1, a0)
+    for x, y in zip(g1, g0):
+        assert rel_l2(x, y) < 1e-5
+    # without footprint rectangles the raster lists ARE the reference lists
+    assert i0["raster_flatten_ids"] is i0["flatten_ids"]
+    full_ids, full_offs = i0["flatten_ids"].cpu(), i0["isect_offsets"].cpu()
+    ids, offs = i1["raster_flatten_ids"].cpu(), i1["raster_isect_offsets"].cpu()
+    assert ids.numel() < 0.9 * full_ids.numel()  # the culling is not a no-op here
+    # the lazily rebuilt reference lists of the tight run are the same lists
+    assert torch.equal(i1["flatten_ids"].cpu(), full_ids) and torch.equal(i1["isect_offsets"].cpu(), full_offs)
+    assert torch.equal(i1["isect_ids"].cpu(), i0["isect_ids"].cpu())
+    ref = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], sc.width, sc.height)
+    opac = sc.opacities * ref.compensations if mode == "antialiased" else sc.opacities
+    tw = i1["tile_width"]
+    dropped_total = 0
+    for tile in range(0, tw * i1["tile_height"], 7):
+        f = full_ids[int(full_offs[tile]) : int(full_offs[tile + 1])].tolist()
+        c = ids[int(offs[tile]) : int(offs[tile + 1])].tolist()
+        it = iter(f)
+        assert all(x in it for x in c), tile  # subsequence, order kept
+        dropped = sorted(set(f) - set(c))
+        assert len(f) - len(c) == len(dropped)
+        if dropped:
+            dropped_total += len(dropped)
+            ty, tx = divmod(tile, tw)
+            yy, xx = torch.meshgrid(torch.arange(16.0) + ty * 16 + 0.5, torch.arange(16.0) + tx * 16 + 0.5, indexing="ij")
+            d = torch.tensor(dropped)
+            _, _, _, alpha, valid = O._tile_terms(xx.reshape(-1), yy.reshape(-1), ref.means2d[d], ref.conics[d], opac[d])
+            assert not bool(valid.any()), (tile, "a dropped entry reaches 1/255 somewhere")
+    assert dropped_total > 0
+
+
 def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
     """257 x 257 = 66049 tiles: tile ids no longer fit the 16-bit in-workspace keys.  The lists must
     still equal the oracle's 64-bit-key sort, and the pixels of tiles with ids beyond 65535 the C
