@@ -41,19 +41,34 @@ __device__ __forceinline__ int alpha_extent(float o, float a, float b, float c, 
   if (!(t255 >= 1.f)) return 0;
   const float det = a * c - b * b;
   if (!(det > 0.f)) return 2;
-  const float tau2 = 2.f * __logf(t255) + 1e-4f;
+  // t255 >= 1 here: the bare v_log_f32 (log2, 1 ulp) needs no denormal scaling; 2 ln(x) = 2 ln2 log2(x)
+  const float tau2 = 1.3862943611f * __builtin_amdgcn_logf(t255) + 1e-4f;
   const float rdet = __builtin_amdgcn_rcpf(det);
   ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet);
   ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
   if (!(ex == ex) || !(ey == ey)) return 2;
-  ex = ex * 1.0005f + 0.02f;
-  ey = ey * 1.0005f + 0.02f;
+  // (multiply, then add: two literal operands -- as one fused multiply-add the 0.02 sat in a VGPR)
+  ex = __fadd_rn(__fmul_rn(ex, 1.0005f), 0.02f);
+  ey = __fadd_rn(__fmul_rn(ey, 1.0005f), 0.02f);
   return 1;
 }
 // does the extent [g - e, g + e] reach a pixel centre of [lo + 0.5, lo + span - 0.5]?  (the comparison
 // form both users share; span = 16 for a tile side, 4 for a strip)
 __device__ __forceinline__ bool extent_reaches(float g, float e, float lo, float span) {
   return !(g + e < lo + 0.5f || g - e > lo + (span - 0.5f));
+}
+// the same against bounds the caller precomputed: first = lo + 0.5f, last = lo + (span - 0.5f)
+__device__ __forceinline__ bool extent_reaches_bounds(float g, float e, float first, float last) {
+  return !(g + e < first || g - e > last);
+}
+// a wave-uniform float, held in a scalar register (gfx950 has no scalar float ALU: a uniform value
+// computed by vector instructions otherwise occupies a VGPR for as long as it lives)
+// (inline asm: the builtin is folded away when the compiler can prove the value uniform, and the
+// value then stays in the vector register its arithmetic produced it in)
+__device__ __forceinline__ float uniform(float v) {
+  float s;
+  asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+  return s;
 }
 
 // ---- DPP / permlane cross-lane moves (no LDS traffic) ------------------------------------

@@ -250,6 +250,13 @@ __device__ __forceinline__ float lane_select(uint64_t m, float if_set, float if_
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
   return r;
 }
+// if_set where the mask bit is set, else 0: the zero is the instruction's inline constant (as a
+// "v" operand of the general form it occupied a VGPR for the whole kernel)
+__device__ __forceinline__ float lane_select0(uint64_t m, float if_set) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(if_set), "s"(m));
+  return r;
+}
 __device__ __forceinline__ int lane_select(uint64_t m, int if_set, int if_clear) {
   int r;
   asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(r) : "v"(if_clear), "v"(if_set), "s"(m));
@@ -290,6 +297,16 @@ __device__ unsigned long long fg_raster_stats[16];
 #define FG_FWD_STRIP_TEST_MIN_PPT 2
 #endif
 
+// The lane id, recomputed where it is used (two instructions the compiler cannot hoist): the
+// per-batch staging code of the raster kernels then does not pin its LDS addresses in registers
+// across the per-entry loops (one staging pass per 64 entries; the registers are worth a wavefront
+// of occupancy in the backward).
+__device__ __forceinline__ int fresh_lane_id() {
+  int l;
+  asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(l));
+  return l;
+}
+
 struct SigmaTerms {
   float hc, bdx, hadx2;
 };
@@ -316,6 +333,17 @@ __device__ __forceinline__ float neg_sigma_log2e(const SigmaTerms& t, float dy) 
   return fmaf(fmaf(t.hc, dy, t.bdx), dy, t.hadx2);
 }
 
+// dy of pixel slot k of a lane: (s.y - pyb) - off with pyb = the lane's row of the TILE's first strip
+// (+ 0.5) and off = 4 * (strip of the slot), a constant or a scalar.  Every launch shape -- whole
+// tile, two strips, one strip, any pixels-per-lane -- evaluates the SAME two subtractions for a
+// given pixel, so forward and backward take identical skip decisions whatever jobs they were cut
+// into; and a lane keeps one row coordinate instead of one per slot.
+template <int PPT>
+__device__ __forceinline__ float slot_dy(float dy_base, int wave, int k) {
+  // PPT 4: wave == 0, strips 0..3; PPT 2: strips wave, wave + 2; PPT 1: strip wave
+  return dy_base - (float)(4 * (wave + k * (4 / PPT)));
+}
+
 template <int C>
 __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (&f)[C]) {
   const float4 v0 = rec[0];
@@ -332,18 +360,36 @@ __device__ __forceinline__ void read_record(const float4* rec, Splat& s, float (
   for (int c = 0; c < C; ++c) f[c] = tmp[c];
 }
 
+// Pixel-centre bounds of a tile and of its four 4-row strips, wave-uniform: ten scalar registers
+// (as hoisted vector values they cost ten VGPRs for the whole kernel -- two wavefronts per SIMD of
+// occupancy in the backward).
+struct StripBounds {
+  float x_first, x_last, y_first[4], y_last[4];
+};
+__device__ __forceinline__ StripBounds strip_bounds(float tile_x0, float tile_y0) {
+  StripBounds sb;
+  sb.x_first = fg::uniform(tile_x0 + 0.5f);
+  sb.x_last = fg::uniform(tile_x0 + ((float)TILE - 0.5f));
+#pragma unroll
+  for (int s4 = 0; s4 < 4; ++s4) {
+    sb.y_first[s4] = fg::uniform(tile_y0 + 4.f * s4 + 0.5f);
+    sb.y_last[s4] = fg::uniform(tile_y0 + 4.f * s4 + 3.5f);
+  }
+  return sb;
+}
+
 // Which of the tile's four 4-row strips can this splat reach with alpha >= 1/255?  (fg::alpha_extent:
 // result-preserving by construction; shared with the binning's tight tile rectangles.)
 __device__ __forceinline__ unsigned strip_mask(float gx, float gy, float o, float a, float b, float c,
-                                               float tile_x0, float tile_y0) {
+                                               const StripBounds& sb) {
   float ex, ey;
   const int kind = fg::alpha_extent(o, a, b, c, ex, ey);
   if (kind != 1) return kind == 0 ? 0u : 0xFu;
-  if (!fg::extent_reaches(gx, ex, tile_x0, (float)TILE)) return 0u;
+  if (!fg::extent_reaches_bounds(gx, ex, sb.x_first, sb.x_last)) return 0u;
   unsigned m = 0;
 #pragma unroll
   for (int s4 = 0; s4 < 4; ++s4)
-    if (fg::extent_reaches(gy, ey, tile_y0 + 4.f * s4, 4.f)) m |= 1u << s4;
+    if (fg::extent_reaches_bounds(gy, ey, sb.y_first[s4], sb.y_last[s4])) m |= 1u << s4;
   return m;
 }
 
@@ -380,12 +426,15 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   auto& lds_list = sh.list;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
-  const int lane = fg::lane_id(), wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave_base + wl;
+  // one wavefront per workgroup (NW == 1, the mixed launches): the wave index is the constant 0 and
+  // every per-wave LDS address folds into an instruction offset instead of a register
+  const int lane = fg::lane_id(), wl = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
+            wave = wave_base + wl;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int col = threadIdx.x & 15, row0 = 4 * wave_base + (threadIdx.x >> 4);
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
-  const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
+  const StripBounds sb = strip_bounds((float)(tile_x * TILE), (float)(tile_y * TILE));
   const unsigned my_strips = wave_strips<PPT>(wave);
 
   // Per-slot pixel state.  The "finished" flags live as 64-bit lane masks in scalar registers and
@@ -395,12 +444,12 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   float T[PPT], acc[PPT][C];
   int last[PPT];
   uint64_t done[PPT];
-  float py[PPT];
+  // the lane's row in the tile's FIRST strip (slot_dy adds the strip)
+  const float pyb = (float)(tile_y * TILE + (int)(threadIdx.x >> 4) - 4 * wl) + 0.5f;
   const uint64_t full = __ballot(true);
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
-    py[k] = (float)iy + 0.5f;
     T[k] = 1.f;
     last[k] = start - 1;
     done[k] = __ballot(!(ix < width && iy < height));
@@ -421,7 +470,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       float4 v[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) v[q] = rec[q];
-      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
       // the forward only ever uses the conic inside the exponent: stage it pre-scaled
       v[0].w *= 0.5f * FG_NEG_LOG2E;
       v[1].x *= FG_NEG_LOG2E;
@@ -456,7 +505,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       Splat s;
       float f[C];
       read_record<C>(lds[j], s, f);
-      const float dx = s.x - px;
+      const float dx = s.x - px, dy_base = s.y - pyb;
       const SigmaTerms st = sigma_terms_prescaled(s.a, s.b, s.c, dx);
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
@@ -465,7 +514,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         if (PPT >= FG_FWD_STRIP_TEST_MIN_PPT && !((packed >> (8 + wave + k * (4 / PPT))) & 1u)) continue;
         // one wave-uniform branch, then select-predicated straight-line code (no nested
         // divergent ifs: each costs exec save/restore and merge copies)
-        const float dy = s.y - py[k];
+        const float dy = slot_dy<PPT>(dy_base, wave, k);
         const float e2 = neg_sigma_log2e(st, dy);
         const float alpha = fminf(FG_ALPHA_MAX, s.o * __builtin_amdgcn_exp2f(e2));
         // valid = !done && !(sigma < 0 || alpha < 1/255)
@@ -477,7 +526,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         const float next_T = T[k] * (1.f - alpha);
         const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
         const uint64_t take = valid & ~stop;
-        const float vis = lane_select(take, alpha * T[k], 0.f);
+        const float vis = lane_select0(take, alpha * T[k]);
 #pragma unroll
         for (int c = 0; c < C; ++c) acc[k][c] += f[c] * vis;
         last[k] = lane_select(take, batch + j, last[k]);
@@ -596,20 +645,23 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   if (end <= start) return;
-  const int lane = fg::lane_id(), wl = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), wave = wave_base + wl;
+  // one wavefront per workgroup (NW == 1, the mixed launches): the wave index is the constant 0 and
+  // every per-wave LDS address folds into an instruction offset instead of a register
+  const int lane = fg::lane_id(), wl = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
+            wave = wave_base + wl;
   const int col = threadIdx.x & 15, row0 = 4 * wave_base + (threadIdx.x >> 4);
   const int ix = tile_x * TILE + col;
   const float px = (float)ix + 0.5f;
-  const float tile_x0 = (float)(tile_x * TILE), tile_y0 = (float)(tile_y * TILE);
+  const StripBounds sb = strip_bounds((float)(tile_x * TILE), (float)(tile_y * TILE));
   const unsigned my_strips = wave_strips<PPT>(wave);
 
-  float T[PPT], tva[PPT], vr[PPT][C], bsum[PPT], py[PPT];
+  float T[PPT], tva[PPT], vr[PPT][C], bsum[PPT];
+  const float pyb = (float)(tile_y * TILE + (int)(threadIdx.x >> 4) - 4 * wl) + 0.5f;  // see slot_dy
   int last[PPT];
   int my_max = start - 1;
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
-    py[k] = (float)iy + 0.5f;
     const bool inside = ix < width && iy < height;
     const size_t pix = (size_t)iy * width + ix;
     T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
@@ -646,25 +698,26 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   for (int b = n_batches - 1; b >= 0; --b) {
     const int batch = start + b * NT;
     __syncthreads();
-    const int idx = batch + (int)threadIdx.x;
+    const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
+    const int idx = batch + tl;
     unsigned mask = 0;
     if (idx <= bin_final) {
       const int gid = flatten_ids[idx];
-      lds_gid[threadIdx.x] = gid;
+      lds_gid[tl] = gid;
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) v[q] = rec[q];
-      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, tile_x0, tile_y0);
+      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
       if constexpr (C == 3) {  // three spare floats in the 48-byte LDS copy: the pre-scaled conic rides along
         v[2].y = v[0].w * (0.5f * FG_NEG_LOG2E);
         v[2].z = v[1].x * FG_NEG_LOG2E;
         v[2].w = v[1].y * (0.5f * FG_NEG_LOG2E);
       }
 #pragma unroll
-      for (int q = 0; q < NV; ++q) lds[threadIdx.x][q] = v[q];
+      for (int q = 0; q < NV; ++q) lds[tl][q] = v[q];
     }
-    lds_mask[threadIdx.x] = mask;
+    lds_mask[tl] = mask;
     __syncthreads();
     // back to front over the entries that can reach this wavefront's strips
     for (int i = NT / 64 - 1; i >= 0; --i) {
@@ -690,7 +743,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         Splat s;
         float f[C];
         read_record<C>(lds[j], s, f);
-        const float dx = s.x - px;
+        const float dx = s.x - px, dy_base = s.y - pyb;
         SigmaTerms st;
         if constexpr (C == 3) {
           const float4 tail = lds[j][2];  // (f2, a', b', c'): the load read_record already issued
@@ -718,7 +771,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         uint64_t valid_k[PPT];
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
-          const float e2 = neg_sigma_log2e(st, s.y - py[k]);
+          const float e2 = neg_sigma_log2e(st, slot_dy<PPT>(dy_base, wave, k));
           vis_k[k] = __builtin_amdgcn_exp2f(e2);
           alpha_k[k] = fminf(FG_ALPHA_MAX, s.o * vis_k[k]);
           valid_k[k] = lanes_sle(idx_j, last[k]) & lanes_ule(e2, 0.f) & lanes_uge(alpha_k[k], FG_ALPHA_SKIP);
@@ -732,10 +785,10 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
           FG_STAT(2, 1);
           FG_STAT(3, __popcll(valid));
           contributed = true;
-          const float dy = s.y - py[k];
+          const float dy = slot_dy<PPT>(dy_base, wave, k);
           const float vis = vis_k[k];
           const float ov = s.o * vis;
-          const float a_eff = lane_select(valid, alpha_k[k], 0.f);
+          const float a_eff = lane_select0(valid, alpha_k[k]);
           const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
           T[k] *= ra;
           const float fac = a_eff * T[k];
@@ -748,7 +801,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
           const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
           bsum[k] += cdot * fac;
           const uint64_t open = valid & lanes_ole(ov, FG_ALPHA_MAX);  // alpha not clamped: gradient flows
-          const float v_o = lane_select(open, vis * v_alpha, 0.f);     // d/d opacity
+          const float v_o = lane_select0(open, vis * v_alpha);        // d/d opacity
           const float v_sigma = -s.o * v_o;
           g[2] += v_o;
           const float vsdy = v_sigma * dy;
@@ -767,7 +820,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
 #pragma unroll
         for (int k = 0; k < PPT; ++k) {
           if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-          const float dy = s.y - py[k];
+          const float dy = slot_dy<PPT>(dy_base, wave, k);
           const float e2 = neg_sigma_log2e(st, dy);
           const float vis = __builtin_amdgcn_exp2f(e2);
           const float ov = s.o * vis;
