@@ -65,9 +65,13 @@ __device__ __forceinline__ bool extent_reaches_bounds(float g, float e, float fi
 // computed by vector instructions otherwise occupies a VGPR for as long as it lives)
 // (inline asm: the builtin is folded away when the compiler can prove the value uniform, and the
 // value then stays in the vector register its arithmetic produced it in)
+// The s_nops are the wait states gfx950 needs around it and hipcc does not insert around asm
+// statements: 1 between a vector write of the VGPR and the v_readfirstlane that reads it (without it
+// the read returned the register's OLD value: every strip mask came out empty), 2 between the SGPR
+// write and a vector instruction reading that SGPR.
 __device__ __forceinline__ float uniform(float v) {
   float s;
-  asm("v_readfirstlane_b32 %0, %1" : "=s"(s) : "v"(v));
+  asm("s_nop 0\n\tv_readfirstlane_b32 %0, %1\n\ts_nop 1" : "=s"(s) : "v"(v));
   return s;
 }
 
