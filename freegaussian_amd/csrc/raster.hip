@@ -273,6 +273,28 @@ struct Composite {
   uint8_t* clamp_mask;      // [H,W] when n_clamp > 0
 };
 
+// List segmentation of the backward (mixed launches, 3 composited channels): a tile's list is walked
+// serially by its wavefront, ~8000 tile jobs are fewer than two per wavefront slot of the chip, and the
+// launch ends when the SIMD with the longest sum of walks ends.  The forward therefore leaves a
+// CHECKPOINT of every pixel's compositing state -- (T, C0, C1, C2) before list entry g -- at every
+// FG_SEG_ENTRIES-th entry of a tile's list (g = start + c * FG_SEG_ENTRIES, slot g / FG_SEG_ENTRIES:
+// unique, tiles own disjoint index ranges), and a backward job walks only ITS share of a tile's
+// segments, starting from the checkpoint at its upper end: more, shorter, independent jobs without
+// repeating any per-entry work (splitting a tile by pixels repeats the record read, the reduction
+// and the atomic of every entry in every part).
+#ifndef FG_SEG_ENTRIES
+#define FG_SEG_ENTRIES 128
+#endif
+#ifndef FG_SEG_PARTS_DEFAULT
+#define FG_SEG_PARTS_DEFAULT 1
+#endif
+struct Segments {
+  float4* ckpt;             // [slots][256 pixels of the tile, row-major]; nullptr = no segmentation
+  const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
+                            // composite epilogue they are rebuilt from the finished image instead
+  int parts;                // backward: jobs per tile (1 = whole list)
+};
+
 // Optional work counters (make stats -> libfgraster_stats.so; never in the product library).
 #ifdef FG_RASTER_STATS
 __device__ unsigned long long fg_raster_stats[16];
@@ -417,7 +439,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ tile_offsets,
                                                 const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                                                 float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                                                const Composite& comp) {
+                                                const Composite& comp, float4* __restrict__ ckpt = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -463,6 +485,15 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     for (int k = 0; k < PPT; ++k) all_done &= done[k];
     // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
     if (__syncthreads_and(all_done == full)) break;
+    if constexpr (C == 3 && NW == 1) {
+      // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
+      if (ckpt && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
+        float4* slot = ckpt + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k)
+          slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
+      }
+    }
     const int idx = batch + (int)threadIdx.x;
     unsigned mask = 0;
     if (idx < end) {
@@ -592,7 +623,8 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
-                        float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp) {
+                        float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
+                        float4* __restrict__ ckpt) {
   __shared__ FwdShared<C, 64> sh;
   // With a list the grid covers the positional job count plus a margin; fg_raster_build_jobs
   // makes the list fit it (build_jobs_kernel).  (A grid of the list's full capacity -- 4 jobs per
@@ -604,13 +636,13 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   if (tile < 0) return;
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                             last_ids, comp);
+                             last_ids, comp, ckpt);
   else if (strip >= 4)
     raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp);
+                             alphas, last_ids, comp, ckpt);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp);
+                             alphas, last_ids, comp, ckpt);
 }
 
 template <int C, int NT>
@@ -633,7 +665,8 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ last_ids,
                                                 const float* __restrict__ v_render,
                                                 const float* __restrict__ v_alphas, float* __restrict__ v_splats,
-                                                const Composite& comp) {
+                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, 1},
+                                                int part = 0) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -689,19 +722,56 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   }
   const int n_used = bin_final - start + 1;
   if (n_used <= 0) return;
-  const int n_batches = (n_used + NT - 1) / NT;
+  // this job's share of the list: [lo, hi) (struct Segments); the whole used list without segmentation
+  int lo = start, hi = bin_final + 1;
+  if constexpr (C == 3 && NW == 1) {
+    if (seg.ckpt && seg.parts > 1) {
+      const int nseg = (n_used + FG_SEG_ENTRIES - 1) / FG_SEG_ENTRIES;
+      const int c0 = part * nseg / seg.parts, c1 = (part + 1) * nseg / seg.parts;
+      if (c0 == c1) return;  // fewer segments than parts: this part is empty
+      lo = start + c0 * FG_SEG_ENTRIES;
+      if (c1 < nseg) {
+        // pixels whose list continues beyond this job's upper end resume from the forward's
+        // checkpoint there: T before entry hi, and the colour composited from entry hi on
+        // (C_final - C_before_hi) as the suffix sum the alpha gradient needs
+        hi = start + c1 * FG_SEG_ENTRIES;
+        const float4* slot = seg.ckpt + (size_t)(hi / FG_SEG_ENTRIES) * (TILE * TILE);
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          if (last[k] >= hi) {  // (implies the pixel is inside the image)
+            const int iy = tile_y * TILE + row0 + k * RSTEP;
+            const size_t pix = (size_t)iy * width + ix;
+            const float4 ck = slot[(row0 + k * RSTEP) * TILE + col];
+            const float prefix[3] = {ck.y, ck.z, ck.w};
+            float sfx = 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+              // raw final colour: the forward's accumulator, or (composite epilogue) the finished image
+              // minus the background term -- exact where the gradient is not blocked by the clamp
+              float cf = seg.render_raw[pix * 3 + c];
+              if (comp.background) cf -= (1.f - alphas[pix]) * comp.background[c];
+              sfx += vr[k][c] * (cf - prefix[c]);
+            }
+            T[k] = ck.x;
+            bsum[k] = sfx;
+          }
+        }
+      }
+    }
+  }
+  const int n_batches = (hi - lo + NT - 1) / NT;
   if (threadIdx.x == 0) { FG_STAT(5, n_used); FG_STAT(6, end - start); }
   float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
 #pragma unroll
   for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
 
   for (int b = n_batches - 1; b >= 0; --b) {
-    const int batch = start + b * NT;
+    const int batch = lo + b * NT;
     __syncthreads();
     const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
     const int idx = batch + tl;
     unsigned mask = 0;
-    if (idx <= bin_final) {
+    if (idx < hi) {
       const int gid = flatten_ids[idx];
       lds_gid[tl] = gid;
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
@@ -936,21 +1006,28 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
                         const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
-                        const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp) {
+                        const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp,
+                        Segments seg) {
   __shared__ BwdShared<C, 64> sh;
-  int strip;
-  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
-                        : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+  int strip, part = 0, b = blockIdx.x;
+  if (seg.parts > 1) {
+    // consecutive workgroups of an XCD (b, b + 8, ...) are the parts of one tile: they share its
+    // records in the XCD's L2
+    const int k = b >> 3;
+    part = k % seg.parts;
+    b = ((k / seg.parts) << 3) | (b & 7);
+  }
+  const int tile = jobs ? job_from_list(b, jobs, cap, strip) : job_of_block(b, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
   if (strip < 0)
     raster_bwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
-                             v_render, v_alphas, v_splats, comp);
+                             v_render, v_alphas, v_splats, comp, seg, part);
   else if (strip >= 4)
     raster_bwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
-                             last_ids, v_render, v_alphas, v_splats, comp);
+                             last_ids, v_render, v_alphas, v_splats, comp, seg, part);
   else
     raster_bwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
-                             last_ids, v_render, v_alphas, v_splats, comp);
+                             last_ids, v_render, v_alphas, v_splats, comp, seg, part);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1160,12 +1237,13 @@ int raster_split(const char* name, int dflt4, int dflt2) {
 template <int C>
 int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
-                     int32_t* last_ids, Composite comp, hipStream_t s) {
+                     int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
                      dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
-                     reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp);
+                     reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
+                     reinterpret_cast<float4*>(ckpt));
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1173,14 +1251,26 @@ template <int C>
 int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                     Composite comp, hipStream_t s) {
+                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1}) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
-  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
-                     dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
-                     reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids, v_render,
-                     v_alphas, v_splats, comp);
+  int grid = jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail);
+  if (seg.parts > 1) {  // whole-tile jobs only, seg.parts list segments each (struct Segments)
+    jobs = nullptr;
+    tail = 0;
+    grid = mixed_grid(tile_w, tile_h, 0) * seg.parts;
+  }
+  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs,
+                     cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids, v_render,
+                     v_alphas, v_splats, comp, seg);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
+// FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
+int seg_parts() {
+  const char* e = getenv("FG_RASTER_SEG_PARTS");
+  const int v = e ? atoi(e) : FG_SEG_PARTS_DEFAULT;
+  return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
 
 #define FG_DISPATCH_C(CALL)                  \
@@ -1229,7 +1319,8 @@ namespace {
 
 int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
-                   int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr) {
+                   int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
+                   float* seg_ckpt = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
@@ -1242,7 +1333,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
-                                         alphas, last_ids, comp, s)                                                 \
+                                         alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr)                   \
        : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
@@ -1257,7 +1348,8 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
 int raster_bwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                    const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                   Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr) {
+                   Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
+                   const float* seg_ckpt = nullptr, const float* image = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_splats) return FG_ERR_INVALID_ARG;
@@ -1268,9 +1360,13 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   const int ppt = raster_ppt_bwd(n_tiles);
   int tail = mixed_tail_bwd(n_tiles);
   if (tail == 0) jobs = nullptr;
+  // list segmentation: 3 channels, checkpoints written by the forward of this very image
+  Segments seg{nullptr, nullptr, 1};
+  if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts()};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
-                                         alphas, last_ids, v_render, v_alphas, v_splats, comp, s)           \
+                                         alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg)      \
        : (ppt == 4) ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
        : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
@@ -1349,19 +1445,27 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
 extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, float* image, float* alphas,
-                                  int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream) {
+                                  int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, fg_stream_t stream) {
   return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
-                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs);
+                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt);
+}
+
+extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects) {
+  if (channels != 3 || width <= 0 || height <= 0 || tile_size != TILE || n_isects <= 0) return 0;
+  const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
+  if (seg_parts() <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
+  return (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE) * 4;
 }
 
 extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, const uint8_t* clamp_mask,
                                   const float* alphas, const int32_t* last_ids, const float* v_image,
-                                  const float* v_alphas, float* v_splats, fg_stream_t stream) {
+                                  const float* v_alphas, float* v_splats, const float* seg_ckpt,
+                                  const float* image, fg_stream_t stream) {
   return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
-                        stream, jobs);
+                        stream, jobs, seg_ckpt, image);
 }
 
 #ifdef FG_RASTER_STATS

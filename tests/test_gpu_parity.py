@@ -916,6 +916,48 @@ def test_1080p_mixed_launch_forward_and_all_gradients_vs_oracle(layout, render_m
     _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
 
 
+@pytest.mark.parametrize("parts,layout,bg", [(2, "uniform", False), (4, "clustered", False), (3, "uniform", True), (16, "clustered", True)])
+def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, monkeypatch):
+    """List segments of the backward (forward checkpoints every 128 list entries; `parts` jobs per
+    tile, each over its share of the list): every gradient against the oracle at 8160 tiles and against
+    the unsegmented walk; with and without the composite epilogue (background + clamp), whose raw
+    colours the backward has to rebuild from the finished image."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = synthetic_scene(40_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    if layout == "clustered":
+        sc.means[:20_000] *= 0.15  # lists of thousands of entries: many segments per tile
+    if not bg:
+        monkeypatch.setenv("FG_RASTER_SEG_PARTS", str(parts))
+        ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 1, "RGB", 3)
+        worst = _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+        seg_grads = {k: v.grad.clone() for k, v in gpu_in.items()}
+        monkeypatch.setenv("FG_RASTER_SEG_PARTS", "1")
+        _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
+        assert torch.equal(o2[0], o1[0])  # the forward does not depend on it
+        for k in seg_grads:
+            assert rel_l2(seg_grads[k], gpu_in1[k].grad) < 2e-5, k
+        return
+    # composite epilogue: the model's raw-parameter front end with a background and the clamp
+    g = torch.Generator().manual_seed(3)
+    raw = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+               features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+    vm, K = sc.viewmats[1:2].to(DEV), sc.Ks[1:2].to(DEV)
+    vr = torch.randn(1, 1080, 1920, 3, generator=g).to(DEV)
+    bgc = torch.tensor([0.3, 0.9, 0.1], device=DEV)
+    outs = []
+    for p_ in (parts, 1):
+        monkeypatch.setenv("FG_RASTER_SEG_PARTS", str(p_))
+        t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+        r, a, _ = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                         t["features_rest"], vm, K, 1920, 1080, 3, background=bgc, clamp=True, absgrad=True)  # fmt: skip
+        ((r * vr).sum() + a.sum()).backward()
+        outs.append((r.detach(), {k: v.grad for k, v in t.items()}))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for k in raw:
+        assert rel_l2(outs[0][1][k], outs[1][1][k]) < 5e-5, k
+
+
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
     """BASELINE.json's headline input itself -- 1M Gaussians, 1920x1080, SH 3, 7.2M intersections --
     forward and backward against the oracle on the WHOLE frame (torch projection / SH / sort + C
