@@ -439,7 +439,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ tile_offsets,
                                                 const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                                                 float* __restrict__ alphas, int32_t* __restrict__ last_ids,
-                                                const Composite& comp, float4* __restrict__ ckpt = nullptr) {
+                                                const Composite& comp, float4* __restrict__ ckpt = nullptr,
+                                                uint32_t* __restrict__ live_words = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -525,6 +526,14 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       cnt += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();  // the list is private to this wavefront
+    // LIVENESS for the backward (one wavefront per job only): bit j of live[k] = "list entry batch + j
+    // had a contributing pixel in slot k".  Written out per batch, one byte per (entry, strip); the
+    // backward then evaluates exactly the (entry, strip) pairs that did something here instead of
+    // re-testing every strip of every entry -- the compares and the exponential of those tests are
+    // the most expensive instructions of its loop (vector issue costs).
+    uint64_t live[PPT];
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) live[k] = 0ull;
     for (int n = 0; n < cnt; ++n) {
       if (all_done == full) break;  // this wavefront has nothing left to do
       // the entry is wave-uniform: move it to a scalar register so that the record address and
@@ -554,6 +563,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         if (valid == 0ull) continue;
         FG_STAT(10, 1);
         FG_STAT(11, __popcll(valid));
+        if (NW == 1) live[k] |= 1ull << j;
         const float next_T = T[k] * (1.f - alpha);
         const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
         const uint64_t take = valid & ~stop;
@@ -567,6 +577,22 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       all_done = full;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) all_done &= done[k];
+    }
+    if constexpr (NW == 1) {
+      if (live_words && batch + lane < end) {
+        // lane j flushes entry batch + j: byte s of the word = strip s (entries this wavefront never
+        // listed, or never reached because all its pixels were done, get an explicit 0)
+        if constexpr (PPT == 4) {
+          uint32_t w = 0;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) w |= (uint32_t)((live[k] >> lane) & 1ull) << (8 * k);
+          live_words[batch + lane] = w;
+        } else {
+          uint8_t* bytes = reinterpret_cast<uint8_t*>(live_words + (batch + lane));
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) bytes[wave + k * (4 / PPT)] = (uint8_t)((live[k] >> lane) & 1ull);
+        }
+      }
     }
   }
 
@@ -624,7 +650,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
-                        float4* __restrict__ ckpt) {
+                        float4* __restrict__ ckpt, uint32_t* __restrict__ live_words) {
   __shared__ FwdShared<C, 64> sh;
   // With a list the grid covers the positional job count plus a margin; fg_raster_build_jobs
   // makes the list fit it (build_jobs_kernel).  (A grid of the list's full capacity -- 4 jobs per
@@ -636,13 +662,13 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   if (tile < 0) return;
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                             last_ids, comp, ckpt);
+                             last_ids, comp, ckpt, live_words);
   else if (strip >= 4)
     raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt);
+                             alphas, last_ids, comp, ckpt, live_words);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt);
+                             alphas, last_ids, comp, ckpt, live_words);
 }
 
 template <int C, int NT>
@@ -656,7 +682,7 @@ struct BwdShared {
   int32_t mx[NT / 64];
 };
 
-template <int C, int PPT, int NW>
+template <int C, int PPT, int NW, bool LIVE = false>
 __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int tile, int wave_base, int width,
                                                 int height, int tile_w, const float4* __restrict__ splats,
                                                 const int32_t* __restrict__ tile_offsets,
@@ -666,7 +692,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                                                 const float* __restrict__ v_render,
                                                 const float* __restrict__ v_alphas, float* __restrict__ v_splats,
                                                 const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, 1},
-                                                int part = 0) {
+                                                int part = 0, const uint32_t* __restrict__ live_words = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -722,6 +748,12 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   }
   const int n_used = bin_final - start + 1;
   if (n_used <= 0) return;
+  // last list index any pixel of each of the job's pixel slots (= strips) used (scalars)
+  int slot_last[PPT];
+  if constexpr (LIVE) {
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) slot_last[k] = __builtin_amdgcn_readfirstlane(fg::wave_max_i32(last[k]));
+  }
   // this job's share of the list: [lo, hi) (struct Segments); the whole used list without segmentation
   int lo = start, hi = bin_final + 1;
   if constexpr (C == 3 && NW == 1) {
@@ -771,14 +803,26 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
     const int idx = batch + tl;
     unsigned mask = 0;
-    if (idx < hi) {
+    if constexpr (LIVE) {
+      // the forward's liveness byte per strip, valid up to the last entry any pixel of that strip
+      // used (beyond it the forward never wrote); dead entries are not even gathered
+      if (idx < hi) {
+        const uint32_t lw = live_words[idx];
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int s4 = wave + k * (4 / PPT);  // the slot's strip (uniform)
+          if (((lw >> (8 * s4)) & 1u) && idx <= slot_last[k]) mask |= 1u << s4;
+        }
+      }
+    }
+    if (LIVE ? mask != 0u : idx < hi) {
       const int gid = flatten_ids[idx];
       lds_gid[tl] = gid;
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) v[q] = rec[q];
-      mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
+      if constexpr (!LIVE) mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
       if constexpr (C == 3) {  // three spare floats in the 48-byte LDS copy: the pre-scaled conic rides along
         v[2].y = v[0].w * (0.5f * FG_NEG_LOG2E);
         v[2].z = v[1].x * FG_NEG_LOG2E;
@@ -797,9 +841,6 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         todo &= ~(1ull << bit);
         const int j = 64 * i + bit;
         const int idx_j = batch + j;
-#if !FG_BWD_BATCHED_PRETEST
-        const unsigned smask = PPT == 1 ? my_strips : __builtin_amdgcn_readfirstlane(lds_mask[j]);
-#endif
         if (NW > 1) {
           // wave-uniform skip: no pixel of THIS wavefront reaches the entry (with one wavefront per
           // tile every staged entry is <= bin_final = max(last), i.e. always reached by some pixel)
@@ -830,109 +871,84 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         // They are zeroed once per tile and again after each reduction that consumed them: an
         // entry to which no lane contributes leaves them untouched (all updates sit behind the
         // uniform any-valid branches).
-#if FG_BWD_BATCHED_PRETEST
-        // Pre-test of all pixel slots first, as PPT independent instruction chains with no branch
-        // between them: one wavefront issues a DEPENDENT vector instruction only every ~8 clocks
-        // (scripts/micro/valu_rate.hip) and a tile has few wavefronts, so the serial
-        // sub-fma-fma-exp-mul-min-cmp-branch chain per slot was latency-bound.  Slots the strip
-        // mask rules out are evaluated too (their masks come out empty: the culling is
-        // result-preserving), which costs less than the branches did.
-        float vis_k[PPT], alpha_k[PPT];
-        uint64_t valid_k[PPT];
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          const float e2 = neg_sigma_log2e(st, slot_dy<PPT>(dy_base, wave, k));
-          vis_k[k] = __builtin_amdgcn_exp2f(e2);
-          alpha_k[k] = fminf(FG_ALPHA_MAX, s.o * vis_k[k]);
-          valid_k[k] = lanes_sle(idx_j, last[k]) & lanes_ule(e2, 0.f) & lanes_uge(alpha_k[k], FG_ALPHA_SKIP);
-          FG_STAT(1, 1);
-        }
+        // one live pixel slot: `valid` lanes contribute (select-predicated straight-line code)
+#define FG_BWD_SLOT_UPDATE(K, VALID, VIS, ALPHA)                                                        \
+  do {                                                                                                  \
+    FG_STAT(2, 1);                                                                                      \
+    FG_STAT(3, __popcll(VALID));                                                                        \
+    contributed = true;                                                                                 \
+    const float dy = slot_dy<PPT>(dy_base, wave, K);                                                    \
+    const float ov = s.o * (VIS);                                                                       \
+    const float a_eff = lane_select0(VALID, ALPHA);                                                     \
+    const float ra = __builtin_amdgcn_rcpf(1.f - a_eff); /* 1 ulp; 1 - alpha >= 1e-3; 1 if masked */    \
+    T[K] *= ra;                                                                                         \
+    const float fac = a_eff * T[K];                                                                     \
+    float cdot = 0.f;                                                                                   \
+    _Pragma("unroll") for (int c = 0; c < C; ++c) {                                                     \
+      g[8 + c] += fac * vr[K][c];                                                                       \
+      cdot += f[c] * vr[K][c];                                                                          \
+    }                                                                                                   \
+    const float v_alpha = (cdot * T[K] - bsum[K] * ra) + tva[K] * ra;                                   \
+    bsum[K] += cdot * fac;                                                                              \
+    const uint64_t open = (VALID) & lanes_ole(ov, FG_ALPHA_MAX); /* alpha not clamped: gradient flows */ \
+    const float v_o = lane_select0(open, (VIS) * v_alpha);       /* d/d opacity */                      \
+    const float v_sigma = -s.o * v_o;                                                                   \
+    g[2] += v_o;                                                                                        \
+    /* dx is the same for all pixel slots of a lane: the conic gradient needs only the moments S0 = sum \
+       v_sigma, S1 = sum v_sigma dy, S2 = sum v_sigma dy^2 per entry (g[3..5], zero at the start of     \
+       every contributing entry) -- finished below */                                                    \
+    const float vsdy = v_sigma * dy;                                                                    \
+    g[3] += v_sigma;                                                                                    \
+    g[4] += vsdy;                                                                                       \
+    g[5] = fmaf(vsdy, dy, g[5]);                                                                        \
+    const float gx = v_sigma * (s.a * dx + s.b * dy);                                                   \
+    const float gy = v_sigma * (s.b * dx + s.c * dy);                                                   \
+    g[0] += gx;                                                                                         \
+    g[1] += gy;                                                                                         \
+    g[6] += fabsf(gx); /* absgrad sums |.| per pixel: not a moment */                                   \
+    g[7] += fabsf(gy);                                                                                  \
+  } while (0)
         bool contributed = false;
+        if constexpr (LIVE) {
+          // The forward recorded which (entry, strip) pairs had a contributing pixel (live_words): only
+          // those are evaluated -- no exponential, no compares for the others.
+          const unsigned smask = __builtin_amdgcn_readfirstlane(lds_mask[j]);
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          const uint64_t valid = valid_k[k];
-          if (valid == 0ull) continue;  // scalar
-          FG_STAT(2, 1);
-          FG_STAT(3, __popcll(valid));
-          contributed = true;
-          const float dy = slot_dy<PPT>(dy_base, wave, k);
-          const float vis = vis_k[k];
-          const float ov = s.o * vis;
-          const float a_eff = lane_select0(valid, alpha_k[k]);
-          const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
-          T[k] *= ra;
-          const float fac = a_eff * T[k];
-          float cdot = 0.f;
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            g[8 + c] += fac * vr[k][c];
-            cdot += f[c] * vr[k][c];
+          for (int k = 0; k < PPT; ++k) {
+            if (!((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
+            const float e2 = neg_sigma_log2e(st, slot_dy<PPT>(dy_base, wave, k));
+            const float vis = __builtin_amdgcn_exp2f(e2);
+            const float alpha = fminf(FG_ALPHA_MAX, s.o * vis);
+            const uint64_t valid = lanes_sle(idx_j, last[k]) & lanes_ule(e2, 0.f) & lanes_uge(alpha, FG_ALPHA_SKIP);
+            FG_STAT(1, 1);
+            if (valid == 0ull) continue;  // (a one-ulp disagreement with the forward's test)
+            FG_BWD_SLOT_UPDATE(k, valid, vis, alpha);
           }
-          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
-          bsum[k] += cdot * fac;
-          const uint64_t open = valid & lanes_ole(ov, FG_ALPHA_MAX);  // alpha not clamped: gradient flows
-          const float v_o = lane_select0(open, vis * v_alpha);        // d/d opacity
-          const float v_sigma = -s.o * v_o;
-          g[2] += v_o;
-          const float vsdy = v_sigma * dy;
-          g[3] += v_sigma;
-          g[4] += vsdy;
-          g[5] = fmaf(vsdy, dy, g[5]);
-          const float gx = v_sigma * (s.a * dx + s.b * dy);
-          const float gy = v_sigma * (s.b * dx + s.c * dy);
-          g[0] += gx;
-          g[1] += gy;
-          g[6] += fabsf(gx);
-          g[7] += fabsf(gy);
-        }
-#else
-        bool contributed = false;
+        } else {
+          // Pre-test of all pixel slots first, as PPT independent instruction chains with no branch
+          // between them: one wavefront issues a DEPENDENT vector instruction only every ~8 clocks
+          // (scripts/micro/valu_rate.hip) and a tile has few wavefronts, so the serial
+          // sub-fma-fma-exp-mul-min-cmp-branch chain per slot was latency-bound.  Slots the strip
+          // mask rules out are evaluated too (their masks come out empty: the culling is
+          // result-preserving), which costs less than the branches did.
+          float vis_k[PPT], alpha_k[PPT];
+          uint64_t valid_k[PPT];
 #pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          if (PPT > 1 && !((smask >> (wave + k * (4 / PPT))) & 1u)) continue;  // wave-uniform
-          const float dy = slot_dy<PPT>(dy_base, wave, k);
-          const float e2 = neg_sigma_log2e(st, dy);
-          const float vis = __builtin_amdgcn_exp2f(e2);
-          const float ov = s.o * vis;
-          const float alpha = fminf(FG_ALPHA_MAX, ov);
-          const bool valid = (idx_j <= last[k]) && !(e2 > 0.f || alpha < FG_ALPHA_SKIP);
-          FG_STAT(1, 1);
-          if (!__any(valid)) continue;  // wave-uniform
-          FG_STAT(2, 1);
-          FG_STAT(3, __popcll(__ballot(valid)));
-          contributed = true;
-          const float a_eff = valid ? alpha : 0.f;
-          const float ra = __builtin_amdgcn_rcpf(1.f - a_eff);  // 1 ulp; 1 - alpha >= 1e-3; 1 if masked
-          T[k] *= ra;
-          const float fac = a_eff * T[k];
-          // only <colour, v_render> enters v_alpha: track the suffix sum as that scalar
-          float cdot = 0.f;
-#pragma unroll
-          for (int c = 0; c < C; ++c) {
-            g[8 + c] += fac * vr[k][c];
-            cdot += f[c] * vr[k][c];
+          for (int k = 0; k < PPT; ++k) {
+            const float e2 = neg_sigma_log2e(st, slot_dy<PPT>(dy_base, wave, k));
+            vis_k[k] = __builtin_amdgcn_exp2f(e2);
+            alpha_k[k] = fminf(FG_ALPHA_MAX, s.o * vis_k[k]);
+            valid_k[k] = lanes_sle(idx_j, last[k]) & lanes_ule(e2, 0.f) & lanes_uge(alpha_k[k], FG_ALPHA_SKIP);
+            FG_STAT(1, 1);
           }
-          const float v_alpha = (cdot * T[k] - bsum[k] * ra) + tva[k] * ra;
-          bsum[k] += cdot * fac;
-          const bool open = valid && (ov <= FG_ALPHA_MAX);  // alpha not clamped: gradient flows
-          const float v_o = open ? vis * v_alpha : 0.f;       // d/d opacity
-          const float v_sigma = -s.o * v_o;
-          g[2] += v_o;
-          // dx is the same for all pixel slots of a lane: the conic gradient needs only the moments
-          // S0 = sum v_sigma, S1 = sum v_sigma dy, S2 = sum v_sigma dy^2 per entry (kept in g[3..5],
-          // which are zero at the start of every contributing entry) -- finished below
-          const float vsdy = v_sigma * dy;
-          g[3] += v_sigma;
-          g[4] += vsdy;
-          g[5] = fmaf(vsdy, dy, g[5]);
-          const float gx = v_sigma * (s.a * dx + s.b * dy);
-          const float gy = v_sigma * (s.b * dx + s.c * dy);
-          g[0] += gx;
-          g[1] += gy;
-          g[6] += fabsf(gx);  // absgrad sums |.| per pixel: not a moment
-          g[7] += fabsf(gy);
+#pragma unroll
+          for (int k = 0; k < PPT; ++k) {
+            const uint64_t valid = valid_k[k];
+            if (valid == 0ull) continue;  // scalar
+            FG_BWD_SLOT_UPDATE(k, valid, vis_k[k], alpha_k[k]);
+          }
         }
-#endif
+#undef FG_BWD_SLOT_UPDATE
         if (!contributed) continue;  // wave-uniform: only ever set under the uniform any-valid branches
         // v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
         g[5] *= 0.5f;
@@ -999,7 +1015,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
                               v_render, v_alphas, v_splats, comp);
 }
 
-template <int C>
+template <int C, bool LIVE>
 __global__ void __launch_bounds__(64)
 raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
                         const int32_t* __restrict__ jobs, int cap,
@@ -1007,27 +1023,30 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
                         const int32_t* __restrict__ last_ids, const float* __restrict__ v_render,
                         const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp,
-                        Segments seg) {
+                        Segments seg, const uint32_t* __restrict__ live_words) {
   __shared__ BwdShared<C, 64> sh;
   int strip, part = 0, b = blockIdx.x;
   if (seg.parts > 1) {
     // consecutive workgroups of an XCD (b, b + 8, ...) are the parts of one tile: they share its
     // records in the XCD's L2
-    const int k = b >> 3;
-    part = k % seg.parts;
-    b = ((k / seg.parts) << 3) | (b & 7);
+    // (rotated by the tile's position: workgroups go to a CU's SIMDs round-robin, tiles with fewer
+    // segments than parts leave the same part numbers empty, and unrotated those all landed on the
+    // same SIMDs -- 4 parts took 0.77 ms against 0.43 for 3)
+    const int k = b >> 3, t = k / seg.parts;
+    part = (k - t * seg.parts + t) % seg.parts;
+    b = (t << 3) | (b & 7);
   }
   const int tile = jobs ? job_from_list(b, jobs, cap, strip) : job_of_block(b, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
   if (strip < 0)
-    raster_bwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas, last_ids,
-                             v_render, v_alphas, v_splats, comp, seg, part);
+    raster_bwd_body<C, 4, 1, LIVE>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
+                                   last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);
   else if (strip >= 4)
-    raster_bwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
-                             last_ids, v_render, v_alphas, v_splats, comp, seg, part);
+    raster_bwd_body<C, 2, 1, LIVE>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids,
+                                   alphas, last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);
   else
-    raster_bwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
-                             last_ids, v_render, v_alphas, v_splats, comp, seg, part);
+    raster_bwd_body<C, 1, 1, LIVE>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
+                                   last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1237,13 +1256,14 @@ int raster_split(const char* name, int dflt4, int dflt2) {
 template <int C>
 int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
-                     int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr) {
+                     int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr,
+                     uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
                      dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
-                     reinterpret_cast<float4*>(ckpt));
+                     reinterpret_cast<float4*>(ckpt), live_words);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1251,7 +1271,8 @@ template <int C>
 int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1}) {
+                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1},
+                     const uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
   int grid = jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail);
@@ -1260,12 +1281,22 @@ int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const
     tail = 0;
     grid = mixed_grid(tile_w, tile_h, 0) * seg.parts;
   }
-  hipLaunchKernelGGL((raster_bwd_mixed_kernel<C>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs,
-                     cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids, v_render,
-                     v_alphas, v_splats, comp, seg);
+  if (live_words)
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail,
+                       jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
+                       v_render, v_alphas, v_splats, comp, seg, live_words);
+  else
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, false>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail,
+                       jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
+                       v_render, v_alphas, v_splats, comp, seg, live_words);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
+// FG_RASTER_LIVE=0: the backward ignores the forward's liveness bytes (A/B)
+const uint32_t* live_use(const uint32_t* live_words) {
+  const char* e = getenv("FG_RASTER_LIVE");
+  return (e && e[0] == '0') ? nullptr : live_words;
+}
 // FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
 int seg_parts() {
   const char* e = getenv("FG_RASTER_SEG_PARTS");
@@ -1320,7 +1351,7 @@ namespace {
 int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                    int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
-                   float* seg_ckpt = nullptr) {
+                   float* seg_ckpt = nullptr, uint32_t* live_words = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
@@ -1333,7 +1364,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
-                                         alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr)                   \
+                                         alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr, live_words)       \
        : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
@@ -1349,7 +1380,8 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
                    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                    const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
                    Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
-                   const float* seg_ckpt = nullptr, const float* image = nullptr) {
+                   const float* seg_ckpt = nullptr, const float* image = nullptr,
+                   const uint32_t* live_words = nullptr) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !alphas || !last_ids || !v_render || !v_splats) return FG_ERR_INVALID_ARG;
@@ -1366,7 +1398,8 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
     seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts()};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
-                                         alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg)      \
+                                         alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
+                                         live_use(live_words))                                              \
        : (ppt == 4) ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
        : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
@@ -1445,9 +1478,10 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
 extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, float* image, float* alphas,
-                                  int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, fg_stream_t stream) {
+                                  int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
+                                  fg_stream_t stream) {
   return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
-                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt);
+                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt, live_words);
 }
 
 extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects) {
@@ -1462,10 +1496,10 @@ extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_
                                   const float* background, int n_clamp, const uint8_t* clamp_mask,
                                   const float* alphas, const int32_t* last_ids, const float* v_image,
                                   const float* v_alphas, float* v_splats, const float* seg_ckpt,
-                                  const float* image, fg_stream_t stream) {
+                                  const float* image, const uint32_t* live_words, fg_stream_t stream) {
   return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
-                        stream, jobs, seg_ckpt, image);
+                        stream, jobs, seg_ckpt, image, live_words);
 }
 
 #ifdef FG_RASTER_STATS

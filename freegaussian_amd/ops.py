@@ -714,7 +714,7 @@ class _RasterSplats(torch.autograd.Function):
         clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
         # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches
         words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size)))
-        jobs = seg_ckpt = None
+        jobs = seg_ckpt = live = None
         if words > 0:
             jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
@@ -722,11 +722,13 @@ class _RasterSplats(torch.autograd.Function):
                                                              int(flatten_ids.numel())))  # fmt: skip
             if n_ck > 0:
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
+            # liveness of every (list entry, strip) pair, noted by the forward for the backward
+            live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)
             _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
                   _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
-                  _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _stream(),
+                  _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _stream(),
                   stage="fg_raster_composite_fwd" if composite else "fg_raster_fwd")  # fmt: skip
         elif composite:  # O1 folded into the kernel epilogue: render is the finished image
             _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
@@ -736,7 +738,7 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
-                              render if seg_ckpt is not None else None)  # fmt: skip
+                              render if seg_ckpt is not None else None, live)  # fmt: skip
         ctx.jobs_bwd = jobs[1] if jobs is not None else None
         ctx.set_materialize_grads(False)  # an unused alpha / render must not cost a zero-fill launch
         ctx.composite = (composite, int(n_clamp))
@@ -748,7 +750,7 @@ class _RasterSplats(torch.autograd.Function):
     @staticmethod
     def backward(ctx, v_render, v_alphas, _v_last):
         (splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
-         image) = ctx.saved_tensors  # fmt: skip
+         image, live) = ctx.saved_tensors  # fmt: skip
         C, width, height, tile_size, absgrad, m2_shape = ctx.geom
         composite, n_clamp = ctx.composite
         N = splats.shape[0]
@@ -759,7 +761,7 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_jobs_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(ctx.jobs_bwd), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas),
                   _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _ptr(seg_ckpt),
-                  _ptr(image), _stream(),
+                  _ptr(image), _ptr(live), _stream(),
                   stage="fg_raster_composite_bwd" if composite else "fg_raster_bwd")  # fmt: skip
             ctx.jobs_bwd = None
         elif composite:

@@ -212,21 +212,26 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * this size / environment); seg_ckpt[floats], uninitialised, goes to BOTH calls and `image` (the
  * forward's output) to the backward: the forward leaves every pixel's compositing state at every
  * 128th entry of a tile's list, and the backward runs several jobs per tile, each over its share of
- * the list, instead of one serial walk.  Same gradients up to float summation order.  NULL = off. */
+ * the list, instead of one serial walk.  Same gradients up to float summation order.  NULL = off.
+ * LIVENESS (any channel count): live_words[n_isects] uint32, uninitialised, to BOTH calls: the
+ * forward notes per (list entry, 4-row strip) whether any pixel took the entry (byte s of word i =
+ * strip s of entry i), and the backward evaluates exactly those pairs instead of re-testing every
+ * strip of every entry -- same gradients, about a third fewer vector issue cycles.  NULL = off. */
 int64_t fg_raster_jobs_words(int width, int height, int tile_size);
 int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
                          int32_t* jobs_fwd, int32_t* jobs_bwd, fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,
-                       int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, fg_stream_t stream);
+                       int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
+                       fg_stream_t stream);
 int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects);
 int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, const uint8_t* clamp_mask,
                        const float* alphas, const int32_t* last_ids, const float* v_image,
                        const float* v_alphas, float* v_splats, const float* seg_ckpt, const float* image,
-                       fg_stream_t stream);
+                       const uint32_t* live_words, fg_stream_t stream);
 /* Split v_splats back into per-tensor gradients (any output nullable). */
 int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
                     float* v_means2d_abs, float* v_conics, float* v_opacities,

@@ -955,7 +955,7 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
         outs.append((r.detach(), {k: v.grad for k, v in t.items()}))
     assert torch.equal(outs[0][0], outs[1][0])
     for k in raw:
-        assert rel_l2(outs[0][1][k], outs[1][1][k]) < 5e-5, k
+        assert rel_l2(outs[0][1][k], outs[1][1][k]) < REL_TOL, k
 
 
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
