@@ -531,9 +531,12 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     // backward then evaluates exactly the (entry, strip) pairs that did something here instead of
     // re-testing every strip of every entry -- the compares and the exponential of those tests are
     // the most expensive instructions of its loop (vector issue costs).
-    uint64_t live[PPT];
+    // (kept in lane j of a vector register, set with v_writelane: the scalar unit, shared by the CU's
+    // four SIMDs, is this kernel's busiest pipe -- as 64-bit scalar masks the bookkeeping cost the
+    // forward 0.211 -> 0.223 ms)
+    int live[PPT];
 #pragma unroll
-    for (int k = 0; k < PPT; ++k) live[k] = 0ull;
+    for (int k = 0; k < PPT; ++k) live[k] = 0;
     for (int n = 0; n < cnt; ++n) {
       if (all_done == full) break;  // this wavefront has nothing left to do
       // the entry is wave-uniform: move it to a scalar register so that the record address and
@@ -563,7 +566,9 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         if (valid == 0ull) continue;
         FG_STAT(10, 1);
         FG_STAT(11, __popcll(valid));
-        if (NW == 1) live[k] |= 1ull << j;
+        // (j comes from a scalar ALU instruction and live[k] was last written dozens of instructions
+        // ago: none of gfx950's lane-access wait states applies)
+        if (NW == 1) asm("v_writelane_b32 %0, 1, %1" : "+v"(live[k]) : "s"(j));
         const float next_T = T[k] * (1.f - alpha);
         const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
         const uint64_t take = valid & ~stop;
@@ -583,14 +588,12 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         // lane j flushes entry batch + j: byte s of the word = strip s (entries this wavefront never
         // listed, or never reached because all its pixels were done, get an explicit 0)
         if constexpr (PPT == 4) {
-          uint32_t w = 0;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) w |= (uint32_t)((live[k] >> lane) & 1ull) << (8 * k);
-          live_words[batch + lane] = w;
+          live_words[batch + lane] = (uint32_t)live[0] | ((uint32_t)live[1] << 8) | ((uint32_t)live[2] << 16) |
+                                     ((uint32_t)live[3] << 24);
         } else {
           uint8_t* bytes = reinterpret_cast<uint8_t*>(live_words + (batch + lane));
 #pragma unroll
-          for (int k = 0; k < PPT; ++k) bytes[wave + k * (4 / PPT)] = (uint8_t)((live[k] >> lane) & 1ull);
+          for (int k = 0; k < PPT; ++k) bytes[wave + k * (4 / PPT)] = (uint8_t)live[k];
         }
       }
     }

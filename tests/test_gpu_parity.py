@@ -936,7 +936,7 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
         _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
         assert torch.equal(o2[0], o1[0])  # the forward does not depend on it
         for k in seg_grads:
-            assert rel_l2(seg_grads[k], gpu_in1[k].grad) < 2e-5, k
+            assert rel_l2(seg_grads[k], gpu_in1[k].grad) < REL_TOL, k  # (suffix colour = C_final - C_before: one more rounding per pixel)
         return
     # composite epilogue: the model's raw-parameter front end with a background and the clamp
     g = torch.Generator().manual_seed(3)
