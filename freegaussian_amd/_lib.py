@@ -46,7 +46,7 @@ SIGNATURES = {
     "fg_raster_composite_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P]),
     "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P]),
     "fg_raster_jobs_words": (c_int64, [c_int, c_int, c_int]),
-    "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, P]),
+    "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P]),
     "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P]),
     "fg_raster_seg_ckpt_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int64]),
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),

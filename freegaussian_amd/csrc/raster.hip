@@ -135,7 +135,26 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
 struct JobParams {
   int tail4, tail2, s4, s2;
   int max_jobs;  // workgroups per XCD of the launch that will read the list
+  // list shares instead of pixel strips (the segmented backward, struct Segments): the last seg_tail
+  // tiles of the sequence become seg_parts jobs each, a tile longer than the s2 threshold as many
+  // jobs (up to 16) as make its shares about half that threshold long; entry = tile << 8 | part << 4 |
+  // (parts - 1), the part numbers rotated by the tile's position
+  int seg_parts, seg_tail;
 };
+__device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
+                                         int thr2, int len) {
+  if (p.seg_parts > 1) {
+    int c = idx >= n - min(p.seg_tail, n) ? p.seg_parts : 1;
+    if (len > thr2) {
+      const int share = max(thr2 >> 1, 1);
+      c = max(c, min(16, (len + share - 1) / share));
+    }
+    return c;
+  }
+  int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
+  level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
+  return 1 << level;
+}
 __global__ void __launch_bounds__(1024)
 build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
                   JobParams pb, int32_t* __restrict__ jobs_fwd, int32_t* __restrict__ jobs_bwd) {
@@ -165,9 +184,7 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
       const int col = idx / rows;
       const int tile = (row0 + idx - col * rows) * tile_w + col;
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
-      level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
-      mine += 1 << level;
+      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
@@ -192,9 +209,7 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
       const int col = idx / rows;
       tile = (row0 + idx - col * rows) * tile_w + col;
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
-      level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
-      cnt = 1 << level;
+      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
     }
     int incl = cnt;
 #pragma unroll
@@ -208,7 +223,9 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
 #pragma unroll
     for (int w = 0; w < NWV; ++w)
       if (w < wave) pos += wave_tot[w];
-    if (cnt == 1) seg[pos] = tile << 3;  // strip -1
+    if (p.seg_parts > 1) {
+      for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 8 | ((j + idx) % cnt) << 4 | (cnt - 1);
+    } else if (cnt == 1) seg[pos] = tile << 3;  // strip -1
     else if (cnt == 2) { seg[pos] = tile << 3 | 5; seg[pos + 1] = tile << 3 | 6; }  // strip 4, 5
     else if (cnt == 4) {
 #pragma unroll
@@ -228,6 +245,16 @@ __device__ __forceinline__ int job_from_list(int b, const int32_t* __restrict__ 
   const int e = jobs[8 + (size_t)xcd * cap + k];
   strip = (e & 7) - 1;
   return e >> 3;
+}
+
+// the same from a list of list-share jobs (JobParams::seg_parts): tile, part, parts
+__device__ __forceinline__ int share_from_list(int b, const int32_t* __restrict__ jobs, int cap, int& part, int& parts) {
+  const int xcd = b & 7, k = b >> 3;
+  if (k >= jobs[xcd]) return -1;
+  const int e = jobs[8 + (size_t)xcd * cap + k];
+  parts = (e & 15) + 1;
+  part = (e >> 4) & 15;
+  return e >> 8;
 }
 
 struct Splat {
@@ -285,14 +312,20 @@ struct Composite {
 #ifndef FG_SEG_ENTRIES
 #define FG_SEG_ENTRIES 128
 #endif
+// measured on MI355X (1M Gaussians, 1080p, profiles/r02_backward_list_shares.md): the last 400 tiles of
+// every XCD's sequence as 3 shares each: 0.398 -> 0.374 ms against two-strip jobs for the last 300
 #ifndef FG_SEG_PARTS_DEFAULT
-#define FG_SEG_PARTS_DEFAULT 1
+#define FG_SEG_PARTS_DEFAULT 3
+#endif
+#ifndef FG_SEG_TAIL_DEFAULT
+#define FG_SEG_TAIL_DEFAULT 400
 #endif
 struct Segments {
   float4* ckpt;             // [slots][256 pixels of the tile, row-major]; nullptr = no segmentation
   const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
                             // composite epilogue they are rebuilt from the finished image instead
-  int parts;                // backward: jobs per tile (1 = whole list)
+  int parts;                // backward: jobs per split tile (1 = whole list)
+  int tail;                 // backward: the last `tail` tiles of every XCD's sequence are split (0 = all)
 };
 
 // Optional work counters (make stats -> libfgraster_stats.so; never in the product library).
@@ -694,7 +727,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ last_ids,
                                                 const float* __restrict__ v_render,
                                                 const float* __restrict__ v_alphas, float* __restrict__ v_splats,
-                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, 1},
+                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, 1, 0},
                                                 int part = 0, const uint32_t* __restrict__ live_words = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
@@ -1028,18 +1061,35 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const float* __restrict__ v_alphas, float* __restrict__ v_splats, Composite comp,
                         Segments seg, const uint32_t* __restrict__ live_words) {
   __shared__ BwdShared<C, 64> sh;
-  int strip, part = 0, b = blockIdx.x;
+  int strip = -1, part = 0, tile;
   if (seg.parts > 1) {
-    // consecutive workgroups of an XCD (b, b + 8, ...) are the parts of one tile: they share its
-    // records in the XCD's L2
-    // (rotated by the tile's position: workgroups go to a CU's SIMDs round-robin, tiles with fewer
-    // segments than parts leave the same part numbers empty, and unrotated those all landed on the
-    // same SIMDs -- 4 parts took 0.77 ms against 0.43 for 3)
-    const int k = b >> 3, t = k / seg.parts;
-    part = (k - t * seg.parts + t) % seg.parts;
-    b = (t << 3) | (b & 7);
+    // list-share jobs (struct Segments): whole tiles, some of them cut into several jobs over shares
+    // of their list -- from the job list (by position and by content, build_jobs_kernel) or, without
+    // one, the last seg.tail tiles of every XCD's sequence
+    if (jobs) {
+      tile = share_from_list(blockIdx.x, jobs, cap, part, seg.parts);
+    } else {
+      // consecutive workgroups of the XCD are the shares of one tile (they share its records in the L2);
+      // part numbers rotated by the tile's position: workgroups go to a CU's SIMDs round-robin, tiles
+      // with fewer segments than parts leave the same part numbers empty, and unrotated those all
+      // landed on the same SIMDs (4 parts: 0.77 ms against 0.43 for 3)
+      const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+      const int q = tile_h >> 3, r = tile_h & 7;
+      const int n = (q + (xcd < r ? 1 : 0)) * tile_w;
+      const int tail = seg.tail > 0 ? min(seg.tail, n) : n, n_main = n - tail;
+      int t = k;
+      if (k >= n_main) {
+        t = n_main + (k - n_main) / seg.parts;
+        part = ((k - n_main) - (t - n_main) * seg.parts + t) % seg.parts;
+      } else {
+        seg.parts = 1;  // (a by-value copy: this workgroup walks its tile's whole list)
+      }
+      tile = job_of_block((t << 3) | xcd, tile_w, tile_h, 0, strip);
+    }
+  } else {
+    tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
+                : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   }
-  const int tile = jobs ? job_from_list(b, jobs, cap, strip) : job_of_block(b, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
   if (strip < 0)
     raster_bwd_body<C, 4, 1, LIVE>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
@@ -1256,6 +1306,33 @@ int raster_split(const char* name, int dflt4, int dflt2) {
   return s4 | (s2 << 16);
 }
 
+// workgroups of a launch of list-share jobs: the positional count (+ half a job per tile for content
+// splits when a list is read: the builder fits the list into it)
+int seg_grid(int tile_w, int tile_h, int parts, int tail, bool listed) {
+  const int n_max = band_tiles_max(tile_w, tile_h);
+  const int split = tail > 0 ? (tail < n_max ? tail : n_max) : n_max;
+  const int per_xcd = n_max - split + split * parts + (listed ? n_max / 2 : 0);
+  const int cap = jobs_cap(tile_w, tile_h);
+  return 8 * (listed && per_xcd > cap ? cap : per_xcd);
+}
+// FG_RASTER_LIVE=0: the backward ignores the forward's liveness bytes (A/B)
+const uint32_t* live_use(const uint32_t* live_words) {
+  const char* e = getenv("FG_RASTER_LIVE");
+  return (e && e[0] == '0') ? nullptr : live_words;
+}
+// FG_RASTER_SEG_TAIL = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
+int seg_tail() {
+  const char* e = getenv("FG_RASTER_SEG_TAIL");
+  const int v = e ? atoi(e) : FG_SEG_TAIL_DEFAULT;
+  return v < 0 ? 0 : v;
+}
+// FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
+int seg_parts() {
+  const char* e = getenv("FG_RASTER_SEG_PARTS");
+  const int v = e ? atoi(e) : FG_SEG_PARTS_DEFAULT;
+  return v < 1 ? 1 : (v > 16 ? 16 : v);
+}
+
 template <int C>
 int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
@@ -1274,16 +1351,12 @@ template <int C>
 int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1},
+                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1, 0},
                      const uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
   int grid = jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail);
-  if (seg.parts > 1) {  // whole-tile jobs only, seg.parts list segments each (struct Segments)
-    jobs = nullptr;
-    tail = 0;
-    grid = mixed_grid(tile_w, tile_h, 0) * seg.parts;
-  }
+  if (seg.parts > 1) grid = seg_grid(tile_w, tile_h, seg.parts, seg.tail, jobs != nullptr);
   if (live_words)
     hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail,
                        jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
@@ -1295,17 +1368,7 @@ int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
-// FG_RASTER_LIVE=0: the backward ignores the forward's liveness bytes (A/B)
-const uint32_t* live_use(const uint32_t* live_words) {
-  const char* e = getenv("FG_RASTER_LIVE");
-  return (e && e[0] == '0') ? nullptr : live_words;
-}
-// FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
-int seg_parts() {
-  const char* e = getenv("FG_RASTER_SEG_PARTS");
-  const int v = e ? atoi(e) : FG_SEG_PARTS_DEFAULT;
-  return v < 1 ? 1 : (v > 16 ? 16 : v);
-}
+
 
 #define FG_DISPATCH_C(CALL)                  \
   switch (channels) {                        \
@@ -1396,9 +1459,9 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   int tail = mixed_tail_bwd(n_tiles);
   if (tail == 0) jobs = nullptr;
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
-  Segments seg{nullptr, nullptr, 1};
+  Segments seg{nullptr, nullptr, 1, 0};
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
-    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts()};
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(), seg_tail()};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -1460,7 +1523,8 @@ extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size) {
 }
 
 extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
-                                    int32_t* jobs_fwd, int32_t* jobs_bwd, fg_stream_t stream) {
+                                    int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
+                                    fg_stream_t stream) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!tile_offsets) return FG_ERR_INVALID_ARG;
@@ -1470,8 +1534,13 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   const int tf = mixed_tail_fwd(n_tiles), tb = mixed_tail_bwd(n_tiles);
   const int sf = raster_split("FG_RASTER_SPLIT_FWD", FG_SPLIT4_FWD, FG_SPLIT2_FWD);
   const int sb = raster_split("FG_RASTER_SPLIT_BWD", FG_SPLIT4_BWD, FG_SPLIT2_BWD);
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8};
-  const JobParams pb{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8};
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8, 0, 0};
+  // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
+  // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
+  const bool shares = bwd_list_shares && tb > 0 && seg_parts() > 1;
+  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), seg_tail(), true) / 8,
+                                          seg_parts(), seg_tail()}
+                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
                      jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
   FG_RETURN_IF_LAUNCH_FAILED();

@@ -725,7 +725,7 @@ class _RasterSplats(torch.autograd.Function):
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
             live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)
             _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
-                  _stream())  # fmt: skip
+                  int(seg_ckpt is not None), _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
                   _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _stream(),

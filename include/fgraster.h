@@ -213,13 +213,15 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * forward's output) to the backward: the forward leaves every pixel's compositing state at every
  * 128th entry of a tile's list, and the backward runs several jobs per tile, each over its share of
  * the list, instead of one serial walk.  Same gradients up to float summation order.  NULL = off.
+ * fg_raster_build_jobs(bwd_list_shares = 1) must then have built the backward's list (its entries
+ * are (tile, part, parts) instead of (tile, strip)).
  * LIVENESS (any channel count): live_words[n_isects] uint32, uninitialised, to BOTH calls: the
  * forward notes per (list entry, 4-row strip) whether any pixel took the entry (byte s of word i =
  * strip s of entry i), and the backward evaluates exactly those pairs instead of re-testing every
  * strip of every entry -- same gradients, about a third fewer vector issue cycles.  NULL = off. */
 int64_t fg_raster_jobs_words(int width, int height, int tile_size);
 int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
-                         int32_t* jobs_fwd, int32_t* jobs_bwd, fg_stream_t stream);
+                         int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,

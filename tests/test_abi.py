@@ -48,7 +48,7 @@ def test_workspace_queries_need_no_gpu():
     assert lib.fg_raster_jobs_words(480, 270, 16) == 0
     assert lib.fg_raster_jobs_words(1920, 1080, 16) == 8 + 8 * 4 * 9 * 120
     assert lib.fg_raster_jobs_words(1920, 1080, 8) == 0  # unsupported tile size
-    assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, None) == -1
+    assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, 0, None) == -1
 
 
 def test_argument_validation_without_gpu():
