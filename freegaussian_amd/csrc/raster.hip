@@ -1326,6 +1326,15 @@ int seg_tail() {
   const int v = e ? atoi(e) : FG_SEG_TAIL_DEFAULT;
   return v < 0 ? 0 : v;
 }
+// ... clamped so that the positional jobs of the largest XCD band (+ the margin for content splits)
+// fit a job list segment
+int seg_tail_fit(int tile_w, int tile_h, int parts, int tail) {
+  const int n_max = band_tiles_max(tile_w, tile_h);
+  if (tail <= 0 || tail > n_max) tail = n_max;
+  const int room = jobs_cap(tile_w, tile_h) - n_max - n_max / 2;
+  const int fit = parts > 1 ? room / (parts - 1) : n_max;
+  return tail < fit ? tail : (fit > 1 ? fit : 1);
+}
 // FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
 int seg_parts() {
   const char* e = getenv("FG_RASTER_SEG_PARTS");
@@ -1461,7 +1470,8 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
   Segments seg{nullptr, nullptr, 1, 0};
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
-    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(), seg_tail()};
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(),
+                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(), seg_tail())};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -1538,8 +1548,9 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const bool shares = bwd_list_shares && tb > 0 && seg_parts() > 1;
-  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), seg_tail(), true) / 8,
-                                          seg_parts(), seg_tail()}
+  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(), seg_tail());
+  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), st, true) / 8,
+                                          seg_parts(), st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
                      jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);

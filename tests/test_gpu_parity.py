@@ -1000,7 +1000,7 @@ def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monk
     assert int(lens.max()) > 20 * ids.numel() // 65536  # some tiles really are above the quarter threshold
     assert torch.equal(r, r_c) and torch.equal(a, a_c)
     for x, y in zip(grads, grads_c):
-        assert rel_l2(x, y) < 1e-5
+        assert rel_l2(x, y) < REL_TOL  # (list shares of the backward: suffix colours by subtraction, one more rounding)
     # centre crop (the heavy tiles) against the C oracle, as in the cfg4 test
     cw, ch = 160, 96
     x0, y0 = (W - cw) // 2 // 16 * 16, (H - ch) // 2 // 16 * 16
