@@ -570,8 +570,16 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     int live[PPT];
 #pragma unroll
     for (int k = 0; k < PPT; ++k) live[k] = 0;
-    for (int n = 0; n < cnt; ++n) {
+    // "every pixel of this wavefront is finished" is re-checked every 8 entries only: the check is
+    // six scalar instructions and the scalar unit, shared by the CU's four SIMDs, is this kernel's
+    // busiest pipe (an entry walked after the last pixel finished finds no valid lane and does nothing)
+    for (int n0 = 0; n0 < cnt; n0 += 8) {
+      all_done = full;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) all_done &= done[k];
       if (all_done == full) break;  // this wavefront has nothing left to do
+      const int n1 = min(n0 + 8, cnt);
+      for (int n = n0; n < n1; ++n) {
       // the entry is wave-uniform: move it to a scalar register so that the record address and
       // the list index are scalar arithmetic (as a vector value the compiler spent a quarter-rate
       // v_mul_lo_u32 per entry on the address)
@@ -612,9 +620,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         T[k] = lane_select(take, next_T, T[k]);
         done[k] |= stop;
       }
-      all_done = full;
-#pragma unroll
-      for (int k = 0; k < PPT; ++k) all_done &= done[k];
+      }
     }
     if constexpr (NW == 1) {
       if (live_words && batch + lane < end) {
