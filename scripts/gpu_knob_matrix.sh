@@ -3,7 +3,9 @@
 # optional path must give the same results).  Usage: gpurun -- 'bash scripts/gpu_knob_matrix.sh'
 for env in "FG_RASTER_PPT_FWD=1 FG_RASTER_PPT_BWD=1" "FG_RASTER_PPT_FWD=4 FG_RASTER_PPT_BWD=2" "FG_RASTER_PPT_FWD=2 FG_RASTER_PPT_BWD=4" \
            "FG_RASTER_TAIL_FWD=3,4 FG_RASTER_TAIL_BWD=5,2 FG_RASTER_SPLIT_FWD=3,2 FG_RASTER_SPLIT_BWD=2,1" "FG_RASTER_TAIL_FWD=100000 FG_RASTER_TAIL_BWD=100000" \
-           "FG_TILE_ORDER=rows" "FG_TILE_ORDER=split" "FG_TILE_ORDER=x" "FG_SPECULATIVE_BINNING=0" "FG_OVERLAP_PACK=1"; do
+           "FG_TILE_ORDER=rows" "FG_SPECULATIVE_BINNING=0" "FG_OVERLAP_PACK=1" \
+           "FG_TIGHT_RECTS=0" "FG_RASTER_LIVE=0" "FG_RASTER_SEG_PARTS=1" "FG_RASTER_SEG_PARTS=5 FG_RASTER_SEG_TAIL=0" \
+           "FG_RASTER_LIVE=0 FG_RASTER_SEG_PARTS=1 FG_RASTER_TAIL_BWD=7,9 FG_RASTER_SPLIT_BWD=2,1" "FG_PREPROCESS_SKIP_CULLED=1"; do
   res=$(env $env timeout 900 python -m pytest tests -m gpu -q -x -k "not two_ranks and not lockstep" 2>&1 | tail -1)
   echo "$env | $res"
 done
