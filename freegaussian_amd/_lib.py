@@ -34,7 +34,7 @@ SIGNATURES = {
     "fg_bin_prepare_workspace_bytes": (c_size_t, [c_int]),
     "fg_bin_prepare": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
     "fg_bin_prepare_rects": (c_int, [c_int, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
-    "fg_bin_prepare_keys": (c_int, [c_int, P, P, P, P, P, P, c_size_t, P]),
+    "fg_bin_prepare_keys": (c_int, [c_int, P, P, P, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_workspace_bytes": (c_size_t, [c_int64]),
     "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_sort_capacity": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t,
@@ -47,7 +47,7 @@ SIGNATURES = {
     "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P]),
     "fg_raster_jobs_words": (c_int64, [c_int, c_int, c_int]),
     "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P]),
-    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P]),
+    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, P]),
     "fg_raster_seg_ckpt_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int64]),
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),

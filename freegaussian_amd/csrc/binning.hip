@@ -97,7 +97,7 @@ scan_blocksums_kernel(int nblocks, int64_t* __restrict__ block_sums) {
 template <bool RAW_TOTALS>
 __global__ void __launch_bounds__(SCAN_BLOCK)
 scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restrict__ order,
-                  const int64_t* __restrict__ block_sums, int64_t* __restrict__ out) {
+                  const int64_t* __restrict__ block_sums, int64_t* __restrict__ out, int64_t* count_out) {
   __shared__ int64_t wave_sums[SCAN_BLOCK / 64];
   int64_t before = 0;
   if (RAW_TOTALS) {
@@ -124,13 +124,19 @@ scan_apply_kernel(int N, const int32_t* __restrict__ in, const int32_t* __restri
   for (int k = 0; k < SCAN_ITEMS; ++k) {
     run += v[k];
     if (base + k < N) out[base + k] = run;
+    // the grand total also goes to the caller's (host-visible) word: no copy launch for the read-back
+    if (count_out && base + k == N - 1) {
+      __hip_atomic_store(count_out, run, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
   }
 }
 constexpr int FG_SCAN_FUSED_MAX = 2048;  // workgroups; beyond that the one-workgroup middle pass is cheaper
 // gathered (optional, N int32 of scratch): with an `order`, pass 1 leaves the gathered values there
 // and pass 2 reads them back coalesced instead of repeating the random gather
 void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_sums, int64_t* out, hipStream_t s,
-                 int32_t* gathered = nullptr, const int2* rect2 = nullptr, int32_t* rects_sorted = nullptr) {
+                 int32_t* gathered = nullptr, const int2* rect2 = nullptr, int32_t* rects_sorted = nullptr,
+                 int64_t* count_out = nullptr) {
   const int nblocks = (N + SCAN_TILE - 1) / SCAN_TILE;
   if (!order) gathered = nullptr;
   hipLaunchKernelGGL(scan_reduce_kernel, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, gathered,
@@ -140,10 +146,12 @@ void launch_scan(int N, const int32_t* in, const int32_t* order, int64_t* block_
     order = nullptr;
   }
   if (nblocks <= FG_SCAN_FUSED_MAX) {
-    hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out);
+    hipLaunchKernelGGL(scan_apply_kernel<true>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out,
+                       count_out);
   } else {
     hipLaunchKernelGGL(scan_blocksums_kernel, dim3(1), dim3(SCAN_BLOCK), 0, s, nblocks, block_sums);
-    hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out);
+    hipLaunchKernelGGL(scan_apply_kernel<false>, dim3(nblocks), dim3(SCAN_BLOCK), 0, s, N, in, order, block_sums, out,
+                       count_out);
   }
 }
 
@@ -446,7 +454,7 @@ extern "C" int fg_bin_prepare_rects(int N, const float* depths, const int32_t* r
 }
 
 extern "C" int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
-                                   int64_t* cum_tiles, int32_t* rects_sorted, void* workspace,
+                                   int64_t* cum_tiles, int32_t* rects_sorted, int64_t* count_out, void* workspace,
                                    size_t workspace_bytes, fg_stream_t stream) {
   if (N < 0) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
@@ -463,7 +471,7 @@ extern "C" int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* t
                                                sort_bytes, s, nullptr, /*iota_vals=*/true);
   if (rc != FG_OK) return rc;
   launch_scan(N, nullptr, (const int32_t*)order, block_sums, cum_tiles, s, reinterpret_cast<int32_t*>(sort_ws),
-              reinterpret_cast<const int2*>(tile_rects), rects_sorted);
+              reinterpret_cast<const int2*>(tile_rects), rects_sorted, count_out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -140,11 +140,15 @@ struct JobParams {
   // jobs (up to 16) as make its shares about half that threshold long; entry = tile << 8 | part << 4 |
   // (parts - 1), the part numbers rotated by the tile's position
   int seg_parts, seg_tail;
+  // graded tail: the last seg_tail2 (<= seg_tail) tiles get seg_parts2 (>= seg_parts) jobs -- the jobs
+  // that run while the launch drains are the shortest ones
+  int seg_parts2, seg_tail2;
 };
 __device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
                                          int thr2, int len) {
   if (p.seg_parts > 1) {
     int c = idx >= n - min(p.seg_tail, n) ? p.seg_parts : 1;
+    if (idx >= n - min(p.seg_tail2, n)) c = max(c, p.seg_parts2);
     if (len > thr2) {
       const int share = max(thr2 >> 1, 1);
       c = max(c, min(16, (len + share - 1) / share));
@@ -335,6 +339,28 @@ __device__ unsigned long long fg_raster_stats[16];
     if (fg::lane_id() == 0) atomicAdd(&fg_raster_stats[i], n_); } while (0)
 #else
 #define FG_STAT(i, n) do { } while (0)
+#endif
+#ifdef FG_RASTER_TIMELINE
+// Job timeline of the mixed launches (make timeline -> libfgraster_timeline.so): per job start / end on the 100 MHz wall clock, the
+// hardware slot it ran on and what it was -- scripts/raster_timeline.py turns it into occupancy over time.
+#define FG_TL_CAP (1 << 17)
+__device__ unsigned long long fg_timeline[FG_TL_CAP * 4];
+__device__ unsigned int fg_timeline_n;
+#define FG_TL_BEGIN() const unsigned long long tl_t0_ = wall_clock64()
+#define FG_TL_END(kernel, tile, strip, part, parts) do { if (threadIdx.x == 0) {                                 \
+    const unsigned slot_ = atomicAdd(&fg_timeline_n, 1u);                                                          \
+    if (slot_ < FG_TL_CAP) {                                                                                       \
+      fg_timeline[4 * slot_ + 0] = tl_t0_;                                                                         \
+      fg_timeline[4 * slot_ + 1] = wall_clock64();                                                                 \
+      fg_timeline[4 * slot_ + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63492) |                \
+                                   ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32);         \
+      fg_timeline[4 * slot_ + 3] = (unsigned long long)(kernel) | ((unsigned long long)((strip) + 1) << 4) |       \
+                                   ((unsigned long long)(part) << 8) | ((unsigned long long)(parts) << 12) |       \
+                                   ((unsigned long long)(tile) << 16) | ((unsigned long long)blockIdx.x << 40);    \
+    } } } while (0)
+#else
+#define FG_TL_BEGIN() do { } while (0)
+#define FG_TL_END(kernel, tile, strip, part, parts) do { } while (0)
 #endif
 
 // 1: the backward sums its per-splat accumulators through LDS; 0: register butterfly (A/B switch)
@@ -692,8 +718,16 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
-                        float4* __restrict__ ckpt, uint32_t* __restrict__ live_words) {
+                        float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
+                        float4* __restrict__ zero4, long long zero_n4) {
   __shared__ FwdShared<C, 64> sh;
+  // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
+  // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
+  if (zero4) {
+    const long long per = (zero_n4 + gridDim.x - 1) / gridDim.x;
+    const long long z0 = per * blockIdx.x, z1 = min(zero_n4, z0 + per);
+    for (long long z = z0 + threadIdx.x; z < z1; z += 64) zero4[z] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   // With a list the grid covers the positional job count plus a margin; fg_raster_build_jobs
   // makes the list fit it (build_jobs_kernel).  (A grid of the list's full capacity -- 4 jobs per
   // tile -- left tens of thousands of empty workgroups to dispatch: 2160p forward 0.52 -> 0.64 ms;
@@ -702,6 +736,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
                         : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
+  FG_TL_BEGIN();
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
                              last_ids, comp, ckpt, live_words);
@@ -711,6 +746,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
                              alphas, last_ids, comp, ckpt, live_words);
+  FG_TL_END(1, tile, strip, 0, 1);
 }
 
 template <int C, int NT>
@@ -1097,6 +1133,7 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
                 : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   }
   if (tile < 0) return;
+  FG_TL_BEGIN();
   if (strip < 0)
     raster_bwd_body<C, 4, 1, LIVE>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
                                    last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);
@@ -1106,6 +1143,7 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   else
     raster_bwd_body<C, 1, 1, LIVE>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
                                    last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);
+  FG_TL_END(2, tile, strip, part, seg.parts);
 }
 
 __global__ void __launch_bounds__(256)
@@ -1314,10 +1352,13 @@ int raster_split(const char* name, int dflt4, int dflt2) {
 
 // workgroups of a launch of list-share jobs: the positional count (+ half a job per tile for content
 // splits when a list is read: the builder fits the list into it)
+int seg_parts2();
+int seg_tail2();
 int seg_grid(int tile_w, int tile_h, int parts, int tail, bool listed) {
   const int n_max = band_tiles_max(tile_w, tile_h);
   const int split = tail > 0 ? (tail < n_max ? tail : n_max) : n_max;
-  const int per_xcd = n_max - split + split * parts + (listed ? n_max / 2 : 0);
+  int per_xcd = n_max - split + split * parts + (listed ? n_max / 2 : 0);
+  if (listed && seg_parts2() > parts) per_xcd += (seg_tail2() < split ? seg_tail2() : split) * (seg_parts2() - parts);
   const int cap = jobs_cap(tile_w, tile_h);
   return 8 * (listed && per_xcd > cap ? cap : per_xcd);
 }
@@ -1341,6 +1382,24 @@ int seg_tail_fit(int tile_w, int tile_h, int parts, int tail) {
   const int fit = parts > 1 ? room / (parts - 1) : n_max;
   return tail < fit ? tail : (fit > 1 ? fit : 1);
 }
+// FG_RASTER_SEG_GRADE = "parts2,tail2": the last tail2 tiles of every XCD's sequence get parts2 jobs
+#ifndef FG_SEG_PARTS2_DEFAULT
+#define FG_SEG_PARTS2_DEFAULT 0
+#endif
+#ifndef FG_SEG_TAIL2_DEFAULT
+#define FG_SEG_TAIL2_DEFAULT 0
+#endif
+int seg_parts2() {
+  const char* e = getenv("FG_RASTER_SEG_GRADE");
+  const int v = e ? atoi(e) : FG_SEG_PARTS2_DEFAULT;
+  return v < 0 ? 0 : (v > 16 ? 16 : v);
+}
+int seg_tail2() {
+  const char* e = getenv("FG_RASTER_SEG_GRADE");
+  const char* c = e ? strchr(e, ',') : nullptr;
+  const int v = e ? (c ? atoi(c + 1) : 0) : FG_SEG_TAIL2_DEFAULT;
+  return v < 0 ? 0 : v;
+}
 // FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
 int seg_parts() {
   const char* e = getenv("FG_RASTER_SEG_PARTS");
@@ -1352,13 +1411,18 @@ template <int C>
 int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                      int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr,
-                     uint32_t* live_words = nullptr) {
+                     uint32_t* live_words = nullptr, float* zero_buf = nullptr, long long zero_floats = 0) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
+  if (zero_buf && ((zero_floats & 3) || (reinterpret_cast<uintptr_t>(zero_buf) & 15))) {
+    if (hipMemsetAsync(zero_buf, 0, (size_t)zero_floats * 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    zero_buf = nullptr;
+  }
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
                      dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
-                     reinterpret_cast<float4*>(ckpt), live_words);
+                     reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
+                     zero_buf ? zero_floats / 4 : 0ll);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1432,8 +1496,9 @@ namespace {
 int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                    int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
-                   float* seg_ckpt = nullptr, uint32_t* live_words = nullptr) {
-  if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
+                   float* seg_ckpt = nullptr, uint32_t* live_words = nullptr, float* zero_buf = nullptr,
+                   long long zero_floats = 0) {
+  if (width <= 0 || height <= 0 || zero_floats < 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
   if (comp.n_clamp < 0 || comp.n_clamp > channels || (comp.n_clamp > 0 && !comp.clamp_mask)) return FG_ERR_INVALID_ARG;
@@ -1443,9 +1508,15 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   const int ppt = raster_ppt_fwd(n_tiles);
   int tail = mixed_tail_fwd(n_tiles);
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
+  if (zero_buf && zero_floats > 0 && tail == 0) {  // only the mixed launch zero-fills in passing
+    if (hipMemsetAsync(zero_buf, 0, (size_t)zero_floats * 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    zero_buf = nullptr;
+  }
+  if (zero_floats == 0) zero_buf = nullptr;
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
-                                         alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr, live_words)       \
+                                         alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr, live_words,       \
+                                         zero_buf, zero_floats)                                                     \
        : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
@@ -1550,14 +1621,14 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   const int tf = mixed_tail_fwd(n_tiles), tb = mixed_tail_bwd(n_tiles);
   const int sf = raster_split("FG_RASTER_SPLIT_FWD", FG_SPLIT4_FWD, FG_SPLIT2_FWD);
   const int sb = raster_split("FG_RASTER_SPLIT_BWD", FG_SPLIT4_BWD, FG_SPLIT2_BWD);
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8, 0, 0};
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8, 0, 0, 0, 0};
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const bool shares = bwd_list_shares && tb > 0 && seg_parts() > 1;
   const int st = seg_tail_fit(tile_w, tile_h, seg_parts(), seg_tail());
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), st, true) / 8,
-                                          seg_parts(), st}
-                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0};
+                                          seg_parts(), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
+                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
                      jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
   FG_RETURN_IF_LAUNCH_FAILED();
@@ -1568,9 +1639,10 @@ extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, float* image, float* alphas,
                                   int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                                  fg_stream_t stream) {
+                                  float* zero_buf, int64_t zero_floats, fg_stream_t stream) {
   return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
-                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt, live_words);
+                        last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt, live_words,
+                        zero_buf, (long long)zero_floats);
 }
 
 extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects) {
@@ -1601,5 +1673,22 @@ extern "C" int fg_debug_raster_stats(unsigned long long* out, int reset) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(fg_raster_stats), z, sizeof(z)) != hipSuccess) return FG_ERR_LAUNCH;
   }
   return FG_OK;
+}
+#endif
+
+#ifdef FG_RASTER_TIMELINE
+// Copies up to cap records (4 x u64 each) to the host and returns how many jobs were recorded.
+extern "C" int fg_debug_raster_timeline(unsigned long long* out, int cap, int reset) {
+  unsigned n = 0;
+  if (hipDeviceSynchronize() != hipSuccess) return -1;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(fg_timeline_n), 4) != hipSuccess) return -1;
+  const unsigned m = n < (unsigned)cap ? n : (unsigned)cap;
+  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_timeline), (size_t)(m < FG_TL_CAP ? m : FG_TL_CAP) * 32) != hipSuccess)
+    return -1;
+  if (reset) {
+    const unsigned z = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(fg_timeline_n), &z, 4) != hipSuccess) return -1;
+  }
+  return (int)n;
 }
 #endif

@@ -34,10 +34,13 @@ class StageTimer:
     timed region).  Events are recorded on the stream the kernels are launched on; nothing
     synchronises until ``summary()``."""
 
-    def __init__(self):
+    def __init__(self, only=None):
         self.events = {}
+        self.only = only  # None = every stage; else the set of stage names that get events
 
     def record(self, name):
+        if self.only is not None and name not in self.only:
+            return None
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         self.events.setdefault(name, []).append((a, b))
         return a, b
@@ -210,6 +213,7 @@ speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
 static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
 last_overflow: Optional[torch.Tensor] = None
 _isect_capacity: dict = {}
+_isect_recent: dict = {}  # key -> list lengths of the last calls
 capacity_redos = 0  # times a speculative list turned out too small and emission + sort were repeated
 
 
@@ -234,6 +238,12 @@ def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
 # gradients, ~30% fewer list entries on the 1M / 1080p scene.  The reference-exact lists
 # (info["flatten_ids"] etc.) are rebuilt on demand from the radius boxes.
 tight_rects = os.environ.get("FG_TIGHT_RECTS", "1") != "0"
+# FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
+# store into pinned host memory (A/B)
+direct_count = os.environ.get("FG_DIRECT_COUNT", "1") != "0"
+# FG_FILL_IN_FORWARD=0: zero the backward's record-gradient array with a fill launch at the head of the
+# backward instead of in passing in the mixed forward launch (A/B)
+fill_in_forward = os.environ.get("FG_FILL_IN_FORWARD", "1") != "0"
 
 
 def _binning_side_outputs(N, tile_size, width, height, dev):
@@ -276,9 +286,13 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     # rectangles in depth order for the emission kernel (no gathers by id there); the counts then
     # come from the rectangles, tiles_touched is only the `info` output
     rects = torch.empty(N, dtype=torch.int32, device=dev) if (tile_w <= 1023 and tile_h <= 1023) else None
+    count_host = None
     if keys_rects is not None and rects is not None:
+        # the list length is also stored straight into pinned host memory by the scan's last workgroup
+        # (no copy launch in the stream; not in static-shape mode, which never reads it on the host)
+        count_host = _count_buffer(dev) if static_capacity is None and direct_count else None
         _call("fg_bin_prepare_keys", N, _ptr(keys_rects[0]), _ptr(keys_rects[1]), _ptr(order), _ptr(cum), _ptr(rects),
-              _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
+              _ptr(count_host), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
     elif rects is not None:
         _call("fg_bin_prepare_rects", N, _ptr(depths), _ptr(radii), _ptr(means2d), tile_size, tile_w, tile_h,
               _ptr(order), _ptr(cum), _ptr(rects), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
@@ -304,8 +318,9 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         globals()["last_overflow"] = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h, keys_rects is not None)
-    count_host = _count_buffer(dev)
-    count_host.copy_(cum[N - 1 :], non_blocking=True)
+    if count_host is None:
+        count_host = _count_buffer(dev)
+        count_host.copy_(cum[N - 1 :], non_blocking=True)
     ready = torch.cuda.Event()
     ready.record()
     capacity = _isect_capacity.get(key) if speculative_binning else None
@@ -323,12 +338,19 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         if n_isects >= 2**31:
             raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
         if key not in _isect_capacity and len(_isect_capacity) >= 256:
-            _isect_capacity.pop(next(iter(_isect_capacity)))  # densification changes N: do not grow for ever
-        # 25% headroom over this view; decays slowly (3% per call) from the largest view seen, so a
-        # camera that moves between light and heavy views does not overflow on every return
-        want = int(n_isects * 1.25) + 4096
-        if capacity is not None:
-            want = max(want, int(capacity * 0.97))
+            old = next(iter(_isect_capacity))  # densification changes N: do not grow for ever
+            _isect_capacity.pop(old)
+            _isect_recent.pop(old, None)
+        # 25% headroom over the heaviest of the last 16 views of this shape, rounded up to 1/32..1/16 of
+        # its magnitude: a camera moving between light and heavy views neither overflows on every
+        # return nor asks the allocator for a new block size every step (every list-sized buffer of
+        # the step -- ids, sort workspace, liveness words, checkpoints -- is sized from this number)
+        recent = _isect_recent.setdefault(key, [])
+        recent.append(n_isects)
+        del recent[:-16]
+        want = int(max(recent) * 1.25) + 4096
+        granule = 1 << max(want.bit_length() - 5, 12)
+        want = -(-want // granule) * granule
         _isect_capacity[key] = min(want, 2**31 - 1)
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
@@ -704,7 +726,7 @@ class _RasterSplats(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad,
-                background=None, n_clamp=0):  # fmt: skip
+                background=None, n_clamp=0, expect_backward=False):  # fmt: skip
         dev = splats.device
         _wait_ready(splats)
         render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
@@ -714,7 +736,7 @@ class _RasterSplats(torch.autograd.Function):
         clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
         # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches
         words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size)))
-        jobs = seg_ckpt = live = None
+        jobs = seg_ckpt = live = v_splats = None
         if words > 0:
             jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
@@ -724,11 +746,16 @@ class _RasterSplats(torch.autograd.Function):
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
             live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)
+            # the backward's record-gradient array (atomics accumulate into it): zero-filled in passing by
+            # the forward launch instead of a fill launch at the head of the backward
+            if fill_in_forward and expect_backward:
+                v_splats = torch.empty(splats.shape[0], SPLAT_FLOATS, dtype=torch.float32, device=dev)
             _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
                   int(seg_ckpt is not None), _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
-                  _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _stream(),
+                  _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _ptr(v_splats),
+                  0 if v_splats is None else v_splats.numel(), _stream(),
                   stage="fg_raster_composite_fwd" if composite else "fg_raster_fwd")  # fmt: skip
         elif composite:  # O1 folded into the kernel epilogue: render is the finished image
             _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
@@ -740,6 +767,7 @@ class _RasterSplats(torch.autograd.Function):
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
                               render if seg_ckpt is not None else None, live)  # fmt: skip
         ctx.jobs_bwd = jobs[1] if jobs is not None else None
+        ctx.v_splats_zeroed = v_splats  # consumed by the first backward; a second one fills its own
         ctx.set_materialize_grads(False)  # an unused alpha / render must not cost a zero-fill launch
         ctx.composite = (composite, int(n_clamp))
         ctx.geom = (channels, width, height, tile_size, absgrad, tuple(means2d.shape))
@@ -756,7 +784,9 @@ class _RasterSplats(torch.autograd.Function):
         N = splats.shape[0]
         v_render = torch.zeros(height, width, C, device=splats.device) if v_render is None else v_render
         v_alphas = None if v_alphas is None else v_alphas.contiguous()  # NULL = no gradient on alpha
-        v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
+        v_splats, ctx.v_splats_zeroed = ctx.v_splats_zeroed, None
+        if v_splats is None:
+            v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=splats.device)
         if ctx.jobs_bwd is not None:
             _call("fg_raster_jobs_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(ctx.jobs_bwd), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas),
@@ -777,7 +807,7 @@ class _RasterSplats(torch.autograd.Function):
         if absgrad and ctx.means2d_ref is not None:
             ctx.means2d_ref.absgrad = v_splats[:, 6:8].view(m2_shape)
             ctx.means2d_ref = None
-        return v_splats, v_means2d, None, None, None, None, None, None, None, None, None
+        return v_splats, v_means2d, None, None, None, None, None, None, None, None, None, None
 
 
 def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad=False,
@@ -795,8 +825,10 @@ def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_o
         raise ValueError("tile_size must be 16")
     if not 1 <= channels <= MAX_CHANNELS:
         raise ValueError(f"1..{MAX_CHANNELS} composited channels supported, got {channels}")
+    # (grad mode is off inside Function.forward: whether a backward can follow is decided here)
+    expect_backward = torch.is_grad_enabled() and (splats.requires_grad or means2d.requires_grad)
     return _RasterSplats.apply(splats, means2d, int(channels), int(width), int(height), int(tile_size), tile_offsets,
-                               flatten_ids, bool(absgrad), background, int(n_clamp))  # fmt: skip
+                               flatten_ids, bool(absgrad), background, int(n_clamp), expect_backward)  # fmt: skip
 
 
 # --------------------------------------------------------------------------------------------

@@ -133,9 +133,12 @@ int fg_bin_prepare_rects(int N, const float* depths, const int32_t* radii, const
  * IN PLACE here -- a scratch array from the caller's point of view) and tile_rects[N,2] (read
  * only).  No key / rectangle kernel runs and the first radix pass numbers the values itself.  With
  * the preprocess pass's FOOTPRINT rectangles the lists hold only (splat, tile) pairs in which the
- * splat can reach alpha >= 1/255 -- the reference's lists minus dead entries, same order. */
+ * splat can reach alpha >= 1/255 -- the reference's lists minus dead entries, same order.
+ * count_out (nullable): one more copy of the list length cum_tiles[N-1], stored with system scope --
+ * pass the device-visible address of pinned host memory and the host has the count after an event
+ * wait, with no copy launch in the stream (the reference reads it with a blocking .item()). */
 int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
-                        int64_t* cum_tiles, int32_t* rects_sorted, void* workspace,
+                        int64_t* cum_tiles, int32_t* rects_sorted, int64_t* count_out, void* workspace,
                         size_t workspace_bytes, fg_stream_t stream);
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
@@ -218,7 +221,10 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * LIVENESS (any channel count): live_words[n_isects] uint32, uninitialised, to BOTH calls: the
  * forward notes per (list entry, 4-row strip) whether any pixel took the entry (byte s of word i =
  * strip s of entry i), and the backward evaluates exactly those pairs instead of re-testing every
- * strip of every entry -- same gradients, about a third fewer vector issue cycles.  NULL = off. */
+ * strip of every entry -- same gradients, about a third fewer vector issue cycles.  NULL = off.
+ * ZERO FILL IN PASSING: zero_buf[zero_floats] (nullable) is zero-filled by the forward call -- meant
+ * for the v_splats array of the coming fg_raster_jobs_bwd, which accumulates with atomics: the forward
+ * launch leaves the memory pipe mostly idle, a separate fill costs ~10 us and a launch boundary. */
 int64_t fg_raster_jobs_words(int width, int height, int tile_size);
 int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
                          int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, fg_stream_t stream);
@@ -226,7 +232,7 @@ int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,
                        int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                       fg_stream_t stream);
+                       float* zero_buf, int64_t zero_floats, fg_stream_t stream);
 int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects);
 int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,

@@ -80,8 +80,8 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     # raw preprocess is SH-only
     assert lib.fg_preprocess_raw_fwd(4, *(n * 8), -1, 16, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
                                      *(n * 10)) == -1  # fmt: skip
-    assert lib.fg_bin_prepare_keys(4, *(n * 6), 0, None) == -1  # keys / rectangles / outputs missing
-    assert lib.fg_bin_prepare_keys(0, *(n * 6), 0, None) == 0
+    assert lib.fg_bin_prepare_keys(4, *(n * 7), 0, None) == -1  # keys / rectangles / outputs missing
+    assert lib.fg_bin_prepare_keys(0, *(n * 7), 0, None) == 0
     # composite raster: clamp count within the channels, mask required
     assert lib.fg_raster_composite_fwd(3, 32, 32, 16, *(n * 4), 4, *(n * 5)) == -1
 
