@@ -132,6 +132,9 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
 // column-major order.  (Giving every tile four workgroups and letting the unused ones return was
 // tried first: the empty workgroups in front of live ones cost the forward 0.218 -> 0.275 ms, and
 // with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
+// forward lists: bit 30 of an entry = "the backward will not cut this tile's list into shares": the
+// forward then writes no compositing checkpoints for it
+constexpr int FG_JOB_NO_CKPT = 1 << 30;
 struct JobParams {
   int tail4, tail2, s4, s2;
   int max_jobs;  // workgroups per XCD of the launch that will read the list
@@ -179,6 +182,7 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
   // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
   int thr4 = p.s4 ? (int)(((int64_t)total * p.s4) >> 16) : 0x7fffffff;
   int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
+  const int thr2_b = pb.s2 ? (int)(((int64_t)total * pb.s2) >> 16) : 0x7fffffff;  // the backward's, as given
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
   // it does; the positional jobs alone always fit
@@ -208,12 +212,15 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
   int32_t* seg = jobs + 8 + (size_t)xcd * cap;
   for (int base = 0; base < n; base += NTH) {
     const int idx = base + (int)threadIdx.x;
-    int cnt = 0, tile = 0;
+    int cnt = 0, tile = 0, flag = 0;
     if (idx < n) {
       const int col = idx / rows;
       tile = (row0 + idx - col * rows) * tile_w + col;
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
+      // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
+      // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
+      if (!bwd && pb.seg_parts > 1 && job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1) flag = FG_JOB_NO_CKPT;
     }
     int incl = cnt;
 #pragma unroll
@@ -229,11 +236,11 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
       if (w < wave) pos += wave_tot[w];
     if (p.seg_parts > 1) {
       for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 8 | ((j + idx) % cnt) << 4 | (cnt - 1);
-    } else if (cnt == 1) seg[pos] = tile << 3;  // strip -1
-    else if (cnt == 2) { seg[pos] = tile << 3 | 5; seg[pos + 1] = tile << 3 | 6; }  // strip 4, 5
+    } else if (cnt == 1) seg[pos] = tile << 3 | flag;  // strip -1
+    else if (cnt == 2) { seg[pos] = tile << 3 | 5 | flag; seg[pos + 1] = tile << 3 | 6 | flag; }  // strip 4, 5
     else if (cnt == 4) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1);  // strip 0..3
+      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1) | flag;  // strip 0..3
     }
     __syncthreads();
     if (threadIdx.x == NTH - 1) carry = pos + cnt;
@@ -243,12 +250,14 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
 }
 
 // job k of XCD (b & 7) from a list; tile or -1
-__device__ __forceinline__ int job_from_list(int b, const int32_t* __restrict__ jobs, int cap, int& strip) {
+__device__ __forceinline__ int job_from_list(int b, const int32_t* __restrict__ jobs, int cap, int& strip,
+                                             bool* no_ckpt = nullptr) {
   const int xcd = b & 7, k = b >> 3;
   if (k >= jobs[xcd]) return -1;
   const int e = jobs[8 + (size_t)xcd * cap + k];
   strip = (e & 7) - 1;
-  return e >> 3;
+  if (no_ckpt) *no_ckpt = (e & FG_JOB_NO_CKPT) != 0;
+  return (e & ~FG_JOB_NO_CKPT) >> 3;
 }
 
 // the same from a list of list-share jobs (JobParams::seg_parts): tile, part, parts
@@ -314,12 +323,14 @@ struct Composite {
 // repeating any per-entry work (splitting a tile by pixels repeats the record read, the reduction
 // and the atomic of every entry in every part).
 #ifndef FG_SEG_ENTRIES
-#define FG_SEG_ENTRIES 128
+#define FG_SEG_ENTRIES 64
 #endif
 // measured on MI355X (1M Gaussians, 1080p, profiles/r02_backward_list_shares.md): the last 400 tiles of
-// every XCD's sequence as 3 shares each: 0.398 -> 0.374 ms against two-strip jobs for the last 300
+// every XCD's sequence as 3 shares each over 128-entry segments: 0.398 -> 0.374 ms against two-strip jobs
+// for the last 300; 4 shares over 64-entry segments: 0.370 -> 0.349 (the forward writes checkpoints only
+// for the tiles the backward splits -- FG_JOB_NO_CKPT -- so the finer grain costs it nothing)
 #ifndef FG_SEG_PARTS_DEFAULT
-#define FG_SEG_PARTS_DEFAULT 3
+#define FG_SEG_PARTS_DEFAULT 4
 #endif
 #ifndef FG_SEG_TAIL_DEFAULT
 #define FG_SEG_TAIL_DEFAULT 400
@@ -346,20 +357,28 @@ __device__ unsigned long long fg_raster_stats[16];
 #define FG_TL_CAP (1 << 17)
 __device__ unsigned long long fg_timeline[FG_TL_CAP * 4];
 __device__ unsigned int fg_timeline_n;
-#define FG_TL_BEGIN() const unsigned long long tl_t0_ = wall_clock64()
+__shared__ unsigned long long fg_tl_acc[2];  // [0] ticks spent staging batches, [1] clock at the first batch
+#define FG_TL_BEGIN() const unsigned long long tl_t0_ = wall_clock64(); if (threadIdx.x == 0) fg_tl_acc[0] = fg_tl_acc[1] = 0
+#define FG_TL_STAGE_BEGIN() const unsigned long long tl_s0_ = wall_clock64(); \
+  if (threadIdx.x == 0 && fg_tl_acc[1] == 0) fg_tl_acc[1] = tl_s0_
+#define FG_TL_STAGE_END() do { if (threadIdx.x == 0) fg_tl_acc[0] += wall_clock64() - tl_s0_; } while (0)
 #define FG_TL_END(kernel, tile, strip, part, parts) do { if (threadIdx.x == 0) {                                 \
     const unsigned slot_ = atomicAdd(&fg_timeline_n, 1u);                                                          \
     if (slot_ < FG_TL_CAP) {                                                                                       \
       fg_timeline[4 * slot_ + 0] = tl_t0_;                                                                         \
       fg_timeline[4 * slot_ + 1] = wall_clock64();                                                                 \
       fg_timeline[4 * slot_ + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63492) |                \
-                                   ((unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63508) << 32);         \
+                                   ((unsigned long long)((unsigned)__builtin_amdgcn_s_getreg(63508) & 15u) << 32) | \
+                                   (fg_tl_acc[0] << 36);                                                           \
       fg_timeline[4 * slot_ + 3] = (unsigned long long)(kernel) | ((unsigned long long)((strip) + 1) << 4) |       \
                                    ((unsigned long long)(part) << 8) | ((unsigned long long)(parts) << 12) |       \
-                                   ((unsigned long long)(tile) << 16) | ((unsigned long long)blockIdx.x << 40);    \
+                                   ((unsigned long long)(tile) << 16) |                                            \
+                                   ((fg_tl_acc[1] ? fg_tl_acc[1] - tl_t0_ : 0ull) << 40);                          \
     } } } while (0)
 #else
 #define FG_TL_BEGIN() do { } while (0)
+#define FG_TL_STAGE_BEGIN() do { } while (0)
+#define FG_TL_STAGE_END() do { } while (0)
 #define FG_TL_END(kernel, tile, strip, part, parts) do { } while (0)
 #endif
 
@@ -554,6 +573,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
       }
     }
+    FG_TL_STAGE_BEGIN();
     const int idx = batch + (int)threadIdx.x;
     unsigned mask = 0;
     if (idx < end) {
@@ -571,6 +591,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     }
     lds_mask[threadIdx.x] = mask;
     __syncthreads();
+    FG_TL_STAGE_END();
     // Each wavefront compacts the entries that can reach its own strips into a private index list
     // (list order preserved: ballot + popcount prefix), then walks it with a plain counted loop.
     // The scalar unit is shared by the CU's four SIMDs and was the busiest pipe of this kernel
@@ -733,9 +754,11 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   // tile -- left tens of thousands of empty workgroups to dispatch: 2160p forward 0.52 -> 0.64 ms;
   // workgroups walking on through a longer list cost 12-19 registers in both kernels.)
   int strip;
-  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
+  bool no_ckpt = false;
+  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip, &no_ckpt)
                         : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
   if (tile < 0) return;
+  if (no_ckpt) ckpt = nullptr;
   FG_TL_BEGIN();
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
@@ -878,6 +901,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   for (int b = n_batches - 1; b >= 0; --b) {
     const int batch = lo + b * NT;
     __syncthreads();
+    FG_TL_STAGE_BEGIN();
     const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
     const int idx = batch + tl;
     unsigned mask = 0;
@@ -911,6 +935,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     }
     lds_mask[tl] = mask;
     __syncthreads();
+    FG_TL_STAGE_END();
     // back to front over the entries that can reach this wavefront's strips
     for (int i = NT / 64 - 1; i >= 0; --i) {
       uint64_t todo = __ballot((lds_mask[64 * i + lane] & my_strips) != 0u);

@@ -214,7 +214,8 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * LIST SEGMENTS of the backward (3 channels): floats = fg_raster_seg_ckpt_floats(...) (0 = off for
  * this size / environment); seg_ckpt[floats], uninitialised, goes to BOTH calls and `image` (the
  * forward's output) to the backward: the forward leaves every pixel's compositing state at every
- * 128th entry of a tile's list, and the backward runs several jobs per tile, each over its share of
+ * 64th entry of a tile's list (only for the tiles the backward's job list splits: hand both calls the
+ * lists of ONE fg_raster_build_jobs call), and the backward runs several jobs per tile, each over its share of
  * the list, instead of one serial walk.  Same gradients up to float summation order.  NULL = off.
  * fg_raster_build_jobs(bwd_list_shares = 1) must then have built the backward's list (its entries
  * are (tile, part, parts) instead of (tile, strip)).

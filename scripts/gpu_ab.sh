@@ -8,7 +8,7 @@ tail -3 $out/pytest.log
 i=0
 for cfg in "$@"; do
   i=$((i+1))
-  env $cfg timeout 200 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-graph > $out/ab_$i.json 2>/dev/null
+  env $cfg timeout 200 python bench.py --steps 60 --warmup 16 --no-cpu-baseline --no-graph > $out/ab_$i.json 2>/dev/null
   python3 - <<PY
 import json
 try:

@@ -44,10 +44,13 @@ step(4)
 cnt = lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
 rec = buf[:min(cnt, CAP)]
 t0, t1, hw, what = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64), rec[:, 2], rec[:, 3]
+what_lo = what & ((1 << 40) - 1)
 kernel = (what & 0xF).astype(int)
 strip = ((what >> 4) & 0xF).astype(int) - 1
 parts = ((what >> 12) & 0xF).astype(int)
 hwid = (hw & 0xFFFFFFFF).astype(np.int64)
+stage_us = (hw >> 36).astype(np.float64) / 100.0  # time spent staging batches (gather -> LDS)
+prologue_us = (what >> 40).astype(np.float64) / 100.0  # job start -> first batch
 xcc = ((hw >> 32) & 0xF).astype(np.int64)
 simd = (hwid >> 4) & 3
 cu = (hwid >> 8) & 0xF
@@ -72,7 +75,10 @@ for kid, name in ((1, "raster_fwd_mixed"), (2, "raster_bwd_mixed")):
         d = dur[kind == kk]
         kinds[str(kk)] = {"jobs": int(d.size), "mean_us": float(d.mean()), "p50_us": float(np.median(d)),
                           "p95_us": float(np.percentile(d, 95)), "max_us": float(d.max()),
-                          "sum_ms": float(d.sum() / 1e3)}
+                          "sum_ms": float(d.sum() / 1e3),
+                          "staging_share": float(stage_us[m][kind == kk].sum() / d.sum()),
+                          "prologue_share": float(prologue_us[m][kind == kk].sum() / d.sum()),
+                          "prologue_mean_us": float(prologue_us[m][kind == kk].mean())}
     usimd = np.unique(sk)
     nsl = 20
     edges = np.linspace(lo, hi, nsl + 1)
