@@ -9,6 +9,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import os
+import time
 
 import torch
 
@@ -223,6 +224,48 @@ def _count_buffer(dev) -> torch.Tensor:
     return torch.empty(1, dtype=torch.int64, pin_memory=True)
 
 
+# Words the scan kernel stores the list length into (fg_bin_prepare_keys count_out): a ring of pinned
+# int64 slots that lives as long as the process, so that a store of a call whose Python side died in
+# between can only ever land in a slot of this ring.  The host writes -1 before the launch and polls.
+_COUNT_RING = 256
+_count_ring = None
+_count_ring_np = None
+_count_ring_next = 0
+
+
+def _count_slot():
+    global _count_ring, _count_ring_np, _count_ring_next
+    if _count_ring is None:
+        _count_ring = torch.empty(_COUNT_RING, dtype=torch.int64, pin_memory=True)
+        _count_ring_np = _count_ring.numpy()
+    i = _count_ring_next
+    _count_ring_next = (i + 1) % _COUNT_RING
+    _count_ring_np[i] = -1
+    return i, _count_ring.data_ptr() + 8 * i
+
+
+def _poll_count(i: int) -> int:
+    """Spin on ring slot i until the kernel's system-scope store arrives (it does while the GPU is
+    still busy with the emission and the tile sort: the wait is microseconds).  No event in the stream."""
+    a = _count_ring_np
+    v = int(a[i])
+    if v >= 0:
+        return v
+    t0 = time.perf_counter()
+    while True:
+        for _ in range(64):
+            v = int(a[i])
+            if v >= 0:
+                return v
+        if time.perf_counter() - t0 > 0.02:
+            break
+    torch.cuda.current_stream().synchronize()  # not seen within 20 ms: drain the queue and look again
+    v = int(a[i])
+    if v < 0:
+        raise _lib.FgRasterError("the list length never arrived in pinned host memory (fg_bin_prepare_keys count_out)")
+    return v
+
+
 @torch.no_grad()
 def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
     """The sorted list's tile ids [n] int32, rebuilt from the tile ranges (the product path does
@@ -286,13 +329,13 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     # rectangles in depth order for the emission kernel (no gathers by id there); the counts then
     # come from the rectangles, tiles_touched is only the `info` output
     rects = torch.empty(N, dtype=torch.int32, device=dev) if (tile_w <= 1023 and tile_h <= 1023) else None
-    count_host = None
+    count_slot = None
     if keys_rects is not None and rects is not None:
         # the list length is also stored straight into pinned host memory by the scan's last workgroup
         # (no copy launch in the stream; not in static-shape mode, which never reads it on the host)
-        count_host = _count_buffer(dev) if static_capacity is None and direct_count else None
+        count_slot, count_ptr = _count_slot() if static_capacity is None and direct_count else (None, None)
         _call("fg_bin_prepare_keys", N, _ptr(keys_rects[0]), _ptr(keys_rects[1]), _ptr(order), _ptr(cum), _ptr(rects),
-              _ptr(count_host), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
+              count_ptr, _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
     elif rects is not None:
         _call("fg_bin_prepare_rects", N, _ptr(depths), _ptr(radii), _ptr(means2d), tile_size, tile_w, tile_h,
               _ptr(order), _ptr(cum), _ptr(rects), _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
@@ -318,11 +361,12 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         globals()["last_overflow"] = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h, keys_rects is not None)
-    if count_host is None:
+    count_host = ready = None
+    if count_slot is None:
         count_host = _count_buffer(dev)
         count_host.copy_(cum[N - 1 :], non_blocking=True)
-    ready = torch.cuda.Event()
-    ready.record()
+        ready = torch.cuda.Event()
+        ready.record()
     capacity = _isect_capacity.get(key) if speculative_binning else None
     tile_keys = flatten_ids = None
     if capacity is not None:
@@ -333,8 +377,11 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
               _ptr(rects), tile_size, tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2),
               ws2.numel(), _stream())  # fmt: skip
     def finish():
-        ready.synchronize()
-        n_isects = int(count_host[0])
+        if count_slot is not None:
+            n_isects = _poll_count(count_slot)
+        else:
+            ready.synchronize()
+            n_isects = int(count_host[0])
         if n_isects >= 2**31:
             raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
         if key not in _isect_capacity and len(_isect_capacity) >= 256:
