@@ -89,6 +89,27 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
   return first + k;
 }
 
+// The eight XCDs' shares of the tile grid in the mixed launches: an nx x (8 / nx) arrangement of
+// rectangles, one per XCD, each walked column-major (a tile and its vertical neighbours, which share
+// most of their splats, run back to back in one L2).  nx = 1 (whole-row bands) is what runs; the other
+// arrangements are an A/B knob (band_nx).
+struct Band {
+  int c0, ncols, r0, nrows;
+};
+__host__ __device__ __forceinline__ Band band_of_xcd(int xcd, int tile_w, int tile_h, int nx) {
+  const int ny = 8 / nx, rx = xcd % nx, ry = xcd / nx;
+  Band b;
+  b.c0 = (rx * tile_w) / nx;
+  b.ncols = ((rx + 1) * tile_w) / nx - b.c0;
+  b.r0 = (ry * tile_h) / ny;
+  b.nrows = ((ry + 1) * tile_h) / ny - b.r0;
+  return b;
+}
+__device__ __forceinline__ int band_tile(const Band& b, int idx, int tile_w) {
+  const int col = idx / b.nrows;
+  return (b.r0 + idx - col * b.nrows) * tile_w + b.c0 + col;
+}
+
 // Mixed launch: job k of XCD x.  The XCD's tiles are those of tile_of_block mode 2 (a band of whole
 // tile rows, column-major); the first n - tail of them are whole-tile jobs (strip = -1), each of
 // the last `tail` is four single-strip jobs.  Why: a tile's list is walked serially by its
@@ -96,15 +117,13 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
 // (FG_DEBUG_K_MOD hook), 1/5 of the tiles of the 1M / 1080p scene take half the time of all of
 // them.  Shorter jobs at the end of every XCD's sequence shorten that tail; splitting every tile
 // would repeat the per-entry work everywhere (slower: profiles/r01_ppt_by_tiles.md).
-__device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int tail_tiles, int& strip) {
+__device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int nx, int tail_tiles, int& strip) {
   // tail_tiles = tail4 | tail2 << 16: the last tail4 tiles of the sequence are four single-strip
   // jobs (strip = 0..3), the tail2 tiles before them two two-strip jobs (strip = 4 + half)
   const int tail4_req = tail_tiles & 0xFFFF, tail2_req = tail_tiles >> 16;
   const int xcd = b & 7, k = b >> 3;
-  const int q = tile_h >> 3, r = tile_h & 7;
-  const int rows = q + (xcd < r ? 1 : 0);
-  const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int n = rows * tile_w;
+  const Band band = band_of_xcd(xcd, tile_w, tile_h, nx);
+  const int n = band.nrows * band.ncols;
   const int tail4 = min(tail4_req, n), tail2 = min(tail2_req, n - tail4), n_main = n - tail4 - tail2;
   int idx;
   if (k < n_main) {
@@ -119,8 +138,7 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int t
     strip = t & 3;
   }
   if (idx >= n) return -1;
-  const int col = idx / rows;
-  return (row0 + idx - col * rows) * tile_w + col;
+  return band_tile(band, idx, tile_w);
 }
 
 // Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
@@ -163,7 +181,7 @@ __device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int
   return 1 << level;
 }
 __global__ void __launch_bounds__(1024)
-build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
+build_jobs_kernel(int tile_w, int tile_h, int nx, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
                   JobParams pb, int32_t* __restrict__ jobs_fwd, int32_t* __restrict__ jobs_bwd) {
   constexpr int NTH = 1024, NWV = NTH / 64;
   __shared__ int wave_tot[NWV];
@@ -173,10 +191,8 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
   int32_t* jobs = bwd ? jobs_bwd : jobs_fwd;
   if (!jobs) return;
   const JobParams p = bwd ? pb : pf;
-  const int q = tile_h >> 3, r = tile_h & 7;
-  const int rows = q + (xcd < r ? 1 : 0);
-  const int row0 = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-  const int n = rows * tile_w;
+  const Band band = band_of_xcd(xcd, tile_w, tile_h, nx);
+  const int n = band.nrows * band.ncols;
   const int total = tile_offsets[tile_w * tile_h];
   const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
   // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
@@ -189,8 +205,7 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
   for (int round = 0; round < 12; ++round) {
     int mine = 0;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
-      const int col = idx / rows;
-      const int tile = (row0 + idx - col * rows) * tile_w + col;
+      const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
     }
@@ -214,8 +229,7 @@ build_jobs_kernel(int tile_w, int tile_h, int cap, const int32_t* __restrict__ t
     const int idx = base + (int)threadIdx.x;
     int cnt = 0, tile = 0, flag = 0;
     if (idx < n) {
-      const int col = idx / rows;
-      tile = (row0 + idx - col * rows) * tile_w + col;
+      tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
       // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
@@ -734,7 +748,7 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 // split into four single-strip jobs (1 pixel per lane) -- see launch_fwd_mixed.
 template <int C>
 __global__ void __launch_bounds__(64)
-raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, int tail_tiles,
                         const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
@@ -756,7 +770,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
   int strip;
   bool no_ckpt = false;
   const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip, &no_ckpt)
-                        : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+                        : job_of_block(blockIdx.x, tile_w, tile_h, nx, tail_tiles, strip);
   if (tile < 0) return;
   if (no_ckpt) ckpt = nullptr;
   FG_TL_BEGIN();
@@ -1120,7 +1134,7 @@ raster_bwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 
 template <int C, bool LIVE>
 __global__ void __launch_bounds__(64)
-raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_tiles,
+raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, int tail_tiles,
                         const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, const float* __restrict__ alphas,
@@ -1141,8 +1155,8 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
       // with fewer segments than parts leave the same part numbers empty, and unrotated those all
       // landed on the same SIMDs (4 parts: 0.77 ms against 0.43 for 3)
       const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-      const int q = tile_h >> 3, r = tile_h & 7;
-      const int n = (q + (xcd < r ? 1 : 0)) * tile_w;
+      const Band band = band_of_xcd(xcd, tile_w, tile_h, nx);
+      const int n = band.nrows * band.ncols;
       const int tail = seg.tail > 0 ? min(seg.tail, n) : n, n_main = n - tail;
       int t = k;
       if (k >= n_main) {
@@ -1151,11 +1165,11 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int tail_
       } else {
         seg.parts = 1;  // (a by-value copy: this workgroup walks its tile's whole list)
       }
-      tile = job_of_block((t << 3) | xcd, tile_w, tile_h, 0, strip);
+      tile = job_of_block((t << 3) | xcd, tile_w, tile_h, nx, 0, strip);
     }
   } else {
     tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip)
-                : job_of_block(blockIdx.x, tile_w, tile_h, tail_tiles, strip);
+                : job_of_block(blockIdx.x, tile_w, tile_h, nx, tail_tiles, strip);
   }
   if (tile < 0) return;
   FG_TL_BEGIN();
@@ -1343,7 +1357,29 @@ int mixed_tail_bwd(int n_tiles) {
   if (getenv("FG_RASTER_PPT_BWD")) return 0;
   return raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
 }
-int band_tiles_max(int tile_w, int tile_h) { return ((tile_h >> 3) + ((tile_h & 7) ? 1 : 0)) * tile_w; }
+// tiles of the largest XCD rectangle for an nx x (8 / nx) arrangement
+int band_tiles_for(int tile_w, int tile_h, int nx) {
+  int m = 0;
+  for (int x = 0; x < 8; ++x) {
+    const Band b = band_of_xcd(x, tile_w, tile_h, nx);
+    m = b.ncols * b.nrows > m ? b.ncols * b.nrows : m;
+  }
+  return m;
+}
+// Whole-row bands (nx = 1) unless FG_RASTER_BANDS=2|4|8 asks for another arrangement.  Measured at
+// 1080p (profiles/r02_job_timeline.md): 8 x 1 column strips give every XCD exactly 1020 tiles instead of
+// 1080 / 960, and all eight then finish when the 1080-tile XCDs did before (an XCD's time is set by its
+// long jobs and the drain after them, not by its tile count); the forward is 5% slower (0.218 against
+// 0.208 ms), 4 x 2 rectangles 13%.
+int band_nx(int tile_w, int tile_h) {
+  const char* e = getenv("FG_RASTER_BANDS");
+  if (e) {
+    const int v = atoi(e);
+    if (v == 1 || v == 2 || v == 4 || v == 8) return v;
+  }
+  return 1;
+}
+int band_tiles_max(int tile_w, int tile_h) { return band_tiles_for(tile_w, tile_h, band_nx(tile_w, tile_h)); }
 int mixed_grid(int tile_w, int tile_h, int tail) {  // positional jobs only
   const int n_max = band_tiles_max(tile_w, tile_h);
   int t4 = tail & 0xFFFF, t2 = tail >> 16;
@@ -1444,7 +1480,7 @@ int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const
     zero_buf = nullptr;
   }
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
-                     dim3(64), 0, s, width, height, tile_w, tile_h, tail, jobs, cap,
+                     dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
                      zero_buf ? zero_floats / 4 : 0ll);
@@ -1462,11 +1498,11 @@ int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const
   int grid = jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail);
   if (seg.parts > 1) grid = seg_grid(tile_w, tile_h, seg.parts, seg.tail, jobs != nullptr);
   if (live_words)
-    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail,
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail,
                        jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
                        v_render, v_alphas, v_splats, comp, seg, live_words);
   else
-    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, false>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, tail,
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, false>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail,
                        jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
                        v_render, v_alphas, v_splats, comp, seg, live_words);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
@@ -1655,6 +1691,7 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
                                           seg_parts(), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
+                     band_nx(tile_w, tile_h),
                      jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
