@@ -349,6 +349,11 @@ struct Composite {
 #ifndef FG_SEG_TAIL_DEFAULT
 #define FG_SEG_TAIL_DEFAULT 400
 #endif
+// The checkpoint buffer starts with a table int32[n_tiles][4]: per tile and 4-row strip, the last list
+// index any pixel of the strip used (written by the forward's jobs, one strip each or all four; read by
+// the backward's share jobs, which then know their share of the list before any pixel state arrives);
+// the checkpoint slots follow, aligned to a slot (256 float4).
+__host__ __device__ __forceinline__ size_t seg_slots_offset4(int n_tiles) { return ((size_t)n_tiles + 255) / 256 * 256; }
 struct Segments {
   float4* ckpt;             // [slots][256 pixels of the tile, row-major]; nullptr = no segmentation
   const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
@@ -369,29 +374,35 @@ __device__ unsigned long long fg_raster_stats[16];
 // Job timeline of the mixed launches (make timeline -> libfgraster_timeline.so): per job start / end on the 100 MHz wall clock, the
 // hardware slot it ran on and what it was -- scripts/raster_timeline.py turns it into occupancy over time.
 #define FG_TL_CAP (1 << 17)
-__device__ unsigned long long fg_timeline[FG_TL_CAP * 4];
+__device__ unsigned long long fg_timeline[FG_TL_CAP * 6];
 __device__ unsigned int fg_timeline_n;
-__shared__ unsigned long long fg_tl_acc[2];  // [0] ticks spent staging batches, [1] clock at the first batch
-#define FG_TL_BEGIN() const unsigned long long tl_t0_ = wall_clock64(); if (threadIdx.x == 0) fg_tl_acc[0] = fg_tl_acc[1] = 0
+__shared__ unsigned long long fg_tl_acc[7];  // [0] ticks spent staging batches, [1] clock at the first batch,
+                                             // [2] job start, [3..6] clocks at FG_TL_MARK(0..3)
+#define FG_TL_BEGIN() const unsigned long long tl_t0_ = wall_clock64(); \
+  if (threadIdx.x == 0) { fg_tl_acc[0] = fg_tl_acc[1] = fg_tl_acc[3] = fg_tl_acc[4] = fg_tl_acc[5] = fg_tl_acc[6] = 0; fg_tl_acc[2] = tl_t0_; }
+#define FG_TL_MARK(i) do { const unsigned long long m_ = wall_clock64(); if (threadIdx.x == 0) fg_tl_acc[3 + (i)] = m_ - fg_tl_acc[2]; } while (0)
 #define FG_TL_STAGE_BEGIN() const unsigned long long tl_s0_ = wall_clock64(); \
   if (threadIdx.x == 0 && fg_tl_acc[1] == 0) fg_tl_acc[1] = tl_s0_
 #define FG_TL_STAGE_END() do { if (threadIdx.x == 0) fg_tl_acc[0] += wall_clock64() - tl_s0_; } while (0)
 #define FG_TL_END(kernel, tile, strip, part, parts) do { if (threadIdx.x == 0) {                                 \
     const unsigned slot_ = atomicAdd(&fg_timeline_n, 1u);                                                          \
     if (slot_ < FG_TL_CAP) {                                                                                       \
-      fg_timeline[4 * slot_ + 0] = tl_t0_;                                                                         \
-      fg_timeline[4 * slot_ + 1] = wall_clock64();                                                                 \
-      fg_timeline[4 * slot_ + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63492) |                \
+      fg_timeline[6 * slot_ + 0] = tl_t0_;                                                                         \
+      fg_timeline[6 * slot_ + 1] = wall_clock64();                                                                 \
+      fg_timeline[6 * slot_ + 2] = (unsigned long long)(unsigned)__builtin_amdgcn_s_getreg(63492) |                \
                                    ((unsigned long long)((unsigned)__builtin_amdgcn_s_getreg(63508) & 15u) << 32) | \
                                    (fg_tl_acc[0] << 36);                                                           \
-      fg_timeline[4 * slot_ + 3] = (unsigned long long)(kernel) | ((unsigned long long)((strip) + 1) << 4) |       \
+      fg_timeline[6 * slot_ + 3] = (unsigned long long)(kernel) | ((unsigned long long)((strip) + 1) << 4) |       \
                                    ((unsigned long long)(part) << 8) | ((unsigned long long)(parts) << 12) |       \
                                    ((unsigned long long)(tile) << 16) |                                            \
                                    ((fg_tl_acc[1] ? fg_tl_acc[1] - tl_t0_ : 0ull) << 40);                          \
+      fg_timeline[6 * slot_ + 4] = fg_tl_acc[3] | (fg_tl_acc[4] << 32);                                            \
+      fg_timeline[6 * slot_ + 5] = fg_tl_acc[5] | (fg_tl_acc[6] << 32);                                            \
     } } } while (0)
 #else
 #define FG_TL_BEGIN() do { } while (0)
 #define FG_TL_STAGE_BEGIN() do { } while (0)
+#define FG_TL_MARK(i) do { } while (0)
 #define FG_TL_STAGE_END() do { } while (0)
 #define FG_TL_END(kernel, tile, strip, part, parts) do { } while (0)
 #endif
@@ -540,6 +551,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   auto& lds_mask = sh.mask;
   auto& lds_list = sh.list;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
+  const int n_tiles = tile_w * ((height + TILE - 1) / TILE);
   const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
   // one wavefront per workgroup (NW == 1, the mixed launches): the wave index is the constant 0 and
   // every per-wave LDS address folds into an instruction offset instead of a register
@@ -581,7 +593,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if constexpr (C == 3 && NW == 1) {
       // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
       if (ckpt && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
-        float4* slot = ckpt + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
+        float4* slot = ckpt + seg_slots_offset4(n_tiles) + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
@@ -699,6 +711,16 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     }
   }
 
+  if constexpr (C == 3 && NW == 1) {
+    if (ckpt) {  // the table in front of the checkpoint slots (seg_slots_offset4)
+      int32_t* tl = reinterpret_cast<int32_t*>(ckpt) + 4 * tile;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const int m = fg::wave_max_i32(last[k]);
+        if (lane == 0) tl[wave + k * (4 / PPT)] = m;
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
@@ -833,79 +855,158 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   const float pyb = (float)(tile_y * TILE + (int)(threadIdx.x >> 4) - 4 * wl) + 0.5f;  // see slot_dy
   int last[PPT];
   int my_max = start - 1;
+  // A share job (struct Segments) takes its bounds from the forward's per-strip table in front of the
+  // checkpoints: the last list index each strip used is known before any pixel state has arrived, so
+  // the checkpoint and final-colour loads go out together with the pixel loads instead of one
+  // dependent round trip later (job timeline: 14 us of a 67 us share job were prologue).
+  FG_TL_MARK(0);  // tile range known
+  int lo = start, hi = end, bin_final = start - 1;
+  int slot_last[PPT];
+  bool from_ckpt = false;  // wave-uniform: pixels whose list continues beyond hi resume from a checkpoint
+  const float4* ck_slot = nullptr;
+  bool share_job = false;
+  if constexpr (C == 3 && NW == 1) share_job = seg.ckpt && seg.parts > 1;
+  if (share_job) {
+    const int4 tl = reinterpret_cast<const int4*>(seg.ckpt)[tile];
+    const int tls[4] = {tl.x, tl.y, tl.z, tl.w};
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      slot_last[k] = __builtin_amdgcn_readfirstlane(tls[wave + k * (4 / PPT)]);
+      bin_final = max(bin_final, slot_last[k]);
+    }
+    const int n_used = bin_final - start + 1;
+    if (n_used <= 0) return;
+    const int nseg = (n_used + FG_SEG_ENTRIES - 1) / FG_SEG_ENTRIES;
+    const int c0 = part * nseg / seg.parts, c1 = (part + 1) * nseg / seg.parts;
+    if (c0 == c1) return;  // fewer segments than parts: this part is empty
+    lo = start + c0 * FG_SEG_ENTRIES;
+    hi = bin_final + 1;
+    if (c1 < nseg) {
+      hi = start + c1 * FG_SEG_ENTRIES;
+      from_ckpt = true;
+      ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE)) +
+                (size_t)(hi / FG_SEG_ENTRIES) * (TILE * TILE);
+    }
+  }
+  FG_TL_MARK(1);  // share bounds known
+  // Pixel state in two phases: first EVERY load of every pixel slot, branch-free (lanes outside the image
+  // read the nearest pixel inside and drop the value), then the arithmetic.  With the loads inside the
+  // per-slot conditionals the compiler could not hoist slot k+1's loads above slot k's branches: four
+  // serialised round trips, 11 us of a 68 us share job (job timeline, FG_TL_MARK).
+  struct Px {
+    float alpha, va;
+    int last;
+    unsigned blocked;
+    float v[C];
+  } raw[PPT];
+  float4 ckv[PPT];
+  float cfv[PPT][3];
+  {
+    const int ixc = min(ix, width - 1);
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const int iyc = min(tile_y * TILE + row0 + k * RSTEP, height - 1);
+      const size_t pix = (size_t)iyc * width + ixc;
+      raw[k].alpha = alphas[pix];
+      raw[k].last = last_ids[pix];
+#pragma unroll
+      for (int c = 0; c < C; ++c) raw[k].v[c] = v_render[pix * C + c];
+    }
+    if (v_alphas) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        raw[k].va = v_alphas[(size_t)min(tile_y * TILE + row0 + k * RSTEP, height - 1) * width + ixc];
+    } else {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) raw[k].va = 0.f;  // v_alphas == nullptr: no gradient on alpha
+    }
+    if (comp.n_clamp > 0) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k)
+        raw[k].blocked = comp.clamp_mask[(size_t)min(tile_y * TILE + row0 + k * RSTEP, height - 1) * width + ixc];
+    } else {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) raw[k].blocked = 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      ckv[k] = make_float4(1.f, 0.f, 0.f, 0.f);
+      cfv[k][0] = cfv[k][1] = cfv[k][2] = 0.f;
+    }
+    if constexpr (C == 3 && NW == 1) {
+      // share jobs: the forward's checkpoint at the job's upper end -- T before entry hi, and the colour
+      // composited from entry hi on (C_final - C_before_hi) as the suffix sum the alpha gradient needs --
+      // loaded for every pixel, used by those whose list continues beyond hi
+      if (from_ckpt) {
+#pragma unroll
+        for (int k = 0; k < PPT; ++k) {
+          const int iyc = min(tile_y * TILE + row0 + k * RSTEP, height - 1);
+          const size_t pix = (size_t)iyc * width + ixc;
+          ckv[k] = ck_slot[(row0 + k * RSTEP) * TILE + col];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) cfv[k][c] = seg.render_raw[pix * 3 + c];
+        }
+      }
+    }
+  }
 #pragma unroll
   for (int k = 0; k < PPT; ++k) {
     const int iy = tile_y * TILE + row0 + k * RSTEP;
     const bool inside = ix < width && iy < height;
-    const size_t pix = (size_t)iy * width + ix;
-    T[k] = inside ? 1.f - alphas[pix] : 1.f;  // final transmittance
-    last[k] = inside ? last_ids[pix] : start - 1;
-    float va = (inside && v_alphas) ? v_alphas[pix] : 0.f;  // v_alphas == nullptr: no gradient on alpha
-    const unsigned blocked = (inside && comp.n_clamp > 0) ? comp.clamp_mask[pix] : 0u;
+    const float alpha_f = inside ? raw[k].alpha : 0.f;
+    T[k] = 1.f - alpha_f;  // final transmittance
+    last[k] = inside ? raw[k].last : start - 1;
+    float va = inside ? raw[k].va : 0.f;
+    const unsigned blocked = inside ? raw[k].blocked : 0u;
     bsum[k] = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
-      float v = inside ? v_render[pix * C + c] : 0.f;
+      float v = inside ? raw[k].v[c] : 0.f;
       if ((blocked >> c) & 1u) v = 0.f;                  // clamped channel: no gradient
       if (comp.background) va -= v * comp.background[c];  // d/dalpha of (1 - alpha) * bg
       vr[k][c] = v;
     }
     tva[k] = T[k] * va;  // T_final * dL/dalpha
-    my_max = max(my_max, last[k]);
-  }
-  // last list entry any pixel of the tile used
-  int bin_final = fg::wave_max_i32(my_max);
-  if (NW > 1) {
-    if (lane == 0) lds_max[wl] = bin_final;
-    __syncthreads();
+    if constexpr (C == 3 && NW == 1) {
+      if (from_ckpt) {
+        // (last >= hi implies the pixel is inside the image)
+        const float prefix[3] = {ckv[k].y, ckv[k].z, ckv[k].w};
+        float sfx = 0.f;
 #pragma unroll
-    for (int w = 0; w < NW; ++w) bin_final = max(bin_final, lds_max[w]);
-  }
-  const int n_used = bin_final - start + 1;
-  if (n_used <= 0) return;
-  // last list index any pixel of each of the job's pixel slots (= strips) used (scalars)
-  int slot_last[PPT];
-  if constexpr (LIVE) {
-#pragma unroll
-    for (int k = 0; k < PPT; ++k) slot_last[k] = __builtin_amdgcn_readfirstlane(fg::wave_max_i32(last[k]));
-  }
-  // this job's share of the list: [lo, hi) (struct Segments); the whole used list without segmentation
-  int lo = start, hi = bin_final + 1;
-  if constexpr (C == 3 && NW == 1) {
-    if (seg.ckpt && seg.parts > 1) {
-      const int nseg = (n_used + FG_SEG_ENTRIES - 1) / FG_SEG_ENTRIES;
-      const int c0 = part * nseg / seg.parts, c1 = (part + 1) * nseg / seg.parts;
-      if (c0 == c1) return;  // fewer segments than parts: this part is empty
-      lo = start + c0 * FG_SEG_ENTRIES;
-      if (c1 < nseg) {
-        // pixels whose list continues beyond this job's upper end resume from the forward's
-        // checkpoint there: T before entry hi, and the colour composited from entry hi on
-        // (C_final - C_before_hi) as the suffix sum the alpha gradient needs
-        hi = start + c1 * FG_SEG_ENTRIES;
-        const float4* slot = seg.ckpt + (size_t)(hi / FG_SEG_ENTRIES) * (TILE * TILE);
-#pragma unroll
-        for (int k = 0; k < PPT; ++k) {
-          if (last[k] >= hi) {  // (implies the pixel is inside the image)
-            const int iy = tile_y * TILE + row0 + k * RSTEP;
-            const size_t pix = (size_t)iy * width + ix;
-            const float4 ck = slot[(row0 + k * RSTEP) * TILE + col];
-            const float prefix[3] = {ck.y, ck.z, ck.w};
-            float sfx = 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-              // raw final colour: the forward's accumulator, or (composite epilogue) the finished image
-              // minus the background term -- exact where the gradient is not blocked by the clamp
-              float cf = seg.render_raw[pix * 3 + c];
-              if (comp.background) cf -= (1.f - alphas[pix]) * comp.background[c];
-              sfx += vr[k][c] * (cf - prefix[c]);
-            }
-            T[k] = ck.x;
-            bsum[k] = sfx;
-          }
+        for (int c = 0; c < 3; ++c) {
+          // raw final colour: the forward's accumulator, or (composite epilogue) the finished image
+          // minus the background term -- exact where the gradient is not blocked by the clamp
+          float f = cfv[k][c];
+          if (comp.background) f -= (1.f - alpha_f) * comp.background[c];
+          sfx += vr[k][c] * (f - prefix[c]);
         }
+        const bool resume = last[k] >= hi;
+        T[k] = resume ? ckv[k].x : T[k];
+        bsum[k] = resume ? sfx : 0.f;
       }
     }
+    my_max = max(my_max, last[k]);
   }
+  FG_TL_MARK(2);  // pixel state loaded
+  if (!share_job) {
+    // last list entry any pixel of the tile used
+    bin_final = fg::wave_max_i32(my_max);
+    if (NW > 1) {
+      if (lane == 0) lds_max[wl] = bin_final;
+      __syncthreads();
+#pragma unroll
+      for (int w = 0; w < NW; ++w) bin_final = max(bin_final, lds_max[w]);
+    }
+    if (bin_final - start + 1 <= 0) return;
+    hi = bin_final + 1;
+    // last list index any pixel of each of the job's pixel slots (= strips) used (scalars)
+    if constexpr (LIVE) {
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) slot_last[k] = __builtin_amdgcn_readfirstlane(fg::wave_max_i32(last[k]));
+    }
+  }
+  const int n_used = bin_final - start + 1;
+  (void)n_used;
   const int n_batches = (hi - lo + NT - 1) / NT;
   if (threadIdx.x == 0) { FG_STAT(5, n_used); FG_STAT(6, end - start); }
   float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
@@ -1711,7 +1812,7 @@ extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height
   if (channels != 3 || width <= 0 || height <= 0 || tile_size != TILE || n_isects <= 0) return 0;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   if (seg_parts() <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
-  return (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE) * 4;
+  return ((int64_t)seg_slots_offset4(n_tiles) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
 }
 
 extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
@@ -1745,7 +1846,7 @@ extern "C" int fg_debug_raster_timeline(unsigned long long* out, int cap, int re
   if (hipDeviceSynchronize() != hipSuccess) return -1;
   if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(fg_timeline_n), 4) != hipSuccess) return -1;
   const unsigned m = n < (unsigned)cap ? n : (unsigned)cap;
-  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_timeline), (size_t)(m < FG_TL_CAP ? m : FG_TL_CAP) * 32) != hipSuccess)
+  if (m && hipMemcpyFromSymbol(out, HIP_SYMBOL(fg_timeline), (size_t)(m < FG_TL_CAP ? m : FG_TL_CAP) * 48) != hipSuccess)
     return -1;
   if (reset) {
     const unsigned z = 0;

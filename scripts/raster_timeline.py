@@ -27,7 +27,7 @@ lib = _lib.load()
 lib.fg_debug_raster_timeline.restype = ctypes.c_int
 lib.fg_debug_raster_timeline.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
 CAP = 1 << 17
-buf = np.zeros((CAP, 4), dtype=np.uint64)
+buf = np.zeros((CAP, 6), dtype=np.uint64)
 
 
 def step(view):
@@ -45,6 +45,8 @@ cnt = lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
 rec = buf[:min(cnt, CAP)]
 t0, t1, hw, what = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64), rec[:, 2], rec[:, 3]
 what_lo = what & ((1 << 40) - 1)
+marks_us = np.stack([(rec[:, 4] & 0xFFFFFFFF), (rec[:, 4] >> 32), (rec[:, 5] & 0xFFFFFFFF), (rec[:, 5] >> 32)],
+                    axis=1).astype(np.float64) / 100.0  # FG_TL_MARK(0..3): microseconds after the job's start
 kernel = (what & 0xF).astype(int)
 strip = ((what >> 4) & 0xF).astype(int) - 1
 parts = ((what >> 12) & 0xF).astype(int)
@@ -78,7 +80,8 @@ for kid, name in ((1, "raster_fwd_mixed"), (2, "raster_bwd_mixed")):
                           "sum_ms": float(d.sum() / 1e3),
                           "staging_share": float(stage_us[m][kind == kk].sum() / d.sum()),
                           "prologue_share": float(prologue_us[m][kind == kk].sum() / d.sum()),
-                          "prologue_mean_us": float(prologue_us[m][kind == kk].mean())}
+                          "prologue_mean_us": float(prologue_us[m][kind == kk].mean()),
+                          "marks_mean_us": [float(x) for x in marks_us[m][kind == kk].mean(axis=0)]}
     usimd = np.unique(sk)
     nsl = 20
     edges = np.linspace(lo, hi, nsl + 1)
