@@ -494,9 +494,11 @@ def main(argv=None):
     ops.stage_timer = ops.StageTimer(only=only)
     t0 = time.perf_counter()
     views_seen = []
+    host_marks = [t0]
     for _ in range(args.steps):
         info, view = step(timed=args.stage_events == "all")
         views_seen.append(view)
+        host_marks.append(time.perf_counter())
     fence()
     dt_local = time.perf_counter() - t0
     gc.enable()
@@ -640,6 +642,11 @@ def main(argv=None):
                 "note": f"includes 24*p*I = {24 * p * I} B of {p}-pass 64-bit-key sort traffic the depth-first binning avoids",
             },
         },
+        # host-side time between consecutive returns of step(): the host waits for the GPU once per step (the
+        # list length), so these follow the GPU's progress; a stall of the host or the driver shows up here
+        "host_step_ms": (lambda d: {"median": sorted(d)[len(d) // 2], "max": max(d), "argmax": d.index(max(d)),
+                                    "over_1.5x_median": sum(1 for x in d if x > 1.5 * sorted(d)[len(d) // 2])})(
+            [(b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:])]),
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
         "stage_ms_from": ("HIP events around every C-ABI call in the timed region" if args.stage_events == "all" else
                           f"{dominant}: HIP events in the timed region; the other stages: a pass of {stage_steps} steps over the "

@@ -1020,9 +1020,11 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
     const int idx = batch + tl;
     unsigned mask = 0;
+    // (the id is loaded alongside the liveness word, not behind it: one round trip less per batch)
+    const int gid_early = (LIVE && idx < hi) ? flatten_ids[idx] : 0;
     if constexpr (LIVE) {
       // the forward's liveness byte per strip, valid up to the last entry any pixel of that strip
-      // used (beyond it the forward never wrote); dead entries are not even gathered
+      // used (beyond it the forward never wrote); dead entries' records are not gathered
       if (idx < hi) {
         const uint32_t lw = live_words[idx];
 #pragma unroll
@@ -1033,7 +1035,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
       }
     }
     if (LIVE ? mask != 0u : idx < hi) {
-      const int gid = flatten_ids[idx];
+      const int gid = LIVE ? gid_early : flatten_ids[idx];
       lds_gid[tl] = gid;
       const float4* rec = splats + (size_t)gid * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
