@@ -353,7 +353,16 @@ struct Composite {
 // index any pixel of the strip used (written by the forward's jobs, one strip each or all four; read by
 // the backward's share jobs, which then know their share of the list before any pixel state arrives);
 // the checkpoint slots follow, aligned to a slot (256 float4).
-__host__ __device__ __forceinline__ size_t seg_slots_offset4(int n_tiles) { return ((size_t)n_tiles + 255) / 256 * 256; }
+// Behind the table: a plane float[height * width] with every pixel's final transmittance exactly as the
+// forward held it.  The reference's backward starts from T_final = 1 - alpha_out, i.e. from a value
+// rounded at ulp(1) -- 6e-4 relative on a saturated pixel (T ~ 1e-4) -- and rebuilds every T_i from it, so
+// ALL its T-dependent terms carry that pixel's factor rho = (1 - alpha_out) / T_exact.  A share job that
+// resumes from the forward's exact checkpoint has to apply rho itself to agree with the reference's
+// arithmetic (without it: 8e-5 relative L2 on the gradients of the 1M / 1080p frame against 1.5e-5).
+__host__ __device__ __forceinline__ size_t seg_plane_offset4(int n_tiles) { return ((size_t)n_tiles + 255) / 256 * 256; }
+__host__ __device__ __forceinline__ size_t seg_slots_offset4(int n_tiles, int width, int height) {
+  return seg_plane_offset4(n_tiles) + ((size_t)width * height / 4 + 256) / 256 * 256;
+}
 struct Segments {
   float4* ckpt;             // [slots][256 pixels of the tile, row-major]; nullptr = no segmentation
   const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
@@ -593,7 +602,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if constexpr (C == 3 && NW == 1) {
       // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
       if (ckpt && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
-        float4* slot = ckpt + seg_slots_offset4(n_tiles) + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
+        float4* slot = ckpt + seg_slots_offset4(n_tiles, width, height) + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
@@ -727,6 +736,9 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if (ix < width && iy < height) {
       const size_t pix = (size_t)iy * width + ix;
       const float alpha_out = 1.f - T[k];
+      if constexpr (C == 3 && NW == 1) {
+        if (ckpt) reinterpret_cast<float*>(ckpt + seg_plane_offset4(n_tiles))[pix] = T[k];  // exact T_final
+      }
       if (comp.background || comp.n_clamp > 0) {
         const float om = 1.f - alpha_out;  // as the host expression (1 - alpha) rounds
         unsigned blocked = 0;
@@ -884,7 +896,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     if (c1 < nseg) {
       hi = start + c1 * FG_SEG_ENTRIES;
       from_ckpt = true;
-      ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE)) +
+      ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE), width, height) +
                 (size_t)(hi / FG_SEG_ENTRIES) * (TILE * TILE);
     }
   }
@@ -900,7 +912,12 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     float v[C];
   } raw[PPT];
   float4 ckv[PPT];
-  float cfv[PPT][3];
+  float cfv[PPT][3], tfe[PPT];
+  const float* t_exact = nullptr;
+  if constexpr (C == 3 && NW == 1) {
+    if (from_ckpt)
+      t_exact = reinterpret_cast<const float*>(seg.ckpt + seg_plane_offset4(tile_w * ((height + TILE - 1) / TILE)));
+  }
   {
     const int ixc = min(ix, width - 1);
 #pragma unroll
@@ -932,6 +949,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     for (int k = 0; k < PPT; ++k) {
       ckv[k] = make_float4(1.f, 0.f, 0.f, 0.f);
       cfv[k][0] = cfv[k][1] = cfv[k][2] = 0.f;
+      tfe[k] = 1.f;
     }
     if constexpr (C == 3 && NW == 1) {
       // share jobs: the forward's checkpoint at the job's upper end -- T before entry hi, and the colour
@@ -943,6 +961,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
           const int iyc = min(tile_y * TILE + row0 + k * RSTEP, height - 1);
           const size_t pix = (size_t)iyc * width + ixc;
           ckv[k] = ck_slot[(row0 + k * RSTEP) * TILE + col];
+          tfe[k] = t_exact[pix];
 #pragma unroll
           for (int c = 0; c < 3; ++c) cfv[k][c] = seg.render_raw[pix * 3 + c];
         }
@@ -981,8 +1000,10 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
           sfx += vr[k][c] * (f - prefix[c]);
         }
         const bool resume = last[k] >= hi;
-        T[k] = resume ? ckv[k].x : T[k];
-        bsum[k] = resume ? sfx : 0.f;
+        // rho: the reference's rounded T_final over the exact one (seg_plane_offset4)
+        const float rho = T[k] * __builtin_amdgcn_rcpf(fmaxf(tfe[k], 1e-30f));
+        T[k] = resume ? ckv[k].x * rho : T[k];
+        bsum[k] = resume ? sfx * rho : 0.f;
       }
     }
     my_max = max(my_max, last[k]);
@@ -1814,7 +1835,7 @@ extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height
   if (channels != 3 || width <= 0 || height <= 0 || tile_size != TILE || n_isects <= 0) return 0;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   if (seg_parts() <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
-  return ((int64_t)seg_slots_offset4(n_tiles) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
+  return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
 }
 
 extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
