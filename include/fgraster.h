@@ -215,8 +215,10 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * this size / environment); seg_ckpt[floats], uninitialised, goes to BOTH calls and `image` (the
  * forward's output) to the backward: the forward leaves every pixel's compositing state at every
  * 64th entry of a tile's list (only for the tiles the backward's job list splits: hand both calls the
- * lists of ONE fg_raster_build_jobs call), and the backward runs several jobs per tile, each over its share of
- * the list, instead of one serial walk.  Same gradients up to float summation order.  NULL = off.
+ * lists of ONE fg_raster_build_jobs call), the last list index each (tile, strip) used and every
+ * pixel's exact final transmittance; the backward runs several jobs per tile, each over its share of
+ * the list, instead of one serial walk.  Same gradients up to float summation order (a share job
+ * reproduces the reference's T_final = 1 - alpha rounding per pixel).  The buffer is opaque.  NULL = off.
  * fg_raster_build_jobs(bwd_list_shares = 1) must then have built the backward's list (its entries
  * are (tile, part, parts) instead of (tile, strip)).
  * LIVENESS (any channel count): live_words[n_isects] uint32, uninitialised, to BOTH calls: the

@@ -918,10 +918,12 @@ def test_1080p_mixed_launch_forward_and_all_gradients_vs_oracle(layout, render_m
 
 @pytest.mark.parametrize("parts,layout,bg", [(2, "uniform", False), (4, "clustered", False), (3, "uniform", True), (16, "clustered", True)])
 def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, monkeypatch):
-    """List segments of the backward (forward checkpoints every 128 list entries; `parts` jobs per
+    """List segments of the backward (forward checkpoints every 64 list entries; `parts` jobs per
     tile, each over its share of the list): every gradient against the oracle at 8160 tiles and against
     the unsegmented walk; with and without the composite epilogue (background + clamp), whose raw
-    colours the backward has to rebuild from the finished image."""
+    colours the backward has to rebuild from the finished image.  A share job resumes from the forward's
+    exact state and applies the reference's per-pixel rounding factor of T_final
+    (profiles/r02_backward_list_shares.md section 5): without it the two walks differ by ~8e-5."""
     from freegaussian_amd.rasterization import rasterize_gauss_params
 
     sc = synthetic_scene(40_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
@@ -935,8 +937,9 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
         monkeypatch.setenv("FG_RASTER_SEG_PARTS", "1")
         _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
         assert torch.equal(o2[0], o1[0])  # the forward does not depend on it
-        for k in seg_grads:
-            assert rel_l2(seg_grads[k], gpu_in1[k].grad) < REL_TOL, k  # (suffix colour = C_final - C_before: one more rounding per pixel)
+        diff = {k: rel_l2(seg_grads[k], gpu_in1[k].grad) for k in seg_grads}
+        print("share jobs vs whole-list walk, rel-L2:", {k: f"{v:.1e}" for k, v in diff.items()})
+        assert all(v < 1e-5 for v in diff.values()), diff  # observed 2-5e-7: atomic order only
         return
     # composite epilogue: the model's raw-parameter front end with a background and the clamp
     g = torch.Generator().manual_seed(3)
@@ -954,8 +957,9 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
         ((r * vr).sum() + a.sum()).backward()
         outs.append((r.detach(), {k: v.grad for k, v in t.items()}))
     assert torch.equal(outs[0][0], outs[1][0])
-    for k in raw:
-        assert rel_l2(outs[0][1][k], outs[1][1][k]) < REL_TOL, k
+    diff = {k: rel_l2(outs[0][1][k], outs[1][1][k]) for k in raw}
+    print("share jobs vs whole-list walk (composite epilogue), rel-L2:", {k: f"{v:.1e}" for k, v in diff.items()})
+    assert all(v < 1e-5 for v in diff.values()), diff
 
 
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
@@ -967,7 +971,7 @@ def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
     sc = north_star_scene(n_views=1)
     ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 0, "RGB", 3, with_alpha_grad=False)  # the bench's upstream gradient
     assert o0[2]["flatten_ids"].numel() > 7_000_000
-    worst = _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+    worst = _assert_full_parity(ref_in, gpu_in, o0, o1, REL_TOL)  # the bar itself (share jobs without rho: up to 1.2e-4)
     assert psnr(o1[0], o0[0]) > 80
     print("cfg4 whole-frame rel-L2 of gradients vs oracle:", {k: f"{v:.2e}" for k, v in worst.items()})
 
