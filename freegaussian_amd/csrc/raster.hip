@@ -1592,6 +1592,19 @@ int seg_parts() {
   return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
 
+// Zero-fill as a kernel of our own: a hipMemsetAsync issued on a stream under torch's graph capture did
+// not end up in the graph here (replays then accumulated onto the previous replay's gradients).
+__global__ void __launch_bounds__(256) zero_fill_kernel(float* __restrict__ p, long long n) {
+  const long long stride = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) p[i] = 0.f;
+}
+int zero_fill(float* p, long long n, hipStream_t s) {
+  if (n <= 0) return FG_OK;
+  const long long blocks = (n + 1023) / 1024;
+  hipLaunchKernelGGL(zero_fill_kernel, dim3((unsigned)(blocks < 65536 ? blocks : 65536)), dim3(256), 0, s, p, n);
+  return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
+}
+
 template <int C>
 int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
@@ -1600,7 +1613,7 @@ int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(tile_w, tile_h);
   if (zero_buf && ((zero_floats & 3) || (reinterpret_cast<uintptr_t>(zero_buf) & 15))) {
-    if (hipMemsetAsync(zero_buf, 0, (size_t)zero_floats * 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    if (zero_fill(zero_buf, zero_floats, s) != FG_OK) return FG_ERR_LAUNCH;
     zero_buf = nullptr;
   }
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
@@ -1694,7 +1707,7 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   int tail = mixed_tail_fwd(n_tiles);
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
   if (zero_buf && zero_floats > 0 && tail == 0) {  // only the mixed launch zero-fills in passing
-    if (hipMemsetAsync(zero_buf, 0, (size_t)zero_floats * 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    if (zero_fill(zero_buf, zero_floats, s) != FG_OK) return FG_ERR_LAUNCH;
     zero_buf = nullptr;
   }
   if (zero_floats == 0) zero_buf = nullptr;
@@ -1729,6 +1742,12 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   const int ppt = raster_ppt_bwd(n_tiles);
   int tail = mixed_tail_bwd(n_tiles);
   if (tail == 0) jobs = nullptr;
+  // liveness words and checkpoints exist only if the forward of this image size was a mixed launch (a
+  // forced FG_RASTER_TAIL_BWD on a small image pairs a classic forward with a mixed backward)
+  if (mixed_tail_fwd(n_tiles) == 0) {
+    live_words = nullptr;
+    seg_ckpt = nullptr;
+  }
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
   Segments seg{nullptr, nullptr, 1, 0};
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
