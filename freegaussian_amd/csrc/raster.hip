@@ -661,12 +661,18 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       for (int k = 0; k < PPT; ++k) all_done &= done[k];
       if (all_done == full) break;  // this wavefront has nothing left to do
       const int n1 = min(n0 + 8, cnt);
+      // The list word of iteration n+1 is read during iteration n: the per-entry chain list word ->
+      // record -> arithmetic was two LDS round trips long and a SIMD's 8 wavefronts did not cover it
+      // (masking 5% of the slot tests away changed nothing; this: 0.211 -> 0.201 ms).  Fetching the whole
+      // record one entry ahead as well, two register sets taking turns, loses again: 72 VGPRs, 0.217 ms.
+      unsigned next_v = lds_list[wl][n0];
       for (int n = n0; n < n1; ++n) {
       // the entry is wave-uniform: move it to a scalar register so that the record address and
       // the list index are scalar arithmetic (as a vector value the compiler spent a quarter-rate
       // v_mul_lo_u32 per entry on the address)
       FG_STAT(8, 1);
-      const unsigned packed = __builtin_amdgcn_readfirstlane((unsigned)lds_list[wl][n]);
+      const unsigned packed = __builtin_amdgcn_readfirstlane(next_v);
+      next_v = lds_list[wl][min(n + 1, NT - 1)];
       const int j = packed & 255u;
       Splat s;
       float f[C];
@@ -1095,6 +1101,11 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         Splat s;
         float f[C];
         read_record<C>(lds[j], s, f);
+        // (the Gaussian's id for the atomics at the end of the entry is read here, with the record: its LDS
+        // round trip is then not on the chain between the reduction and the atomics: 0.344 -> 0.340 ms.
+        // Deferring the read-back half of the reduction behind the next entry's record read as well: 80
+        // VGPRs, 0.347 -- dropped.)
+        const int gid_v = lds_gid[j];
         const float dx = s.x - px, dy_base = s.y - pyb;
         SigmaTerms st;
         if constexpr (C == 3) {
@@ -1202,7 +1213,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                      // operations cost 4-8 issue clocks each, fg_common.h)
           const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wl], lane);
           if ((lane & 3) == 0 && (lane >> 2) < 8 + C) {
-            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            const int gid_s = __builtin_amdgcn_readfirstlane(gid_v);
             float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
@@ -1212,14 +1223,14 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
           const float total = fg::wave_reduce12_transposed(g);
           if (fg::wave_reduce12_owner(lane)) {
             // the Gaussian id is wave-uniform: scalar base address + per-lane slot offset
-            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            const int gid_s = __builtin_amdgcn_readfirstlane(gid_v);
             float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + fg::wave_reduce12_index(lane);
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         } else {
           const float total = fg::wave_reduce16_transposed(g);
           if ((lane & 3) == 0) {
-            const int gid_s = __builtin_amdgcn_readfirstlane(lds_gid[j]);
+            const int gid_s = __builtin_amdgcn_readfirstlane(gid_v);
             float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
