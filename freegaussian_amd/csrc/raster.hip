@@ -1465,6 +1465,10 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
 #ifndef FG_TAIL2_TILES_BWD
 #define FG_TAIL2_TILES_BWD 300
 #endif
+// mixed launches (job lists, liveness, list shares) from this many tiles up; below: classic launches
+#ifndef FG_MIXED_MIN_TILES
+#define FG_MIXED_MIN_TILES 900
+#endif
 // Returns tail4 | tail2 << 16 (both clamped to 16 bits); the variables take "t4" or "t4,t2".
 int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
   const char* e = getenv(name);
@@ -1474,10 +1478,20 @@ int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
     const char* c = strchr(e, ',');
     if (c) t2 = atoi(c + 1);
   } else {
-    if (n_tiles < 5000 || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
+    if (n_tiles < FG_MIXED_MIN_TILES || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
     const int per_xcd = n_tiles / 8;
-    t4 = dflt4 < per_xcd / 2 ? dflt4 : per_xcd / 2;
-    t2 = dflt2 < per_xcd * 3 / 10 ? dflt2 : per_xcd * 3 / 10;
+    if (n_tiles < 5000) {
+      // 900..5000 tiles (640x360 ... 1280x720; 960x540 is the reference's half-resolution phase): fewer tiles than
+      // wavefront slots -- every tile of the forward as four single-strip jobs, every tile of the
+      // backward in list shares (seg_tail), liveness and checkpoints as at full size.  960x540 / 300k
+      // Gaussians: step 0.589 -> 0.536 ms (backward 0.274 -> 0.182, forward 0.100 -> 0.109);
+      // 1280x720 / 500k: 0.725 -> 0.650.
+      t4 = dflt4 > 0 ? 0xFFFF : 0;
+      t2 = dflt4 > 0 ? 0 : (dflt2 < per_xcd * 3 / 10 ? dflt2 : per_xcd * 3 / 10);
+    } else {
+      t4 = dflt4 < per_xcd / 2 ? dflt4 : per_xcd / 2;
+      t2 = dflt2 < per_xcd * 3 / 10 ? dflt2 : per_xcd * 3 / 10;
+    }
   }
   t4 = t4 < 0 ? 0 : (t4 > 0xFFFF ? 0xFFFF : t4);
   t2 = t2 < 0 ? 0 : (t2 > 0x7FFF ? 0x7FFF : t2);
@@ -1564,9 +1578,9 @@ const uint32_t* live_use(const uint32_t* live_words) {
   return (e && e[0] == '0') ? nullptr : live_words;
 }
 // FG_RASTER_SEG_TAIL = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
-int seg_tail() {
+int seg_tail(int n_tiles) {
   const char* e = getenv("FG_RASTER_SEG_TAIL");
-  const int v = e ? atoi(e) : FG_SEG_TAIL_DEFAULT;
+  const int v = e ? atoi(e) : (n_tiles < 5000 ? 0 : FG_SEG_TAIL_DEFAULT);  // below 5000 tiles: every tile
   return v < 0 ? 0 : v;
 }
 // ... clamped so that the positional jobs of the largest XCD band (+ the margin for content splits)
@@ -1763,7 +1777,7 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   Segments seg{nullptr, nullptr, 1, 0};
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
     seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(),
-                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(), seg_tail())};
+                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(), seg_tail(n_tiles))};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -1840,7 +1854,7 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const bool shares = bwd_list_shares && tb > 0 && seg_parts() > 1;
-  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(), seg_tail());
+  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(), seg_tail(n_tiles));
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), st, true) / 8,
                                           seg_parts(), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
