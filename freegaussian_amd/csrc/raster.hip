@@ -146,7 +146,7 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int n
 // total * a2 / 65536 two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
 // mean, scripts/clustered_check.py) whole-tile jobs for those tiles made the forward 0.81 ms; every
 // tile in quarters 0.39 ms.  Layout of a list (int32): [0..7] jobs per XCD, then 8 segments of
-// `cap` = 4 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
+// `cap` = 8 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
 // column-major order.  (Giving every tile four workgroups and letting the unused ones return was
 // tried first: the empty workgroups in front of live ones cost the forward 0.218 -> 0.275 ms, and
 // with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
@@ -345,6 +345,9 @@ struct Composite {
 // for the tiles the backward splits -- FG_JOB_NO_CKPT -- so the finer grain costs it nothing)
 #ifndef FG_SEG_PARTS_DEFAULT
 #define FG_SEG_PARTS_DEFAULT 4
+#endif
+#ifndef FG_SEG_PARTS_SMALL
+#define FG_SEG_PARTS_SMALL 6
 #endif
 #ifndef FG_SEG_TAIL_DEFAULT
 #define FG_SEG_TAIL_DEFAULT 400
@@ -1536,7 +1539,7 @@ int mixed_grid(int tile_w, int tile_h, int tail) {  // positional jobs only
   t2 = t2 < n_max - t4 ? t2 : n_max - t4;
   return 8 * (n_max + 3 * t4 + t2);
 }
-int jobs_cap(int tile_w, int tile_h) { return 4 * band_tiles_max(tile_w, tile_h); }
+int jobs_cap(int tile_w, int tile_h) { return 8 * band_tiles_max(tile_w, tile_h); }
 // grid of a launch that reads job lists: the positional job count + half a job per tile for the
 // content splits (the builder fits the list into it)
 int listed_grid(int tile_w, int tile_h, int tail) {
@@ -1611,9 +1614,11 @@ int seg_tail2() {
   return v < 0 ? 0 : v;
 }
 // FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
-int seg_parts() {
+int seg_parts(int n_tiles) {
   const char* e = getenv("FG_RASTER_SEG_PARTS");
-  const int v = e ? atoi(e) : FG_SEG_PARTS_DEFAULT;
+  // below 5000 tiles there are fewer tiles than wavefront slots: 6 shares per tile (960x540: backward
+  // 0.181 -> 0.178, 1280x720: 0.246 -> 0.236; 8: 0.175 / 0.229)
+  const int v = e ? atoi(e) : (n_tiles < 5000 ? FG_SEG_PARTS_SMALL : FG_SEG_PARTS_DEFAULT);
   return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
 
@@ -1775,9 +1780,9 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   }
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
   Segments seg{nullptr, nullptr, 1, 0};
-  if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts() > 1)
-    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(),
-                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(), seg_tail(n_tiles))};
+  if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts(n_tiles) > 1)
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(n_tiles),
+                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(n_tiles), seg_tail(n_tiles))};
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -1853,10 +1858,10 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8, 0, 0, 0, 0};
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
-  const bool shares = bwd_list_shares && tb > 0 && seg_parts() > 1;
-  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(), seg_tail(n_tiles));
-  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(), st, true) / 8,
-                                          seg_parts(), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
+  const bool shares = bwd_list_shares && tb > 0 && seg_parts(n_tiles) > 1;
+  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(n_tiles), seg_tail(n_tiles));
+  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(n_tiles), st, true) / 8,
+                                          seg_parts(n_tiles), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
   hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
                      band_nx(tile_w, tile_h),
@@ -1878,7 +1883,7 @@ extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_
 extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects) {
   if (channels != 3 || width <= 0 || height <= 0 || tile_size != TILE || n_isects <= 0) return 0;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-  if (seg_parts() <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
+  if (seg_parts(n_tiles) <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
   return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
 }
 
