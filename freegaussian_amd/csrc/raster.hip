@@ -344,7 +344,7 @@ struct Composite {
 // for the last 300; 4 shares over 64-entry segments: 0.370 -> 0.349 (the forward writes checkpoints only
 // for the tiles the backward splits -- FG_JOB_NO_CKPT -- so the finer grain costs it nothing)
 #ifndef FG_SEG_PARTS_DEFAULT
-#define FG_SEG_PARTS_DEFAULT 4
+#define FG_SEG_PARTS_DEFAULT 5
 #endif
 #ifndef FG_SEG_PARTS_SMALL
 #define FG_SEG_PARTS_SMALL 6
