@@ -358,9 +358,10 @@ def rasterize_gauss_params(
     )
     means2d_info = means2d_n.unsqueeze(0)
     bg = None
-    if background is not None:
-        bg = torch.zeros(channels, device=means.device, dtype=torch.float32)
-        bg[:3] = background.detach().reshape(-1).to(means.device, torch.float32)
+    if background is not None:  # (RGB: the tensor itself; more channels: one pad op -- no zeros + slice copy)
+        bg = background.detach().reshape(-1).to(means.device, torch.float32)
+        if channels > 3:
+            bg = torch.nn.functional.pad(bg, (0, channels - 3))
 
     def composite():
         return ops.rasterize_splats(splats, means2d_info, channels, width, height, tile_size, offsets, flatten_ids,
