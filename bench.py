@@ -535,10 +535,11 @@ def main(argv=None):
     wkey = f"{N}x{W}x{H}xsh{args.sh_degree}"
     # the dominant KERNEL: exchange / host-composed stages are not kernels of the path
     kernel_stages = {s: v for s, v in stages.items() if s in alg}
-    if not kernel_stages:  # --stage-events none: an A/B of the events' own cost, no roofline to report
+    no_events = not kernel_stages
+    if no_events:  # --stage-events none: an A/B of the events' own cost, no roofline to report
         stages = dict(stages)
-        kernel_stages = {"fg_raster_bwd": float("nan")}
-        stages["fg_raster_bwd"] = float("nan")
+        kernel_stages = {"fg_raster_bwd": 1.0}
+        stages["fg_raster_bwd"] = 1.0  # placeholder (ms); the roofline block is dropped below
     dom = max(kernel_stages, key=lambda s: kernel_stages[s])
     roof = {
         # the contract prices this path against HBM (no dense contraction, no MFMA);
@@ -554,6 +555,9 @@ def main(argv=None):
         "launch_counts": "I, V of the last timed step's view; duration averaged over the views of the timed region",
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
+    if no_events:
+        roof = {"bound": "hbm", "kernel": dom, "note": "--stage-events none: no kernel was timed"}
+        stages = {}
     if dom in ("fg_raster_bwd", "fg_raster_fwd"):
         roof["measured_limiter"] = ("vector issue + dependent-issue latency (VALU), not HBM: measured traffic is below "
                                     "the algorithmic bytes (L2 / Infinity Cache hits) -- see vector_issue_roofline")  # fmt: skip
