@@ -2,7 +2,9 @@
 SH degrees, render modes, raster modes, packed / unpacked, with hostile Gaussians mixed in
 (behind the camera, huge, tiny, nearly transparent, NaN-free).  Integer results must be equal;
 images and gradients within the 1e-4 bar (knife-edge pixels bounded as in tests/helpers.py).
-Usage: python scripts/fuzz_parity.py [n_cases] [seed]  -> one line per case + a summary."""
+Usage: python scripts/fuzz_parity.py [n_cases] [seed] [big]  -> one line per case + a summary.
+`big`: images of 640x360 ... 1920x1080 (900 ... 8160 tiles: the mixed launches with job lists, strips, list
+shares and liveness) with up to 40000 Gaussians."""
 import os
 import sys
 
@@ -19,6 +21,7 @@ from oracle import raster_oracle as O  # noqa: E402
 torch.set_num_threads(min(os.cpu_count() or 1, 16))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
 dev = "cuda"
 bad = 0
 for case in range(n_cases):
@@ -26,6 +29,9 @@ for case in range(n_cases):
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
     n = [1, 2, 17, 300, 3000, 12000][ri(0, 5)]
     W, H = ri(17, 300), ri(17, 200)
+    if big:
+        n = [3000, 12000, 40000][ri(0, 2)]
+        W, H = ri(640, 1920), ri(360, 1080)
     deg = [None, 0, 1, 2, 3][ri(0, 4)]
     mode = ["RGB", "RGB+ED", "ED"][ri(0, 2)]
     rmode = ["classic", "antialiased"][ri(0, 1)]
