@@ -218,6 +218,14 @@ _isect_recent: dict = {}  # key -> list lengths of the last calls
 capacity_redos = 0  # times a speculative list turned out too small and emission + sort were repeated
 
 
+def list_capacity_for(recent_lengths) -> int:
+    """Speculative list capacity from the list lengths of the last calls of a shape: 25% headroom over the
+    heaviest, rounded up to 1/32..1/16 of its magnitude (one allocation size per shape, not one per view)."""
+    want = int(max(recent_lengths) * 1.25) + 4096
+    granule = 1 << max(want.bit_length() - 5, 12)
+    return min(-(-want // granule) * granule, 2**31 - 1)
+
+
 def _count_buffer(dev) -> torch.Tensor:
     # one pinned 8-byte buffer per call (torch's caching host allocator makes this cheap): a shared
     # one would be overwritten by a second in-flight call on the same device
@@ -395,10 +403,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         recent = _isect_recent.setdefault(key, [])
         recent.append(n_isects)
         del recent[:-16]
-        want = int(max(recent) * 1.25) + 4096
-        granule = 1 << max(want.bit_length() - 5, 12)
-        want = -(-want // granule) * granule
-        _isect_capacity[key] = min(want, 2**31 - 1)
+        _isect_capacity[key] = list_capacity_for(recent)
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
         if capacity is not None:

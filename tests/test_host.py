@@ -286,3 +286,21 @@ def test_model_load_state_dict_resizes_and_remaps_like_the_reference():
     dst2 = FreeGaussianModel(FreeGaussianModelConfig(), num_points=9)
     dst2.load_state_dict(legacy)
     assert dst2.num_points == 70 and torch.equal(dst2.means, src.means)
+
+
+def test_list_capacity_is_one_size_per_shape():
+    """ops.list_capacity_for: the speculative capacity of the intersection lists covers the heaviest of the
+    recent views with 25% headroom and does not change when the views differ by a few percent (every
+    list-sized buffer of a step is allocated from it: a new size per view would churn the allocator)."""
+    from freegaussian_amd.ops import list_capacity_for
+
+    base = 5_085_668
+    ring = [int(base * f) for f in (1.0, 0.985, 1.012, 0.97, 1.03, 0.99, 1.02, 0.975)]
+    caps = {list_capacity_for(ring[: i + 1][-16:]) for i in range(2, len(ring))} | {list_capacity_for(ring)}
+    assert len(caps) <= 2  # (the first views may still grow it once)
+    cap = list_capacity_for(ring)
+    assert cap >= 1.25 * max(ring) and cap <= 1.25 * max(ring) * (1 + 1 / 16) + 8192
+    granule = 1 << max((int(max(ring) * 1.25) + 4096).bit_length() - 5, 12)
+    assert cap % granule == 0
+    assert list_capacity_for([0]) >= 4096 and list_capacity_for([2**31]) == 2**31 - 1
+    assert list_capacity_for([10, 1_000_000, 10]) == list_capacity_for([1_000_000])
