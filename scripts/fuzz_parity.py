@@ -22,6 +22,12 @@ torch.set_num_threads(min(os.cpu_count() or 1, 16))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
+# FUZZ_COMPOSITOR=c: the oracle composites with the C restatement of the reference's backward (T_i rebuilt
+# from the rounded T_final) instead of torch autograd; FUZZ_ONLY=k: run case k only
+use_c = os.environ.get("FUZZ_COMPOSITOR") == "c"
+only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
+if use_c:
+    from oracle import c_oracle as CO  # noqa: E402
 dev = "cuda"
 bad = 0
 for case in range(n_cases):
@@ -36,6 +42,8 @@ for case in range(n_cases):
     mode = ["RGB", "RGB+ED", "ED"][ri(0, 2)]
     rmode = ["classic", "antialiased"][ri(0, 1)]
     packed = bool(ri(0, 1))
+    if only is not None and case != only:
+        continue
     sc = synthetic_scene(n, W, H, n_views=2, seed=seed0 * 1000 + case)
     k = max(1, n // 10)
     with torch.no_grad():  # hostile rows
@@ -49,7 +57,8 @@ for case in range(n_cases):
     ins0 = [t.clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, colors)]
     ins1 = [t.detach().to(dev).requires_grad_(True) for t in ins0]
     kw = dict(sh_degree=deg, render_mode=mode, packed=packed, absgrad=True, rasterize_mode=rmode)
-    r0, a0, i0 = O.rasterization(*ins0, sc.viewmats[v : v + 1], sc.Ks[v : v + 1], W, H, **kw)
+    r0, a0, i0 = O.rasterization(*ins0, sc.viewmats[v : v + 1], sc.Ks[v : v + 1], W, H,
+                                 **(dict(kw, compositor=CO.composite) if use_c else kw))
     r1, a1, i1 = rasterization(*ins1, sc.viewmats[v : v + 1].to(dev), sc.Ks[v : v + 1].to(dev), W, H, **kw)
     ok = r1.shape == r0.shape and a1.shape == a0.shape
     ok = ok and torch.equal(i1["radii"].cpu(), i0["radii"]) and torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
