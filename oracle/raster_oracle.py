@@ -22,13 +22,16 @@ the constants the reference's call sites do state:
 * wxyz quaternion order            ``freegaussian/utils.py:287-290``
 * render modes RGB / RGB+ED / ED   ``freegaussian_model.py:821-824``, ``preprocess/knn_gaussian.py:108``
 
-BACKWARD.  Gradients of this module are torch autograd of its forward: every T_i is the exact
-running product.  gsplat's hand-written backward -- what the C restatement (``fg_oracle.c``, reachable
-through ``rasterization(compositor=c_oracle.composite)``) and the HIP kernels follow -- instead starts
-each pixel from ``T_final = 1 - alpha_out`` (rounded at ulp(1): 6e-4 relative on a saturated pixel) and
-rebuilds the T_i from it.  The two differ by ~1e-4 relative L2 on deep lists (1M Gaussians: 1.4e-4); the
-parity bar for gradients is therefore held against the C compositor (tests at 8160 tiles, the whole-frame
-leg of bench.py: 1-2e-5), this module's own backward serves the small cases and the timing leg.
+BACKWARD.  One semantics everywhere: the compositing stage is an autograd node (``_CompositeRef``) whose
+backward is the analytic restatement ``rasterize_backward(..., alpha_out=...)`` in the REFERENCE's order --
+gsplat's hand-written backward starts each pixel from ``T_final = 1 - alpha_out`` (a value rounded at
+ulp(1): 6e-4 relative on a saturated pixel) and rebuilds every T_i from it by multiplying with
+``1 / (1 - alpha_i)`` on the way back; every T-dependent term carries that rounding.  ``fg_oracle.c`` and
+the HIP kernels do the same, so all three are held to the same 1e-4 bar.  ``rasterization(...,
+backward="autograd")`` keeps the plain autograd of the forward (exact running products T_i) as the
+cross-check of the algebra (fp64: 1e-10 against the analytic form with exact T); on deep lists the two
+semantics differ by ~1e-4 relative L2 in fp32 (1M Gaussians: 1.4e-4), which is why parity is NOT judged
+against the autograd form.
 
 Everything is plain PyTorch on CPU.  The projection is written component-by-component with
 a fixed operation order and only IEEE-exact operations (+ - * / sqrt), so that a GPU kernel
@@ -393,11 +396,20 @@ def rasterize(
 
 
 def rasterize_backward(
-    means2d, conics, colors, opacities, width, height, tile_size, offsets, flatten_ids, v_render, v_alpha
+    means2d, conics, colors, opacities, width, height, tile_size, offsets, flatten_ids, v_render, v_alpha,
+    alpha_out=None,
 ):
     """K6 restated analytically (not via autograd) so that ``absgrad`` -- the sum over pixels
     of |dL/d means2d| that ``freegaussian_model.py:377`` reads from ``means2d.absgrad`` -- is
-    defined.  Returns (v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities)."""
+    defined.  Returns (v_means2d, v_means2d_abs, v_conics, v_colors, v_opacities).
+
+    ``alpha_out`` [H,W] or [H,W,1] = the forward's alpha image: the REFERENCE's backward semantics (the
+    autograd of the call at ``freegaussian_model.py:847-868``): each pixel starts from
+    ``T_final = 1 - alpha_out`` and T_i is rebuilt walking back, ``T *= 1 / (1 - alpha_i)``, exactly the
+    order of ``fg_oracle.c::fgo_raster_bwd``.  Without it the exact forward products are used (the
+    algebra's own cross-check)."""
+    if alpha_out is not None:
+        alpha_out = alpha_out.reshape(height, width)
     N, C = colors.shape
     dt = colors.dtype
     tile_w = (width + tile_size - 1) // tile_size
@@ -422,8 +434,15 @@ def rasterize_backward(
         dx, dy, sigma, alpha, valid = _tile_terms(px, py, xy, con, op)
         a, T_excl, include, stopped = _composite_state(alpha, valid)
         inc = include.to(dt)
+        if alpha_out is None:
+            T_final = torch.where(include, 1.0 - a, torch.ones_like(a)).prod(dim=1)  # [P]
+        else:
+            # reference order: T = 1 - alpha_out;  for i = last .. first:  T *= 1 / (1 - alpha_i)
+            T_final = 1.0 - alpha_out[y0:y1, x0:x1].reshape(-1).to(dt)
+            r_inc = torch.where(include, 1.0 / (1.0 - a), torch.ones_like(a))
+            seq = torch.cat([T_final[:, None], torch.flip(r_inc, [1])], 1)
+            T_excl = torch.flip(torch.cumprod(seq, 1)[:, 1:], [1])  # T in front of entry i
         fac = a * T_excl * inc  # [P,L]
-        T_final = torch.where(include, 1.0 - a, torch.ones_like(a)).prod(dim=1)  # [P]
         vr = v_render[y0:y1, x0:x1].reshape(-1, C)  # [P,C]
         va = v_alpha[y0:y1, x0:x1].reshape(-1)  # [P]
         # colour gradient
@@ -470,6 +489,38 @@ class _AbsgradTap(torch.autograd.Function):
         return v_render, v_alpha, None
 
 
+class _CompositeRef(torch.autograd.Function):
+    """K5 + K6 as ONE autograd node with the reference's backward semantics (``rasterize_backward`` with
+    ``alpha_out``): what ``rasterization`` uses by default.  Also defines ``means2d.absgrad``."""
+
+    @staticmethod
+    def forward(ctx, means2d, conics, feats, opac, geom, offsets, flatten_ids, holder):
+        width, height, tile_size = geom
+        with torch.no_grad():
+            render, alpha, last_ids = rasterize(means2d, conics, feats, opac, width, height, tile_size, offsets,
+                                                flatten_ids)  # fmt: skip
+        ctx.save_for_backward(means2d, conics, feats, opac, offsets, flatten_ids, alpha)
+        ctx.geom, ctx.holder = geom, holder
+        ctx.mark_non_differentiable(last_ids)
+        return render, alpha, last_ids
+
+    @staticmethod
+    def backward(ctx, v_render, v_alpha, _v_last):
+        means2d, conics, feats, opac, offsets, flatten_ids, alpha = ctx.saved_tensors
+        width, height, tile_size = ctx.geom
+        if v_render is None:
+            v_render = torch.zeros(height, width, feats.shape[1], dtype=feats.dtype)
+        if v_alpha is None:
+            v_alpha = torch.zeros(height, width, 1, dtype=feats.dtype)
+        with torch.no_grad():
+            v_xy, v_abs, v_conic, v_col, v_op = rasterize_backward(
+                means2d, conics, feats, opac, width, height, tile_size, offsets, flatten_ids, v_render,
+                v_alpha[..., 0], alpha_out=alpha)  # fmt: skip
+        if ctx.holder is not None:
+            ctx.holder.absgrad = v_abs[None]
+        return v_xy, v_conic, v_col, v_op, None, None, None, None
+
+
 @dataclass
 class RasterResult:
     render: torch.Tensor  # [1,H,W,C]
@@ -500,6 +551,7 @@ def rasterization(
     eps2d: float = EPS2D,
     extra_channels: Optional[torch.Tensor] = None,
     compositor=None,
+    backward: str = "reference",
 ):
     """The whole K0 boundary on CPU for one camera, differentiable by autograd.
 
@@ -507,7 +559,11 @@ def rasterization(
     channels (used for the flow channels F1).  ``compositor``: another implementation of the K5/K6
     stage, ``f(means2d, conics, feats, opac, W, H, tile, offsets, flatten_ids, absgrad_holder) ->
     (render, alpha, last_ids)`` -- ``c_oracle.composite`` plugs the scalar C restatement in, which
-    makes full-resolution oracle runs affordable (the torch compositing costs ~10 ms per tile)."""
+    makes full-resolution oracle runs affordable (the torch compositing costs ~10 ms per tile).
+    ``backward``: "reference" (default; T rebuilt from ``1 - alpha_out``, see the module header) or
+    "autograd" (plain autograd of the forward, the exact-T cross-check; only without ``compositor``)."""
+    if backward not in ("reference", "autograd"):
+        raise ValueError(f"Unknown backward: {backward}")
     if rasterize_mode not in ("classic", "antialiased"):
         raise ValueError(f"Unknown rasterize_mode: {rasterize_mode}")
     if render_mode not in ("RGB", "D", "ED", "RGB+D", "RGB+ED"):
@@ -552,11 +608,15 @@ def rasterization(
         render, alpha, last_ids = compositor(
             m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids, means2d_out if absgrad else None
         )
+    elif backward == "reference":
+        render, alpha, last_ids = _CompositeRef.apply(
+            m2, proj.conics, feats, opac, (int(width), int(height), int(tile_size)), offsets, flatten_ids,
+            means2d_out if absgrad else None)  # fmt: skip
     else:
         render, alpha, last_ids = rasterize(
             m2, proj.conics, feats, opac, width, height, tile_size, offsets, flatten_ids
         )
-    if compositor is None and absgrad and torch.is_grad_enabled() and render.requires_grad:
+    if compositor is None and backward == "autograd" and absgrad and torch.is_grad_enabled() and render.requires_grad:
         args = tuple(t.detach() for t in (proj.means2d, proj.conics, feats, opac)) + (
             width, height, tile_size, offsets, flatten_ids)  # fmt: skip
         render, alpha = _AbsgradTap.apply(render, alpha, {"args": args, "holder": means2d_out})

@@ -7,7 +7,7 @@ mkdir -p $out
 export TMPDIR=/tmp
 nproc > $out/host.txt; grep -m1 "model name" /proc/cpuinfo >> $out/host.txt; free -g | head -2 >> $out/host.txt
 if [ "$2" != "skip-tests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --timeout 600 --durations=12 2>&1 | tail -60 > $out/pytest.log
+  FG_PARITY_REPORT=$out/parity_margins.jsonl timeout 1500 python -m pytest tests -m gpu -q --timeout 600 --durations=12 2>&1 | tail -120 > $out/pytest.log
   timeout 200 python __graft_entry__.py smoke 2>&1 | tail -2 > $out/smoke.log
 fi
 timeout 900 python bench.py > $out/bench.json 2> $out/bench.err; echo "rc=$?" >> $out/bench.err

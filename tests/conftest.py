@@ -28,3 +28,23 @@ def _built_library():
 
         g.build()
     yield
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """FG_PARITY_REPORT=<file>: the measured value of every parity comparison of the session, worst per
+    (test, line), as JSON lines."""
+    path = os.environ.get("FG_PARITY_REPORT")
+    if not path:
+        return
+    import json
+
+    import helpers
+
+    worst = {}
+    for test, where, kind, value in helpers.RECORDS:
+        key = (test, where, kind)
+        worst[key] = max(worst.get(key, float("-inf")), value)
+    os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+    with open(path, "w") as f:
+        for (test, where, kind), value in sorted(worst.items()):
+            f.write(json.dumps({"test": test, "at": where, "kind": kind, "value": value}) + "\n")

@@ -1,19 +1,47 @@
-"""Shared comparison helpers for the parity tests."""
+"""Shared comparison helpers for the parity tests.
+
+Every comparison made through this module is also RECORDED (test id, source line, measured value) and,
+when ``FG_PARITY_REPORT`` names a file, written there at session end (``conftest.py``): the margins the
+suite actually has against the bar, not just pass / fail (``profiles/r03_parity_margins.md``)."""
+import os
+import sys
+
 import torch
 
 # Floating-point tolerance of the parity bar (BASELINE.json north_star: "within 1e-4 rel fp32").
 REL_TOL = 1e-4
 
+# Knife-edge pixels (see close_except_knife_edge): the bound on their share of an image.  Set from the
+# observed counts of the GPU suite (profiles/r03_parity_margins.md: worst case 5.3e-5 of the pixels of a
+# 1080p frame); a pixel that flips differs by at most one skipped splat, alpha < 1/255 times its colour.
+KNIFE_EDGE_MAX_FRAC = 2e-4
+
+RECORDS = []  # (test id, "file:line", kind, value)
+
+
+def _record(kind: str, value: float, depth: int = 2) -> None:
+    f = sys._getframe(depth)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "").split(" ")[0]
+    RECORDS.append((test, f"{os.path.basename(f.f_code.co_filename)}:{f.f_lineno}", kind, float(value)))
+
 
 def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
     """max |a-b| / max |b|  (scale-relative max error)."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    v = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    _record("rel_err", v)
+    return v
+
+
+def _rel_l2(a, b) -> float:
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return ((a - b).norm() / max(b.norm().item(), 1e-30)).item()
 
 
 def rel_l2(a: torch.Tensor, b: torch.Tensor) -> float:
-    a, b = a.detach().double().cpu(), b.detach().double().cpu()
-    return ((a - b).norm() / max(b.norm().item(), 1e-30)).item()
+    v = _rel_l2(a, b)
+    _record("rel_l2", v)
+    return v
 
 
 def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
@@ -21,16 +49,26 @@ def psnr(a: torch.Tensor, b: torch.Tensor) -> float:
     return float("inf") if mse == 0 else -10.0 * torch.log10(torch.tensor(mse)).item()
 
 
-def close_except_knife_edge(a: torch.Tensor, b: torch.Tensor, tol: float = REL_TOL, max_frac: float = 1e-3) -> bool:
+def close_except_knife_edge(a: torch.Tensor, b: torch.Tensor, tol: float = REL_TOL,
+                            max_frac: float = KNIFE_EDGE_MAX_FRAC) -> bool:  # fmt: skip
     """Images agree within `tol` (scale-relative) except on a vanishing fraction of pixels.
 
     A pixel whose alpha for some splat lies within rounding of the 1/255 skip threshold (or whose
     transmittance lies within rounding of the 1e-4 stop) legitimately takes the other branch under
     a different exp() implementation: the pixel then differs by up to ~1/255 * colour.  At the
     deep lists of the full-size scene (hundreds of evaluations per pixel) a handful of such
-    pixels per image is expected; they are bounded in number and in size here."""
+    pixels per image is expected; they are bounded in number (`max_frac`, set from the observed
+    counts) and in size (one skipped splat: 2/255 of the scale) here, and the relative L2 over the
+    whole image -- flipped pixels included -- must still meet `tol`.  The observed count is recorded."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     scale = max(b.abs().max().item(), 1e-12)
     err = (a - b).abs() / scale
-    frac_bad = (err.reshape(-1, err.shape[-1]).max(dim=-1).values > tol).double().mean().item()
-    return frac_bad <= max_frac and err.max().item() <= 2.0 / 255.0 and rel_l2(a, b) <= 10 * tol
+    per_pixel = err.reshape(-1, err.shape[-1]).max(dim=-1).values
+    n_bad = int((per_pixel > tol).sum().item())
+    frac_bad = n_bad / max(per_pixel.numel(), 1)
+    l2 = _rel_l2(a, b)
+    _record("knife_edge_pixels", n_bad)
+    _record("knife_edge_frac", frac_bad)
+    _record("knife_edge_max_err", err.max().item() if err.numel() else 0.0)
+    _record("knife_edge_rel_l2", l2)
+    return frac_bad <= max_frac and (err.numel() == 0 or err.max().item() <= 2.0 / 255.0) and l2 <= tol

@@ -226,7 +226,7 @@ def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
     campos = torch.linalg.inv(vm)[:3, 3]
     rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
     rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
-    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
+    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, REL_TOL)
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
@@ -399,7 +399,8 @@ def test_raster_forward_backward_vs_oracle(channels, ppt, monkeypatch):
     r_ref, a_ref, last_ref = O.rasterize(ref.means2d, ref.conics, feats, sc.opacities, W, H, 16, offs, vals)
     g = torch.Generator().manual_seed(5)
     vr, va = torch.randn(H, W, channels, generator=g), torch.randn(H, W, 1, generator=g)
-    gref = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, W, H, 16, offs, vals, vr, va[..., 0])
+    gref = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, W, H, 16, offs, vals, vr, va[..., 0],
+                                alpha_out=a_ref)  # fmt: skip
 
     m2 = ref.means2d.to(DEV).requires_grad_(True)
     con = ref.conics.to(DEV).requires_grad_(True)
@@ -414,7 +415,7 @@ def test_raster_forward_backward_vs_oracle(channels, ppt, monkeypatch):
     for name, x, y in [("means2d", m2.grad, gref[0]), ("absgrad", m2.absgrad, gref[1]), ("conics", con.grad, gref[2]),
                        ("features", ft.grad, gref[3]), ("opacities", op.grad, gref[4])]:  # fmt: skip
         assert rel_l2(x, y) < REL_TOL, name
-        assert rel_err(x, y) < 10 * REL_TOL, name
+        assert rel_err(x, y) < REL_TOL, name
 
 
 def test_raster_dense_stack_hits_transmittance_stop():
@@ -433,14 +434,14 @@ def test_raster_dense_stack_hits_transmittance_stop():
     r_ref, a_ref, last_ref = O.rasterize(m2, conics, feats, op, W, H, 16, offs, vals)
     assert (a_ref > 1 - 1.5e-4).float().mean() > 0.5  # the stop rule is what ends most pixels
     vr, va = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g)
-    gref = O.rasterize_backward(m2, conics, feats, op, W, H, 16, offs, vals, vr, va[..., 0])
+    gref = O.rasterize_backward(m2, conics, feats, op, W, H, 16, offs, vals, vr, va[..., 0], alpha_out=a_ref)
     t = [x.to(DEV).requires_grad_(True) for x in (m2, conics, feats, op)]
     r, a, last = ops.rasterize_to_pixels(*t, W, H, 16, offs.to(DEV), vals.to(DEV), absgrad=True)
     ((r * vr.to(DEV)).sum() + (a * va.to(DEV)).sum()).backward()
     assert rel_err(r, r_ref) < REL_TOL and rel_err(a, a_ref) < REL_TOL
     assert (last.cpu() != last_ref).float().mean().item() < 1e-3
     for x, y in zip([t[0].grad, t[0].absgrad, t[1].grad, t[2].grad, t[3].grad], gref):
-        assert rel_l2(x, y) < 2 * REL_TOL
+        assert rel_l2(x, y) < REL_TOL
 
 
 # ------------------------------------------------------------------------------------------
@@ -490,11 +491,11 @@ def test_full_pipeline_modes(render_mode, sh_degree, rmode):
     assert torch.equal(i1["isect_ids"].cpu(), i0["isect_ids"])
     assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
     assert r1.shape == r0.shape and a1.shape == a0.shape
-    assert rel_err(r1, r0) < 3 * REL_TOL and rel_err(a1, a0) < REL_TOL
+    assert rel_err(r1, r0) < REL_TOL and rel_err(a1, a0) < REL_TOL
     for k in ref_in:
         if ref_in[k].grad is None:
             continue
-        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < REL_TOL, k
 
 
 def test_packed_mode_info():
@@ -511,7 +512,7 @@ def test_packed_mode_info():
     assert torch.equal(i1["gaussian_ids"].cpu(), i0["gaussian_ids"])
     assert i1["means2d"].shape == (i0["gaussian_ids"].numel(), 2)
     assert torch.equal(i1["means2d"].cpu(), i0["means2d"]) and torch.equal(i1["depths"].cpu(), i0["depths"])
-    assert rel_err(r1, r0) < 3 * REL_TOL
+    assert rel_err(r1, r0) < REL_TOL
 
 
 def test_backward_is_repeatable_within_tolerance():
@@ -595,14 +596,14 @@ def test_composited_flow_channels_f1():
     disp = torch.randn(6000, 2, generator=g)
     ref_in, gpu_in, (r0, a0, i0), (r1, a1, i1) = _run_both(sc, 0, "RGB+ED", 3, extra=disp)
     assert r1.shape[-1] == 6
-    assert rel_err(r1[..., 4:], r0[..., 4:]) < 3 * REL_TOL
+    assert rel_err(r1[..., 4:], r0[..., 4:]) < REL_TOL
     for k in ref_in:
-        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < REL_TOL, k
 
 
 # ------------------------------------------------------------------------------------------
 # H1-H4, O1, S1: the host mirror of FreeGaussianModel.get_outputs around the HIP raster
-def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True):
+def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True, log_scale=-3.2):
     import copy
 
     from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelConfig
@@ -612,7 +613,7 @@ def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True):
     cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=3000)
     model = FreeGaussianModel(cfg, seed_points=(torch.rand(n, 3) - 0.5) * 2.0)
     with torch.no_grad():
-        model.gauss_params["scales"].fill_(-3.2)
+        model.gauss_params["scales"].fill_(log_scale)
         model.gauss_params["features_rest"].normal_(0, 0.1)
         for p in model.deform.parameters():
             p.mul_(0.3)
@@ -651,13 +652,13 @@ def test_model_get_outputs_training_step_matches_oracle():
     out = model.get_outputs(cam)
     rgb0, acc0, _, info0 = _oracle_outputs(ref, cam, "RGB")
     assert out["depth"] is None and out["rgb"].shape == (cam.height, cam.width, 3)
-    assert rel_err(out["rgb"], rgb0) < 3 * REL_TOL and rel_err(out["accumulation"], acc0) < 3 * REL_TOL
+    assert rel_err(out["rgb"], rgb0) < REL_TOL and rel_err(out["accumulation"], acc0) < REL_TOL
     assert torch.equal(model.radii.cpu(), info0["radii"][0])
     gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(3))
     (out["rgb"] - gt.to(DEV)).abs().mean().backward()
     (rgb0 - gt).abs().mean().backward()
     for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
-        assert rel_l2(model.gauss_params[k].grad, ref.gauss_params[k].grad) < 5 * REL_TOL, k
+        assert rel_l2(model.gauss_params[k].grad, ref.gauss_params[k].grad) < REL_TOL, k
     gd = torch.cat([p.grad.flatten() for p in model.deform.parameters()])
     gd0 = torch.cat([p.grad.flatten() for p in ref.deform.parameters()])
     assert rel_l2(gd, gd0) < 2e-3  # GEMM chains in different orders on CPU/GPU
@@ -678,7 +679,7 @@ def test_model_get_outputs_eval_depth_and_background():
         rgb0, acc0, r0, _ = _oracle_outputs(ref, cam, "RGB+ED")
     d0 = torch.where(acc0 > 0, r0[0, ..., 3:4], r0[0, ..., 3:4].max())
     assert out["depth"].shape == (cam.height, cam.width, 1) and out["background"].shape == (cam.height, cam.width, 3)
-    assert rel_err(out["rgb"], rgb0) < 3 * REL_TOL and rel_err(out["depth"], d0) < 3 * REL_TOL
+    assert rel_err(out["rgb"], rgb0) < REL_TOL and rel_err(out["depth"], d0) < REL_TOL
 
 
 def test_crop_box_render_equals_rendering_the_subset():
@@ -852,7 +853,7 @@ def test_full_size_cfg4_properties_and_oracle_crop():
     campos = torch.linalg.inv(sc.viewmats[0])[:3, 3]
     rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
     rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
-    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
+    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, REL_TOL)
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
@@ -888,7 +889,7 @@ def _assert_full_parity(ref_in, gpu_in, o0, o1, tol):
     assert torch.equal(i1["radii"].cpu(), i0["radii"])
     assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
     assert torch.equal(i1["isect_offsets"].cpu().reshape(-1), i0["isect_offsets"].reshape(-1))
-    assert close_except_knife_edge(r1[0], r0[0], 3 * REL_TOL) and close_except_knife_edge(a1[0], a0[0], REL_TOL)
+    assert close_except_knife_edge(r1[0], r0[0], REL_TOL) and close_except_knife_edge(a1[0], a0[0], REL_TOL)
     worst = {}
     for k in ref_in:
         worst[k] = rel_l2(gpu_in[k].grad, ref_in[k].grad)
@@ -916,7 +917,7 @@ def test_1080p_mixed_launch_forward_and_all_gradients_vs_oracle(layout, render_m
         offs = o0[2]["isect_offsets"].reshape(-1)
         lens = torch.diff(offs)
         assert int(lens.max()) > 20 * int(offs[-1]) // 65536  # some tiles are above the four-strip threshold
-    _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+    _assert_full_parity(ref_in, gpu_in, o0, o1, REL_TOL)
 
 
 @pytest.mark.parametrize("parts,layout,bg", [(2, "uniform", False), (4, "clustered", False), (3, "uniform", True), (16, "clustered", True)])
@@ -935,7 +936,7 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
     if not bg:
         monkeypatch.setenv("FG_RASTER_SEG_PARTS", str(parts))
         ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 1, "RGB", 3)
-        worst = _assert_full_parity(ref_in, gpu_in, o0, o1, 3 * REL_TOL)
+        worst = _assert_full_parity(ref_in, gpu_in, o0, o1, REL_TOL)
         seg_grads = {k: v.grad.clone() for k, v in gpu_in.items()}
         monkeypatch.setenv("FG_RASTER_SEG_PARTS", "1")
         _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
@@ -1025,7 +1026,7 @@ def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monk
     campos = torch.linalg.inv(sc.viewmats[0])[:3, 3]
     rgb = torch.clamp_min(O.sh_eval(3, sc.means - campos, sc.colors) + 0.5, 0.0)
     rc, ac, _ = CO.raster_fwd(m2, info["conics"][0].cpu(), rgb, sc.opacities, cw, ch, 16, coffs, cv)
-    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, 3 * REL_TOL)
+    assert close_except_knife_edge(r[0, y0 : y0 + ch, x0 : x0 + cw], rc, REL_TOL)
     assert close_except_knife_edge(a[0, y0 : y0 + ch, x0 : x0 + cw], ac, REL_TOL)
 
 
@@ -1039,9 +1040,9 @@ def test_cfg2_conerf_like_300k_psnr_and_gradients():
     assert torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
     assert torch.equal(i1["isect_offsets"].cpu(), i0["isect_offsets"])
     assert psnr(r1, r0) >= 60.0
-    assert close_except_knife_edge(r1, r0, 3 * REL_TOL) and close_except_knife_edge(a1, a0, REL_TOL)
+    assert close_except_knife_edge(r1, r0, REL_TOL) and close_except_knife_edge(a1, a0, REL_TOL)
     for k in ref_in:
-        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < 3 * REL_TOL, k
+        assert rel_l2(gpu_in[k].grad, ref_in[k].grad) < REL_TOL, k
 
 
 @pytest.mark.parametrize("N,W,H", [(60_000, 480, 270), (300_000, 960, 540)])
@@ -1088,11 +1089,11 @@ def test_cfg3_flow_derivative_scene(N, W, H):
     loss1 = FL.flow_loss(out["flow_gs"], target.to(DEV)) + out["render"][..., :3].mean()
     loss1.backward()
     assert out["flow_gs"].shape == (1, H, W, 2) and out["render"].shape == (1, H, W, 4)
-    assert close_except_knife_edge(out["flow_gs"], r0[..., 4:], 3 * REL_TOL)
-    assert close_except_knife_edge(out["render"], r0[..., :4], 3 * REL_TOL)
+    assert close_except_knife_edge(out["flow_gs"], r0[..., 4:], REL_TOL)
+    assert close_except_knife_edge(out["render"], r0[..., :4], REL_TOL)
     assert abs(loss1.item() - loss0.item()) < 1e-5
     for a, b, name in zip(gpu, ref, ["means_t", "means_0", "quats", "scales", "opacities", "colors"]):
-        assert rel_l2(a.grad, b.grad) < 5 * REL_TOL, name
+        assert rel_l2(a.grad, b.grad) < REL_TOL, name
 
     # F2 + camera flow map with the (v, w) of this camera pair
     c2w_t, c2w_0 = torch.linalg.inv(vm_t[0]), torch.linalg.inv(vm_0[0])
@@ -1113,12 +1114,13 @@ def test_cfg3_flow_derivative_scene(N, W, H):
     assert rel_err(ug1, ug0) < REL_TOL and rel_err(uc1, uc0) < REL_TOL
 
 
-@pytest.mark.parametrize("n,W,H", [(6000, 160, 96), (50_000, 1920, 1080)])
+@pytest.mark.parametrize("n,W,H", [(6000, 160, 96), (50_000, 1920, 1080), (1_000_000, 1920, 1080)])
 def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     """configs[4] 'freegaussian-control stage-2': frozen deform -> per-attribute mean displacement
     -> control MLP -> deltas scattered into the masked Gaussians -> the same raster call.
-    Second case: 1920x1080 = 8160 tiles ("as cfg4") -- the mixed / job-list
-    launches under the stage-2 front end, 5% of the rows masked; oracle with the C compositing."""
+    Second case: 1920x1080 = 8160 tiles -- the mixed / job-list launches under the stage-2 front end, 5% of
+    the rows masked; oracle with the C compositing.  Third case: SURVEY.md section 8d's stated size ("as
+    cfg4": 1M Gaussians at 1920x1080)."""
     import copy
 
     from freegaussian_amd.model import FreeGaussianControlModel, FreeGaussianModelConfig
@@ -1126,7 +1128,7 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     from oracle import c_oracle as CO
 
     compositor = CO.composite if W * H > 10**6 else None
-    _, base, cam = _model_and_camera(n=n, W=W, H=H, training=True)
+    _, base, cam = _model_and_camera(n=n, W=W, H=H, training=True, log_scale=-3.2 if n < 10**6 else -5.0)
     N = base.num_points
     mask = torch.zeros(N, 3, dtype=torch.bool)
     mask[: N // 20, 0] = True  # 5% of the rows set (cfg5), overlapping attributes
@@ -1166,14 +1168,14 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
                                 cam.height, sh_degree=deg, render_mode="RGB", packed=False, compositor=compositor)  # fmt: skip
     rgb0 = torch.clamp(r0[..., :3] + (1 - a0) * torch.zeros(3), 0.0, 1.0).squeeze(0)
     assert deg == 3 and cm.step == 30000
-    assert close_except_knife_edge(out["rgb"], rgb0, 3 * REL_TOL)
+    assert close_except_knife_edge(out["rgb"], rgb0, REL_TOL)
     gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(9))
     (out["rgb"] - gt.to(DEV)).abs().mean().backward()
     (rgb0 - gt).abs().mean().backward()
     gc = torch.cat([p.grad.flatten() for p in cm.control.parameters()])
     gc0 = torch.cat([p.grad.flatten() for p in cm_cpu.control.parameters()])
     assert rel_l2(gc, gc0) < 2e-3
-    assert rel_l2(cm.gauss_params["means"].grad, cm_cpu.gauss_params["means"].grad) < 5 * REL_TOL
+    assert rel_l2(cm.gauss_params["means"].grad, cm_cpu.gauss_params["means"].grad) < REL_TOL
     assert all(p.grad is None for p in cm.deform.parameters())  # frozen (evaluated under no_grad)
 
 
@@ -1217,9 +1219,9 @@ def test_edge_cases_zero_gaussians_and_short_sh_tables():
         g = torch.randn(r0.shape, generator=torch.Generator().manual_seed(deg))
         (r0 * g).sum().backward()
         (r1 * g.to(DEV)).sum().backward()
-        assert close_except_knife_edge(r1, r0, 3 * REL_TOL)
-        assert gpu[4].grad.shape == (4000, K, 3) and rel_l2(gpu[4].grad, ref[4].grad) < 3 * REL_TOL
-        assert rel_l2(gpu[0].grad, ref[0].grad) < 3 * REL_TOL
+        assert close_except_knife_edge(r1, r0, REL_TOL)
+        assert gpu[4].grad.shape == (4000, K, 3) and rel_l2(gpu[4].grad, ref[4].grad) < REL_TOL
+        assert rel_l2(gpu[0].grad, ref[0].grad) < REL_TOL
     with pytest.raises(ValueError):
         rasterization(*[t.to(DEV) for t in cpu[:4]], torch.rand(4000, 9, device=DEV), sc.viewmats[:1].to(DEV),
                       sc.Ks[:1].to(DEV), 96, 64, sh_degree=None, packed=False)  # 9 channels > 8

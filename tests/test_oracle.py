@@ -56,10 +56,63 @@ def test_raster_forward_backward_between_oracles():
     assert (l0 != l1).float().mean().item() < 1e-3
     g = torch.Generator().manual_seed(1)
     vr, va = torch.randn(100, 150, 4, generator=g), torch.randn(100, 150, 1, generator=g)
-    g0 = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals, vr, va[..., 0])
+    g0 = O.rasterize_backward(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals, vr, va[..., 0],
+                              alpha_out=a0)  # fmt: skip
     g1 = CO.raster_bwd(ref.means2d, ref.conics, feats, sc.opacities, 150, 100, 16, offs, vals, a1, l1, vr, va)
     for x, y in zip(g1, g0):
-        assert rel_l2(x, y) < REL_TOL
+        assert rel_l2(x, y) < 0.2 * REL_TOL  # same semantics (T rebuilt from 1 - alpha_out): rounding only
+
+
+def test_reference_backward_semantics_torch_vs_c_on_deep_lists():
+    """Opaque stacks (most pixels end on the T <= 1e-4 stop, alpha_out within a few ulp of 1): the regime
+    where ``T_final = 1 - alpha_out`` is a coarsely rounded number.  The torch oracle's default backward and
+    the C compositor follow the same (reference) order and must agree to rounding; the exact-T autograd form
+    is measurably further from both -- the reason parity is judged against the reference form."""
+    g = torch.Generator().manual_seed(11)
+    N, W, H = 600, 64, 48
+    m2 = torch.rand(N, 2, generator=g) * torch.tensor([W, H])
+    conics = torch.tensor([[0.02, 0.0, 0.02]]).repeat(N, 1)
+    op = torch.full((N,), 0.9)
+    radii = torch.full((N,), 40, dtype=torch.int32)
+    feats = torch.rand(N, 3, generator=g)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    _, keys, vals = O.isect_tiles(m2, radii, torch.rand(N, generator=g) + 1, 16, tw, th)
+    offs = O.isect_offsets(keys, tw * th)
+    vr, va = torch.randn(H, W, 3, generator=g), torch.randn(H, W, 1, generator=g)
+    r, a, last = O.rasterize(m2, conics, feats, op, W, H, 16, offs, vals)
+    assert (a > 1 - 1.5e-4).float().mean() > 0.5
+    g_ref = O.rasterize_backward(m2, conics, feats, op, W, H, 16, offs, vals, vr, va[..., 0], alpha_out=a)
+    g_exact = O.rasterize_backward(m2, conics, feats, op, W, H, 16, offs, vals, vr, va[..., 0])
+    rc, ac, lc = CO.raster_fwd(m2, conics, feats, op, W, H, 16, offs, vals)
+    g_c = CO.raster_bwd(m2, conics, feats, op, W, H, 16, offs, vals, ac, lc, vr, va)
+    worst_same = max(rel_l2(x, y) for x, y in zip(g_c, g_ref))
+    worst_other = max(rel_l2(x, y) for x, y in zip(g_c, g_exact))
+    assert worst_same < 0.2 * REL_TOL, worst_same
+    assert worst_other > 2 * worst_same, (worst_other, worst_same)
+
+
+def test_rasterization_default_backward_is_the_reference_form_and_autograd_is_the_cross_check():
+    sc = synthetic_scene(3000, 96, 64, seed=2)
+    outs = {}
+    for mode in ("reference", "autograd", "c"):
+        t = [x.clone().requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        kw = dict(sh_degree=3, absgrad=True, render_mode="RGB+ED")
+        if mode == "c":
+            kw["compositor"] = CO.composite
+        else:
+            kw["backward"] = mode
+        r, a, info = O.rasterization(*t, sc.viewmats[:1], sc.Ks[:1], 96, 64, **kw)
+        info["means2d"].retain_grad()
+        gen = torch.Generator().manual_seed(0)
+        ((r * torch.randn(r.shape, generator=gen)).sum() + (a * torch.randn(a.shape, generator=gen)).sum()).backward()
+        outs[mode] = [x.grad for x in t] + [info["means2d"].grad, info["means2d"].absgrad]
+    for x, y in zip(outs["reference"], outs["c"]):
+        assert rel_l2(x, y) < 0.2 * REL_TOL
+    for x, y in zip(outs["reference"], outs["autograd"]):
+        assert rel_l2(x, y) < REL_TOL  # shallow lists: the two semantics are close
+    with pytest.raises(ValueError):
+        O.rasterization(sc.means, sc.quats, sc.scales, sc.opacities, sc.colors, sc.viewmats[:1], sc.Ks[:1], 96, 64,
+                        sh_degree=3, backward="exact")
 
 
 def test_analytic_backward_equals_autograd_fp64():
