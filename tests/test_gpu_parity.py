@@ -17,6 +17,15 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 
 
+def _smooth_loss(rgb, gt):
+    """Mean squared error instead of the reference's L1 (freegaussian_model.py:951): L1's sign() is
+    discontinuous, so a pixel within rounding of its target hands the two implementations OPPOSITE upstream
+    gradients for that pixel (measured at 1M Gaussians / 1080p: a dozen such pixels move the parameter
+    gradients by 3e-4) -- a property of the loss, not of the kernels under test.  The harness trains with L1."""
+    return ((rgb - gt) ** 2).mean()
+
+
+
 @pytest.fixture(scope="module", autouse=True)
 def _need_gpu():
     if not torch.cuda.is_available():
@@ -655,8 +664,8 @@ def test_model_get_outputs_training_step_matches_oracle():
     assert rel_err(out["rgb"], rgb0) < REL_TOL and rel_err(out["accumulation"], acc0) < REL_TOL
     assert torch.equal(model.radii.cpu(), info0["radii"][0])
     gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(3))
-    (out["rgb"] - gt.to(DEV)).abs().mean().backward()
-    (rgb0 - gt).abs().mean().backward()
+    _smooth_loss(out["rgb"], gt.to(DEV)).backward()
+    _smooth_loss(rgb0, gt).backward()
     for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities"):
         assert rel_l2(model.gauss_params[k].grad, ref.gauss_params[k].grad) < REL_TOL, k
     gd = torch.cat([p.grad.flatten() for p in model.deform.parameters()])
@@ -1170,8 +1179,8 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     assert deg == 3 and cm.step == 30000
     assert close_except_knife_edge(out["rgb"], rgb0, REL_TOL)
     gt = torch.rand(cam.height, cam.width, 3, generator=torch.Generator().manual_seed(9))
-    (out["rgb"] - gt.to(DEV)).abs().mean().backward()
-    (rgb0 - gt).abs().mean().backward()
+    _smooth_loss(out["rgb"], gt.to(DEV)).backward()
+    _smooth_loss(rgb0, gt).backward()
     gc = torch.cat([p.grad.flatten() for p in cm.control.parameters()])
     gc0 = torch.cat([p.grad.flatten() for p in cm_cpu.control.parameters()])
     assert rel_l2(gc, gc0) < 2e-3
