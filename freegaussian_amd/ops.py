@@ -289,6 +289,10 @@ def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
 # gradients, ~30% fewer list entries on the 1M / 1080p scene.  The reference-exact lists
 # (info["flatten_ids"] etc.) are rebuilt on demand from the radius boxes.
 tight_rects = os.environ.get("FG_TIGHT_RECTS", "1") != "0"
+# FG_BANDED_BINNING=0: the depth-first binning of rounds 1-2 (fg_bin_prepare_keys + fg_bin_emit_sort) instead of
+# the banded count / scatter / per-tile sort (fg_tilebin_*): identical lists (A/B, and the fallback beyond
+# fg_tilebin_supported)
+banded_binning = os.environ.get("FG_BANDED_BINNING", "1") != "0"
 # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
 # store into pinned host memory (A/B)
 direct_count = os.environ.get("FG_DIRECT_COUNT", "1") != "0"
@@ -331,6 +335,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     if N == 0:
         offsets.zero_()
         return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), offsets
+    if keys_rects is not None and banded_binning and lib.fg_tilebin_supported(tile_w, tile_h):
+        return _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -417,6 +423,74 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
 
     if defer and capacity is not None:
         return tile_keys, flatten_ids, offsets, finish
+    tk, ids, _ = finish()
+    return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
+
+
+def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
+    """Banded binning (csrc/tilebin.hip: fg_tilebin_count + fg_tilebin_fill), same contract as ``bin_tiles``.
+    The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
+    from the previous calls of this shape and refilled exactly if the list turned out longer."""
+    lib = _lib.load()
+    depth_keys, rects = keys_rects
+    n_tiles = tile_w * tile_h
+    ws1 = torch.empty(int(lib.fg_tilebin_count_workspace_bytes(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
+    static = static_capacity is not None
+    count_slot, count_ptr = (None, None) if (static or not direct_count) else _count_slot()
+    _call("fg_tilebin_count", N, _ptr(rects), tile_w, tile_h, _ptr(offsets), count_ptr, _ptr(ws1), ws1.numel(),
+          _stream(), stage="fg_bin_prepare")  # fmt: skip
+
+    def fill(cap):
+        ids = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws2 = torch.empty(int(lib.fg_tilebin_fill_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
+        _call("fg_tilebin_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(offsets), _ptr(ws1),
+              _ptr(ids), _ptr(ws2), ws2.numel(), _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+        return ids
+
+    def keys_for(n):
+        return tile_keys_from_offsets(offsets, n) if want_keys else None
+
+    if static:
+        # static-shape mode (graphed.GraphedRaster): fixed-size list, no readback; valid iff the count fits
+        cap = int(static_capacity)
+        flatten_ids = fill(cap)
+        globals()["last_overflow"] = offsets[n_tiles:] > cap
+        tk = None  # (keys: tile_keys_from_offsets on demand)
+        return (tk, flatten_ids, offsets, None) if defer else (tk, flatten_ids, offsets)
+    key = (dev, N, tile_w, tile_h, "banded")
+    count_host = ready = None
+    if count_slot is None:
+        count_host = _count_buffer(dev)
+        count_host.copy_(offsets[n_tiles:], non_blocking=True)
+        ready = torch.cuda.Event()
+        ready.record()
+    capacity = _isect_capacity.get(key) if speculative_binning else None
+    flatten_ids = fill(capacity) if capacity is not None else None
+
+    def finish():
+        if count_slot is not None:
+            n_isects = _poll_count(count_slot)
+        else:
+            ready.synchronize()
+            n_isects = int(count_host[0])
+        if key not in _isect_capacity and len(_isect_capacity) >= 256:
+            old = next(iter(_isect_capacity))
+            _isect_capacity.pop(old)
+            _isect_recent.pop(old, None)
+        recent = _isect_recent.setdefault(key, [])
+        recent.append(n_isects)
+        del recent[:-16]
+        _isect_capacity[key] = list_capacity_for(recent)
+        if capacity is not None and n_isects <= capacity:
+            return keys_for(n_isects), flatten_ids[:n_isects], False
+        if capacity is not None:
+            globals()["capacity_redos"] += 1
+        if n_isects == 0:
+            return keys_for(0), torch.empty(0, dtype=torch.int32, device=dev), capacity is not None
+        return keys_for(n_isects), fill(n_isects), True
+
+    if defer and capacity is not None:
+        return None, flatten_ids, offsets, finish
     tk, ids, _ = finish()
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 

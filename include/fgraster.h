@@ -140,6 +140,26 @@ int fg_bin_prepare_rects(int N, const float* depths, const int32_t* radii, const
 int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
                         int64_t* cum_tiles, int32_t* rects_sorted, int64_t* count_out, void* workspace,
                         size_t workspace_bytes, fg_stream_t stream);
+/* ---- K3+K4, banded form (what rasterization() runs when the fused preprocess pass supplied keys and
+ * rectangles; identical lists) -------------------------------------------------------------------------
+ * Count per tile -> scan -> scatter into per-tile segments -> every tile's segment sorted by (depth
+ * bits, Gaussian id) in LDS: 5 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort.
+ * Every XCD (workgroup id % 8) handles one band of tile rows end to end, so the scattered stores of a
+ * tile's segment meet in one L2 (csrc/tilebin.hip).  tile_rects / depth_keys: the optional outputs of
+ * fg_preprocess_fwd.  fg_tilebin_count writes tile_offsets[T + 1] (exact, independent of any capacity)
+ * and, if count_out is not NULL, the list length with system scope (pinned host memory).
+ * fg_tilebin_fill writes flatten_ids[0 .. tile_offsets[T]) -- nothing at all when the list is longer than
+ * `capacity` (the host then repeats the call with exact buffers; the count workspace stays valid).
+ * Replaces the binning + sort implied by tile_size=16 at freegaussian_model.py:806,857. */
+int fg_tilebin_supported(int tile_w, int tile_h);
+size_t fg_tilebin_count_workspace_bytes(int N, int tile_w, int tile_h);
+int fg_tilebin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
+                     int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
+size_t fg_tilebin_fill_workspace_bytes(int64_t capacity);
+int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                    int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                    int32_t* flatten_ids, void* workspace, size_t workspace_bytes, fg_stream_t stream);
+
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
  * of traffic per intersection over emission + the two sort passes. */

@@ -304,6 +304,92 @@ def test_speculative_binning_capacity_and_overflow():
     ops.speculative_binning = was
 
 
+def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
+    """The same keys / rectangles through both binning paths; returns the banded lists."""
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    z = torch.zeros(N, device=DEV)
+    args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
+    outs = []
+    for banded in (False, True):
+        monkeypatch.setattr(ops, "banded_binning", banded)
+        ops._isect_capacity.clear()
+        runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
+        if overflow:
+            for k in list(ops._isect_capacity):
+                ops._isect_capacity[k] = 1024  # far too small: the fill writes nothing, the host refills exactly
+            runs.append(ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False))
+        for _, f, o in runs[1:]:
+            assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
+        outs.append(runs[0])
+    (_, f0, o0), (_, f1, o1) = outs
+    assert torch.equal(o1, o0), "tile ranges differ"
+    assert torch.equal(f1, f0), "lists differ"
+    return f1, o1
+
+
+def _pack_rects(x0, y0, w, h):
+    return torch.stack([x0 | (y0 << 16), w | (h << 16)], -1).to(torch.int32).contiguous()
+
+
+@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "one", "all_culled", "few_rows", "2160p"])
+def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
+    """csrc/tilebin.hip (count per tile -> scan -> scatter -> per-tile LDS sort by (depth bits, id)) against the
+    depth-first binning on the same depth keys and footprint rectangles: `torch.equal` lists and ranges.
+    Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
+    a tile with more entries than fit the LDS sort (the pass through global memory); one Gaussian; nothing
+    visible; an image with fewer tile rows than XCD bands; 32 400 tiles."""
+    g = torch.Generator().manual_seed(31)
+    W, H = 640, 400
+    if case == "scene":
+        sc = _scene(n=50000, w=W, h=H, seed=19)
+        t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        _, _, _, _, _, splats = ops.preprocess(*t, None, sc.viewmats[0].to(DEV), sc.Ks[0].to(DEV), W, H, sh_degree=3)
+        keys, rects = splats._fg_bin
+        N = 50000
+        f, o = _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=True)
+        assert f.numel() > 100_000
+        return
+    if case == "few_rows":
+        W, H = 640, 40  # 3 tile rows: five of the eight bands are empty
+    if case == "2160p":
+        W, H = 3840, 2160
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    N = {"ties": 30000, "heavy_tile": 20000, "one": 1, "all_culled": 5000, "few_rows": 4000, "2160p": 200_000}[case]
+    x0 = torch.randint(0, tw, (N,), generator=g)
+    y0 = torch.randint(0, th, (N,), generator=g)
+    w = torch.minimum(torch.randint(1, 5, (N,), generator=g), tw - x0)
+    h = torch.minimum(torch.randint(1, 5, (N,), generator=g), th - y0)
+    depth = torch.rand(N, generator=g) * 6 + 0.7
+    if case == "ties":
+        depth = depth[torch.randint(0, 40, (N,), generator=g)]  # 40 distinct depths: runs of hundreds of equal keys
+        depth[:2000] = 3.0
+    if case == "heavy_tile":
+        x0[:6000], y0[:6000], w[:6000], h[:6000] = 7, 5, 2, 2  # 6000 entries in each of four tiles (> 2048: global pass)
+        depth[1000:1500] = 2.5  # ... with ties inside
+        w[6000:6100], h[6000:6100] = tw - x0[6000:6100], th - y0[6000:6100]  # and a few huge rectangles
+    keys = depth.float().view(torch.int32).clone()
+    if case == "all_culled":
+        w[:], h[:] = 0, 0
+        keys[:] = -1
+    cull = torch.rand(N, generator=g) < 0.15
+    if case not in ("one",):
+        w[cull], h[cull] = 0, 0
+        keys[cull] = -1  # 0xFFFFFFFF
+    rects = _pack_rects(x0, y0, w, h).to(DEV)
+    f, o = _banded_vs_depth_first(N, W, H, rects, keys.to(DEV), monkeypatch)
+    # ... and against the rule itself: per tile, ids ordered by (depth bits, id)
+    area = (w * h).long()
+    assert int(o[-1]) == int(area.sum()) == f.numel()
+    gid = torch.repeat_interleave(torch.arange(N), area)
+    kk = torch.arange(int(area.sum())) - torch.repeat_interleave(torch.cumsum(area, 0) - area, area)
+    wg = torch.clamp_min(w[gid], 1)
+    tile = (y0[gid] + kk // wg) * tw + x0[gid] + kk % wg
+    order = torch.argsort(((keys[gid].long() & 0xFFFFFFFF) << 20) | gid)  # (depth bits, id) ...
+    order = order[torch.sort(tile[order], stable=True).indices]  # ... then stably by tile
+    assert torch.equal(f.cpu().long(), gid[order])
+    assert torch.equal(o.cpu().long(), torch.searchsorted(tile[order].contiguous(), torch.arange(tw * th + 1)))
+
+
 def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
     sc = _scene(n=20000, w=256, h=160, seed=17)
     t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
