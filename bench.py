@@ -87,18 +87,41 @@ def free_port():
         return s.getsockname()[1]
 
 
+def visible_gpu_count():
+    """GPUs a rank of this launch would see, counted WITHOUT importing torch or calling into HIP (either would
+    open the driver in the launcher): the KFD topology nodes that have SIMDs, capped by the *_VISIBLE_DEVICES
+    lists.  No /sys/class/kfd = no AMD GPU driver = 0."""
+    import re
+
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    n = 0
+    try:
+        for d in os.listdir(base):
+            try:
+                m = re.search(r"^simd_count\s+(\d+)", open(os.path.join(base, d, "properties")).read(), re.M)
+            except OSError:
+                continue
+            n += bool(m and int(m.group(1)) > 0)
+    except OSError:
+        return 0
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
+
+
 def launch_ranks(args, argv):
     """Start args.gpus rank processes of this script, relay rank 0's stdout, return the exit code.
-    Runs before this process has imported freegaussian_amd or touched the GPU (counting devices
-    does not initialise it); the children are fresh interpreters, never an exec of this one."""
+    Runs before this process has imported torch / freegaussian_amd or touched the GPU (devices are counted
+    from sysfs); the children are fresh interpreters, never an exec of this one.  Every rank checks again
+    for itself (LOCAL_RANK against its own device count) before it joins the process group."""
     import subprocess
 
     n = args.gpus
     backend = os.environ.get("FG_BENCH_BACKEND", "nccl")
     if backend == "nccl" and not os.environ.get("FG_BENCH_ECHO"):
-        import torch
-
-        have = torch.cuda.device_count()
+        have = visible_gpu_count()
         if have < n:
             print(f"[bench] --gpus {n} but only {have} GPU(s) visible: one rank per GPU over RCCL, devices are "
                   "never shared (FG_BENCH_BACKEND=gloo exercises the N-rank control flow on fewer GPUs)",
@@ -506,28 +529,28 @@ def main(argv=None):
     # them, 0.987 without), so the timed region below carries events around the dominant kernel only --
     # the two the roofline's duration needs -- and the stage table comes from this pass over the same views.
     stage_steps = min(args.steps, 24) if args.stage_events != "none" else 0
-    ops.stage_timer = ops.StageTimer()
+    ops.default_context.stage_timer = ops.StageTimer()
     for _ in range(stage_steps):
         step(timed=True)
     fence()
-    stages = ops.stage_timer.summary() if stage_steps else {}
-    ops.stage_timer = None
+    stages = ops.default_context.stage_timer.summary() if stage_steps else {}
+    ops.default_context.stage_timer = None
     kernel_names = ("fg_raster_bwd", "fg_raster_fwd", "fg_raster_composite_bwd", "fg_raster_composite_fwd",
                     "fg_preprocess_fwd", "fg_preprocess_bwd", "fg_bin_prepare", "fg_bin_emit_sort_capacity")
     cand = {s: v for s, v in stages.items() if s in kernel_names}
     dominant = max(cand, key=lambda s: cand[s]) if cand else "fg_raster_bwd"
     gc.collect()
     gc.disable()  # a generation-2 collection inside a 50 ms timed region is a 1-3 ms outlier, not a property of the path
-    redo0 = ops.capacity_redos
+    redo0 = ops.default_context.capacity_redos
     only = {"all": None, "dominant": {dominant}, "none": set()}[args.stage_events]
-    ops.stage_timer = ops.StageTimer(only=only)
+    ops.default_context.stage_timer = ops.StageTimer(only=only)
     # one untimed step AFTER the collection and the timer swap: the first step behind them was a 1.7x outlier
     # (3.5% of a 20-step mean) that belongs to the bench, not to the path.  Like every warm-up step it advances
     # the view ring, on all ranks alike.
     step(timed=args.stage_events == "all")
     fence()
-    if ops.stage_timer is not None:
-        ops.stage_timer = ops.StageTimer(only=only)  # its events are not part of the timed region's averages
+    if ops.default_context.stage_timer is not None:
+        ops.default_context.stage_timer = ops.StageTimer(only=only)  # its events are not part of the timed region's averages
     t0 = time.perf_counter()
     views_seen = []
     host_marks = [t0]
@@ -538,13 +561,13 @@ def main(argv=None):
     fence()
     dt_local = time.perf_counter() - t0
     gc.enable()
-    timed_stages = ops.stage_timer.summary()
-    ops.stage_timer = None
+    timed_stages = ops.default_context.stage_timer.summary()
+    ops.default_context.stage_timer = None
     if args.stage_events == "all":
         stages = timed_stages
     stages = dict(stages)
     stages.update(timed_stages)  # the dominant kernel's duration: from the timed region itself
-    redos = ops.capacity_redos - redo0
+    redos = ops.default_context.capacity_redos - redo0
     t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
     per_rank = [t.clone() for _ in range(world)]
     if world > 1:

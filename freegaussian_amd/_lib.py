@@ -46,15 +46,17 @@ SIGNATURES = {
     "fg_tilebin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, c_size_t, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
-    "fg_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P]),
-    "fg_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P]),
-    "fg_raster_composite_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P]),
-    "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P]),
-    "fg_raster_jobs_words": (c_int64, [c_int, c_int, c_int]),
-    "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P]),
-    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, P]),
-    "fg_raster_seg_ckpt_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int64]),
-    "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
+    # (the pointer before the stream of every raster entry point is the `const fg_raster_config*`)
+    "fg_raster_config_init": (None, [P]),
+    "fg_raster_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P]),
+    "fg_raster_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+    "fg_raster_composite_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P]),
+    "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P]),
+    "fg_raster_jobs_words": (c_int64, [c_int, c_int, c_int, P]),
+    "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, P]),
+    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, P, P]),
+    "fg_raster_seg_ckpt_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int64, P]),
+    "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
                                   c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
@@ -84,12 +86,33 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 _lib = None
 
 
 class FgRasterError(RuntimeError):
     pass
+
+
+class RasterConfig(ctypes.Structure):
+    """``fg_raster_config`` of include/fgraster.h: the launch policy of the raster kernels, handed to every
+    raster entry point (the library itself reads no environment variable).  Field order = the header's."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "size", "ppt_fwd", "ppt_bwd", "tile_order", "bands_nx", "tail4_fwd", "tail2_fwd", "tail4_bwd", "tail2_bwd",
+        "split4_fwd", "split2_fwd", "split4_bwd", "split2_bwd", "use_liveness", "seg_parts", "seg_tail", "seg_parts2",
+        "seg_tail2", "debug_only_xcd", "debug_k_mod")]  # fmt: skip
+
+    FIELDS = tuple(n for n, _ in _fields_)[1:]
+
+    @classmethod
+    def defaults(cls) -> "RasterConfig":
+        cfg = cls()
+        load().fg_raster_config_init(ctypes.byref(cfg))
+        return cfg
+
+    def ptr(self) -> int:
+        return ctypes.addressof(self)
 
 
 def load() -> ctypes.CDLL:

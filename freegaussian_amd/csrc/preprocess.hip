@@ -456,18 +456,15 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   }
 }
 
-// FG_PREPROCESS_SKIP_CULLED=1: fetch the coefficient rows of visible Gaussians only, after the
-// projection / the radii are known.  OFF by default: measured on MI355X (1M / 1080p, 16% culled,
-// profiles/r02_preprocess_skip_culled.md) it saves the 30 MB of dead rows and LOSES more than that
-// by putting the slab fetch behind the cull instead of under it: forward 0.072 -> 0.099 ms,
-// backward 0.109 -> 0.134 ms.
-int skip_culled_rows() {
-  static const int v = [] {
-    const char* e = getenv("FG_PREPROCESS_SKIP_CULLED");
-    return (e && e[0] == '1') ? 1 : 0;
-  }();
-  return v;
-}
+// -DFG_PREPROCESS_SKIP_CULLED=1 (a build-time A/B switch; the library reads no environment): fetch the
+// coefficient rows of visible Gaussians only, after the projection / the radii are known.  OFF: measured on
+// MI355X (1M / 1080p, 16% culled, profiles/r02_preprocess_skip_culled.md) it saves the 30 MB of dead rows and
+// LOSES more than that by putting the slab fetch behind the cull instead of under it: forward 0.072 -> 0.099
+// ms, backward 0.109 -> 0.134 ms.
+#ifndef FG_PREPROCESS_SKIP_CULLED
+#define FG_PREPROCESS_SKIP_CULLED 0
+#endif
+int skip_culled_rows() { return FG_PREPROCESS_SKIP_CULLED; }
 
 bool layout_ok(const FeatLayout& fl) {
   if (fl.sh_degree > 3 || fl.n_extra < 0 || fl.n_color < 0) return false;

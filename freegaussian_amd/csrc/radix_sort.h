@@ -248,6 +248,9 @@ scatter_kernel(int64_t n, const int64_t* __restrict__ n_dev, const KeyT* __restr
   }
 }
 
+// one word, as a launch of our own (a hipMemsetAsync under torch's graph capture was dropped from the graph)
+static __global__ void set_word_kernel(uint32_t* p, uint32_t v) { *p = v; }
+
 // (A single-kernel variant of the passes -- ticketed tiles, chained scan with decoupled look-back
 // -- was built, verified bit-exact and measured slower on MI355X: profiles/r01_onesweep.md; it was
 // removed again, see the git history of this file.)
@@ -278,7 +281,10 @@ template <typename KeyT>
 static inline int sort_pairs(int64_t n, KeyT* keys, uint32_t* vals, int end_bit, void* workspace,
                              size_t ws_bytes, hipStream_t s, const int64_t* n_dev = nullptr, bool iota_vals = false) {
   if (iota_vals && (n <= 1 || end_bit <= 0)) {
-    if (n == 1 && hipMemsetAsync(vals, 0, 4, s) != hipSuccess) return FG_ERR_LAUNCH;
+    if (n == 1) {
+      hipLaunchKernelGGL(set_word_kernel, dim3(1), dim3(1), 0, s, vals, 0u);
+      if (hipGetLastError() != hipSuccess) return FG_ERR_LAUNCH;
+    }
     return FG_OK;
   }
   if (n <= 1 || end_bit <= 0) return FG_OK;

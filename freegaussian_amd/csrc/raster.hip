@@ -1365,23 +1365,31 @@ unpack_grads_kernel(int N, int C, const float* __restrict__ v_splats, float* __r
 // Pixels per lane.  Measured on MI355X (1M Gaussians, 1080p, profiles/r01_ppt_sweep.md): with
 // strip culling the forward is fastest with 2 pixels per lane (2 wavefronts per tile) and the
 // backward with 4 (one wavefront per tile: the 16-value wave reduction + atomic is paid once
-// per 256 pixels and no cross-wave step exists).  FG_RASTER_PPT_FWD / _BWD override.
-int env_ppt(const char* name, int dflt) {
-  const char* e = getenv(name);
-  const int v = e ? atoi(e) : dflt;
-  return (v == 1 || v == 2 || v == 4) ? v : dflt;  // dflt 0 = "not forced"
+// per 256 pixels and no cross-wave step exists).  fg_raster_config::ppt_fwd / ppt_bwd override.
+//
+// LAUNCH POLICY.  Everything below that used to be read from FG_RASTER_* environment variables comes in
+// through the caller's fg_raster_config (include/fgraster.h; NULL = the measured defaults): the library
+// reads no environment and keeps no state.  `Cfg` is the caller's struct with every "-1 = default" left
+// as it is; the functions below resolve a field where they use it.
+using Cfg = fg_raster_config;
+Cfg resolve(const fg_raster_config* c) {
+  Cfg r;
+  fg_raster_config_init(&r);
+  if (c) {
+    // a caller compiled against an older, shorter struct: take the fields it has
+    const size_t n = (size_t)c->size < sizeof(Cfg) ? (size_t)c->size : sizeof(Cfg);
+    if (n >= sizeof(int32_t)) memcpy(&r, c, n);
+    r.size = (int32_t)sizeof(Cfg);
+  }
+  return r;
 }
-int tile_order_mode() {  // FG_TILE_ORDER = rows | bands | cols (default, measured best: profiles/r01_tile_order.md)
-  static int mode = [] {
-    const char* e = getenv("FG_TILE_ORDER");
-    const char* x = getenv("FG_DEBUG_ONLY_XCD");
-    const int only = (x && x[0] >= '0' && x[0] <= '7') ? ((x[0] - '0' + 1) << 8) : 0;
-    const char* km = getenv("FG_DEBUG_K_MOD");
-    const int dbg = only | ((km ? atoi(km) : 0) << 12);
-    if (!e) return 2 | dbg;
-    return (e[0] == 'r' ? 0 : e[0] == 'c' ? 2 : e[0] == 's' ? 3 : e[0] == 'x' ? 4 : e[0] == 'y' ? 5 : 1) | dbg;
-  }();
-  return mode;
+int forced_ppt(int v) { return (v == 1 || v == 2 || v == 4) ? v : 0; }
+// tile order of the classic launches (profiles/r01_tile_order.md: column-major bands, 2, measured best)
+// | the two measurement hooks (debug_only_xcd: only that XCD's workgroups work; debug_k_mod: every m-th tile)
+int tile_order_mode(const Cfg& c) {
+  const int order = (c.tile_order >= 0 && c.tile_order <= 5) ? c.tile_order : 2;
+  const int only = (c.debug_only_xcd >= 0 && c.debug_only_xcd <= 7) ? ((c.debug_only_xcd + 1) << 8) : 0;
+  return order | only | ((c.debug_k_mod > 0 ? c.debug_k_mod : 0) << 12);
 }
 int launch_grid(int mode, int tile_w, int tile_h) {
   switch (mode) {
@@ -1392,29 +1400,29 @@ int launch_grid(int mode, int tile_w, int tile_h) {
     default: return 8 * ((tile_h + 7) / 8) * tile_w;
   }
 }
-// Pixels per lane by tile count (FG_RASTER_PPT_FWD / _BWD override).  A tile's list is walked
+// Pixels per lane by tile count (fg_raster_config::ppt_fwd / ppt_bwd override).  A tile's list is walked
 // serially by each of its wavefronts, so with few tiles the launch is bound by the longest list,
 // not by throughput: more, smaller wavefronts per tile then win although they repeat the
 // per-entry work.  Measured (profiles/r01_ppt_by_tiles.md): 8160 tiles -> fwd 2 / bwd 4;
 // 2040 tiles (960x540) -> 1 / 1: fwd 0.178 -> 0.117 ms, bwd 0.420 -> 0.317 ms;
 // 510 tiles (480x270) -> 1 / 1: fwd 0.138 -> 0.071, bwd 0.357 -> 0.151.
-int raster_ppt_fwd(int n_tiles) {
-  const int forced = env_ppt("FG_RASTER_PPT_FWD", 0);  // read per call: tests switch it within a process
+int raster_ppt_fwd(const Cfg& c, int n_tiles) {
+  const int forced = forced_ppt(c.ppt_fwd);
   if (forced) return forced;
   return n_tiles >= 6000 ? 2 : 1;
 }
-int raster_ppt_bwd(int n_tiles) {
-  const int forced = env_ppt("FG_RASTER_PPT_BWD", 0);
+int raster_ppt_bwd(const Cfg& c, int n_tiles) {
+  const int forced = forced_ppt(c.ppt_bwd);
   if (forced) return forced;
   return n_tiles >= 6000 ? 4 : (n_tiles >= 3000 ? 2 : 1);
 }
 
 template <int C, int PPT>
-int launch_fwd(int width, int height, const float* splats, const int32_t* tile_offsets,
+int launch_fwd(const Cfg& cfg, int width, int height, const float* splats, const int32_t* tile_offsets,
                const int32_t* flatten_ids, float* render, float* alphas, int32_t* last_ids, Composite comp,
                hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int mode = tile_order_mode();
+  const int mode = tile_order_mode(cfg);
   const int grid = launch_grid(mode & 255, tile_w, tile_h);
   hipLaunchKernelGGL((raster_fwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
@@ -1423,11 +1431,11 @@ int launch_fwd(int width, int height, const float* splats, const int32_t* tile_o
 }
 
 template <int C, int PPT>
-int launch_bwd(int width, int height, const float* splats, const int32_t* tile_offsets,
+int launch_bwd(const Cfg& cfg, int width, int height, const float* splats, const int32_t* tile_offsets,
                const int32_t* flatten_ids, const float* alphas, const int32_t* last_ids, const float* v_render,
                const float* v_alphas, float* v_splats, Composite comp, hipStream_t s) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int mode = tile_order_mode();
+  const int mode = tile_order_mode(cfg);
   const int grid = launch_grid(mode & 255, tile_w, tile_h);
   hipLaunchKernelGGL((raster_bwd_kernel<C, PPT>), dim3(grid), dim3(256 / PPT), 0, s, width, height, tile_w,
                      tile_h, mode, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas,
@@ -1440,7 +1448,7 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
 // of a launch is about one job per wavefront slot of the XCD (128 SIMDs x 4-8 slots), whatever the
 // image size -- 510 / 300 were the best settings at 1080p, 1440p and 2160p alike
 // (profiles/r01_tail_split.md); at most half / 30% of the XCD's tiles.  0 = classic launch.
-// FG_RASTER_TAIL_FWD / _BWD = "t4" or "t4,t2" override.
+// fg_raster_config::tail4_fwd / tail2_fwd / tail4_bwd / tail2_bwd override (-1 = these defaults).
 // content thresholds in 1/65536 of the total list length (16 = total / 2^12): measured on the
 // uniform and on the clustered scene (profiles/r01_tail_split.md); at 8160 tiles 16 / 20 are 2.0x /
 // 2.5x the mean list length
@@ -1472,16 +1480,14 @@ int launch_bwd(int width, int height, const float* splats, const int32_t* tile_o
 #ifndef FG_MIXED_MIN_TILES
 #define FG_MIXED_MIN_TILES 900
 #endif
-// Returns tail4 | tail2 << 16 (both clamped to 16 bits); the variables take "t4" or "t4,t2".
-int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
-  const char* e = getenv(name);
+// Returns tail4 | tail2 << 16 (both clamped to 16 bits); req4 >= 0: the caller's numbers (req2 < 0: 0).
+int raster_tail(const Cfg& cfg, int req4, int req2, int n_tiles, int dflt4, int dflt2) {
   int t4, t2 = 0;
-  if (e) {
-    t4 = atoi(e);
-    const char* c = strchr(e, ',');
-    if (c) t2 = atoi(c + 1);
+  if (req4 >= 0) {
+    t4 = req4;
+    if (req2 > 0) t2 = req2;
   } else {
-    if (n_tiles < FG_MIXED_MIN_TILES || (tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
+    if (n_tiles < FG_MIXED_MIN_TILES || (tile_order_mode(cfg) & 255) != 2 || (tile_order_mode(cfg) >> 8) != 0) return 0;
     const int per_xcd = n_tiles / 8;
     if (n_tiles < 5000) {
       // 900..5000 tiles (640x360 ... 1280x720; 960x540 is the reference's half-resolution phase): fewer tiles than
@@ -1501,13 +1507,13 @@ int raster_tail(const char* name, int n_tiles, int dflt4, int dflt2) {
   return t4 | (t2 << 16);
 }
 // tail4 | tail2 << 16 of the mixed launch, or 0 = classic launch for this image size / environment
-int mixed_tail_fwd(int n_tiles) {
-  if (getenv("FG_RASTER_PPT_FWD")) return 0;
-  return raster_tail("FG_RASTER_TAIL_FWD", n_tiles, FG_TAIL4_TILES_FWD, FG_TAIL2_TILES_FWD);
+int mixed_tail_fwd(const Cfg& c, int n_tiles) {
+  if (forced_ppt(c.ppt_fwd)) return 0;  // forced pixels per lane: the classic launch
+  return raster_tail(c, c.tail4_fwd, c.tail2_fwd, n_tiles, FG_TAIL4_TILES_FWD, FG_TAIL2_TILES_FWD);
 }
-int mixed_tail_bwd(int n_tiles) {
-  if (getenv("FG_RASTER_PPT_BWD")) return 0;
-  return raster_tail("FG_RASTER_TAIL_BWD", n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
+int mixed_tail_bwd(const Cfg& c, int n_tiles) {
+  if (forced_ppt(c.ppt_bwd)) return 0;
+  return raster_tail(c, c.tail4_bwd, c.tail2_bwd, n_tiles, FG_TAIL4_TILES_BWD, FG_TAIL2_TILES_BWD);
 }
 // tiles of the largest XCD rectangle for an nx x (8 / nx) arrangement
 int band_tiles_for(int tile_w, int tile_h, int nx) {
@@ -1518,45 +1524,40 @@ int band_tiles_for(int tile_w, int tile_h, int nx) {
   }
   return m;
 }
-// Whole-row bands (nx = 1) unless FG_RASTER_BANDS=2|4|8 asks for another arrangement.  Measured at
+// Whole-row bands (nx = 1) unless fg_raster_config::bands_nx = 2|4|8 asks for another arrangement.  Measured at
 // 1080p (profiles/r02_job_timeline.md): 8 x 1 column strips give every XCD exactly 1020 tiles instead of
 // 1080 / 960, and all eight then finish when the 1080-tile XCDs did before (an XCD's time is set by its
 // long jobs and the drain after them, not by its tile count); the forward is 5% slower (0.218 against
 // 0.208 ms), 4 x 2 rectangles 13%.
-int band_nx(int tile_w, int tile_h) {
-  const char* e = getenv("FG_RASTER_BANDS");
-  if (e) {
-    const int v = atoi(e);
-    if (v == 1 || v == 2 || v == 4 || v == 8) return v;
-  }
-  return 1;
+int band_nx(const Cfg& c) {
+  const int v = c.bands_nx;
+  return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 1;
 }
-int band_tiles_max(int tile_w, int tile_h) { return band_tiles_for(tile_w, tile_h, band_nx(tile_w, tile_h)); }
-int mixed_grid(int tile_w, int tile_h, int tail) {  // positional jobs only
-  const int n_max = band_tiles_max(tile_w, tile_h);
+int band_tiles_max(const Cfg& c, int tile_w, int tile_h) { return band_tiles_for(tile_w, tile_h, band_nx(c)); }
+int mixed_grid(const Cfg& c, int tile_w, int tile_h, int tail) {  // positional jobs only
+  const int n_max = band_tiles_max(c, tile_w, tile_h);
   int t4 = tail & 0xFFFF, t2 = tail >> 16;
   t4 = t4 < n_max ? t4 : n_max;
   t2 = t2 < n_max - t4 ? t2 : n_max - t4;
   return 8 * (n_max + 3 * t4 + t2);
 }
-int jobs_cap(int tile_w, int tile_h) { return 8 * band_tiles_max(tile_w, tile_h); }
+int jobs_cap(const Cfg& c, int tile_w, int tile_h) { return 8 * band_tiles_max(c, tile_w, tile_h); }
 // grid of a launch that reads job lists: the positional job count + half a job per tile for the
 // content splits (the builder fits the list into it)
-int listed_grid(int tile_w, int tile_h, int tail) {
-  const int g = mixed_grid(tile_w, tile_h, tail) / 8;
-  const int cap = jobs_cap(tile_w, tile_h);
-  const int want = g + band_tiles_max(tile_w, tile_h) / 2;
+int listed_grid(const Cfg& c, int tile_w, int tile_h, int tail) {
+  const int g = mixed_grid(c, tile_w, tile_h, tail) / 8;
+  const int cap = jobs_cap(c, tile_w, tile_h);
+  const int want = g + band_tiles_max(c, tile_w, tile_h) / 2;
   return 8 * (want < cap ? want : cap);
 }
 // Content thresholds of the mixed launch: "a4,a2" = split a tile in four when its list is longer than
-// total * a4 / 65536, in two when longer than total * a2 / 65536 (FG_RASTER_SPLIT_FWD / _BWD; "0" = off).
-int raster_split(const char* name, int dflt4, int dflt2) {
-  const char* e = getenv(name);
+// total * a4 / 65536, in two when longer than total * a2 / 65536 (fg_raster_config::split4_* / split2_*:
+// -1 = the defaults, 0 = off; a given split4 with split2 < 0 means split2 = 0).
+int raster_split(int req4, int req2, int dflt4, int dflt2) {
   int s4 = dflt4, s2 = dflt2;
-  if (e) {
-    s4 = atoi(e);
-    const char* c = strchr(e, ',');
-    s2 = c ? atoi(c + 1) : 0;
+  if (req4 >= 0) {
+    s4 = req4;
+    s2 = req2 > 0 ? req2 : 0;
   }
   s4 = s4 < 0 ? 0 : (s4 > 0x7FFF ? 0x7FFF : s4);
   s2 = s2 < 0 ? 0 : (s2 > 0x7FFF ? 0x7FFF : s2);
@@ -1565,60 +1566,48 @@ int raster_split(const char* name, int dflt4, int dflt2) {
 
 // workgroups of a launch of list-share jobs: the positional count (+ half a job per tile for content
 // splits when a list is read: the builder fits the list into it)
-int seg_parts2();
-int seg_tail2();
-int seg_grid(int tile_w, int tile_h, int parts, int tail, bool listed) {
-  const int n_max = band_tiles_max(tile_w, tile_h);
+int seg_parts2(const Cfg& c);
+int seg_tail2(const Cfg& c);
+int seg_grid(const Cfg& c, int tile_w, int tile_h, int parts, int tail, bool listed) {
+  const int n_max = band_tiles_max(c, tile_w, tile_h);
   const int split = tail > 0 ? (tail < n_max ? tail : n_max) : n_max;
   int per_xcd = n_max - split + split * parts + (listed ? n_max / 2 : 0);
-  if (listed && seg_parts2() > parts) per_xcd += (seg_tail2() < split ? seg_tail2() : split) * (seg_parts2() - parts);
-  const int cap = jobs_cap(tile_w, tile_h);
+  if (listed && seg_parts2(c) > parts) per_xcd += (seg_tail2(c) < split ? seg_tail2(c) : split) * (seg_parts2(c) - parts);
+  const int cap = jobs_cap(c, tile_w, tile_h);
   return 8 * (listed && per_xcd > cap ? cap : per_xcd);
 }
-// FG_RASTER_LIVE=0: the backward ignores the forward's liveness bytes (A/B)
-const uint32_t* live_use(const uint32_t* live_words) {
-  const char* e = getenv("FG_RASTER_LIVE");
-  return (e && e[0] == '0') ? nullptr : live_words;
-}
-// FG_RASTER_SEG_TAIL = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
-int seg_tail(int n_tiles) {
-  const char* e = getenv("FG_RASTER_SEG_TAIL");
-  const int v = e ? atoi(e) : (n_tiles < 5000 ? 0 : FG_SEG_TAIL_DEFAULT);  // below 5000 tiles: every tile
-  return v < 0 ? 0 : v;
+// use_liveness = 0: the backward ignores the forward's liveness bytes (A/B)
+const uint32_t* live_use(const Cfg& c, const uint32_t* live_words) { return c.use_liveness == 0 ? nullptr : live_words; }
+// seg_tail = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
+int seg_tail(const Cfg& c, int n_tiles) {
+  return c.seg_tail >= 0 ? c.seg_tail : (n_tiles < 5000 ? 0 : FG_SEG_TAIL_DEFAULT);  // below 5000 tiles: every tile
 }
 // ... clamped so that the positional jobs of the largest XCD band (+ the margin for content splits)
 // fit a job list segment
-int seg_tail_fit(int tile_w, int tile_h, int parts, int tail) {
-  const int n_max = band_tiles_max(tile_w, tile_h);
+int seg_tail_fit(const Cfg& c, int tile_w, int tile_h, int parts, int tail) {
+  const int n_max = band_tiles_max(c, tile_w, tile_h);
   if (tail <= 0 || tail > n_max) tail = n_max;
-  const int room = jobs_cap(tile_w, tile_h) - n_max - n_max / 2;
+  const int room = jobs_cap(c, tile_w, tile_h) - n_max - n_max / 2;
   const int fit = parts > 1 ? room / (parts - 1) : n_max;
   return tail < fit ? tail : (fit > 1 ? fit : 1);
 }
-// FG_RASTER_SEG_GRADE = "parts2,tail2": the last tail2 tiles of every XCD's sequence get parts2 jobs
+// seg_parts2 / seg_tail2: the last tail2 tiles of every XCD's sequence get parts2 jobs
 #ifndef FG_SEG_PARTS2_DEFAULT
 #define FG_SEG_PARTS2_DEFAULT 0
 #endif
 #ifndef FG_SEG_TAIL2_DEFAULT
 #define FG_SEG_TAIL2_DEFAULT 0
 #endif
-int seg_parts2() {
-  const char* e = getenv("FG_RASTER_SEG_GRADE");
-  const int v = e ? atoi(e) : FG_SEG_PARTS2_DEFAULT;
-  return v < 0 ? 0 : (v > 16 ? 16 : v);
+int seg_parts2(const Cfg& c) {
+  const int v = c.seg_parts2 >= 0 ? c.seg_parts2 : FG_SEG_PARTS2_DEFAULT;
+  return v > 16 ? 16 : v;
 }
-int seg_tail2() {
-  const char* e = getenv("FG_RASTER_SEG_GRADE");
-  const char* c = e ? strchr(e, ',') : nullptr;
-  const int v = e ? (c ? atoi(c + 1) : 0) : FG_SEG_TAIL2_DEFAULT;
-  return v < 0 ? 0 : v;
-}
-// FG_RASTER_SEG_PARTS = jobs per tile of the segmented backward (0 / 1 = off)
-int seg_parts(int n_tiles) {
-  const char* e = getenv("FG_RASTER_SEG_PARTS");
+int seg_tail2(const Cfg& c) { return c.seg_tail2 >= 0 ? c.seg_tail2 : FG_SEG_TAIL2_DEFAULT; }
+// seg_parts = jobs per tile of the segmented backward (0 / 1 = off)
+int seg_parts(const Cfg& c, int n_tiles) {
   // below 5000 tiles there are fewer tiles than wavefront slots: 6 shares per tile (960x540: backward
   // 0.181 -> 0.178, 1280x720: 0.246 -> 0.236; 8: 0.175 / 0.229)
-  const int v = e ? atoi(e) : (n_tiles < 5000 ? FG_SEG_PARTS_SMALL : FG_SEG_PARTS_DEFAULT);
+  const int v = c.seg_parts >= 0 ? c.seg_parts : (n_tiles < 5000 ? FG_SEG_PARTS_SMALL : FG_SEG_PARTS_DEFAULT);
   return v < 1 ? 1 : (v > 16 ? 16 : v);
 }
 
@@ -1636,18 +1625,18 @@ int zero_fill(float* p, long long n, hipStream_t s) {
 }
 
 template <int C>
-int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
+int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                      int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr,
                      uint32_t* live_words = nullptr, float* zero_buf = nullptr, long long zero_floats = 0) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int cap = jobs_cap(tile_w, tile_h);
+  const int cap = jobs_cap(cfg, tile_w, tile_h);
   if (zero_buf && ((zero_floats & 3) || (reinterpret_cast<uintptr_t>(zero_buf) & 15))) {
     if (zero_fill(zero_buf, zero_floats, s) != FG_OK) return FG_ERR_LAUNCH;
     zero_buf = nullptr;
   }
-  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail)),
-                     dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail, jobs, cap,
+  hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(cfg, tile_w, tile_h, tail) : mixed_grid(cfg, tile_w, tile_h, tail)),
+                     dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
                      zero_buf ? zero_floats / 4 : 0ll);
@@ -1655,21 +1644,21 @@ int launch_fwd_mixed(int width, int height, int tail, const int32_t* jobs, const
 }
 
 template <int C>
-int launch_bwd_mixed(int width, int height, int tail, const int32_t* jobs, const float* splats,
+int launch_bwd_mixed(const Cfg& cfg, int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
                      Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1, 0},
                      const uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
-  const int cap = jobs_cap(tile_w, tile_h);
-  int grid = jobs ? listed_grid(tile_w, tile_h, tail) : mixed_grid(tile_w, tile_h, tail);
-  if (seg.parts > 1) grid = seg_grid(tile_w, tile_h, seg.parts, seg.tail, jobs != nullptr);
+  const int cap = jobs_cap(cfg, tile_w, tile_h);
+  int grid = jobs ? listed_grid(cfg, tile_w, tile_h, tail) : mixed_grid(cfg, tile_w, tile_h, tail);
+  if (seg.parts > 1) grid = seg_grid(cfg, tile_w, tile_h, seg.parts, seg.tail, jobs != nullptr);
   if (live_words)
-    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail,
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, true>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail,
                        jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
                        v_render, v_alphas, v_splats, comp, seg, live_words);
   else
-    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, false>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(tile_w, tile_h), tail,
+    hipLaunchKernelGGL((raster_bwd_mixed_kernel<C, false>), dim3(grid), dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail,
                        jobs, cap, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, alphas, last_ids,
                        v_render, v_alphas, v_splats, comp, seg, live_words);
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
@@ -1721,7 +1710,7 @@ extern "C" int fg_unpack_grads(int N, int channels, const float* v_splats, float
 
 namespace {
 
-int raster_fwd_any(int channels, int width, int height, int tile_size, const float* splats,
+int raster_fwd_any(const fg_raster_config* config, int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                    int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
                    float* seg_ckpt = nullptr, uint32_t* live_words = nullptr, float* zero_buf = nullptr,
@@ -1733,8 +1722,9 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-  const int ppt = raster_ppt_fwd(n_tiles);
-  int tail = mixed_tail_fwd(n_tiles);
+  const Cfg cfg = resolve(config);
+  const int ppt = raster_ppt_fwd(cfg, n_tiles);
+  int tail = mixed_tail_fwd(cfg, n_tiles);
   if (tail == 0) jobs = nullptr;  // classic launch (small image / forced pixels per lane)
   if (zero_buf && zero_floats > 0 && tail == 0) {  // only the mixed launch zero-fills in passing
     if (zero_fill(zero_buf, zero_floats, s) != FG_OK) return FG_ERR_LAUNCH;
@@ -1742,21 +1732,21 @@ int raster_fwd_any(int channels, int width, int height, int tile_size, const flo
   }
   if (zero_floats == 0) zero_buf = nullptr;
 #define CALL(CC)                                                                                                    \
-  rc = (tail > 0)   ? launch_fwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
+  rc = (tail > 0)   ? launch_fwd_mixed<CC>(cfg, width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
                                          alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr, live_words,       \
                                          zero_buf, zero_floats)                                                     \
-       : (ppt == 4) ? launch_fwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+       : (ppt == 4) ? launch_fwd<CC, 4>(cfg, width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
-       : (ppt == 2) ? launch_fwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+       : (ppt == 2) ? launch_fwd<CC, 2>(cfg, width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
-                    : launch_fwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
+                    : launch_fwd<CC, 1>(cfg, width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)
   FG_DISPATCH_C(CALL)
 #undef CALL
   return rc;
 }
 
-int raster_bwd_any(int channels, int width, int height, int tile_size, const float* splats,
+int raster_bwd_any(const fg_raster_config* config, int channels, int width, int height, int tile_size, const float* splats,
                    const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                    const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
                    Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
@@ -1769,29 +1759,31 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
   hipStream_t s = fg_hip_stream(stream);
   int rc = FG_OK;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-  const int ppt = raster_ppt_bwd(n_tiles);
-  int tail = mixed_tail_bwd(n_tiles);
+  const Cfg cfg = resolve(config);
+  const int ppt = raster_ppt_bwd(cfg, n_tiles);
+  int tail = mixed_tail_bwd(cfg, n_tiles);
   if (tail == 0) jobs = nullptr;
   // liveness words and checkpoints exist only if the forward of this image size was a mixed launch (a
-  // forced FG_RASTER_TAIL_BWD on a small image pairs a classic forward with a mixed backward)
-  if (mixed_tail_fwd(n_tiles) == 0) {
+  // forced tail4_bwd on a small image pairs a classic forward with a mixed backward)
+  if (mixed_tail_fwd(cfg, n_tiles) == 0) {
     live_words = nullptr;
     seg_ckpt = nullptr;
   }
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
   Segments seg{nullptr, nullptr, 1, 0};
-  if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts(n_tiles) > 1)
-    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(n_tiles),
-                   seg_tail_fit((width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(n_tiles), seg_tail(n_tiles))};
+  if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts(cfg, n_tiles) > 1)
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(cfg, n_tiles),
+                   seg_tail_fit(cfg, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(cfg, n_tiles),
+                                seg_tail(cfg, n_tiles))};
 #define CALL(CC)                                                                                            \
-  rc = (tail > 0)   ? launch_bwd_mixed<CC>(width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
+  rc = (tail > 0)   ? launch_bwd_mixed<CC>(cfg, width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
-                                         live_use(live_words))                                              \
-       : (ppt == 4) ? launch_bwd<CC, 4>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                                         live_use(cfg, live_words))                                              \
+       : (ppt == 4) ? launch_bwd<CC, 4>(cfg, width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
-       : (ppt == 2) ? launch_bwd<CC, 2>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+       : (ppt == 2) ? launch_bwd<CC, 2>(cfg, width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)                                \
-                    : launch_bwd<CC, 1>(width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
+                    : launch_bwd<CC, 1>(cfg, width, height, splats, tile_offsets, flatten_ids, alphas, last_ids, \
                                       v_render, v_alphas, v_splats, comp, s)
   FG_DISPATCH_C(CALL)
 #undef CALL
@@ -1802,24 +1794,25 @@ int raster_bwd_any(int channels, int width, int height, int tile_size, const flo
 
 extern "C" int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
                              const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
-                             float* alphas, int32_t* last_ids, fg_stream_t stream) {
-  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, render, alphas,
+                             float* alphas, int32_t* last_ids, const fg_raster_config* config, fg_stream_t stream) {
+  return raster_fwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, render, alphas,
                         last_ids, Composite{nullptr, 0, nullptr}, stream);
 }
 
 extern "C" int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
                              const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                              const int32_t* last_ids, const float* v_render, const float* v_alphas,
-                             float* v_splats, fg_stream_t stream) {
-  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                             float* v_splats, const fg_raster_config* config, fg_stream_t stream) {
+  return raster_bwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_render, v_alphas, v_splats, Composite{nullptr, 0, nullptr}, stream);
 }
 
 extern "C" int fg_raster_composite_fwd(int channels, int width, int height, int tile_size, const float* splats,
                                        const int32_t* tile_offsets, const int32_t* flatten_ids,
                                        const float* background, int n_clamp, float* image, float* alphas,
-                                       int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream) {
-  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
+                                       int32_t* last_ids, uint8_t* clamp_mask, const fg_raster_config* config,
+                                       fg_stream_t stream) {
+  return raster_fwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
                         last_ids, Composite{background, n_clamp, clamp_mask}, stream);
 }
 
@@ -1827,45 +1820,62 @@ extern "C" int fg_raster_composite_bwd(int channels, int width, int height, int 
                                        const int32_t* tile_offsets, const int32_t* flatten_ids,
                                        const float* background, int n_clamp, const uint8_t* clamp_mask,
                                        const float* alphas, const int32_t* last_ids, const float* v_image,
-                                       const float* v_alphas, float* v_splats, fg_stream_t stream) {
-  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                                       const float* v_alphas, float* v_splats, const fg_raster_config* config,
+                                       fg_stream_t stream) {
+  return raster_bwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
                         stream);
 }
 
 // ---- job lists ---------------------------------------------------------------------------------
-extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size) {
+extern "C" void fg_raster_config_init(fg_raster_config* c) {
+  if (!c) return;
+  c->size = (int32_t)sizeof(fg_raster_config);
+  c->ppt_fwd = c->ppt_bwd = 0;
+  c->tile_order = -1;
+  c->bands_nx = 0;
+  c->tail4_fwd = c->tail2_fwd = c->tail4_bwd = c->tail2_bwd = -1;
+  c->split4_fwd = c->split2_fwd = c->split4_bwd = c->split2_bwd = -1;
+  c->use_liveness = 1;
+  c->seg_parts = c->seg_tail = c->seg_parts2 = c->seg_tail2 = -1;
+  c->debug_only_xcd = -1;
+  c->debug_k_mod = 0;
+}
+
+extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
   if (width <= 0 || height <= 0 || tile_size != TILE) return 0;
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int n_tiles = tile_w * tile_h;
-  if ((tile_order_mode() & 255) != 2 || (tile_order_mode() >> 8) != 0) return 0;
-  if (mixed_tail_fwd(n_tiles) == 0 && mixed_tail_bwd(n_tiles) == 0) return 0;  // classic launches: no lists
-  return 8 + 8 * (int64_t)jobs_cap(tile_w, tile_h);
+  const Cfg cfg = resolve(config);
+  if ((tile_order_mode(cfg) & 255) != 2 || (tile_order_mode(cfg) >> 8) != 0) return 0;
+  if (mixed_tail_fwd(cfg, n_tiles) == 0 && mixed_tail_bwd(cfg, n_tiles) == 0) return 0;  // classic launches: no lists
+  return 8 + 8 * (int64_t)jobs_cap(cfg, tile_w, tile_h);
 }
 
 extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
                                     int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
-                                    fg_stream_t stream) {
+                                    const fg_raster_config* config, fg_stream_t stream) {
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!tile_offsets) return FG_ERR_INVALID_ARG;
   if (!jobs_fwd && !jobs_bwd) return FG_OK;
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int n_tiles = tile_w * tile_h;
-  const int tf = mixed_tail_fwd(n_tiles), tb = mixed_tail_bwd(n_tiles);
-  const int sf = raster_split("FG_RASTER_SPLIT_FWD", FG_SPLIT4_FWD, FG_SPLIT2_FWD);
-  const int sb = raster_split("FG_RASTER_SPLIT_BWD", FG_SPLIT4_BWD, FG_SPLIT2_BWD);
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(tile_w, tile_h, tf) / 8, 0, 0, 0, 0};
+  const Cfg cfg = resolve(config);
+  const int tf = mixed_tail_fwd(cfg, n_tiles), tb = mixed_tail_bwd(cfg, n_tiles);
+  const int sf = raster_split(cfg.split4_fwd, cfg.split2_fwd, FG_SPLIT4_FWD, FG_SPLIT2_FWD);
+  const int sb = raster_split(cfg.split4_bwd, cfg.split2_bwd, FG_SPLIT4_BWD, FG_SPLIT2_BWD);
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(cfg, tile_w, tile_h, tf) / 8, 0, 0, 0, 0};
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
-  const bool shares = bwd_list_shares && tb > 0 && seg_parts(n_tiles) > 1;
-  const int st = seg_tail_fit(tile_w, tile_h, seg_parts(n_tiles), seg_tail(n_tiles));
-  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(tile_w, tile_h, seg_parts(n_tiles), st, true) / 8,
-                                          seg_parts(n_tiles), st, seg_parts2(), seg_tail2() < st ? seg_tail2() : st}
-                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
-  hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h,
-                     band_nx(tile_w, tile_h),
-                     jobs_cap(tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
+  const int sp = seg_parts(cfg, n_tiles);
+  const bool shares = bwd_list_shares && tb > 0 && sp > 1;
+  const int st = seg_tail_fit(cfg, tile_w, tile_h, sp, seg_tail(cfg, n_tiles));
+  const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(cfg, tile_w, tile_h, sp, st, true) / 8, sp, st,
+                                          seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st}
+                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
+  hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h, band_nx(cfg),
+                     jobs_cap(cfg, tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -1874,16 +1884,19 @@ extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, float* image, float* alphas,
                                   int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                                  float* zero_buf, int64_t zero_floats, fg_stream_t stream) {
-  return raster_fwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
+                                  float* zero_buf, int64_t zero_floats, const fg_raster_config* config,
+                                  fg_stream_t stream) {
+  return raster_fwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
                         last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt, live_words,
                         zero_buf, (long long)zero_floats);
 }
 
-extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects) {
+extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects,
+                                             const fg_raster_config* config) {
   if (channels != 3 || width <= 0 || height <= 0 || tile_size != TILE || n_isects <= 0) return 0;
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
-  if (seg_parts(n_tiles) <= 1 || mixed_tail_bwd(n_tiles) == 0 || mixed_tail_fwd(n_tiles) == 0) return 0;
+  const Cfg cfg = resolve(config);
+  if (seg_parts(cfg, n_tiles) <= 1 || mixed_tail_bwd(cfg, n_tiles) == 0 || mixed_tail_fwd(cfg, n_tiles) == 0) return 0;
   return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
 }
 
@@ -1892,8 +1905,9 @@ extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_
                                   const float* background, int n_clamp, const uint8_t* clamp_mask,
                                   const float* alphas, const int32_t* last_ids, const float* v_image,
                                   const float* v_alphas, float* v_splats, const float* seg_ckpt,
-                                  const float* image, const uint32_t* live_words, fg_stream_t stream) {
-  return raster_bwd_any(channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
+                                  const float* image, const uint32_t* live_words, const fg_raster_config* config,
+                                  fg_stream_t stream) {
+  return raster_bwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, alphas, last_ids,
                         v_image, v_alphas, v_splats, Composite{background, n_clamp, const_cast<uint8_t*>(clamp_mask)},
                         stream, jobs, seg_ckpt, image, live_words);
 }

@@ -54,30 +54,80 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
   return v;
 }
 
-// ---- count (SCATTER = false) / scatter (SCATTER = true) -------------------------------------------
-// Workgroup (xcd = blockIdx % 8, chunk = blockIdx / 8): the chunk's 4096 Gaussians, clipped to the XCD's
-// band of tile rows.  A wavefront reads 64 rectangles per round, keeps the ones that reach the band in
+// ---- count ------------------------------------------------------------------------------------------
+// Workgroup (xcd = blockIdx % 8, chunk = blockIdx / 8): per tile of the XCD's band, how many of the chunk's
+// 4096 rectangles cover it.  No pair is enumerated: every rectangle (clipped to the band) adds +1 / -1 at
+// its four corners of an LDS grid and two prefix sums (along x, then along y) turn the corners into counts
+// -- work per rectangle, not per (rectangle, tile) pair.
+__global__ void __launch_bounds__(TB_BLOCK)
+tb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, uint32_t* __restrict__ table,
+                uint32_t* __restrict__ ticket) {
+  extern __shared__ int32_t s_grid[];  // [(rows + 1)][tile_w + 1] corner marks -> counts
+  const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+  const Rows br = band_rows(xcd, tile_h);
+  const int nr = br.r1 - br.r0, gw = tile_w + 1, T = tile_w * tile_h;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;  // for the scan kernel behind this one
+  if (nr <= 0) return;
+  for (int i = threadIdx.x; i < (nr + 1) * gw; i += TB_BLOCK) s_grid[i] = 0;
+  __syncthreads();
+  const int g0 = chunk * TB_CHUNK + threadIdx.x;
+  int2 rc[TB_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < TB_ROUNDS; ++r) rc[r] = (g0 + r * TB_BLOCK < N) ? rects[g0 + r * TB_BLOCK] : make_int2(0, 0);
+#pragma unroll
+  for (int r = 0; r < TB_ROUNDS; ++r) {
+    const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
+    const int ya = max(y0, br.r0) - br.r0, yb = min(y0 + h, br.r1) - br.r0;
+    if (w > 0 && yb > ya) {
+      atomicAdd(&s_grid[ya * gw + x0], 1);
+      atomicAdd(&s_grid[ya * gw + x0 + w], -1);
+      atomicAdd(&s_grid[yb * gw + x0], -1);
+      atomicAdd(&s_grid[yb * gw + x0 + w], 1);
+    }
+  }
+  __syncthreads();
+  // along x: wavefront w takes rows w, w + 4, ...; 64 cells per step with a running carry
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  for (int row = wave; row < nr; row += TB_BLOCK / 64) {
+    int carry = 0;
+    for (int x = 0; x < tile_w; x += 64) {
+      const int v = x + lane < tile_w ? s_grid[row * gw + x + lane] : 0;
+      const int incl = (int)wave_incl_scan_u32((uint32_t)v, lane) + carry;
+      if (x + lane < tile_w) s_grid[row * gw + x + lane] = incl;
+      carry = __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+  __syncthreads();
+  // along y, and out: thread = column
+  uint32_t* out = table + (size_t)chunk * T + br.r0 * tile_w;
+  for (int x = threadIdx.x; x < tile_w; x += TB_BLOCK) {
+    int run = 0;
+    for (int row = 0; row < nr; ++row) {
+      run += s_grid[row * gw + x];
+      out[row * tile_w + x] = (uint32_t)run;
+    }
+  }
+}
+
+// ---- scatter ----------------------------------------------------------------------------------------
+// Workgroup (xcd = blockIdx % 8, chunk = blockIdx / 8): the (depth bits, id) pair of every (Gaussian, tile)
+// pair of the chunk's 4096 Gaussians inside the XCD's band of tile rows, written to the tile's segment; the
+// slot comes from an LDS cursor per tile (tile start + the chunks before this one, from the scanned table).  A wavefront reads 64 rectangles per round, keeps the ones that reach the band in
 // a queue (7 of 8 do not) and, whenever 64 are queued, walks their (Gaussian, tile) pairs 64 at a time:
 // every lane finds the owner of its slot by binary search over the wave's exclusive counts.
-template <bool SCATTER>
 __global__ void __launch_bounds__(TB_BLOCK)
-tb_enum_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w, int tile_h,
-               uint32_t* __restrict__ table, const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ pairs,
-               long long capacity, uint32_t* __restrict__ ticket) {
-  extern __shared__ uint32_t s_cnt[];  // [tiles of the band]: counts, or cursors into the tile segments
+tb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w, int tile_h,
+               const uint32_t* __restrict__ table, const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ pairs,
+               long long capacity) {
+  extern __shared__ uint32_t s_cnt[];  // [tiles of the band]: cursors into the tile segments
   __shared__ int4 s_q[TB_BLOCK / 64][128];
   __shared__ int32_t s_excl[TB_BLOCK / 64][64];
   const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
   const Rows br = band_rows(xcd, tile_h);
   const int tb = br.r0 * tile_w, nb = (br.r1 - br.r0) * tile_w, T = tile_w * tile_h;
-  if (!SCATTER && blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;  // for the scan kernel behind this one
-  uint32_t* row = table + (size_t)chunk * T + tb;
-  if (SCATTER) {
-    if ((long long)tile_offsets[T] > capacity) return;  // the guess was too small: the host repeats the call
-    for (int i = threadIdx.x; i < nb; i += TB_BLOCK) s_cnt[i] = (uint32_t)tile_offsets[tb + i] + row[i];
-  } else {
-    for (int i = threadIdx.x; i < nb; i += TB_BLOCK) s_cnt[i] = 0;
-  }
+  const uint32_t* row = table + (size_t)chunk * T + tb;
+  if ((long long)tile_offsets[T] > capacity) return;  // the guess was too small: the host repeats the call
+  for (int i = threadIdx.x; i < nb; i += TB_BLOCK) s_cnt[i] = (uint32_t)tile_offsets[tb + i] + row[i];
   __syncthreads();
 
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
@@ -111,12 +161,8 @@ tb_enum_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict
         ty += ((ty + 1) * ow <= t);
         const int tx = t - ty * ow;
         const int local = ((o.z >> 16) + ty - br.r0) * tile_w + (o.z & 0xFFFF) + tx;
-        if (SCATTER) {
-          const uint32_t pos = atomicAdd(&s_cnt[local], 1u);
-          pairs[pos] = ((uint64_t)(uint32_t)o.y << 32) | (uint64_t)(uint32_t)o.x;
-        } else {
-          atomicAdd(&s_cnt[local], 1u);
-        }
+        const uint32_t pos = atomicAdd(&s_cnt[local], 1u);
+        pairs[pos] = ((uint64_t)(uint32_t)o.y << 32) | (uint64_t)(uint32_t)o.x;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -143,7 +189,7 @@ tb_enum_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict
       hit = w > 0 && yb > ya;
       e = make_int4(g, 0, (rc.x & 0xFFFF) | (ya << 16), w | ((yb - ya) << 16));
     }
-    if (SCATTER && hit) e.y = (int)depth_keys[g];
+    if (hit) e.y = (int)depth_keys[g];
     const uint64_t bal = __ballot(hit);
     if (hit) q[qn + __popcll(bal & lt_mask)] = e;
     qn += __popcll(bal);
@@ -154,58 +200,58 @@ tb_enum_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict
     }
   }
   if (qn > 0) drain(qn);
-  __syncthreads();
-  if (!SCATTER)
-    for (int i = threadIdx.x; i < nb; i += TB_BLOCK) row[i] = s_cnt[i];
 }
 
 // ---- scan: per tile the exclusive prefix over chunks (in place) and the tile's count; the last
 // workgroup to finish turns the counts into tile_offsets[T + 1] and publishes the list length ---------
+// 16 tiles x 16 chunk slices per workgroup: the walk over a tile's column of the table is a chain of
+// memory round trips, so it is cut into 16 short ones (4 tiles x 64: 38 us; this: see profiles/).
+constexpr int TS_TILES = 16, TS_SLICES = TB_BLOCK / TS_TILES;
 __global__ void __launch_bounds__(TB_BLOCK)
 tb_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table, int32_t* __restrict__ tile_offsets,
                uint32_t* __restrict__ ticket, int64_t* __restrict__ count_out) {
-  __shared__ uint32_t part[TB_BLOCK / 64][64];
+  __shared__ uint32_t part[TS_SLICES][TS_TILES];
   __shared__ uint32_t wave_tot[TB_BLOCK / 64];
   __shared__ int is_last;
-  const int tl = threadIdx.x & 63, qd = threadIdx.x >> 6, t = blockIdx.x * 64 + tl;
-  const int cq = (n_chunks + 3) / 4, c0 = min(qd * cq, n_chunks), c1 = min(c0 + cq, n_chunks);
+  const int tl = threadIdx.x % TS_TILES, qd = threadIdx.x / TS_TILES, t = blockIdx.x * TS_TILES + tl;
+  const int cq = (n_chunks + TS_SLICES - 1) / TS_SLICES, c0 = min(qd * cq, n_chunks), c1 = min(c0 + cq, n_chunks);
+  constexpr int U = 16;
+  uint32_t v[U];
   uint32_t s = 0;
+  // (slices of up to U chunks stay in registers between the two phases; longer ones are re-read)
+  const bool small = c1 - c0 <= U;
   if (t < T) {
-    int c = c0;
-    for (; c + 8 <= c1; c += 8) {
-      uint32_t v[8];
+    if (small) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(c + u) * T + t];
+      for (int u = 0; u < U; ++u) v[u] = c0 + u < c1 ? table[(size_t)(c0 + u) * T + t] : 0u;
 #pragma unroll
-      for (int u = 0; u < 8; ++u) s += v[u];
+      for (int u = 0; u < U; ++u) s += v[u];
+    } else {
+      for (int c = c0; c < c1; ++c) s += table[(size_t)c * T + t];
     }
-    for (; c < c1; ++c) s += table[(size_t)c * T + t];
   }
   part[qd][tl] = s;
   __syncthreads();
   uint32_t run = 0, total = 0;
 #pragma unroll
-  for (int k = 0; k < TB_BLOCK / 64; ++k) {
+  for (int k = 0; k < TS_SLICES; ++k) {
     const uint32_t p = part[k][tl];
     if (k < qd) run += p;
     total += p;
   }
   if (t < T) {
-    int c = c0;
-    for (; c + 8 <= c1; c += 8) {
-      uint32_t v[8];
+    if (small) {
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = table[(size_t)(c + u) * T + t];
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        table[(size_t)(c + u) * T + t] = run;
+      for (int u = 0; u < U; ++u) {
+        if (c0 + u < c1) table[(size_t)(c0 + u) * T + t] = run;
         run += v[u];
       }
-    }
-    for (; c < c1; ++c) {
-      const uint32_t v = table[(size_t)c * T + t];
-      table[(size_t)c * T + t] = run;
-      run += v;
+    } else {
+      for (int c = c0; c < c1; ++c) {
+        const uint32_t x = table[(size_t)c * T + t];
+        table[(size_t)c * T + t] = run;
+        run += x;
+      }
     }
     if (qd == 0) tile_offsets[t + 1] = (int32_t)total;  // the tile's count, for the pass below
   }
@@ -306,24 +352,32 @@ __device__ __forceinline__ void block_min_max(uint32_t lo, uint32_t hi, uint32_t
   kmax = max(max(red[4], red[5]), max(red[6], red[7]));
   __syncthreads();
 }
-// position of element i among the entries with the same depth bits (they are adjacent after the sort, in
-// the order they arrived): the number of smaller ids in its run.  Ties are rare (identical depth bits).
+// Position of element i inside its RUN -- the entries whose sorted key bits (depth bits minus the tile's
+// smallest, shifted right by `low`) are equal; they are adjacent after the passes, in arrival order -- by the
+// full (depth bits, id) order: the number of smaller elements of the run.  Runs are exact depth ties when
+// every differing bit was sorted (low = 0) and short groups otherwise (see tb_sort_kernel).
 template <typename Ptr>
-__device__ __forceinline__ int tie_position(Ptr cur, int n, int i, uint64_t e) {
-  const uint32_t key = (uint32_t)(e >> 32), id = (uint32_t)e;
-  const bool left = i > 0 && (uint32_t)(cur[i - 1] >> 32) == key;
-  const bool right = i + 1 < n && (uint32_t)(cur[i + 1] >> 32) == key;
+__device__ __forceinline__ int run_position(Ptr cur, int n, int i, uint64_t e, uint32_t kmin, int low) {
+  const uint32_t key = ((uint32_t)(e >> 32) - kmin) >> low;
+  const bool left = i > 0 && (((uint32_t)(cur[i - 1] >> 32) - kmin) >> low) == key;
+  const bool right = i + 1 < n && (((uint32_t)(cur[i + 1] >> 32) - kmin) >> low) == key;
   if (!left && !right) return i;
   int a = i;
-  while (a > 0 && (uint32_t)(cur[a - 1] >> 32) == key) --a;
+  while (a > 0 && (((uint32_t)(cur[a - 1] >> 32) - kmin) >> low) == key) --a;
   int smaller = 0;
   for (int j = a; j < n; ++j) {
     const uint64_t o = cur[j];
-    if ((uint32_t)(o >> 32) != key) break;
-    smaller += (uint32_t)o < id;
+    if ((((uint32_t)(o >> 32) - kmin) >> low) != key) break;
+    smaller += o < e;
   }
   return a + smaller;
 }
+// How many key bits the passes sort: all `bits` that differ inside the tile up to 16 (two 8-bit passes); of
+// more only the TOP 16 -- the rest is settled by run_position.  A tile of ~600 entries spread over 65536
+// values of the sorted bits has runs of one or two entries; the 1M / 1080p scene has 24 differing bits, i.e.
+// two passes instead of three.  (Entries crowded into few values -- a wall plus one far outlier -- make long
+// runs: slower, never wrong.)
+__device__ __forceinline__ int unsorted_low_bits(int bits) { return bits > 16 ? bits - 16 : 0; }
 
 // A tile too long for LDS: the same passes through global memory (src <-> alt, both L2-resident), two
 // sweeps per pass (per-wave digit counts; stable slots).  One workgroup; rare (thousands of entries).
@@ -340,12 +394,12 @@ __device__ void sort_tile_global(uint64_t* a, uint64_t* b, int n, int32_t* ids_o
   uint32_t kmin, kmax;
   block_min_max(lo, hi, red, kmin, kmax);
   const uint32_t range = kmax - kmin;
-  const int bits = range ? 32 - __builtin_clz(range) : 0, passes = (bits + 7) / 8;
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
   const int span = ((n + 4 * 64 - 1) / (4 * 64)) * 64;  // a wavefront's contiguous share
   const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
   uint64_t* src = a;
   uint64_t* dst = b;
-  int first = 0;
+  int first = low;
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
@@ -373,7 +427,7 @@ __device__ void sort_tile_global(uint64_t* a, uint64_t* b, int n, int32_t* ids_o
   }
   for (int i = threadIdx.x; i < n; i += TB_BLOCK) {
     const uint64_t e = src[i];
-    ids_out[tie_position(src, n, i, e)] = (int32_t)(uint32_t)e;
+    ids_out[run_position(src, n, i, e, kmin, low)] = (int32_t)(uint32_t)e;
   }
 }
 
@@ -381,7 +435,7 @@ __device__ void sort_tile_global(uint64_t* a, uint64_t* b, int n, int32_t* ids_o
 // and one LDS image: per pass every wavefront counts the digits of its contiguous share, the counts
 // become start slots (digit-major, wavefronts in order: stable), and every element is written to its
 // slot of the image and read back in order.  Keys are depth bits minus the tile's smallest: the passes
-// cover only the bits that differ inside the tile (24 -> 3 passes on the 1M / 1080p scene).
+// cover only bits that differ inside the tile, at most the top 16 of them (unsorted_low_bits).
 __global__ void __launch_bounds__(TB_BLOCK)
 tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ pairs,
                uint64_t* __restrict__ pairs_alt, long long capacity, int32_t* __restrict__ flatten_ids) {
@@ -421,8 +475,8 @@ tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   uint32_t kmin, kmax;
   block_min_max(lo, hi, red, kmin, kmax);
   const uint32_t range = kmax - kmin;
-  const int bits = range ? 32 - __builtin_clz(range) : 0, passes = (bits + 7) / 8;
-  int first = 0;
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
+  int first = low;
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
@@ -434,13 +488,30 @@ tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
       if (q < R && ibase + q * 64 < n) atomicAdd(&wave_cnt[wave][(((uint32_t)(e[q] >> 32) - kmin) >> first) & mask], 1u);
     __syncthreads();
     digit_starts(wave_cnt, scan_tmp);
+    // stable slots: the group's lowest lane advances the wave's cursor of the digit by the group size; all
+    // the atomics of a lane are issued before any result is consumed (same-address LDS atomics of one
+    // wavefront retire in issue order): one LDS round trip on the chain instead of R
+    uint32_t rk[TB_SORT_KPT];
 #pragma unroll
     for (int q = 0; q < TB_SORT_KPT; ++q) {
+      rk[q] = 0;
       if (q < R) {
         const bool in = ibase + q * 64 < n;
         const unsigned d = (((uint32_t)(e[q] >> 32) - kmin) >> first) & mask;
-        const uint32_t slot = stable_slot(d, nbits, in, wave_cnt[wave], lane, lt_mask);
-        if (in) img[slot] = e[q];
+        const uint64_t peers = same_digit_lanes(d, nbits, in);
+        const uint32_t leader = in ? (uint32_t)__builtin_ctzll(peers) : (uint32_t)lane;
+        uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+        if (in && leader == (uint32_t)lane) r = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(peers));
+        rk[q] = r | (leader << 16);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < TB_SORT_KPT; ++q) {
+      if (q < R) {
+        const uint32_t leader = rk[q] >> 16;
+        const uint32_t before = (uint32_t)__shfl((int)(rk[q] & 0xFFFFu), (int)leader);
+        const uint32_t slot = (leader == (uint32_t)lane) ? before : before + (rk[q] & 0xFFFFu);
+        if (ibase + q * 64 < n) img[slot] = e[q];
       }
     }
     __syncthreads();
@@ -459,7 +530,7 @@ tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   for (int q = 0; q < TB_SORT_KPT; ++q) {
     if (q < R) {
       const int i = ibase + q * 64;
-      if (i < n) flatten_ids[off + tie_position(img, n, i, e[q])] = (int32_t)(uint32_t)e[q];
+      if (i < n) flatten_ids[off + run_position(img, n, i, e[q], kmin, low)] = (int32_t)(uint32_t)e[q];
     }
   }
 }
@@ -488,12 +559,11 @@ extern "C" int fg_tilebin_count(int N, const int32_t* tile_rects, int tile_w, in
   const int T = tile_w * tile_h, nc = n_chunks_of(N);
   uint32_t* table = static_cast<uint32_t*>(workspace);
   uint32_t* ticket = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + al256((size_t)nc * T * 4));
-  const size_t lds = (size_t)band_tiles_max(tile_w, tile_h) * 4;
-  hipLaunchKernelGGL(tb_enum_kernel<false>, dim3(8 * nc), dim3(TB_BLOCK), lds, s, N,
-                     reinterpret_cast<const int2*>(tile_rects), nullptr, tile_w, tile_h, table, nullptr, nullptr, 0ll,
-                     ticket);
-  hipLaunchKernelGGL(tb_scan_kernel, dim3((T + 63) / 64), dim3(TB_BLOCK), 0, s, T, nc, table, tile_offsets, ticket,
-                     count_out);
+  const size_t lds = (size_t)((tile_h + 7) / 8 + 1) * (tile_w + 1) * 4;
+  hipLaunchKernelGGL(tb_count_kernel, dim3(8 * nc), dim3(TB_BLOCK), lds, s, N, reinterpret_cast<const int2*>(tile_rects),
+                     tile_w, tile_h, table, ticket);
+  hipLaunchKernelGGL(tb_scan_kernel, dim3((T + TS_TILES - 1) / TS_TILES), dim3(TB_BLOCK), 0, s, T, nc, table,
+                     tile_offsets, ticket, count_out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -515,9 +585,9 @@ extern "C" int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t*
   uint64_t* pairs_alt = reinterpret_cast<uint64_t*>(static_cast<char*>(workspace) + al256((size_t)capacity * 8));
   uint32_t* table = static_cast<uint32_t*>(const_cast<void*>(count_workspace));
   const size_t lds = (size_t)band_tiles_max(tile_w, tile_h) * 4;
-  hipLaunchKernelGGL(tb_enum_kernel<true>, dim3(8 * nc), dim3(TB_BLOCK), lds, s, N,
+  hipLaunchKernelGGL(tb_scatter_kernel, dim3(8 * nc), dim3(TB_BLOCK), lds, s, N,
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, table, tile_offsets, pairs,
-                     (long long)capacity, nullptr);
+                     (long long)capacity);
   hipLaunchKernelGGL(tb_sort_kernel, dim3(8 * band_tiles_max(tile_w, tile_h)), dim3(TB_BLOCK), 0, s, tile_w, tile_h,
                      tile_offsets, pairs, pairs_alt, (long long)capacity, flatten_ids);
   FG_RETURN_IF_LAUNCH_FAILED();

@@ -28,7 +28,8 @@ from .viewdp import FlatGaussianParams
 
 class GraphedRaster:
     def __init__(self, params: FlatGaussianParams, width: int, height: int, sh_degree: int = 3,
-                 render_mode: str = "RGB", capacity: Optional[int] = None, headroom: float = 1.5):  # fmt: skip
+                 render_mode: str = "RGB", capacity: Optional[int] = None, headroom: float = 1.5,
+                 ctx: Optional[ops.RasterContext] = None):  # fmt: skip
         self.params, self.width, self.height = params, int(width), int(height)
         self.sh_degree, self.render_mode, self.headroom = sh_degree, render_mode, float(headroom)
         dev = params.flat.device
@@ -39,10 +40,11 @@ class GraphedRaster:
         self.capacity = capacity
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.render = self.alpha = self.overflow = None
+        self.ctx = ctx if ctx is not None else ops.current()  # launch policy, list capacities, hooks
 
     # one eager (exact) step; also measures the list length for the capacity
     def _eager(self):
-        with self.params.direct_grads():
+        with ops.use(self.ctx), self.params.direct_grads():
             r, a, info = rasterization(*self.params.raster_inputs(), self.viewmat, self.K, self.width, self.height,
                                        sh_degree=self.sh_degree, render_mode=self.render_mode, packed=False,
                                        absgrad=True)  # fmt: skip
@@ -53,7 +55,7 @@ class GraphedRaster:
         import gc
 
         gc.collect()  # drop unreachable autograd graphs (reference cycles) that still hold the parameters
-        ops.static_capacity = self.capacity
+        self.ctx.static_capacity = self.capacity
         try:
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
@@ -64,12 +66,12 @@ class GraphedRaster:
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.render, self.alpha = self._run_static()
-                self.overflow = ops.last_overflow
+                self.overflow = self.ctx.last_overflow
         finally:
-            ops.static_capacity = None
+            self.ctx.static_capacity = None
 
     def _run_static(self):
-        with self.params.direct_grads():
+        with ops.use(self.ctx), self.params.direct_grads():
             r, a, _ = rasterization(*self.params.raster_inputs(), self.viewmat, self.K, self.width, self.height,
                                     sh_degree=self.sh_degree, render_mode=self.render_mode, packed=False,
                                     absgrad=True)  # fmt: skip

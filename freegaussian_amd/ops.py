@@ -9,6 +9,7 @@ from __future__ import annotations
 from typing import Optional, Tuple
 
 import os
+import threading
 import time
 
 import torch
@@ -51,7 +52,151 @@ class StageTimer:
         return {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in self.events.items()}
 
 
-stage_timer: Optional[StageTimer] = None
+def _env_flag(name: str, default: bool) -> bool:
+    v = os.environ.get(name)
+    return default if v is None else v != "0"
+
+
+def launch_policy(**fields) -> "_lib.RasterConfig":
+    """An ``fg_raster_config`` (include/fgraster.h) with the library's defaults and ``fields`` set, e.g.
+    ``launch_policy(ppt_fwd=1, ppt_bwd=1)``, ``launch_policy(seg_parts=4)``."""
+    cfg = _lib.RasterConfig.defaults()
+    for k, v in fields.items():
+        if k not in _lib.RasterConfig.FIELDS:
+            raise ValueError(f"unknown launch-policy field {k!r}")
+        setattr(cfg, k, int(v))
+    return cfg
+
+
+def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
+    """The FG_RASTER_* / FG_TILE_ORDER / FG_DEBUG_* variables (read HERE, once per context -- the library
+    reads no environment) as an ``fg_raster_config``.  FG_RASTER_PPT_FWD / _BWD = 1|2|4;
+    FG_RASTER_TAIL_FWD / _BWD = "t4[,t2]"; FG_RASTER_SPLIT_FWD / _BWD = "a4[,a2]"; FG_RASTER_BANDS = 1|2|4|8;
+    FG_RASTER_LIVE = 0; FG_RASTER_SEG_PARTS, FG_RASTER_SEG_TAIL = n; FG_RASTER_SEG_GRADE = "parts2,tail2";
+    FG_TILE_ORDER = rows|bands|cols|split|x|y; FG_DEBUG_ONLY_XCD = 0..7; FG_DEBUG_K_MOD = m."""
+    env = os.environ if env is None else env
+    f = {}
+
+    def pair(name, a, b):
+        v = env.get(name)
+        if v is not None:
+            parts = v.split(",")
+            f[a] = int(parts[0])
+            f[b] = int(parts[1]) if len(parts) > 1 else 0
+
+    for name, field in (("FG_RASTER_PPT_FWD", "ppt_fwd"), ("FG_RASTER_PPT_BWD", "ppt_bwd"), ("FG_RASTER_BANDS", "bands_nx"),
+                        ("FG_RASTER_SEG_PARTS", "seg_parts"), ("FG_RASTER_SEG_TAIL", "seg_tail"),
+                        ("FG_DEBUG_ONLY_XCD", "debug_only_xcd"), ("FG_DEBUG_K_MOD", "debug_k_mod")):  # fmt: skip
+        if env.get(name) is not None:
+            f[field] = int(env[name])
+    pair("FG_RASTER_TAIL_FWD", "tail4_fwd", "tail2_fwd")
+    pair("FG_RASTER_TAIL_BWD", "tail4_bwd", "tail2_bwd")
+    pair("FG_RASTER_SPLIT_FWD", "split4_fwd", "split2_fwd")
+    pair("FG_RASTER_SPLIT_BWD", "split4_bwd", "split2_bwd")
+    pair("FG_RASTER_SEG_GRADE", "seg_parts2", "seg_tail2")
+    if env.get("FG_RASTER_LIVE") == "0":
+        f["use_liveness"] = 0
+    if env.get("FG_TILE_ORDER"):
+        f["tile_order"] = {"r": 0, "b": 1, "c": 2, "s": 3, "x": 4, "y": 5}.get(env["FG_TILE_ORDER"][0], 1)
+    return launch_policy(**f)
+
+
+class RasterContext:
+    """Everything a call of the raster path reads besides its arguments: the launch policy handed to the C
+    ABI, the host-side switches, the optional hooks (stage timer, gradient buffers, colour-gradient sink,
+    static list capacity) and the list-capacity history.  One per model / stream of work; nothing here is
+    module state.  A call uses the context that is current on its thread (``with ops.use(ctx):`` or the
+    ``ctx=`` argument of ``rasterization``; ``ops.default_context`` otherwise) and every autograd node keeps
+    the context of its forward, so the backward -- run by autograd's own thread -- sees the same one."""
+
+    def __init__(self, policy=None, env=None):
+        e = os.environ if env is None else env
+        self.policy = policy if policy is not None else launch_policy_from_env(e)
+        self.stage_timer: Optional[StageTimer] = None
+        # list capacity: guesses per (device, N, tile grid) and the lengths of the last calls
+        self.speculative_binning = e.get("FG_SPECULATIVE_BINNING", "1") != "0"
+        self.static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
+        self.last_overflow: Optional[torch.Tensor] = None
+        self.isect_capacity: dict = {}
+        self.isect_recent: dict = {}
+        self.capacity_redos = 0  # times a speculative list turned out too small and the fill was repeated
+        # Footprint rectangles (FG_TIGHT_RECTS=0 turns them off): the fused preprocess passes also write the
+        # depth sort keys and, per Gaussian, the tile rectangle shrunk to the tiles where the splat can reach
+        # alpha >= 1/255; the raster lists are then binned from those.  Same images and gradients, ~30% fewer
+        # list entries on the 1M / 1080p scene.  The reference-exact lists (info["flatten_ids"] etc.) are
+        # rebuilt on demand from the radius boxes.
+        self.tight_rects = e.get("FG_TIGHT_RECTS", "1") != "0"
+        # FG_BANDED_BINNING=0: the depth-first binning of rounds 1-2 (fg_bin_prepare_keys + fg_bin_emit_sort)
+        # instead of the banded count / scatter / per-tile sort (fg_tilebin_*): identical lists (A/B, and the
+        # fallback beyond fg_tilebin_supported)
+        self.banded_binning = e.get("FG_BANDED_BINNING", "1") != "0"
+        # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
+        # store into pinned host memory (A/B)
+        self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
+        # FG_FILL_IN_FORWARD=0: zero the backward's record-gradient array with a fill launch at the head of
+        # the backward instead of in passing in the mixed forward launch (A/B)
+        self.fill_in_forward = e.get("FG_FILL_IN_FORWARD", "1") != "0"
+        # Optional two-stream forward (FG_OVERLAP_PACK=1, off by default): the projection (whose outputs the
+        # binning needs) runs on the current stream, the colour + record half (HBM-bound, 300 B per
+        # Gaussian) on a side stream, concurrently with the binning kernels.  Measured on MI355X at 1M /
+        # 1080p (profiles/r01_two_stream_forward.md): no gain -- the 3900-workgroup colour kernel crowds the
+        # small sort kernels out (fg_bin_prepare 0.114 -> 0.153 ms) by as much as it hides.
+        self.overlap_pack = e.get("FG_OVERLAP_PACK", "0") == "1"
+        # Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
+        # written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
+        # The kernels overwrite their outputs densely, so the buffer needs no zeroing.
+        self.grad_alloc = None
+        # Optional hook for the factored view-DP exchange (viewdp.FlatGaussianParams.factored_exchange): when
+        # set, the fused backward of an SH-coloured view hands the clamp-masked colour gradient g[N,3] (+ what
+        # is needed to rebuild the coefficient gradient) to the sink instead of writing the dense [N,K,3]
+        # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
+        self.color_grad_sink = None
+
+    def cfg(self) -> int:
+        """Address of the launch policy (the `const fg_raster_config*` argument)."""
+        return self.policy.ptr()
+
+
+_default_context: Optional[RasterContext] = None
+_tls = threading.local()
+
+
+def _get_default() -> RasterContext:
+    global _default_context
+    if _default_context is None:
+        _default_context = RasterContext()
+    return _default_context
+
+
+def current() -> RasterContext:
+    """The context of the calling thread (innermost ``use``), else the process default."""
+    stack = getattr(_tls, "stack", None)
+    return stack[-1] if stack else _get_default()
+
+
+class use:
+    """``with ops.use(ctx): ...`` -- calls of the raster path on this thread read ``ctx``."""
+
+    def __init__(self, ctx: Optional[RasterContext]):
+        self.ctx = ctx
+
+    def __enter__(self):
+        if self.ctx is not None:
+            if not hasattr(_tls, "stack"):
+                _tls.stack = []
+            _tls.stack.append(self.ctx)
+        return self.ctx if self.ctx is not None else current()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            _tls.stack.pop()
+        return False
+
+
+def __getattr__(name):  # ops.default_context: created on first use (it loads the library for the policy)
+    if name == "default_context":
+        return _get_default()
+    raise AttributeError(name)
 
 
 def _call(name: str, *args, on=None, stage=None) -> None:
@@ -59,6 +204,7 @@ def _call(name: str, *args, on=None, stage=None) -> None:
     kernels go to (``on``: a torch stream other than the current one; the caller passes its raw
     handle as the entry point's stream argument).  ``stage``: name the time is booked under."""
     fn = getattr(_lib.load(), name)
+    stage_timer = current().stage_timer
     ev = stage_timer.record(stage or name) if stage_timer is not None else None
     if ev:
         ev[0].record(on) if on is not None else ev[0].record()
@@ -84,6 +230,7 @@ class _Project(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, viewmat, K, width, height, eps2d, near, far, radius_clip, tile_size,
                 calc_comp):  # fmt: skip
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         lib = _lib.load()
         N = means.shape[0]
         dev = means.device
@@ -105,7 +252,12 @@ class _Project(torch.autograd.Function):
         return radii, means2d, depths, conics, comp, tiles
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comp, _v_tiles):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _Project._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, _v_radii, v_means2d, v_depths, v_conics, v_comp, _v_tiles):
         lib = _lib.load()
         means, quats, scales, viewmat, K, radii, conics, comp = ctx.saved_tensors
         width, height, eps2d = ctx.args
@@ -146,6 +298,7 @@ def project(means, quats, scales, viewmat, K, width, height, eps2d=0.3, near_pla
 class _SH(torch.autograd.Function):
     @staticmethod
     def forward(ctx, degree, means, viewmat, coeffs, radii):
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         lib = _lib.load()
         N, k_stored = coeffs.shape[0], coeffs.shape[1]
         colors = torch.empty(N, 3, dtype=torch.float32, device=means.device)
@@ -156,7 +309,12 @@ class _SH(torch.autograd.Function):
         return colors
 
     @staticmethod
-    def backward(ctx, v_colors):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _SH._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, v_colors):
         lib = _lib.load()
         means, viewmat, coeffs, radii, colors = ctx.saved_tensors
         N, k_stored = coeffs.shape[0], coeffs.shape[1]
@@ -207,17 +365,6 @@ def isect_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h
     return isect_ids, flatten_ids, offsets
 
 
-# Module-level state below (hooks, caches, timers) is per process and not synchronised: drive one
-# device from one Python thread (autograd's own backward thread only ever reads the hooks).
-# bin_tiles: capacity guesses per (device, N, tile grid)
-speculative_binning = os.environ.get("FG_SPECULATIVE_BINNING", "1") != "0"
-static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
-last_overflow: Optional[torch.Tensor] = None
-_isect_capacity: dict = {}
-_isect_recent: dict = {}  # key -> list lengths of the last calls
-capacity_redos = 0  # times a speculative list turned out too small and emission + sort were repeated
-
-
 def list_capacity_for(recent_lengths) -> int:
     """Speculative list capacity from the list lengths of the last calls of a shape: 25% headroom over the
     heaviest, rounded up to 1/32..1/16 of its magnitude (one allocation size per shape, not one per view)."""
@@ -239,16 +386,20 @@ _COUNT_RING = 256
 _count_ring = None
 _count_ring_np = None
 _count_ring_next = 0
+_count_ring_lock = threading.Lock()
+_count_ring_stream = [None] * _COUNT_RING  # the stream the store into slot i was enqueued on
 
 
 def _count_slot():
     global _count_ring, _count_ring_np, _count_ring_next
-    if _count_ring is None:
-        _count_ring = torch.empty(_COUNT_RING, dtype=torch.int64, pin_memory=True)
-        _count_ring_np = _count_ring.numpy()
-    i = _count_ring_next
-    _count_ring_next = (i + 1) % _COUNT_RING
+    with _count_ring_lock:
+        if _count_ring is None:
+            _count_ring = torch.empty(_COUNT_RING, dtype=torch.int64, pin_memory=True)
+            _count_ring_np = _count_ring.numpy()
+        i = _count_ring_next
+        _count_ring_next = (i + 1) % _COUNT_RING
     _count_ring_np[i] = -1
+    _count_ring_stream[i] = torch.cuda.current_stream()
     return i, _count_ring.data_ptr() + 8 * i
 
 
@@ -267,7 +418,8 @@ def _poll_count(i: int) -> int:
                 return v
         if time.perf_counter() - t0 > 0.02:
             break
-    torch.cuda.current_stream().synchronize()  # not seen within 20 ms: drain the queue and look again
+    # not seen within 20 ms: drain the stream the store was enqueued on (not whatever is current now) and look again
+    (_count_ring_stream[i] or torch.cuda.current_stream()).synchronize()
     v = int(a[i])
     if v < 0:
         raise _lib.FgRasterError("the list length never arrived in pinned host memory (fg_bin_prepare_keys count_out)")
@@ -283,28 +435,10 @@ def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
     return torch.repeat_interleave(tiles, counts, output_size=int(n))
 
 
-# Footprint rectangles (FG_TIGHT_RECTS=0 turns them off): the fused preprocess passes also write the
-# depth sort keys and, per Gaussian, the tile rectangle shrunk to the tiles where the splat can reach
-# alpha >= 1/255; the raster lists are then binned from those (fg_bin_prepare_keys).  Same images and
-# gradients, ~30% fewer list entries on the 1M / 1080p scene.  The reference-exact lists
-# (info["flatten_ids"] etc.) are rebuilt on demand from the radius boxes.
-tight_rects = os.environ.get("FG_TIGHT_RECTS", "1") != "0"
-# FG_BANDED_BINNING=0: the depth-first binning of rounds 1-2 (fg_bin_prepare_keys + fg_bin_emit_sort) instead of
-# the banded count / scatter / per-tile sort (fg_tilebin_*): identical lists (A/B, and the fallback beyond
-# fg_tilebin_supported)
-banded_binning = os.environ.get("FG_BANDED_BINNING", "1") != "0"
-# FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
-# store into pinned host memory (A/B)
-direct_count = os.environ.get("FG_DIRECT_COUNT", "1") != "0"
-# FG_FILL_IN_FORWARD=0: zero the backward's record-gradient array with a fill launch at the head of the
-# backward instead of in passing in the mixed forward launch (A/B)
-fill_in_forward = os.environ.get("FG_FILL_IN_FORWARD", "1") != "0"
-
-
 def _binning_side_outputs(N, tile_size, width, height, dev):
     """(depth_keys, tile_rects) buffers for the preprocess passes, or (None, None)."""
     tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
-    if not tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
+    if not current().tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
         return None, None
     return torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 2, dtype=torch.int32, device=dev)
 
@@ -335,8 +469,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     if N == 0:
         offsets.zero_()
         return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), offsets
-    if keys_rects is not None and banded_binning and lib.fg_tilebin_supported(tile_w, tile_h):
-        return _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+    rctx = current()
+    static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
+    if keys_rects is not None and rctx.banded_binning and lib.fg_tilebin_supported(tile_w, tile_h):
+        return _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -347,7 +483,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     if keys_rects is not None and rects is not None:
         # the list length is also stored straight into pinned host memory by the scan's last workgroup
         # (no copy launch in the stream; not in static-shape mode, which never reads it on the host)
-        count_slot, count_ptr = _count_slot() if static_capacity is None and direct_count else (None, None)
+        count_slot, count_ptr = _count_slot() if static_capacity is None and rctx.direct_count else (None, None)
         _call("fg_bin_prepare_keys", N, _ptr(keys_rects[0]), _ptr(keys_rects[1]), _ptr(order), _ptr(cum), _ptr(rects),
               count_ptr, _ptr(ws), ws.numel(), _stream(), stage="fg_bin_prepare")  # fmt: skip
     elif rects is not None:
@@ -372,7 +508,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         _call("fg_bin_emit_sort_capacity", N, cap, _ptr(means2d), _ptr(radii), _ptr(order), _ptr(cum), _ptr(rects),
               tile_size, tile_w, tile_h, _ptr(tile_keys), _ptr(flatten_ids), _ptr(offsets), _ptr(ws2), ws2.numel(),
               _stream())  # fmt: skip
-        globals()["last_overflow"] = cum[N - 1 :] > cap
+        rctx.last_overflow = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h, keys_rects is not None)
     count_host = ready = None
@@ -381,7 +517,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         count_host.copy_(cum[N - 1 :], non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
-    capacity = _isect_capacity.get(key) if speculative_binning else None
+    capacity = _isect_capacity.get(key) if rctx.speculative_binning else None
     tile_keys = flatten_ids = None
     if capacity is not None:
         tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev) if want_keys else None
@@ -413,7 +549,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
         if capacity is not None:
-            globals()["capacity_redos"] += 1
+            rctx.capacity_redos += 1
         tk = torch.empty(n_isects, dtype=torch.int32, device=dev) if want_keys else None
         ids = torch.empty(n_isects, dtype=torch.int32, device=dev)
         ws3 = torch.empty(int(lib.fg_bin_emit_workspace_bytes(n_isects)), dtype=torch.uint8, device=dev)
@@ -427,7 +563,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
+def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
     """Banded binning (csrc/tilebin.hip: fg_tilebin_count + fg_tilebin_fill), same contract as ``bin_tiles``.
     The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
     from the previous calls of this shape and refilled exactly if the list turned out longer."""
@@ -435,8 +571,9 @@ def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, 
     depth_keys, rects = keys_rects
     n_tiles = tile_w * tile_h
     ws1 = torch.empty(int(lib.fg_tilebin_count_workspace_bytes(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
+    static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     static = static_capacity is not None
-    count_slot, count_ptr = (None, None) if (static or not direct_count) else _count_slot()
+    count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
     _call("fg_tilebin_count", N, _ptr(rects), tile_w, tile_h, _ptr(offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
@@ -454,7 +591,7 @@ def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, 
         # static-shape mode (graphed.GraphedRaster): fixed-size list, no readback; valid iff the count fits
         cap = int(static_capacity)
         flatten_ids = fill(cap)
-        globals()["last_overflow"] = offsets[n_tiles:] > cap
+        rctx.last_overflow = offsets[n_tiles:] > cap
         tk = None  # (keys: tile_keys_from_offsets on demand)
         return (tk, flatten_ids, offsets, None) if defer else (tk, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h, "banded")
@@ -464,7 +601,7 @@ def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, 
         count_host.copy_(offsets[n_tiles:], non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
-    capacity = _isect_capacity.get(key) if speculative_binning else None
+    capacity = _isect_capacity.get(key) if rctx.speculative_binning else None
     flatten_ids = fill(capacity) if capacity is not None else None
 
     def finish():
@@ -484,7 +621,7 @@ def _bin_tiles_banded(N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, 
         if capacity is not None and n_isects <= capacity:
             return keys_for(n_isects), flatten_ids[:n_isects], False
         if capacity is not None:
-            globals()["capacity_redos"] += 1
+            rctx.capacity_redos += 1
         if n_isects == 0:
             return keys_for(0), torch.empty(0, dtype=torch.int32, device=dev), capacity is not None
         return keys_for(n_isects), fill(n_isects), True
@@ -533,6 +670,7 @@ class _Rasterize(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, conics, features, opacities, width, height, tile_size, tile_offsets, flatten_ids,
                 absgrad):  # fmt: skip
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         lib = _lib.load()
         m2 = means2d.reshape(-1, 2)
         N, C = features.shape
@@ -543,7 +681,7 @@ class _Rasterize(torch.autograd.Function):
         alphas = torch.empty(height, width, 1, dtype=torch.float32, device=dev)
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
         _call("fg_raster_fwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
-                              _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
+                              _ptr(render), _ptr(alphas), _ptr(last_ids), ctx.rctx.cfg(), _stream())  # fmt: skip
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids)
         ctx.geom = (N, C, width, height, tile_size, absgrad, tuple(means2d.shape))
         ctx.means2d_ref = means2d if absgrad else None  # the object that receives .absgrad
@@ -551,7 +689,12 @@ class _Rasterize(torch.autograd.Function):
         return render, alphas, last_ids
 
     @staticmethod
-    def backward(ctx, v_render, v_alphas, _v_last):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _Rasterize._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, v_render, v_alphas, _v_last):
         lib = _lib.load()
         splats, tile_offsets, flatten_ids, alphas, last_ids = ctx.saved_tensors
         N, C, width, height, tile_size, absgrad, m2_shape = ctx.geom
@@ -561,7 +704,7 @@ class _Rasterize(torch.autograd.Function):
         v_splats = torch.zeros(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
         _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
                               _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()),
-                              _ptr(v_alphas.contiguous()), _ptr(v_splats), _stream())  # fmt: skip
+                              _ptr(v_alphas.contiguous()), _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
         v_means2d = torch.empty(N, 2, dtype=torch.float32, device=dev)
         v_abs = torch.empty(N, 2, dtype=torch.float32, device=dev) if absgrad else None
         v_conics = torch.empty(N, 3, dtype=torch.float32, device=dev)
@@ -595,20 +738,8 @@ def rasterize_to_pixels(means2d, conics, features, opacities, width, height, til
 # --------------------------------------------------------------------------------------------
 # Fused path: K1+K2+pack in one pass, raster on records, unpack+K8+K7 in one pass
 
-# Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
-# written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
-# The kernels overwrite their outputs densely, so the buffer needs no zeroing.
-grad_alloc = None
-
-
-# Optional hook for the factored view-DP exchange (viewdp.FlatGaussianParams.factored_exchange):
-# when set, the fused backward of an SH-coloured view hands the clamp-masked colour gradient
-# g[N,3] (+ what is needed to rebuild the coefficient gradient) to the sink instead of writing the
-# dense [N,K,3] coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
-color_grad_sink = None
-
-
 def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
+    grad_alloc = current().grad_alloc  # (RasterContext.grad_alloc: gradients written straight into the caller's buffers)
     if grad_alloc is not None:
         buf = grad_alloc(t)
         if buf is not None:
@@ -616,13 +747,8 @@ def _alloc_grad(t: torch.Tensor) -> torch.Tensor:
     return torch.empty_like(t)
 
 
-# Optional two-stream forward (FG_OVERLAP_PACK=1, off by default): the projection (whose outputs the
-# binning needs) runs on the current stream, the colour + record half (HBM-bound, 300 B per
-# Gaussian) on a side stream, concurrently with the binning kernels.  The records carry the event
-# their consumer (the raster forward) must wait for.  Measured on MI355X at 1M / 1080p
-# (profiles/r01_two_stream_forward.md): no gain -- the 3900-workgroup colour kernel crowds the small
-# sort kernels out (fg_bin_prepare 0.114 -> 0.153 ms) by as much as it hides.
-overlap_pack = os.environ.get("FG_OVERLAP_PACK", "0") == "1"
+# side streams of the optional two-stream forward (RasterContext.overlap_pack); the records carry the event
+# their consumer (the raster forward) must wait for
 _side_streams: dict = {}
 
 
@@ -643,6 +769,7 @@ def _wait_ready(t: torch.Tensor) -> None:
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, extra, viewmat, K, cfg):
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg[:10]
         N = means.shape[0]
         dev = means.device
@@ -659,7 +786,7 @@ class _Preprocess(torch.autograd.Function):
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
         depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
-        if overlap_pack and len(cfg) > 10 and cfg[10]:
+        if ctx.rctx.overlap_pack and len(cfg) > 10 and cfg[10]:
             main = torch.cuda.current_stream()
             side = _side_stream(dev)
             _call("fg_project_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(viewmat), _ptr(K), width, height,
@@ -693,7 +820,12 @@ class _Preprocess(torch.autograd.Function):
         return radii, means2d, depths, conics, tiles, splats
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _Preprocess._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
         means, quats, scales, opacities, colors, extra, viewmat, K, radii = ctx.saved_tensors
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg[:10]
         k_stored, n_color, n_extra = ctx.layout
@@ -713,6 +845,7 @@ class _Preprocess(torch.autograd.Function):
             m2_stride = v_means2d.stride(0)
         else:
             v_means2d, m2_stride = v_means2d.contiguous(), 2
+        color_grad_sink = ctx.rctx.color_grad_sink
         if color_grad_sink is not None and sh_degree >= 0 and colors is not None:
             # factored form: 12 B of colour gradient per Gaussian instead of the 192-B coefficient row
             v_rgb = color_grad_sink("alloc", N, means.device)  # [N,3] or [N,6] (g | unit view direction)
@@ -759,6 +892,7 @@ class _PreprocessRaw(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest,
                 extra, viewmat, K, cfg):  # fmt: skip
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = cfg
         N = means.shape[0]
         dev = means.device
@@ -787,7 +921,12 @@ class _PreprocessRaw(torch.autograd.Function):
         return radii, means2d, depths, conics, tiles, splats
 
     @staticmethod
-    def backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _PreprocessRaw._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
         (means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest, extra, viewmat, K,
          radii) = ctx.saved_tensors  # fmt: skip
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg
@@ -853,6 +992,7 @@ class _RasterSplats(torch.autograd.Function):
     @staticmethod
     def forward(ctx, splats, means2d, channels, width, height, tile_size, tile_offsets, flatten_ids, absgrad,
                 background=None, n_clamp=0, expect_backward=False):  # fmt: skip
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         dev = splats.device
         _wait_ready(splats)
         render = torch.empty(height, width, channels, dtype=torch.float32, device=dev)
@@ -861,35 +1001,36 @@ class _RasterSplats(torch.autograd.Function):
         composite = background is not None or n_clamp > 0
         clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
         # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches
-        words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size)))
+        cfgp = ctx.rctx.cfg()
+        words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size), cfgp))
         jobs = seg_ckpt = live = v_splats = None
         if words > 0:
             jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
             n_ck = int(_lib.load().fg_raster_seg_ckpt_floats(channels, int(width), int(height), int(tile_size),
-                                                             int(flatten_ids.numel())))  # fmt: skip
+                                                             int(flatten_ids.numel()), cfgp))  # fmt: skip
             if n_ck > 0:
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
             live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)
             # the backward's record-gradient array (atomics accumulate into it): zero-filled in passing by
             # the forward launch instead of a fill launch at the head of the backward
-            if fill_in_forward and expect_backward:
+            if ctx.rctx.fill_in_forward and expect_backward:
                 v_splats = torch.empty(splats.shape[0], SPLAT_FLOATS, dtype=torch.float32, device=dev)
             _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
-                  int(seg_ckpt is not None), _stream())  # fmt: skip
+                  int(seg_ckpt is not None), cfgp, _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
                   _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _ptr(v_splats),
-                  0 if v_splats is None else v_splats.numel(), _stream(),
+                  0 if v_splats is None else v_splats.numel(), cfgp, _stream(),
                   stage="fg_raster_composite_fwd" if composite else "fg_raster_fwd")  # fmt: skip
         elif composite:  # O1 folded into the kernel epilogue: render is the finished image
             _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas), _ptr(last_ids),
-                  _ptr(clamp_mask), _stream())  # fmt: skip
+                  _ptr(clamp_mask), cfgp, _stream())  # fmt: skip
         else:
             _call("fg_raster_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
-                  _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), _stream())  # fmt: skip
+                  _ptr(flatten_ids), _ptr(render), _ptr(alphas), _ptr(last_ids), cfgp, _stream())  # fmt: skip
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
                               render if seg_ckpt is not None else None, live)  # fmt: skip
         ctx.jobs_bwd = jobs[1] if jobs is not None else None
@@ -902,7 +1043,12 @@ class _RasterSplats(torch.autograd.Function):
         return render, alphas, last_ids
 
     @staticmethod
-    def backward(ctx, v_render, v_alphas, _v_last):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _RasterSplats._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, v_render, v_alphas, _v_last):
         (splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
          image, live) = ctx.saved_tensors  # fmt: skip
         C, width, height, tile_size, absgrad, m2_shape = ctx.geom
@@ -917,17 +1063,17 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_jobs_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(ctx.jobs_bwd), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas),
                   _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _ptr(seg_ckpt),
-                  _ptr(image), _ptr(live), _stream(),
+                  _ptr(image), _ptr(live), ctx.rctx.cfg(), _stream(),
                   stage="fg_raster_composite_bwd" if composite else "fg_raster_bwd")  # fmt: skip
             ctx.jobs_bwd = None
         elif composite:
             _call("fg_raster_composite_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas), _ptr(last_ids),
-                  _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _stream())  # fmt: skip
+                  _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
         else:
             _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
                   _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas),
-                  _ptr(v_splats), _stream())  # fmt: skip
+                  _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
         # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
         v_means2d = v_splats[:, 0:2].view(m2_shape)
         if absgrad and ctx.means2d_ref is not None:
@@ -989,6 +1135,7 @@ def reprojection_flow(depth0: torch.Tensor, depth1: torch.Tensor, K: torch.Tenso
 class _GaussianFlow(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means2d, depths, vel, radii, K, veloc, omega):
+        ctx.rctx = current()  # the backward (autograd's thread) reads the same context
         lib = _lib.load()
         N = depths.shape[0]
         u_gs = torch.empty(N, 2, dtype=torch.float32, device=depths.device)
@@ -999,7 +1146,12 @@ class _GaussianFlow(torch.autograd.Function):
         return u_gs, u_cam
 
     @staticmethod
-    def backward(ctx, v_gs, v_cam):
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _GaussianFlow._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, v_gs, v_cam):
         lib = _lib.load()
         means2d, depths, vel, radii, K, veloc, omega = ctx.saved_tensors
         N = depths.shape[0]

@@ -140,8 +140,11 @@ def rasterization(
     rasterize_mode: str = "classic",
     extra_channels: Optional[torch.Tensor] = None,
     fused: bool = True,
+    ctx: Optional["ops.RasterContext"] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """Render one camera.  Returns ``(render [1,H,W,C], alpha [1,H,W,1], info)``.
+    ``ctx`` (an extension): the ``ops.RasterContext`` -- launch policy, list-capacity history, hooks -- this
+    call and its backward use; default: the calling thread's current one (``ops.use``), else the process's.
 
     ``info["means2d"]`` is a non-leaf tensor in the graph ([1,N,2], or [nnz,2] when packed):
     ``.retain_grad()`` works on it and after backward it carries ``.absgrad`` when
@@ -176,6 +179,11 @@ def rasterization(
         raise FgRasterError("rasterization needs CUDA/HIP tensors: the raster path has no CPU fallback")
     if N == 0:  # nothing to draw: empty image, empty lists (no kernel is launched on empty buffers)
         return _empty_result(means, width, height, tile_size, render_mode, sh_degree, colors, extra_channels, packed)
+    if ctx is not None:
+        with ops.use(ctx):
+            return rasterization(means, quats, scales, opacities, colors, viewmats, Ks, width, height, near_plane,
+                                 far_plane, radius_clip, eps2d, sh_degree, packed, tile_size, backgrounds, render_mode,
+                                 sparse_grad, absgrad, rasterize_mode, extra_channels, fused)  # fmt: skip
 
     viewmat = viewmats[0]
     K = Ks[0]
@@ -306,6 +314,7 @@ def rasterize_gauss_params(
     absgrad: bool = False,
     rasterize_mode: str = "classic",
     extra_channels: Optional[torch.Tensor] = None,
+    ctx: Optional["ops.RasterContext"] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor, Dict]:
     """The model-side front end of SURVEY.md section 8f row 3: what FreeGaussianModel.get_outputs
     does around the raster call (freegaussian_model.py:801 SH ``cat``, :844-851 ``exp`` /
@@ -327,6 +336,12 @@ def rasterize_gauss_params(
         raise FgRasterError("rasterize_gauss_params needs CUDA/HIP tensors: the raster path has no CPU fallback")
     if not render_mode.startswith("RGB"):
         raise ValueError("the raw-parameter path renders colour: use rasterization() for depth-only modes")
+    if ctx is not None:
+        with ops.use(ctx):
+            return rasterize_gauss_params(means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmats,
+                                          Ks, width, height, sh_degree, d_quats, d_scales, background, clamp, near_plane,
+                                          far_plane, radius_clip, eps2d, tile_size, render_mode, absgrad, rasterize_mode,
+                                          extra_channels)  # fmt: skip
     N = means.shape[0]
     if N == 0:  # nothing to draw (everything culled away): the background, empty lists
         render, alpha, info = _empty_result(means, width, height, tile_size, render_mode, sh_degree, None,

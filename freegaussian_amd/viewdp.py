@@ -76,7 +76,7 @@ class FlatGaussianParams:
 
     def direct_grads(self):
         """Context manager: while active, the fused raster backward writes the gradients of these
-        parameters STRAIGHT into their slices of the flat buffer (``ops.grad_alloc`` hook) and
+        parameters STRAIGHT into their slices of the flat buffer (``RasterContext.grad_alloc`` of the current context) and
         ``.grad`` is unbound first, so autograd adopts those slices instead of adding into them:
         no AccumulateGrad pass and no zeroing (the kernels overwrite densely).  Valid when every
         parameter is used by exactly one ``rasterization`` call per backward (one view per step per
@@ -89,18 +89,19 @@ class FlatGaussianParams:
         def cm():
             for p in self.params.values():
                 p.grad = None
-            prev = ops.grad_alloc
+            rctx = ops.current()  # the context the rasterization calls inside the block will capture
+            prev = rctx.grad_alloc
             def alloc(t):
                 # a FRESH view object each time: autograd only adopts (instead of cloning) a
                 # gradient tensor nobody else holds a reference to
                 base = self._by_ptr.get(t.data_ptr())
                 return None if base is None else base.view(base.shape)
 
-            ops.grad_alloc = alloc
+            rctx.grad_alloc = alloc
             try:
                 yield self
             finally:
-                ops.grad_alloc = prev
+                rctx.grad_alloc = prev
 
         return cm()
 
@@ -158,8 +159,9 @@ class FlatGaussianParams:
 
         @contextlib.contextmanager
         def cm():
-            prev_sink = ops.color_grad_sink
-            ops.color_grad_sink = sink
+            rctx = ops.current()
+            prev_sink = rctx.color_grad_sink
+            rctx.color_grad_sink = sink
             try:
                 # shared means: the raster inputs ARE the parameters, gradients land directly in the flat
                 # buffer.  Per-view means are computed from the parameters (deformation): ordinary
@@ -167,7 +169,7 @@ class FlatGaussianParams:
                 with (contextlib.nullcontext(self) if per_view_means else self.direct_grads()):
                     yield self
             finally:
-                ops.color_grad_sink = prev_sink
+                rctx.color_grad_sink = prev_sink
             if "payload" not in state:
                 raise RuntimeError("factored_exchange: no SH-coloured rasterization backward ran inside the context")
             rest = self.flat_grad[: 11 * n]

@@ -13,7 +13,8 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer unless the comment says "host";
- *   - the library allocates nothing, keeps no global state and never synchronises: the
+ *   - the library allocates nothing, keeps no global state, reads no environment variable and never
+ *     synchronises (launch policy comes in through fg_raster_config): the
  *     caller owns every buffer (scratch sizes from the *_workspace_bytes queries) and every
  *     call is asynchronous on `stream` (a hipStream_t passed as void*; NULL = default stream);
  *   - re-entrant across streams; return 0 on success, a negative FG_ERR_* code otherwise;
@@ -42,7 +43,7 @@ typedef void* fg_stream_t;
 
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
-#define FG_ABI_VERSION 2
+#define FG_ABI_VERSION 3
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -190,12 +191,45 @@ int fg_isect_keys(int64_t n_isects, const uint32_t* tile_keys, const int32_t* fl
 int fg_pack_splats(int N, int channels, const float* means2d, const float* conics,
                    const float* opacities, const float* features, float* splats,
                    fg_stream_t stream);
+/* LAUNCH POLICY of the raster kernels (ABI version 3: rounds 1-2 read FG_RASTER_* environment variables
+ * inside the library).  Every raster entry point takes a `const fg_raster_config*`; NULL = the defaults
+ * measured on MI355X (csrc/raster.hip), and so is every field left at its fg_raster_config_init value.
+ * Results do not depend on the policy (same images; gradients up to float summation order) -- it decides
+ * how the work is cut into jobs.  The SAME config must go to all calls of one image (job-list words, build,
+ * forward, checkpoint size, backward).  The Python host fills it from the FG_RASTER_* variables it reads
+ * (freegaussian_amd/ops.py::LaunchPolicy); a non-Python host fills the struct directly. */
+typedef struct fg_raster_config {
+  int32_t size;            /* sizeof(fg_raster_config) of the caller's build (set by fg_raster_config_init) */
+  int32_t ppt_fwd;         /* pixels per lane of the forward: 0 = by tile count; 1 | 2 | 4 = forced (classic launch) */
+  int32_t ppt_bwd;         /* the same for the backward */
+  int32_t tile_order;      /* classic launches, workgroup -> tile map: -1 = default (2: XCD row bands walked
+                              column-major); 0 rows, 1 bands, 2 cols, 3 split, 4 / 5 rectangles */
+  int32_t bands_nx;        /* mixed launches: XCD shares as nx x (8 / nx) rectangles; 0 / 1 = row bands (default) */
+  int32_t tail4_fwd;       /* forward: the last tail4 tiles of every XCD's sequence as four single-strip jobs ... */
+  int32_t tail2_fwd;       /* ... the tail2 tiles before them as two two-strip jobs; -1 = defaults; 0,0 = classic launch */
+  int32_t tail4_bwd;
+  int32_t tail2_bwd;
+  int32_t split4_fwd;      /* content split: a tile longer than total * split4 / 65536 becomes four jobs ... */
+  int32_t split2_fwd;      /* ... longer than total * split2 / 65536 two; -1 = defaults, 0 = off */
+  int32_t split4_bwd;
+  int32_t split2_bwd;
+  int32_t use_liveness;    /* 0: the backward ignores the forward's liveness words (A/B); default 1 */
+  int32_t seg_parts;       /* list shares per split tile of the backward (0 / 1 = off); -1 = default (5; 6 below 5000 tiles) */
+  int32_t seg_tail;        /* tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile); -1 = default */
+  int32_t seg_parts2;      /* graded tail: the last seg_tail2 tiles get seg_parts2 shares; -1 = default (off) */
+  int32_t seg_tail2;
+  int32_t debug_only_xcd;  /* measurement hooks of the classic launches: only this XCD's workgroups work (-1 = off) */
+  int32_t debug_k_mod;     /* ... only every m-th tile of each XCD (0 = off) */
+} fg_raster_config;
+void fg_raster_config_init(fg_raster_config* config);
+
 /* render[H,W,C] alphas[H,W] last_ids[H,W] (index into the sorted list of the last splat that
  * contributed; tile start - 1 if none).  No background: the caller composites it
  * (freegaussian_model.py:875-877). */
 int fg_raster_fwd(int channels, int width, int height, int tile_size, const float* splats,
                   const int32_t* tile_offsets, const int32_t* flatten_ids, float* render,
-                  float* alphas, int32_t* last_ids, fg_stream_t stream);
+                  float* alphas, int32_t* last_ids, const fg_raster_config* config,
+                    fg_stream_t stream);
 /* v_alphas may be NULL (no gradient on alpha).
  * v_splats[N,16] must be ZEROED by the caller; per-Gaussian gradients are accumulated as
  *   [v_x, v_y, v_opacity, v_conic_a, v_conic_b, v_conic_c, |v_x|, |v_y|, v_f0..v_f(C-1)]
@@ -203,7 +237,8 @@ int fg_raster_fwd(int channels, int width, int height, int tile_size, const floa
 int fg_raster_bwd(int channels, int width, int height, int tile_size, const float* splats,
                   const int32_t* tile_offsets, const int32_t* flatten_ids,
                   const float* alphas, const int32_t* last_ids, const float* v_render,
-                  const float* v_alphas, float* v_splats, fg_stream_t stream);
+                  const float* v_alphas, float* v_splats, const fg_raster_config* config,
+                    fg_stream_t stream);
 /* The same kernels with the model's post-composite O1 folded in (SURVEY.md section 8f row 3;
  * freegaussian_model.py:875-877 `rgb = clamp(render[..., :3] + (1 - alpha) * background, 0, 1)`):
  *   image[c] = render[c] + (1 - alpha) * background[c]   (background[C], nullable = none),
@@ -214,12 +249,14 @@ int fg_raster_bwd(int channels, int width, int height, int tile_size, const floa
 int fg_raster_composite_fwd(int channels, int width, int height, int tile_size, const float* splats,
                             const int32_t* tile_offsets, const int32_t* flatten_ids,
                             const float* background, int n_clamp, float* image, float* alphas,
-                            int32_t* last_ids, uint8_t* clamp_mask, fg_stream_t stream);
+                            int32_t* last_ids, uint8_t* clamp_mask, const fg_raster_config* config,
+                    fg_stream_t stream);
 int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, const float* splats,
                             const int32_t* tile_offsets, const int32_t* flatten_ids,
                             const float* background, int n_clamp, const uint8_t* clamp_mask,
                             const float* alphas, const int32_t* last_ids, const float* v_image,
-                            const float* v_alphas, float* v_splats, fg_stream_t stream);
+                            const float* v_alphas, float* v_splats, const fg_raster_config* config,
+                    fg_stream_t stream);
 /* ---- Job lists for the raster launches ---------------------------------------------------------
  * At 900 tiles and more the library runs the raster kernels as one wavefront per JOB: a whole tile
  * (4 pixels per lane), half a tile or a quarter.  Without a list the job sizes depend on the tile's
@@ -227,12 +264,12 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * the tile's list length (tiles far longer than the mean are split wherever they are), which is
  * what non-uniform scenes need (scripts/clustered_check.py).  Caller-allocated like everything else:
  *   words = fg_raster_jobs_words(...)   int32 words of ONE list; 0 = the library would not use lists
- *                                        for this size / environment (call the plain entry points)
+ *                                        for this size / config (call the plain entry points)
  *   fg_raster_build_jobs(...)            one small launch, after tile_offsets exist; either list nullable
  *   fg_raster_jobs_fwd / _bwd            fg_raster_composite_fwd / _bwd with a list (jobs == NULL:
  *                                        identical to those)
  * LIST SEGMENTS of the backward (3 channels): floats = fg_raster_seg_ckpt_floats(...) (0 = off for
- * this size / environment); seg_ckpt[floats], uninitialised, goes to BOTH calls and `image` (the
+ * this size / config); seg_ckpt[floats], uninitialised, goes to BOTH calls and `image` (the
  * forward's output) to the backward: the forward leaves every pixel's compositing state at every
  * 64th entry of a tile's list (only for the tiles the backward's job list splits: hand both calls the
  * lists of ONE fg_raster_build_jobs call), the last list index each (tile, strip) used and every
@@ -248,21 +285,24 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
  * ZERO FILL IN PASSING: zero_buf[zero_floats] (nullable) is zero-filled by the forward call -- meant
  * for the v_splats array of the coming fg_raster_jobs_bwd, which accumulates with atomics: the forward
  * launch leaves the memory pipe mostly idle, a separate fill costs ~10 us and a launch boundary. */
-int64_t fg_raster_jobs_words(int width, int height, int tile_size);
+int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config);
 int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
-                         int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, fg_stream_t stream);
+                         int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, const fg_raster_config* config,
+                    fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,
                        int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                       float* zero_buf, int64_t zero_floats, fg_stream_t stream);
-int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects);
+                       float* zero_buf, int64_t zero_floats, const fg_raster_config* config,
+                    fg_stream_t stream);
+int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects, const fg_raster_config* config);
 int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, const uint8_t* clamp_mask,
                        const float* alphas, const int32_t* last_ids, const float* v_image,
                        const float* v_alphas, float* v_splats, const float* seg_ckpt, const float* image,
-                       const uint32_t* live_words, fg_stream_t stream);
+                       const uint32_t* live_words, const fg_raster_config* config,
+                    fg_stream_t stream);
 /* Split v_splats back into per-tensor gradients (any output nullable). */
 int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d,
                     float* v_means2d_abs, float* v_conics, float* v_opacities,

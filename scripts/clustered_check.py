@@ -36,13 +36,13 @@ def step():
 for _ in range(5):
     info = step()
 torch.cuda.synchronize()
-ops.stage_timer = ops.StageTimer()
+ops.default_context.stage_timer = ops.StageTimer()
 t0 = time.perf_counter()
 for _ in range(20):
     step()
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20 * 1e3
-st = ops.stage_timer.summary()
+st = ops.default_context.stage_timer.summary()
 offs = info["isect_offsets"].reshape(-1).long()
 lens = (torch.cat([offs[1:], torch.tensor([info["flatten_ids"].numel()], device=offs.device)]) - offs).float() if offs.numel() == info["tile_width"] * info["tile_height"] else (offs[1:] - offs[:-1]).float()
 print(json.dumps({"tail_fwd": os.environ.get("FG_RASTER_TAIL_FWD"), "tail_bwd": os.environ.get("FG_RASTER_TAIL_BWD"),

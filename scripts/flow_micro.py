@@ -30,11 +30,11 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-ops.stage_timer = ops.StageTimer()
+ops.default_context.stage_timer = ops.StageTimer()
 for _ in range(30):
     step()
-st = ops.stage_timer.summary()
-ops.stage_timer = None
+st = ops.default_context.stage_timer.summary()
+ops.default_context.stage_timer = None
 bytes_ = {"fg_camera_flow": H * W * (4 + 8), "fg_flow_fwd": N * (8 + 4 + 12 + 4 + 16), "fg_flow_bwd": N * (8 + 4 + 12 + 4 + 16 + 8 + 4 + 12)}
 for k, ms in st.items():
     print(f"{k}: {ms * 1e3:.1f} us, {bytes_[k] / 1e6:.0f} MB algorithmic -> {bytes_[k] / ms / 1e6:.0f} GB/s")

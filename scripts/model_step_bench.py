@@ -51,15 +51,15 @@ def step():
 for _ in range(5):
     step()
 torch.cuda.synchronize()
-ops.stage_timer = ops.StageTimer()
+ops.default_context.stage_timer = ops.StageTimer()
 t0 = time.perf_counter()
 for _ in range(steps):
     step()
 issue = (time.perf_counter() - t0) / steps * 1e3  # host time to enqueue a step (includes the one host sync)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps * 1e3
-stages = ops.stage_timer.summary()
-ops.stage_timer = None
+stages = ops.default_context.stage_timer.summary()
+ops.default_context.stage_timer = None
 res = {"model_step_ms": dt, "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
 if os.environ.get("FG_MODEL_PROFILE"):
     from torch.profiler import ProfilerActivity, profile

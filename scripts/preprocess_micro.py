@@ -34,9 +34,9 @@ for f in (run_act, run_raw):
     for _ in range(3):
         f()
     torch.cuda.synchronize()
-    ops.stage_timer = ops.StageTimer()
+    ops.default_context.stage_timer = ops.StageTimer()
     for _ in range(20):
         f()
     torch.cuda.synchronize()
-    print(f.__name__, {k: round(v, 4) for k, v in ops.stage_timer.summary().items()})
-    ops.stage_timer = None
+    print(f.__name__, {k: round(v, 4) for k, v in ops.default_context.stage_timer.summary().items()})
+    ops.default_context.stage_timer = None

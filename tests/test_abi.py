@@ -45,17 +45,17 @@ def test_workspace_queries_need_no_gpu():
     assert lib.fg_sort_workspace_bytes(n) >= n * 12
     # job lists: none for small images (classic launches), 8 counters + 8 segments of 8 entries per
     # tile of the largest XCD band otherwise
-    assert lib.fg_raster_jobs_words(480, 270, 16) == 0
-    assert lib.fg_raster_jobs_words(1920, 1080, 16) == 8 + 8 * 8 * 9 * 120
-    assert lib.fg_raster_jobs_words(1920, 1080, 8) == 0  # unsupported tile size
-    assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, 0, None) == -1
+    assert lib.fg_raster_jobs_words(480, 270, 16, None) == 0
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) == 8 + 8 * 8 * 9 * 120
+    assert lib.fg_raster_jobs_words(1920, 1080, 8, None) == 0  # unsupported tile size
+    assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, 0, None, None) == -1
 
 
 def test_argument_validation_without_gpu():
     """Bad arguments are rejected before any launch, so this is safe on a CPU-only box."""
     lib = _lib.load()
     assert lib.fg_project_fwd(-1, *([None] * 5), 1, 1, 0.3, 0.01, 1e10, 0.0, 16, *([None] * 7)) == -1
-    assert lib.fg_raster_fwd(3, 64, 64, 8, *([None] * 7)) in (-1, -4)
+    assert lib.fg_raster_fwd(3, 64, 64, 8, *([None] * 8)) in (-1, -4)
     assert lib.fg_sh_fwd(10, 4, 16, *([None] * 6)) == -1
     assert lib.fg_sort_pairs(10, None, None, 70, None, 0, None) == -1
 
@@ -83,7 +83,49 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_bin_prepare_keys(4, *(n * 7), 0, None) == -1  # keys / rectangles / outputs missing
     assert lib.fg_bin_prepare_keys(0, *(n * 7), 0, None) == 0
     # composite raster: clamp count within the channels, mask required
-    assert lib.fg_raster_composite_fwd(3, 32, 32, 16, *(n * 4), 4, *(n * 5)) == -1
+    assert lib.fg_raster_composite_fwd(3, 32, 32, 16, *(n * 4), 4, *(n * 6)) == -1
+
+
+def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):
+    """ABI version 3: the library reads no environment variable; the launch policy is an fg_raster_config the
+    host fills (ops.launch_policy_from_env maps the FG_RASTER_* variables of rounds 1-2 onto it)."""
+    import ctypes
+
+    from freegaussian_amd import ops
+
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "freegaussian_amd", "csrc")):
+        for f in files:
+            if f.endswith((".hip", ".h")):
+                assert "getenv" not in open(os.path.join(dirpath, f)).read(), f
+    lib = _lib.load()
+    dflt = _lib.RasterConfig.defaults()
+    assert dflt.size == ctypes.sizeof(_lib.RasterConfig) and dflt.seg_parts == -1 and dflt.use_liveness == 1
+    # the environment no longer reaches the library ...
+    monkeypatch.setenv("FG_RASTER_PPT_FWD", "1")
+    monkeypatch.setenv("FG_RASTER_PPT_BWD", "1")
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) > 0
+    # ... the struct does: forced pixels per lane mean classic launches, i.e. no job lists
+    forced = ops.launch_policy_from_env()
+    assert forced.ppt_fwd == 1 and forced.ppt_bwd == 1
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, forced.ptr()) == 0
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, ops.launch_policy(bands_nx=8).ptr()) == 8 + 8 * 8 * 15 * 68
+    assert lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 10**6, ops.launch_policy(seg_parts=1).ptr()) == 0
+    assert lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 10**6, None) > 0
+    env = {"FG_RASTER_TAIL_BWD": "7,9", "FG_RASTER_SPLIT_BWD": "2", "FG_RASTER_LIVE": "0", "FG_TILE_ORDER": "rows",
+           "FG_RASTER_SEG_GRADE": "8,100", "FG_DEBUG_ONLY_XCD": "3"}  # fmt: skip
+    p = ops.launch_policy_from_env(env)
+    assert (p.tail4_bwd, p.tail2_bwd, p.split4_bwd, p.split2_bwd, p.use_liveness, p.tile_order, p.seg_parts2, p.seg_tail2,
+            p.debug_only_xcd) == (7, 9, 2, 0, 0, 0, 8, 100, 3)  # fmt: skip
+    with pytest.raises(ValueError):
+        ops.launch_policy(no_such_field=1)
+    # two contexts, two policies, one process: nothing is module state
+    a, b = ops.RasterContext(policy=ops.launch_policy(ppt_fwd=2)), ops.RasterContext(env={})
+    with ops.use(a):
+        assert ops.current() is a
+        with ops.use(b):
+            assert ops.current() is b and ops.current().policy.ppt_fwd == 0
+        assert ops.current().policy.ppt_fwd == 2
+    assert ops.current() is ops.default_context
 
 
 def test_product_does_not_import_oracle():

@@ -33,6 +33,14 @@ def _need_gpu():
     _lib.load()
 
 
+def _setenv_policy(monkeypatch, name, value):
+    """The FG_RASTER_* knobs are read by the Python host when a RasterContext is created (the library reads no
+    environment); tests switch them inside one process: the default context's launch policy is rebuilt from
+    the patched environment (both are restored when the test ends)."""
+    monkeypatch.setenv(name, value)
+    monkeypatch.setattr(ops.default_context, "policy", ops.launch_policy_from_env())
+
+
 def _scene(n=6000, w=200, h=120, seed=3, **kw):
     return synthetic_scene(n, w, h, n_views=2, seed=seed, **kw)
 
@@ -152,7 +160,7 @@ def test_footprint_rectangles_cull_only_dead_entries(mode, monkeypatch):
     pixel centre: a subsequence, tile by tile, of the radius-box lists; every dropped entry is dead
     by the oracle's own alpha test; image bit-identical, gradients equal up to atomic order; and
     info["flatten_ids"] / ["isect_offsets"] / ["isect_ids"] still are the reference's full lists."""
-    if ops.overlap_pack:
+    if ops.default_context.overlap_pack:
         pytest.skip("FG_OVERLAP_PACK=1: the two-stream forward bins from the radius boxes")
     sc = _scene(n=30000, w=400, h=240, seed=13)
     sc.opacities[::3] *= 0.05  # many faint splats: their 3-sigma boxes are mostly dead area
@@ -161,7 +169,7 @@ def test_footprint_rectangles_cull_only_dead_entries(mode, monkeypatch):
     vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
     outs = []
     for tight in (True, False):
-        monkeypatch.setattr(ops, "tight_rects", tight)
+        monkeypatch.setattr(ops.default_context, "tight_rects", tight)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True,
                                    rasterize_mode=mode)  # fmt: skip
@@ -247,10 +255,10 @@ def test_mixed_launch_equals_classic_launch(monkeypatch):
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     outs = []
     for tail, split in (("0", "0"), ("7", "20,16"), ("3,5", "2,1"), ("2,2", "8,0"), ("100000", "0")):
-        monkeypatch.setenv("FG_RASTER_TAIL_FWD", tail)
-        monkeypatch.setenv("FG_RASTER_TAIL_BWD", tail)
-        monkeypatch.setenv("FG_RASTER_SPLIT_FWD", split)  # content-aware job sizes (job lists)
-        monkeypatch.setenv("FG_RASTER_SPLIT_BWD", split)
+        _setenv_policy(monkeypatch, "FG_RASTER_TAIL_FWD", tail)
+        _setenv_policy(monkeypatch, "FG_RASTER_TAIL_BWD", tail)
+        _setenv_policy(monkeypatch, "FG_RASTER_SPLIT_FWD", split)  # content-aware job sizes (job lists)
+        _setenv_policy(monkeypatch, "FG_RASTER_SPLIT_BWD", split)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, render_mode="RGB+ED", absgrad=True, packed=False)
         g = torch.Generator().manual_seed(0)
@@ -285,23 +293,23 @@ def test_speculative_binning_capacity_and_overflow():
     tw, th = (sc.width + 15) // 16, (sc.height + 15) // 16
     cnt, _, _ = O.isect_tiles(p.means2d, p.radii, p.depths, 16, tw, th, sort=False)
     args = (p.means2d.to(DEV), p.radii.to(DEV), p.depths.to(DEV), cnt.to(DEV), 16, tw, th)
-    ops._isect_capacity.clear()
-    was = ops.speculative_binning
-    ops.speculative_binning = False
+    ops.default_context.isect_capacity.clear()
+    was = ops.default_context.speculative_binning
+    ops.default_context.speculative_binning = False
     k0, f0, o0 = ops.bin_tiles(*args)
-    ops.speculative_binning = True
-    key = next(iter(ops._isect_capacity))
-    assert ops._isect_capacity[key] >= f0.numel()
+    ops.default_context.speculative_binning = True
+    key = next(iter(ops.default_context.isect_capacity))
+    assert ops.default_context.isect_capacity[key] >= f0.numel()
     k1, f1, o1 = ops.bin_tiles(*args)  # capacity path
     assert f1.numel() == f0.numel() and f1._base is not None  # a slice of the capacity buffer
     assert torch.equal(k0, k1) and torch.equal(f0, f1) and torch.equal(o0, o1)
-    ops._isect_capacity[key] = max(f0.numel() // 3, 1)  # far too small: truncated, detected, redone
+    ops.default_context.isect_capacity[key] = max(f0.numel() // 3, 1)  # far too small: truncated, detected, redone
     k2, f2, o2 = ops.bin_tiles(*args)
     assert torch.equal(k0, k2) and torch.equal(f0, f2) and torch.equal(o0, o2)
-    ops._isect_capacity[key] = f0.numel()  # exactly enough
+    ops.default_context.isect_capacity[key] = f0.numel()  # exactly enough
     k3, f3, o3 = ops.bin_tiles(*args)
     assert torch.equal(k0, k3) and torch.equal(f0, f3) and torch.equal(o0, o3)
-    ops.speculative_binning = was
+    ops.default_context.speculative_binning = was
 
 
 def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
@@ -311,12 +319,12 @@ def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     outs = []
     for banded in (False, True):
-        monkeypatch.setattr(ops, "banded_binning", banded)
-        ops._isect_capacity.clear()
+        monkeypatch.setattr(ops.default_context, "banded_binning", banded)
+        ops.default_context.isect_capacity.clear()
         runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
         if overflow:
-            for k in list(ops._isect_capacity):
-                ops._isect_capacity[k] = 1024  # far too small: the fill writes nothing, the host refills exactly
+            for k in list(ops.default_context.isect_capacity):
+                ops.default_context.isect_capacity[k] = 1024  # far too small: the fill writes nothing, the host refills exactly
             runs.append(ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False))
         for _, f, o in runs[1:]:
             assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
@@ -394,11 +402,11 @@ def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
     sc = _scene(n=20000, w=256, h=160, seed=17)
     t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
-    ops._isect_capacity.clear()
+    ops.default_context.isect_capacity.clear()
     r0, a0, i0 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)  # exact (no guess yet)
     r1, a1, i1 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)  # speculative
-    for key in list(ops._isect_capacity):
-        ops._isect_capacity[key] = 1000  # force the overflow path
+    for key in list(ops.default_context.isect_capacity):
+        ops.default_context.isect_capacity[key] = 1000  # force the overflow path
     r2, a2, i2 = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False)
     for r, a, i in ((r1, a1, i1), (r2, a2, i2)):
         assert torch.equal(r, r0) and torch.equal(a, a0)
@@ -407,22 +415,22 @@ def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
 
 
 def test_two_stream_forward_gives_identical_results():
-    """ops.overlap_pack: projection on the current stream, colour + record packing (fg_sh_pack_fwd)
+    """ops.default_context.overlap_pack: projection on the current stream, colour + record packing (fg_sh_pack_fwd)
     on a side stream overlapping the binning; the raster forward waits for the records' event."""
     sc = _scene(n=15000, w=240, h=144, seed=23)
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     outs = []
-    was = ops.overlap_pack
+    was = ops.default_context.overlap_pack
     try:
         for flag in (False, True):
-            ops.overlap_pack = flag
+            ops.default_context.overlap_pack = flag
             t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
             r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, render_mode="RGB+ED",
                                        packed=False, absgrad=True, rasterize_mode="antialiased")  # fmt: skip
             (r.sum() + a.sum()).backward()
             outs.append((r.detach(), a.detach(), info["radii"], [x.grad for x in t]))
     finally:
-        ops.overlap_pack = was
+        ops.default_context.overlap_pack = was
     (r0, a0, rad0, g0), (r1, a1, rad1, g1) = outs
     assert torch.equal(r0, r1) and torch.equal(a0, a1) and torch.equal(rad0, rad1)
     for x, y in zip(g0, g1):
@@ -485,8 +493,8 @@ def test_raster_forward_backward_vs_oracle(channels, ppt, monkeypatch):
     """ppt = 0: the library's own choice for this tile count; 1 / 2 / 4: every pixels-per-lane body
     of the classic launch (4 / 2 / 1 wavefronts per tile) directly against the oracle."""
     if ppt:
-        monkeypatch.setenv("FG_RASTER_PPT_FWD", str(ppt))
-        monkeypatch.setenv("FG_RASTER_PPT_BWD", str(ppt))
+        _setenv_policy(monkeypatch, "FG_RASTER_PPT_FWD", str(ppt))
+        _setenv_policy(monkeypatch, "FG_RASTER_PPT_BWD", str(ppt))
     sc = _scene(n=8000, w=150, h=100)  # 150x100: partial tiles on both edges
     sc.opacities[:400] = 1.0  # exercise the 0.999 clamp branch
     ref, feats, offs, vals = _raster_inputs(sc, channels=channels)
@@ -1002,7 +1010,7 @@ def test_1080p_mixed_launch_forward_and_all_gradients_vs_oracle(layout, render_m
     gradient, the screen-space gradient and absgrad (VERDICT r1 weak #2)."""
     from freegaussian_amd import _lib
 
-    if int(_lib.load().fg_raster_jobs_words(1920, 1080, 16)) == 0:  # job-list launches are what runs here by default
+    if int(_lib.load().fg_raster_jobs_words(1920, 1080, 16, ops.default_context.cfg())) == 0:  # job-list launches are what runs here by default
         pytest.skip("classic launches forced by the environment (FG_RASTER_PPT_* / FG_TILE_ORDER)")
     sc = synthetic_scene(40_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
     if layout == "clustered":
@@ -1029,11 +1037,11 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
     if layout == "clustered":
         sc.means[:20_000] *= 0.15  # lists of thousands of entries: many segments per tile
     if not bg:
-        monkeypatch.setenv("FG_RASTER_SEG_PARTS", str(parts))
+        _setenv_policy(monkeypatch, "FG_RASTER_SEG_PARTS", str(parts))
         ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 1, "RGB", 3)
         worst = _assert_full_parity(ref_in, gpu_in, o0, o1, REL_TOL)
         seg_grads = {k: v.grad.clone() for k, v in gpu_in.items()}
-        monkeypatch.setenv("FG_RASTER_SEG_PARTS", "1")
+        _setenv_policy(monkeypatch, "FG_RASTER_SEG_PARTS", "1")
         _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
         assert torch.equal(o2[0], o1[0])  # the forward does not depend on it
         diff = {k: rel_l2(seg_grads[k], gpu_in1[k].grad) for k in seg_grads}
@@ -1049,7 +1057,7 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
     bgc = torch.tensor([0.3, 0.9, 0.1], device=DEV)
     outs = []
     for p_ in (parts, 1):
-        monkeypatch.setenv("FG_RASTER_SEG_PARTS", str(p_))
+        _setenv_policy(monkeypatch, "FG_RASTER_SEG_PARTS", str(p_))
         t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
         r, a, _ = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
                                          t["features_rest"], vm, K, 1920, 1080, 3, background=bgc, clamp=True, absgrad=True)  # fmt: skip
@@ -1091,8 +1099,8 @@ def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monk
     outs = []
     for classic in (False, True):
         if classic:
-            monkeypatch.setenv("FG_RASTER_TAIL_FWD", "0")
-            monkeypatch.setenv("FG_RASTER_TAIL_BWD", "0")
+            _setenv_policy(monkeypatch, "FG_RASTER_TAIL_FWD", "0")
+            _setenv_policy(monkeypatch, "FG_RASTER_TAIL_BWD", "0")
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
         (r * vr).sum().backward()
@@ -1393,9 +1401,9 @@ def test_graph_replays_with_classic_forward_and_listed_backward(live, monkeypatc
     from freegaussian_amd.graphed import GraphedRaster
     from freegaussian_amd.viewdp import FlatGaussianParams
 
-    monkeypatch.setenv("FG_RASTER_TAIL_BWD", "7,9")
-    monkeypatch.setenv("FG_RASTER_SPLIT_BWD", "2,1")
-    monkeypatch.setenv("FG_RASTER_LIVE", live)
+    _setenv_policy(monkeypatch, "FG_RASTER_TAIL_BWD", "7,9")
+    _setenv_policy(monkeypatch, "FG_RASTER_SPLIT_BWD", "2,1")
+    _setenv_policy(monkeypatch, "FG_RASTER_LIVE", live)
     sc = synthetic_scene(30000, 320, 192, n_views=4, seed=31)
     fp = FlatGaussianParams.from_scene(sc, DEV)
     ref = FlatGaussianParams.from_scene(sc, DEV)
