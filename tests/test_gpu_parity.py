@@ -355,7 +355,7 @@ def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
         keys, rects = splats._fg_bin
         N = 50000
         f, o = _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=True)
-        assert f.numel() > 100_000
+        assert f.numel() > 50_000
         return
     if case == "few_rows":
         W, H = 640, 40  # 3 tile rows: five of the eight bands are empty
