@@ -261,29 +261,51 @@ tb_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table, int32_t* __res
   __syncthreads();
   if (!is_last) return;
   __threadfence();  // acquire: the other workgroups' counts (they sit in other XCDs' L2s)
-  // inclusive scan of the counts in place; thread i owns a contiguous run
-  const int per = (T + TB_BLOCK - 1) / TB_BLOCK;
-  const int i0 = min((int)threadIdx.x * per, T), i1 = min(i0 + per, T);
-  uint32_t sum = 0;
-  for (int i = i0; i < i1; ++i) sum += (uint32_t)__hip_atomic_load(&tile_offsets[i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // inclusive scan of the counts in place, 4096 at a time: coalesced loads into LDS (16 independent loads per
+  // thread -- a chain of single loads here cost 60 us), every thread scans 16 consecutive values, block scan
+  __shared__ uint32_t buf[TB_BLOCK * 16];
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const uint32_t incl = wave_incl_scan_u32(sum, lane);
-  if (lane == 63) wave_tot[wave] = incl;
-  __syncthreads();
-  uint32_t base = incl - sum, all = 0;
+  uint32_t carry = 0;
+  for (int base = 0; base < T; base += TB_BLOCK * 16) {
 #pragma unroll
-  for (int k = 0; k < TB_BLOCK / 64; ++k) {
-    if (k < wave) base += wave_tot[k];
-    all += wave_tot[k];
-  }
-  for (int i = i0; i < i1; ++i) {
-    base += (uint32_t)__hip_atomic_load(&tile_offsets[i + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    tile_offsets[i + 1] = (int32_t)base;
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + k * TB_BLOCK + threadIdx.x;
+      buf[k * TB_BLOCK + threadIdx.x] = i < T ? (uint32_t)tile_offsets[i + 1] : 0u;
+    }
+    __syncthreads();
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = buf[threadIdx.x * 16 + k];
+      sum += v[k];
+    }
+    const uint32_t incl = wave_incl_scan_u32(sum, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t run = carry + incl - sum, all = 0;
+#pragma unroll
+    for (int k = 0; k < TB_BLOCK / 64; ++k) {
+      if (k < wave) run += wave_tot[k];
+      all += wave_tot[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      run += v[k];
+      buf[threadIdx.x * 16 + k] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + k * TB_BLOCK + threadIdx.x;
+      if (i < T) tile_offsets[i + 1] = (int32_t)buf[k * TB_BLOCK + threadIdx.x];
+    }
+    carry += all;
+    __syncthreads();
   }
   if (threadIdx.x == 0) {
     tile_offsets[0] = 0;
     if (count_out) {  // the list length straight into the caller's host-visible word (no copy launch)
-      __hip_atomic_store(count_out, (int64_t)all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __hip_atomic_store(count_out, (int64_t)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __threadfence_system();
     }
   }
@@ -438,7 +460,8 @@ __device__ void sort_tile_global(uint64_t* a, uint64_t* b, int n, int32_t* ids_o
 // cover only bits that differ inside the tile, at most the top 16 of them (unsorted_low_bits).
 __global__ void __launch_bounds__(TB_BLOCK)
 tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, uint64_t* __restrict__ pairs,
-               uint64_t* __restrict__ pairs_alt, long long capacity, int32_t* __restrict__ flatten_ids) {
+               uint64_t* __restrict__ pairs_alt, long long capacity, int32_t* __restrict__ flatten_ids,
+               int32_t* __restrict__ list_offsets) {
   __shared__ uint64_t img[TB_SORT_MAX];
   __shared__ uint32_t wave_cnt[TB_BLOCK / 64][256];
   __shared__ uint32_t scan_tmp[TB_BLOCK / 64];
@@ -447,9 +470,16 @@ tb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   const Rows br = band_rows(xcd, tile_h);
   if (k >= (br.r1 - br.r0) * tile_w) return;
   const int tile = br.r0 * tile_w + k, T = tile_w * tile_h;
-  if ((long long)tile_offsets[T] > capacity) return;
+  const int total = tile_offsets[T];
+  const bool over = (long long)total > capacity;
   const int off = tile_offsets[tile], n = tile_offsets[tile + 1] - off;
-  if (n <= 0) return;
+  // the ranges the CONSUMERS of flatten_ids read: the tile ranges when the list fits, empty lists when it
+  // does not (nothing was filled; whoever was enqueued speculatively behind this call walks nothing)
+  if (threadIdx.x == 0) {
+    list_offsets[tile] = over ? 0 : off;
+    if (tile == T - 1) list_offsets[T] = over ? 0 : total;
+  }
+  if (over || n <= 0) return;
   if (n > TB_SORT_MAX) {
     sort_tile_global(pairs + off, pairs_alt + off, n, flatten_ids + off, wave_cnt, scan_tmp, red);
     return;
@@ -574,9 +604,11 @@ extern "C" size_t fg_tilebin_fill_workspace_bytes(int64_t capacity) {
 
 extern "C" int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                                int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
-                               int32_t* flatten_ids, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+                               int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                               fg_stream_t stream) {
   if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
-  if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !workspace) return FG_ERR_INVALID_ARG;
+  if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !list_offsets || !workspace)
+    return FG_ERR_INVALID_ARG;
   if (!fg_tilebin_supported(tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
   if (workspace_bytes < fg_tilebin_fill_workspace_bytes(capacity)) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
@@ -589,7 +621,7 @@ extern "C" int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t*
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, table, tile_offsets, pairs,
                      (long long)capacity);
   hipLaunchKernelGGL(tb_sort_kernel, dim3(8 * band_tiles_max(tile_w, tile_h)), dim3(TB_BLOCK), 0, s, tile_w, tile_h,
-                     tile_offsets, pairs, pairs_alt, (long long)capacity, flatten_ids);
+                     tile_offsets, pairs, pairs_alt, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -99,3 +99,126 @@ class GraphedRaster:
             self._capture()
             return r, a, True
         return self.render, self.alpha, False
+
+
+class GraphedModelStep:
+    """``FreeGaussianModel.get_outputs`` + loss + backward as ONE hipGraph, for the launch-bound sizes.
+
+    The reference trains its first 6000 steps at 1/4 and 1/2 resolution (freegaussian_model.py:626-633,
+    :807-815); there a step is ~60 launches of a few microseconds each and the eager host cannot keep the GPU
+    busy (profiles/r02_low_resolutions.md).  Everything between the host side of the camera and the gradients
+    -- deform MLP, activations, raster forward, background, loss, the whole backward -- is captured once per
+    SHAPE and replayed.  What makes a shape: the Gaussian count and parameter storage (densification
+    re-allocates both), the scheduled resolution, the SH degree, whether the deform net is active, the render
+    mode.  A replay that finds more list entries than its fixed capacity is redone (the graph is re-captured
+    with more room and replayed: exact).  The optimizers, ``after_train_iter`` and ``refinement_after`` stay
+    eager and see ordinary ``.grad`` tensors (static buffers the replay refills; never ``set_to_none`` them
+    while a graph is live -- ``harness.train_step`` skips its ``zero_grad`` on graphed steps).
+
+    Not graphed (falls back to ``model.get_outputs``): eval, crop boxes, images above ``max_tiles`` (the eager
+    path is GPU-bound there and its speculative list capacity needs no re-capture), the stage-2 control model."""
+
+    def __init__(self, model, loss_fn, max_tiles: int = 2200, headroom: float = 1.5,
+                 ctx: Optional[ops.RasterContext] = None):  # fmt: skip
+        self.model, self.loss_fn = model, loss_fn
+        self.max_tiles, self.headroom = int(max_tiles), float(headroom)
+        self.ctx = ctx if ctx is not None else ops.current()
+        self.key = None
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.capacity: Optional[int] = None
+        self.captures = 0  # (re-)captures so far: shape changes + overflows
+        self.replays = 0
+        self.static = {}
+
+    def applicable(self, camera) -> bool:
+        from .model import FreeGaussianModel
+
+        m = self.model
+        if not m.training or m.crop_box is not None or m.device.type != "cuda":
+            return False
+        if type(m)._get_outputs_on_active_rows is not FreeGaussianModel._get_outputs_on_active_rows:
+            return False  # (the stage-2 model assembles its inputs differently)
+        s = m._get_downscale_factor()
+        w, h = int(camera.width * (1 / s)), int(camera.height * (1 / s))
+        return ((w + 15) // 16) * ((h + 15) // 16) <= self.max_tiles
+
+    def _key(self, W, H):
+        m = self.model
+        deg = min(m.step // m.config.sh_degree_interval, m.config.sh_degree)
+        return (m.num_points, m.gauss_params["means"].data_ptr(), W, H, deg, m.step >= m.config.warm_up,
+                m._render_mode(), m.config.background_color)  # fmt: skip
+
+    def _forward_backward(self):
+        m, st = self.model, self.static
+        out = m._outputs_from(st["viewmat"], st["K"], st["W"], st["H"], st["times"])
+        loss = self.loss_fn(out["rgb"], st["gt"])
+        loss.backward()
+        return out, loss
+
+    def _capture(self):
+        import gc
+
+        m = self.model
+        for p in m.parameters():
+            p.grad = None  # the captured backward allocates the .grad tensors from the graph's pool
+        self.graph = None
+        gc.collect()
+        self.ctx.static_capacity = self.capacity
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side), ops.use(self.ctx):
+                for _ in range(2):
+                    self._forward_backward()
+                    for p in m.parameters():
+                        p.grad = None
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with ops.use(self.ctx), torch.cuda.graph(g):
+                out, loss = self._forward_backward()
+                self.static["overflow"] = self.ctx.last_overflow
+            self.graph, self.static["out"], self.static["loss"] = g, out, loss
+            self.captures += 1
+        finally:
+            self.ctx.static_capacity = None
+
+    def step(self, camera, gt_image):
+        """-> (outputs dict, loss): static tensors, refilled by the next step.  Gradients are in ``.grad``."""
+        m, st = self.model, self.static
+        viewmat, K, W, H = m._camera_setup(camera)
+        gt = m.get_gt_img(gt_image)
+        times = camera.times.to(m.device)
+        key = self._key(W, H)
+        if key != self.key or self.graph is None:
+            # a new shape: an eager forward measures the list length, then the capture
+            self.key, self.graph = key, None
+            st.clear()
+            st.update(viewmat=viewmat.clone(), K=K.clone(), times=times.clone(), gt=gt.clone(), W=W, H=H)
+            n = self._measure()
+            if self.capacity is None or n > self.capacity or 3 * n * self.headroom < self.capacity:
+                self.capacity = int(n * self.headroom) + 4096
+            self._capture()
+        else:
+            st["viewmat"].copy_(viewmat, non_blocking=True)
+            st["K"].copy_(K, non_blocking=True)
+            st["times"].copy_(times, non_blocking=True)
+            st["gt"].copy_(gt, non_blocking=True)
+        self.graph.replay()
+        self.replays += 1
+        if bool(st["overflow"].item()):  # the list did not fit: more room, capture again, replay (exact)
+            self.capacity = int(self._measure() * self.headroom) + 4096
+            self._capture()
+            self.graph.replay()
+        return st["out"], st["loss"]
+
+    def release(self) -> None:
+        """Drop the graph and its static buffers (the next applicable step captures afresh)."""
+        self.graph, self.key = None, None
+        self.static.clear()
+
+    def _measure(self) -> int:
+        """Length of the raster list for the static inputs (an eager, exact forward)."""
+        m, st = self.model, self.static
+        with torch.no_grad(), ops.use(self.ctx):
+            m._outputs_from(st["viewmat"], st["K"], st["W"], st["H"], st["times"])
+        return int(m.last_list_length)

@@ -72,19 +72,29 @@ def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = Non
 
 
 def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
-               grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None) -> Dict[str, float]:  # fmt: skip
+               grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None, graphed=None) -> Dict[str, float]:  # fmt: skip
     """One iteration in the reference's callback order: step_cb -> get_outputs ->
     loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter ->
     refinement_after every ``refine_every`` steps (freegaussian_model.py:575-590; needs
     ``num_train_data``, the number of training cameras, :416).  View-sharded DP: pass
-    ``grad_sync=viewdp.all_reduce_model_grads`` and ``stats_sync=viewdp.sync_densify_stats``."""
+    ``grad_sync=viewdp.all_reduce_model_grads`` and ``stats_sync=viewdp.sync_densify_stats``.
+    ``graphed``: a ``graphed.GraphedModelStep(model, main_loss)``: while the scheduled resolution is
+    launch-bound (the reference's first 6000 steps at 1/4 and 1/2 resolution) get_outputs + loss + backward
+    replay as one hipGraph; the rest of the step is unchanged."""
     model.step_cb(step)
-    for o in opts.values():
-        o.zero_grad(set_to_none=True)
-    out = model.get_outputs(camera)
-    gt = model.get_gt_img(gt_image)
-    loss = main_loss(out["rgb"], gt)
-    loss.backward()
+    if graphed is not None and graphed.applicable(camera):
+        # (no zero_grad: the replay refills the .grad tensors, which are static buffers of the graph)
+        out, loss = graphed.step(camera, gt_image)
+        gt = graphed.static["gt"]
+    else:
+        if graphed is not None:
+            graphed.release()  # grads of a graph that is no longer replayed must not be mistaken for fresh ones
+        for o in opts.values():
+            o.zero_grad(set_to_none=True)
+        out = model.get_outputs(camera)
+        gt = model.get_gt_img(gt_image)
+        loss = main_loss(out["rgb"], gt)
+        loss.backward()
     if grad_sync is not None:
         grad_sync(model)
     apply_schedules(opts, step, table)

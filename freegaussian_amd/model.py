@@ -143,6 +143,7 @@ class FreeGaussianModel(nn.Module):
         self.vis_counts: Optional[torch.Tensor] = None
         self.max_2Dsize: Optional[torch.Tensor] = None
         self.last_size = (1, 1)
+        self.last_list_length = 0
         self.crop_box = None  # (:220) set through set_crop by the viewer / render scripts
         self._active_crop: Optional[torch.Tensor] = None
 
@@ -296,6 +297,7 @@ class FreeGaussianModel(nn.Module):
             info["means2d"].retain_grad()
         self.xys = info["means2d"]  # [1,N,2]
         self.radii = info["radii"][0]  # [N]
+        self.last_list_length = int(info["raster_flatten_ids"].numel())  # (the capacity, in static-shape mode)
         background = self._get_background_color()
         rgb = torch.clamp(render[..., :3] + (1 - alpha) * background, 0.0, 1.0)
         if render_mode == "RGB+ED":
@@ -336,6 +338,7 @@ class FreeGaussianModel(nn.Module):
             info["means2d"].retain_grad()
         self.xys = info["means2d"]
         self.radii = info["radii"][0]
+        self.last_list_length = int(info["raster_flatten_ids"].numel())  # (the capacity, in static-shape mode)
         if render_mode == "RGB+ED":
             depth = rgb[..., 3:4]
             depth = torch.where(alpha > 0, depth, depth.detach().max()).squeeze(0)
@@ -366,12 +369,17 @@ class FreeGaussianModel(nn.Module):
 
     def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)
+        return self._outputs_from(viewmat, K, W, H, camera.times)
+
+    def _outputs_from(self, viewmat, K, W, H, times):
+        """H4 + the raster call on device-resident camera data: everything of ``get_outputs`` behind the host
+        side of the camera (what ``graphed.GraphedModelStep`` captures)."""
         if self.step < self.config.warm_up:
             means = self.means
             d_rotation, d_scaling = 0.0, 0.0
         else:
             pts = self.means
-            times = camera.times.to(self.device).expand(pts.shape[0], -1)
+            times = times.to(self.device).expand(pts.shape[0], -1)
             d_xyz, d_rotation, d_scaling = self.deform(pts.detach(), times)
             means = from_homogenous(torch.bmm(d_xyz, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
         return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
@@ -391,17 +399,20 @@ class FreeGaussianModel(nn.Module):
         if self.step >= self.config.stop_split_at:
             return
         with torch.no_grad():
+            # The reference indexes with the boolean mask (`x[visible] += ...`, :379-392): every such line is
+            # a nonzero() with a host sync and a gather / scatter pair.  The same numbers with fixed shapes:
+            # adding 0.0 and taking max(x, 0) with x >= 0 leave the invisible rows bit-for-bit as they were.
             visible = (self.radii > 0).flatten()
-            grads = self.xys.absgrad[0][visible].norm(dim=-1)
+            grads = self.xys.absgrad[0].norm(dim=-1)
             if self.xys_grad_norm is None:
                 self.xys_grad_norm = torch.zeros(self.num_points, device=self.device)
                 self.vis_counts = torch.ones(self.num_points, device=self.device)
-            self.vis_counts[visible] += 1
-            self.xys_grad_norm[visible] += grads
+            self.vis_counts += visible.to(self.vis_counts.dtype)
+            self.xys_grad_norm += torch.where(visible, grads, torch.zeros_like(grads))
             if self.max_2Dsize is None:
                 self.max_2Dsize = torch.zeros(self.num_points, device=self.device)
-            new = self.radii[visible].float() / float(max(self.last_size))
-            self.max_2Dsize[visible] = torch.maximum(self.max_2Dsize[visible], new)
+            new = self.radii.float() / float(max(self.last_size))
+            self.max_2Dsize = torch.maximum(self.max_2Dsize, torch.where(visible, new, torch.zeros_like(new)))
 
     def get_gaussian_param_groups(self) -> Dict[str, List[nn.Parameter]]:
         return {k: [self.gauss_params[k]] for k in ("means", "scales", "quats", "features_dc", "features_rest", "opacities")}

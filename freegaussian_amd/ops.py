@@ -566,22 +566,25 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
 def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
     """Banded binning (csrc/tilebin.hip: fg_tilebin_count + fg_tilebin_fill), same contract as ``bin_tiles``.
     The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
-    from the previous calls of this shape and refilled exactly if the list turned out longer."""
+    from the previous calls of this shape and refilled exactly if the list turned out longer.  The ranges
+    handed to the consumers (``list_offsets``, the returned offsets tensor) are the tile ranges when the list
+    fitted and all-zero when it did not, so a raster launch enqueued on a too-small guess walks nothing."""
     lib = _lib.load()
     depth_keys, rects = keys_rects
     n_tiles = tile_w * tile_h
+    tile_offsets, offsets = offsets, torch.empty_like(offsets)  # exact ranges / the ranges consumers read
     ws1 = torch.empty(int(lib.fg_tilebin_count_workspace_bytes(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     static = static_capacity is not None
     count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
-    _call("fg_tilebin_count", N, _ptr(rects), tile_w, tile_h, _ptr(offsets), count_ptr, _ptr(ws1), ws1.numel(),
+    _call("fg_tilebin_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(lib.fg_tilebin_fill_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
-        _call("fg_tilebin_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(offsets), _ptr(ws1),
-              _ptr(ids), _ptr(ws2), ws2.numel(), _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+        _call("fg_tilebin_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1),
+              _ptr(ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
         return ids
 
     def keys_for(n):
@@ -591,14 +594,14 @@ def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_
         # static-shape mode (graphed.GraphedRaster): fixed-size list, no readback; valid iff the count fits
         cap = int(static_capacity)
         flatten_ids = fill(cap)
-        rctx.last_overflow = offsets[n_tiles:] > cap
+        rctx.last_overflow = tile_offsets[n_tiles:] > cap
         tk = None  # (keys: tile_keys_from_offsets on demand)
         return (tk, flatten_ids, offsets, None) if defer else (tk, flatten_ids, offsets)
     key = (dev, N, tile_w, tile_h, "banded")
     count_host = ready = None
     if count_slot is None:
         count_host = _count_buffer(dev)
-        count_host.copy_(offsets[n_tiles:], non_blocking=True)
+        count_host.copy_(tile_offsets[n_tiles:], non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
     capacity = _isect_capacity.get(key) if rctx.speculative_binning else None
@@ -623,6 +626,7 @@ def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_
         if capacity is not None:
             rctx.capacity_redos += 1
         if n_isects == 0:
+            offsets.zero_()
             return keys_for(0), torch.empty(0, dtype=torch.int32, device=dev), capacity is not None
         return keys_for(n_isects), fill(n_isects), True
 

@@ -149,8 +149,10 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * tile's segment meet in one L2 (csrc/tilebin.hip).  tile_rects / depth_keys: the optional outputs of
  * fg_preprocess_fwd.  fg_tilebin_count writes tile_offsets[T + 1] (exact, independent of any capacity)
  * and, if count_out is not NULL, the list length with system scope (pinned host memory).
- * fg_tilebin_fill writes flatten_ids[0 .. tile_offsets[T]) -- nothing at all when the list is longer than
- * `capacity` (the host then repeats the call with exact buffers; the count workspace stays valid).
+ * fg_tilebin_fill writes flatten_ids[0 .. tile_offsets[T]) and list_offsets[T + 1] = tile_offsets -- or, when
+ * the list is longer than `capacity`, no ids at all and list_offsets = 0 (empty lists: consumers enqueued
+ * speculatively behind the call walk nothing; the host then repeats the call with exact buffers, the count
+ * workspace stays valid).  Consumers of flatten_ids read list_offsets, not tile_offsets.
  * Replaces the binning + sort implied by tile_size=16 at freegaussian_model.py:806,857. */
 int fg_tilebin_supported(int tile_w, int tile_h);
 size_t fg_tilebin_count_workspace_bytes(int N, int tile_w, int tile_h);
@@ -159,7 +161,8 @@ int fg_tilebin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, i
 size_t fg_tilebin_fill_workspace_bytes(int64_t capacity);
 int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                     int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
-                    int32_t* flatten_ids, void* workspace, size_t workspace_bytes, fg_stream_t stream);
+                    int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                    fg_stream_t stream);
 
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
