@@ -1,6 +1,8 @@
 """Model-level step (FreeGaussianModel.get_outputs + backward, no deform MLP) on the bench scene:
 what a user of the reference model sees around the raster call (§8f row 3).
-Usage: python scripts/model_step_bench.py [n_gauss] [steps]"""
+Usage: python scripts/model_step_bench.py [n_gauss] [steps] [width] [height]
+With width x height at or below graphed.GraphedModelStep's tile limit the same step is also timed as one
+hipGraph replay (`graphed_model_step_ms`): the reference's first 6000 steps run at 1/4 and 1/2 resolution."""
 import json
 import os
 import sys
@@ -16,7 +18,8 @@ from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
-W, H = 1920, 1080
+W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
+H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
 cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9,
@@ -60,7 +63,22 @@ torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps * 1e3
 stages = ops.default_context.stage_timer.summary()
 ops.default_context.stage_timer = None
-res = {"model_step_ms": dt, "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
+graphed_ms = None
+from freegaussian_amd.graphed import GraphedModelStep  # noqa: E402
+
+gstep = GraphedModelStep(model, lambda rgb, gt: (rgb * gt).sum())
+if gstep.applicable(cam):
+    for p in params:
+        p.grad = None
+    for _ in range(5):
+        gstep.step(cam, vr)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        gstep.step(cam, vr)
+    torch.cuda.synchronize()
+    graphed_ms = (time.perf_counter() - t0) / steps * 1e3
+res = {"model_step_ms": dt, "graphed_model_step_ms": graphed_ms, "size": [n, W, H], "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
 if os.environ.get("FG_MODEL_PROFILE"):
     from torch.profiler import ProfilerActivity, profile
 

@@ -1424,6 +1424,60 @@ def test_graph_replays_with_classic_forward_and_listed_backward(live, monkeypatc
         del r0, a0
 
 
+def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
+    """harness.train_step(graphed=GraphedModelStep(...)): get_outputs + loss + backward replayed as one hipGraph
+    at a launch-bound size, against the eager step: 200 steps with a refinement every 100 (the Gaussian set is
+    re-allocated twice: re-capture), an SH degree change every 80 steps (another shape) and a list-capacity
+    overflow forced half way.  Up to the first refinement the two runs may differ only by the order of float
+    atomics (parameters within 1e-4 relative L2 after 99 Adam steps); over the whole run the same trajectory
+    (counts within 3%, losses within 10%) -- the comparison the eager-vs-torch densification test makes."""
+    import copy
+
+    from freegaussian_amd import harness as Hn
+    from freegaussian_amd.graphed import GraphedModelStep
+
+    runs = []
+    for use_graph in (False, True):
+        torch.manual_seed(123)
+        model, _, cam = _model_and_camera(n=6000, W=320, H=192, step=1, training=True)
+        c = model.config
+        c.warm_up, c.refine_start, c.refine_every, c.reset_alpha_every = 150, 50, 100, 30
+        c.densify_grad_thresh, c.stop_screen_size_at, c.sh_degree_interval = 2e-4, 0, 80
+        with torch.no_grad():
+            model.gauss_params["opacities"].copy_(torch.randn(6000, 1, generator=torch.Generator().manual_seed(3)).to(DEV) * 1.5)
+        target = copy.deepcopy(model)
+        with torch.no_grad():
+            target.gauss_params["features_dc"].add_(0.3)
+        target.eval()
+        with torch.no_grad():
+            gt = target.get_outputs(copy.deepcopy(cam))["rgb"].clamp(0, 1)
+        opts = Hn.build_optimizers(model)
+        g = GraphedModelStep(model, Hn.main_loss) if use_graph else None
+        assert g is None or g.applicable(cam)
+        torch.manual_seed(7)
+        hist, snap = [], None
+        for i in range(1, 201):
+            if g is not None and i == 60:
+                g.capacity = 2000  # far too small for the next capture: the overflow flag must trigger the redo
+                g.release()
+            hist.append(Hn.train_step(model, opts, copy.deepcopy(cam), gt, i, num_train_data=2, graphed=g))
+            if i == 99:
+                snap = {k: v.detach().clone() for k, v in model.gauss_params.items()}
+        runs.append((hist, snap, model, g))
+    (h0, s0, m0, _), (h1, s1, m1, g) = runs
+    assert g.replays >= 200 and g.captures >= 6  # first shape, degree 1 / 2, the forced overflow (2), two refinements
+    assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
+    for k in s0:
+        assert rel_l2(s1[k], s0[k]) < REL_TOL, k
+    c0, c1 = [h["gaussian_count"] for h in h0], [h["gaussian_count"] for h in h1]
+    assert c0[-1] != 6000 and len(set(c0)) >= 3  # two refinements happened
+    assert all(abs(a - b) <= 0.03 * b for a, b in zip(c1, c0))
+    for a, b in zip(h1, h0):
+        assert abs(a["loss"] - b["loss"]) <= 0.1 * abs(b["loss"]) + 1e-7
+    # the deform net took part after the warm-up (step 150) in both runs
+    assert all(p.grad is not None for p in m1.deform.parameters())
+
+
 def test_partial_requires_grad_noncontiguous_and_half_inputs():
     """Boundary hygiene: inputs that are non-contiguous views, lower precision, or only partly
     differentiable behave like their contiguous fp32 counterparts."""
