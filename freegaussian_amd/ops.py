@@ -628,7 +628,8 @@ def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_
         if n_isects == 0:
             offsets.zero_()
             return keys_for(0), torch.empty(0, dtype=torch.int32, device=dev), capacity is not None
-        return keys_for(n_isects), fill(n_isects), True
+        ids = fill(n_isects)  # (writes `offsets`, which keys_for reads: fill first)
+        return keys_for(n_isects), ids, True
 
     if defer and capacity is not None:
         return None, flatten_ids, offsets, finish

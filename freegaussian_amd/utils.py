@@ -55,7 +55,9 @@ def exp_se3(screw: torch.Tensor, theta: torch.Tensor) -> torch.Tensor:
     G = th * eye + (1.0 - c) * W + (th - s) * W2
     p = G @ v.unsqueeze(-1)
     top = torch.cat([R, p], dim=-1)
-    bottom = screw.new_tensor([0.0, 0.0, 0.0, 1.0]).expand(top.shape[0], 1, 4)
+    # (built on the device: a host list -> device copy is not allowed under hipGraph capture)
+    bottom = top.new_zeros(top.shape[0], 1, 4)
+    bottom[:, :, 3] = 1.0
     return torch.cat([top, bottom], dim=1)
 
 

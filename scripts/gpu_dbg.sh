@@ -1,11 +1,7 @@
 #!/bin/bash
 out=gpurun_out/${1:-dbg}; mkdir -p $out
-for b in 0 1; do
-  echo "== banded=$b 65536 test"
-  FG_BANDED_BINNING=$b AMD_SERIALIZE_KERNEL=3 HIP_LAUNCH_BLOCKING=1 timeout 300 python -m pytest tests -m gpu -q -x -k "65536" 2>&1 | grep -v "^  File\|pluggy\|^$" | tail -12
-done
-echo "== banded tests"
-timeout 600 python -m pytest tests -m gpu -q -k "banded" 2>&1 | tail -15
-echo "== graphed model"
-timeout 600 python -m pytest tests -m gpu -q -x -k "graphed_model" 2>&1 | tail -30
-for sz in "100000 30 480 270" "300000 30 960 540"; do timeout 300 python scripts/model_step_bench.py $sz 2>&1 | tail -22 | head -8; done
+FG_PARITY_REPORT=$out/margins.jsonl timeout 1200 python -m pytest tests -m gpu -q --timeout 600 2>&1 | grep -v "^  File\|pluggy" | tail -40 > $out/pytest.log
+tail -25 $out/pytest.log
+for sz in "100000 30 480 270" "300000 30 960 540"; do timeout 300 python scripts/model_step_bench.py $sz 2>/dev/null | tr -d '\n ' | cut -c1-900; echo; done
+for b in 0 1; do FG_BANDED_BINNING=$b timeout 300 python bench.py --width 960 --height 540 --n-gauss 300000 --steps 50 --warmup 10 --no-cpu-baseline --no-graph 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print('960x540 banded=$b', round(d['ms_per_step'],4), d['stage_ms'], d['host_step_ms'], d['config']['list_capacity_redos_in_timed_region'])"; done
