@@ -13,7 +13,8 @@ from freegaussian_amd.model import Camera, FreeGaussianModel, FreeGaussianModelC
 from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-W, H = 1920, 1080
+W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
+H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
 cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9)
@@ -53,4 +54,6 @@ for _ in range(100):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(32)
+st.sort_stats("tottime").print_stats(18)
+ms = torch.cuda.memory_stats()
+print({k: ms[k] for k in ("num_alloc_retries", "num_device_alloc", "num_device_free", "allocation.all.allocated")})

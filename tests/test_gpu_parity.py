@@ -1458,14 +1458,16 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
         hist, snap = [], None
         for i in range(1, 201):
             if g is not None and i == 60:
-                g.capacity = 2000  # far too small for the next capture: the overflow flag must trigger the redo
-                g.release()
+                g.capacity = 2000  # a graph whose list capacity is far too small: the replay's overflow flag must
+                g._capture()  # trigger the redo (measure, capture with room, replay)
             hist.append(Hn.train_step(model, opts, copy.deepcopy(cam), gt, i, num_train_data=2, graphed=g))
             if i == 99:
                 snap = {k: v.detach().clone() for k, v in model.gauss_params.items()}
         runs.append((hist, snap, model, g))
     (h0, s0, m0, _), (h1, s1, m1, g) = runs
-    assert g.replays >= 200 and g.captures >= 6  # first shape, degree 1 / 2, the forced overflow (2), two refinements
+    # captures: the first shape, the forced small graph + its redo, SH degree 1 and 2, the deform net switching
+    # on, the refinement at step 100 (the one at step 200 is the last step)
+    assert g.replays >= 200 and g.captures >= 6, (g.replays, g.captures)
     assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
     for k in s0:
         assert rel_l2(s1[k], s0[k]) < REL_TOL, k
