@@ -60,13 +60,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 // its four corners of an LDS grid and two prefix sums (along x, then along y) turn the corners into counts
 // -- work per rectangle, not per (rectangle, tile) pair.
 __global__ void __launch_bounds__(TB_BLOCK)
-tb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, uint32_t* __restrict__ table,
-                uint32_t* __restrict__ ticket) {
+tb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, uint32_t* __restrict__ table) {
   extern __shared__ int32_t s_grid[];  // [(rows + 1)][tile_w + 1] corner marks -> counts
   const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
   const Rows br = band_rows(xcd, tile_h);
   const int nr = br.r1 - br.r0, gw = tile_w + 1, T = tile_w * tile_h;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *ticket = 0;  // for the scan kernel behind this one
   if (nr <= 0) return;
   for (int i = threadIdx.x; i < (nr + 1) * gw; i += TB_BLOCK) s_grid[i] = 0;
   __syncthreads();
@@ -202,17 +200,13 @@ tb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   if (qn > 0) drain(qn);
 }
 
-// ---- scan: per tile the exclusive prefix over chunks (in place) and the tile's count; the last
-// workgroup to finish turns the counts into tile_offsets[T + 1] and publishes the list length ---------
+// ---- scan: per tile the exclusive prefix over chunks (in place) and the tile's count ---------------------
 // 16 tiles x 16 chunk slices per workgroup: the walk over a tile's column of the table is a chain of
 // memory round trips, so it is cut into 16 short ones (4 tiles x 64: 38 us; this: see profiles/).
 constexpr int TS_TILES = 16, TS_SLICES = TB_BLOCK / TS_TILES;
 __global__ void __launch_bounds__(TB_BLOCK)
-tb_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table, int32_t* __restrict__ tile_offsets,
-               uint32_t* __restrict__ ticket, int64_t* __restrict__ count_out) {
+tb_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table, int32_t* __restrict__ tile_offsets) {
   __shared__ uint32_t part[TS_SLICES][TS_TILES];
-  __shared__ uint32_t wave_tot[TB_BLOCK / 64];
-  __shared__ int is_last;
   const int tl = threadIdx.x % TS_TILES, qd = threadIdx.x / TS_TILES, t = blockIdx.x * TS_TILES + tl;
   const int cq = (n_chunks + TS_SLICES - 1) / TS_SLICES, c0 = min(qd * cq, n_chunks), c1 = min(c0 + cq, n_chunks);
   constexpr int U = 16;
@@ -255,12 +249,14 @@ tb_scan_kernel(int T, int n_chunks, uint32_t* __restrict__ table, int32_t* __res
     }
     if (qd == 0) tile_offsets[t + 1] = (int32_t)total;  // the tile's count, for the pass below
   }
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-  __syncthreads();
-  if (!is_last) return;
-  __threadfence();  // acquire: the other workgroups' counts (they sit in other XCDs' L2s)
+}
+
+// ... and the counts become tile_offsets[T + 1]: ONE workgroup, its own launch.  (As the tail of the kernel
+// above -- the last workgroup to arrive, found with a ticket -- every one of the 510 workgroups paid a
+// device-scope release, i.e. an L2 write-back, before taking its ticket: 65 us for a kernel that moves 16 MB.)
+__global__ void __launch_bounds__(TB_BLOCK)
+tb_offsets_kernel(int T, int32_t* __restrict__ tile_offsets, int64_t* __restrict__ count_out) {
+  __shared__ uint32_t wave_tot[TB_BLOCK / 64];
   // inclusive scan of the counts in place, 4096 at a time: coalesced loads into LDS (16 independent loads per
   // thread -- a chain of single loads here cost 60 us), every thread scans 16 consecutive values, block scan
   __shared__ uint32_t buf[TB_BLOCK * 16];
@@ -588,12 +584,12 @@ extern "C" int fg_tilebin_count(int N, const int32_t* tile_rects, int tile_w, in
   hipStream_t s = fg_hip_stream(stream);
   const int T = tile_w * tile_h, nc = n_chunks_of(N);
   uint32_t* table = static_cast<uint32_t*>(workspace);
-  uint32_t* ticket = reinterpret_cast<uint32_t*>(static_cast<char*>(workspace) + al256((size_t)nc * T * 4));
   const size_t lds = (size_t)((tile_h + 7) / 8 + 1) * (tile_w + 1) * 4;
   hipLaunchKernelGGL(tb_count_kernel, dim3(8 * nc), dim3(TB_BLOCK), lds, s, N, reinterpret_cast<const int2*>(tile_rects),
-                     tile_w, tile_h, table, ticket);
+                     tile_w, tile_h, table);
   hipLaunchKernelGGL(tb_scan_kernel, dim3((T + TS_TILES - 1) / TS_TILES), dim3(TB_BLOCK), 0, s, T, nc, table,
-                     tile_offsets, ticket, count_out);
+                     tile_offsets);
+  hipLaunchKernelGGL(tb_offsets_kernel, dim3(1), dim3(TB_BLOCK), 0, s, T, tile_offsets, count_out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
