@@ -44,6 +44,11 @@ SIGNATURES = {
     "fg_tilebin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
     "fg_tilebin_fill_workspace_bytes": (c_size_t, [c_int64]),
     "fg_tilebin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
+    "fg_stbin_supported": (c_int, [c_int, c_int, c_int]),
+    "fg_stbin_count_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "fg_stbin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
+    "fg_stbin_fill_workspace_bytes": (c_size_t, [c_int64]),
+    "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     # (the pointer before the stream of every raster entry point is the `const fg_raster_config*`)

@@ -1,0 +1,745 @@
+// K3 + K4, supertile form: the banded binning of tilebin.hip one level coarser.  A SUPERTILE is 2 x 2
+// tiles (32 x 32 pixels).  A Gaussian is scattered once per supertile its rectangle touches (2.4 on the
+// 1M / 1080p scene) instead of once per tile (6.0), every supertile's entries are sorted ONCE by (depth
+// bits, id), and the four tile lists are read off the sorted run in order -- an entry goes to the tiles
+// its rectangle covers.  Same lists as the reference algorithm (tile | depth keys, stable sort: behind
+// `tile_size=16` of /root/reference freegaussian/freegaussian_model.py:847-868), bit for bit: inside a
+// tile the order is the total order (depth bits, id) whatever route the entries took.
+//
+//   count   (xcd, chunk): corner marks of the chunk's rectangles on the band's tile grid and supertile grid
+//           (LDS), two prefix sums each -> table_t[chunk][T], table_s[chunk][S]
+//   columns per tile the sum over chunks; per supertile the exclusive prefix over chunks and the sum
+//   offsets one workgroup: tile_offsets[T + 1], st_offsets[S + 1], the list length to the host
+//   scatter (xcd, chunk): one 16-byte entry {depth bits, id, rectangle} per (Gaussian, supertile) pair
+//   sort    one workgroup per supertile: sort, then emit the four tile lists
+//
+// XCD = workgroup id % 8 owns a band of supertile rows in every kernel (private L2s: the scattered
+// stores of a segment meet in one L2; the raster kernels walk the same bands).
+#include "fg_common.h"
+
+namespace {
+
+constexpr int SB_BLOCK = 256;
+constexpr int SB_WAVES = SB_BLOCK / 64;
+constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
+constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
+constexpr int SB_SORT_MAX = 2048;                    // entries of a supertile sorted in LDS
+constexpr int SB_SORT_KPT = SB_SORT_MAX / SB_BLOCK;  // 8 per thread
+constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
+
+struct Geo {
+  int tile_w, tile_h, sw, sh;
+};
+__host__ __device__ __forceinline__ Geo geo_of(int tile_w, int tile_h) {
+  Geo g;
+  g.tile_w = tile_w;
+  g.tile_h = tile_h;
+  g.sw = (tile_w + 1) >> 1;
+  g.sh = (tile_h + 1) >> 1;
+  return g;
+}
+struct Band {
+  int sr0, sr1;  // supertile rows
+  int tr0, tr1;  // tile rows
+};
+__host__ __device__ __forceinline__ Band band_of(int xcd, const Geo& g) {
+  Band b;
+  b.sr0 = (xcd * g.sh) / 8;
+  b.sr1 = ((xcd + 1) * g.sh) / 8;
+  b.tr0 = 2 * b.sr0;
+  b.tr1 = 2 * b.sr1 < g.tile_h ? 2 * b.sr1 : g.tile_h;
+  return b;
+}
+int max_band_st_rows(const Geo& g) { return (g.sh + 7) / 8; }
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(v, d);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// corner marks -> counts: prefix along x (a wavefront per row, 64 cells a step), then along y with the
+// result written out (thread = column); grid[rows + 1][cols + 1], counts for [rows][cols]
+__device__ __forceinline__ void marks_to_counts(int32_t* grid, int rows, int cols, uint32_t* __restrict__ out) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6, gw = cols + 1;
+  for (int row = wave; row < rows; row += SB_WAVES) {
+    int carry = 0;
+    for (int x = 0; x < cols; x += 64) {
+      const int v = x + lane < cols ? grid[row * gw + x + lane] : 0;
+      const int incl = (int)wave_incl_scan((uint32_t)v, lane) + carry;
+      if (x + lane < cols) grid[row * gw + x + lane] = incl;
+      carry = __builtin_amdgcn_readlane(incl, 63);
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < cols; x += SB_BLOCK) {
+    int run = 0;
+    for (int row = 0; row < rows; ++row) {
+      run += grid[row * gw + x];
+      out[row * cols + x] = (uint32_t)run;
+    }
+  }
+}
+
+// ---- count --------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(SB_BLOCK)
+sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, uint32_t* __restrict__ table_t,
+                uint32_t* __restrict__ table_s) {
+  extern __shared__ int32_t s_grid[];  // tile grid [(tile rows + 1)][tile_w + 1], then supertile grid
+  const Geo g = geo_of(tile_w, tile_h);
+  const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+  const Band b = band_of(xcd, g);
+  const int ntr = b.tr1 - b.tr0, nsr = b.sr1 - b.sr0;
+  if (nsr <= 0) return;
+  const int gwt = tile_w + 1, gws = g.sw + 1;
+  int32_t* gt = s_grid;
+  int32_t* gs = s_grid + (ntr + 1) * gwt;
+  for (int i = threadIdx.x; i < (ntr + 1) * gwt + (nsr + 1) * gws; i += SB_BLOCK) s_grid[i] = 0;
+  __syncthreads();
+  const int g0 = chunk * SB_CHUNK + threadIdx.x;
+  int2 rc[SB_ROUNDS];
+#pragma unroll
+  for (int r = 0; r < SB_ROUNDS; ++r) rc[r] = (g0 + r * SB_BLOCK < N) ? rects[g0 + r * SB_BLOCK] : make_int2(0, 0);
+#pragma unroll
+  for (int r = 0; r < SB_ROUNDS; ++r) {
+    const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
+    const int ya = max(y0, b.tr0), yb = min(y0 + h, b.tr1);
+    if (w > 0 && yb > ya) {
+      const int ra = ya - b.tr0, rb = yb - b.tr0;
+      atomicAdd(&gt[ra * gwt + x0], 1);
+      atomicAdd(&gt[ra * gwt + x0 + w], -1);
+      atomicAdd(&gt[rb * gwt + x0], -1);
+      atomicAdd(&gt[rb * gwt + x0 + w], 1);
+      const int sxa = x0 >> 1, sxb = ((x0 + w - 1) >> 1) + 1;
+      const int sya = (ya >> 1) - b.sr0, syb = ((yb - 1) >> 1) + 1 - b.sr0;
+      atomicAdd(&gs[sya * gws + sxa], 1);
+      atomicAdd(&gs[sya * gws + sxb], -1);
+      atomicAdd(&gs[syb * gws + sxa], -1);
+      atomicAdd(&gs[syb * gws + sxb], 1);
+    }
+  }
+  __syncthreads();
+  const int T = tile_w * tile_h, S = g.sw * g.sh;
+  marks_to_counts(gt, ntr, tile_w, table_t + (size_t)chunk * T + b.tr0 * tile_w);
+  marks_to_counts(gs, nsr, g.sw, table_s + (size_t)chunk * S + b.sr0 * g.sw);
+}
+
+// ---- columns: 16 columns x 16 chunk slices per workgroup.  Workgroups [0, wg_t) sum the tile columns,
+// the rest turn the supertile columns into exclusive prefixes over chunks (in place) + the sum -----------
+constexpr int SC_COLS = 16, SC_SLICES = SB_BLOCK / SC_COLS;
+__global__ void __launch_bounds__(SB_BLOCK)
+sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restrict__ table_t,
+                  uint32_t* __restrict__ table_s, int32_t* __restrict__ tile_offsets, int32_t* __restrict__ st_offsets) {
+  __shared__ uint32_t part[SC_SLICES][SC_COLS];
+  const bool tiles = (int)blockIdx.x < wg_t;
+  const int n = tiles ? T : S;
+  const int cl = threadIdx.x % SC_COLS, qd = threadIdx.x / SC_COLS;
+  const int col = ((int)blockIdx.x - (tiles ? 0 : wg_t)) * SC_COLS + cl;
+  const int cq = (n_chunks + SC_SLICES - 1) / SC_SLICES, c0 = min(qd * cq, n_chunks), c1 = min(c0 + cq, n_chunks);
+  const uint32_t* src = tiles ? table_t : table_s;
+  constexpr int U = 16;
+  uint32_t v[U], s = 0;
+  const bool small = c1 - c0 <= U;
+  if (col < n) {
+    if (small) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) v[u] = c0 + u < c1 ? src[(size_t)(c0 + u) * n + col] : 0u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) s += v[u];
+    } else {
+      for (int c = c0; c < c1; ++c) s += src[(size_t)c * n + col];
+    }
+  }
+  part[qd][cl] = s;
+  __syncthreads();
+  uint32_t run = 0, total = 0;
+#pragma unroll
+  for (int k = 0; k < SC_SLICES; ++k) {
+    const uint32_t p = part[k][cl];
+    if (k < qd) run += p;
+    total += p;
+  }
+  if (col >= n) return;
+  if (tiles) {
+    if (qd == 0) tile_offsets[col + 1] = (int32_t)total;  // counts; sb_offsets_kernel scans them
+    return;
+  }
+  if (small) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u < c1) table_s[(size_t)(c0 + u) * n + col] = run;
+      run += v[u];
+    }
+  } else {
+    for (int c = c0; c < c1; ++c) {
+      const uint32_t x = table_s[(size_t)c * n + col];
+      table_s[(size_t)c * n + col] = run;
+      run += x;
+    }
+  }
+  if (qd == 0) st_offsets[col + 1] = (int32_t)total;
+}
+
+// ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup ----------------
+__device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
+                                                         uint32_t* wave_tot) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  uint32_t carry = 0;
+  for (int base = 0; base < n; base += SB_BLOCK * 16) {
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + k * SB_BLOCK + threadIdx.x;
+      buf[k * SB_BLOCK + threadIdx.x] = i < n ? (uint32_t)offs[i + 1] : 0u;
+    }
+    __syncthreads();
+    uint32_t v[16], sum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      v[k] = buf[threadIdx.x * 16 + k];
+      sum += v[k];
+    }
+    const uint32_t incl = wave_incl_scan(sum, lane);
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t run = carry + incl - sum, all = 0;
+#pragma unroll
+    for (int k = 0; k < SB_WAVES; ++k) {
+      if (k < wave) run += wave_tot[k];
+      all += wave_tot[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      run += v[k];
+      buf[threadIdx.x * 16 + k] = run;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int i = base + k * SB_BLOCK + threadIdx.x;
+      if (i < n) offs[i + 1] = (int32_t)buf[k * SB_BLOCK + threadIdx.x];
+    }
+    carry += all;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) offs[0] = 0;
+  return carry;
+}
+__global__ void __launch_bounds__(SB_BLOCK)
+sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __restrict__ st_offsets,
+                  int64_t* __restrict__ count_out) {
+  __shared__ uint32_t buf[SB_BLOCK * 16];
+  __shared__ uint32_t wave_tot[SB_WAVES];
+  const uint32_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);
+  scan_counts_in_place(S, st_offsets, buf, wave_tot);
+  if (threadIdx.x == 0 && count_out) {  // the list length straight into the caller's host-visible word
+    __hip_atomic_store(count_out, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+  }
+}
+
+// ---- scatter --------------------------------------------------------------------------------------------
+// Workgroup (xcd, chunk): a wavefront reads 64 rectangles per round, queues the ones that reach the band
+// (7 of 8 do not) and, whenever 64 are queued, walks their (Gaussian, supertile) pairs 64 at a time: every
+// lane finds the owner of its slot by binary search over the wave's exclusive counts and writes the entry
+// {depth bits, id, rectangle} to the slot an LDS cursor of the supertile hands out (segment start + the
+// chunks before this one, from the scanned table).
+__global__ void __launch_bounds__(SB_BLOCK)
+sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
+                  int tile_h, const uint32_t* __restrict__ table_s, const int32_t* __restrict__ tile_offsets,
+                  const int32_t* __restrict__ st_offsets, uint4* __restrict__ entries, long long capacity) {
+  extern __shared__ uint32_t s_cur[];  // [supertiles of the band]
+  __shared__ int4 s_q[SB_WAVES][128];
+  __shared__ int32_t s_excl[SB_WAVES][64];
+  const Geo g = geo_of(tile_w, tile_h);
+  const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
+  const Band b = band_of(xcd, g);
+  const int S = g.sw * g.sh, sb0 = b.sr0 * g.sw, nbs = (b.sr1 - b.sr0) * g.sw;
+  if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;  // the guess was too small: the host repeats the call
+  const uint32_t* row = table_s + (size_t)chunk * S + sb0;
+  for (int i = threadIdx.x; i < nbs; i += SB_BLOCK) s_cur[i] = (uint32_t)st_offsets[sb0 + i] + row[i];
+  __syncthreads();
+
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}; the supertile rectangle is recomputed when drained
+  int32_t* ex = s_excl[wave];
+  int qn = 0;
+
+  auto drain = [&](int m) {
+    const int4 e = q[lane];
+    const int w = e.w & 0xFFFF, h = e.w >> 16, x0 = e.z & 0xFFFF, y0 = e.z >> 16;
+    const int ya = max(y0, b.tr0), yb = min(y0 + h, b.tr1);
+    const int sxa = x0 >> 1, snx = ((x0 + w - 1) >> 1) + 1 - sxa;
+    const int sya = ya >> 1, sny = ((yb - 1) >> 1) + 1 - sya;
+    const uint32_t cnt = lane < m ? (uint32_t)(snx * sny) : 0u;
+    const uint32_t incl = wave_incl_scan(cnt, lane);
+    const int total = (int)__builtin_amdgcn_readlane((int)incl, 63);
+    ex[lane] = lane < m ? (int)(incl - cnt) : total;
+    __builtin_amdgcn_wave_barrier();
+    for (int s0 = 0; s0 < total; s0 += 64) {
+      const int slot = s0 + lane;
+      if (slot < total) {
+        int lo = 0;
+#pragma unroll
+        for (int step = 32; step > 0; step >>= 1)
+          if (ex[lo + step] <= slot) lo += step;
+        const int4 o = q[lo];
+        const int t = slot - ex[lo];
+        const int ow = o.w & 0xFFFF, ox0 = o.z & 0xFFFF, oy0 = o.z >> 16;
+        const int oxa = ox0 >> 1, onx = ((ox0 + ow - 1) >> 1) + 1 - oxa;
+        const int oya = max(oy0, b.tr0) >> 1;
+        int ty = (int)((float)t * __builtin_amdgcn_rcpf((float)onx));
+        ty -= (ty * onx > t);
+        ty += ((ty + 1) * onx <= t);
+        const int tx = t - ty * onx;
+        const int local = (oya + ty - b.sr0) * g.sw + oxa + tx;
+        const uint32_t pos = atomicAdd(&s_cur[local], 1u);
+        entries[pos] = make_uint4((uint32_t)o.y, (uint32_t)o.x, (uint32_t)o.z, (uint32_t)o.w);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+  auto pop64 = [&]() {
+    const int rest = qn - 64;
+    int4 keep = make_int4(0, 0, 0, 0);
+    if (lane < rest) keep = q[64 + lane];
+    __builtin_amdgcn_wave_barrier();
+    if (lane < rest) q[lane] = keep;
+    __builtin_amdgcn_wave_barrier();
+    qn = rest;
+  };
+
+  const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SB_WAVES);
+  for (int r = 0; r < SB_ROUNDS; ++r) {
+    const int gi = g0 + r * 64 + lane;
+    bool hit = false;
+    int4 e = make_int4(0, 0, 0, 1 | (1 << 16));
+    if (gi < N) {
+      const int2 rc = rects[gi];
+      const int w = rc.y & 0xFFFF, h = rc.y >> 16, y0 = rc.x >> 16;
+      hit = w > 0 && min(y0 + h, b.tr1) > max(y0, b.tr0);
+      e = make_int4(gi, 0, rc.x, rc.y);
+    }
+    if (hit) e.y = (int)depth_keys[gi];
+    const uint64_t bal = __ballot(hit);
+    if (hit) q[qn + __popcll(bal & lt_mask)] = e;
+    qn += __popcll(bal);
+    __builtin_amdgcn_wave_barrier();
+    if (qn >= 64) {
+      drain(64);
+      pop64();
+    }
+  }
+  if (qn > 0) drain(qn);
+}
+
+// ---- per-supertile sort + emission ------------------------------------------------------------------------
+// An element: depth bits << 32 | id << 4 | tile mask (bit j: the rectangle covers tile j = 2 * (row in the
+// supertile) + column).  Order = (depth bits, id): the mask sits below the id and never decides.
+__device__ __forceinline__ uint64_t same_digit_lanes(unsigned d, int nbits, bool in) {
+  const uint64_t in_mask = __ballot(in);
+  uint32_t lo = (uint32_t)in_mask, hi = (uint32_t)(in_mask >> 32);
+  for (int bit = 0; bit < nbits; ++bit) {
+    const int sel = (int)(d << (31 - bit)) >> 31;
+    const uint64_t m = __ballot(sel != 0);
+    lo = __builtin_amdgcn_bitop3_b32(lo, (uint32_t)m, (uint32_t)sel, 0x90);
+    hi = __builtin_amdgcn_bitop3_b32(hi, (uint32_t)(m >> 32), (uint32_t)sel, 0x90);
+  }
+  return ((uint64_t)hi << 32) | lo;
+}
+// wave_cnt[w][digit] counts -> start slots (digit-major, wavefronts in order inside a digit); thread = digit
+__device__ __forceinline__ void digit_starts(uint32_t (*wave_cnt)[256], uint32_t* scan_tmp) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  uint32_t c[SB_WAVES], tot = 0;
+#pragma unroll
+  for (int w = 0; w < SB_WAVES; ++w) {
+    c[w] = wave_cnt[w][threadIdx.x];
+    tot += c[w];
+  }
+  const uint32_t incl = wave_incl_scan(tot, lane);
+  if (lane == 63) scan_tmp[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - tot;
+#pragma unroll
+  for (int w = 0; w < SB_WAVES; ++w)
+    if (w < wave) run += scan_tmp[w];
+#pragma unroll
+  for (int w = 0; w < SB_WAVES; ++w) {
+    wave_cnt[w][threadIdx.x] = run;
+    run += c[w];
+  }
+  __syncthreads();
+}
+__device__ __forceinline__ void block_min_max(uint32_t lo, uint32_t hi, uint32_t* red, uint32_t& kmin, uint32_t& kmax) {
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, m));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, m));
+  }
+  const int wave = threadIdx.x >> 6;
+  if (fg::lane_id() == 0) {
+    red[wave] = lo;
+    red[4 + wave] = hi;
+  }
+  __syncthreads();
+  kmin = min(min(red[0], red[1]), min(red[2], red[3]));
+  kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+  __syncthreads();
+}
+// Position of element i inside its RUN -- the elements whose sorted key bits (depth bits minus the
+// segment's smallest, shifted right by `low`) are equal; adjacent after the passes, in arrival order -- by
+// the full order: the number of smaller elements of the run.
+template <typename Ptr>
+__device__ __forceinline__ int run_position(Ptr cur, int n, int i, uint64_t e, uint32_t kmin, int low) {
+  const uint32_t key = ((uint32_t)(e >> 32) - kmin) >> low;
+  const bool left = i > 0 && (((uint32_t)(cur[i - 1] >> 32) - kmin) >> low) == key;
+  const bool right = i + 1 < n && (((uint32_t)(cur[i + 1] >> 32) - kmin) >> low) == key;
+  if (!left && !right) return i;
+  int a = i;
+  while (a > 0 && (((uint32_t)(cur[a - 1] >> 32) - kmin) >> low) == key) --a;
+  int smaller = 0;
+  for (int j = a; j < n; ++j) {
+    const uint64_t o = cur[j];
+    if ((((uint32_t)(o >> 32) - kmin) >> low) != key) break;
+    smaller += o < e;
+  }
+  return a + smaller;
+}
+// The passes sort all key bits that differ inside the segment up to 16 (two 8-bit passes), of more only the
+// TOP 16; run_position settles the rest.  ~1000 entries over 65536 values of the sorted bits: runs of one or
+// two.  (Entries crowded into few values -- a wall plus one far outlier -- make long runs: slower, never wrong.)
+__device__ __forceinline__ int unsorted_low_bits(int bits) { return bits > 16 ? bits - 16 : 0; }
+
+__device__ __forceinline__ uint64_t element_of(const uint4 en, int tx0, int ty0, int tile_w, int tile_h) {
+  const int x0 = en.z & 0xFFFF, y0 = en.z >> 16, w = en.w & 0xFFFF, h = en.w >> 16;
+  uint32_t mask = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tx = tx0 + (j & 1), ty = ty0 + (j >> 1);
+    if (tx < tile_w && ty < tile_h && tx >= x0 && tx < x0 + w && ty >= y0 && ty < y0 + h) mask |= 1u << j;
+  }
+  return ((uint64_t)en.x << 32) | ((uint64_t)en.y << 4) | mask;
+}
+
+// The tile lists of a supertile from its n elements in final order (cur: LDS or global), read in order by the
+// workgroup: wavefront w owns the contiguous share [w span, (w + 1) span), counts its elements per tile, the
+// counts become bases (wavefronts in order), and a second walk writes every element's id to base + rank.
+template <typename Ptr>
+__device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base, int32_t* __restrict__ flatten_ids,
+                                           uint32_t (*cnt)[4]) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int span = ((n + SB_BLOCK - 1) / SB_BLOCK) * 64;
+  const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
+  uint32_t c[4] = {0, 0, 0, 0};
+  for (int i0 = w0; i0 < w1; i0 += 64) {
+    const int i = i0 + lane;
+    const uint32_t m = i < w1 ? (uint32_t)cur[i] & 15u : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] += (uint32_t)__popcll(__ballot((m >> j) & 1u));
+  }
+  if (lane < 4) cnt[wave][lane] = c[lane];
+  __syncthreads();
+  uint32_t base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    base[j] = (uint32_t)tile_base[j];
+    for (int w = 0; w < SB_WAVES; ++w)
+      if (w < wave) base[j] += cnt[w][j];
+  }
+  for (int i0 = w0; i0 < w1; i0 += 64) {
+    const int i = i0 + lane;
+    const uint64_t e = i < w1 ? cur[i] : 0ull;
+    const uint32_t m = (uint32_t)e & 15u, id = (uint32_t)(e >> 4) & 0x0FFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t bal = __ballot((m >> j) & 1u);
+      if ((m >> j) & 1u) flatten_ids[base[j] + (uint32_t)__popcll(bal & lt_mask)] = (int32_t)id;
+      base[j] += (uint32_t)__popcll(bal);
+    }
+  }
+}
+
+// A supertile too long for LDS: the same passes through global memory (a <-> b, both L2-resident), two sweeps
+// per pass (per-wavefront digit counts; stable slots), then the run fix into the other buffer.  Returns the
+// buffer holding the final order.  One workgroup; rare (thousands of entries).
+__device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32_t (*wave_cnt)[256], uint32_t* scan_tmp,
+                                         uint32_t* red) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+  for (int i = threadIdx.x; i < n; i += SB_BLOCK) {
+    const uint32_t k = (uint32_t)(a[i] >> 32);
+    lo = min(lo, k);
+    hi = max(hi, k);
+  }
+  uint32_t kmin, kmax;
+  block_min_max(lo, hi, red, kmin, kmax);
+  const uint32_t range = kmax - kmin;
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
+  const int span = ((n + SB_BLOCK - 1) / SB_BLOCK) * 64;
+  const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
+  uint64_t* src = a;
+  uint64_t* dst = b;
+  int first = low;
+  for (int p = 0; p < passes; ++p) {
+    const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
+    const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+    for (int w = 0; w < SB_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+    for (int i = w0 + lane; i < w1; i += 64)
+      atomicAdd(&wave_cnt[wave][(((uint32_t)(src[i] >> 32) - kmin) >> first) & mask], 1u);
+    __syncthreads();
+    digit_starts(wave_cnt, scan_tmp);
+    for (int i0 = w0; i0 < w1; i0 += 64) {
+      const int i = i0 + lane;
+      const bool in = i < w1;
+      const uint64_t e = in ? src[i] : 0ull;
+      const unsigned d = (((uint32_t)(e >> 32) - kmin) >> first) & mask;
+      const uint64_t peers = same_digit_lanes(d, nbits, in);
+      const int leader = in ? (int)__builtin_ctzll(peers) : lane;
+      uint32_t slot = 0;
+      if (in && leader == lane) slot = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(peers));
+      slot = (uint32_t)__shfl((int)slot, leader) + (uint32_t)__popcll(peers & lt_mask);
+      if (in) dst[slot] = e;
+    }
+    __threadfence();  // the next pass reads what other wavefronts wrote, through this CU's L1
+    __syncthreads();
+    uint64_t* t = src;
+    src = dst;
+    dst = t;
+    first += nbits;
+  }
+  for (int i = threadIdx.x; i < n; i += SB_BLOCK) {
+    const uint64_t e = src[i];
+    dst[run_position(src, n, i, e, kmin, low)] = e;
+  }
+  __threadfence();
+  __syncthreads();
+  return dst;
+}
+
+__global__ void __launch_bounds__(SB_BLOCK)
+sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
+               const uint4* __restrict__ entries, uint64_t* __restrict__ scratch_a, uint64_t* __restrict__ scratch_b,
+               long long capacity, int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
+  __shared__ uint64_t img[SB_SORT_MAX];
+  __shared__ uint32_t wave_cnt[SB_WAVES][256];
+  __shared__ uint32_t scan_tmp[SB_WAVES];
+  __shared__ uint32_t red[8];
+  __shared__ uint32_t tcnt[SB_WAVES][4];
+  const Geo g = geo_of(tile_w, tile_h);
+  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+  const Band b = band_of(xcd, g);
+  if (k >= (b.sr1 - b.sr0) * g.sw) return;
+  const int st = b.sr0 * g.sw + k, sy = st / g.sw, sx = st - sy * g.sw;
+  const int tx0 = 2 * sx, ty0 = 2 * sy, T = tile_w * tile_h;
+  const int total = tile_offsets[T];
+  const bool over = (long long)total > capacity;
+  int tile_base[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tx = tx0 + (j & 1), ty = ty0 + (j >> 1);
+    const bool inside = tx < tile_w && ty < tile_h;
+    const int tile = ty * tile_w + tx;
+    tile_base[j] = inside ? tile_offsets[tile] : 0;
+    // the ranges the CONSUMERS of flatten_ids read: the tile ranges when the list fits, empty lists when it
+    // does not (nothing is filled then; whoever was enqueued speculatively behind this call walks nothing)
+    if (inside && threadIdx.x == 0) {
+      list_offsets[tile] = over ? 0 : tile_base[j];
+      if (tile == T - 1) list_offsets[T] = over ? 0 : total;
+    }
+  }
+  const int off = st_offsets[st], n = st_offsets[st + 1] - off;
+  if (over || n <= 0) return;
+  if (n > SB_SORT_MAX) {
+    uint64_t* a = scratch_a + off;
+    for (int i = threadIdx.x; i < n; i += SB_BLOCK) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
+    __threadfence();
+    __syncthreads();
+    const uint64_t* fin = sort_segment_global(a, scratch_b + off, n, wave_cnt, scan_tmp, red);
+    emit_tiles(fin, n, tile_base, flatten_ids, tcnt);
+    return;
+  }
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int R = (n + SB_BLOCK - 1) / SB_BLOCK;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
+  const int ibase = wave * R * 64 + lane;
+  uint64_t e[SB_SORT_KPT];
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int q = 0; q < SB_SORT_KPT; ++q) {
+    e[q] = 0;
+    if (q < R) {
+      const int i = ibase + q * 64;
+      if (i < n) {
+        e[q] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
+        lo = min(lo, (uint32_t)(e[q] >> 32));
+        hi = max(hi, (uint32_t)(e[q] >> 32));
+      }
+    }
+  }
+  uint32_t kmin, kmax;
+  block_min_max(lo, hi, red, kmin, kmax);
+  const uint32_t range = kmax - kmin;
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
+  int first = low;
+  for (int p = 0; p < passes; ++p) {
+    const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
+    const uint32_t mask = (1u << nbits) - 1u;
+#pragma unroll
+    for (int w = 0; w < SB_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SB_SORT_KPT; ++q)
+      if (q < R && ibase + q * 64 < n) atomicAdd(&wave_cnt[wave][(((uint32_t)(e[q] >> 32) - kmin) >> first) & mask], 1u);
+    __syncthreads();
+    digit_starts(wave_cnt, scan_tmp);
+    // stable slots: the group's lowest lane advances the wavefront's cursor of the digit by the group size; all
+    // the atomics of a lane are issued before any result is consumed (same-address LDS atomics of one
+    // wavefront retire in issue order): one LDS round trip on the chain instead of R
+    uint32_t rk[SB_SORT_KPT];
+#pragma unroll
+    for (int q = 0; q < SB_SORT_KPT; ++q) {
+      rk[q] = 0;
+      if (q < R) {
+        const bool in = ibase + q * 64 < n;
+        const unsigned d = (((uint32_t)(e[q] >> 32) - kmin) >> first) & mask;
+        const uint64_t peers = same_digit_lanes(d, nbits, in);
+        const uint32_t leader = in ? (uint32_t)__builtin_ctzll(peers) : (uint32_t)lane;
+        uint32_t r = (uint32_t)__popcll(peers & lt_mask);
+        if (in && leader == (uint32_t)lane) r = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(peers));
+        rk[q] = r | (leader << 16);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SB_SORT_KPT; ++q) {
+      if (q < R) {
+        const uint32_t leader = rk[q] >> 16;
+        const uint32_t before = (uint32_t)__shfl((int)(rk[q] & 0xFFFFu), (int)leader);
+        const uint32_t slot = (leader == (uint32_t)lane) ? before : before + (rk[q] & 0xFFFFu);
+        if (ibase + q * 64 < n) img[slot] = e[q];
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < SB_SORT_KPT; ++q)
+      if (q < R && ibase + q * 64 < n) e[q] = img[ibase + q * 64];
+    first += nbits;
+  }
+  if (passes == 0) {  // every element has the same depth bits: the image is the input, ties decide
+#pragma unroll
+    for (int q = 0; q < SB_SORT_KPT; ++q)
+      if (q < R && ibase + q * 64 < n) img[ibase + q * 64] = e[q];
+    __syncthreads();
+  }
+  // the run fix, into the image: positions first (they read the image), then the moves
+  int pos[SB_SORT_KPT];
+#pragma unroll
+  for (int q = 0; q < SB_SORT_KPT; ++q) {
+    pos[q] = 0;
+    if (q < R && ibase + q * 64 < n) pos[q] = run_position(img, n, ibase + q * 64, e[q], kmin, low);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SB_SORT_KPT; ++q)
+    if (q < R && ibase + q * 64 < n) img[pos[q]] = e[q];
+  __syncthreads();
+  emit_tiles(img, n, tile_base, flatten_ids, tcnt);
+}
+
+size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+int n_chunks_of(int N) { return (N + SB_CHUNK - 1) / SB_CHUNK; }
+
+struct CountWs {
+  uint32_t *table_t, *table_s;
+  int32_t* st_offsets;
+  size_t bytes;
+};
+CountWs count_ws(void* base, int N, const Geo& g) {
+  const size_t nc = (size_t)n_chunks_of(N > 0 ? N : 1), T = (size_t)g.tile_w * g.tile_h, S = (size_t)g.sw * g.sh;
+  char* p = static_cast<char*>(base);
+  CountWs w;
+  size_t o = 0;
+  w.table_t = reinterpret_cast<uint32_t*>(p + o);
+  o += al256(nc * T * 4);
+  w.table_s = reinterpret_cast<uint32_t*>(p + o);
+  o += al256(nc * S * 4);
+  w.st_offsets = reinterpret_cast<int32_t*>(p + o);
+  o += al256((S + 1) * 4);
+  w.bytes = o;
+  return w;
+}
+size_t count_lds_bytes(const Geo& g) {
+  const int nsr = max_band_st_rows(g);
+  return ((size_t)(2 * nsr + 1) * (g.tile_w + 1) + (size_t)(nsr + 1) * (g.sw + 1)) * 4;
+}
+
+}  // namespace
+
+extern "C" int fg_stbin_supported(int N, int tile_w, int tile_h) {
+  if (N < 0 || N >= (1 << 28) || tile_w <= 0 || tile_h <= 0 || tile_w > 1023 || tile_h > 1023) return 0;
+  const Geo g = geo_of(tile_w, tile_h);
+  if (count_lds_bytes(g) > (size_t)SB_MAX_LDS_WORDS * 4) return 0;
+  return (size_t)max_band_st_rows(g) * g.sw <= (size_t)SB_MAX_LDS_WORDS ? 1 : 0;
+}
+
+extern "C" size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h) {
+  if (N < 0 || tile_w <= 0 || tile_h <= 0) return 0;
+  return count_ws(nullptr, N, geo_of(tile_w, tile_h)).bytes;
+}
+
+extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
+                              int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+  if (N <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_rects || !tile_offsets || !workspace) return FG_ERR_INVALID_ARG;
+  if (!fg_stbin_supported(N, tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
+  const Geo g = geo_of(tile_w, tile_h);
+  const CountWs w = count_ws(workspace, N, g);
+  if (workspace_bytes < w.bytes) return FG_ERR_WORKSPACE;
+  hipStream_t s = fg_hip_stream(stream);
+  const int T = tile_w * tile_h, S = g.sw * g.sh, nc = n_chunks_of(N);
+  hipLaunchKernelGGL(sb_count_kernel, dim3(8 * nc), dim3(SB_BLOCK), count_lds_bytes(g), s, N,
+                     reinterpret_cast<const int2*>(tile_rects), tile_w, tile_h, w.table_t, w.table_s);
+  const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
+  hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
+                     tile_offsets, w.st_offsets);
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(SB_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" size_t fg_stbin_fill_workspace_bytes(int64_t capacity) {
+  const size_t c = (size_t)(capacity > 0 ? capacity : 1);
+  return al256(c * 16) + 2 * al256(c * 8);
+}
+
+extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                             int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                             int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                             fg_stream_t stream) {
+  if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
+  if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !list_offsets || !workspace)
+    return FG_ERR_INVALID_ARG;
+  if (!fg_stbin_supported(N, tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
+  if (workspace_bytes < fg_stbin_fill_workspace_bytes(capacity)) return FG_ERR_WORKSPACE;
+  hipStream_t s = fg_hip_stream(stream);
+  const Geo g = geo_of(tile_w, tile_h);
+  const CountWs w = count_ws(const_cast<void*>(count_workspace), N, g);
+  const int nc = n_chunks_of(N);
+  char* p = static_cast<char*>(workspace);
+  uint4* entries = reinterpret_cast<uint4*>(p);
+  uint64_t* sa = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 16));
+  uint64_t* sb = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 16) + al256((size_t)capacity * 8));
+  const int max_band_st = max_band_st_rows(g) * g.sw;
+  hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
+                     reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
+                     w.st_offsets, entries, (long long)capacity);
+  hipLaunchKernelGGL(sb_sort_kernel, dim3(8 * max_band_st), dim3(SB_BLOCK), 0, s, tile_w, tile_h, tile_offsets,
+                     w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}

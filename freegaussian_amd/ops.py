@@ -126,10 +126,12 @@ class RasterContext:
         # list entries on the 1M / 1080p scene.  The reference-exact lists (info["flatten_ids"] etc.) are
         # rebuilt on demand from the radius boxes.
         self.tight_rects = e.get("FG_TIGHT_RECTS", "1") != "0"
-        # FG_BANDED_BINNING=0: the depth-first binning of rounds 1-2 (fg_bin_prepare_keys + fg_bin_emit_sort)
-        # instead of the banded count / scatter / per-tile sort (fg_tilebin_*): identical lists (A/B, and the
-        # fallback beyond fg_tilebin_supported)
-        self.banded_binning = e.get("FG_BANDED_BINNING", "1") != "0"
+        # FG_BINNING = supertile (default: fg_stbin_*, count / scatter per 2x2-tile supertile / one sort per
+        # supertile) | banded (fg_tilebin_*: the same per tile) | depthfirst (rounds 1-2: fg_bin_prepare_keys +
+        # fg_bin_emit_sort, also the fallback beyond fg_*bin_supported).  Identical lists.
+        self.binning = e.get("FG_BINNING", "supertile")
+        if self.binning not in ("supertile", "banded", "depthfirst"):
+            raise ValueError(f"FG_BINNING={self.binning!r}: supertile | banded | depthfirst")
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -471,8 +473,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         return torch.empty(0, dtype=torch.int32, device=dev), torch.empty(0, dtype=torch.int32, device=dev), offsets
     rctx = current()
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
-    if keys_rects is not None and rctx.banded_binning and lib.fg_tilebin_supported(tile_w, tile_h):
-        return _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+    if keys_rects is not None and rctx.binning == "supertile" and lib.fg_stbin_supported(N, tile_w, tile_h):
+        return _bin_tiles_banded(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+    if keys_rects is not None and rctx.binning != "depthfirst" and lib.fg_tilebin_supported(tile_w, tile_h):
+        return _bin_tiles_banded(rctx, "fg_tilebin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -563,8 +567,9 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
-    """Banded binning (csrc/tilebin.hip: fg_tilebin_count + fg_tilebin_fill), same contract as ``bin_tiles``.
+def _bin_tiles_banded(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
+    """Banded binning, same contract as ``bin_tiles``: ``abi`` = "fg_stbin" (csrc/stbin.hip: per 2x2-tile
+    supertile) or "fg_tilebin" (csrc/tilebin.hip: per tile); ``<abi>_count`` then ``<abi>_fill``.
     The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
     from the previous calls of this shape and refilled exactly if the list turned out longer.  The ranges
     handed to the consumers (``list_offsets``, the returned offsets tensor) are the tile ranges when the list
@@ -573,17 +578,17 @@ def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_
     depth_keys, rects = keys_rects
     n_tiles = tile_w * tile_h
     tile_offsets, offsets = offsets, torch.empty_like(offsets)  # exact ranges / the ranges consumers read
-    ws1 = torch.empty(int(lib.fg_tilebin_count_workspace_bytes(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
+    ws1 = torch.empty(int(getattr(lib, abi + "_count_workspace_bytes")(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     static = static_capacity is not None
     count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
-    _call("fg_tilebin_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
+    _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
-        ws2 = torch.empty(int(lib.fg_tilebin_fill_workspace_bytes(cap)), dtype=torch.uint8, device=dev)
-        _call("fg_tilebin_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1),
+        ws2 = torch.empty(int(getattr(lib, abi + "_fill_workspace_bytes")(cap)), dtype=torch.uint8, device=dev)
+        _call(abi + "_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1),
               _ptr(ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
         return ids
 
@@ -597,7 +602,7 @@ def _bin_tiles_banded(rctx, N, keys_rects, tile_w, tile_h, offsets, defer, want_
         rctx.last_overflow = tile_offsets[n_tiles:] > cap
         tk = None  # (keys: tile_keys_from_offsets on demand)
         return (tk, flatten_ids, offsets, None) if defer else (tk, flatten_ids, offsets)
-    key = (dev, N, tile_w, tile_h, "banded")
+    key = (dev, N, tile_w, tile_h, abi)
     count_host = ready = None
     if count_slot is None:
         count_host = _count_buffer(dev)

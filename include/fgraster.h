@@ -164,6 +164,23 @@ int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects
                     int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                     fg_stream_t stream);
 
+/* ---- K3+K4, supertile form (the default of rasterization(); identical lists) -------------------------------
+ * The banded binning one level coarser (csrc/stbin.hip): a supertile is 2 x 2 tiles; a Gaussian is scattered
+ * once per supertile its rectangle touches (16-byte entry: depth bits, id, rectangle), every supertile's
+ * entries are sorted once by (depth bits, id) and the four tile lists are read off the sorted run.  2.5x fewer
+ * scattered entries and sorted elements than per tile on the 1M / 1080p scene.  Same contract as fg_tilebin_*
+ * (count: tile_offsets + list length; fill: flatten_ids + list_offsets, nothing but empty ranges when the list
+ * is longer than `capacity`).  N < 2^28. */
+int fg_stbin_supported(int N, int tile_w, int tile_h);
+size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
+int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
+                   int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
+size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
+int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                  int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                  int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                  fg_stream_t stream);
+
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
  * of traffic per intersection over emission + the two sort passes. */

@@ -318,8 +318,8 @@ def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
     z = torch.zeros(N, device=DEV)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     outs = []
-    for banded in (False, True):
-        monkeypatch.setattr(ops.default_context, "banded_binning", banded)
+    for mode in ("depthfirst", "banded", "supertile"):
+        monkeypatch.setattr(ops.default_context, "binning", mode)
         ops.default_context.isect_capacity.clear()
         runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
         if overflow:
@@ -329,10 +329,11 @@ def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
         for _, f, o in runs[1:]:
             assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
         outs.append(runs[0])
-    (_, f0, o0), (_, f1, o1) = outs
-    assert torch.equal(o1, o0), "tile ranges differ"
-    assert torch.equal(f1, f0), "lists differ"
-    return f1, o1
+    (_, f0, o0), (_, f1, o1), (_, f2, o2) = outs
+    assert torch.equal(o1, o0) and torch.equal(o2, o0), "tile ranges differ"
+    assert torch.equal(f1, f0), "lists differ (banded)"
+    assert torch.equal(f2, f0), "lists differ (supertile)"
+    return f2, o2
 
 
 def _pack_rects(x0, y0, w, h):
@@ -341,8 +342,9 @@ def _pack_rects(x0, y0, w, h):
 
 @pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "one", "all_culled", "few_rows", "2160p"])
 def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
-    """csrc/tilebin.hip (count per tile -> scan -> scatter -> per-tile LDS sort by (depth bits, id)) against the
-    depth-first binning on the same depth keys and footprint rectangles: `torch.equal` lists and ranges.
+    """csrc/stbin.hip (count -> scan -> scatter per supertile -> one sort per supertile, four tile lists read off
+    it) and csrc/tilebin.hip (the same per tile) against the depth-first binning on the same depth keys and
+    footprint rectangles: `torch.equal` lists and ranges.
     Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
     a tile with more entries than fit the LDS sort (the pass through global memory); one Gaussian; nothing
     visible; an image with fewer tile rows than XCD bands; 32 400 tiles."""
@@ -1428,10 +1430,11 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     """harness.train_step(graphed=GraphedModelStep(...)): get_outputs + loss + backward replayed as one hipGraph
     at a launch-bound size, against the eager step: 200 steps with a refinement every 100 (the Gaussian set is
     re-allocated twice: re-capture), an SH degree change every 80 steps (another shape) and a list-capacity
-    overflow forced half way.  The two runs differ by the order of float atomics, which the L1 loss's sign()
-    and Adam's normalisation amplify step by step: parameters within 1e-4 relative L2 after 3 steps, within
-    1e-2 after 99; over the whole run the same trajectory (counts within 3%, losses within 10%) -- the
-    comparison the eager-vs-torch densification test makes."""
+    overflow forced half way.  One step from the same state: the replay's gradients equal the eager step's up
+    to the order of float atomics (1e-5).  Over many steps that noise is amplified without bound -- Adam turns a
+    gradient that is zero up to rounding (the radial component of a quaternion) into +-lr steps, the L1 loss's
+    sign() flips on pixels that sit on their target -- so the run is held to the same trajectory instead (counts
+    within 3%, losses within 10%): the comparison the eager-vs-torch densification test makes."""
     import copy
 
     from freegaussian_amd import harness as Hn
@@ -1455,15 +1458,23 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
         opts = Hn.build_optimizers(model)
         g = GraphedModelStep(model, Hn.main_loss) if use_graph else None
         assert g is None or g.applicable(cam)
+        # one step from the initial state, gradients only
+        model.step_cb(1)
+        if g is not None:
+            g.step(copy.deepcopy(cam), gt)
+        else:
+            Hn.main_loss(model.get_outputs(copy.deepcopy(cam))["rgb"], model.get_gt_img(gt)).backward()
+        first_grads = {k: v.grad.detach().clone() for k, v in model.gauss_params.items()}
+        if g is None:
+            for v in model.parameters():
+                v.grad = None
         torch.manual_seed(7)
-        hist, snap, snap3 = [], None, None
+        hist, snap, snap3 = [], None, first_grads
         for i in range(1, 201):
             if g is not None and i == 60:
                 g.capacity = 2000  # a graph whose list capacity is far too small: the replay's overflow flag must
                 g._capture()  # trigger the redo (measure, capture with room, replay)
             hist.append(Hn.train_step(model, opts, copy.deepcopy(cam), gt, i, num_train_data=2, graphed=g))
-            if i == 3:
-                snap3 = {k: v.detach().clone() for k, v in model.gauss_params.items()}
             if i == 99:
                 snap = {k: v.detach().clone() for k, v in model.gauss_params.items()}
         runs.append((hist, (snap3, snap), model, g))
@@ -1473,8 +1484,8 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     assert g.replays >= 200 and g.captures >= 6, (g.replays, g.captures)
     assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
     for k in s0:
-        assert rel_l2(t1[k], t0[k]) < REL_TOL, k
-        assert rel_l2(s1[k], s0[k]) < 1e-2, k
+        assert rel_l2(t1[k], t0[k]) < 1e-5, k  # the first step's gradients: atomic order only
+        assert s1[k].shape == s0[k].shape
     c0, c1 = [h["gaussian_count"] for h in h0], [h["gaussian_count"] for h in h1]
     assert c0[-1] != 6000 and len(set(c0)) >= 3  # two refinements happened
     assert all(abs(a - b) <= 0.03 * b for a, b in zip(c1, c0))
