@@ -45,17 +45,22 @@ __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const f
     const float4* src4 = reinterpret_cast<const float4*>(src);
     const int total4 = total / 4;
     const unsigned magic = ((1u << 20) + row_floats - 1) / row_floats;
+    const bool partial = use_floats < row_floats;  // (wave-uniform)
     float4 v[SLAB_MAX_Q];
     bool fetch[SLAB_MAX_Q];
 #pragma unroll
     for (int t = 0; t < SLAB_MAX_Q; ++t) {
       const int q = threadIdx.x + t * BLOCK;
       fetch[t] = q < total4;
-      if (row_live && fetch[t]) {  // a float4 touches at most two rows (rows are >= 3 floats)
+      if ((row_live || partial) && fetch[t]) {  // a float4 touches at most two rows (rows are >= 3 floats)
         const int e = 4 * q;
         const int r = (int)(((unsigned)e * magic) >> 20);
         const int r2 = (int)(((unsigned)(e + 3) * magic) >> 20);
-        fetch[t] = row_live[r] | row_live[r2 < nrows ? r2 : r];
+        // columns in use: the float4 starts inside them, or runs over into the next row's first columns
+        // (SH degree < 3 -- the reference's first 3000 steps -- uses 12 / 48 / 108 of a row's 192 bytes: the
+        // rest of the row is not fetched)
+        if (partial) fetch[t] = (e - r * row_floats < use_floats) | (r2 != r);
+        if (row_live) fetch[t] = fetch[t] & (row_live[r] | row_live[r2 < nrows ? r2 : r]);
       }
       if (fetch[t]) v[t] = FG_SLAB_LOAD(&src4[q]);
     }

@@ -23,8 +23,10 @@ constexpr int SB_BLOCK = 256;
 constexpr int SB_WAVES = SB_BLOCK / 64;
 constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
 constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
-constexpr int SB_SORT_MAX = 2048;                    // entries of a supertile sorted in LDS
-constexpr int SB_SORT_KPT = SB_SORT_MAX / SB_BLOCK;  // 8 per thread
+constexpr int SS_BLOCK = 512, SS_WAVES = SS_BLOCK / 64;  // the sort kernel's workgroup
+constexpr int SB_SORT_MAX = 4096;                    // entries of a supertile sorted in LDS (1250 on average, up to
+                                                     // ~2300, on the 1M / 1080p scene; larger: through global memory)
+constexpr int SB_SORT_KPT = SB_SORT_MAX / SS_BLOCK;  // 8 per thread
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 
 struct Geo {
@@ -183,7 +185,7 @@ sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restri
   if (qd == 0) st_offsets[col + 1] = (int32_t)total;
 }
 
-// ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup ----------------
+// ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup per array --------
 __device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
                                                          uint32_t* wave_tot) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
@@ -232,8 +234,11 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
                   int64_t* __restrict__ count_out) {
   __shared__ uint32_t buf[SB_BLOCK * 16];
   __shared__ uint32_t wave_tot[SB_WAVES];
+  if (blockIdx.x == 1) {  // (two workgroups: the two scans side by side)
+    scan_counts_in_place(S, st_offsets, buf, wave_tot);
+    return;
+  }
   const uint32_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);
-  scan_counts_in_place(S, st_offsets, buf, wave_tot);
   if (threadIdx.x == 0 && count_out) {  // the list length straight into the caller's host-visible word
     __hip_atomic_store(count_out, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
@@ -353,23 +358,28 @@ __device__ __forceinline__ uint64_t same_digit_lanes(unsigned d, int nbits, bool
 // wave_cnt[w][digit] counts -> start slots (digit-major, wavefronts in order inside a digit); thread = digit
 __device__ __forceinline__ void digit_starts(uint32_t (*wave_cnt)[256], uint32_t* scan_tmp) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  uint32_t c[SB_WAVES], tot = 0;
+  const bool own = threadIdx.x < 256;  // threads 0..255 own a digit each (wavefronts 0..3)
+  uint32_t c[SS_WAVES], tot = 0, incl = 0;
+  if (own) {
 #pragma unroll
-  for (int w = 0; w < SB_WAVES; ++w) {
-    c[w] = wave_cnt[w][threadIdx.x];
-    tot += c[w];
+    for (int w = 0; w < SS_WAVES; ++w) {
+      c[w] = wave_cnt[w][threadIdx.x];
+      tot += c[w];
+    }
+    incl = wave_incl_scan(tot, lane);
+    if (lane == 63) scan_tmp[wave] = incl;
   }
-  const uint32_t incl = wave_incl_scan(tot, lane);
-  if (lane == 63) scan_tmp[wave] = incl;
   __syncthreads();
-  uint32_t run = incl - tot;
+  if (own) {
+    uint32_t run = incl - tot;
 #pragma unroll
-  for (int w = 0; w < SB_WAVES; ++w)
-    if (w < wave) run += scan_tmp[w];
+    for (int w = 0; w < 4; ++w)
+      if (w < wave) run += scan_tmp[w];
 #pragma unroll
-  for (int w = 0; w < SB_WAVES; ++w) {
-    wave_cnt[w][threadIdx.x] = run;
-    run += c[w];
+    for (int w = 0; w < SS_WAVES; ++w) {
+      wave_cnt[w][threadIdx.x] = run;
+      run += c[w];
+    }
   }
   __syncthreads();
 }
@@ -382,11 +392,16 @@ __device__ __forceinline__ void block_min_max(uint32_t lo, uint32_t hi, uint32_t
   const int wave = threadIdx.x >> 6;
   if (fg::lane_id() == 0) {
     red[wave] = lo;
-    red[4 + wave] = hi;
+    red[SS_WAVES + wave] = hi;
   }
   __syncthreads();
-  kmin = min(min(red[0], red[1]), min(red[2], red[3]));
-  kmax = max(max(red[4], red[5]), max(red[6], red[7]));
+  kmin = red[0];
+  kmax = red[SS_WAVES];
+#pragma unroll
+  for (int w = 1; w < SS_WAVES; ++w) {
+    kmin = min(kmin, red[w]);
+    kmax = max(kmax, red[SS_WAVES + w]);
+  }
   __syncthreads();
 }
 // Position of element i inside its RUN -- the elements whose sorted key bits (depth bits minus the
@@ -432,7 +447,7 @@ __device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base,
                                            uint32_t (*cnt)[4]) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int span = ((n + SB_BLOCK - 1) / SB_BLOCK) * 64;
+  const int span = ((n + SS_BLOCK - 1) / SS_BLOCK) * 64;
   const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
   uint32_t c[4] = {0, 0, 0, 0};
   for (int i0 = w0; i0 < w1; i0 += 64) {
@@ -447,7 +462,7 @@ __device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     base[j] = (uint32_t)tile_base[j];
-    for (int w = 0; w < SB_WAVES; ++w)
+    for (int w = 0; w < SS_WAVES; ++w)
       if (w < wave) base[j] += cnt[w][j];
   }
   for (int i0 = w0; i0 < w1; i0 += 64) {
@@ -471,7 +486,7 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-  for (int i = threadIdx.x; i < n; i += SB_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += SS_BLOCK) {
     const uint32_t k = (uint32_t)(a[i] >> 32);
     lo = min(lo, k);
     hi = max(hi, k);
@@ -480,7 +495,7 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   block_min_max(lo, hi, red, kmin, kmax);
   const uint32_t range = kmax - kmin;
   const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
-  const int span = ((n + SB_BLOCK - 1) / SB_BLOCK) * 64;
+  const int span = ((n + SS_BLOCK - 1) / SS_BLOCK) * 64;
   const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
   uint64_t* src = a;
   uint64_t* dst = b;
@@ -488,8 +503,7 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
-#pragma unroll
-    for (int w = 0; w < SB_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < SS_WAVES * 256; i += SS_BLOCK) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
     for (int i = w0 + lane; i < w1; i += 64)
       atomicAdd(&wave_cnt[wave][(((uint32_t)(src[i] >> 32) - kmin) >> first) & mask], 1u);
@@ -514,7 +528,7 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
     dst = t;
     first += nbits;
   }
-  for (int i = threadIdx.x; i < n; i += SB_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += SS_BLOCK) {
     const uint64_t e = src[i];
     dst[run_position(src, n, i, e, kmin, low)] = e;
   }
@@ -523,15 +537,15 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   return dst;
 }
 
-__global__ void __launch_bounds__(SB_BLOCK)
+__global__ void __launch_bounds__(SS_BLOCK)
 sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                const uint4* __restrict__ entries, uint64_t* __restrict__ scratch_a, uint64_t* __restrict__ scratch_b,
                long long capacity, int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
   __shared__ uint64_t img[SB_SORT_MAX];
-  __shared__ uint32_t wave_cnt[SB_WAVES][256];
-  __shared__ uint32_t scan_tmp[SB_WAVES];
-  __shared__ uint32_t red[8];
-  __shared__ uint32_t tcnt[SB_WAVES][4];
+  __shared__ uint32_t wave_cnt[SS_WAVES][256];
+  __shared__ uint32_t scan_tmp[4];
+  __shared__ uint32_t red[2 * SS_WAVES];
+  __shared__ uint32_t tcnt[SS_WAVES][4];
   const Geo g = geo_of(tile_w, tile_h);
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
   const Band b = band_of(xcd, g);
@@ -558,7 +572,7 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   if (over || n <= 0) return;
   if (n > SB_SORT_MAX) {
     uint64_t* a = scratch_a + off;
-    for (int i = threadIdx.x; i < n; i += SB_BLOCK) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
+    for (int i = threadIdx.x; i < n; i += SS_BLOCK) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
     __threadfence();
     __syncthreads();
     const uint64_t* fin = sort_segment_global(a, scratch_b + off, n, wave_cnt, scan_tmp, red);
@@ -567,7 +581,7 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   }
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int R = (n + SB_BLOCK - 1) / SB_BLOCK;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
+  const int R = (n + SS_BLOCK - 1) / SS_BLOCK;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
   const int ibase = wave * R * 64 + lane;
   uint64_t e[SB_SORT_KPT];
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
@@ -591,8 +605,7 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
-#pragma unroll
-    for (int w = 0; w < SB_WAVES; ++w) wave_cnt[w][threadIdx.x] = 0;
+    for (int i = threadIdx.x; i < SS_WAVES * 256; i += SS_BLOCK) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SB_SORT_KPT; ++q)
@@ -707,7 +720,7 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
   hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
                      tile_offsets, w.st_offsets);
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(1), dim3(SB_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(2), dim3(SB_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -738,7 +751,7 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
                      w.st_offsets, entries, (long long)capacity);
-  hipLaunchKernelGGL(sb_sort_kernel, dim3(8 * max_band_st), dim3(SB_BLOCK), 0, s, tile_w, tile_h, tile_offsets,
+  hipLaunchKernelGGL(sb_sort_kernel, dim3(8 * max_band_st), dim3(SS_BLOCK), 0, s, tile_w, tile_h, tile_offsets,
                      w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;

@@ -138,6 +138,10 @@ class RasterContext:
         # FG_FILL_IN_FORWARD=0: zero the backward's record-gradient array with a fill launch at the head of
         # the backward instead of in passing in the mixed forward launch (A/B)
         self.fill_in_forward = e.get("FG_FILL_IN_FORWARD", "1") != "0"
+        # The forward's compositing checkpoints for the backward's list shares cost 64 bytes per list entry of
+        # the speculative capacity (fg_raster_seg_ckpt_floats), allocated per training forward and held until
+        # the backward.  Above this many bytes (FG_SEG_CKPT_BUDGET_MB, default 2048) a step does without them.
+        self.seg_ckpt_budget_bytes = int(float(e.get("FG_SEG_CKPT_BUDGET_MB", "2048")) * (1 << 20))
         # Optional two-stream forward (FG_OVERLAP_PACK=1, off by default): the projection (whose outputs the
         # binning needs) runs on the current stream, the colour + record half (HBM-bound, 300 B per
         # Gaussian) on a side stream, concurrently with the binning kernels.  Measured on MI355X at 1M /
@@ -1019,7 +1023,9 @@ class _RasterSplats(torch.autograd.Function):
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
             n_ck = int(_lib.load().fg_raster_seg_ckpt_floats(channels, int(width), int(height), int(tile_size),
                                                              int(flatten_ids.numel()), cfgp))  # fmt: skip
-            if n_ck > 0:
+            # (64 bytes per list entry of CAPACITY -- 0.4 GB at 6M entries -- held from forward to backward:
+            # beyond the context's budget the backward runs without list shares, i.e. as pixel-strip jobs)
+            if n_ck > 0 and 4 * n_ck <= ctx.rctx.seg_ckpt_budget_bytes:
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
             live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)

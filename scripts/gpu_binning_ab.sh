@@ -1,5 +1,5 @@
 #!/bin/bash
-# Banded binning against the depth-first binning: parity tests, step time A/B, per-kernel durations.
+# The three binning paths: parity tests, step time A/B, per-kernel durations of the default.
 # Usage: gpurun --timeout 1500 -- 'bash scripts/gpu_binning_ab.sh <tag> [full]'
 tag=${1:-bin}
 out=gpurun_out/$tag
@@ -7,17 +7,17 @@ mkdir -p $out
 export TMPDIR=/tmp
 sel='-k "banded or binning or footprint or cfg1 or full_pipeline or speculative or redoes or 65536 or graph"'
 [ "$2" = "full" ] && sel=""
-eval FG_PARITY_REPORT=$out/margins.jsonl timeout 1200 python -m pytest tests -m gpu -q --timeout 600 $sel 2>&1 | tail -40 > $out/pytest.log
+eval FG_PARITY_REPORT=$out/margins.jsonl timeout 1200 python -m pytest tests -m gpu -q --timeout 600 $sel 2>&1 | grep -v "^  File\|pluggy" | tail -40 > $out/pytest.log
 tail -12 $out/pytest.log
-for b in 0 1; do
-  FG_BANDED_BINNING=$b timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $out/bench_b$b.json 2> $out/bench_b$b.err
+for b in depthfirst banded supertile; do
+  FG_BINNING=$b timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $out/bench_$b.json 2> $out/bench_$b.err
   python - <<PY
 import json
 try:
-    d=json.load(open("$out/bench_b$b.json"))
-    print("banded=$b", round(d["value"],1), "Mpix/s", round(d["ms_per_step"],4), "ms", d["stage_ms"])
+    d=json.load(open("$out/bench_$b.json"))
+    print("$b", round(d["value"],1), "Mpix/s", round(d["ms_per_step"],4), "ms", d["stage_ms"])
 except Exception as e:
-    print("banded=$b failed", e); print(open("$out/bench_b$b.err").read()[-1500:])
+    print("$b failed", e); print(open("$out/bench_$b.err").read()[-1500:])
 PY
 done
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o stats -- python3 bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-graph > $out/prof_bench.json 2> $out/prof.err
@@ -25,6 +25,6 @@ find $out/prof -name "*kernel_stats*" -exec cp {} $out/kernel_stats.csv \;
 find $out/prof -name "*kernel_trace*" -delete
 python - <<PY
 import csv
-for r in list(csv.DictReader(open("$out/kernel_stats.csv")))[:12]:
+for r in list(csv.DictReader(open("$out/kernel_stats.csv")))[:13]:
     print(f'{r["Name"][:64]:64s} calls={r["Calls"]:>5s} avg_us={float(r["AverageNs"])/1e3:8.1f}')
 PY

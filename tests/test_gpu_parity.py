@@ -1349,6 +1349,35 @@ def test_factored_view_dp_exchange_two_ranks_on_one_gpu():
         assert out.returncode == 0 and "exchange ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
 
 
+def test_world_size_8_exchange_and_bench_launcher_over_gloo_on_one_gpu():
+    """The driver's 8-GPU RCCL run must not be the first time world = 8 executes: (1) the factored exchange
+    against the plain all-reduce with EIGHT ranks (eight payload strides in the all-gather, eight views in the
+    local SH rebuild), shared and per-view means, over gloo with all ranks on this GPU; (2) `bench.py --gpus 8`
+    through its own launcher with FG_BENCH_BACKEND=gloo: n_gpus 8, the factored exchange kept, no fallback."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for per_view, port in (("0", "29541"), ("1", "29543")):
+        env = dict(os.environ, FG_BENCH_BACKEND="gloo", FG_PER_VIEW_MEANS=per_view, OMP_NUM_THREADS="4")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr",
+               "127.0.0.1", "--master-port", port, os.path.join(root, "scripts", "exchange_check.py")]  # fmt: skip
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0 and "exchange ok" in out.stdout and "world=8" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(FG_BENCH_BACKEND="gloo", OMP_NUM_THREADS="4")
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                          "--n-gauss", "50000", "--width", "640", "--height", "360"], env=env, capture_output=True,
+                         text=True, timeout=900)  # fmt: skip
+    assert res.returncode == 0, res.stderr[-3000:]
+    line = json.loads(res.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 8 and len(line["per_rank_mpix_per_s"]) == 8
+    assert line["exchange"]["kind"] == "factored" and line["exchange"]["fallback"] is None
+    assert "gloo" in line["exchange"]["backend"] and "gloo gradient exchange" in line["config"]["workload"]
+
+
 def test_view_dp_training_keeps_two_ranks_in_lockstep():
     """FreeGaussianModel trained view-sharded on 2 ranks sharing this GPU (gloo): gradient exchange,
     densification-statistics exchange and shared split samples keep the replicas bit-identical
@@ -1484,7 +1513,9 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     assert g.replays >= 200 and g.captures >= 6, (g.replays, g.captures)
     assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
     for k in s0:
-        assert rel_l2(t1[k], t0[k]) < 1e-5, k  # the first step's gradients: atomic order only
+        # the first step's gradients: atomic order only.  (The scene's Gaussians are isotropic, so the gradient of
+        # the rotations is zero up to rounding -- ~1e-13 of noise, which has no relative error to speak of.)
+        assert float(t0[k].norm()) < 1e-9 or rel_l2(t1[k], t0[k]) < 1e-5, k
         assert s1[k].shape == s0[k].shape
     c0, c1 = [h["gaussian_count"] for h in h0], [h["gaussian_count"] for h in h1]
     assert c0[-1] != 6000 and len(set(c0)) >= 3  # two refinements happened
