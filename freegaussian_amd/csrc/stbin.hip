@@ -23,10 +23,10 @@ constexpr int SB_BLOCK = 256;
 constexpr int SB_WAVES = SB_BLOCK / 64;
 constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
 constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
-constexpr int SS_BLOCK = 512, SS_WAVES = SS_BLOCK / 64;  // the sort kernel's workgroup
+constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 8;  // wavefronts per workgroup of the two sort launches
 constexpr int SB_SORT_MAX = 4096;                    // entries of a supertile sorted in LDS (1250 on average, up to
                                                      // ~2300, on the 1M / 1080p scene; larger: through global memory)
-constexpr int SB_SORT_KPT = SB_SORT_MAX / SS_BLOCK;  // 8 per thread
+constexpr int SB_SORT_KPT = 8;                       // elements per thread
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 
 struct Geo {
@@ -356,13 +356,14 @@ __device__ __forceinline__ uint64_t same_digit_lanes(unsigned d, int nbits, bool
   return ((uint64_t)hi << 32) | lo;
 }
 // wave_cnt[w][digit] counts -> start slots (digit-major, wavefronts in order inside a digit); thread = digit
+template <int NW>
 __device__ __forceinline__ void digit_starts(uint32_t (*wave_cnt)[256], uint32_t* scan_tmp) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const bool own = threadIdx.x < 256;  // threads 0..255 own a digit each (wavefronts 0..3)
-  uint32_t c[SS_WAVES], tot = 0, incl = 0;
+  uint32_t c[NW], tot = 0, incl = 0;
   if (own) {
 #pragma unroll
-    for (int w = 0; w < SS_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
       c[w] = wave_cnt[w][threadIdx.x];
       tot += c[w];
     }
@@ -376,13 +377,14 @@ __device__ __forceinline__ void digit_starts(uint32_t (*wave_cnt)[256], uint32_t
     for (int w = 0; w < 4; ++w)
       if (w < wave) run += scan_tmp[w];
 #pragma unroll
-    for (int w = 0; w < SS_WAVES; ++w) {
+    for (int w = 0; w < NW; ++w) {
       wave_cnt[w][threadIdx.x] = run;
       run += c[w];
     }
   }
   __syncthreads();
 }
+template <int NW>
 __device__ __forceinline__ void block_min_max(uint32_t lo, uint32_t hi, uint32_t* red, uint32_t& kmin, uint32_t& kmax) {
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) {
@@ -392,15 +394,15 @@ __device__ __forceinline__ void block_min_max(uint32_t lo, uint32_t hi, uint32_t
   const int wave = threadIdx.x >> 6;
   if (fg::lane_id() == 0) {
     red[wave] = lo;
-    red[SS_WAVES + wave] = hi;
+    red[NW + wave] = hi;
   }
   __syncthreads();
   kmin = red[0];
-  kmax = red[SS_WAVES];
+  kmax = red[NW];
 #pragma unroll
-  for (int w = 1; w < SS_WAVES; ++w) {
+  for (int w = 1; w < NW; ++w) {
     kmin = min(kmin, red[w]);
-    kmax = max(kmax, red[SS_WAVES + w]);
+    kmax = max(kmax, red[NW + w]);
   }
   __syncthreads();
 }
@@ -442,12 +444,12 @@ __device__ __forceinline__ uint64_t element_of(const uint4 en, int tx0, int ty0,
 // The tile lists of a supertile from its n elements in final order (cur: LDS or global), read in order by the
 // workgroup: wavefront w owns the contiguous share [w span, (w + 1) span), counts its elements per tile, the
 // counts become bases (wavefronts in order), and a second walk writes every element's id to base + rank.
-template <typename Ptr>
+template <int NW, typename Ptr>
 __device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base, int32_t* __restrict__ flatten_ids,
                                            uint32_t (*cnt)[4]) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int span = ((n + SS_BLOCK - 1) / SS_BLOCK) * 64;
+  const int span = ((n + (64 * NW) - 1) / (64 * NW)) * 64;
   const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
   uint32_t c[4] = {0, 0, 0, 0};
   for (int i0 = w0; i0 < w1; i0 += 64) {
@@ -462,7 +464,7 @@ __device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base,
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     base[j] = (uint32_t)tile_base[j];
-    for (int w = 0; w < SS_WAVES; ++w)
+    for (int w = 0; w < NW; ++w)
       if (w < wave) base[j] += cnt[w][j];
   }
   for (int i0 = w0; i0 < w1; i0 += 64) {
@@ -481,21 +483,22 @@ __device__ __forceinline__ void emit_tiles(Ptr cur, int n, const int* tile_base,
 // A supertile too long for LDS: the same passes through global memory (a <-> b, both L2-resident), two sweeps
 // per pass (per-wavefront digit counts; stable slots), then the run fix into the other buffer.  Returns the
 // buffer holding the final order.  One workgroup; rare (thousands of entries).
+template <int NW>
 __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32_t (*wave_cnt)[256], uint32_t* scan_tmp,
                                          uint32_t* red) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-  for (int i = threadIdx.x; i < n; i += SS_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += (64 * NW)) {
     const uint32_t k = (uint32_t)(a[i] >> 32);
     lo = min(lo, k);
     hi = max(hi, k);
   }
   uint32_t kmin, kmax;
-  block_min_max(lo, hi, red, kmin, kmax);
+  block_min_max<NW>(lo, hi, red, kmin, kmax);
   const uint32_t range = kmax - kmin;
   const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
-  const int span = ((n + SS_BLOCK - 1) / SS_BLOCK) * 64;
+  const int span = ((n + (64 * NW) - 1) / (64 * NW)) * 64;
   const int w0 = min(wave * span, n), w1 = min(w0 + span, n);
   uint64_t* src = a;
   uint64_t* dst = b;
@@ -503,12 +506,12 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
-    for (int i = threadIdx.x; i < SS_WAVES * 256; i += SS_BLOCK) (&wave_cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += (64 * NW)) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
     for (int i = w0 + lane; i < w1; i += 64)
       atomicAdd(&wave_cnt[wave][(((uint32_t)(src[i] >> 32) - kmin) >> first) & mask], 1u);
     __syncthreads();
-    digit_starts(wave_cnt, scan_tmp);
+    digit_starts<NW>(wave_cnt, scan_tmp);
     for (int i0 = w0; i0 < w1; i0 += 64) {
       const int i = i0 + lane;
       const bool in = i < w1;
@@ -528,7 +531,7 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
     dst = t;
     first += nbits;
   }
-  for (int i = threadIdx.x; i < n; i += SS_BLOCK) {
+  for (int i = threadIdx.x; i < n; i += (64 * NW)) {
     const uint64_t e = src[i];
     dst[run_position(src, n, i, e, kmin, low)] = e;
   }
@@ -537,15 +540,17 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   return dst;
 }
 
-__global__ void __launch_bounds__(SS_BLOCK)
+template <int NW>
+__global__ void __launch_bounds__(64 * NW)
 sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                const uint4* __restrict__ entries, uint64_t* __restrict__ scratch_a, uint64_t* __restrict__ scratch_b,
                long long capacity, int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
-  __shared__ uint64_t img[SB_SORT_MAX];
-  __shared__ uint32_t wave_cnt[SS_WAVES][256];
+  constexpr int MAXN = 64 * NW * SB_SORT_KPT;  // elements sorted in LDS by this variant
+  __shared__ uint64_t img[MAXN];
+  __shared__ uint32_t wave_cnt[NW][256];
   __shared__ uint32_t scan_tmp[4];
-  __shared__ uint32_t red[2 * SS_WAVES];
-  __shared__ uint32_t tcnt[SS_WAVES][4];
+  __shared__ uint32_t red[2 * NW];
+  __shared__ uint32_t tcnt[NW][4];
   const Geo g = geo_of(tile_w, tile_h);
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
   const Band b = band_of(xcd, g);
@@ -563,25 +568,28 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
     tile_base[j] = inside ? tile_offsets[tile] : 0;
     // the ranges the CONSUMERS of flatten_ids read: the tile ranges when the list fits, empty lists when it
     // does not (nothing is filled then; whoever was enqueued speculatively behind this call walks nothing)
-    if (inside && threadIdx.x == 0) {
+    if (NW == SB_SMALL_WAVES && inside && threadIdx.x == 0) {
       list_offsets[tile] = over ? 0 : tile_base[j];
       if (tile == T - 1) list_offsets[T] = over ? 0 : total;
     }
   }
   const int off = st_offsets[st], n = st_offsets[st + 1] - off;
   if (over || n <= 0) return;
-  if (n > SB_SORT_MAX) {
+  // two launches share the supertiles: 256-thread workgroups (20 KB of LDS: eight per CU) take the ones
+  // with up to 2048 entries -- nearly all --, 512-thread workgroups the longer ones
+  if (NW == SB_SMALL_WAVES ? n > MAXN : n <= 64 * SB_SMALL_WAVES * SB_SORT_KPT) return;
+  if (n > MAXN) {
     uint64_t* a = scratch_a + off;
-    for (int i = threadIdx.x; i < n; i += SS_BLOCK) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
+    for (int i = threadIdx.x; i < n; i += (64 * NW)) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
     __threadfence();
     __syncthreads();
-    const uint64_t* fin = sort_segment_global(a, scratch_b + off, n, wave_cnt, scan_tmp, red);
-    emit_tiles(fin, n, tile_base, flatten_ids, tcnt);
+    const uint64_t* fin = sort_segment_global<NW>(a, scratch_b + off, n, wave_cnt, scan_tmp, red);
+    emit_tiles<NW>(fin, n, tile_base, flatten_ids, tcnt);
     return;
   }
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  const int R = (n + SS_BLOCK - 1) / SS_BLOCK;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
+  const int R = (n + (64 * NW) - 1) / (64 * NW);  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
   const int ibase = wave * R * 64 + lane;
   uint64_t e[SB_SORT_KPT];
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
@@ -598,20 +606,20 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
     }
   }
   uint32_t kmin, kmax;
-  block_min_max(lo, hi, red, kmin, kmax);
+  block_min_max<NW>(lo, hi, red, kmin, kmax);
   const uint32_t range = kmax - kmin;
   const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
   int first = low;
   for (int p = 0; p < passes; ++p) {
     const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
     const uint32_t mask = (1u << nbits) - 1u;
-    for (int i = threadIdx.x; i < SS_WAVES * 256; i += SS_BLOCK) (&wave_cnt[0][0])[i] = 0;
+    for (int i = threadIdx.x; i < NW * 256; i += (64 * NW)) (&wave_cnt[0][0])[i] = 0;
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < SB_SORT_KPT; ++q)
       if (q < R && ibase + q * 64 < n) atomicAdd(&wave_cnt[wave][(((uint32_t)(e[q] >> 32) - kmin) >> first) & mask], 1u);
     __syncthreads();
-    digit_starts(wave_cnt, scan_tmp);
+    digit_starts<NW>(wave_cnt, scan_tmp);
     // stable slots: the group's lowest lane advances the wavefront's cursor of the digit by the group size; all
     // the atomics of a lane are issued before any result is consumed (same-address LDS atomics of one
     // wavefront retire in issue order): one LDS round trip on the chain instead of R
@@ -662,7 +670,7 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   for (int q = 0; q < SB_SORT_KPT; ++q)
     if (q < R && ibase + q * 64 < n) img[pos[q]] = e[q];
   __syncthreads();
-  emit_tiles(img, n, tile_base, flatten_ids, tcnt);
+  emit_tiles<NW>(img, n, tile_base, flatten_ids, tcnt);
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -751,8 +759,10 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
                      w.st_offsets, entries, (long long)capacity);
-  hipLaunchKernelGGL(sb_sort_kernel, dim3(8 * max_band_st), dim3(SS_BLOCK), 0, s, tile_w, tile_h, tile_offsets,
-                     w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
+  hipLaunchKernelGGL(sb_sort_kernel<SB_SMALL_WAVES>, dim3(8 * max_band_st), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w,
+                     tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
+  hipLaunchKernelGGL(sb_sort_kernel<SB_LARGE_WAVES>, dim3(8 * max_band_st), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w,
+                     tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
