@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # process can have touched the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILES = ("r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
+PMC_FILES = ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
 N_VIEWS = 8
 
 
@@ -692,8 +692,14 @@ def main(argv=None):
             "section 8d use it); I_raster = entries of the lists actually binned and composited: the footprint rectangles "
             "drop (splat, tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
             "counts_are_for_view": view,
-            "binning": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I "
-            f"(the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
+            "binning": {
+                "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 16-byte entry per "
+                "(Gaussian, 2x2-tile supertile) scattered inside the XCD's band -> one LDS sort per supertile by (depth "
+                "bits, id), four tile lists read off it; 6 launches",
+                "banded": "banded (csrc/tilebin.hip): count -> scan -> one pair per (Gaussian, tile) scattered inside "
+                "the XCD's band -> one LDS sort per tile; 5 launches",
+                "depthfirst": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I; 26 launches",
+            }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
             "list_capacity_redos_in_timed_region": redos,
         },

@@ -27,6 +27,7 @@ constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 8;  // wavefronts per workgro
 constexpr int SB_SORT_MAX = 4096;                    // entries of a supertile sorted in LDS (1250 on average, up to
                                                      // ~2300, on the 1M / 1080p scene; larger: through global memory)
 constexpr int SB_SORT_KPT = 8;                       // elements per thread
+constexpr int SB_BUCKET_BITS = 11, SB_BUCKETS = 1 << SB_BUCKET_BITS;  // the counting pass of the LDS sort
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 
 struct Geo {
@@ -547,10 +548,12 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
                long long capacity, int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
   constexpr int MAXN = 64 * NW * SB_SORT_KPT;  // elements sorted in LDS by this variant
   __shared__ uint64_t img[MAXN];
-  __shared__ uint32_t wave_cnt[NW][256];
+  __shared__ uint32_t bucket[SB_BUCKETS];  // (as [NW][256] per-wavefront digit counters in the global-memory path)
   __shared__ uint32_t scan_tmp[4];
   __shared__ uint32_t red[2 * NW];
   __shared__ uint32_t tcnt[NW][4];
+  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(bucket);
+  static_assert(SB_BUCKETS >= NW * 256, "the fallback's counters live in the bucket array");
   const Geo g = geo_of(tile_w, tile_h);
   const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
   const Band b = band_of(xcd, g);
@@ -587,8 +590,14 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
     emit_tiles<NW>(fin, n, tile_base, flatten_ids, tcnt);
     return;
   }
+  // ---- in LDS: ONE counting pass on the top SB_BUCKET_BITS of the key bits that differ inside the segment,
+  // then every bucket is put in order by run_position (a full (depth bits, id) comparison inside the bucket).
+  // Because the buckets get sorted anyway, the counting pass need not be stable: an element's slot is its
+  // bucket's base + the value a returning LDS atomic on the bucket's counter handed it -- no ballots, no
+  // per-wavefront counters, three barriers.  (Two stable 8-bit passes before: 2.2x the vector instructions and
+  // 14 more barriers on a workgroup's critical path, which is what bounds this kernel: 2040 workgroups are one
+  // round on the chip.)  ~1250 elements over 2048 buckets: a bucket holds one or two.
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int R = (n + (64 * NW) - 1) / (64 * NW);  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
   const int ibase = wave * R * 64 + lane;
   uint64_t e[SB_SORT_KPT];
@@ -605,59 +614,47 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
       }
     }
   }
+  for (int i = threadIdx.x; i < SB_BUCKETS; i += 64 * NW) bucket[i] = 0;
   uint32_t kmin, kmax;
-  block_min_max<NW>(lo, hi, red, kmin, kmax);
+  block_min_max<NW>(lo, hi, red, kmin, kmax);  // (its barriers also cover the zeroing above)
   const uint32_t range = kmax - kmin;
-  const int bits = range ? 32 - __builtin_clz(range) : 0, low = unsorted_low_bits(bits), passes = (bits - low + 7) / 8;
-  int first = low;
-  for (int p = 0; p < passes; ++p) {
-    const int nbits = (bits - first + (passes - p) - 1) / (passes - p);
-    const uint32_t mask = (1u << nbits) - 1u;
-    for (int i = threadIdx.x; i < NW * 256; i += (64 * NW)) (&wave_cnt[0][0])[i] = 0;
-    __syncthreads();
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = bits > SB_BUCKET_BITS ? bits - SB_BUCKET_BITS : 0;
+  uint32_t rk[SB_SORT_KPT];
 #pragma unroll
-    for (int q = 0; q < SB_SORT_KPT; ++q)
-      if (q < R && ibase + q * 64 < n) atomicAdd(&wave_cnt[wave][(((uint32_t)(e[q] >> 32) - kmin) >> first) & mask], 1u);
-    __syncthreads();
-    digit_starts<NW>(wave_cnt, scan_tmp);
-    // stable slots: the group's lowest lane advances the wavefront's cursor of the digit by the group size; all
-    // the atomics of a lane are issued before any result is consumed (same-address LDS atomics of one
-    // wavefront retire in issue order): one LDS round trip on the chain instead of R
-    uint32_t rk[SB_SORT_KPT];
-#pragma unroll
-    for (int q = 0; q < SB_SORT_KPT; ++q) {
-      rk[q] = 0;
-      if (q < R) {
-        const bool in = ibase + q * 64 < n;
-        const unsigned d = (((uint32_t)(e[q] >> 32) - kmin) >> first) & mask;
-        const uint64_t peers = same_digit_lanes(d, nbits, in);
-        const uint32_t leader = in ? (uint32_t)__builtin_ctzll(peers) : (uint32_t)lane;
-        uint32_t r = (uint32_t)__popcll(peers & lt_mask);
-        if (in && leader == (uint32_t)lane) r = atomicAdd(&wave_cnt[wave][d], (uint32_t)__popcll(peers));
-        rk[q] = r | (leader << 16);
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < SB_SORT_KPT; ++q) {
-      if (q < R) {
-        const uint32_t leader = rk[q] >> 16;
-        const uint32_t before = (uint32_t)__shfl((int)(rk[q] & 0xFFFFu), (int)leader);
-        const uint32_t slot = (leader == (uint32_t)lane) ? before : before + (rk[q] & 0xFFFFu);
-        if (ibase + q * 64 < n) img[slot] = e[q];
-      }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int q = 0; q < SB_SORT_KPT; ++q)
-      if (q < R && ibase + q * 64 < n) e[q] = img[ibase + q * 64];
-    first += nbits;
+  for (int q = 0; q < SB_SORT_KPT; ++q) {
+    rk[q] = 0;
+    if (q < R && ibase + q * 64 < n) rk[q] = atomicAdd(&bucket[((uint32_t)(e[q] >> 32) - kmin) >> low], 1u);
   }
-  if (passes == 0) {  // every element has the same depth bits: the image is the input, ties decide
+  __syncthreads();
+  {  // counts -> bases: thread t owns SB_BUCKETS / (64 NW) consecutive buckets
+    constexpr int PER = SB_BUCKETS / (64 * NW);
+    uint32_t c[PER], tot = 0;
 #pragma unroll
-    for (int q = 0; q < SB_SORT_KPT; ++q)
-      if (q < R && ibase + q * 64 < n) img[ibase + q * 64] = e[q];
+    for (int k = 0; k < PER; ++k) {
+      c[k] = bucket[threadIdx.x * PER + k];
+      tot += c[k];
+    }
+    const uint32_t incl = wave_incl_scan(tot, lane);
+    if (lane == 63) red[wave] = incl;
     __syncthreads();
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < wave) run += red[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      bucket[threadIdx.x * PER + k] = run;
+      run += c[k];
+    }
   }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SB_SORT_KPT; ++q)
+    if (q < R && ibase + q * 64 < n) img[bucket[((uint32_t)(e[q] >> 32) - kmin) >> low] + rk[q]] = e[q];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SB_SORT_KPT; ++q)
+    if (q < R && ibase + q * 64 < n) e[q] = img[ibase + q * 64];
   // the run fix, into the image: positions first (they read the image), then the moves
   int pos[SB_SORT_KPT];
 #pragma unroll
