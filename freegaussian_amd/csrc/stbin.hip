@@ -13,8 +13,9 @@
 //   scatter (xcd, chunk): one 16-byte entry {depth bits, id, rectangle} per (Gaussian, supertile) pair
 //   sort    one workgroup per supertile: sort, then emit the four tile lists
 //
-// XCD = workgroup id % 8 owns a band of supertile rows in every kernel (private L2s: the scattered
-// stores of a segment meet in one L2; the raster kernels walk the same bands).
+// In count and scatter XCD = workgroup id % 8 owns a band of supertile rows (private L2s: the scattered
+// stores of a segment meet in one L2 and leave it as whole lines); the sort deals supertiles to the XCDs
+// round-robin (balance beats locality there: a segment is read once).
 #include "fg_common.h"
 
 namespace {
@@ -24,8 +25,8 @@ constexpr int SB_WAVES = SB_BLOCK / 64;
 constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
 constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
 constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 8;  // wavefronts per workgroup of the two sort launches
-constexpr int SB_SORT_MAX = 4096;                    // entries of a supertile sorted in LDS (1250 on average, up to
-                                                     // ~2300, on the 1M / 1080p scene; larger: through global memory)
+// (a supertile holds 1250 entries on average, up to ~2300, on the 1M / 1080p scene; 64 x wavefronts x SB_SORT_KPT
+// are sorted in LDS -- 2048 / 4096 for the two launches --, longer segments through global memory)
 constexpr int SB_SORT_KPT = 8;                       // elements per thread
 constexpr int SB_BUCKET_BITS = 11, SB_BUCKETS = 1 << SB_BUCKET_BITS;  // the counting pass of the LDS sort
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
@@ -555,10 +556,10 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(bucket);
   static_assert(SB_BUCKETS >= NW * 256, "the fallback's counters live in the bucket array");
   const Geo g = geo_of(tile_w, tile_h);
-  const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
-  const Band b = band_of(xcd, g);
-  if (k >= (b.sr1 - b.sr0) * g.sw) return;
-  const int st = b.sr0 * g.sw + k, sy = st / g.sw, sx = st - sy * g.sw;
+  // supertile = workgroup id: neighbours go to different XCDs.  (By band, like the count and scatter kernels,
+  // the long segments of a centre-weighted image all land on the two or three XCDs that own the middle rows.)
+  const int st = blockIdx.x, sy = st / g.sw, sx = st - sy * g.sw;
+  if (st >= g.sw * g.sh) return;
   const int tx0 = 2 * sx, ty0 = 2 * sy, T = tile_w * tile_h;
   const int total = tile_offsets[T];
   const bool over = (long long)total > capacity;
@@ -756,9 +757,9 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
                      w.st_offsets, entries, (long long)capacity);
-  hipLaunchKernelGGL(sb_sort_kernel<SB_SMALL_WAVES>, dim3(8 * max_band_st), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w,
+  hipLaunchKernelGGL(sb_sort_kernel<SB_SMALL_WAVES>, dim3(g.sw * g.sh), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w,
                      tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
-  hipLaunchKernelGGL(sb_sort_kernel<SB_LARGE_WAVES>, dim3(8 * max_band_st), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w,
+  hipLaunchKernelGGL(sb_sort_kernel<SB_LARGE_WAVES>, dim3(g.sw * g.sh), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w,
                      tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
