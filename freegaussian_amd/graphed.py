@@ -116,7 +116,20 @@ class GraphedModelStep:
     while a graph is live -- ``harness.train_step`` skips its ``zero_grad`` on graphed steps).
 
     Not graphed (falls back to ``model.get_outputs``): eval, crop boxes, images above ``max_tiles`` (the eager
-    path is GPU-bound there and its speculative list capacity needs no re-capture), the stage-2 control model."""
+    path is GPU-bound there and its speculative list capacity needs no re-capture), the stage-2 control model,
+    depth output during training, and every step with the deform net active (``step >= warm_up``).
+
+    Why no MLP and why the returned loss is recomputed eagerly: on this stack (ROCm 7.2, PyTorch 2.10) a
+    ``hipMemsetAsync`` issued under stream capture does not become a node of the graph (found in round 2 with this
+    library's own fill).  PyTorch's multi-block reductions (``mean`` / ``sum`` / ``max`` over more than one
+    workgroup) zero their semaphore words with exactly such a memset; on replay the words hold whatever the graph's
+    pool last put there and, once that is non-zero, every later replay returns one workgroup's partial result
+    (measured: the in-graph SSIM of a converging image reads 0.0 from the 7th replay on, the eager value of the same
+    static image 0.996).  The gradient of a captured ``mean`` is a broadcast and does not depend on the reduction's
+    value, so the raster + L1/SSIM step is safe as a graph -- its gradients equal the eager step's to 1e-5 --, but
+    the loss VALUE is not, and an MLP backward (bias gradients are reductions) is not either.  The deform phase of
+    the reference (from step 3000, at 1/2 resolution) therefore stays eager; the 1/4-resolution phase, the most
+    launch-bound one, has no deform net (``warm_up`` = 3000 = ``resolution_schedule``)."""
 
     def __init__(self, model, loss_fn, max_tiles: int = 2200, headroom: float = 1.5,
                  ctx: Optional[ops.RasterContext] = None):  # fmt: skip
@@ -136,6 +149,8 @@ class GraphedModelStep:
         m = self.model
         if not m.training or m.crop_box is not None or m.device.type != "cuda":
             return False
+        if m.step >= m.config.warm_up or m._render_mode() != "RGB":
+            return False  # torch reductions (MLP bias gradients, depth max) are not replay-safe here: see the class docstring
         if type(m)._get_outputs_on_active_rows is not FreeGaussianModel._get_outputs_on_active_rows:
             return False  # (the stage-2 model assembles its inputs differently)
         s = m._get_downscale_factor()
@@ -159,22 +174,32 @@ class GraphedModelStep:
         import gc
 
         m = self.model
-        for p in m.parameters():
-            p.grad = None  # the captured backward allocates the .grad tensors from the graph's pool
         self.graph = None
-        gc.collect()
+        self.static.pop("out", None)
+        self.static.pop("loss", None)
         self.ctx.static_capacity = self.capacity
         try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side), ops.use(self.ctx):
+            # Warm-up and capture on ONE stream.  An AccumulateGrad node remembers the stream of the forward that
+            # created it and lives as long as any autograd graph that reaches the parameter: warm-up iterations on
+            # a different stream than the capture (torch's recipe) left such nodes behind through `model.xys`, the
+            # captured backward then accumulated on THAT stream, and the replays went wrong after a few steps
+            # (first visible in the loss scalars).  So: same stream, and nothing that holds a graph survives into
+            # the capture.
+            stream = torch.cuda.Stream()
+            stream.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(stream), ops.use(self.ctx):
                 for _ in range(2):
-                    self._forward_backward()
                     for p in m.parameters():
-                        p.grad = None
-            torch.cuda.current_stream().wait_stream(side)
+                        p.grad = None  # the captured backward allocates the .grad tensors from the graph's pool
+                    out, loss = self._forward_backward()
+                    del out, loss
+                    m.xys = None
+            for p in m.parameters():
+                p.grad = None
+            gc.collect()
+            torch.cuda.current_stream().wait_stream(stream)
             g = torch.cuda.CUDAGraph()
-            with ops.use(self.ctx), torch.cuda.graph(g):
+            with ops.use(self.ctx), torch.cuda.graph(g, stream=stream):
                 out, loss = self._forward_backward()
                 self.static["overflow"] = self.ctx.last_overflow
             self.graph, self.static["out"], self.static["loss"] = g, out, loss
@@ -209,7 +234,9 @@ class GraphedModelStep:
             self.capacity = int(self._measure() * self.headroom) + 4096
             self._capture()
             self.graph.replay()
-        return st["out"], st["loss"]
+        with torch.no_grad():  # the value, outside the graph (in-graph reductions are not replay-safe: docstring)
+            loss = self.loss_fn(st["out"]["rgb"], st["gt"])
+        return st["out"], loss
 
     def release(self) -> None:
         """Drop the graph and its static buffers (the next applicable step captures afresh)."""

@@ -1457,9 +1457,10 @@ def test_graph_replays_with_classic_forward_and_listed_backward(live, monkeypatc
 
 def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     """harness.train_step(graphed=GraphedModelStep(...)): get_outputs + loss + backward replayed as one hipGraph
-    at a launch-bound size, against the eager step: 200 steps with a refinement every 100 (the Gaussian set is
-    re-allocated twice: re-capture), an SH degree change every 80 steps (another shape) and a list-capacity
-    overflow forced half way.  One step from the same state: the replay's gradients equal the eager step's up
+    at a launch-bound size, against the eager step: 200 steps with a refinement at step 100 (the Gaussian set is
+    re-allocated: re-capture), an SH degree change every 80 steps (another shape), a list-capacity overflow forced
+    half way, and the deform net switching on at step 150 (from there the step is eager again: torch reductions,
+    which an MLP backward contains, are not replay-safe on this stack -- graphed.GraphedModelStep).  One step from the same state: the replay's gradients equal the eager step's up
     to the order of float atomics (1e-5).  Over many steps that noise is amplified without bound -- Adam turns a
     gradient that is zero up to rounding (the radial component of a quaternion) into +-lr steps, the L1 loss's
     sign() flips on pixels that sit on their target -- so the run is held to the same trajectory instead (counts
@@ -1508,9 +1509,9 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
                 snap = {k: v.detach().clone() for k, v in model.gauss_params.items()}
         runs.append((hist, (snap3, snap), model, g))
     (h0, (t0, s0), m0, _), (h1, (t1, s1), m1, g) = runs
-    # captures: the first shape, the forced small graph + its redo, SH degree 1 and 2, the deform net switching
-    # on, the refinement at step 100 (the one at step 200 is the last step)
-    assert g.replays >= 200 and g.captures >= 6, (g.replays, g.captures)
+    # captures: the first shape, the forced small graph + its redo, SH degree 1, the refinement at step 100;
+    # replays: steps 1..149 (+ the first-step check, + the redo)
+    assert 149 <= g.replays <= 153 and g.captures >= 5 and g.graph is None, (g.replays, g.captures)
     assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
     for k in s0:
         # the first step's gradients: atomic order only.  (The scene's Gaussians are isotropic, so the gradient of
@@ -1522,8 +1523,8 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     assert all(abs(a - b) <= 0.03 * b for a, b in zip(c1, c0)), (sorted(set(c0)), sorted(set(c1)))
     for i, (a, b) in enumerate(zip(h1, h0)):
         assert abs(a["loss"] - b["loss"]) <= 0.1 * abs(b["loss"]) + 1e-7, (i, a, b)
-    # the deform net took part after the warm-up (step 150) in both runs
-    assert all(p.grad is not None for p in m1.deform.parameters())
+    # the deform net took part after the warm-up (step 150) in both runs -- eagerly
+    assert all(p.grad is not None for p in m1.deform.parameters()) and not g.applicable(cam)
 
 
 def test_partial_requires_grad_noncontiguous_and_half_inputs():
