@@ -51,7 +51,7 @@ def step():
     (out["rgb"] * vr).sum().backward()
 
 
-for _ in range(5):
+for _ in range(25):  # (the caching allocator and the list-capacity history settle over the first steps)
     step()
 torch.cuda.synchronize()
 ops.default_context.stage_timer = ops.StageTimer()

@@ -1509,9 +1509,10 @@ def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
                 snap = {k: v.detach().clone() for k, v in model.gauss_params.items()}
         runs.append((hist, (snap3, snap), model, g))
     (h0, (t0, s0), m0, _), (h1, (t1, s1), m1, g) = runs
-    # captures: the first shape, the forced small graph + its redo, SH degree 1, the refinement at step 100;
+    # captures: the first shape, the forced small graph + its redo, SH degree 1 (+ the refinement at step 100 when it
+    # changes the set);
     # replays: steps 1..149 (+ the first-step check, + the redo)
-    assert 149 <= g.replays <= 153 and g.captures >= 5 and g.graph is None, (g.replays, g.captures)
+    assert 149 <= g.replays <= 153 and g.captures >= 4 and g.graph is None, (g.replays, g.captures)
     assert h0[98]["gaussian_count"] == h1[98]["gaussian_count"] == 6000
     for k in s0:
         # the first step's gradients: atomic order only.  (The scene's Gaussians are isotropic, so the gradient of
