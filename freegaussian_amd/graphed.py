@@ -160,8 +160,10 @@ class GraphedModelStep:
     def _key(self, W, H):
         m = self.model
         deg = min(m.step // m.config.sh_degree_interval, m.config.sh_degree)
-        return (m.num_points, m.gauss_params["means"].data_ptr(), W, H, deg, m.step >= m.config.warm_up,
-                m._render_mode(), m.config.background_color)  # fmt: skip
+        # the storage of EVERY Gaussian parameter: densification re-allocates all of them, the opacity reset
+        # (freegaussian_model.py:475-490, `.data = clamp(...)`) only one -- a graph must never read a stale one
+        ptrs = tuple(p.data_ptr() for p in m.gauss_params.values())
+        return (m.num_points, ptrs, W, H, deg, m.step >= m.config.warm_up, m._render_mode(), m.config.background_color)
 
     def _forward_backward(self):
         m, st = self.model, self.static
