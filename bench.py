@@ -46,6 +46,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--settle-s", type=float, default=1.0,
+                    help="after the W warm-up steps, keep stepping (untimed) until this much wall time has passed: a "
+                    "fresh process starts on a GPU at idle clocks and a cold caching allocator, and the first runs "
+                    "of a box measured 8-25%% slower than the ones after them with 35 untimed steps in front")
     ap.add_argument("--n-gauss", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -524,6 +528,21 @@ def main(argv=None):
     for _ in range(max(args.warmup, 0)):
         step()
     fence()
+    # ... and until the device has been busy for --settle-s seconds (clocks, allocator, list-capacity history):
+    # the same number of extra steps on every rank (rank 0 decides), all untimed
+    settle_steps = 0
+    if args.settle_s > 0:
+        t_settle = time.perf_counter()
+        while True:
+            for _ in range(8):
+                step()
+            settle_steps += 8
+            fence()
+            go_on = torch.tensor([1 if time.perf_counter() - t_settle < args.settle_s else 0], device=dev)
+            if world > 1:
+                dist.broadcast(go_on, 0)
+            if int(go_on.item()) == 0:
+                break
     # Stage pass (untimed): HIP events around EVERY C-ABI call and around forward / backward / exchange of
     # every step.  Sixteen event records per step cost ~0.06 ms of a ~1 ms step (measured: 1.045 ms with
     # them, 0.987 without), so the timed region below carries events around the dominant kernel only --
@@ -702,6 +721,8 @@ def main(argv=None):
             }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
             "list_capacity_redos_in_timed_region": redos,
+            "untimed_steps_before_timed_region": {"warmup": args.warmup, "settle": settle_steps, "stage_pass": stage_steps,
+                                                  "after_timer_swap": 1},
         },
         "roofline": roof,
         "vector_issue_roofline": issue,
