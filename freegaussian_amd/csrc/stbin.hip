@@ -24,11 +24,11 @@ constexpr int SB_BLOCK = 256;
 constexpr int SB_WAVES = SB_BLOCK / 64;
 constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
 constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
-constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 8;  // wavefronts per workgroup of the two sort launches
+constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 16;  // wavefronts per workgroup of the two sort launches
 // (a supertile holds 1250 entries on average, up to ~2300, on the 1M / 1080p scene; 64 x wavefronts x SB_SORT_KPT
-// are sorted in LDS -- 2048 / 4096 for the two launches --, longer segments through global memory)
+// are sorted in LDS -- 2048 / 8192 for the two launches --, longer segments through global memory)
 constexpr int SB_SORT_KPT = 8;                       // elements per thread
-constexpr int SB_BUCKET_BITS = 11, SB_BUCKETS = 1 << SB_BUCKET_BITS;  // the counting pass of the LDS sort
+constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the counting pass of the LDS sorts
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 
 struct Geo {
@@ -187,43 +187,54 @@ sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restri
   if (qd == 0) st_offsets[col + 1] = (int32_t)total;
 }
 
-// ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup per array --------
+// ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup per array.  1024
+// threads x 8 values: the 8160 tiles of a 1080p frame are one trip through memory, not two ----------------------
+constexpr int SO_BLOCK = 1024, SO_WAVES = SO_BLOCK / 64, SO_PER = 8;
 __device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
                                                          uint32_t* wave_tot) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   uint32_t carry = 0;
-  for (int base = 0; base < n; base += SB_BLOCK * 16) {
+  for (int base = 0; base < n; base += SO_BLOCK * SO_PER) {
+    uint32_t in[SO_PER];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = base + k * SB_BLOCK + threadIdx.x;
-      buf[k * SB_BLOCK + threadIdx.x] = i < n ? (uint32_t)offs[i + 1] : 0u;
+    for (int k = 0; k < SO_PER; ++k) {
+      const int i = base + k * SO_BLOCK + threadIdx.x;
+      in[k] = i < n ? (uint32_t)offs[i + 1] : 0u;
     }
+#pragma unroll
+    for (int k = 0; k < SO_PER; ++k) buf[k * SO_BLOCK + threadIdx.x] = in[k];
     __syncthreads();
-    uint32_t v[16], sum = 0;
+    uint32_t v[SO_PER], sum = 0;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      v[k] = buf[threadIdx.x * 16 + k];
-      sum += v[k];
+    for (int k = 0; k < SO_PER; k += 4) {
+      const uint4 x = *reinterpret_cast<const uint4*>(&buf[threadIdx.x * SO_PER + k]);
+      v[k] = x.x; v[k + 1] = x.y; v[k + 2] = x.z; v[k + 3] = x.w;
     }
+#pragma unroll
+    for (int k = 0; k < SO_PER; ++k) sum += v[k];
     const uint32_t incl = wave_incl_scan(sum, lane);
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
     uint32_t run = carry + incl - sum, all = 0;
 #pragma unroll
-    for (int k = 0; k < SB_WAVES; ++k) {
-      if (k < wave) run += wave_tot[k];
-      all += wave_tot[k];
+    for (int k = 0; k < SO_WAVES; ++k) {
+      const uint32_t t = wave_tot[k];
+      if (k < wave) run += t;
+      all += t;
     }
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
+    for (int k = 0; k < SO_PER; ++k) {
       run += v[k];
-      buf[threadIdx.x * 16 + k] = run;
+      v[k] = run;
     }
+#pragma unroll
+    for (int k = 0; k < SO_PER; k += 4)
+      *reinterpret_cast<uint4*>(&buf[threadIdx.x * SO_PER + k]) = make_uint4(v[k], v[k + 1], v[k + 2], v[k + 3]);
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const int i = base + k * SB_BLOCK + threadIdx.x;
-      if (i < n) offs[i + 1] = (int32_t)buf[k * SB_BLOCK + threadIdx.x];
+    for (int k = 0; k < SO_PER; ++k) {
+      const int i = base + k * SO_BLOCK + threadIdx.x;
+      if (i < n) offs[i + 1] = (int32_t)buf[k * SO_BLOCK + threadIdx.x];
     }
     carry += all;
     __syncthreads();
@@ -231,11 +242,11 @@ __device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restr
   if (threadIdx.x == 0) offs[0] = 0;
   return carry;
 }
-__global__ void __launch_bounds__(SB_BLOCK)
+__global__ void __launch_bounds__(SO_BLOCK)
 sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __restrict__ st_offsets,
                   int64_t* __restrict__ count_out) {
-  __shared__ uint32_t buf[SB_BLOCK * 16];
-  __shared__ uint32_t wave_tot[SB_WAVES];
+  __shared__ alignas(16) uint32_t buf[SO_BLOCK * SO_PER];
+  __shared__ uint32_t wave_tot[SO_WAVES];
   if (blockIdx.x == 1) {  // (two workgroups: the two scans side by side)
     scan_counts_in_place(S, st_offsets, buf, wave_tot);
     return;
@@ -250,13 +261,14 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
 // ---- scatter --------------------------------------------------------------------------------------------
 // Workgroup (xcd, chunk): a wavefront reads 64 rectangles per round, queues the ones that reach the band
 // (7 of 8 do not) and, whenever 64 are queued, walks their (Gaussian, supertile) pairs 64 at a time: every
-// lane finds the owner of its slot by binary search over the wave's exclusive counts and writes the entry
-// {depth bits, id, rectangle} to the slot an LDS cursor of the supertile hands out (segment start + the
-// chunks before this one, from the scanned table).
+// lane finds the owner of its slot by binary search over the wave's exclusive counts and writes the element
+// depth bits << 32 | id << 4 | tile mask (bit j: the rectangle covers tile j = 2 * (row in the supertile) +
+// column) to the slot an LDS cursor of the supertile hands out (segment start + the chunks before this one,
+// from the scanned table).  Order = (depth bits, id): the mask sits below the id and never decides.
 __global__ void __launch_bounds__(SB_BLOCK)
 sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
                   int tile_h, const uint32_t* __restrict__ table_s, const int32_t* __restrict__ tile_offsets,
-                  const int32_t* __restrict__ st_offsets, uint4* __restrict__ entries, long long capacity) {
+                  const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries, long long capacity) {
   extern __shared__ uint32_t s_cur[];  // [supertiles of the band]
   __shared__ int4 s_q[SB_WAVES][128];
   __shared__ int32_t s_excl[SB_WAVES][64];
@@ -304,7 +316,12 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
         const int tx = t - ty * onx;
         const int local = (oya + ty - b.sr0) * g.sw + oxa + tx;
         const uint32_t pos = atomicAdd(&s_cur[local], 1u);
-        entries[pos] = make_uint4((uint32_t)o.y, (uint32_t)o.x, (uint32_t)o.z, (uint32_t)o.w);
+        // which of the supertile's four tiles the rectangle covers (bit j: tile 2 * row + column)
+        const int oh = o.w >> 16, c0 = 2 * (oxa + tx), r0 = 2 * (oya + ty);
+        const uint32_t cols = (uint32_t)(c0 >= ox0) | ((uint32_t)(c0 + 1 < ox0 + ow) << 1);
+        const uint32_t rows = (uint32_t)(r0 >= oy0) | ((uint32_t)(r0 + 1 < oy0 + oh) << 1);
+        const uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
+        entries[pos] = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
       }
     }
     __builtin_amdgcn_wave_barrier();
@@ -319,25 +336,36 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
     qn = rest;
   };
 
+  // The wavefront's rectangles SB_GROUP rounds at a time, then the depth bits of the ones that reach the band:
+  // two memory round trips per group.  (Loaded round by round, rectangle then key, a wavefront waited 2 x 16 times.)
+  constexpr int SB_GROUP = 8;
   const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SB_WAVES);
-  for (int r = 0; r < SB_ROUNDS; ++r) {
-    const int gi = g0 + r * 64 + lane;
-    bool hit = false;
-    int4 e = make_int4(0, 0, 0, 1 | (1 << 16));
-    if (gi < N) {
-      const int2 rc = rects[gi];
-      const int w = rc.y & 0xFFFF, h = rc.y >> 16, y0 = rc.x >> 16;
-      hit = w > 0 && min(y0 + h, b.tr1) > max(y0, b.tr0);
-      e = make_int4(gi, 0, rc.x, rc.y);
+#pragma unroll 1
+  for (int rg = 0; rg < SB_ROUNDS; rg += SB_GROUP) {
+    const int gb = g0 + rg * 64 + lane;
+    int2 rc[SB_GROUP];
+#pragma unroll
+    for (int r = 0; r < SB_GROUP; ++r) rc[r] = gb + r * 64 < N ? rects[gb + r * 64] : make_int2(0, 0);
+    uint32_t hits = 0;
+#pragma unroll
+    for (int r = 0; r < SB_GROUP; ++r) {
+      const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, y0 = rc[r].x >> 16;
+      hits |= (uint32_t)(w > 0 && min(y0 + h, b.tr1) > max(y0, b.tr0)) << r;
     }
-    if (hit) e.y = (int)depth_keys[gi];
-    const uint64_t bal = __ballot(hit);
-    if (hit) q[qn + __popcll(bal & lt_mask)] = e;
-    qn += __popcll(bal);
-    __builtin_amdgcn_wave_barrier();
-    if (qn >= 64) {
-      drain(64);
-      pop64();
+    uint32_t dk[SB_GROUP];
+#pragma unroll
+    for (int r = 0; r < SB_GROUP; ++r) dk[r] = (hits >> r) & 1u ? depth_keys[gb + r * 64] : 0u;
+#pragma unroll
+    for (int r = 0; r < SB_GROUP; ++r) {
+      const bool hit = (hits >> r) & 1u;
+      const uint64_t bal = __ballot(hit);
+      if (hit) q[qn + __popcll(bal & lt_mask)] = make_int4(gb + r * 64, (int)dk[r], rc[r].x, rc[r].y);
+      qn += __popcll(bal);
+      __builtin_amdgcn_wave_barrier();
+      if (qn >= 64) {
+        drain(64);
+        pop64();
+      }
     }
   }
   if (qn > 0) drain(qn);
@@ -427,21 +455,9 @@ __device__ __forceinline__ int run_position(Ptr cur, int n, int i, uint64_t e, u
   }
   return a + smaller;
 }
-// The passes sort all key bits that differ inside the segment up to 16 (two 8-bit passes), of more only the
-// TOP 16; run_position settles the rest.  ~1000 entries over 65536 values of the sorted bits: runs of one or
-// two.  (Entries crowded into few values -- a wall plus one far outlier -- make long runs: slower, never wrong.)
+// The global-memory passes sort all key bits that differ inside the segment up to 16 (two 8-bit passes), of
+// more only the TOP 16; run_position settles the rest.
 __device__ __forceinline__ int unsorted_low_bits(int bits) { return bits > 16 ? bits - 16 : 0; }
-
-__device__ __forceinline__ uint64_t element_of(const uint4 en, int tx0, int ty0, int tile_w, int tile_h) {
-  const int x0 = en.z & 0xFFFF, y0 = en.z >> 16, w = en.w & 0xFFFF, h = en.w >> 16;
-  uint32_t mask = 0;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int tx = tx0 + (j & 1), ty = ty0 + (j >> 1);
-    if (tx < tile_w && ty < tile_h && tx >= x0 && tx < x0 + w && ty >= y0 && ty < y0 + h) mask |= 1u << j;
-  }
-  return ((uint64_t)en.x << 32) | ((uint64_t)en.y << 4) | mask;
-}
 
 // The tile lists of a supertile from its n elements in final order (cur: LDS or global), read in order by the
 // workgroup: wavefront w owns the contiguous share [w span, (w + 1) span), counts its elements per tile, the
@@ -542,19 +558,206 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
   return dst;
 }
 
-template <int NW>
+// ---- the LDS sort + emission of one segment by a GROUP of NW wavefronts (a whole workgroup, or one of several
+// groups of a workgroup running in lockstep: every barrier below is a workgroup barrier, so all groups of a
+// workgroup must call this the same number of times -- with n = 0 when they have nothing to do) ----------------
+template <int NW, int KPT, int BB>
+struct SortShared {
+  // (the large variant gives up 128 elements so that two workgroups -- 2 x 80 KB -- fit a CU's 160 KB of LDS)
+  static constexpr int MAXN = 64 * NW * KPT - (NW > 8 ? 128 : 0);
+  uint64_t img[MAXN];
+  alignas(16) uint32_t bucket[(1 << BB) + 4];  // counts -> exclusive bases; [1 << BB] = n
+  uint32_t red[2 * NW];
+  uint32_t wtot[NW];
+  uint32_t scan_tmp[4];
+  alignas(16) uint32_t tcnt[NW][4];
+};
+
+// ONE counting pass on the top BB of the key bits that differ inside the segment, then every bucket is put in
+// order by a full (depth bits, id) comparison among its own elements.  Because the buckets get sorted anyway the
+// counting pass need not be stable: an element's slot is its bucket's base + the value a returning LDS atomic on
+// the bucket's counter handed it -- no ballots, no per-wavefront counters.  ~1250 elements over 2048 buckets: a
+// bucket holds one or two.  (Exact depth ties crowd one bucket: every element still ranks itself in O(bucket).)
+// Then the tile lists: wavefront w owns the contiguous share [w R 64, (w + 1) R 64) of the sorted run; ONE walk
+// takes every element's rank among the wavefront's elements of each tile (ballots), the per-wavefront counts
+// become bases, the ids go out.
+template <int NW, int KPT, int BB>
+__device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, const uint64_t* __restrict__ src, int n,
+                                              const int* tile_base, int32_t* __restrict__ flatten_ids) {
+  constexpr int NT = 64 * NW, NB = 1 << BB, PER = NB / NT;
+  static_assert(NB % NT == 0 && PER >= 1 && (PER % 4 == 0 || PER < 4), "buckets per thread");
+  const int lane = gt & 63, gw = gt >> 6;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int R = (n + NT - 1) / NT;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
+  const int ibase = gw * R * 64 + lane;
+  // Straight-line code over all KPT rounds with a per-lane `valid` bit each (no branches on the round count:
+  // with `if (q < R) { load; use }` every load was followed by its own wait -- eight dependent round trips).
+  uint32_t valid = 0;
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) valid |= (uint32_t)(q < R && ibase + q * 64 < n) << q;
+  uint64_t e[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) e[q] = 0;
+  if (n > 0) {
+#pragma unroll
+    for (int q = 0; q < KPT; ++q) e[q] = src[(valid >> q) & 1u ? ibase + q * 64 : 0];  // all in flight together
+  }
+  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const bool v = (valid >> q) & 1u;
+    e[q] = v ? e[q] : 0ull;
+    lo = v ? min(lo, (uint32_t)(e[q] >> 32)) : lo;
+    hi = v ? max(hi, (uint32_t)(e[q] >> 32)) : hi;
+  }
+  if constexpr (PER >= 4) {
+#pragma unroll
+    for (int k = 0; k < PER; k += 4) *reinterpret_cast<uint4*>(&sh.bucket[gt * PER + k]) = make_uint4(0, 0, 0, 0);
+  } else {
+#pragma unroll
+    for (int k = 0; k < PER; ++k) sh.bucket[gt * PER + k] = 0;
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+    lo = min(lo, (uint32_t)__shfl_xor((int)lo, m));
+    hi = max(hi, (uint32_t)__shfl_xor((int)hi, m));
+  }
+  if (lane == 0) {
+    sh.red[gw] = lo;
+    sh.red[NW + gw] = hi;
+  }
+  __syncthreads();
+  uint32_t kmin = sh.red[0], kmax = sh.red[NW];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) {
+    kmin = min(kmin, sh.red[w]);
+    kmax = max(kmax, sh.red[NW + w]);
+  }
+  const uint32_t range = n > 0 ? kmax - kmin : 0u;
+  const int bits = range ? 32 - __builtin_clz(range) : 0, low = bits > BB ? bits - BB : 0;
+  uint32_t rk[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    rk[q] = 0;
+    if ((valid >> q) & 1u) rk[q] = atomicAdd(&sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low], 1u);
+  }
+  __syncthreads();
+  {  // counts -> exclusive bases: thread t owns PER consecutive buckets
+    uint32_t c[PER], tot = 0;
+    if constexpr (PER >= 4) {
+#pragma unroll
+      for (int k = 0; k < PER; k += 4) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&sh.bucket[gt * PER + k]);
+        c[k] = v.x; c[k + 1] = v.y; c[k + 2] = v.z; c[k + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) c[k] = sh.bucket[gt * PER + k];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) tot += c[k];
+    const uint32_t incl = wave_incl_scan(tot, lane);
+    if (lane == 63) sh.wtot[gw] = incl;
+    __syncthreads();
+    uint32_t run = incl - tot;
+#pragma unroll
+    for (int w = 0; w < NW; ++w)
+      if (w < gw) run += sh.wtot[w];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+      const uint32_t x = c[k];
+      c[k] = run;
+      run += x;
+    }
+    if constexpr (PER >= 4) {
+#pragma unroll
+      for (int k = 0; k < PER; k += 4) *reinterpret_cast<uint4*>(&sh.bucket[gt * PER + k]) = make_uint4(c[k], c[k + 1], c[k + 2], c[k + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) sh.bucket[gt * PER + k] = c[k];
+    }
+    if (gt == NT - 1) sh.bucket[NB] = run;  // = n
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KPT; ++q)
+    if ((valid >> q) & 1u) sh.img[sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low] + rk[q]] = e[q];
+  __syncthreads();
+  // the order inside every bucket: an element's place = the bucket's base + the number of smaller elements in it
+  int pos[KPT];
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    pos[q] = -1;
+    if ((valid >> q) & 1u) {
+      const uint32_t bk = ((uint32_t)(e[q] >> 32) - kmin) >> low;
+      const int s0 = (int)sh.bucket[bk], s1 = (int)sh.bucket[bk + 1];
+      if (s1 - s0 > 1) {
+        int smaller = 0;
+        for (int j = s0; j < s1; ++j) smaller += sh.img[j] < e[q];
+        pos[q] = s0 + smaller;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < KPT; ++q)
+    if (pos[q] >= 0) sh.img[pos[q]] = e[q];  // (elements alone in their bucket are in place)
+  __syncthreads();
+  // ---- emission ----
+  uint32_t idm[KPT], ranks[KPT];
+  uint32_t pre[KPT][4], c[4] = {0, 0, 0, 0};  // (wave-uniform: scalar registers)
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    idm[q] = 0;
+    if ((valid >> q) & 1u) idm[q] = (uint32_t)sh.img[ibase + q * 64];  // id << 4 | mask
+  }
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    ranks[q] = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint64_t bal = __ballot((idm[q] >> j) & 1u);
+      ranks[q] |= (uint32_t)__popcll(bal & lt_mask) << (8 * j);
+      pre[q][j] = c[j];
+      c[j] += (uint32_t)__popcll(bal);
+    }
+  }
+  if (lane == 0) *reinterpret_cast<uint4*>(sh.tcnt[gw]) = make_uint4(c[0], c[1], c[2], c[3]);
+  __syncthreads();
+  uint32_t base[4];
+  {
+    uint4 t = make_uint4(0, 0, 0, 0);
+    if (lane < gw) t = *reinterpret_cast<const uint4*>(sh.tcnt[lane]);  // (gw <= NW - 1 < 64)
+    uint32_t v[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int m = 1; m < (NW > 1 ? NW : 2); m <<= 1) v[j] += (uint32_t)__shfl_xor((int)v[j], m);
+      base[j] = (uint32_t)tile_base[j] + (uint32_t)__builtin_amdgcn_readfirstlane((int)v[j]);
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < KPT; ++q) {
+    const uint32_t id = idm[q] >> 4;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if ((idm[q] >> j) & 1u) flatten_ids[base[j] + pre[q][j] + ((ranks[q] >> (8 * j)) & 0xFFu)] = (int32_t)id;
+  }
+}
+
+// Two launches share the supertiles: SB_SMALL (256 threads, up to 2048 elements, 24 KB of LDS) takes nearly all
+// of them on the 1M / 1080p scene, SB_LARGE (1024 threads, up to 8192 elements) the heavier ones; beyond that the
+// segment goes through global memory.
+template <int NW, int BB>
 __global__ void __launch_bounds__(64 * NW)
 sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
-               const uint4* __restrict__ entries, uint64_t* __restrict__ scratch_a, uint64_t* __restrict__ scratch_b,
-               long long capacity, int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
-  constexpr int MAXN = 64 * NW * SB_SORT_KPT;  // elements sorted in LDS by this variant
-  __shared__ uint64_t img[MAXN];
-  __shared__ uint32_t bucket[SB_BUCKETS];  // (as [NW][256] per-wavefront digit counters in the global-memory path)
-  __shared__ uint32_t scan_tmp[4];
-  __shared__ uint32_t red[2 * NW];
-  __shared__ uint32_t tcnt[NW][4];
-  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(bucket);
-  static_assert(SB_BUCKETS >= NW * 256, "the fallback's counters live in the bucket array");
+               uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, long long capacity,
+               int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
+  constexpr int MAXN = SortShared<NW, SB_SORT_KPT, BB>::MAXN;  // elements sorted in LDS by this variant
+  constexpr bool SMALL = NW == SB_SMALL_WAVES;
+  __shared__ SortShared<NW, SB_SORT_KPT, BB> sh;
+  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
+  static_assert((1 << BB) >= NW * 256, "the fallback's counters live in the bucket array");
   const Geo g = geo_of(tile_w, tile_h);
   // supertile = workgroup id: neighbours go to different XCDs.  (By band, like the count and scatter kernels,
   // the long segments of a centre-weighted image all land on the two or three XCDs that own the middle rows.)
@@ -572,103 +775,20 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
     tile_base[j] = inside ? tile_offsets[tile] : 0;
     // the ranges the CONSUMERS of flatten_ids read: the tile ranges when the list fits, empty lists when it
     // does not (nothing is filled then; whoever was enqueued speculatively behind this call walks nothing)
-    if (NW == SB_SMALL_WAVES && inside && threadIdx.x == 0) {
+    if (SMALL && inside && threadIdx.x == 0) {
       list_offsets[tile] = over ? 0 : tile_base[j];
       if (tile == T - 1) list_offsets[T] = over ? 0 : total;
     }
   }
   const int off = st_offsets[st], n = st_offsets[st + 1] - off;
   if (over || n <= 0) return;
-  // two launches share the supertiles: 256-thread workgroups (20 KB of LDS: eight per CU) take the ones
-  // with up to 2048 entries -- nearly all --, 512-thread workgroups the longer ones
-  if (NW == SB_SMALL_WAVES ? n > MAXN : n <= 64 * SB_SMALL_WAVES * SB_SORT_KPT) return;
+  if (SMALL ? n > MAXN : n <= SortShared<SB_SMALL_WAVES, SB_SORT_KPT, SB_SMALL_BUCKET_BITS>::MAXN) return;
   if (n > MAXN) {
-    uint64_t* a = scratch_a + off;
-    for (int i = threadIdx.x; i < n; i += (64 * NW)) a[i] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
-    __threadfence();
-    __syncthreads();
-    const uint64_t* fin = sort_segment_global<NW>(a, scratch_b + off, n, wave_cnt, scan_tmp, red);
-    emit_tiles<NW>(fin, n, tile_base, flatten_ids, tcnt);
+    const uint64_t* fin = sort_segment_global<NW>(entries + off, scratch + off, n, wave_cnt, sh.scan_tmp, sh.red);
+    emit_tiles<NW>(fin, n, tile_base, flatten_ids, sh.tcnt);
     return;
   }
-  // ---- in LDS: ONE counting pass on the top SB_BUCKET_BITS of the key bits that differ inside the segment,
-  // then every bucket is put in order by run_position (a full (depth bits, id) comparison inside the bucket).
-  // Because the buckets get sorted anyway, the counting pass need not be stable: an element's slot is its
-  // bucket's base + the value a returning LDS atomic on the bucket's counter handed it -- no ballots, no
-  // per-wavefront counters, three barriers.  (Two stable 8-bit passes before: 2.2x the vector instructions and
-  // 14 more barriers on a workgroup's critical path, which is what bounds this kernel: 2040 workgroups are one
-  // round on the chip.)  ~1250 elements over 2048 buckets: a bucket holds one or two.
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const int R = (n + (64 * NW) - 1) / (64 * NW);  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
-  const int ibase = wave * R * 64 + lane;
-  uint64_t e[SB_SORT_KPT];
-  uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q) {
-    e[q] = 0;
-    if (q < R) {
-      const int i = ibase + q * 64;
-      if (i < n) {
-        e[q] = element_of(entries[off + i], tx0, ty0, tile_w, tile_h);
-        lo = min(lo, (uint32_t)(e[q] >> 32));
-        hi = max(hi, (uint32_t)(e[q] >> 32));
-      }
-    }
-  }
-  for (int i = threadIdx.x; i < SB_BUCKETS; i += 64 * NW) bucket[i] = 0;
-  uint32_t kmin, kmax;
-  block_min_max<NW>(lo, hi, red, kmin, kmax);  // (its barriers also cover the zeroing above)
-  const uint32_t range = kmax - kmin;
-  const int bits = range ? 32 - __builtin_clz(range) : 0, low = bits > SB_BUCKET_BITS ? bits - SB_BUCKET_BITS : 0;
-  uint32_t rk[SB_SORT_KPT];
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q) {
-    rk[q] = 0;
-    if (q < R && ibase + q * 64 < n) rk[q] = atomicAdd(&bucket[((uint32_t)(e[q] >> 32) - kmin) >> low], 1u);
-  }
-  __syncthreads();
-  {  // counts -> bases: thread t owns SB_BUCKETS / (64 NW) consecutive buckets
-    constexpr int PER = SB_BUCKETS / (64 * NW);
-    uint32_t c[PER], tot = 0;
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      c[k] = bucket[threadIdx.x * PER + k];
-      tot += c[k];
-    }
-    const uint32_t incl = wave_incl_scan(tot, lane);
-    if (lane == 63) red[wave] = incl;
-    __syncthreads();
-    uint32_t run = incl - tot;
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-      if (w < wave) run += red[w];
-#pragma unroll
-    for (int k = 0; k < PER; ++k) {
-      bucket[threadIdx.x * PER + k] = run;
-      run += c[k];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q)
-    if (q < R && ibase + q * 64 < n) img[bucket[((uint32_t)(e[q] >> 32) - kmin) >> low] + rk[q]] = e[q];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q)
-    if (q < R && ibase + q * 64 < n) e[q] = img[ibase + q * 64];
-  // the run fix, into the image: positions first (they read the image), then the moves
-  int pos[SB_SORT_KPT];
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q) {
-    pos[q] = 0;
-    if (q < R && ibase + q * 64 < n) pos[q] = run_position(img, n, ibase + q * 64, e[q], kmin, low);
-  }
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < SB_SORT_KPT; ++q)
-    if (q < R && ibase + q * 64 < n) img[pos[q]] = e[q];
-  __syncthreads();
-  emit_tiles<NW>(img, n, tile_base, flatten_ids, tcnt);
+  sort_emit_lds<NW, SB_SORT_KPT, BB>(sh, (int)threadIdx.x, entries + off, n, tile_base, flatten_ids);
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -726,14 +846,14 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
   hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
                      tile_offsets, w.st_offsets);
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(2), dim3(SB_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(2), dim3(SO_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
 
 extern "C" size_t fg_stbin_fill_workspace_bytes(int64_t capacity) {
   const size_t c = (size_t)(capacity > 0 ? capacity : 1);
-  return al256(c * 16) + 2 * al256(c * 8);
+  return 2 * al256(c * 8);
 }
 
 extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
@@ -750,17 +870,18 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   const CountWs w = count_ws(const_cast<void*>(count_workspace), N, g);
   const int nc = n_chunks_of(N);
   char* p = static_cast<char*>(workspace);
-  uint4* entries = reinterpret_cast<uint4*>(p);
-  uint64_t* sa = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 16));
-  uint64_t* sb = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 16) + al256((size_t)capacity * 8));
+  uint64_t* entries = reinterpret_cast<uint64_t*>(p);
+  uint64_t* scratch = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 8));
   const int max_band_st = max_band_st_rows(g) * g.sw;
   hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
                      reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
                      w.st_offsets, entries, (long long)capacity);
-  hipLaunchKernelGGL(sb_sort_kernel<SB_SMALL_WAVES>, dim3(g.sw * g.sh), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w,
-                     tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
-  hipLaunchKernelGGL(sb_sort_kernel<SB_LARGE_WAVES>, dim3(g.sw * g.sh), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w,
-                     tile_h, tile_offsets, w.st_offsets, entries, sa, sb, (long long)capacity, flatten_ids, list_offsets);
+  hipLaunchKernelGGL((sb_sort_kernel<SB_LARGE_WAVES, SB_LARGE_BUCKET_BITS>), dim3(g.sw * g.sh), dim3(64 * SB_LARGE_WAVES),
+                     0, s, tile_w, tile_h, tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids,
+                     list_offsets);
+  hipLaunchKernelGGL((sb_sort_kernel<SB_SMALL_WAVES, SB_SMALL_BUCKET_BITS>), dim3(g.sw * g.sh), dim3(64 * SB_SMALL_WAVES),
+                     0, s, tile_w, tile_h, tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids,
+                     list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
