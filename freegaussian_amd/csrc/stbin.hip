@@ -6,28 +6,37 @@
 // `tile_size=16` of /root/reference freegaussian/freegaussian_model.py:847-868), bit for bit: inside a
 // tile the order is the total order (depth bits, id) whatever route the entries took.
 //
-//   count   (xcd, chunk): corner marks of the chunk's rectangles on the band's tile grid and supertile grid
-//           (LDS), two prefix sums each -> table_t[chunk][T], table_s[chunk][S]
+//   count   one workgroup per chunk of 4096 Gaussians: corner marks of the chunk's rectangles on the tile grid and
+//           the supertile grid (LDS, the whole image when it fits -- 1080p does --, else in bands of rows with the
+//           rectangles kept in registers), two prefix sums each -> table_t[chunk][T], table_s[chunk][S]
 //   columns per tile the sum over chunks; per supertile the exclusive prefix over chunks and the sum
-//   offsets one workgroup: tile_offsets[T + 1], st_offsets[S + 1], the list length to the host
-//   scatter (xcd, chunk): one 16-byte entry {depth bits, id, rectangle} per (Gaussian, supertile) pair
+//   offsets one workgroup per array: tile_offsets[T + 1], st_offsets[S + 1], the list length to the host
+//   scatter one workgroup per chunk: one 8-byte element per (Gaussian, supertile) pair to the slot an LDS cursor
+//           of the supertile hands out
 //   sort    one workgroup per supertile: sort, then emit the four tile lists
 //
-// In count and scatter XCD = workgroup id % 8 owns a band of supertile rows (private L2s: the scattered
-// stores of a segment meet in one L2 and leave it as whole lines); the sort deals supertiles to the XCDs
-// round-robin (balance beats locality there: a segment is read once).
+// Every rectangle is read ONCE by count and once by scatter.  (Round 3 began with workgroups per (XCD band, chunk)
+// so that a segment's scattered stores met in one L2: count and scatter then each pulled the rectangles through
+// all eight L2s -- 62 + 95 MB of fabric reads for 12 MB of data, and that, not the stores, bounded both kernels.)
+// The sort deals supertiles to the XCDs round-robin.
 #include "fg_common.h"
 
 namespace {
 
-constexpr int SB_BLOCK = 256;
-constexpr int SB_WAVES = SB_BLOCK / 64;
-constexpr int SB_CHUNK = 4096;                       // Gaussians per (chunk, band) workgroup
-constexpr int SB_ROUNDS = SB_CHUNK / SB_BLOCK;
-constexpr int SB_SMALL_WAVES = 4, SB_LARGE_WAVES = 16;  // wavefronts per workgroup of the two sort launches
-// (a supertile holds 1250 entries on average, up to ~2300, on the 1M / 1080p scene; 64 x wavefronts x SB_SORT_KPT
-// are sorted in LDS -- 2048 / 8192 for the two launches --, longer segments through global memory)
-constexpr int SB_SORT_KPT = 8;                       // elements per thread
+constexpr int SB_BLOCK = 256;                        // columns kernel
+constexpr int SB_CHUNK = 4096;                       // Gaussians per workgroup of count and scatter
+constexpr int SC_BLOCK = 1024, SC_WAVES = SC_BLOCK / 64, SC_PER = SB_CHUNK / SC_BLOCK;
+#ifndef FG_SB_SMALL_WAVES
+#define FG_SB_SMALL_WAVES 8
+#endif
+#ifndef FG_SB_SMALL_KPT
+#define FG_SB_SMALL_KPT 6
+#endif
+constexpr int SB_SMALL_WAVES = FG_SB_SMALL_WAVES, SB_LARGE_WAVES = 16;  // wavefronts per workgroup of the two sort launches
+// (a supertile holds 1250 entries on average, up to ~2300, on the 1M / 1080p scene; 64 x wavefronts x elements per thread
+// are sorted in LDS -- 3072 / 8064 for the two launches --, longer segments through global memory)
+constexpr int SB_SMALL_KPT = FG_SB_SMALL_KPT, SB_LARGE_KPT = 8;  // elements per thread
+constexpr int SB_LARGE_GRID = 512;                   // persistent workgroups of the large launch (two per CU)
 constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the counting pass of the LDS sorts
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 
@@ -42,19 +51,17 @@ __host__ __device__ __forceinline__ Geo geo_of(int tile_w, int tile_h) {
   g.sh = (tile_h + 1) >> 1;
   return g;
 }
-struct Band {
-  int sr0, sr1;  // supertile rows
-  int tr0, tr1;  // tile rows
-};
-__host__ __device__ __forceinline__ Band band_of(int xcd, const Geo& g) {
-  Band b;
-  b.sr0 = (xcd * g.sh) / 8;
-  b.sr1 = ((xcd + 1) * g.sh) / 8;
-  b.tr0 = 2 * b.sr0;
-  b.tr1 = 2 * b.sr1 < g.tile_h ? 2 * b.sr1 : g.tile_h;
-  return b;
+// Supertile rows per LDS pass: count holds (2 rows + 1) x (tile_w + 1) tile marks and (rows + 1) x (sw + 1)
+// supertile marks, scatter rows x sw cursors.  0 = does not fit at all.
+__host__ __device__ __forceinline__ int count_band_rows(const Geo& g) {
+  const int per = 2 * (g.tile_w + 1) + (g.sw + 1), fixed = (g.tile_w + 1) + (g.sw + 1);
+  const int rows = (SB_MAX_LDS_WORDS - fixed) / per;
+  return rows < g.sh ? (rows > 0 ? rows : 0) : g.sh;
 }
-int max_band_st_rows(const Geo& g) { return (g.sh + 7) / 8; }
+__host__ __device__ __forceinline__ int scatter_band_rows(const Geo& g) {
+  const int rows = SB_MAX_LDS_WORDS / g.sw;
+  return rows < g.sh ? rows : g.sh;
+}
 
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 #pragma unroll
@@ -65,70 +72,90 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
   return v;
 }
 
-// corner marks -> counts: prefix along x (a wavefront per row, 64 cells a step), then along y with the
-// result written out (thread = column); grid[rows + 1][cols + 1], counts for [rows][cols]
-__device__ __forceinline__ void marks_to_counts(int32_t* grid, int rows, int cols, uint32_t* __restrict__ out) {
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6, gw = cols + 1;
-  for (int row = wave; row < rows; row += SB_WAVES) {
+// corner marks -> counts, both grids in the same two phases: prefix along x (a wavefront per row, 64 cells a
+// step), then along y with the result written out (thread = column); grids [rows + 1][cols + 1]
+__device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w, uint32_t* __restrict__ out_t,
+                                                int32_t* gs, int nsr, int sw, uint32_t* __restrict__ out_s) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  for (int r = wave; r < ntr + nsr; r += SC_WAVES) {
+    const bool tiles = r < ntr;
+    int32_t* row = tiles ? gt + r * (tile_w + 1) : gs + (r - ntr) * (sw + 1);
+    const int cols = tiles ? tile_w : sw;
     int carry = 0;
     for (int x = 0; x < cols; x += 64) {
-      const int v = x + lane < cols ? grid[row * gw + x + lane] : 0;
+      const int v = x + lane < cols ? row[x + lane] : 0;
       const int incl = (int)wave_incl_scan((uint32_t)v, lane) + carry;
-      if (x + lane < cols) grid[row * gw + x + lane] = incl;
+      if (x + lane < cols) row[x + lane] = incl;
       carry = __builtin_amdgcn_readlane(incl, 63);
     }
   }
   __syncthreads();
-  for (int x = threadIdx.x; x < cols; x += SB_BLOCK) {
-    int run = 0;
-    for (int row = 0; row < rows; ++row) {
-      run += grid[row * gw + x];
-      out[row * cols + x] = (uint32_t)run;
+  for (int c = threadIdx.x; c < tile_w + sw; c += SC_BLOCK) {
+    const bool tiles = c < tile_w;
+    const int x = tiles ? c : c - tile_w, cols = tiles ? tile_w : sw, rows = tiles ? ntr : nsr;
+    const int32_t* col = (tiles ? gt : gs) + x;
+    uint32_t* out = (tiles ? out_t : out_s) + x;
+    int run = 0, row = 0;
+    for (; row + 4 <= rows; row += 4) {
+      int v[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) v[k] = col[(row + k) * (cols + 1)];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        run += v[k];
+        out[(size_t)(row + k) * cols] = (uint32_t)run;
+      }
+    }
+    for (; row < rows; ++row) {
+      run += col[row * (cols + 1)];
+      out[(size_t)row * cols] = (uint32_t)run;
     }
   }
 }
 
 // ---- count --------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(SB_BLOCK)
-sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, uint32_t* __restrict__ table_t,
-                uint32_t* __restrict__ table_s) {
+__global__ void __launch_bounds__(SC_BLOCK)
+sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, int band_rows,
+                uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
   extern __shared__ int32_t s_grid[];  // tile grid [(tile rows + 1)][tile_w + 1], then supertile grid
   const Geo g = geo_of(tile_w, tile_h);
-  const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
-  const Band b = band_of(xcd, g);
-  const int ntr = b.tr1 - b.tr0, nsr = b.sr1 - b.sr0;
-  if (nsr <= 0) return;
+  const int chunk = blockIdx.x;
   const int gwt = tile_w + 1, gws = g.sw + 1;
-  int32_t* gt = s_grid;
-  int32_t* gs = s_grid + (ntr + 1) * gwt;
-  for (int i = threadIdx.x; i < (ntr + 1) * gwt + (nsr + 1) * gws; i += SB_BLOCK) s_grid[i] = 0;
-  __syncthreads();
-  const int g0 = chunk * SB_CHUNK + threadIdx.x;
-  int2 rc[SB_ROUNDS];
-#pragma unroll
-  for (int r = 0; r < SB_ROUNDS; ++r) rc[r] = (g0 + r * SB_BLOCK < N) ? rects[g0 + r * SB_BLOCK] : make_int2(0, 0);
-#pragma unroll
-  for (int r = 0; r < SB_ROUNDS; ++r) {
-    const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
-    const int ya = max(y0, b.tr0), yb = min(y0 + h, b.tr1);
-    if (w > 0 && yb > ya) {
-      const int ra = ya - b.tr0, rb = yb - b.tr0;
-      atomicAdd(&gt[ra * gwt + x0], 1);
-      atomicAdd(&gt[ra * gwt + x0 + w], -1);
-      atomicAdd(&gt[rb * gwt + x0], -1);
-      atomicAdd(&gt[rb * gwt + x0 + w], 1);
-      const int sxa = x0 >> 1, sxb = ((x0 + w - 1) >> 1) + 1;
-      const int sya = (ya >> 1) - b.sr0, syb = ((yb - 1) >> 1) + 1 - b.sr0;
-      atomicAdd(&gs[sya * gws + sxa], 1);
-      atomicAdd(&gs[sya * gws + sxb], -1);
-      atomicAdd(&gs[syb * gws + sxa], -1);
-      atomicAdd(&gs[syb * gws + sxb], 1);
-    }
-  }
-  __syncthreads();
   const int T = tile_w * tile_h, S = g.sw * g.sh;
-  marks_to_counts(gt, ntr, tile_w, table_t + (size_t)chunk * T + b.tr0 * tile_w);
-  marks_to_counts(gs, nsr, g.sw, table_s + (size_t)chunk * S + b.sr0 * g.sw);
+  const int g0 = chunk * SB_CHUNK + threadIdx.x;
+  int2 rc[SC_PER];
+#pragma unroll
+  for (int r = 0; r < SC_PER; ++r) rc[r] = (g0 + r * SC_BLOCK < N) ? rects[g0 + r * SC_BLOCK] : make_int2(0, 0);
+  for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's grids fit the LDS)
+    const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
+    const int ntr = tr1 - tr0, nsr = sr1 - sr0;
+    int32_t* gt = s_grid;
+    int32_t* gs = s_grid + (ntr + 1) * gwt;
+    for (int i = threadIdx.x; i < (ntr + 1) * gwt + (nsr + 1) * gws; i += SC_BLOCK) s_grid[i] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_PER; ++r) {
+      const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
+      const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
+      if (w > 0 && yb > ya) {
+        const int ra = ya - tr0, rb = yb - tr0;
+        atomicAdd(&gt[ra * gwt + x0], 1);
+        atomicAdd(&gt[ra * gwt + x0 + w], -1);
+        atomicAdd(&gt[rb * gwt + x0], -1);
+        atomicAdd(&gt[rb * gwt + x0 + w], 1);
+        const int sxa = x0 >> 1, sxb = ((x0 + w - 1) >> 1) + 1;
+        const int sya = (ya >> 1) - sr0, syb = ((yb - 1) >> 1) + 1 - sr0;
+        atomicAdd(&gs[sya * gws + sxa], 1);
+        atomicAdd(&gs[sya * gws + sxb], -1);
+        atomicAdd(&gs[syb * gws + sxa], -1);
+        atomicAdd(&gs[syb * gws + sxb], 1);
+      }
+    }
+    __syncthreads();
+    marks_to_counts(gt, ntr, tile_w, table_t + (size_t)chunk * T + tr0 * tile_w, gs, nsr, g.sw,
+                    table_s + (size_t)chunk * S + sr0 * g.sw);
+    __syncthreads();
+  }
 }
 
 // ---- columns: 16 columns x 16 chunk slices per workgroup.  Workgroups [0, wg_t) sum the tile columns,
@@ -259,116 +286,109 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
 }
 
 // ---- scatter --------------------------------------------------------------------------------------------
-// Workgroup (xcd, chunk): a wavefront reads 64 rectangles per round, queues the ones that reach the band
-// (7 of 8 do not) and, whenever 64 are queued, walks their (Gaussian, supertile) pairs 64 at a time: every
-// lane finds the owner of its slot by binary search over the wave's exclusive counts and writes the element
+// One workgroup per chunk; a wavefront takes 64 Gaussians a round: every lane finds the owner of its slot among
+// the round's (Gaussian, supertile) pairs by binary search over the exclusive counts and writes the element
 // depth bits << 32 | id << 4 | tile mask (bit j: the rectangle covers tile j = 2 * (row in the supertile) +
 // column) to the slot an LDS cursor of the supertile hands out (segment start + the chunks before this one,
 // from the scanned table).  Order = (depth bits, id): the mask sits below the id and never decides.
-__global__ void __launch_bounds__(SB_BLOCK)
+__global__ void __launch_bounds__(SC_BLOCK)
 sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
-                  int tile_h, const uint32_t* __restrict__ table_s, const int32_t* __restrict__ tile_offsets,
-                  const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries, long long capacity) {
-  extern __shared__ uint32_t s_cur[];  // [supertiles of the band]
-  __shared__ int4 s_q[SB_WAVES][128];
-  __shared__ int32_t s_excl[SB_WAVES][64];
+                  int tile_h, int band_rows, const uint32_t* __restrict__ table_s,
+                  const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
+                  uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list) {
+  extern __shared__ uint32_t s_cur[];  // [supertiles of the pass]
+  __shared__ int s_large;
+  __shared__ int4 s_q[SC_WAVES][64];
+  __shared__ int32_t s_excl[SC_WAVES][64];
+  __shared__ unsigned long long s_marks[SC_WAVES];
   const Geo g = geo_of(tile_w, tile_h);
-  const int xcd = blockIdx.x & 7, chunk = blockIdx.x >> 3;
-  const Band b = band_of(xcd, g);
-  const int S = g.sw * g.sh, sb0 = b.sr0 * g.sw, nbs = (b.sr1 - b.sr0) * g.sw;
+  const int chunk = blockIdx.x, S = g.sw * g.sh;
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;  // the guess was too small: the host repeats the call
-  const uint32_t* row = table_s + (size_t)chunk * S + sb0;
-  for (int i = threadIdx.x; i < nbs; i += SB_BLOCK) s_cur[i] = (uint32_t)st_offsets[sb0 + i] + row[i];
-  __syncthreads();
-
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-  int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}; the supertile rectangle is recomputed when drained
-  int32_t* ex = s_excl[wave];
-  int qn = 0;
-
-  auto drain = [&](int m) {
-    const int4 e = q[lane];
-    const int w = e.w & 0xFFFF, h = e.w >> 16, x0 = e.z & 0xFFFF, y0 = e.z >> 16;
-    const int ya = max(y0, b.tr0), yb = min(y0 + h, b.tr1);
-    const int sxa = x0 >> 1, snx = ((x0 + w - 1) >> 1) + 1 - sxa;
-    const int sya = ya >> 1, sny = ((yb - 1) >> 1) + 1 - sya;
-    const uint32_t cnt = lane < m ? (uint32_t)(snx * sny) : 0u;
-    const uint32_t incl = wave_incl_scan(cnt, lane);
-    const int total = (int)__builtin_amdgcn_readlane((int)incl, 63);
-    ex[lane] = lane < m ? (int)(incl - cnt) : total;
-    __builtin_amdgcn_wave_barrier();
-    for (int s0 = 0; s0 < total; s0 += 64) {
-      const int slot = s0 + lane;
-      if (slot < total) {
-        int lo = 0;
-#pragma unroll
-        for (int step = 32; step > 0; step >>= 1)
-          if (ex[lo + step] <= slot) lo += step;
-        const int4 o = q[lo];
-        const int t = slot - ex[lo];
-        const int ow = o.w & 0xFFFF, ox0 = o.z & 0xFFFF, oy0 = o.z >> 16;
-        const int oxa = ox0 >> 1, onx = ((ox0 + ow - 1) >> 1) + 1 - oxa;
-        const int oya = max(oy0, b.tr0) >> 1;
-        int ty = (int)((float)t * __builtin_amdgcn_rcpf((float)onx));
-        ty -= (ty * onx > t);
-        ty += ((ty + 1) * onx <= t);
-        const int tx = t - ty * onx;
-        const int local = (oya + ty - b.sr0) * g.sw + oxa + tx;
-        const uint32_t pos = atomicAdd(&s_cur[local], 1u);
-        // which of the supertile's four tiles the rectangle covers (bit j: tile 2 * row + column)
-        const int oh = o.w >> 16, c0 = 2 * (oxa + tx), r0 = 2 * (oya + ty);
-        const uint32_t cols = (uint32_t)(c0 >= ox0) | ((uint32_t)(c0 + 1 < ox0 + ow) << 1);
-        const uint32_t rows = (uint32_t)(r0 >= oy0) | ((uint32_t)(r0 + 1 < oy0 + oh) << 1);
-        const uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
-        entries[pos] = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
-      }
-    }
-    __builtin_amdgcn_wave_barrier();
-  };
-  auto pop64 = [&]() {
-    const int rest = qn - 64;
-    int4 keep = make_int4(0, 0, 0, 0);
-    if (lane < rest) keep = q[64 + lane];
-    __builtin_amdgcn_wave_barrier();
-    if (lane < rest) q[lane] = keep;
-    __builtin_amdgcn_wave_barrier();
-    qn = rest;
-  };
-
-  // The wavefront's rectangles SB_GROUP rounds at a time, then the depth bits of the ones that reach the band:
-  // two memory round trips per group.  (Loaded round by round, rectangle then key, a wavefront waited 2 x 16 times.)
-  constexpr int SB_GROUP = 8;
-  const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SB_WAVES);
-#pragma unroll 1
-  for (int rg = 0; rg < SB_ROUNDS; rg += SB_GROUP) {
-    const int gb = g0 + rg * 64 + lane;
-    int2 rc[SB_GROUP];
-#pragma unroll
-    for (int r = 0; r < SB_GROUP; ++r) rc[r] = gb + r * 64 < N ? rects[gb + r * 64] : make_int2(0, 0);
-    uint32_t hits = 0;
-#pragma unroll
-    for (int r = 0; r < SB_GROUP; ++r) {
-      const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, y0 = rc[r].x >> 16;
-      hits |= (uint32_t)(w > 0 && min(y0 + h, b.tr1) > max(y0, b.tr0)) << r;
-    }
-    uint32_t dk[SB_GROUP];
-#pragma unroll
-    for (int r = 0; r < SB_GROUP; ++r) dk[r] = (hits >> r) & 1u ? depth_keys[gb + r * 64] : 0u;
-#pragma unroll
-    for (int r = 0; r < SB_GROUP; ++r) {
-      const bool hit = (hits >> r) & 1u;
-      const uint64_t bal = __ballot(hit);
-      if (hit) q[qn + __popcll(bal & lt_mask)] = make_int4(gb + r * 64, (int)dk[r], rc[r].x, rc[r].y);
-      qn += __popcll(bal);
-      __builtin_amdgcn_wave_barrier();
-      if (qn >= 64) {
-        drain(64);
-        pop64();
-      }
-    }
+  if (chunk == 0) {
+    // the supertiles too long for the small sort launch, for the large one's persistent workgroups (order: any)
+    if (threadIdx.x == 0) s_large = 0;
+    __syncthreads();
+    for (int i = threadIdx.x; i < S; i += SC_BLOCK)
+      if (st_offsets[i + 1] - st_offsets[i] > small_max) large_list[1 + atomicAdd(&s_large, 1)] = i;
+    __syncthreads();
+    if (threadIdx.x == 0) large_list[0] = s_large;
   }
-  if (qn > 0) drain(qn);
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}
+  int32_t* ex = s_excl[wave];
+  unsigned long long* marks = &s_marks[wave];
+  // the wavefront's rectangles and depth bits: all loads in flight together
+  const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SC_WAVES) + lane;
+  int2 rc[SC_PER];
+  uint32_t dk[SC_PER];
+#pragma unroll
+  for (int r = 0; r < SC_PER; ++r) {
+    const bool in = g0 + r * 64 < N;
+    rc[r] = in ? rects[g0 + r * 64] : make_int2(0, 0);
+    dk[r] = in ? depth_keys[g0 + r * 64] : 0u;
+  }
+  for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's cursors fit the LDS)
+    const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
+    const int sb0 = sr0 * g.sw, nbs = (sr1 - sr0) * g.sw;
+    const uint32_t* row = table_s + (size_t)chunk * S + sb0;
+    for (int i = threadIdx.x; i < nbs; i += SC_BLOCK) s_cur[i] = (uint32_t)st_offsets[sb0 + i] + row[i];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < SC_PER; ++r) {
+      const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
+      const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
+      const bool hit = w > 0 && yb > ya;
+      const int sxa = x0 >> 1, snx = ((x0 + w - 1) >> 1) + 1 - sxa;
+      const int sya = ya >> 1, sny = ((yb - 1) >> 1) + 1 - sya;
+      const uint32_t cnt = hit ? (uint32_t)(snx * sny) : 0u;
+      const uint32_t incl = wave_incl_scan(cnt, lane);
+      const int total = (int)__builtin_amdgcn_readlane((int)incl, 63);
+      // the round's Gaussians with pairs, compacted: owner k = the k-th of them
+      const uint64_t hm = __ballot(hit);
+      const int ci = __popcll(hm & lt_mask);
+      if (hit) {
+        q[ci] = make_int4(g0 + r * 64, (int)dk[r], rc[r].x, rc[r].y);
+        ex[ci] = (int)(incl - cnt);
+      }
+      __builtin_amdgcn_wave_barrier();
+      for (int s0 = 0; s0 < total; s0 += 64) {
+        // Owner of slot s0 + lane = the number of owners whose pairs end before it: the ones that ended before the
+        // window (a ballot) + the END MARKS below this lane's bit in a 64-bit word the owners ending inside the
+        // window OR together in LDS.  (A binary search over the exclusive counts was six dependent LDS reads.)
+        if (lane == 0) *marks = 0ull;
+        __builtin_amdgcn_wave_barrier();
+        const int endpos = (int)incl - 1 - s0;
+        if (hit && endpos >= 0 && endpos < 64) atomicOr(marks, 1ull << endpos);
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t m = __hip_atomic_load(marks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+        const int before = __popcll(__ballot(hit && (int)incl <= s0));
+        const int slot = s0 + lane;
+        if (slot < total) {
+          const int lo = before + __popcll(m & lt_mask);
+          const int4 o = q[lo];
+          const int t = slot - ex[lo];
+          const int ow = o.w & 0xFFFF, oh = o.w >> 16, ox0 = o.z & 0xFFFF, oy0 = o.z >> 16;
+          const int oxa = ox0 >> 1, onx = ((ox0 + ow - 1) >> 1) + 1 - oxa;
+          const int oya = max(oy0, tr0) >> 1;
+          int ty = (int)((float)t * __builtin_amdgcn_rcpf((float)onx));
+          ty -= (ty * onx > t);
+          ty += ((ty + 1) * onx <= t);
+          const int tx = t - ty * onx;
+          const int local = (oya + ty - sr0) * g.sw + oxa + tx;
+          const uint32_t pos = atomicAdd(&s_cur[local], 1u);
+          // which of the supertile's four tiles the rectangle covers (bit j: tile 2 * row + column)
+          const int c0 = 2 * (oxa + tx), r0 = 2 * (oya + ty);
+          const uint32_t cols = (uint32_t)(c0 >= ox0) | ((uint32_t)(c0 + 1 < ox0 + ow) << 1);
+          const uint32_t rows = (uint32_t)(r0 >= oy0) | ((uint32_t)(r0 + 1 < oy0 + oh) << 1);
+          const uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
+entries[pos] = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
+        }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+  }
 }
 
 // ---- per-supertile sort + emission ------------------------------------------------------------------------
@@ -581,30 +601,34 @@ struct SortShared {
 // Then the tile lists: wavefront w owns the contiguous share [w R 64, (w + 1) R 64) of the sorted run; ONE walk
 // takes every element's rank among the wavefront's elements of each tile (ballots), the per-wavefront counts
 // become bases, the ids go out.
+// Rounds q = 0 .. KPT - 1 come in blocks: a block (4 rounds, or 3) runs iff the segment reaches it (a scalar branch) and is
+// straight-line code with a per-lane `valid` bit per round inside -- its loads are in flight together.  (With
+// `if (q < R && i < n) { load; use }` per round every load was followed by its own wait: KPT dependent round trips.)
+#define SB_FOR_ROUNDS(q)                                 \
+  _Pragma("unroll") for (int qb_ = 0; qb_ < KPT; qb_ += QB) \
+    if (qb_ < R)                                         \
+      _Pragma("unroll") for (int q = qb_; q < qb_ + QB; ++q)
+
 template <int NW, int KPT, int BB>
 __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, const uint64_t* __restrict__ src, int n,
                                               const int* tile_base, int32_t* __restrict__ flatten_ids) {
   constexpr int NT = 64 * NW, NB = 1 << BB, PER = NB / NT;
   static_assert(NB % NT == 0 && PER >= 1 && (PER % 4 == 0 || PER < 4), "buckets per thread");
+  constexpr int QB = KPT % 4 == 0 ? 4 : 3;
+  static_assert(KPT % QB == 0, "rounds come in blocks");
   const int lane = gt & 63, gw = gt >> 6;
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   const int R = (n + NT - 1) / NT;  // rounds; wavefront w owns [w R 64, (w + 1) R 64)
   const int ibase = gw * R * 64 + lane;
-  // Straight-line code over all KPT rounds with a per-lane `valid` bit each (no branches on the round count:
-  // with `if (q < R) { load; use }` every load was followed by its own wait -- eight dependent round trips).
   uint32_t valid = 0;
 #pragma unroll
   for (int q = 0; q < KPT; ++q) valid |= (uint32_t)(q < R && ibase + q * 64 < n) << q;
   uint64_t e[KPT];
 #pragma unroll
   for (int q = 0; q < KPT; ++q) e[q] = 0;
-  if (n > 0) {
-#pragma unroll
-    for (int q = 0; q < KPT; ++q) e[q] = src[(valid >> q) & 1u ? ibase + q * 64 : 0];  // all in flight together
-  }
+  SB_FOR_ROUNDS(q) e[q] = src[(valid >> q) & 1u ? ibase + q * 64 : 0];  // (R > 0 here: src[0] exists)
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-#pragma unroll
-  for (int q = 0; q < KPT; ++q) {
+  SB_FOR_ROUNDS(q) {
     const bool v = (valid >> q) & 1u;
     e[q] = v ? e[q] : 0ull;
     lo = v ? min(lo, (uint32_t)(e[q] >> 32)) : lo;
@@ -637,10 +661,9 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   const int bits = range ? 32 - __builtin_clz(range) : 0, low = bits > BB ? bits - BB : 0;
   uint32_t rk[KPT];
 #pragma unroll
-  for (int q = 0; q < KPT; ++q) {
-    rk[q] = 0;
+  for (int q = 0; q < KPT; ++q) rk[q] = 0;
+  SB_FOR_ROUNDS(q)
     if ((valid >> q) & 1u) rk[q] = atomicAdd(&sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low], 1u);
-  }
   __syncthreads();
   {  // counts -> exclusive bases: thread t owns PER consecutive buckets
     uint32_t c[PER], tot = 0;
@@ -679,15 +702,14 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
     if (gt == NT - 1) sh.bucket[NB] = run;  // = n
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < KPT; ++q)
+  SB_FOR_ROUNDS(q)
     if ((valid >> q) & 1u) sh.img[sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low] + rk[q]] = e[q];
   __syncthreads();
   // the order inside every bucket: an element's place = the bucket's base + the number of smaller elements in it
   int pos[KPT];
 #pragma unroll
-  for (int q = 0; q < KPT; ++q) {
-    pos[q] = -1;
+  for (int q = 0; q < KPT; ++q) pos[q] = -1;
+  SB_FOR_ROUNDS(q) {
     if ((valid >> q) & 1u) {
       const uint32_t bk = ((uint32_t)(e[q] >> 32) - kmin) >> low;
       const int s0 = (int)sh.bucket[bk], s1 = (int)sh.bucket[bk + 1];
@@ -699,20 +721,17 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
     }
   }
   __syncthreads();
-#pragma unroll
-  for (int q = 0; q < KPT; ++q)
+  SB_FOR_ROUNDS(q)
     if (pos[q] >= 0) sh.img[pos[q]] = e[q];  // (elements alone in their bucket are in place)
   __syncthreads();
   // ---- emission ----
   uint32_t idm[KPT], ranks[KPT];
   uint32_t pre[KPT][4], c[4] = {0, 0, 0, 0};  // (wave-uniform: scalar registers)
 #pragma unroll
-  for (int q = 0; q < KPT; ++q) {
-    idm[q] = 0;
+  for (int q = 0; q < KPT; ++q) idm[q] = 0;
+  SB_FOR_ROUNDS(q)
     if ((valid >> q) & 1u) idm[q] = (uint32_t)sh.img[ibase + q * 64];  // id << 4 | mask
-  }
-#pragma unroll
-  for (int q = 0; q < KPT; ++q) {
+  SB_FOR_ROUNDS(q) {
     ranks[q] = 0;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -736,36 +755,31 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
       base[j] = (uint32_t)tile_base[j] + (uint32_t)__builtin_amdgcn_readfirstlane((int)v[j]);
     }
   }
-#pragma unroll
-  for (int q = 0; q < KPT; ++q) {
+  SB_FOR_ROUNDS(q) {
     const uint32_t id = idm[q] >> 4;
 #pragma unroll
     for (int j = 0; j < 4; ++j)
       if ((idm[q] >> j) & 1u) flatten_ids[base[j] + pre[q][j] + ((ranks[q] >> (8 * j)) & 0xFFu)] = (int32_t)id;
   }
 }
+#undef SB_FOR_ROUNDS
 
-// Two launches share the supertiles: SB_SMALL (256 threads, up to 2048 elements, 24 KB of LDS) takes nearly all
-// of them on the 1M / 1080p scene, SB_LARGE (1024 threads, up to 8192 elements) the heavier ones; beyond that the
-// segment goes through global memory.
-template <int NW, int BB>
-__global__ void __launch_bounds__(64 * NW)
-sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
-               uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, long long capacity,
-               int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
-  constexpr int MAXN = SortShared<NW, SB_SORT_KPT, BB>::MAXN;  // elements sorted in LDS by this variant
-  constexpr bool SMALL = NW == SB_SMALL_WAVES;
-  __shared__ SortShared<NW, SB_SORT_KPT, BB> sh;
+// Two launches share the supertiles: the SMALL one (512 threads, up to 3072 elements, 32 KB of LDS) has a workgroup
+// per supertile and takes all of them on the 1M / 1080p scene; the LARGE one (1024 threads, up to 8064 elements) is
+// SB_LARGE_GRID persistent workgroups over the list of longer segments the scatter kernel left (empty: they return);
+// beyond its capacity a segment goes through global memory.
+template <int NW, int KPT, int BB, bool SMALL>
+__device__ __forceinline__ void sort_supertile(SortShared<NW, KPT, BB>& sh, int st, int tile_w, int tile_h,
+                                               const int32_t* __restrict__ tile_offsets,
+                                               const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
+                                               uint64_t* __restrict__ scratch, bool over, int total,
+                                               int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
+  constexpr int MAXN = SortShared<NW, KPT, BB>::MAXN;  // elements sorted in LDS by this variant
   uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
   static_assert((1 << BB) >= NW * 256, "the fallback's counters live in the bucket array");
   const Geo g = geo_of(tile_w, tile_h);
-  // supertile = workgroup id: neighbours go to different XCDs.  (By band, like the count and scatter kernels,
-  // the long segments of a centre-weighted image all land on the two or three XCDs that own the middle rows.)
-  const int st = blockIdx.x, sy = st / g.sw, sx = st - sy * g.sw;
-  if (st >= g.sw * g.sh) return;
+  const int sy = st / g.sw, sx = st - sy * g.sw;
   const int tx0 = 2 * sx, ty0 = 2 * sy, T = tile_w * tile_h;
-  const int total = tile_offsets[T];
-  const bool over = (long long)total > capacity;
   int tile_base[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -782,13 +796,46 @@ sb_sort_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
   }
   const int off = st_offsets[st], n = st_offsets[st + 1] - off;
   if (over || n <= 0) return;
-  if (SMALL ? n > MAXN : n <= SortShared<SB_SMALL_WAVES, SB_SORT_KPT, SB_SMALL_BUCKET_BITS>::MAXN) return;
+  if (SMALL && n > MAXN) return;  // (on the large launch's list)
   if (n > MAXN) {
     const uint64_t* fin = sort_segment_global<NW>(entries + off, scratch + off, n, wave_cnt, sh.scan_tmp, sh.red);
     emit_tiles<NW>(fin, n, tile_base, flatten_ids, sh.tcnt);
     return;
   }
-  sort_emit_lds<NW, SB_SORT_KPT, BB>(sh, (int)threadIdx.x, entries + off, n, tile_base, flatten_ids);
+  sort_emit_lds<NW, KPT, BB>(sh, (int)threadIdx.x, entries + off, n, tile_base, flatten_ids);
+}
+
+__global__ void __launch_bounds__(64 * SB_SMALL_WAVES)
+sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
+                     const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
+                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
+                     int32_t* __restrict__ list_offsets) {
+  __shared__ SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS> sh;
+  // supertile = workgroup id: neighbours go to different XCDs.  (By band the long segments of a centre-weighted
+  // image all land on the two or three XCDs that own the middle rows.)
+  const int st = blockIdx.x;
+  if (st >= ((tile_w + 1) >> 1) * ((tile_h + 1) >> 1)) return;
+  const int total = tile_offsets[tile_w * tile_h];
+  sort_supertile<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS, true>(
+      sh, st, tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, (long long)total > capacity, total, flatten_ids,
+      list_offsets);
+}
+
+__global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
+sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
+                     const int32_t* __restrict__ st_offsets, const int32_t* __restrict__ large_list,
+                     uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, long long capacity,
+                     int32_t* __restrict__ flatten_ids) {
+  __shared__ SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS> sh;
+  const int total = tile_offsets[tile_w * tile_h];
+  if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
+  const int count = large_list[0];
+  for (int k = blockIdx.x; k < count; k += gridDim.x) {
+    sort_supertile<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS, false>(
+        sh, large_list[1 + k], tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, false, total, flatten_ids,
+        nullptr);
+    __syncthreads();
+  }
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
@@ -797,6 +844,7 @@ int n_chunks_of(int N) { return (N + SB_CHUNK - 1) / SB_CHUNK; }
 struct CountWs {
   uint32_t *table_t, *table_s;
   int32_t* st_offsets;
+  int32_t* large_list;  // [0] = how many supertiles the small sort launch leaves to the large one, then their indices
   size_t bytes;
 };
 CountWs count_ws(void* base, int N, const Geo& g) {
@@ -810,11 +858,13 @@ CountWs count_ws(void* base, int N, const Geo& g) {
   o += al256(nc * S * 4);
   w.st_offsets = reinterpret_cast<int32_t*>(p + o);
   o += al256((S + 1) * 4);
+  w.large_list = reinterpret_cast<int32_t*>(p + o);
+  o += al256((S + 1) * 4);
   w.bytes = o;
   return w;
 }
 size_t count_lds_bytes(const Geo& g) {
-  const int nsr = max_band_st_rows(g);
+  const int nsr = count_band_rows(g);
   return ((size_t)(2 * nsr + 1) * (g.tile_w + 1) + (size_t)(nsr + 1) * (g.sw + 1)) * 4;
 }
 
@@ -823,8 +873,7 @@ size_t count_lds_bytes(const Geo& g) {
 extern "C" int fg_stbin_supported(int N, int tile_w, int tile_h) {
   if (N < 0 || N >= (1 << 28) || tile_w <= 0 || tile_h <= 0 || tile_w > 1023 || tile_h > 1023) return 0;
   const Geo g = geo_of(tile_w, tile_h);
-  if (count_lds_bytes(g) > (size_t)SB_MAX_LDS_WORDS * 4) return 0;
-  return (size_t)max_band_st_rows(g) * g.sw <= (size_t)SB_MAX_LDS_WORDS ? 1 : 0;
+  return count_band_rows(g) > 0 && scatter_band_rows(g) > 0 ? 1 : 0;
 }
 
 extern "C" size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h) {
@@ -841,8 +890,8 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
   if (workspace_bytes < w.bytes) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
   const int T = tile_w * tile_h, S = g.sw * g.sh, nc = n_chunks_of(N);
-  hipLaunchKernelGGL(sb_count_kernel, dim3(8 * nc), dim3(SB_BLOCK), count_lds_bytes(g), s, N,
-                     reinterpret_cast<const int2*>(tile_rects), tile_w, tile_h, w.table_t, w.table_s);
+  hipLaunchKernelGGL(sb_count_kernel, dim3(nc), dim3(SC_BLOCK), count_lds_bytes(g), s, N,
+                     reinterpret_cast<const int2*>(tile_rects), tile_w, tile_h, count_band_rows(g), w.table_t, w.table_s);
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
   hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
                      tile_offsets, w.st_offsets);
@@ -872,16 +921,16 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   char* p = static_cast<char*>(workspace);
   uint64_t* entries = reinterpret_cast<uint64_t*>(p);
   uint64_t* scratch = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 8));
-  const int max_band_st = max_band_st_rows(g) * g.sw;
-  hipLaunchKernelGGL(sb_scatter_kernel, dim3(8 * nc), dim3(SB_BLOCK), (size_t)max_band_st * 4, s, N,
-                     reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, w.table_s, tile_offsets,
-                     w.st_offsets, entries, (long long)capacity);
-  hipLaunchKernelGGL((sb_sort_kernel<SB_LARGE_WAVES, SB_LARGE_BUCKET_BITS>), dim3(g.sw * g.sh), dim3(64 * SB_LARGE_WAVES),
-                     0, s, tile_w, tile_h, tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids,
-                     list_offsets);
-  hipLaunchKernelGGL((sb_sort_kernel<SB_SMALL_WAVES, SB_SMALL_BUCKET_BITS>), dim3(g.sw * g.sh), dim3(64 * SB_SMALL_WAVES),
-                     0, s, tile_w, tile_h, tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids,
-                     list_offsets);
+  const int band_rows = scatter_band_rows(g), S = g.sw * g.sh;
+  constexpr int small_max = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>::MAXN;
+  hipLaunchKernelGGL(sb_scatter_kernel, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
+                     reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, w.table_s,
+                     tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+  hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
+                     tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries, scratch, (long long)capacity,
+                     flatten_ids);
+  hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h, tile_offsets,
+                     w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -340,14 +340,14 @@ def _pack_rects(x0, y0, w, h):
     return torch.stack([x0 | (y0 << 16), w | (h << 16)], -1).to(torch.int32).contiguous()
 
 
-@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "one", "all_culled", "few_rows", "2160p"])
+@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "one", "all_culled", "few_rows", "2160p"])
 def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
     """csrc/stbin.hip (count -> scan -> scatter per supertile -> one sort per supertile, four tile lists read off
     it) and csrc/tilebin.hip (the same per tile) against the depth-first binning on the same depth keys and
     footprint rectangles: `torch.equal` lists and ranges.
     Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
-    a tile with more entries than fit the LDS sort (the pass through global memory); one Gaussian; nothing
-    visible; an image with fewer tile rows than XCD bands; 32 400 tiles."""
+    tiles with more entries than fit the small LDS sort (the large one), than fit any (the pass through global
+    memory); one Gaussian; nothing visible; an image with fewer tile rows than XCD bands; 32 400 tiles."""
     g = torch.Generator().manual_seed(31)
     W, H = 640, 400
     if case == "scene":
@@ -364,7 +364,8 @@ def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
     if case == "2160p":
         W, H = 3840, 2160
     tw, th = (W + 15) // 16, (H + 15) // 16
-    N = {"ties": 30000, "heavy_tile": 20000, "one": 1, "all_culled": 5000, "few_rows": 4000, "2160p": 200_000}[case]
+    N = {"ties": 30000, "heavy_tile": 20000, "huge_tile": 40000, "one": 1, "all_culled": 5000, "few_rows": 4000,
+         "2160p": 200_000}[case]
     x0 = torch.randint(0, tw, (N,), generator=g)
     y0 = torch.randint(0, th, (N,), generator=g)
     w = torch.minimum(torch.randint(1, 5, (N,), generator=g), tw - x0)
@@ -374,9 +375,12 @@ def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
         depth = depth[torch.randint(0, 40, (N,), generator=g)]  # 40 distinct depths: runs of hundreds of equal keys
         depth[:2000] = 3.0
     if case == "heavy_tile":
-        x0[:6000], y0[:6000], w[:6000], h[:6000] = 7, 5, 2, 2  # 6000 entries in each of four tiles (> 2048: global pass)
+        x0[:6000], y0[:6000], w[:6000], h[:6000] = 7, 5, 2, 2  # 6000 entries in each of four tiles / supertiles (the large LDS sort)
         depth[1000:1500] = 2.5  # ... with ties inside
         w[6000:6100], h[6000:6100] = tw - x0[6000:6100], th - y0[6000:6100]  # and a few huge rectangles
+    if case == "huge_tile":
+        x0[:20000], y0[:20000], w[:20000], h[:20000] = 8, 4, 2, 2  # 20000 entries in one supertile: the pass through global memory
+        depth[3000:3400] = 1.75
     keys = depth.float().view(torch.int32).clone()
     if case == "all_culled":
         w[:], h[:] = 0, 0
