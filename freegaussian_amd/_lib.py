@@ -64,17 +64,17 @@ SIGNATURES = {
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
-                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P]),
+                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_sh_pack_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
-                                  c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P]),
+                                  c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_raw_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P, P, c_int,
                                       c_int, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P,
-                                      P, P, P]),
+                                      P, P, P, P]),
     "fg_preprocess_raw_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
-                                      c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+                                      c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
-                                           c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P]),
+                                           c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P]),
     "fg_sh_grad_accumulate": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P]),
     "fg_densify_flags": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P,
                                  P, P, P, P]),
@@ -91,7 +91,8 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 3
+ABI_VERSION = 4
+SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None
 
 

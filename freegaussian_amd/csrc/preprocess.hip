@@ -25,6 +25,11 @@ using namespace fgsh;
 
 constexpr int REC = FG_SPLAT_FLOATS;  // 16 floats per record
 constexpr int RSTRIDE = 20;           // padded LDS stride of a record (floats, 16-B aligned)
+// The forward's note for the backward of the SH colour (sh_degree >= 1): J[c][d] = d colour_c / d dir_d before the
+// clamp (9 floats, row-major by channel) and the clamp mask (bit c: channel c passed max(. + 0.5, 0)) as the bits
+// of a 10th.  The backward then needs 40 bytes per Gaussian instead of the 192-byte coefficient row.
+constexpr int JAC = FG_SH_JAC_FLOATS;
+constexpr int JSTRIDE = 11;           // odd LDS stride of a Jacobian row
 
 struct FeatLayout {
   int sh_degree;  // >= 0: colours are SH coefficients [N,k_stored,3]; -1: direct colours [N,n_color]
@@ -127,8 +132,9 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
                       int tile_h, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
                       float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ compensations,
                       int32_t* __restrict__ tiles_touched, float* __restrict__ splats,
-                      uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects, int skip_culled) {
-  __shared__ float lds[BLOCK * ROW];  // coefficient slab, then the record slab
+                      uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects, float* __restrict__ sh_jac,
+                      int skip_culled) {
+  __shared__ float lds[BLOCK * ROW];  // coefficient slab, then the record slab, then the Jacobian slab
   __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
@@ -169,6 +175,9 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   float rec[REC];
 #pragma unroll
   for (int c = 0; c < REC; ++c) rec[c] = 0.f;
+  float jac[JAC];
+#pragma unroll
+  for (int c = 0; c < JAC; ++c) jac[c] = 0.f;
   int32_t radius = 0, touched = 0;
   float o_comp = 0.f;
   int x0 = 0, x1 = 0, y0 = 0, y1 = 0;  // the reference's tile rectangle (radius box)
@@ -245,6 +254,22 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
       }
       rec[6] = fmaxf(r + 0.5f, 0.f); rec[7] = fmaxf(g + 0.5f, 0.f); rec[8] = fmaxf(b + 0.5f, 0.f);
       c0 = 9;
+      if (sh_jac && kk > 1) {
+        float bx[16], by[16], bz[16];
+        sh_basis_grad(fl.sh_degree, dx, dy, dz, bx, by, bz);
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          float jx = 0.f, jy = 0.f, jz = 0.f;
+#pragma unroll
+          for (int k = 1; k < 16; ++k)
+            if (k < kk) {
+              jx += bx[k] * row[3 * k + c]; jy += by[k] * row[3 * k + c]; jz += bz[k] * row[3 * k + c];
+            }
+          jac[3 * c] = jx; jac[3 * c + 1] = jy; jac[3 * c + 2] = jz;
+        }
+        // (the comparison the backward made on its recomputed colours)
+        jac[9] = __int_as_float((int)(r + 0.5f > 0.f) | ((int)(g + 0.5f > 0.f) << 1) | ((int)(b + 0.5f > 0.f) << 2));
+      }
     } else {
 #pragma unroll
       for (int c = 0; c < FG_MAX_CHANNELS; ++c)
@@ -269,6 +294,14 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   }
   __syncthreads();
   lds_to_slab_at<RSTRIDE, false>(splats + (size_t)row0 * REC, lds, 0, nrows, REC, REC);
+  if (sh_jac && kk > 1) {  // ---- Jacobian slab out the same way
+    __syncthreads();
+    float* jrow = lds + threadIdx.x * JSTRIDE;
+#pragma unroll
+    for (int c = 0; c < JAC; ++c) jrow[c] = jac[c];
+    __syncthreads();
+    lds_to_slab_at<JSTRIDE, true>(sh_jac + (size_t)row0 * JAC, lds, 0, nrows, JAC, JAC);
+  }
 }
 
 __global__ void __launch_bounds__(BLOCK)
@@ -283,7 +316,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
                       const float* __restrict__ v_means2d, int m2_stride, const float* __restrict__ v_depths,
                       const float* __restrict__ v_conics, float* __restrict__ v_means, float* __restrict__ v_quats,
                       float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
-                      float* __restrict__ v_extra, int skip_culled) {
+                      float* __restrict__ v_extra, const float* __restrict__ sh_jac, int skip_culled) {
   __shared__ float lds[BLOCK * ROW];       // coefficient slab in, v_coeffs slab out
   __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
@@ -291,7 +324,8 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
   const bool active = (i < N) && radii[i] > 0;
-  if (kk > 1) {
+  // with the forward's Jacobian note the coefficient rows are not read at all
+  if (kk > 1 && !sh_jac) {
     if (skip_culled) {  // only the visible Gaussians' coefficient rows are read back
       row_live[threadIdx.x] = active;
       __syncthreads();
@@ -345,6 +379,27 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       sh_dx = dx; sh_dy = dy; sh_dz = dz;
       sh_basis(fl.sh_degree, dx, dy, dz, basis);
       const float* crow = lds + threadIdx.x * ROW;
+      if (kk > 1 && sh_jac) {
+        // the lane's own 40-byte note: five 8-byte loads (the lines are shared by neighbouring lanes)
+        const float2* jp = reinterpret_cast<const float2*>(sh_jac + (size_t)i * JAC);
+        float j[JAC];
+#pragma unroll
+        for (int q2 = 0; q2 < JAC / 2; ++q2) {
+          const float2 v = jp[q2];
+          j[2 * q2] = v.x; j[2 * q2 + 1] = v.y;
+        }
+        const int m = __float_as_int(j[9]);
+        vr = (m & 1) ? rec[8] : 0.f;
+        vg = (m & 2) ? rec[9] : 0.f;
+        vb = (m & 4) ? rec[10] : 0.f;
+        const float vdx = vr * j[0] + vg * j[3] + vb * j[6];
+        const float vdy = vr * j[1] + vg * j[4] + vb * j[7];
+        const float vdz = vr * j[2] + vg * j[5] + vb * j[8];
+        const float dp = vdx * dx + vdy * dy + vdz * dz;
+        g_m[0] = (vdx - dp * dx) * inv;
+        g_m[1] = (vdy - dp * dy) * inv;
+        g_m[2] = (vdz - dp * dz) * inv;
+      } else {
       // recompute the clamp mask: colour = max(sh + 0.5, 0)
       float cr = 0.f, cg = 0.f, cb = 0.f;
       if (kk > 1) {
@@ -374,6 +429,7 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
         g_m[0] = (vdx - dp * dx) * inv;
         g_m[1] = (vdy - dp * dy) * inv;
         g_m[2] = (vdz - dp * dz) * inv;
+      }
       }
     }
     // ---- opacity / compensation -----------------------------------------------------------------
@@ -484,7 +540,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
                           int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                           int tile_size, int antialiased, int32_t* radii, float* means2d, float* depths,
                           float* conics, float* compensations, int32_t* tiles_touched, float* splats,
-                          uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream) {
+                          uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
   FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
   if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
@@ -498,7 +554,7 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
                      fl, raw, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
                      near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
                      depths, conics, compensations, tiles_touched, splats, depth_keys,
-                     reinterpret_cast<int2*>(tile_rects), skip_culled_rows());
+                     reinterpret_cast<int2*>(tile_rects), sh_jac, skip_culled_rows());
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -511,7 +567,7 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
                           const int32_t* radii, const float* v_splats, const float* v_means2d, int v_means2d_stride,
                           const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                           float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
-                          fg_stream_t stream) {
+                          const float* sh_jac, fg_stream_t stream) {
   FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
   if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl) || v_means2d_stride < 2) return FG_ERR_INVALID_ARG;
   if (N == 0) return FG_OK;
@@ -531,7 +587,7 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
   hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
                      fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, v_rgb_floats, means, quats, scales, opacities, colors,
                      viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
-                     v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
+                     v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra, sh_jac,
                      skip_culled_rows());
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
@@ -546,11 +602,12 @@ extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, 
                                  float near_plane, float far_plane, float radius_clip, int tile_size,
                                  int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                                  float* compensations, int32_t* tiles_touched, float* splats,
-                                 uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream) {
+                                 uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{0, nullptr, nullptr, nullptr}, means, quats, scales, opacities, colors,
                                sh_degree, k_stored, n_color, with_depth, extra, n_extra, viewmat, K, width, height,
                                eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased, radii, means2d,
-                               depths, conics, compensations, tiles_touched, splats, depth_keys, tile_rects, stream);
+                               depths, conics, compensations, tiles_touched, splats, depth_keys, tile_rects, sh_jac,
+                               stream);
 }
 
 extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
@@ -560,12 +617,12 @@ extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, 
                                  const float* v_splats, const float* v_means2d, int v_means2d_stride,
                                  const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                                  float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
-                                 fg_stream_t stream) {
+                                 const float* sh_jac, fg_stream_t stream) {
   return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, nullptr, 3, means, quats,
                                scales, opacities, colors, sh_degree, k_stored, n_color, with_depth, n_extra, viewmat,
                                K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                                v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra,
-                               stream);
+                               sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const float* d_quats,
@@ -577,12 +634,12 @@ extern "C" int fg_preprocess_raw_fwd(int N, const float* means, const float* qua
                                      float radius_clip, int tile_size, int antialiased, int32_t* radii,
                                      float* means2d, float* depths, float* conics, float* compensations,
                                      int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
-                                     int32_t* tile_rects, fg_stream_t stream) {
+                                     int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{1, d_quats, d_scales, features_rest}, means, quats, log_scales,
                                opacity_logits, features_dc, sh_degree, k_stored, 3, with_depth, extra, n_extra,
                                viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
                                antialiased, radii, means2d, depths, conics, compensations, tiles_touched, splats,
-                               depth_keys, tile_rects, stream);
+                               depth_keys, tile_rects, sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
@@ -595,12 +652,12 @@ extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* qua
                                      const float* v_conics, float* v_means, float* v_quats, float* v_d_quats,
                                      float* v_log_scales, float* v_d_scales, float* v_opacity_logits,
                                      float* v_features_dc, float* v_features_rest, float* v_extra,
-                                     fg_stream_t stream) {
+                                     const float* sh_jac, fg_stream_t stream) {
   return launch_preprocess_bwd(N, RawForm{1, d_quats, d_scales, features_rest}, v_d_quats, v_d_scales,
                                v_features_rest, nullptr, 3, means, quats, log_scales, opacity_logits, features_dc, sh_degree,
                                k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
                                v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats,
-                               v_log_scales, v_opacity_logits, v_features_dc, v_extra, stream);
+                               v_log_scales, v_opacity_logits, v_features_dc, v_extra, sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, const float* scales,
@@ -610,12 +667,13 @@ extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float
                                           const float* v_splats, const float* v_means2d, int v_means2d_stride,
                                           const float* v_depths, const float* v_conics, float* v_means,
                                           float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
-                                          int v_rgb_floats, float* v_extra, fg_stream_t stream) {
+                                          int v_rgb_floats, float* v_extra, const float* sh_jac, fg_stream_t stream) {
   if (!v_rgb) return FG_ERR_INVALID_ARG;
   return launch_preprocess_bwd(N, RawForm{0, nullptr, nullptr, nullptr}, nullptr, nullptr, nullptr, v_rgb, v_rgb_floats, means, quats,
                                scales, opacities, colors, sh_degree, k_stored, 3, with_depth, n_extra, viewmat, K,
                                width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
-                               v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, nullptr, v_extra, stream);
+                               v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, nullptr, v_extra, sh_jac,
+                               stream);
 }
 
 extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities, const float* colors, int sh_degree,
@@ -632,7 +690,7 @@ extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities,
                      N, fl, RawForm{0, nullptr, nullptr, nullptr}, means, nullptr, nullptr, opacities, colors, extra,
                      viewmat, nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 16, 0, 0, antialiased, const_cast<int32_t*>(radii),
                      const_cast<float*>(means2d), const_cast<float*>(depths), const_cast<float*>(conics),
-                     const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, 0);
+                     const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, nullptr, 0);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -148,6 +148,9 @@ class RasterContext:
         # 1080p (profiles/r01_two_stream_forward.md): no gain -- the 3900-workgroup colour kernel crowds the
         # small sort kernels out (fg_bin_prepare 0.114 -> 0.153 ms) by as much as it hides.
         self.overlap_pack = e.get("FG_OVERLAP_PACK", "0") == "1"
+        # FG_SH_JAC=0: the per-Gaussian backward reads the SH coefficient rows again (192 B per Gaussian) instead of
+        # the 40-byte note (d colour / d direction + clamp mask) the forward leaves for it.
+        self.sh_jacobian = e.get("FG_SH_JAC", "1") != "0"
         # Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
         # written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
         # The kernels overwrite their outputs densely, so the buffer needs no zeroing.
@@ -800,6 +803,7 @@ class _Preprocess(torch.autograd.Function):
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
         depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
+        sh_jac = None  # the forward's note for the backward of the SH colour (include/fgraster.h, fg_preprocess_fwd)
         if ctx.rctx.overlap_pack and len(cfg) > 10 and cfg[10]:
             main = torch.cuda.current_stream()
             side = _side_stream(dev)
@@ -819,14 +823,16 @@ class _Preprocess(torch.autograd.Function):
                     t.record_stream(side)  # the caching allocator must not recycle them under the side kernel
             splats._fg_ready = ready
         else:
+            if sh_degree >= 1 and ctx.rctx.sh_jacobian:
+                sh_jac = torch.empty(N, _lib.SH_JAC_FLOATS, dtype=torch.float32, device=dev)
             _call("fg_preprocess_fwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
                   sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
                   height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
                   _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _ptr(depth_keys),
-                  _ptr(tile_rects), _stream())  # fmt: skip
+                  _ptr(tile_rects), _ptr(sh_jac), _stream())  # fmt: skip
             if depth_keys is not None:
                 splats._fg_bin = (depth_keys, tile_rects)  # for ops.bin_tiles(keys_rects=...)
-        ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii)
+        ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii, sh_jac)
         ctx.set_materialize_grads(False)  # unused depths / conics gradients arrive as None, not as zero tensors
         ctx.cfg = cfg
         ctx.layout = (k_stored, n_color, n_extra)
@@ -840,7 +846,7 @@ class _Preprocess(torch.autograd.Function):
 
     @staticmethod
     def _backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
-        means, quats, scales, opacities, colors, extra, viewmat, K, radii = ctx.saved_tensors
+        means, quats, scales, opacities, colors, extra, viewmat, K, radii, sh_jac = ctx.saved_tensors
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg[:10]
         k_stored, n_color, n_extra = ctx.layout
         N = means.shape[0]
@@ -868,7 +874,8 @@ class _Preprocess(torch.autograd.Function):
                   eps2d, int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
                   _ptr(None if v_depths is None else v_depths.contiguous()),
                   _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
-                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _stream())  # fmt: skip
+                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _ptr(sh_jac),
+                  _stream())  # fmt: skip
             color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, colors)
             return v_means, v_quats, v_scales, v_opac, None, v_extra, None, None, None
         v_colors = _alloc_grad(colors) if colors is not None else None
@@ -877,7 +884,7 @@ class _Preprocess(torch.autograd.Function):
               int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
               _ptr(None if v_depths is None else v_depths.contiguous()),
               _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
-              _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _ptr(v_extra), _stream())  # fmt: skip
+              _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _ptr(v_extra), _ptr(sh_jac), _stream())  # fmt: skip
         return v_means, v_quats, v_scales, v_opac, v_colors, v_extra, None, None, None
 
 
@@ -920,15 +927,18 @@ class _PreprocessRaw(torch.autograd.Function):
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
         depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
+        sh_jac = None
+        if sh_degree >= 1 and ctx.rctx.sh_jacobian:
+            sh_jac = torch.empty(N, _lib.SH_JAC_FLOATS, dtype=torch.float32, device=dev)
         _call("fg_preprocess_raw_fwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
               _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, near, far, radius_clip, tile_size,
               int(antialiased), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles),
-              _ptr(splats), _ptr(depth_keys), _ptr(tile_rects), _stream())  # fmt: skip
+              _ptr(splats), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_jac), _stream())  # fmt: skip
         if depth_keys is not None:
             splats._fg_bin = (depth_keys, tile_rects)
         ctx.save_for_backward(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
-                              features_rest, extra, viewmat, K, radii)  # fmt: skip
+                              features_rest, extra, viewmat, K, radii, sh_jac)  # fmt: skip
         ctx.set_materialize_grads(False)
         ctx.cfg = cfg
         ctx.mark_non_differentiable(radii, tiles)
@@ -942,7 +952,7 @@ class _PreprocessRaw(torch.autograd.Function):
     @staticmethod
     def _backward(ctx, _v_radii, v_means2d, v_depths, v_conics, _v_tiles, v_splats):
         (means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest, extra, viewmat, K,
-         radii) = ctx.saved_tensors  # fmt: skip
+         radii, sh_jac) = ctx.saved_tensors  # fmt: skip
         (width, height, eps2d, near, far, radius_clip, tile_size, antialiased, sh_degree, with_depth) = ctx.cfg
         N = means.shape[0]
         dev = means.device
@@ -968,7 +978,8 @@ class _PreprocessRaw(torch.autograd.Function):
               _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
               _ptr(None if v_depths is None else v_depths.contiguous()),
               _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats), _ptr(v_dq),
-              _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _ptr(v_extra), _stream())  # fmt: skip
+              _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _ptr(v_extra), _ptr(sh_jac),
+              _stream())  # fmt: skip
         return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, v_dc, v_rest, v_extra, None, None, None
 
 

@@ -43,7 +43,8 @@ typedef void* fg_stream_t;
 
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
-#define FG_ABI_VERSION 3
+#define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
+#define FG_ABI_VERSION 4
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -342,7 +343,12 @@ int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d
  *   the splat can reach alpha >= 1/255 at a pixel centre (opacity-aware extents of the ellipse
  *   sigma <= ln(255 o), inflated so that rounding only ever keeps more).  Lists binned from it are
  *   the reference's lists minus entries that contribute to no pixel, in the same order; images and
- *   gradients are unchanged.  (0, 0) when culled or when nothing is reached. */
+ *   gradients are unchanged.  (0, 0) when culled or when nothing is reached.
+ * Optional output for the backward (nullable; SH colours of degree >= 1 only, ignored otherwise):
+ *   sh_jac[N,FG_SH_JAC_FLOATS] f32 = d colour_c / d direction_d before the clamp (9 floats, c-major) and the
+ *   clamp mask (bit c of the 10th float's bits: channel c passed max(. + 0.5, 0)).  Handed to
+ *   fg_preprocess_bwd it replaces the 192-byte coefficient row the backward would read again per
+ *   Gaussian by 40 bytes (same gradients up to the order of fp32 sums).  Rows of culled Gaussians are 0. */
 int fg_preprocess_fwd(int N, const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* colors, int sh_degree, int k_stored,
                       int n_color, int with_depth, const float* extra, int n_extra,
@@ -350,7 +356,7 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       float near_plane, float far_plane, float radius_clip, int tile_size,
                       int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                       float* compensations, int32_t* tiles_touched, float* splats,
-                      uint32_t* depth_keys, int32_t* tile_rects, fg_stream_t stream);
+                      uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream);
 /* The colour + record half of fg_preprocess_fwd on its own: inputs are the projection outputs of
  * fg_project_fwd (radii, means2d, depths, conics; compensations when antialiased).  Splitting the
  * forward this way lets a host run this HBM-bound half on a second stream while the
@@ -368,7 +374,9 @@ int fg_sh_pack_fwd(int N, const float* means, const float* opacities, const floa
  * record array, i.e. v_means2d may simply point at v_splats);
  * v_depths[N] / v_conics[N,3] (nullable) are extra gradients on those outputs.  Every output is
  * overwritten densely (zeros for culled Gaussians): v_means[N,3] v_quats[N,4] v_scales[N,3]
- * v_opacities[N] v_colors (same shape as colors) v_extra[N,n_extra]. */
+ * v_opacities[N] v_colors (same shape as colors) v_extra[N,n_extra].
+ * sh_jac (nullable): the note fg_preprocess_fwd wrote for the same inputs; NULL = the coefficient rows
+ * are read and the clamp mask / direction gradient recomputed from them. */
 int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
                       const float* opacities, const float* colors, int sh_degree, int k_stored,
                       int n_color, int with_depth, int n_extra, const float* viewmat, const float* K,
@@ -376,7 +384,7 @@ int fg_preprocess_bwd(int N, const float* means, const float* quats, const float
                       const float* v_splats, const float* v_means2d, int v_means2d_stride,
                       const float* v_depths, const float* v_conics, float* v_means, float* v_quats,
                       float* v_scales, float* v_opacities, float* v_colors, float* v_extra,
-                      fg_stream_t stream);
+                      const float* sh_jac, fg_stream_t stream);
 
 /* The same two passes on the RAW parameter forms of the reference's gauss_params
  * (freegaussian_model.py:187-196), with the activations its get_outputs applies before the raster
@@ -398,7 +406,7 @@ int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const f
                           float radius_clip, int tile_size, int antialiased, int32_t* radii,
                           float* means2d, float* depths, float* conics, float* compensations,
                           int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
-                          int32_t* tile_rects, fg_stream_t stream);
+                          int32_t* tile_rects, float* sh_jac, fg_stream_t stream);
 int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
                           const float* log_scales, const float* d_scales,
                           const float* opacity_logits, const float* features_dc,
@@ -409,7 +417,7 @@ int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const f
                           const float* v_conics, float* v_means, float* v_quats, float* v_d_quats,
                           float* v_log_scales, float* v_d_scales, float* v_opacity_logits,
                           float* v_features_dc, float* v_features_rest, float* v_extra,
-                          fg_stream_t stream);
+                          const float* sh_jac, fg_stream_t stream);
 
 /* ---- X: factored SH-gradient exchange for view-sharded data parallelism (section 8e) ----------
  * The SH coefficient gradient of one view is rank-1 per Gaussian: v_coeffs[i,k,:] =
@@ -429,7 +437,7 @@ int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, co
                                const float* v_splats, const float* v_means2d, int v_means2d_stride,
                                const float* v_depths, const float* v_conics, float* v_means,
                                float* v_quats, float* v_scales, float* v_opacities, float* v_rgb,
-                               int v_rgb_floats, float* v_extra, fg_stream_t stream);
+                               int v_rgb_floats, float* v_extra, const float* sh_jac, fg_stream_t stream);
 int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
                           const float* payload, int64_t view_stride, int payload_floats, float scale,
                           float* v_coeffs, fg_stream_t stream);

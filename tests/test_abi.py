@@ -79,7 +79,7 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_bin_prepare_rects(4, *(n * 3), 16, 4, 4, *(n * 4), 0, None) == -1
     # raw preprocess is SH-only
     assert lib.fg_preprocess_raw_fwd(4, *(n * 8), -1, 16, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
-                                     *(n * 10)) == -1  # fmt: skip
+                                     *(n * 11)) == -1  # fmt: skip
     assert lib.fg_bin_prepare_keys(4, *(n * 7), 0, None) == -1  # keys / rectangles / outputs missing
     assert lib.fg_bin_prepare_keys(0, *(n * 7), 0, None) == 0
     # composite raster: clamp count within the channels, mask required
@@ -87,7 +87,7 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
 
 
 def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):
-    """ABI version 3: the library reads no environment variable; the launch policy is an fg_raster_config the
+    """ABI version 3 onwards: the library reads no environment variable; the launch policy is an fg_raster_config the
     host fills (ops.launch_policy_from_env maps the FG_RASTER_* variables of rounds 1-2 onto it)."""
     import ctypes
 

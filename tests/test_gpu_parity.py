@@ -885,6 +885,37 @@ def test_fused_path_equals_stagewise_path(render_mode, sh_degree, rmode, extra):
     assert rel_l2(m0, m1) < 1e-5 and rel_l2(ab0, ab1) < 1e-5
 
 
+@pytest.mark.parametrize("sh_degree", [1, 2, 3])
+@pytest.mark.parametrize("raw", [False, True])
+def test_backward_from_the_forwards_sh_note_equals_the_backward_from_the_coefficient_rows(sh_degree, raw):
+    """fg_preprocess_fwd leaves d colour / d direction and the clamp mask (40 B per Gaussian, `sh_jac`) so that
+    fg_preprocess_bwd need not read the 192-byte coefficient rows again: same images, same gradients as the
+    backward that recomputes both from the rows (FG_SH_JAC=0 / RasterContext.sh_jacobian = False)."""
+    sc = _scene(n=12001, w=176, h=128, seed=23)  # (an odd count: the last workgroup's slab takes the scalar path)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+    outs = []
+    for note in (True, False):
+        ctx = ops.RasterContext()
+        ctx.sh_jacobian = note
+        if raw:
+            from freegaussian_amd.rasterization import rasterize_gauss_params
+
+            t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales.log(), torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                                                          sc.colors[:, 0].contiguous(), sc.colors[:, 1:].contiguous())]  # fmt: skip
+            r = rasterize_gauss_params(*t, vm, K, sc.width, sc.height, sh_degree=sh_degree, ctx=ctx)[0]
+        else:
+            t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+            r = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=sh_degree, packed=False, absgrad=True, ctx=ctx)[0]
+        (r.reshape(vr.shape) * vr).sum().backward()
+        outs.append((r.detach(), [x.grad for x in t]))
+    (r0, g0), (r1, g1) = outs
+    assert torch.equal(r0, r1)
+    for x, y in zip(g0, g1):
+        assert rel_l2(x, y) < 2e-6  # (the order of fp32 sums differs: sum over bases first / over channels first)
+    assert float(g0[0].abs().max()) > 0 and float(g0[-1].abs().max()) > 0
+
+
 def test_direct_grad_buffers_fill_the_flat_gradient():
     """viewdp.FlatGaussianParams.direct_grads(): the fused backward writes straight into the flat
     all-reduce buffer (no AccumulateGrad add, no zeroing) and matches ordinary autograd."""
