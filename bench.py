@@ -712,11 +712,9 @@ def main(argv=None):
             "drop (splat, tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
             "counts_are_for_view": view,
             "binning": {
-                "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 16-byte entry per "
-                "(Gaussian, 2x2-tile supertile) scattered inside the XCD's band -> one LDS sort per supertile by (depth "
-                "bits, id), four tile lists read off it; 6 launches",
-                "banded": "banded (csrc/tilebin.hip): count -> scan -> one pair per (Gaussian, tile) scattered inside "
-                "the XCD's band -> one LDS sort per tile; 5 launches",
+                "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 8-byte element per "
+                "(Gaussian, 2x2-tile supertile) scattered into the supertile's segment -> one LDS sort per supertile by "
+                "(depth bits, id), four tile lists read off it; 7 launches",
                 "depthfirst": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I; 26 launches",
             }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",

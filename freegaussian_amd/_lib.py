@@ -39,11 +39,6 @@ SIGNATURES = {
     "fg_bin_emit_sort": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t, P]),
     "fg_bin_emit_sort_capacity": (c_int, [c_int, c_int64, P, P, P, P, P, c_int, c_int, c_int, P, P, P, P, c_size_t,
                                           P]),
-    "fg_tilebin_supported": (c_int, [c_int, c_int]),
-    "fg_tilebin_count_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "fg_tilebin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
-    "fg_tilebin_fill_workspace_bytes": (c_size_t, [c_int64]),
-    "fg_tilebin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
     "fg_stbin_supported": (c_int, [c_int, c_int, c_int]),
     "fg_stbin_count_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fg_stbin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),

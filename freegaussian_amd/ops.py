@@ -127,11 +127,11 @@ class RasterContext:
         # rebuilt on demand from the radius boxes.
         self.tight_rects = e.get("FG_TIGHT_RECTS", "1") != "0"
         # FG_BINNING = supertile (default: fg_stbin_*, count / scatter per 2x2-tile supertile / one sort per
-        # supertile) | banded (fg_tilebin_*: the same per tile) | depthfirst (rounds 1-2: fg_bin_prepare_keys +
-        # fg_bin_emit_sort, also the fallback beyond fg_*bin_supported).  Identical lists.
+        # supertile) | depthfirst (rounds 1-2: fg_bin_prepare_keys + fg_bin_emit_sort, also the fallback beyond
+        # fg_stbin_supported).  Identical lists.
         self.binning = e.get("FG_BINNING", "supertile")
-        if self.binning not in ("supertile", "banded", "depthfirst"):
-            raise ValueError(f"FG_BINNING={self.binning!r}: supertile | banded | depthfirst")
+        if self.binning not in ("supertile", "depthfirst"):
+            raise ValueError(f"FG_BINNING={self.binning!r}: supertile | depthfirst")
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -481,9 +481,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     rctx = current()
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     if keys_rects is not None and rctx.binning == "supertile" and lib.fg_stbin_supported(N, tile_w, tile_h):
-        return _bin_tiles_banded(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
-    if keys_rects is not None and rctx.binning != "depthfirst" and lib.fg_tilebin_supported(tile_w, tile_h):
-        return _bin_tiles_banded(rctx, "fg_tilebin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+        return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -574,9 +572,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _bin_tiles_banded(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
-    """Banded binning, same contract as ``bin_tiles``: ``abi`` = "fg_stbin" (csrc/stbin.hip: per 2x2-tile
-    supertile) or "fg_tilebin" (csrc/tilebin.hip: per tile); ``<abi>_count`` then ``<abi>_fill``.
+def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
+    """Supertile binning (csrc/stbin.hip), same contract as ``bin_tiles``: ``fg_stbin_count`` then ``fg_stbin_fill``.
     The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
     from the previous calls of this shape and refilled exactly if the list turned out longer.  The ranges
     handed to the consumers (``list_offsets``, the returned offsets tensor) are the tile ranges when the list

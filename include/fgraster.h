@@ -142,36 +142,22 @@ int fg_bin_prepare_rects(int N, const float* depths, const int32_t* radii, const
 int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, int32_t* order,
                         int64_t* cum_tiles, int32_t* rects_sorted, int64_t* count_out, void* workspace,
                         size_t workspace_bytes, fg_stream_t stream);
-/* ---- K3+K4, banded form (what rasterization() runs when the fused preprocess pass supplied keys and
+/* ---- K3+K4, supertile form (what rasterization() runs when the fused preprocess pass supplied keys and
  * rectangles; identical lists) -------------------------------------------------------------------------
- * Count per tile -> scan -> scatter into per-tile segments -> every tile's segment sorted by (depth
- * bits, Gaussian id) in LDS: 5 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort.
- * Every XCD (workgroup id % 8) handles one band of tile rows end to end, so the scattered stores of a
- * tile's segment meet in one L2 (csrc/tilebin.hip).  tile_rects / depth_keys: the optional outputs of
- * fg_preprocess_fwd.  fg_tilebin_count writes tile_offsets[T + 1] (exact, independent of any capacity)
- * and, if count_out is not NULL, the list length with system scope (pinned host memory).
- * fg_tilebin_fill writes flatten_ids[0 .. tile_offsets[T]) and list_offsets[T + 1] = tile_offsets -- or, when
- * the list is longer than `capacity`, no ids at all and list_offsets = 0 (empty lists: consumers enqueued
- * speculatively behind the call walk nothing; the host then repeats the call with exact buffers, the count
- * workspace stays valid).  Consumers of flatten_ids read list_offsets, not tile_offsets.
+ * Count per tile and per supertile (2 x 2 tiles) -> scans -> one 8-byte element (depth bits << 32 | id << 4 |
+ * which of the four tiles) scattered per (Gaussian, supertile) pair into the supertile's segment -> every
+ * segment sorted ONCE by (depth bits, Gaussian id) in LDS and the four tile lists read off the sorted run:
+ * 7 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
+ * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
+ * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
+ * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, the list length
+ * with system scope (pinned host memory).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
+ * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
+ * list_offsets = 0 (empty lists: consumers enqueued speculatively behind the call walk nothing; the host then
+ * repeats the call with exact buffers, the count workspace stays valid).  Consumers of flatten_ids read
+ * list_offsets, not tile_offsets.  N < 2^28; fg_stbin_supported = 0 for tile grids wider than ~2700 tiles
+ * (callers then take fg_bin_prepare_keys + fg_bin_emit_sort).
  * Replaces the binning + sort implied by tile_size=16 at freegaussian_model.py:806,857. */
-int fg_tilebin_supported(int tile_w, int tile_h);
-size_t fg_tilebin_count_workspace_bytes(int N, int tile_w, int tile_h);
-int fg_tilebin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
-                     int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
-size_t fg_tilebin_fill_workspace_bytes(int64_t capacity);
-int fg_tilebin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
-                    int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
-                    int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
-                    fg_stream_t stream);
-
-/* ---- K3+K4, supertile form (the default of rasterization(); identical lists) -------------------------------
- * The banded binning one level coarser (csrc/stbin.hip): a supertile is 2 x 2 tiles; a Gaussian is scattered
- * once per supertile its rectangle touches (16-byte entry: depth bits, id, rectangle), every supertile's
- * entries are sorted once by (depth bits, id) and the four tile lists are read off the sorted run.  2.5x fewer
- * scattered entries and sorted elements than per tile on the 1M / 1080p scene.  Same contract as fg_tilebin_*
- * (count: tile_offsets + list length; fill: flatten_ids + list_offsets, nothing but empty ranges when the list
- * is longer than `capacity`).  N < 2^28. */
 int fg_stbin_supported(int N, int tile_w, int tile_h);
 size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
 int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,

@@ -5,12 +5,12 @@ tag=${1:-bin}
 out=gpurun_out/$tag
 mkdir -p $out
 export TMPDIR=/tmp
-sel='-k "banded or binning or footprint or cfg1 or full_pipeline or speculative or redoes or 65536 or graph"'
+sel='-k "supertile or binning or footprint or cfg1 or full_pipeline or speculative or redoes or 65536 or graph"'
 [ "$2" = "full" ] && sel=""
 eval FG_PARITY_REPORT=$out/margins.jsonl timeout 1200 python -m pytest tests -m gpu -q --timeout 600 $sel 2>&1 | grep -v "^  File\|pluggy" | tail -40 > $out/pytest.log
 tail -12 $out/pytest.log
 timeout 300 python bench.py --steps 30 --warmup 10 --no-cpu-baseline --no-graph > /dev/null 2>&1  # (the first process on a fresh box runs slow)
-for b in depthfirst banded supertile supertile; do
+for b in depthfirst supertile supertile; do
   FG_BINNING=$b timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph > $out/bench_$b.json 2> $out/bench_$b.err
   python - <<PY
 import json

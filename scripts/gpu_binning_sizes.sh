@@ -6,7 +6,7 @@ out=gpurun_out/$tag
 mkdir -p $out
 for cfg in "3000000 1920 1080" "2000000 2560 1440" "4000000 3840 2160"; do
   set -- $cfg
-  for b in depthfirst banded supertile; do
+  for b in depthfirst supertile; do
     FG_BINNING=$b timeout 400 python bench.py --steps 20 --warmup 5 --settle-s 0.3 --no-cpu-baseline --no-graph --n-gauss $1 --width $2 --height $3 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms']

@@ -33,7 +33,7 @@ find $out -name "*counter_collection.csv" -size +1M -delete
 for sz in "100000 50 480 270" "300000 50 960 540" "1000000 30 1920 1080"; do timeout 300 python scripts/model_step_bench.py $sz 2>/dev/null | tr -d '\n ' > $out/model_step_$(echo $sz | tr ' ' '_').json; cut -c1-260 $out/model_step_$(echo $sz | tr ' ' '_').json; echo; done
 timeout 600 python scripts/half_strip_estimate.py 2>/dev/null | tee $out/half_strip_estimate.txt | tail -4
 bash scripts/gpu_sizes.sh 2>/dev/null | tee $out/sizes.txt
-for b in depthfirst banded supertile depthfirst banded supertile; do
+for b in depthfirst supertile depthfirst supertile; do
   FG_BINNING=$b timeout 300 python bench.py --steps 50 --warmup 10 --no-cpu-baseline --no-graph 2>/dev/null | python3 -c "
 import json,sys; d=json.loads(sys.stdin.read()); print('$b', round(d['value'],1), round(d['ms_per_step'],4), d['stage_ms'])" | tee -a $out/binning_ab.txt
 done

@@ -312,13 +312,13 @@ def test_speculative_binning_capacity_and_overflow():
     ops.default_context.speculative_binning = was
 
 
-def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
-    """The same keys / rectangles through both binning paths; returns the banded lists."""
+def _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
+    """The same keys / rectangles through both binning paths; returns the supertile path's lists."""
     tw, th = (W + 15) // 16, (H + 15) // 16
     z = torch.zeros(N, device=DEV)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     outs = []
-    for mode in ("depthfirst", "banded", "supertile"):
+    for mode in ("depthfirst", "supertile"):
         monkeypatch.setattr(ops.default_context, "binning", mode)
         ops.default_context.isect_capacity.clear()
         runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
@@ -329,10 +329,9 @@ def _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False):
         for _, f, o in runs[1:]:
             assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
         outs.append(runs[0])
-    (_, f0, o0), (_, f1, o1), (_, f2, o2) = outs
-    assert torch.equal(o1, o0) and torch.equal(o2, o0), "tile ranges differ"
-    assert torch.equal(f1, f0), "lists differ (banded)"
-    assert torch.equal(f2, f0), "lists differ (supertile)"
+    (_, f0, o0), (_, f2, o2) = outs
+    assert torch.equal(o2, o0), "tile ranges differ"
+    assert torch.equal(f2, f0), "lists differ"
     return f2, o2
 
 
@@ -341,13 +340,13 @@ def _pack_rects(x0, y0, w, h):
 
 
 @pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "one", "all_culled", "few_rows", "2160p"])
-def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
+def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     """csrc/stbin.hip (count -> scan -> scatter per supertile -> one sort per supertile, four tile lists read off
-    it) and csrc/tilebin.hip (the same per tile) against the depth-first binning on the same depth keys and
-    footprint rectangles: `torch.equal` lists and ranges.
+    it) against the depth-first binning on the same depth keys and footprint rectangles: `torch.equal` lists and
+    ranges.
     Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
     tiles with more entries than fit the small LDS sort (the large one), than fit any (the pass through global
-    memory); one Gaussian; nothing visible; an image with fewer tile rows than XCD bands; 32 400 tiles."""
+    memory); one Gaussian; nothing visible; an image of three tile rows; 32 400 tiles (the count kernel's grids in four passes)."""
     g = torch.Generator().manual_seed(31)
     W, H = 640, 400
     if case == "scene":
@@ -356,11 +355,11 @@ def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
         _, _, _, _, _, splats = ops.preprocess(*t, None, sc.viewmats[0].to(DEV), sc.Ks[0].to(DEV), W, H, sh_degree=3)
         keys, rects = splats._fg_bin
         N = 50000
-        f, o = _banded_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=True)
+        f, o = _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=True)
         assert f.numel() > 50_000
         return
     if case == "few_rows":
-        W, H = 640, 40  # 3 tile rows: five of the eight bands are empty
+        W, H = 640, 40  # 3 tile rows, 2 supertile rows (the lower one half outside the image)
     if case == "2160p":
         W, H = 3840, 2160
     tw, th = (W + 15) // 16, (H + 15) // 16
@@ -390,7 +389,7 @@ def test_banded_binning_equals_depth_first_binning(case, monkeypatch):
         w[cull], h[cull] = 0, 0
         keys[cull] = -1  # 0xFFFFFFFF
     rects = _pack_rects(x0, y0, w, h).to(DEV)
-    f, o = _banded_vs_depth_first(N, W, H, rects, keys.to(DEV), monkeypatch)
+    f, o = _supertile_vs_depth_first(N, W, H, rects, keys.to(DEV), monkeypatch)
     # ... and against the rule itself: per tile, ids ordered by (depth bits, id)
     area = (w * h).long()
     assert int(o[-1]) == int(area.sum()) == f.numel()
