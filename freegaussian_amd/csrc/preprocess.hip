@@ -86,21 +86,62 @@ __device__ __forceinline__ Activated load_activated(const RawForm& raw, int i, c
   return a;
 }
 
-// raw form: SH coefficient rows of a workgroup, split in two arrays -> LDS rows [dc | rest]
-__device__ __forceinline__ void coeffs_to_lds(float* lds, const RawForm& raw, const float* __restrict__ colors,
-                                              int row0, int nrows, int k_stored, int kk,
-                                              const uint8_t* row_live = nullptr) {
-  slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3, nrows, 3, 3);  // features_dc: 12 B rows, always fetched
+// The coefficient rows of a 64-Gaussian workgroup come through LDS in two HALVES of 32 rows: 6.3 KB of LDS per
+// workgroup instead of 12.5 and 24 instead of 48 registers of loads in flight per lane -- these passes run as
+// fast as a CU holds wavefronts (forward 87 / 100 / 117 us at 12 / 9 / 7 workgroups per CU,
+// profiles/r03_preprocess_occupancy.md).  Half h: rows 32 h .. 32 h + 31 of the workgroup at LDS rows 0 .. 31;
+// lanes 32 h .. 32 h + 31 then evaluate their rows (the other half idles through that stretch).
+// Raw form: the row is split in two arrays, features_dc [N,3] (`colors`, base 0) and features_rest
+// [N,k_stored-1,3] (bases 1..).
+constexpr int HROWS = BLOCK / 2;
+static_assert(HROWS * ROW >= BLOCK * RSTRIDE && HROWS * ROW >= BLOCK * JSTRIDE, "record / note slabs reuse the LDS rows");
+#ifndef FG_PRE_FWD_WAVES
+#define FG_PRE_FWD_WAVES 6
+#endif
+#ifndef FG_PRE_BWD_WAVES
+#define FG_PRE_BWD_WAVES 4
+#endif
+__device__ __forceinline__ void stage_coeffs_half(float* lds, const FeatLayout& fl, const RawForm& raw,
+                                                  const float* __restrict__ colors, int row0, int nrows, int kk, int h,
+                                                  const uint8_t* row_live) {
+  const int r0 = row0 + h * HROWS, nr = min(HROWS, nrows - h * HROWS);
+  if (nr <= 0) return;
+  const uint8_t* live = row_live ? row_live + h * HROWS : nullptr;
+  if (!raw.enabled) {
+    slab_to_lds_at<ROW, HROWS>(lds, 0, colors + (size_t)r0 * 3 * fl.k_stored, nr, 3 * fl.k_stored, 3 * kk, live);
+    return;
+  }
+  slab_to_lds_at<ROW, HROWS>(lds, 0, colors + (size_t)r0 * 3, nr, 3, 3);  // features_dc: 12 B rows, always fetched
   if (kk > 1)
-    slab_to_lds_at(lds, 3, raw.features_rest + (size_t)row0 * 3 * (k_stored - 1), nrows, 3 * (k_stored - 1),
-                   3 * (kk - 1), row_live);
+    slab_to_lds_at<ROW, HROWS>(lds, 3, raw.features_rest + (size_t)r0 * 3 * (fl.k_stored - 1), nr, 3 * (fl.k_stored - 1),
+                               3 * (kk - 1), live);
 }
-// all coefficient rows of the workgroup -> LDS, skipping rows whose flag in row_live is 0
-__device__ __forceinline__ void stage_coeffs(float* lds, const FeatLayout& fl, const RawForm& raw,
-                                             const float* __restrict__ colors, int row0, int nrows, int kk,
-                                             const uint8_t* row_live) {
-  if (raw.enabled) coeffs_to_lds(lds, raw, colors, row0, nrows, fl.k_stored, kk, row_live);
-  else slab_to_lds_at(lds, 0, colors + (size_t)row0 * 3 * fl.k_stored, nrows, 3 * fl.k_stored, 3 * kk, row_live);
+
+// What the SH colour and its backward need from a Gaussian's coefficient row: the colour before + 0.5 / clamp, and
+// (want_jac) d colour_c / d direction_d.
+struct ShSums {
+  float col[3];
+  float jac[9];
+};
+__device__ __forceinline__ void sh_row_sums(ShSums& a, const float* row, int degree, int kk, float dx, float dy, float dz,
+                                            bool want_jac) {
+  float basis[16];
+  sh_basis(degree, dx, dy, dz, basis);
+  sh_dot(basis, row, kk, a.col[0], a.col[1], a.col[2]);
+  if (want_jac) {
+    float bx[16], by[16], bz[16];
+    sh_basis_grad(degree, dx, dy, dz, bx, by, bz);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float jx = 0.f, jy = 0.f, jz = 0.f;
+#pragma unroll
+      for (int k = 1; k < 16; ++k)
+        if (k < kk) {
+          jx += bx[k] * row[3 * k + c]; jy += by[k] * row[3 * k + c]; jz += bz[k] * row[3 * k + c];
+        }
+      a.jac[3 * c] = jx; a.jac[3 * c + 1] = jy; a.jac[3 * c + 2] = jz;
+    }
+  }
 }
 
 // Shrink the tile range [t0, t1) to the tiles whose pixel centres the extent [g - e, g + e] reaches
@@ -123,7 +164,7 @@ __device__ __forceinline__ void tighten_tile_range(float g, float e, float ts, i
 // (written by fg_project_fwd); only the colour + record part runs -- the half of the forward that
 // can overlap the latency-bound binning on a second stream (fg_sh_pack_fwd).
 template <bool PACK_ONLY>
-__global__ void __launch_bounds__(BLOCK)
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(FG_PRE_FWD_WAVES)))
 preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict__ means, const float* __restrict__ quats,
                       const float* __restrict__ scales, const float* __restrict__ opacities,
                       const float* __restrict__ colors, const float* __restrict__ extra,
@@ -134,7 +175,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
                       int32_t* __restrict__ tiles_touched, float* __restrict__ splats,
                       uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects, float* __restrict__ sh_jac,
                       int skip_culled) {
-  __shared__ float lds[BLOCK * ROW];  // coefficient slab, then the record slab, then the Jacobian slab
+  __shared__ float lds[HROWS * ROW];  // half the coefficient slab at a time, then the record slab, then the Jacobian slab
   __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
@@ -142,7 +183,7 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
   // skip_culled: the coefficient rows are fetched AFTER the projection, visible Gaussians only (a
   // culled Gaussian's row is 192 of its 236 bytes); otherwise up front, under the projection
-  if (kk > 0 && !skip_culled) stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, nullptr);
+  if (kk > 0 && !skip_culled) stage_coeffs_half(lds, fl, raw, colors, row0, nrows, kk, 0, nullptr);
 
   // ---- K1 -------------------------------------------------------------------------------------
   bool ok = false;
@@ -229,44 +270,37 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   if (kk > 0 && skip_culled) {
     row_live[threadIdx.x] = ok;
     __syncthreads();
-    stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, row_live);
+    stage_coeffs_half(lds, fl, raw, colors, row0, nrows, kk, 0, row_live);
   }
-  if (kk > 0) __syncthreads();
+  const bool want_jac = sh_jac && kk > 1;
+  ShSums sums;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) sums.col[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) sums.jac[c] = 0.f;
+  if (kk > 0) {
+    float dx = 0.f, dy = 0.f, dz = 1.f;
+    if (ok) {
+      float inv;
+      view_dir(viewmat, mx, my, mz, dx, dy, dz, inv);
+    }
+    const float* row = lds + (threadIdx.x & (HROWS - 1)) * ROW;
+    __syncthreads();  // first half staged
+    if (ok && threadIdx.x < HROWS) sh_row_sums(sums, row, fl.sh_degree, kk, dx, dy, dz, want_jac);
+    __syncthreads();
+    stage_coeffs_half(lds, fl, raw, colors, row0, nrows, kk, 1, skip_culled ? row_live : nullptr);
+    __syncthreads();
+    if (ok && threadIdx.x >= HROWS) sh_row_sums(sums, row, fl.sh_degree, kk, dx, dy, dz, want_jac);
+  }
   if (ok) {
     int c0 = 6;
     if (kk > 0) {
-      float cx, cy, cz;
-      camera_position(viewmat, cx, cy, cz);
-      float dx = mx - cx, dy = my - cy, dz = mz - cz;
-      const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-      dx *= inv; dy *= inv; dz *= inv;
-      float basis[16];
-      sh_basis(fl.sh_degree, dx, dy, dz, basis);
-      const float* row = lds + threadIdx.x * ROW;
-      float r = 0.f, g = 0.f, b = 0.f;
-#pragma unroll
-      for (int k = 0; k < 16; ++k) {
-        if (k < kk) {
-          r += basis[k] * row[3 * k];
-          g += basis[k] * row[3 * k + 1];
-          b += basis[k] * row[3 * k + 2];
-        }
-      }
+      const float r = sums.col[0], g = sums.col[1], b = sums.col[2];
       rec[6] = fmaxf(r + 0.5f, 0.f); rec[7] = fmaxf(g + 0.5f, 0.f); rec[8] = fmaxf(b + 0.5f, 0.f);
       c0 = 9;
-      if (sh_jac && kk > 1) {
-        float bx[16], by[16], bz[16];
-        sh_basis_grad(fl.sh_degree, dx, dy, dz, bx, by, bz);
+      if (want_jac) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-          float jx = 0.f, jy = 0.f, jz = 0.f;
-#pragma unroll
-          for (int k = 1; k < 16; ++k)
-            if (k < kk) {
-              jx += bx[k] * row[3 * k + c]; jy += by[k] * row[3 * k + c]; jz += bz[k] * row[3 * k + c];
-            }
-          jac[3 * c] = jx; jac[3 * c + 1] = jy; jac[3 * c + 2] = jz;
-        }
+        for (int c = 0; c < 9; ++c) jac[c] = sums.jac[c];
         // (the comparison the backward made on its recomputed colours)
         jac[9] = __int_as_float((int)(r + 0.5f > 0.f) | ((int)(g + 0.5f > 0.f) << 1) | ((int)(b + 0.5f > 0.f) << 2));
       }
@@ -304,7 +338,10 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
   }
 }
 
-__global__ void __launch_bounds__(BLOCK)
+// NOTE: the forward's sh_jac is given (sh_degree >= 1) -- the coefficient rows are not read; otherwise the same sums
+// are recomputed from the rows, in two windows like the forward.
+template <bool NOTE>
+__global__ void __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(NOTE ? FG_PRE_BWD_WAVES : 3)))
 preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d_quats,
                       float* __restrict__ v_d_scales, float* __restrict__ v_features_rest,
                       float* __restrict__ v_rgb, int v_rgb_floats,
@@ -317,34 +354,44 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
                       const float* __restrict__ v_conics, float* __restrict__ v_means, float* __restrict__ v_quats,
                       float* __restrict__ v_scales, float* __restrict__ v_opacities, float* __restrict__ v_colors,
                       float* __restrict__ v_extra, const float* __restrict__ sh_jac, int skip_culled) {
-  __shared__ float lds[BLOCK * ROW];       // coefficient slab in, v_coeffs slab out
+  __shared__ float lds[HROWS * ROW];   // half the coefficient slab in (no note) / half the v_coeffs slab out at a time
   __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
   const int i = row0 + threadIdx.x;
   const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
   const bool active = (i < N) && radii[i] > 0;
-  // with the forward's Jacobian note the coefficient rows are not read at all
-  if (kk > 1 && !sh_jac) {
+  // the unit view direction the SH basis is evaluated at (also sent along by the factored exchange); with the
+  // forward's note it is not needed before the projection backward and is computed behind it (registers)
+  float sh_dx = 0.f, sh_dy = 0.f, sh_dz = 1.f, sh_inv = 0.f;
+  auto view_direction = [&]() { view_dir(viewmat, means[3 * i], means[3 * i + 1], means[3 * i + 2], sh_dx, sh_dy, sh_dz, sh_inv); };
+  if (!NOTE && active && kk > 0) view_direction();
+  ShSums sums;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) sums.col[c] = 0.f;
+#pragma unroll
+  for (int c = 0; c < 9; ++c) sums.jac[c] = 0.f;
+  if (!NOTE && kk > 1) {
     if (skip_culled) {  // only the visible Gaussians' coefficient rows are read back
       row_live[threadIdx.x] = active;
       __syncthreads();
     }
-    stage_coeffs(lds, fl, raw, colors, row0, nrows, kk, skip_culled ? row_live : nullptr);
+    const float* row = lds + (threadIdx.x & (HROWS - 1)) * ROW;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (h) __syncthreads();  // everyone is done with the first half
+      stage_coeffs_half(lds, fl, raw, colors, row0, nrows, kk, h, skip_culled ? row_live : nullptr);
+      __syncthreads();
+      if (active && (int)(threadIdx.x / HROWS) == h) sh_row_sums(sums, row, fl.sh_degree, kk, sh_dx, sh_dy, sh_dz, true);
+    }
   }
-  __syncthreads();
 
   float g_m[3] = {0.f, 0.f, 0.f}, g_q[4] = {0.f, 0.f, 0.f, 0.f}, g_s[3] = {0.f, 0.f, 0.f};
   float g_o = 0.f;
   float vr = 0.f, vg = 0.f, vb = 0.f;
-  float sh_dx = 0.f, sh_dy = 0.f, sh_dz = 0.f;  // unit view direction the SH basis was evaluated at
-  float basis[16];
-#pragma unroll
-  for (int k = 0; k < 16; ++k) basis[k] = 0.f;
   float rec[REC];
 #pragma unroll
   for (int c = 0; c < REC; ++c) rec[c] = 0.f;
-  Activated a;
   if (active) {
     // the lane's own 64-byte gradient record, four 16-byte loads (the lines are shared by the four
     // loads and served from cache after the first; staging them through LDS as well would cost
@@ -355,118 +402,10 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       const float4 v = rp[q4];
       rec[4 * q4] = v.x; rec[4 * q4 + 1] = v.y; rec[4 * q4 + 2] = v.z; rec[4 * q4 + 3] = v.w;
     }
-    const Cam cam = load_cam(viewmat, K);
-    const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
-    a = load_activated(raw, i, quats, scales, opacities);
-    const float s[3] = {a.s[0], a.s[1], a.s[2]};
-    const Fwd f = project_core(cam, mx, my, mz, a.q[0], a.q[1], a.q[2], a.q[3], s[0], s[1], s[2], width, height,
-                               eps2d);
-
-    // feature gradients: [colour | depth | extra] start at record slot 8
-    const int ncol = kk > 0 ? 3 : fl.n_color;
-    float v_depth = v_depths ? v_depths[i] : 0.f;
-#pragma unroll
-    for (int c = 0; c < FG_MAX_CHANNELS; ++c)
-      if (fl.with_depth && c == ncol) v_depth += rec[8 + c];
-
-    // ---- K8 -----------------------------------------------------------------------------------
-    if (kk > 0) {
-      float cx, cy, cz;
-      camera_position(viewmat, cx, cy, cz);
-      const float ux = mx - cx, uy = my - cy, uz = mz - cz;
-      const float inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
-      const float dx = ux * inv, dy = uy * inv, dz = uz * inv;
-      sh_dx = dx; sh_dy = dy; sh_dz = dz;
-      sh_basis(fl.sh_degree, dx, dy, dz, basis);
-      const float* crow = lds + threadIdx.x * ROW;
-      if (kk > 1 && sh_jac) {
-        // the lane's own 40-byte note: five 8-byte loads (the lines are shared by neighbouring lanes)
-        const float2* jp = reinterpret_cast<const float2*>(sh_jac + (size_t)i * JAC);
-        float j[JAC];
-#pragma unroll
-        for (int q2 = 0; q2 < JAC / 2; ++q2) {
-          const float2 v = jp[q2];
-          j[2 * q2] = v.x; j[2 * q2 + 1] = v.y;
-        }
-        const int m = __float_as_int(j[9]);
-        vr = (m & 1) ? rec[8] : 0.f;
-        vg = (m & 2) ? rec[9] : 0.f;
-        vb = (m & 4) ? rec[10] : 0.f;
-        const float vdx = vr * j[0] + vg * j[3] + vb * j[6];
-        const float vdy = vr * j[1] + vg * j[4] + vb * j[7];
-        const float vdz = vr * j[2] + vg * j[5] + vb * j[8];
-        const float dp = vdx * dx + vdy * dy + vdz * dz;
-        g_m[0] = (vdx - dp * dx) * inv;
-        g_m[1] = (vdy - dp * dy) * inv;
-        g_m[2] = (vdz - dp * dz) * inv;
-      } else {
-      // recompute the clamp mask: colour = max(sh + 0.5, 0)
-      float cr = 0.f, cg = 0.f, cb = 0.f;
-      if (kk > 1) {
-#pragma unroll
-        for (int k = 0; k < 16; ++k)
-          if (k < kk) {
-            cr += basis[k] * crow[3 * k]; cg += basis[k] * crow[3 * k + 1]; cb += basis[k] * crow[3 * k + 2];
-          }
-      } else {
-        const float* c0p = colors + (size_t)i * 3 * (raw.enabled ? 1 : fl.k_stored);
-        cr = basis[0] * c0p[0]; cg = basis[0] * c0p[1]; cb = basis[0] * c0p[2];
-      }
-      vr = (cr + 0.5f > 0.f) ? rec[8] : 0.f;
-      vg = (cg + 0.5f > 0.f) ? rec[9] : 0.f;
-      vb = (cb + 0.5f > 0.f) ? rec[10] : 0.f;
-      if (kk > 1) {
-        float bx[16], by[16], bz[16];
-        sh_basis_grad(fl.sh_degree, dx, dy, dz, bx, by, bz);
-        float vdx = 0.f, vdy = 0.f, vdz = 0.f;
-#pragma unroll
-        for (int k = 1; k < 16; ++k)
-          if (k < kk) {
-            const float sdot = vr * crow[3 * k] + vg * crow[3 * k + 1] + vb * crow[3 * k + 2];
-            vdx += bx[k] * sdot; vdy += by[k] * sdot; vdz += bz[k] * sdot;
-          }
-        const float dp = vdx * dx + vdy * dy + vdz * dz;
-        g_m[0] = (vdx - dp * dx) * inv;
-        g_m[1] = (vdy - dp * dy) * inv;
-        g_m[2] = (vdz - dp * dz) * inv;
-      }
-      }
-    }
-    // ---- opacity / compensation -----------------------------------------------------------------
-    float vcomp = 0.f;
-    if (antialiased) {
-      g_o = rec[2] * f.comp;
-      vcomp = rec[2] * a.o;
-    } else {
-      g_o = rec[2];
-    }
-    // ---- K7 -------------------------------------------------------------------------------------
-    const float vca = rec[3] + (v_conics ? v_conics[3 * i] : 0.f);
-    const float vcb = rec[4] + (v_conics ? v_conics[3 * i + 1] : 0.f);
-    const float vcc = rec[5] + (v_conics ? v_conics[3 * i + 2] : 0.f);
-    project_backward(cam, f, s, eps2d, v_means2d[(size_t)m2_stride * i], v_means2d[(size_t)m2_stride * i + 1],
-                     v_depth, vca, vcb, vcc,
-                     antialiased != 0, vcomp, g_m, g_q, g_s);
-    if (raw.enabled) {
-      // chain rule through the activations; the deltas receive the activated-value gradients as is
-      if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
-      if (v_d_scales) { v_d_scales[3 * i] = g_s[0]; v_d_scales[3 * i + 1] = g_s[1]; v_d_scales[3 * i + 2] = g_s[2]; }
-      const float dp = g_q[0] * a.qn[0] + g_q[1] * a.qn[1] + g_q[2] * a.qn[2] + g_q[3] * a.qn[3];
-#pragma unroll
-      for (int c = 0; c < 4; ++c) g_q[c] = (g_q[c] - dp * a.qn[c]) * a.inv_norm;  // through q/|q|
-#pragma unroll
-      for (int c = 0; c < 3; ++c) g_s[c] *= a.es[c];                              // through exp
-      g_o *= a.o * (1.f - a.o);                                                   // through sigmoid
-    }
-  } else if (raw.enabled && i < N) {
-    if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (v_d_scales) { v_d_scales[3 * i] = 0.f; v_d_scales[3 * i + 1] = 0.f; v_d_scales[3 * i + 2] = 0.f; }
   }
+  // the feature gradients that pass straight through go out first (zeros for culled Gaussians): the record's
+  // upper half is then dead through the projection backward (registers: 136 -> 128 = a fourth wavefront per SIMD)
   if (i < N) {
-    v_means[3 * i] = g_m[0]; v_means[3 * i + 1] = g_m[1]; v_means[3 * i + 2] = g_m[2];
-    reinterpret_cast<float4*>(v_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
-    v_scales[3 * i] = g_s[0]; v_scales[3 * i + 1] = g_s[1]; v_scales[3 * i + 2] = g_s[2];
-    v_opacities[i] = g_o;
     const int ncol = kk > 0 ? 3 : fl.n_color;
     if (kk == 0) {
 #pragma unroll
@@ -481,6 +420,98 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       }
     }
   }
+  if (active) {
+    {
+      const Cam cam = load_cam(viewmat, K);
+      const float mx = means[3 * i], my = means[3 * i + 1], mz = means[3 * i + 2];
+      const Activated a = load_activated(raw, i, quats, scales, opacities);
+      const float s[3] = {a.s[0], a.s[1], a.s[2]};
+      const Fwd f = project_core(cam, mx, my, mz, a.q[0], a.q[1], a.q[2], a.q[3], s[0], s[1], s[2], width, height,
+                                 eps2d);
+      // feature gradients: [colour | depth | extra] start at record slot 8
+      const int ncol = kk > 0 ? 3 : fl.n_color;
+      float v_depth = v_depths ? v_depths[i] : 0.f;
+#pragma unroll
+      for (int c = 0; c < FG_MAX_CHANNELS; ++c)
+        if (fl.with_depth && c == ncol) v_depth += rec[8 + c];
+      // ---- opacity / compensation -----------------------------------------------------------------
+      float vcomp = 0.f;
+      if (antialiased) {
+        g_o = rec[2] * f.comp;
+        vcomp = rec[2] * a.o;
+      } else {
+        g_o = rec[2];
+      }
+      // ---- K7 -------------------------------------------------------------------------------------
+      const float vca = rec[3] + (v_conics ? v_conics[3 * i] : 0.f);
+      const float vcb = rec[4] + (v_conics ? v_conics[3 * i + 1] : 0.f);
+      const float vcc = rec[5] + (v_conics ? v_conics[3 * i + 2] : 0.f);
+      project_backward(cam, f, s, eps2d, v_means2d[(size_t)m2_stride * i], v_means2d[(size_t)m2_stride * i + 1],
+                       v_depth, vca, vcb, vcc,
+                       antialiased != 0, vcomp, g_m, g_q, g_s);
+    }
+    if (raw.enabled) {
+      // chain rule through the activations; the deltas receive the activated-value gradients as is.  The
+      // activations are evaluated AGAIN here (index made opaque so that the two evaluations are not merged): kept
+      // from before the projection backward their nine values would be live through it.
+      int i2 = i;
+      asm volatile("" : "+v"(i2));
+      const Activated a = load_activated(raw, i2, quats, scales, opacities);
+      if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
+      if (v_d_scales) { v_d_scales[3 * i] = g_s[0]; v_d_scales[3 * i + 1] = g_s[1]; v_d_scales[3 * i + 2] = g_s[2]; }
+      const float dp = g_q[0] * a.qn[0] + g_q[1] * a.qn[1] + g_q[2] * a.qn[2] + g_q[3] * a.qn[3];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) g_q[c] = (g_q[c] - dp * a.qn[c]) * a.inv_norm;  // through q/|q|
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g_s[c] *= a.es[c];                              // through exp
+      g_o *= a.o * (1.f - a.o);                                                   // through sigmoid
+    }
+    // ---- K8 (behind K7: the means' gradient gets the SH colour's share added) ------------------------
+    if (NOTE && kk > 0) view_direction();
+    if (kk > 1) {
+      float j[JAC];
+      if (NOTE) {
+        // the lane's own 40-byte note: five 8-byte loads (the lines are shared by neighbouring lanes)
+        const float2* jp = reinterpret_cast<const float2*>(sh_jac + (size_t)i * JAC);
+#pragma unroll
+        for (int q2 = 0; q2 < JAC / 2; ++q2) {
+          const float2 v = jp[q2];
+          j[2 * q2] = v.x; j[2 * q2 + 1] = v.y;
+        }
+      } else {
+#pragma unroll
+        for (int c = 0; c < 9; ++c) j[c] = sums.jac[c];
+        // the clamp mask: colour = max(sh + 0.5, 0)
+        j[9] = __int_as_float((int)(sums.col[0] + 0.5f > 0.f) | ((int)(sums.col[1] + 0.5f > 0.f) << 1) |
+                              ((int)(sums.col[2] + 0.5f > 0.f) << 2));
+      }
+      const int m = __float_as_int(j[9]);
+      vr = (m & 1) ? rec[8] : 0.f;
+      vg = (m & 2) ? rec[9] : 0.f;
+      vb = (m & 4) ? rec[10] : 0.f;
+      const float vdx = vr * j[0] + vg * j[3] + vb * j[6];
+      const float vdy = vr * j[1] + vg * j[4] + vb * j[7];
+      const float vdz = vr * j[2] + vg * j[5] + vb * j[8];
+      const float dp = vdx * sh_dx + vdy * sh_dy + vdz * sh_dz;
+      g_m[0] += (vdx - dp * sh_dx) * sh_inv;
+      g_m[1] += (vdy - dp * sh_dy) * sh_inv;
+      g_m[2] += (vdz - dp * sh_dz) * sh_inv;
+    } else if (kk == 1) {
+      const float* c0p = colors + (size_t)i * 3 * (raw.enabled ? 1 : fl.k_stored);
+      vr = (C0 * c0p[0] + 0.5f > 0.f) ? rec[8] : 0.f;
+      vg = (C0 * c0p[1] + 0.5f > 0.f) ? rec[9] : 0.f;
+      vb = (C0 * c0p[2] + 0.5f > 0.f) ? rec[10] : 0.f;
+    }
+  } else if (raw.enabled && i < N) {
+    if (v_d_quats) reinterpret_cast<float4*>(v_d_quats)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (v_d_scales) { v_d_scales[3 * i] = 0.f; v_d_scales[3 * i + 1] = 0.f; v_d_scales[3 * i + 2] = 0.f; }
+  }
+  if (i < N) {
+    v_means[3 * i] = g_m[0]; v_means[3 * i + 1] = g_m[1]; v_means[3 * i + 2] = g_m[2];
+    reinterpret_cast<float4*>(v_quats)[i] = make_float4(g_q[0], g_q[1], g_q[2], g_q[3]);
+    v_scales[3 * i] = g_s[0]; v_scales[3 * i + 1] = g_s[1]; v_scales[3 * i + 2] = g_s[2];
+    v_opacities[i] = g_o;
+  }
   // factored SH gradient (view-DP exchange): the masked colour gradient itself, 12 B instead of the
   // 192-B coefficient row it expands to (v_coeffs[k] = basis_k(dir) * v_rgb, rebuilt after the
   // exchange by fg_sh_grad_accumulate)
@@ -491,23 +522,34 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
       o[3] = sh_dx; o[4] = sh_dy; o[5] = sh_dz;
     }
   }
-  // ---- v_coeffs rows out through LDS -------------------------------------------------------------
+  // ---- v_coeffs rows out through LDS, half the workgroup's rows at a time ------------------------------
   if (kk > 0 && v_colors) {
-    __syncthreads();  // everyone is done reading the coefficient slab
-    float* row = lds + threadIdx.x * ROW;
+    float basis[16];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      const float bk = (k < kk) ? basis[k] : 0.f;
-      row[3 * k] = bk * vr; row[3 * k + 1] = bk * vg; row[3 * k + 2] = bk * vb;
-    }
-    __syncthreads();
-    if (raw.enabled) {
-      lds_to_slab_at(v_colors + (size_t)row0 * 3, lds, 0, nrows, 3, 3);  // v_features_dc
-      if (fl.k_stored > 1)
-        lds_to_slab_at(v_features_rest + (size_t)row0 * 3 * (fl.k_stored - 1), lds, 3, nrows,
-                       3 * (fl.k_stored - 1), 45);
-    } else {
-      lds_to_slab_at(v_colors + (size_t)row0 * 3 * fl.k_stored, lds, 0, nrows, 3 * fl.k_stored, 48);
+    for (int k = 0; k < 16; ++k) basis[k] = 0.f;
+    if (active) sh_basis(fl.sh_degree, sh_dx, sh_dy, sh_dz, basis);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r0 = row0 + h * HROWS, nr = min(HROWS, nrows - h * HROWS);
+      if (nr <= 0) break;
+      __syncthreads();  // everyone is done with the LDS rows (coefficient halves / the previous output half)
+      if ((int)(threadIdx.x / HROWS) == h) {
+        float* row = lds + (threadIdx.x & (HROWS - 1)) * ROW;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const float bk = (k < kk) ? basis[k] : 0.f;
+          row[3 * k] = bk * vr; row[3 * k + 1] = bk * vg; row[3 * k + 2] = bk * vb;
+        }
+      }
+      __syncthreads();
+      if (raw.enabled) {
+        lds_to_slab_at<ROW, true, HROWS>(v_colors + (size_t)r0 * 3, lds, 0, nr, 3, 3);  // v_features_dc
+        if (fl.k_stored > 1)
+          lds_to_slab_at<ROW, true, HROWS>(v_features_rest + (size_t)r0 * 3 * (fl.k_stored - 1), lds, 3, nr,
+                                           3 * (fl.k_stored - 1), 45);
+      } else {
+        lds_to_slab_at<ROW, true, HROWS>(v_colors + (size_t)r0 * 3 * fl.k_stored, lds, 0, nr, 3 * fl.k_stored, 48);
+      }
     }
   }
 }
@@ -584,8 +626,9 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
     if ((raw.d_quats != nullptr) != (v_d_quats != nullptr) || (raw.d_scales != nullptr) != (v_d_scales != nullptr))
       return FG_ERR_INVALID_ARG;
   }
-  hipLaunchKernelGGL(preprocess_bwd_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream), N,
-                     fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, v_rgb_floats, means, quats, scales, opacities, colors,
+  const bool note = sh_jac != nullptr && sh_degree >= 1;
+  hipLaunchKernelGGL(note ? preprocess_bwd_kernel<true> : preprocess_bwd_kernel<false>, dim3((N + BLOCK - 1) / BLOCK),
+                     dim3(BLOCK), 0, fg_hip_stream(stream), N, fl, raw, v_d_quats, v_d_scales, v_features_rest, v_rgb, v_rgb_floats, means, quats, scales, opacities, colors,
                      viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, v_means2d_stride,
                      v_depths, v_conics, v_means, v_quats, v_scales, v_opacities, v_colors, v_extra, sh_jac,
                      skip_culled_rows());

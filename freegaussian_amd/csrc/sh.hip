@@ -35,22 +35,11 @@ sh_fwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, 
   if (i >= N) return;
   float r = 0.f, g = 0.f, b = 0.f;
   if (!radii || radii[i] > 0) {
-    float cx, cy, cz;
-    camera_position(viewmat, cx, cy, cz);
-    float dx = means[3 * i] - cx, dy = means[3 * i + 1] - cy, dz = means[3 * i + 2] - cz;
-    const float inv = 1.f / sqrtf(dx * dx + dy * dy + dz * dz);
-    dx *= inv; dy *= inv; dz *= inv;
+    float dx, dy, dz, inv;
+    view_dir(viewmat, means[3 * i], means[3 * i + 1], means[3 * i + 2], dx, dy, dz, inv);
     float basis[16];
     sh_basis(degree, dx, dy, dz, basis);
-    const float* row = lds + threadIdx.x * ROW;
-#pragma unroll
-    for (int k = 0; k < 16; ++k) {
-      if (k < kk) {
-        r += basis[k] * row[3 * k];
-        g += basis[k] * row[3 * k + 1];
-        b += basis[k] * row[3 * k + 2];
-      }
-    }
+    sh_dot(basis, lds + threadIdx.x * ROW, kk, r, g, b);
     r = fmaxf(r + 0.5f, 0.f);
     g = fmaxf(g + 0.5f, 0.f);
     b = fmaxf(b + 0.5f, 0.f);
@@ -86,11 +75,8 @@ sh_bwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, 
     vr = colors[3 * i] > 0.f ? v_colors[3 * i] : 0.f;
     vg = colors[3 * i + 1] > 0.f ? v_colors[3 * i + 1] : 0.f;
     vb = colors[3 * i + 2] > 0.f ? v_colors[3 * i + 2] : 0.f;
-    float cx, cy, cz;
-    camera_position(viewmat, cx, cy, cz);
-    const float ux = means[3 * i] - cx, uy = means[3 * i + 1] - cy, uz = means[3 * i + 2] - cz;
-    const float inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
-    const float dx = ux * inv, dy = uy * inv, dz = uz * inv;
+    float dx, dy, dz, inv;
+    view_dir(viewmat, means[3 * i], means[3 * i + 1], means[3 * i + 2], dx, dy, dz, inv);
     sh_basis(degree, dx, dy, dz, basis);
     if (need_dir) {
       float bx[16], by[16], bz[16];

@@ -25,6 +25,7 @@ constexpr int ROW = 49;  // 48 floats (16 bases x 3) + 1 pad -> odd stride, conf
 
 // camera position = -W^-1 t for the 3x4 world->camera transform
 __device__ __forceinline__ void camera_position(const float* __restrict__ vm, float& cx, float& cy, float& cz) {
+#pragma clang fp contract(off)  // (the same bits wherever it is inlined, like sh_basis below)
   const float a = vm[0], b = vm[1], c = vm[2], d = vm[4], e = vm[5], f = vm[6], g = vm[8], h = vm[9], i = vm[10];
   const float tx = vm[3], ty = vm[7], tz = vm[11];
   const float A = e * i - f * h, B = -(d * i - f * g), C = d * h - e * g;
@@ -39,8 +40,22 @@ __device__ __forceinline__ void camera_position(const float* __restrict__ vm, fl
   cz = -(i20 * tx + i21 * ty + i22 * tz);
 }
 
-// basis values b[k] for k < (degree+1)^2
+// unit view direction of a mean and 1 / distance
+__device__ __forceinline__ void view_dir(const float* __restrict__ vm, float mx, float my, float mz, float& dx, float& dy,
+                                         float& dz, float& inv) {
+#pragma clang fp contract(off)
+  float cx, cy, cz;
+  camera_position(vm, cx, cy, cz);
+  const float ux = mx - cx, uy = my - cy, uz = mz - cz;
+  inv = 1.f / sqrtf(ux * ux + uy * uy + uz * uz);
+  dx = ux * inv; dy = uy * inv; dz = uz * inv;
+}
+
+// basis values b[k] for k < (degree+1)^2.  No FMA contraction in here: where the compiler fuses a multiply into
+// an add depends on the code around the call (2 z^2 - x^2 - y^2 next to the gradient's x^2, y^2 ...), and the fused
+// and the stage-by-stage paths must give the same bits (tests: torch.equal).
 __device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, float (&b)[16]) {
+#pragma clang fp contract(off)
   b[0] = C0;
   if (degree > 0) {
     b[1] = -C1 * y; b[2] = C1 * z; b[3] = -C1 * x;
@@ -57,6 +72,21 @@ __device__ __forceinline__ void sh_basis(int degree, float x, float y, float z, 
       b[13] = C3_4 * x * (4.f * zz - xx - yy);
       b[14] = C3_5 * z * (xx - yy);
       b[15] = C3_6 * x * (xx - 3.f * yy);
+    }
+  }
+}
+
+// colour (before + 0.5 / clamp) = sum_k basis_k coeff_k, one explicit FMA per term in the order of the bases: the
+// same bits wherever it is inlined.  row: [16 x 3] coefficients of one Gaussian.
+__device__ __forceinline__ void sh_dot(const float (&basis)[16], const float* row, int kk, float& r, float& g, float& b) {
+#pragma clang fp contract(off)
+  r = g = b = 0.f;
+#pragma unroll
+  for (int k = 0; k < 16; ++k) {
+    if (k < kk) {
+      r = __builtin_fmaf(basis[k], row[3 * k], r);
+      g = __builtin_fmaf(basis[k], row[3 * k + 1], g);
+      b = __builtin_fmaf(basis[k], row[3 * k + 2], b);
     }
   }
 }

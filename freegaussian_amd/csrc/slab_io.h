@@ -32,14 +32,17 @@ namespace fgsh {
 // (row, column) of an element comes from a multiply-shift division (exact for rows <= 48 floats
 // and slabs <= 2^14 elements), row wrap inside a float4 is branch-free and dropped columns land
 // in the row's last pad slot (column STRIDE-1), so there is no divergent code between load and store.
-constexpr int SLAB_MAX_Q = (BLOCK * 48 / 4 + BLOCK - 1) / BLOCK;  // float4 per lane of a full slab
+constexpr int slab_max_q(int maxrows) { return (maxrows * 48 / 4 + BLOCK - 1) / BLOCK; }  // float4 per lane of a slab
+constexpr int SLAB_MAX_Q = slab_max_q(BLOCK);
 
 // row_live (LDS, one byte per row, nullable): rows whose flag is 0 are not fetched (their LDS rows
 // keep whatever they held; nobody reads them) -- culled Gaussians' 192-byte coefficient rows are a
 // sixth of the forward's traffic on the 1M / 1080p scene.
-template <int STRIDE = ROW>
+// MAXROWS: the most rows a call stages (a workgroup's 64, or 32 when it stages its rows in two halves).
+template <int STRIDE = ROW, int MAXROWS = BLOCK>
 __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const float* __restrict__ src, int nrows,
                                                int row_floats, int use_floats, const uint8_t* row_live = nullptr) {
+  constexpr int SLAB_MAX_Q = slab_max_q(MAXROWS);
   const int total = nrows * row_floats;
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const float4* src4 = reinterpret_cast<const float4*>(src);
@@ -93,9 +96,10 @@ __device__ __forceinline__ void slab_to_lds_at(float* lds, int lds_col0, const f
 // slab; columns >= lds_cols are written as zero.
 // NT: the slab is not read again on the GPU soon (gradient outputs) -> non-temporal stores; the
 // splat records, which the raster kernels gather right afterwards, keep the default policy.
-template <int STRIDE = ROW, bool NT = true>
+template <int STRIDE = ROW, bool NT = true, int MAXROWS = BLOCK>
 __device__ __forceinline__ void lds_to_slab_at(float* __restrict__ dst, const float* lds, int lds_col0, int nrows,
                                                int row_floats, int lds_cols) {
+  constexpr int SLAB_MAX_Q = slab_max_q(MAXROWS);
   const int total = nrows * row_floats;
   if ((total & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
     float4* dst4 = reinterpret_cast<float4*>(dst);
