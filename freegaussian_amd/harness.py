@@ -72,7 +72,8 @@ def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = Non
 
 
 def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
-               grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None, graphed=None) -> Dict[str, float]:  # fmt: skip
+               grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None, graphed=None,
+               mask: Optional[torch.Tensor] = None) -> Dict[str, float]:  # fmt: skip
     """One iteration in the reference's callback order: step_cb -> get_outputs ->
     loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter ->
     refinement_after every ``refine_every`` steps (freegaussian_model.py:575-590; needs
@@ -80,9 +81,12 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     ``grad_sync=viewdp.all_reduce_model_grads`` and ``stats_sync=viewdp.sync_densify_stats``.
     ``graphed``: a ``graphed.GraphedModelStep(model, main_loss)``: while the scheduled resolution is
     launch-bound (the reference's first 6000 steps at 1/4 and 1/2 resolution) get_outputs + loss + backward
-    replay as one hipGraph; the rest of the step is unchanged."""
+    replay as one hipGraph; the rest of the step is unchanged.  ``mask`` [H,W,1]: the batch's optional mask
+    (freegaussian_model.py:956-963).  The loss is the sum of ``model.get_loss_dict`` (main loss + the optional
+    scale regulariser), as nerfstudio's trainer sums it."""
     model.step_cb(step)
-    if graphed is not None and graphed.applicable(camera):
+    plain_loss = mask is None and gt_image.shape[-1] == 3 and not model.config.use_scale_regularization
+    if graphed is not None and plain_loss and graphed.applicable(camera):
         # (no zero_grad: the replay refills the .grad tensors, which are static buffers of the graph)
         out, loss = graphed.step(camera, gt_image)
         gt = graphed.static["gt"]
@@ -92,8 +96,10 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
         for o in opts.values():
             o.zero_grad(set_to_none=True)
         out = model.get_outputs(camera)
-        gt = model.get_gt_img(gt_image)
-        loss = main_loss(out["rgb"], gt)
+        batch = {"image": gt_image} if mask is None else {"image": gt_image, "mask": mask}
+        loss_dict = model.get_loss_dict(out, batch)
+        loss = loss_dict["main_loss"] + loss_dict["scale_reg"]
+        gt = model.composite_with_background(model.get_gt_img(gt_image), out["background"])
         loss.backward()
     if grad_sync is not None:
         grad_sync(model)

@@ -100,6 +100,9 @@ class FreeGaussianModelConfig:
     split_screen_size: float = 0.05
     stop_screen_size_at: int = 4000
     output_depth_during_training: bool = False
+    ssim_lambda: float = 0.2  # (:96)
+    use_scale_regularization: bool = False  # (:102; the PhysGaussian ratio penalty, every 10th step)
+    max_gauss_ratio: float = 10.0  # (:104)
     rasterize_mode: str = "classic"
     num_random: int = 50000
     random_scale: float = 10.0
@@ -222,6 +225,47 @@ class FreeGaussianModel(nn.Module):
             image = image.float() / 255.0
         d = self._get_downscale_factor()
         return (resize_image(image, d) if d > 1 else image).to(self.device)
+
+    def composite_with_background(self, image: torch.Tensor, background: torch.Tensor) -> torch.Tensor:
+        """(:911-922) a ground-truth image with an alpha channel over the step's background colour."""
+        if image.shape[2] == 4:
+            alpha = image[..., -1].unsqueeze(-1).repeat((1, 1, 3))
+            return alpha * image[..., :3] + (1 - alpha) * background
+        return image
+
+    def get_metrics_dict(self, outputs, batch):
+        """(:924-941) without the colour-corrected variant and the camera optimizer (mode "off", :120)."""
+        gt_rgb = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
+        mse = torch.nn.functional.mse_loss(outputs["rgb"], gt_rgb)
+        return {"psnr": -10.0 * torch.log10(mse), "gaussian_count": self.num_points}
+
+    def get_loss_dict(self, outputs, batch, metrics_dict=None):
+        """(:944-990) main loss (1 - ssim_lambda) L1 + ssim_lambda (1 - SSIM) on the composited ground truth, the
+        optional mask (both images blacked out), the optional scale-ratio regulariser on every 10th step.  The
+        camera-optimizer and bilateral-grid terms of the reference are not mirrored (both off in every shipped
+        config)."""
+        from .harness import ssim
+
+        gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
+        pred_img = outputs["rgb"]
+        if "mask" in batch:
+            d = self._get_downscale_factor()
+            mask = batch["mask"]
+            mask = (resize_image(mask.float(), d) if d > 1 else mask.float()).to(self.device)
+            assert mask.shape[:2] == gt_img.shape[:2] == pred_img.shape[:2]
+            gt_img = gt_img * mask
+            pred_img = pred_img * mask
+        l1 = torch.abs(gt_img - pred_img).mean()
+        simloss = 1 - ssim(gt_img.permute(2, 0, 1)[None, ...], pred_img.permute(2, 0, 1)[None, ...])
+        if self.config.use_scale_regularization and self.step % 10 == 0:
+            scale_exp = torch.exp(self.scales)
+            ratio = scale_exp.amax(dim=-1) / scale_exp.amin(dim=-1)
+            limit = torch.tensor(self.config.max_gauss_ratio, device=ratio.device)
+            scale_reg = 0.1 * (torch.maximum(ratio, limit) - self.config.max_gauss_ratio).mean()
+        else:
+            scale_reg = torch.tensor(0.0, device=self.device)
+        lam = self.config.ssim_lambda
+        return {"main_loss": (1 - lam) * l1 + lam * simloss, "scale_reg": scale_reg}
 
     # -- the pieces of get_outputs shared by stage 1 and stage 2 ------------------------------------
     def _camera_setup(self, camera: Camera):

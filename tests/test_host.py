@@ -269,6 +269,44 @@ def test_harness_loss_ssim_and_schedule():
     assert opts["opacities"].param_groups[0]["lr"] == 0.05
 
 
+def test_loss_dict_mirrors_the_reference_expressions():
+    """get_loss_dict / composite_with_background / get_metrics_dict (freegaussian_model.py:911-990): RGBA ground
+    truth over the step's background, the mask blacking out both images, main loss from L1 and SSIM with
+    ssim_lambda, the scale-ratio regulariser 0.1 mean(max(ratio, max_gauss_ratio) - max_gauss_ratio) on every
+    10th step only -- spelled out again here from the reference's lines."""
+    from freegaussian_amd.harness import ssim
+
+    g = torch.Generator().manual_seed(5)
+    cfg = FreeGaussianModelConfig(num_downscales=0, use_scale_regularization=True, max_gauss_ratio=3.0)
+    model = FreeGaussianModel(cfg, seed_points=torch.randn(50, 3, generator=g))
+    with torch.no_grad():
+        model.gauss_params["scales"].copy_(torch.randn(50, 3, generator=g))
+    model.train()
+    H, W = 24, 32
+    pred, bg = torch.rand(H, W, 3, generator=g), torch.rand(3, generator=g)
+    rgba = torch.rand(H, W, 4, generator=g)
+    mask = (torch.rand(H, W, 1, generator=g) > 0.3).float()
+    outputs = {"rgb": pred, "background": bg}
+    gt = rgba[..., 3:] * rgba[..., :3] + (1 - rgba[..., 3:]) * bg  # (:918-920)
+    assert torch.allclose(model.composite_with_background(rgba, bg), gt)
+    assert model.composite_with_background(pred, bg) is pred
+    model.step = 20
+    d = model.get_loss_dict(outputs, {"image": rgba, "mask": mask})
+    g_m, p_m = gt * mask, pred * mask
+    main = 0.8 * (g_m - p_m).abs().mean() + 0.2 * (1 - ssim(g_m.permute(2, 0, 1)[None], p_m.permute(2, 0, 1)[None]))
+    assert torch.allclose(d["main_loss"], main, atol=1e-7)
+    se = torch.exp(model.scales)
+    reg = 0.1 * (torch.maximum(se.amax(-1) / se.amin(-1), torch.tensor(3.0)) - 3.0).mean()  # (:968-976)
+    assert float(reg) > 0 and torch.allclose(d["scale_reg"], reg)
+    model.step = 21  # not a 10th step
+    assert float(model.get_loss_dict(outputs, {"image": rgba})["scale_reg"]) == 0.0
+    m = model.get_metrics_dict(outputs, {"image": rgba})
+    assert abs(float(m["psnr"]) - float(-10 * torch.log10(((pred - gt) ** 2).mean()))) < 1e-5 and m["gaussian_count"] == 50
+    # uint8 ground truth (:906-907)
+    u8 = (torch.rand(H, W, 3, generator=g) * 255).to(torch.uint8)
+    assert torch.allclose(model.get_gt_img(u8), u8.float() / 255.0)
+
+
 def test_model_load_state_dict_resizes_and_remaps_like_the_reference():
     """freegaussian_model.py:278-291: parameters re-allocated to the checkpoint's count, legacy
     names remapped, step forced to 30000."""
