@@ -6,10 +6,11 @@
 // splat record the raster kernels gather.  Backward reads the 64-byte gradient record the raster
 // backward accumulated (+ v_means2d, which autograd routes separately so that
 // info["means2d"].grad exists) and writes v_means / v_quats / v_scales / v_opacities and the dense
-// 192-byte v_coeffs row.  Both directions stream the [256 x 48] coefficient slab and the
-// [256 x 16] record slab of a 256-Gaussian workgroup through LDS so every global access is a
-// fully coalesced 16-byte-per-lane stream; rows are read back per lane at padded strides
-// (49 / 20 floats) that are LDS-bank-conflict free.
+// 192-byte v_coeffs row.  One 64-lane wavefront per 64 Gaussians; the coefficient rows (32 at a time), the
+// [64 x 16] record slab and the [64 x 10] note for the backward stream through LDS so that every global access
+// is a fully coalesced 16-byte-per-lane stream; rows are read back per lane at padded strides (49 / 20 / 11
+// floats) that are LDS-bank-conflict free.  The backward reads the forward's note (d colour / d direction +
+// clamp mask, 40 B) instead of the coefficient row.
 //
 // Same arithmetic as project.hip / sh.hip (shared headers); results are bit-identical to the
 // unfused entry points.

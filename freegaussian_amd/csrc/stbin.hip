@@ -1,4 +1,4 @@
-// K3 + K4, supertile form: the banded binning of tilebin.hip one level coarser.  A SUPERTILE is 2 x 2
+// K3 + K4, supertile form: count -> scan -> scatter -> sort per segment, with a SUPERTILE of 2 x 2
 // tiles (32 x 32 pixels).  A Gaussian is scattered once per supertile its rectangle touches (2.4 on the
 // 1M / 1080p scene) instead of once per tile (6.0), every supertile's entries are sorted ONCE by (depth
 // bits, id), and the four tile lists are read off the sorted run in order -- an entry goes to the tiles
@@ -39,6 +39,8 @@ constexpr int SB_SMALL_KPT = FG_SB_SMALL_KPT, SB_LARGE_KPT = 8;  // elements per
 constexpr int SB_LARGE_GRID = 512;                   // persistent workgroups of the large launch (two per CU)
 constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the counting pass of the LDS sorts
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
+constexpr int SB_SCATTER_LDS_BYTES = 132 * 1024;     // dynamic LDS of the staging scatter (+ 21 KB static: one workgroup per CU)
+constexpr int SB_MIN_STAGE = 4096;                   // staging buffers smaller than this are not worth the second sweep
 
 struct Geo {
   int tile_w, tile_h, sw, sh;
@@ -287,17 +289,25 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
 
 // ---- scatter --------------------------------------------------------------------------------------------
 // One workgroup per chunk; a wavefront takes 64 Gaussians a round: every lane finds the owner of its slot among
-// the round's (Gaussian, supertile) pairs by binary search over the exclusive counts and writes the element
-// depth bits << 32 | id << 4 | tile mask (bit j: the rectangle covers tile j = 2 * (row in the supertile) +
-// column) to the slot an LDS cursor of the supertile hands out (segment start + the chunks before this one,
-// from the scanned table).  Order = (depth bits, id): the mask sits below the id and never decides.
+// the round's (Gaussian, supertile) pairs and writes the element depth bits << 32 | id << 4 | tile mask (bit j:
+// the rectangle covers tile j = 2 * (row in the supertile) + column) to the slot an LDS cursor of the supertile
+// hands out (segment start + the chunks before this one, from the scanned table).  Order = (depth bits, id): the
+// mask sits below the id and never decides.
+// STAGE (whenever the whole image's cursors and a staging buffer fit the LDS): the chunk's elements are first put
+// in LDS ordered by supertile -- the cursors then count from a LOCAL exclusive scan of the chunk's own counts --
+// and go out in one sweep, a run of ~5 consecutive addresses per (chunk, supertile) instead of one scattered
+// 8-byte store per element (2.45M of those left the L2 as 32-byte writes each: 70 MB for 20 MB of elements and
+// +13 us over coalesced stores, profiles/r03_binning.md section 4).  Elements beyond the staging buffer's `stage_cap`
+// (a chunk of huge rectangles) are stored directly, as without STAGE.
+template <bool STAGE>
 __global__ void __launch_bounds__(SC_BLOCK)
 sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
-                  int tile_h, int band_rows, const uint32_t* __restrict__ table_s,
+                  int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                   uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list) {
-  extern __shared__ uint32_t s_cur[];  // [supertiles of the pass]
+  extern __shared__ uint32_t s_cur[];  // [supertiles of the pass] (STAGE: + destination deltas + staging buffer)
   __shared__ int s_large;
+  __shared__ uint32_t s_wave_tot[SC_WAVES];
   __shared__ int4 s_q[SC_WAVES][64];
   __shared__ int32_t s_excl[SC_WAVES][64];
   __shared__ unsigned long long s_marks[SC_WAVES];
@@ -328,11 +338,44 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
     rc[r] = in ? rects[g0 + r * 64] : make_int2(0, 0);
     dk[r] = in ? depth_keys[g0 + r * 64] : 0u;
   }
+  // STAGE: s_cur = local cursors, s_gd[st] = (global slot) - (local slot) of the chunk's run in supertile st
+  const int s_pad = (S + 1) & ~1;
+  uint32_t* s_gd = s_cur + s_pad;
+  uint64_t* stage = reinterpret_cast<uint64_t*>(s_gd + s_pad);
+  uint16_t* stage_st = reinterpret_cast<uint16_t*>(stage + stage_cap);
+  uint32_t chunk_pairs = 0;
+  if (STAGE) {
+    const uint32_t* row = table_s + (size_t)chunk * S;
+    const bool last = (chunk + 1) * SB_CHUNK >= N;
+    auto count_of = [&](int i) {  // this chunk's pairs in supertile i: the next chunk's prefix minus this one's
+      return (last ? (uint32_t)(st_offsets[i + 1] - st_offsets[i]) : row[S + i]) - row[i];
+    };
+    const int per = (S + SC_BLOCK - 1) / SC_BLOCK, i0 = min((int)threadIdx.x * per, S), i1 = min(i0 + per, S);
+    uint32_t sum = 0;
+    for (int i = i0; i < i1; ++i) sum += count_of(i);
+    const uint32_t incl = wave_incl_scan(sum, lane);
+    if (lane == 63) s_wave_tot[wave] = incl;
+    __syncthreads();
+    uint32_t base = incl - sum;
+#pragma unroll
+    for (int w = 0; w < SC_WAVES; ++w) {
+      const uint32_t t = s_wave_tot[w];
+      if (w < wave) base += t;
+      chunk_pairs += t;
+    }
+    for (int i = i0; i < i1; ++i) {
+      s_cur[i] = base;
+      s_gd[i] = (uint32_t)st_offsets[i] + row[i] - base;
+      base += count_of(i);
+    }
+  }
   for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's cursors fit the LDS)
     const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
     const int sb0 = sr0 * g.sw, nbs = (sr1 - sr0) * g.sw;
-    const uint32_t* row = table_s + (size_t)chunk * S + sb0;
-    for (int i = threadIdx.x; i < nbs; i += SC_BLOCK) s_cur[i] = (uint32_t)st_offsets[sb0 + i] + row[i];
+    if (!STAGE) {
+      const uint32_t* row = table_s + (size_t)chunk * S + sb0;
+      for (int i = threadIdx.x; i < nbs; i += SC_BLOCK) s_cur[i] = (uint32_t)st_offsets[sb0 + i] + row[i];
+    }
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SC_PER; ++r) {
@@ -382,12 +425,24 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
           const uint32_t cols = (uint32_t)(c0 >= ox0) | ((uint32_t)(c0 + 1 < ox0 + ow) << 1);
           const uint32_t rows = (uint32_t)(r0 >= oy0) | ((uint32_t)(r0 + 1 < oy0 + oh) << 1);
           const uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
-entries[pos] = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
+          const uint64_t element = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
+          if (!STAGE) {
+            entries[pos] = element;
+          } else if (pos < (uint32_t)stage_cap) {
+            stage[pos] = element;
+            stage_st[pos] = (uint16_t)local;
+          } else {
+            entries[pos + s_gd[local]] = element;
+          }
         }
       }
       __builtin_amdgcn_wave_barrier();
     }
     __syncthreads();
+  }
+  if (STAGE) {  // the staged elements out, ordered by supertile: consecutive lanes, runs of consecutive addresses
+    const uint32_t n_staged = min(chunk_pairs, (uint32_t)stage_cap);
+    for (uint32_t i = threadIdx.x; i < n_staged; i += SC_BLOCK) entries[i + s_gd[stage_st[i]]] = stage[i];
   }
 }
 
@@ -923,9 +978,26 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
   uint64_t* scratch = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 8));
   const int band_rows = scatter_band_rows(g), S = g.sw * g.sh;
   constexpr int small_max = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>::MAXN;
-  hipLaunchKernelGGL(sb_scatter_kernel, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
-                     reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, w.table_s,
-                     tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+  // staging buffer: whatever the LDS leaves beside the two [S] arrays, if that is worth it (10 bytes per element)
+  const int s_pad = (S + 1) & ~1;
+  int stage_cap = band_rows == g.sh && S <= 65535 ? ((int)SB_SCATTER_LDS_BYTES - 8 * s_pad) / 10 : 0;
+  stage_cap = stage_cap >= SB_MIN_STAGE ? (stage_cap & ~63) : 0;
+  if (stage_cap) {
+    const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
+    static bool attr_set = false;  // (dynamic LDS beyond 64 KB; benign if two threads race to set the same value)
+    if (!attr_set) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SCATTER_LDS_BYTES);
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc), dim3(SC_BLOCK), lds, s, N,
+                       reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+  } else {
+    hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
+                       reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+  }
   hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
                      tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries, scratch, (long long)capacity,
                      flatten_ids);
