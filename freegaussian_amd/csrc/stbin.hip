@@ -219,10 +219,11 @@ sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restri
 // ---- offsets: inclusive scans of the counts at [1 .. n] in place, [0] = 0; one workgroup per array.  1024
 // threads x 8 values: the 8160 tiles of a 1080p frame are one trip through memory, not two ----------------------
 constexpr int SO_BLOCK = 1024, SO_WAVES = SO_BLOCK / 64, SO_PER = 8;
-__device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
+__device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
                                                          uint32_t* wave_tot) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   uint32_t carry = 0;
+  uint64_t total = 0;  // (the offsets are 32-bit; the total is reported in full so that the host can refuse a list it cannot index)
   for (int base = 0; base < n; base += SO_BLOCK * SO_PER) {
     uint32_t in[SO_PER];
 #pragma unroll
@@ -266,10 +267,11 @@ __device__ __forceinline__ uint32_t scan_counts_in_place(int n, int32_t* __restr
       if (i < n) offs[i + 1] = (int32_t)buf[k * SO_BLOCK + threadIdx.x];
     }
     carry += all;
+    total += all;
     __syncthreads();
   }
   if (threadIdx.x == 0) offs[0] = 0;
-  return carry;
+  return total;
 }
 __global__ void __launch_bounds__(SO_BLOCK)
 sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __restrict__ st_offsets,
@@ -280,7 +282,7 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
     scan_counts_in_place(S, st_offsets, buf, wave_tot);
     return;
   }
-  const uint32_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);
+  const uint64_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);
   if (threadIdx.x == 0 && count_out) {  // the list length straight into the caller's host-visible word
     __hip_atomic_store(count_out, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();

@@ -622,6 +622,8 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
         else:
             ready.synchronize()
             n_isects = int(count_host[0])
+        if n_isects >= 2**31:
+            raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
         if key not in _isect_capacity and len(_isect_capacity) >= 256:
             old = next(iter(_isect_capacity))
             _isect_capacity.pop(old)
