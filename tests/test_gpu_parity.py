@@ -339,14 +339,15 @@ def _pack_rects(x0, y0, w, h):
     return torch.stack([x0 | (y0 << 16), w | (h << 16)], -1).to(torch.int32).contiguous()
 
 
-@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "one", "all_culled", "few_rows", "2160p"])
+@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "one", "all_culled", "few_rows", "2160p", "2880p"])
 def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     """csrc/stbin.hip (count -> scan -> scatter per supertile -> one sort per supertile, four tile lists read off
     it) against the depth-first binning on the same depth keys and footprint rectangles: `torch.equal` lists and
     ranges.
     Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
     tiles with more entries than fit the small LDS sort (the large one), than fit any (the pass through global
-    memory); one Gaussian; nothing visible; an image of three tile rows; 32 400 tiles (the count kernel's grids in four passes)."""
+    memory); one Gaussian; nothing visible; an image of three tile rows; 32 400 tiles (the count kernel's grids in four passes); 57 600 tiles (the scatter's
+    cursors in two passes, elements stored directly)."""
     g = torch.Generator().manual_seed(31)
     W, H = 640, 400
     if case == "scene":
@@ -362,9 +363,11 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
         W, H = 640, 40  # 3 tile rows, 2 supertile rows (the lower one half outside the image)
     if case == "2160p":
         W, H = 3840, 2160
+    if case == "2880p":
+        W, H = 5120, 2880  # 14 400 supertiles: the scatter's cursors in two passes, no staging; count grids in seven
     tw, th = (W + 15) // 16, (H + 15) // 16
     N = {"ties": 30000, "heavy_tile": 20000, "huge_tile": 40000, "one": 1, "all_culled": 5000, "few_rows": 4000,
-         "2160p": 200_000}[case]
+         "2160p": 200_000, "2880p": 150_000}[case]
     x0 = torch.randint(0, tw, (N,), generator=g)
     y0 = torch.randint(0, th, (N,), generator=g)
     w = torch.minimum(torch.randint(1, 5, (N,), generator=g), tw - x0)
