@@ -47,9 +47,10 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--settle-s", type=float, default=1.0,
-                    help="after the W warm-up steps, keep stepping (untimed) until this much wall time has passed: a "
-                    "fresh process starts on a GPU at idle clocks and a cold caching allocator, and the first runs "
-                    "of a box measured 8-25%% slower than the ones after them with 35 untimed steps in front")
+                    help="seconds of untimed steps right before the timed region, with no host synchronisation in "
+                    "between: the device's clocks follow its recent load (the dominant kernel ran 0.39 ms right "
+                    "after an idle stretch and 0.31-0.34 ms 48 steps later), so a short timed region behind a pause "
+                    "measures the ramp")
     ap.add_argument("--n-gauss", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
@@ -528,21 +529,33 @@ def main(argv=None):
     for _ in range(max(args.warmup, 0)):
         step()
     fence()
-    # ... and until the device has been busy for --settle-s seconds (clocks, allocator, list-capacity history):
-    # the same number of extra steps on every rank (rank 0 decides), all untimed
+    # Everything from here to the timed region keeps the device BUSY: its clocks follow its recent load with a time
+    # constant of tens of milliseconds -- behind an idle stretch (a collection, an event summary) the dominant
+    # kernel ran 0.39 ms and was still getting faster 48 steps later (0.31-0.34 ms; FG_BENCH_SERIES=1 prints the
+    # series), so a 20-step region behind a pause timed the ramp, not the path.  Order: collection, calibration,
+    # settle (--settle-s seconds of steps, no host synchronisation inside), stage pass, a shorter second settle behind
+    # the stage pass's summary, fence, timed region.  Step counts are the same on every rank (rank 0 decides).
+    gc.collect()
+    gc.disable()  # a generation-2 collection inside a 50 ms timed region is a 1-3 ms outlier, not a property of the path
     settle_steps = 0
+
+    def settle(seconds, per_step):
+        n = torch.tensor([max(8, int(seconds / per_step))], device=dev)
+        if world > 1:
+            dist.broadcast(n, 0)
+        for _ in range(int(n.item())):
+            step(timed=args.stage_events == "all")
+        return int(n.item())
+
+    per_step = 1e-3
     if args.settle_s > 0:
-        t_settle = time.perf_counter()
-        while True:
-            for _ in range(8):
-                step()
-            settle_steps += 8
-            fence()
-            go_on = torch.tensor([1 if time.perf_counter() - t_settle < args.settle_s else 0], device=dev)
-            if world > 1:
-                dist.broadcast(go_on, 0)
-            if int(go_on.item()) == 0:
-                break
+        fence()
+        t_cal = time.perf_counter()
+        for _ in range(8):
+            step()
+        fence()
+        per_step = max((time.perf_counter() - t_cal) / 8, 1e-5)
+        settle_steps = 8 + settle(args.settle_s, per_step)
     # Stage pass (untimed): HIP events around EVERY C-ABI call and around forward / backward / exchange of
     # every step.  Sixteen event records per step cost ~0.06 ms of a ~1 ms step (measured: 1.045 ms with
     # them, 0.987 without), so the timed region below carries events around the dominant kernel only --
@@ -558,18 +571,14 @@ def main(argv=None):
                     "fg_preprocess_fwd", "fg_preprocess_bwd", "fg_bin_prepare", "fg_bin_emit_sort_capacity")
     cand = {s: v for s, v in stages.items() if s in kernel_names}
     dominant = max(cand, key=lambda s: cand[s]) if cand else "fg_raster_bwd"
-    gc.collect()
-    gc.disable()  # a generation-2 collection inside a 50 ms timed region is a 1-3 ms outlier, not a property of the path
-    redo0 = ops.default_context.capacity_redos
     only = {"all": None, "dominant": {dominant}, "none": set()}[args.stage_events]
     ops.default_context.stage_timer = ops.StageTimer(only=only)
-    # one untimed step AFTER the collection and the timer swap: the first step behind them was a 1.7x outlier
-    # (3.5% of a 20-step mean) that belongs to the bench, not to the path.  Like every warm-up step it advances
-    # the view ring, on all ranks alike.
-    step(timed=args.stage_events == "all")
-    fence()
+    if args.settle_s > 0:
+        settle_steps += settle(max(args.settle_s / 3, 0.2), per_step)
+    redo0 = ops.default_context.capacity_redos
     if ops.default_context.stage_timer is not None:
-        ops.default_context.stage_timer = ops.StageTimer(only=only)  # its events are not part of the timed region's averages
+        ops.default_context.stage_timer = ops.StageTimer(only=only)  # the settle steps' events are not part of the timed region's averages
+    fence()
     t0 = time.perf_counter()
     views_seen = []
     host_marks = [t0]
@@ -581,7 +590,11 @@ def main(argv=None):
     dt_local = time.perf_counter() - t0
     gc.enable()
     timed_stages = ops.default_context.stage_timer.summary()
+    dom_series = [a.elapsed_time(b) for a, b in ops.default_context.stage_timer.events.get(dominant, [])]
     ops.default_context.stage_timer = None
+    if os.environ.get("FG_BENCH_SERIES"):  # per-step durations of the dominant kernel and host marks (diagnosis)
+        print("[bench] dominant kernel ms per timed step:", [round(x, 4) for x in dom_series], file=sys.stderr)
+        print("[bench] host ms per timed step:", [round((b - a) * 1e3, 4) for a, b in zip(host_marks, host_marks[1:])], file=sys.stderr)
     if args.stage_events == "all":
         stages = timed_stages
     stages = dict(stages)
@@ -719,8 +732,8 @@ def main(argv=None):
             }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
             "list_capacity_redos_in_timed_region": redos,
-            "untimed_steps_before_timed_region": {"warmup": args.warmup, "settle": settle_steps, "stage_pass": stage_steps,
-                                                  "after_timer_swap": 1},
+            "untimed_steps_before_timed_region": {"warmup": args.warmup, "stage_pass": stage_steps, "settle": settle_steps,
+                                                  "order": "warm-up, settle (no host sync inside), stage pass, shorter settle, fence, timed region"},
         },
         "roofline": roof,
         "vector_issue_roofline": issue,
