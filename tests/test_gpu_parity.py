@@ -408,6 +408,39 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     assert torch.equal(o.cpu().long(), torch.searchsorted(tile[order].contiguous(), torch.arange(tw * th + 1)))
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_supertile_binning_fuzz_against_depth_first(seed, monkeypatch):
+    """Random image sizes (1 x 1 tiles ... 300 x 170), Gaussian counts (1 ... 200k), rectangle size mixes (points,
+    a few tiles, a tenth of the image), depth-tie densities and culled fractions through both binning paths:
+    `torch.equal` lists and ranges, with a speculative capacity, and with one that is too small."""
+    g = torch.Generator().manual_seed(1000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
+    tw, th = (ri(1, 12), ri(1, 12)) if seed % 4 == 0 else (ri(8, 300), ri(5, 170))
+    W, H = 16 * tw - ri(0, 15), 16 * th - ri(0, 15)
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    N = ri(1, 2000) if seed % 3 == 0 else ri(2000, 200_000)
+    x0 = torch.randint(0, tw, (N,), generator=g)
+    y0 = torch.randint(0, th, (N,), generator=g)
+    kind = torch.rand(N, generator=g)
+    big = max(2, tw // 3), max(2, th // 3)
+    w = torch.where(kind < 0.6, torch.randint(1, 4, (N,), generator=g), torch.randint(1, 9, (N,), generator=g))
+    h = torch.where(kind < 0.6, torch.randint(1, 4, (N,), generator=g), torch.randint(1, 9, (N,), generator=g))
+    huge = kind > 0.995
+    w = torch.where(huge, torch.randint(1, big[0] + 1, (N,), generator=g), w)
+    h = torch.where(huge, torch.randint(1, big[1] + 1, (N,), generator=g), h)
+    w, h = torch.minimum(w, tw - x0), torch.minimum(h, th - y0)
+    depth = torch.rand(N, generator=g) * 50 + 0.01
+    if seed % 2:
+        depth = depth[torch.randint(0, max(1, N // 50), (N,), generator=g)]  # runs of ~50 equal keys
+    keys = depth.float().view(torch.int32).clone()
+    cull = torch.rand(N, generator=g) < float(torch.rand(1, generator=g)) * 0.5
+    w[cull], h[cull] = 0, 0
+    keys[cull] = -1
+    rects = _pack_rects(x0, y0, w, h).to(DEV)
+    f, o = _supertile_vs_depth_first(N, W, H, rects, keys.to(DEV), monkeypatch, overflow=True)
+    assert int(o[-1]) == int((w * h).sum()) == f.numel()
+
+
 def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
     sc = _scene(n=20000, w=256, h=160, seed=17)
     t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
