@@ -569,9 +569,11 @@ def main(argv=None):
     # the two the roofline's duration needs -- and the stage table comes from this pass over the same views.
     stage_steps = min(args.steps, 24) if args.stage_events != "none" else 0
     ops.default_context.stage_timer = ops.StageTimer()
+    t_pass = time.perf_counter()  # (the device is busy with the settle steps: this interval includes their tail)
     for _ in range(stage_steps):
         step(timed=True)
     fence()
+    stage_pass_ms = (time.perf_counter() - t_pass) / max(stage_steps, 1) * 1e3
     stages = ops.default_context.stage_timer.summary() if stage_steps else {}
     ops.default_context.stage_timer = None
     kernel_names = ("fg_raster_bwd", "fg_raster_fwd", "fg_raster_composite_bwd", "fg_raster_composite_fwd",
@@ -765,10 +767,11 @@ def main(argv=None):
                                     "over_1.5x_median": sum(1 for x in d if x > 1.5 * sorted(d)[len(d) // 2])})(
             [(b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:])]),
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
+        "stage_pass_ms_per_step": round(stage_pass_ms, 4),
         "stage_ms_from": ("HIP events around every C-ABI call in the timed region" if args.stage_events == "all" else
                           f"{dominant}: HIP events in the timed region; the other stages: a pass of {stage_steps} steps over the "
-                          "same views with events around every call, run (untimed) right before the timed region -- sixteen "
-                          "event records per step cost ~0.06 ms of the step"),
+                          "same views with events around every call (untimed; stage_pass_ms_per_step is that pass's own wall "
+                          "time per step: sixteen event records per step cost a few percent of it)"),
     }  # fmt: skip
     if world > 1:
         xm = pct(t_xchg, 0.5)
