@@ -220,9 +220,9 @@ sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restri
 // threads x 8 values: the 8160 tiles of a 1080p frame are one trip through memory, not two ----------------------
 constexpr int SO_BLOCK = 1024, SO_WAVES = SO_BLOCK / 64, SO_PER = 8;
 __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
-                                                         uint32_t* wave_tot) {
+                                                         uint32_t* wave_tot, uint32_t* largest = nullptr) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  uint32_t carry = 0;
+  uint32_t carry = 0, big = 0;
   uint64_t total = 0;  // (the offsets are 32-bit; the total is reported in full so that the host can refuse a list it cannot index)
   for (int base = 0; base < n; base += SO_BLOCK * SO_PER) {
     uint32_t in[SO_PER];
@@ -232,7 +232,10 @@ __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restr
       in[k] = i < n ? (uint32_t)offs[i + 1] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < SO_PER; ++k) buf[k * SO_BLOCK + threadIdx.x] = in[k];
+    for (int k = 0; k < SO_PER; ++k) {
+      buf[k * SO_BLOCK + threadIdx.x] = in[k];
+      big = max(big, in[k]);
+    }
     __syncthreads();
     uint32_t v[SO_PER], sum = 0;
 #pragma unroll
@@ -271,6 +274,16 @@ __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) offs[0] = 0;
+  if (largest) {  // the largest count, for the caller's one thread that wants it (thread 0)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) big = max(big, (uint32_t)__shfl_xor((int)big, m));
+    __syncthreads();
+    if (lane == 0) wave_tot[wave] = big;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < SO_WAVES; ++k) big = max(big, wave_tot[k]);
+    *largest = big;
+  }
   return total;
 }
 __global__ void __launch_bounds__(SO_BLOCK)
@@ -279,7 +292,12 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
   __shared__ alignas(16) uint32_t buf[SO_BLOCK * SO_PER];
   __shared__ uint32_t wave_tot[SO_WAVES];
   if (blockIdx.x == 1) {  // (two workgroups: the two scans side by side)
-    scan_counts_in_place(S, st_offsets, buf, wave_tot);
+    uint32_t longest = 0;
+    scan_counts_in_place(S, st_offsets, buf, wave_tot, &longest);
+    if (threadIdx.x == 0 && count_out) {  // the longest supertile segment, beside the list length (the host's path choice)
+      __hip_atomic_store(count_out + 1, (int64_t)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      __threadfence_system();
+    }
     return;
   }
   const uint64_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);

@@ -132,6 +132,16 @@ class RasterContext:
         self.binning = e.get("FG_BINNING", "supertile")
         if self.binning not in ("supertile", "depthfirst"):
             raise ValueError(f"FG_BINNING={self.binning!r}: supertile | depthfirst")
+        # The supertile path sorts a segment in LDS up to 8064 elements; a longer one (a dense cluster: tens of
+        # thousands of splats over one 32 x 32-pixel supertile) goes through global memory in ONE workgroup --
+        # correct but slow (2.8 ms at a 111 000-entry tile).  fg_stbin_count reports the longest segment with the
+        # list length; a shape that showed such a segment is binned depth-first for the next
+        # `heavy_cooldown` calls, then probed again.  FG_ADAPTIVE_BINNING=0: always the configured path.
+        self.adaptive_binning = e.get("FG_ADAPTIVE_BINNING", "1") != "0"
+        self.heavy_segment = 8064
+        self.heavy_cooldown = 256
+        self.heavy_shapes = {}  # shape key -> calls left on the depth-first path
+        self.binning_fallbacks = 0  # calls that took the depth-first path because of a heavy segment seen earlier
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -400,38 +410,41 @@ _count_ring_stream = [None] * _COUNT_RING  # the stream the store into slot i wa
 
 
 def _count_slot():
+    """A slot of two pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
+    segment (fg_stbin_count only; stays -1 otherwise)."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
         if _count_ring is None:
-            _count_ring = torch.empty(_COUNT_RING, dtype=torch.int64, pin_memory=True)
+            _count_ring = torch.empty(2 * _COUNT_RING, dtype=torch.int64, pin_memory=True)
             _count_ring_np = _count_ring.numpy()
         i = _count_ring_next
         _count_ring_next = (i + 1) % _COUNT_RING
-    _count_ring_np[i] = -1
+    _count_ring_np[2 * i] = -1
+    _count_ring_np[2 * i + 1] = -1
     _count_ring_stream[i] = torch.cuda.current_stream()
-    return i, _count_ring.data_ptr() + 8 * i
+    return i, _count_ring.data_ptr() + 16 * i
 
 
-def _poll_count(i: int) -> int:
-    """Spin on ring slot i until the kernel's system-scope store arrives (it does while the GPU is
+def _poll_count(i: int, word: int = 0) -> int:
+    """Spin on a word of ring slot i until the kernel's system-scope store arrives (it does while the GPU is
     still busy with the emission and the tile sort: the wait is microseconds).  No event in the stream."""
-    a = _count_ring_np
-    v = int(a[i])
+    a, j = _count_ring_np, 2 * i + word
+    v = int(a[j])
     if v >= 0:
         return v
     t0 = time.perf_counter()
     while True:
         for _ in range(64):
-            v = int(a[i])
+            v = int(a[j])
             if v >= 0:
                 return v
         if time.perf_counter() - t0 > 0.02:
             break
     # not seen within 20 ms: drain the stream the store was enqueued on (not whatever is current now) and look again
     (_count_ring_stream[i] or torch.cuda.current_stream()).synchronize()
-    v = int(a[i])
+    v = int(a[j])
     if v < 0:
-        raise _lib.FgRasterError("the list length never arrived in pinned host memory (fg_bin_prepare_keys count_out)")
+        raise _lib.FgRasterError("the list length never arrived in pinned host memory (count_out of the binning call)")
     return v
 
 
@@ -481,7 +494,13 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     rctx = current()
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     if keys_rects is not None and rctx.binning == "supertile" and lib.fg_stbin_supported(N, tile_w, tile_h):
-        return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+        hkey = (dev, N, tile_w, tile_h)
+        left = rctx.heavy_shapes.get(hkey, 0) if rctx.adaptive_binning else 0
+        if left <= 0:
+            return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+        if static_capacity is None:  # (a captured graph keeps the path of the eager call that measured it)
+            rctx.heavy_shapes[hkey] = left - 1  # (0: the next call probes the supertile path again)
+        rctx.binning_fallbacks += 1
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -619,6 +638,10 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     def finish():
         if count_slot is not None:
             n_isects = _poll_count(count_slot)
+            if rctx.adaptive_binning and _poll_count(count_slot, 1) > rctx.heavy_segment:
+                if len(rctx.heavy_shapes) >= 256:
+                    rctx.heavy_shapes.pop(next(iter(rctx.heavy_shapes)))
+                rctx.heavy_shapes[(dev, N, tile_w, tile_h)] = rctx.heavy_cooldown
         else:
             ready.synchronize()
             n_isects = int(count_host[0])

@@ -150,8 +150,10 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * 7 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
  * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
- * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, the list length
- * with system scope (pinned host memory).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
+ * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, TWO words with
+ * system scope (pinned host memory): count_out[0] the list length, count_out[1] the longest supertile segment
+ * (segments beyond 8064 elements are sorted by one workgroup through global memory -- correct, slow: a host
+ * that sees them can take fg_bin_prepare_keys + fg_bin_emit_sort for that scene, as rasterization() does).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
  * list_offsets = 0 (empty lists: consumers enqueued speculatively behind the call walk nothing; the host then
  * repeats the call with exact buffers, the count workspace stays valid).  Consumers of flatten_ids read

@@ -47,4 +47,5 @@ offs = info["isect_offsets"].reshape(-1).long()
 lens = (torch.cat([offs[1:], torch.tensor([info["flatten_ids"].numel()], device=offs.device)]) - offs).float() if offs.numel() == info["tile_width"] * info["tile_height"] else (offs[1:] - offs[:-1]).float()
 print(json.dumps({"tail_fwd": os.environ.get("FG_RASTER_TAIL_FWD"), "tail_bwd": os.environ.get("FG_RASTER_TAIL_BWD"),
                   "I": info["flatten_ids"].numel(), "mean_len": float(lens.mean()), "max_len": float(lens.max()),
-                  "step_ms": round(dt, 4), "fwd": st.get("fg_raster_fwd"), "bwd": st.get("fg_raster_bwd")}))
+                  "step_ms": round(dt, 4), "fwd": st.get("fg_raster_fwd"), "bwd": st.get("fg_raster_bwd"),
+                  "binning": os.environ.get("FG_BINNING", "supertile"), "stages": {k: round(v, 4) for k, v in st.items()}}))

@@ -408,6 +408,46 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     assert torch.equal(o.cpu().long(), torch.searchsorted(tile[order].contiguous(), torch.arange(tw * th + 1)))
 
 
+def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
+    """fg_stbin_count reports the longest supertile segment beside the list length; a shape that showed one beyond
+    the LDS sorts' capacity (a dense cluster) is binned depth-first for the next `heavy_cooldown` calls, then
+    probed again.  Same lists either way."""
+    g = torch.Generator().manual_seed(77)
+    W, H, N = 640, 400, 60_000
+    tw, th = W // 16, H // 16
+    x0 = torch.randint(0, tw, (N,), generator=g)
+    y0 = torch.randint(0, th, (N,), generator=g)
+    w = torch.minimum(torch.randint(1, 4, (N,), generator=g), tw - x0)
+    h = torch.minimum(torch.randint(1, 4, (N,), generator=g), th - y0)
+    x0[:30000], y0[:30000], w[:30000], h[:30000] = 10, 6, 2, 2  # 30 000 entries in one supertile
+    keys = (torch.rand(N, generator=g) * 9 + 0.5).view(torch.int32).clone()
+    rects = _pack_rects(x0, y0, w, h).to(DEV)
+    z = torch.zeros(N, device=DEV)
+    args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
+    ctx = ops.RasterContext()
+    ctx.heavy_cooldown = 3
+    light = ops.RasterContext()
+    light.adaptive_binning = False
+    with ops.use(light):
+        ref = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
+    assert light.binning_fallbacks == 0
+    with ops.use(ctx):
+        runs = [ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False) for _ in range(6)]
+    # call 0 sees the heavy segment (supertile path), calls 1-3 run depth-first, call 4 probes again, call 5 depth-first
+    assert ctx.binning_fallbacks == 4 and len(ctx.heavy_shapes) == 1
+    for _, f, o in runs:
+        assert torch.equal(f, ref[1]) and torch.equal(o, ref[2])
+    # a light scene never leaves the supertile path
+    x0[:30000] = torch.randint(0, tw - 1, (30000,), generator=g)
+    y0[:30000] = torch.randint(0, th - 1, (30000,), generator=g)
+    rects = _pack_rects(x0, y0, w, h).to(DEV)
+    ctx2 = ops.RasterContext()
+    with ops.use(ctx2):
+        for _ in range(3):
+            ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
+    assert ctx2.binning_fallbacks == 0 and not ctx2.heavy_shapes
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_supertile_binning_fuzz_against_depth_first(seed, monkeypatch):
     """Random image sizes (1 x 1 tiles ... 300 x 170), Gaussian counts (1 ... 200k), rectangle size mixes (points,
