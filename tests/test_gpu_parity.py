@@ -425,6 +425,8 @@ def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
     z = torch.zeros(N, device=DEV)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     ctx = ops.RasterContext()
+    if ctx.binning != "supertile" or not ctx.direct_count or not ctx.adaptive_binning:
+        pytest.skip("the environment selects another binning path / no count word / no adaptive choice")
     ctx.heavy_cooldown = 3
     light = ops.RasterContext()
     light.adaptive_binning = False
