@@ -33,7 +33,7 @@ with torch.no_grad():
     gp["features_dc"].copy_(sc.colors[:, 0])
     gp["features_rest"].copy_(sc.colors[:, 1:])
 model = model.to(dev).train()
-model.step = 3000  # SH degree 3
+model.step = int(os.environ.get("FG_MODEL_STEP", "3000"))  # SH degree = step // 1000, 3 from step 3000 on
 w2c = sc.viewmats[0]
 c2w = torch.linalg.inv(w2c)
 c2w[:3, 1:3] *= -1  # OpenCV -> OpenGL (get_viewmat flips back)
