@@ -825,6 +825,8 @@ class _Preprocess(torch.autograd.Function):
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
         depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
+        if ctx.rctx.color_grad_sink is not None and sh_degree >= 0 and colors is not None:
+            ctx.rctx.color_grad_sink("view", viewmat, dev)  # (view-DP: the factored exchange prepares its payload)
         sh_jac = None  # the forward's note for the backward of the SH colour (include/fgraster.h, fg_preprocess_fwd)
         if ctx.rctx.overlap_pack and len(cfg) > 10 and cfg[10]:
             main = torch.cuda.current_stream()
@@ -1123,6 +1125,8 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
                   _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas),
                   _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
+        if ctx.rctx.color_grad_sink is not None and C >= 3:
+            ctx.rctx.color_grad_sink("records", splats, v_splats)  # (view-DP: the colour gradient can leave now)
         # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
         v_means2d = v_splats[:, 0:2].view(m2_shape)
         if absgrad and ctx.means2d_ref is not None:

@@ -117,8 +117,9 @@ class FlatGaussianParams:
         (44 B), and (3) every rank rebuilds ``sum_views basis (x) g`` locally with
         ``fg_sh_grad_accumulate`` -- 192 B per Gaussian that never cross xGMI.  At 8 ranks and 1M
         Gaussians that is 84 MB received + a 44 MB all-reduce instead of a 236 MB all-reduce.
-        The all-gather is issued from inside the backward (as soon as ``g`` exists) and the
-        local rebuild overlaps the small all-reduce.  On exit every ``.grad`` holds the (averaged)
+        The all-gather is issued from inside the backward as soon as ``g`` exists -- with shared means that is
+        right behind the raster backward, under the per-Gaussian backward -- and the local rebuild overlaps the
+        small all-reduce.  On exit every ``.grad`` holds the (averaged)
         sum over ranks, exactly as after ``all_reduce_grads`` up to fp32 summation order.
 
         ``per_view_means=True``: the ranks render different positions of the same Gaussians
@@ -136,16 +137,7 @@ class FlatGaussianParams:
         pf = 6 if per_view_means else 3
         stride = n * 6 if per_view_means else (n + 1) * 3
 
-        def sink(what, *a):
-            if what == "alloc":
-                state["payload"] = torch.empty(stride, device=self.flat.device, dtype=torch.float32)
-                return state["payload"][: pf * n].view(n, pf)
-            _v_rgb, means, viewmat, sh_degree, colors = a
-            payload = state["payload"]
-            if not per_view_means:
-                vm = viewmat.reshape(-1, 4)[:3]
-                payload[3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
-            state.update(means=means, sh_degree=int(sh_degree), k_stored=int(colors.shape[1]))
+        def gather(payload):
             if world > 1:
                 gathered = torch.empty(world * stride, device=payload.device, dtype=torch.float32)
                 if dist.get_backend(group) == "nccl":
@@ -156,6 +148,43 @@ class FlatGaussianParams:
                 state["gathered"] = gathered
             else:
                 state["gathered"] = payload
+
+        def sink(what, *a):
+            """Protocol with ops: "view" (per-Gaussian forward: the view is known), "records" (raster backward: the
+            record gradients are final), "alloc" / "ready" (per-Gaussian backward, around fg_preprocess_bwd_factored)."""
+            if what == "view":  # shared means: the camera position can be put in place during the forward
+                if not per_view_means:
+                    viewmat, dev = a
+                    state["payload"] = torch.empty(stride, device=dev, dtype=torch.float32)
+                    vm = viewmat.reshape(-1, 4)[:3]
+                    state["payload"][3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
+                    state["early"] = True
+                return None
+            if what == "records":
+                # g = clamp-masked colour gradient is FINAL as soon as the raster backward is: the record's colour is
+                # max(sh + 0.5, 0), so the mask is (colour > 0), and slots 8..10 of the gradient record are dL/dcolour.
+                # Its all-gather starts here, under the per-Gaussian backward, instead of behind it.
+                if state.get("early") and not state.get("sent"):
+                    splats, v_splats = a
+                    g = state["payload"][: 3 * n].view(n, 3)
+                    torch.where(splats[:, 6:9] > 0, v_splats[:, 8:11], torch.zeros((), device=g.device), out=g)
+                    gather(state["payload"])
+                    state["sent"] = True
+                return None
+            if what == "alloc":
+                if state.get("sent"):  # the payload is in flight: the kernel's own copy of g goes to a scratch array
+                    return torch.empty(n, pf, device=self.flat.device, dtype=torch.float32)
+                state["payload"] = torch.empty(stride, device=self.flat.device, dtype=torch.float32)
+                return state["payload"][: pf * n].view(n, pf)
+            _v_rgb, means, viewmat, sh_degree, colors = a
+            state.update(means=means, sh_degree=int(sh_degree), k_stored=int(colors.shape[1]))
+            if state.get("sent"):
+                return None
+            payload = state["payload"]
+            if not per_view_means:
+                vm = viewmat.reshape(-1, 4)[:3]
+                payload[3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
+            gather(payload)
 
         @contextlib.contextmanager
         def cm():
