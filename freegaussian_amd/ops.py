@@ -161,6 +161,9 @@ class RasterContext:
         # FG_SH_JAC=0: the per-Gaussian backward reads the SH coefficient rows again (192 B per Gaussian) instead of
         # the 40-byte note (d colour / d direction + clamp mask) the forward leaves for it.
         self.sh_jacobian = e.get("FG_SH_JAC", "1") != "0"
+        # FG_JOBS_SIDE_STREAM=1: the raster job lists (fg_raster_build_jobs: 16 workgroups, 9 us) are built on a side
+        # stream from the EXACT tile ranges as soon as fg_stbin_count has them, beside the scatter and the sorts.
+        self.jobs_side_stream = e.get("FG_JOBS_SIDE_STREAM", "0") == "1"
         # Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
         # written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
         # The kernels overwrite their outputs densely, so the buffer needs no zeroing.
@@ -607,6 +610,10 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
     _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
+    if rctx.jobs_side_stream and not static:
+        counted = torch.cuda.Event()
+        counted.record()
+        offsets._fg_exact = (tile_offsets, counted)  # (for _RasterSplats: job lists on a side stream)
 
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -1068,8 +1075,20 @@ class _RasterSplats(torch.autograd.Function):
             # the forward launch instead of a fill launch at the head of the backward
             if ctx.rctx.fill_in_forward and expect_backward:
                 v_splats = torch.empty(splats.shape[0], SPLAT_FLOATS, dtype=torch.float32, device=dev)
-            _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
-                  int(seg_ckpt is not None), cfgp, _stream())  # fmt: skip
+            exact = getattr(tile_offsets, "_fg_exact", None) if ctx.rctx.jobs_side_stream else None
+            if exact is not None:
+                main, side = torch.cuda.current_stream(), _side_stream(dev)
+                side.wait_event(exact[1])
+                _call("fg_raster_build_jobs", width, height, tile_size, _ptr(exact[0]), _ptr(jobs[0]), _ptr(jobs[1]),
+                      int(seg_ckpt is not None), cfgp, side.cuda_stream, on=side)  # fmt: skip
+                built = torch.cuda.Event()
+                built.record(side)
+                jobs.record_stream(side)
+                exact[0].record_stream(side)
+                main.wait_event(built)
+            else:
+                _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
+                      int(seg_ckpt is not None), cfgp, _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
                   _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _ptr(v_splats),
