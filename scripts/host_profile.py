@@ -36,4 +36,4 @@ for _ in range(200):
 torch.cuda.synchronize()
 pr.disable()
 st = pstats.Stats(pr)
-st.sort_stats("tottime").print_stats(28)
+st.sort_stats(os.environ.get("FG_PROF_SORT", "tottime")).print_stats(int(os.environ.get("FG_PROF_N", "28")))
