@@ -872,7 +872,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   const StripBounds sb = strip_bounds((float)(tile_x * TILE), (float)(tile_y * TILE));
   const unsigned my_strips = wave_strips<PPT>(wave);
 
-  float T[PPT], tva[PPT], vr[PPT][C], bsum[PPT];
+  float T[PPT], rest[PPT], vr[PPT][C];
   const float pyb = (float)(tile_y * TILE + (int)(threadIdx.x >> 4) - 4 * wl) + 0.5f;  // see slot_dy
   int last[PPT];
   int my_max = start - 1;
@@ -986,7 +986,6 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     last[k] = inside ? raw[k].last : start - 1;
     float va = inside ? raw[k].va : 0.f;
     const unsigned blocked = inside ? raw[k].blocked : 0u;
-    bsum[k] = 0.f;
 #pragma unroll
     for (int c = 0; c < C; ++c) {
       float v = inside ? raw[k].v[c] : 0.f;
@@ -994,7 +993,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
       if (comp.background) va -= v * comp.background[c];  // d/dalpha of (1 - alpha) * bg
       vr[k][c] = v;
     }
-    tva[k] = T[k] * va;  // T_final * dL/dalpha
+    rest[k] = T[k] * va;  // T_final * dL/dalpha, minus the composited suffix of a resumed pixel (below)
     if constexpr (C == 3 && NW == 1) {
       if (from_ckpt) {
         // (last >= hi implies the pixel is inside the image)
@@ -1012,7 +1011,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         // rho: the reference's rounded T_final over the exact one (seg_plane_offset4)
         const float rho = T[k] * __builtin_amdgcn_rcpf(fmaxf(tfe[k], 1e-30f));
         T[k] = resume ? ckv[k].x * rho : T[k];
-        bsum[k] = resume ? sfx * rho : 0.f;
+        rest[k] -= resume ? sfx * rho : 0.f;
       }
     }
     my_max = max(my_max, last[k]);
@@ -1143,27 +1142,24 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
       g[8 + c] += fac * vr[K][c];                                                                       \
       cdot += f[c] * vr[K][c];                                                                          \
     }                                                                                                   \
-    const float v_alpha = (cdot * T[K] - bsum[K] * ra) + tva[K] * ra;                                   \
-    bsum[K] += cdot * fac;                                                                              \
+    /* rest[K] = T_final dL/dalpha - (what the entries behind this one composited, dotted with dL/dC) */ \
+    const float v_alpha = fmaf(cdot, T[K], rest[K] * ra);                                               \
+    rest[K] = fmaf(-cdot, fac, rest[K]);                                                                \
     const uint64_t open = (VALID) & lanes_ole(ov, FG_ALPHA_MAX); /* alpha not clamped: gradient flows */ \
     const float v_o = lane_select0(open, (VIS) * v_alpha);       /* d/d opacity */                      \
     const float v_sigma = -s.o * v_o;                                                                   \
     g[2] += v_o;                                                                                        \
-    /* dx is the same for all pixel slots of a lane: the conic gradient needs only the moments S0 = sum \
-       v_sigma, S1 = sum v_sigma dy, S2 = sum v_sigma dy^2 per entry (g[3..5], zero at the start of     \
-       every contributing entry) -- finished below */                                                    \
+    /* dx is the same for all pixel slots of a lane: the conic and the mean gradients need only the     \
+       moments S0 = sum v_sigma (= -o g[2]), S1 = sum v_sigma dy, S2 = sum v_sigma dy^2 per entry       \
+       (g[4], g[5], zero at the start of every contributing entry) -- finished below */                 \
     const float vsdy = v_sigma * dy;                                                                    \
-    g[3] += v_sigma;                                                                                    \
     g[4] += vsdy;                                                                                       \
     g[5] = fmaf(vsdy, dy, g[5]);                                                                        \
-    const float gx = v_sigma * (s.a * dx + s.b * dy);                                                   \
-    const float gy = v_sigma * (s.b * dx + s.c * dy);                                                   \
-    g[0] += gx;                                                                                         \
-    g[1] += gy;                                                                                         \
-    g[6] += fabsf(gx); /* absgrad sums |.| per pixel: not a moment */                                   \
-    g[7] += fabsf(gy);                                                                                  \
+    g[6] += fabsf(v_sigma * fmaf(s.b, dy, adx)); /* absgrad sums |.| per pixel: not a moment */         \
+    g[7] += fabsf(v_sigma * fmaf(s.c, dy, bdx));                                                        \
   } while (0)
         bool contributed = false;
+        const float adx = s.a * dx, bdx = s.b * dx;
         if constexpr (LIVE) {
           // The forward recorded which (entry, strip) pairs had a contributing pixel (live_words): only
           // those are evaluated -- no exponential, no compares for the others.
@@ -1205,10 +1201,15 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         }
 #undef FG_BWD_SLOT_UPDATE
         if (!contributed) continue;  // wave-uniform: only ever set under the uniform any-valid branches
-        // v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
-        g[5] *= 0.5f;
-        g[4] *= dx;
-        g[3] *= 0.5f * dx * dx;
+        // v_mean2d = (a dx S0 + b S1, b dx S0 + c S1), v_conic = (1/2 dx^2 S0, dx S1, 1/2 S2)
+        {
+          const float s0 = -s.o * g[2], s1 = g[4];
+          g[0] = fmaf(s.b, s1, adx * s0);
+          g[1] = fmaf(s.c, s1, bdx * s0);
+          g[3] = (0.5f * dx * dx) * s0;
+          g[4] = dx * s1;
+          g[5] *= 0.5f;
+        }
         FG_STAT(4, 1);
 #if FG_BWD_LDS_REDUCE
         (void)lds_red;
@@ -1238,10 +1239,11 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
             __hip_atomic_fetch_add(dst, total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           }
         }
-        // only the accumulators this channel count ever writes need clearing (8 + C of the 16);
-        // two at a time with v_mov_b64 where they pair up
+        // only the accumulators the slot updates add to need clearing (g[2], g[4 .. 8 + C); g[0], g[1], g[3]
+        // are assigned per entry); two at a time with v_mov_b64 where they pair up
+        asm volatile("v_mov_b32 %0, 0" : "=v"(g[2]));
 #pragma unroll
-        for (int q = 0; q + 1 < 8 + C; q += 2) {
+        for (int q = 4; q + 1 < 8 + C; q += 2) {
           struct F2 { float a, b; };
           double z;
           asm volatile("v_mov_b64 %0, 0" : "=v"(z));
