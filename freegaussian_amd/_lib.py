@@ -44,6 +44,8 @@ SIGNATURES = {
     "fg_stbin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
     "fg_stbin_fill_workspace_bytes": (c_size_t, [c_int64]),
     "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
+    "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
+                                   c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     # (the pointer before the stream of every raster entry point is the `const fg_raster_config*`)
@@ -86,7 +88,7 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None
 

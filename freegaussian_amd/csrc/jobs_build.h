@@ -1,0 +1,174 @@
+// Job lists of the raster launches: the device code that builds them and the plan the host derives from a
+// fg_raster_config.  Shared by raster.hip (fg_raster_build_jobs: a launch of its own) and stbin.hip
+// (fg_stbin_fill_jobs: sixteen extra workgroups at the head of the large-segment sort launch, so that no launch
+// stands between the sorted lists and the raster forward).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/fgraster.h"
+
+namespace fgjobs {
+
+// The eight XCDs' shares of the tile grid in the mixed launches: an nx x (8 / nx) arrangement of
+// rectangles, one per XCD, each walked column-major (a tile and its vertical neighbours, which share
+// most of their splats, run back to back in one L2).  nx = 1 (whole-row bands) is what runs; the other
+// arrangements are an A/B knob (band_nx).
+struct Band {
+  int c0, ncols, r0, nrows;
+};
+__host__ __device__ __forceinline__ Band band_of_xcd(int xcd, int tile_w, int tile_h, int nx) {
+  const int ny = 8 / nx, rx = xcd % nx, ry = xcd / nx;
+  Band b;
+  b.c0 = (rx * tile_w) / nx;
+  b.ncols = ((rx + 1) * tile_w) / nx - b.c0;
+  b.r0 = (ry * tile_h) / ny;
+  b.nrows = ((ry + 1) * tile_h) / ny - b.r0;
+  return b;
+}
+__device__ __forceinline__ int band_tile(const Band& b, int idx, int tile_w) {
+  const int col = idx / b.nrows;
+  return (b.r0 + idx - col * b.nrows) * tile_w + b.c0 + col;
+}
+
+
+// Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
+// whose list is longer than total * a4 / 65536 becomes four single-strip jobs, longer than
+// total * a2 / 65536 two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
+// mean, scripts/clustered_check.py) whole-tile jobs for those tiles made the forward 0.81 ms; every
+// tile in quarters 0.39 ms.  Layout of a list (int32): [0..7] jobs per XCD, then 8 segments of
+// `cap` = 8 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
+// column-major order.  (Giving every tile four workgroups and letting the unused ones return was
+// tried first: the empty workgroups in front of live ones cost the forward 0.218 -> 0.275 ms, and
+// with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
+// forward lists: bit 30 of an entry = "the backward will not cut this tile's list into shares": the
+// forward then writes no compositing checkpoints for it
+constexpr int FG_JOB_NO_CKPT = 1 << 30;
+struct JobParams {
+  int tail4, tail2, s4, s2;
+  int max_jobs;  // workgroups per XCD of the launch that will read the list
+  // list shares instead of pixel strips (the segmented backward, struct Segments): the last seg_tail
+  // tiles of the sequence become seg_parts jobs each, a tile longer than the s2 threshold as many
+  // jobs (up to 16) as make its shares about half that threshold long; entry = tile << 8 | part << 4 |
+  // (parts - 1), the part numbers rotated by the tile's position
+  int seg_parts, seg_tail;
+  // graded tail: the last seg_tail2 (<= seg_tail) tiles get seg_parts2 (>= seg_parts) jobs -- the jobs
+  // that run while the launch drains are the shortest ones
+  int seg_parts2, seg_tail2;
+};
+__device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
+                                         int thr2, int len) {
+  if (p.seg_parts > 1) {
+    int c = idx >= n - min(p.seg_tail, n) ? p.seg_parts : 1;
+    if (idx >= n - min(p.seg_tail2, n)) c = max(c, p.seg_parts2);
+    if (len > thr2) {
+      const int share = max(thr2 >> 1, 1);
+      c = max(c, min(16, (len + share - 1) / share));
+    }
+    return c;
+  }
+  int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
+  level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
+  return 1 << level;
+}
+// what one build needs on the device (kernel argument, by value)
+struct JobBuild {
+  int tile_w, tile_h, nx, cap;
+  JobParams pf, pb;
+  int32_t* jobs_fwd;
+  int32_t* jobs_bwd;
+};
+constexpr int FG_JOB_BLOCKS = 16;  // workgroups of one build: 8 XCD bands x (forward list, backward list)
+
+// host: fill `out` for fg_raster_build_jobs' arguments (raster.hip, where the launch policy lives);
+// FG_OK and out->jobs_fwd == out->jobs_bwd == nullptr when there is nothing to build
+__attribute__((visibility("hidden"))) int plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
+              const fg_raster_config* config, JobBuild* out);
+
+// workgroup `block` (0 .. FG_JOB_BLOCKS) of a build, NTH threads (a multiple of 64, all of the workgroup)
+template <int NTH>
+__device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, const int32_t* __restrict__ tile_offsets) {
+  constexpr int NWV = NTH / 64;
+  __shared__ int wave_tot[NWV];
+  __shared__ int carry;
+  const int xcd = block & 7;
+  const bool bwd = block >= 8;
+  const int tile_w = jb.tile_w, tile_h = jb.tile_h, cap = jb.cap;
+  const JobParams &pf = jb.pf, &pb = jb.pb;
+  int32_t* jobs = bwd ? jb.jobs_bwd : jb.jobs_fwd;
+  if (!jobs) return;
+  const JobParams p = bwd ? pb : pf;
+  const Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);
+  const int n = band.nrows * band.ncols;
+  const int total = tile_offsets[tile_w * tile_h];
+  const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
+  // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
+  int thr4 = p.s4 ? (int)(((int64_t)total * p.s4) >> 16) : 0x7fffffff;
+  int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
+  const int thr2_b = pb.s2 ? (int)(((int64_t)total * pb.s2) >> 16) : 0x7fffffff;  // the backward's, as given
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
+  // it does; the positional jobs alone always fit
+  for (int round = 0; round < 12; ++round) {
+    int mine = 0;
+    for (int idx = threadIdx.x; idx < n; idx += NTH) {
+      const int tile = band_tile(band, idx, tile_w);
+      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
+    __syncthreads();
+    if (lane == 0) wave_tot[wave] = mine;
+    __syncthreads();
+    int all = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) all += wave_tot[w];
+    if (all <= p.max_jobs) break;  // uniform across the workgroup
+    thr4 = thr4 > 0x50000000 ? 0x7fffffff : thr4 + (thr4 >> 1) + 1;
+    thr2 = thr2 > 0x50000000 ? 0x7fffffff : thr2 + (thr2 >> 1) + 1;
+    if (round == 10) thr4 = thr2 = 0x7fffffff;
+  }
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  int32_t* seg = jobs + 8 + (size_t)xcd * cap;
+  for (int base = 0; base < n; base += NTH) {
+    const int idx = base + (int)threadIdx.x;
+    int cnt = 0, tile = 0, flag = 0;
+    if (idx < n) {
+      tile = band_tile(band, idx, tile_w);
+      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
+      // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
+      // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
+      if (!bwd && pb.seg_parts > 1 && job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1) flag = FG_JOB_NO_CKPT;
+    }
+    int incl = cnt;
+#pragma unroll
+    for (int k = 1; k < 64; k <<= 1) {
+      const int o = __shfl_up(incl, k);
+      if (lane >= k) incl += o;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int pos = carry + incl - cnt;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w)
+      if (w < wave) pos += wave_tot[w];
+    if (p.seg_parts > 1) {
+      for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 8 | ((j + idx) % cnt) << 4 | (cnt - 1);
+    } else if (cnt == 1) seg[pos] = tile << 3 | flag;  // strip -1
+    else if (cnt == 2) { seg[pos] = tile << 3 | 5 | flag; seg[pos + 1] = tile << 3 | 6 | flag; }  // strip 4, 5
+    else if (cnt == 4) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1) | flag;  // strip 0..3
+    }
+    __syncthreads();
+    if (threadIdx.x == NTH - 1) carry = pos + cnt;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) jobs[xcd] = carry;
+}
+
+}  // namespace fgjobs

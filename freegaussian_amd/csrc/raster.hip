@@ -24,7 +24,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "jobs_build.h"
+
 namespace {
+using namespace fgjobs;
 
 constexpr int TILE = 16;
 
@@ -89,27 +92,6 @@ __device__ __forceinline__ int tile_of_block(int b, int n, int tile_w, int tile_
   return first + k;
 }
 
-// The eight XCDs' shares of the tile grid in the mixed launches: an nx x (8 / nx) arrangement of
-// rectangles, one per XCD, each walked column-major (a tile and its vertical neighbours, which share
-// most of their splats, run back to back in one L2).  nx = 1 (whole-row bands) is what runs; the other
-// arrangements are an A/B knob (band_nx).
-struct Band {
-  int c0, ncols, r0, nrows;
-};
-__host__ __device__ __forceinline__ Band band_of_xcd(int xcd, int tile_w, int tile_h, int nx) {
-  const int ny = 8 / nx, rx = xcd % nx, ry = xcd / nx;
-  Band b;
-  b.c0 = (rx * tile_w) / nx;
-  b.ncols = ((rx + 1) * tile_w) / nx - b.c0;
-  b.r0 = (ry * tile_h) / ny;
-  b.nrows = ((ry + 1) * tile_h) / ny - b.r0;
-  return b;
-}
-__device__ __forceinline__ int band_tile(const Band& b, int idx, int tile_w) {
-  const int col = idx / b.nrows;
-  return (b.r0 + idx - col * b.nrows) * tile_w + b.c0 + col;
-}
-
 // Mixed launch: job k of XCD x.  The XCD's tiles are those of tile_of_block mode 2 (a band of whole
 // tile rows, column-major); the first n - tail of them are whole-tile jobs (strip = -1), each of
 // the last `tail` is four single-strip jobs.  Why: a tile's list is walked serially by its
@@ -141,126 +123,9 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int n
   return band_tile(band, idx, tile_w);
 }
 
-// Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
-// whose list is longer than total * a4 / 65536 becomes four single-strip jobs, longer than
-// total * a2 / 65536 two two-strip jobs.  On a scene with half of the Gaussians in a small ball (longest list 20x the
-// mean, scripts/clustered_check.py) whole-tile jobs for those tiles made the forward 0.81 ms; every
-// tile in quarters 0.39 ms.  Layout of a list (int32): [0..7] jobs per XCD, then 8 segments of
-// `cap` = 8 x (tiles of the largest XCD band) entries, entry = tile << 3 | (strip + 1) in the XCD's
-// column-major order.  (Giving every tile four workgroups and letting the unused ones return was
-// tried first: the empty workgroups in front of live ones cost the forward 0.218 -> 0.275 ms, and
-// with the live one always in slot 0 every whole-tile job landed on the same SIMD of its CU.)
-// forward lists: bit 30 of an entry = "the backward will not cut this tile's list into shares": the
-// forward then writes no compositing checkpoints for it
-constexpr int FG_JOB_NO_CKPT = 1 << 30;
-struct JobParams {
-  int tail4, tail2, s4, s2;
-  int max_jobs;  // workgroups per XCD of the launch that will read the list
-  // list shares instead of pixel strips (the segmented backward, struct Segments): the last seg_tail
-  // tiles of the sequence become seg_parts jobs each, a tile longer than the s2 threshold as many
-  // jobs (up to 16) as make its shares about half that threshold long; entry = tile << 8 | part << 4 |
-  // (parts - 1), the part numbers rotated by the tile's position
-  int seg_parts, seg_tail;
-  // graded tail: the last seg_tail2 (<= seg_tail) tiles get seg_parts2 (>= seg_parts) jobs -- the jobs
-  // that run while the launch drains are the shortest ones
-  int seg_parts2, seg_tail2;
-};
-__device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
-                                         int thr2, int len) {
-  if (p.seg_parts > 1) {
-    int c = idx >= n - min(p.seg_tail, n) ? p.seg_parts : 1;
-    if (idx >= n - min(p.seg_tail2, n)) c = max(c, p.seg_parts2);
-    if (len > thr2) {
-      const int share = max(thr2 >> 1, 1);
-      c = max(c, min(16, (len + share - 1) / share));
-    }
-    return c;
-  }
-  int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
-  level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
-  return 1 << level;
-}
 __global__ void __launch_bounds__(1024)
-build_jobs_kernel(int tile_w, int tile_h, int nx, int cap, const int32_t* __restrict__ tile_offsets, JobParams pf,
-                  JobParams pb, int32_t* __restrict__ jobs_fwd, int32_t* __restrict__ jobs_bwd) {
-  constexpr int NTH = 1024, NWV = NTH / 64;
-  __shared__ int wave_tot[NWV];
-  __shared__ int carry;
-  const int xcd = blockIdx.x & 7;
-  const bool bwd = blockIdx.x >= 8;
-  int32_t* jobs = bwd ? jobs_bwd : jobs_fwd;
-  if (!jobs) return;
-  const JobParams p = bwd ? pb : pf;
-  const Band band = band_of_xcd(xcd, tile_w, tile_h, nx);
-  const int n = band.nrows * band.ncols;
-  const int total = tile_offsets[tile_w * tile_h];
-  const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
-  // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
-  int thr4 = p.s4 ? (int)(((int64_t)total * p.s4) >> 16) : 0x7fffffff;
-  int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
-  const int thr2_b = pb.s2 ? (int)(((int64_t)total * pb.s2) >> 16) : 0x7fffffff;  // the backward's, as given
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
-  // it does; the positional jobs alone always fit
-  for (int round = 0; round < 12; ++round) {
-    int mine = 0;
-    for (int idx = threadIdx.x; idx < n; idx += NTH) {
-      const int tile = band_tile(band, idx, tile_w);
-      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
-    }
-#pragma unroll
-    for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
-    __syncthreads();
-    if (lane == 0) wave_tot[wave] = mine;
-    __syncthreads();
-    int all = 0;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) all += wave_tot[w];
-    if (all <= p.max_jobs) break;  // uniform across the workgroup
-    thr4 = thr4 > 0x50000000 ? 0x7fffffff : thr4 + (thr4 >> 1) + 1;
-    thr2 = thr2 > 0x50000000 ? 0x7fffffff : thr2 + (thr2 >> 1) + 1;
-    if (round == 10) thr4 = thr2 = 0x7fffffff;
-  }
-  if (threadIdx.x == 0) carry = 0;
-  __syncthreads();
-  int32_t* seg = jobs + 8 + (size_t)xcd * cap;
-  for (int base = 0; base < n; base += NTH) {
-    const int idx = base + (int)threadIdx.x;
-    int cnt = 0, tile = 0, flag = 0;
-    if (idx < n) {
-      tile = band_tile(band, idx, tile_w);
-      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
-      // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
-      // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
-      if (!bwd && pb.seg_parts > 1 && job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1) flag = FG_JOB_NO_CKPT;
-    }
-    int incl = cnt;
-#pragma unroll
-    for (int k = 1; k < 64; k <<= 1) {
-      const int o = __shfl_up(incl, k);
-      if (lane >= k) incl += o;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int pos = carry + incl - cnt;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w)
-      if (w < wave) pos += wave_tot[w];
-    if (p.seg_parts > 1) {
-      for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 8 | ((j + idx) % cnt) << 4 | (cnt - 1);
-    } else if (cnt == 1) seg[pos] = tile << 3 | flag;  // strip -1
-    else if (cnt == 2) { seg[pos] = tile << 3 | 5 | flag; seg[pos + 1] = tile << 3 | 6 | flag; }  // strip 4, 5
-    else if (cnt == 4) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1) | flag;  // strip 0..3
-    }
-    __syncthreads();
-    if (threadIdx.x == NTH - 1) carry = pos + cnt;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) jobs[xcd] = carry;
+build_jobs_kernel(fgjobs::JobBuild jb, const int32_t* __restrict__ tile_offsets) {
+  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets);
 }
 
 // job k of XCD (b & 7) from a list; tile or -1
@@ -1854,12 +1719,11 @@ extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, co
   return 8 + 8 * (int64_t)jobs_cap(cfg, tile_w, tile_h);
 }
 
-extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
-                                    int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
-                                    const fg_raster_config* config, fg_stream_t stream) {
+int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
+                      const fg_raster_config* config, fgjobs::JobBuild* out) {
+  out->jobs_fwd = out->jobs_bwd = nullptr;
   if (width <= 0 || height <= 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
-  if (!tile_offsets) return FG_ERR_INVALID_ARG;
   if (!jobs_fwd && !jobs_bwd) return FG_OK;
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int n_tiles = tile_w * tile_h;
@@ -1876,8 +1740,19 @@ extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const 
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(cfg, tile_w, tile_h, sp, st, true) / 8, sp, st,
                                           seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
-  hipLaunchKernelGGL(build_jobs_kernel, dim3(16), dim3(1024), 0, fg_hip_stream(stream), tile_w, tile_h, band_nx(cfg),
-                     jobs_cap(cfg, tile_w, tile_h), tile_offsets, pf, pb, jobs_fwd, jobs_bwd);
+  *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd};
+  return FG_OK;
+}
+
+extern "C" int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
+                                    int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
+                                    const fg_raster_config* config, fg_stream_t stream) {
+  if (!tile_offsets) return FG_ERR_INVALID_ARG;
+  fgjobs::JobBuild jb;
+  const int rc = fgjobs::plan_jobs(width, height, tile_size, jobs_fwd, jobs_bwd, bwd_list_shares, config, &jb);
+  if (rc != FG_OK) return rc;
+  if (!jb.jobs_fwd && !jb.jobs_bwd) return FG_OK;
+  hipLaunchKernelGGL(build_jobs_kernel, dim3(fgjobs::FG_JOB_BLOCKS), dim3(1024), 0, fg_hip_stream(stream), jb, tile_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -20,6 +20,7 @@
 // all eight L2s -- 62 + 95 MB of fabric reads for 12 MB of data, and that, not the stores, bounded both kernels.)
 // The sort deals supertiles to the XCDs round-robin.
 #include "fg_common.h"
+#include "jobs_build.h"
 
 namespace {
 
@@ -900,12 +901,19 @@ __global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
 sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
                      const int32_t* __restrict__ st_offsets, const int32_t* __restrict__ large_list,
                      uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, long long capacity,
-                     int32_t* __restrict__ flatten_ids) {
+                     int32_t* __restrict__ flatten_ids, int job_blocks, fgjobs::JobBuild jb) {
   __shared__ SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS> sh;
+  // fg_stbin_fill_jobs: the first job_blocks workgroups build the raster launches' job lists from the (exact) tile
+  // ranges, beside the large segments' sorts and with no launch of their own.  (This kernel, not the small-segment
+  // one: the builder's 118 registers are this kernel's anyway; there they halved the sort's occupancy, 54 -> 62 us.)
+  if ((int)blockIdx.x < job_blocks) {
+    fgjobs::build_jobs_block<64 * SB_LARGE_WAVES>((int)blockIdx.x, jb, tile_offsets);
+    return;
+  }
   const int total = tile_offsets[tile_w * tile_h];
   if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
   const int count = large_list[0];
-  for (int k = blockIdx.x; k < count; k += gridDim.x) {
+  for (int k = (int)blockIdx.x - job_blocks; k < count; k += (int)gridDim.x - job_blocks) {
     sort_supertile<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS, false>(
         sh, large_list[1 + k], tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, false, total, flatten_ids,
         nullptr);
@@ -980,10 +988,11 @@ extern "C" size_t fg_stbin_fill_workspace_bytes(int64_t capacity) {
   return 2 * al256(c * 8);
 }
 
-extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
-                             int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
-                             int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
-                             fg_stream_t stream) {
+namespace {
+
+int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h, int64_t capacity,
+               const int32_t* tile_offsets, const void* count_workspace, int32_t* flatten_ids, int32_t* list_offsets,
+               void* workspace, size_t workspace_bytes, const fgjobs::JobBuild* jobs, fg_stream_t stream) {
   if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
   if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !list_offsets || !workspace)
     return FG_ERR_INVALID_ARG;
@@ -1018,11 +1027,37 @@ extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* t
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
   }
-  hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
-                     tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries, scratch, (long long)capacity,
-                     flatten_ids);
+  const int job_blocks = jobs && (jobs->jobs_fwd || jobs->jobs_bwd) ? fgjobs::FG_JOB_BLOCKS : 0;
+  hipLaunchKernelGGL(sb_sort_large_kernel, dim3((S < SB_LARGE_GRID ? S : SB_LARGE_GRID) + job_blocks),
+                     dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries,
+                     scratch, (long long)capacity, flatten_ids, job_blocks, job_blocks ? *jobs : fgjobs::JobBuild{});
   hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h, tile_offsets,
                      w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
+}
+
+}  // namespace
+
+extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                             int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                             int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                             fg_stream_t stream) {
+  return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
+                    list_offsets, workspace, workspace_bytes, nullptr, stream);
+}
+
+extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                                  int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                                  int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                                  int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
+                                  int bwd_list_shares, const fg_raster_config* config, fg_stream_t stream) {
+  if (width <= 0 || height <= 0 || tile_size <= 0) return FG_ERR_INVALID_ARG;
+  if ((width + tile_size - 1) / tile_size != tile_w || (height + tile_size - 1) / tile_size != tile_h)
+    return FG_ERR_INVALID_ARG;
+  fgjobs::JobBuild jb;
+  const int rc = fgjobs::plan_jobs(width, height, tile_size, jobs_fwd, jobs_bwd, bwd_list_shares, config, &jb);
+  if (rc != FG_OK) return rc;
+  return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
+                    list_offsets, workspace, workspace_bytes, &jb, stream);
 }

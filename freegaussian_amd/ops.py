@@ -161,9 +161,10 @@ class RasterContext:
         # FG_SH_JAC=0: the per-Gaussian backward reads the SH coefficient rows again (192 B per Gaussian) instead of
         # the 40-byte note (d colour / d direction + clamp mask) the forward leaves for it.
         self.sh_jacobian = e.get("FG_SH_JAC", "1") != "0"
-        # FG_JOBS_SIDE_STREAM=1: the raster job lists (fg_raster_build_jobs: 16 workgroups, 9 us) are built on a side
-        # stream from the EXACT tile ranges as soon as fg_stbin_count has them, beside the scatter and the sorts.
-        self.jobs_side_stream = e.get("FG_JOBS_SIDE_STREAM", "0") == "1"
+        # The raster job lists (fg_raster_build_jobs: 16 workgroups, 9 us) are built inside a sort launch of
+        # fg_stbin_fill_jobs when the caller of bin_tiles says what will be rastered (raster_hint);
+        # FG_JOBS_IN_FILL=0: by a launch of their own in front of the raster forward, as before ABI version 5.
+        self.jobs_in_fill = e.get("FG_JOBS_IN_FILL", "1") != "0"
         # Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
         # written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
         # The kernels overwrite their outputs densely, so the buffer needs no zeroing.
@@ -469,7 +470,7 @@ def _binning_side_outputs(N, tile_size, width, height, dev):
 
 
 def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False, want_keys=True,
-              keys_rects=None):
+              keys_rects=None, raster_hint=None):
     """Depth-first binning (fg_bin_prepare + fg_bin_emit_sort): the production path.
     -> (tile_keys[I] uint32-as-int32, flatten_ids[I] int32, tile_offsets[T+1] int32); the lists are
     bit-identical to ``isect_tiles`` (same (tile, depth, id) order).
@@ -484,7 +485,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     the kernels' workspace; ``tile_keys_from_offsets`` rebuilds them on demand).
     ``keys_rects=(depth_keys[N], tile_rects[N,2])`` from the fused preprocess pass: the lists are binned
     from those rectangles (footprint rectangles: a subsequence of the reference's lists); depth_keys
-    is consumed (sorted in place)."""
+    is consumed (sorted in place).
+    ``raster_hint=(channels, width, height)``: what ``rasterize_splats`` will be called with -- the supertile path then
+    builds the raster job lists inside one of its own launches (``fg_stbin_fill_jobs``) and leaves them on the returned
+    offsets tensor for it (``_fg_jobs``)."""
     want_keys = want_keys or tile_w * tile_h > 65536
     lib = _lib.load()
     N = means2d.shape[0]
@@ -500,7 +504,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         hkey = (dev, N, tile_w, tile_h)
         left = rctx.heavy_shapes.get(hkey, 0) if rctx.adaptive_binning else 0
         if left <= 0:
-            return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev)
+            return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev,
+                                        raster_hint if tile_size == TILE_SIZE else None)
         if static_capacity is None:  # (a captured graph keeps the path of the eager call that measured it)
             rctx.heavy_shapes[hkey] = left - 1  # (0: the next call probes the supertile path again)
         rctx.binning_fallbacks += 1
@@ -594,7 +599,31 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev):
+def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list):
+    """Floats of the forward's compositing checkpoints for the backward's list shares; 0 = the step does without
+    (off for this size / config, or beyond the context's budget)."""
+    n_ck = int(_lib.load().fg_raster_seg_ckpt_floats(int(channels), int(width), int(height), int(tile_size), int(n_list),
+                                                     rctx.cfg()))  # fmt: skip
+    # (64 bytes per list entry of CAPACITY -- 0.4 GB at 6M entries -- held from forward to backward: beyond the
+    # context's budget the backward runs without list shares, i.e. as pixel-strip jobs)
+    return n_ck if n_ck > 0 and 4 * n_ck <= rctx.seg_ckpt_budget_bytes else 0
+
+
+def _plan_job_lists(rctx, raster_hint, n_list, dev):
+    """(jobs[2, words], bwd_list_shares, key) for fg_stbin_fill_jobs, or None when the raster launches of this size /
+    config take no lists.  ``key`` is what _RasterSplats.forward compares before it trusts the lists."""
+    if raster_hint is None:
+        return None
+    channels, width, height = (int(v) for v in raster_hint)
+    words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, rctx.cfg()))
+    if words <= 0:
+        return None
+    shares = _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, n_list) > 0
+    jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
+    return jobs, shares, (rctx, channels, width, height, TILE_SIZE)
+
+
+def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev, raster_hint=None):
     """Supertile binning (csrc/stbin.hip), same contract as ``bin_tiles``: ``fg_stbin_count`` then ``fg_stbin_fill``.
     The tile ranges are exact after the count call; the ids are filled speculatively into a buffer sized
     from the previous calls of this shape and refilled exactly if the list turned out longer.  The ranges
@@ -610,16 +639,20 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
     _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
-    if rctx.jobs_side_stream and not static:
-        counted = torch.cuda.Event()
-        counted.record()
-        offsets._fg_exact = (tile_offsets, counted)  # (for _RasterSplats: job lists on a side stream)
 
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(getattr(lib, abi + "_fill_workspace_bytes")(cap)), dtype=torch.uint8, device=dev)
-        _call(abi + "_fill", N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1),
-              _ptr(ids), _ptr(offsets), _ptr(ws2), ws2.numel(), _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+        args = (N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1), _ptr(ids),
+                _ptr(offsets), _ptr(ws2), ws2.numel())  # fmt: skip
+        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev) if rctx.jobs_in_fill else None
+        if prebuilt is None:
+            _call(abi + "_fill", *args, _stream(), stage="fg_bin_emit_sort_capacity")
+        else:
+            jobs, shares, cfgp = prebuilt[0], prebuilt[1], rctx.cfg()
+            _call(abi + "_fill_jobs", *args, int(raster_hint[1]), int(raster_hint[2]), TILE_SIZE, _ptr(jobs[0]),
+                  _ptr(jobs[1]), int(shares), cfgp, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+        offsets._fg_jobs = prebuilt  # (for _RasterSplats.forward; None: it builds the lists itself)
         return ids
 
     def keys_for(n):
@@ -1061,13 +1094,9 @@ class _RasterSplats(torch.autograd.Function):
         words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size), cfgp))
         jobs = seg_ckpt = live = v_splats = None
         if words > 0:
-            jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
-            n_ck = int(_lib.load().fg_raster_seg_ckpt_floats(channels, int(width), int(height), int(tile_size),
-                                                             int(flatten_ids.numel()), cfgp))  # fmt: skip
-            # (64 bytes per list entry of CAPACITY -- 0.4 GB at 6M entries -- held from forward to backward:
-            # beyond the context's budget the backward runs without list shares, i.e. as pixel-strip jobs)
-            if n_ck > 0 and 4 * n_ck <= ctx.rctx.seg_ckpt_budget_bytes:
+            n_ck = _seg_ckpt_floats(ctx.rctx, channels, width, height, tile_size, flatten_ids.numel())
+            if n_ck > 0:
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
             live = torch.empty(max(int(flatten_ids.numel()), 1), dtype=torch.int32, device=dev)
@@ -1075,18 +1104,13 @@ class _RasterSplats(torch.autograd.Function):
             # the forward launch instead of a fill launch at the head of the backward
             if ctx.rctx.fill_in_forward and expect_backward:
                 v_splats = torch.empty(splats.shape[0], SPLAT_FLOATS, dtype=torch.float32, device=dev)
-            exact = getattr(tile_offsets, "_fg_exact", None) if ctx.rctx.jobs_side_stream else None
-            if exact is not None:
-                main, side = torch.cuda.current_stream(), _side_stream(dev)
-                side.wait_event(exact[1])
-                _call("fg_raster_build_jobs", width, height, tile_size, _ptr(exact[0]), _ptr(jobs[0]), _ptr(jobs[1]),
-                      int(seg_ckpt is not None), cfgp, side.cuda_stream, on=side)  # fmt: skip
-                built = torch.cuda.Event()
-                built.record(side)
-                jobs.record_stream(side)
-                exact[0].record_stream(side)
-                main.wait_event(built)
+            # job lists: the ones fg_stbin_fill_jobs built for exactly this call, or a launch of our own
+            prebuilt = getattr(tile_offsets, "_fg_jobs", None)
+            key = (ctx.rctx, int(channels), int(width), int(height), int(tile_size))
+            if prebuilt is not None and prebuilt[1] == (seg_ckpt is not None) and prebuilt[2] == key:
+                jobs = prebuilt[0]
             else:
+                jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
                 _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
                       int(seg_ckpt is not None), cfgp, _stream())  # fmt: skip
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),

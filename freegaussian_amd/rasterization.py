@@ -230,7 +230,7 @@ def rasterization(
     keys_rects = getattr(splats, "_fg_bin", None) if fused else None
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
         means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
-        keys_rects=keys_rects,
+        keys_rects=keys_rects, raster_hint=(channels, width, height) if fused else None,
     )
 
     if packed:
@@ -369,7 +369,7 @@ def rasterize_gauss_params(
     keys_rects = getattr(splats, "_fg_bin", None)
     tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
         means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
-        keys_rects=keys_rects,
+        keys_rects=keys_rects, raster_hint=(channels, width, height),
     )
     means2d_info = means2d_n.unsqueeze(0)
     bg = None

@@ -44,7 +44,7 @@ typedef void* fg_stream_t;
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
 #define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
-#define FG_ABI_VERSION 4
+#define FG_ABI_VERSION 5
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -169,6 +169,7 @@ int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, 
                   int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                   fg_stream_t stream);
+/* (fg_stbin_fill_jobs, with the job lists further down: this call and fg_raster_build_jobs in the same launches) */
 
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
  * 65536 tiles): they are then kept as 16-bit values inside the workspace -- 34 instead of 48 bytes
@@ -298,6 +299,17 @@ int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_rast
 int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* tile_offsets,
                          int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, const fg_raster_config* config,
                     fg_stream_t stream);
+/* fg_stbin_fill + fg_raster_build_jobs in the same launches: sixteen extra workgroups at the head of the
+ * large-segment sort launch build the raster job lists from tile_offsets beside the sorts -- no launch
+ * between the sorted lists and fg_raster_jobs_fwd (9 us of a 0.75 ms step on the 1M / 1080p scene).  width, height,
+ * tile_size must give tile_w x tile_h; jobs_fwd / jobs_bwd / bwd_list_shares / config as for fg_raster_build_jobs
+ * (both lists NULL: identical to fg_stbin_fill).  The lists depend on tile_offsets only: they stay valid when the
+ * call is repeated with a larger capacity. */
+int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+                       int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+                       int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
+                       int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
+                       int bwd_list_shares, const fg_raster_config* config, fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,

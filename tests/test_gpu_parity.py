@@ -450,6 +450,83 @@ def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
     assert ctx2.binning_fallbacks == 0 and not ctx2.heavy_shapes
 
 
+@pytest.mark.parametrize("size", [(1920, 1080, 400_000), (960, 540, 100_000), (640, 368, 60_000)])
+def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size):
+    """fg_stbin_fill_jobs (ABI 5): sixteen extra workgroups of the large-segment sort launch build the raster job lists.
+    Same int32 words as fg_raster_build_jobs on the same tile ranges, for both kinds of backward list; and
+    rasterize_splats takes the lists bin_tiles left on the offsets tensor (no launch of its own)."""
+    from freegaussian_amd import _lib
+    W, H, N = size
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    g = torch.Generator().manual_seed(5)
+    x0 = torch.randint(0, tw, (N,), generator=g)
+    y0 = torch.randint(0, th, (N,), generator=g)
+    w = torch.minimum(torch.randint(1, 5, (N,), generator=g), tw - x0)
+    h = torch.minimum(torch.randint(1, 5, (N,), generator=g), th - y0)
+    x0[: N // 8], y0[: N // 8] = tw // 2, th // 2  # a heavy spot: tiles the content thresholds split
+    w[: N // 8], h[: N // 8] = 1, 1
+    keys = (torch.rand(N, generator=g) * 9 + 0.5).view(torch.int32).clone()
+    rects = _pack_rects(x0, y0, w, h).to(DEV)
+    z = torch.zeros(N, device=DEV)
+    args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
+    for budget_mb in (2048, 0):  # list shares for the backward / pixel strips
+        ctx = ops.RasterContext()
+        if ctx.binning != "supertile" or not ctx.jobs_in_fill:
+            pytest.skip("the environment selects another path")
+        ctx.adaptive_binning = False
+        ctx.seg_ckpt_budget_bytes = budget_mb << 20
+        with ops.use(ctx):
+            for _ in range(2):  # exact, then speculative
+                _, ids, offs = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False,
+                                             raster_hint=(3, W, H))  # fmt: skip
+                words = int(_lib.load().fg_raster_jobs_words(W, H, 16, ctx.cfg()))
+                if words == 0:
+                    assert offs._fg_jobs is None
+                    continue
+                jobs, shares, key = offs._fg_jobs
+                assert key == (ctx, 3, W, H, 16) and jobs.shape == (2, words)
+                assert shares == (budget_mb > 0 and int(_lib.load().fg_raster_seg_ckpt_floats(3, W, H, 16, ids.numel(), ctx.cfg())) > 0)
+                ref = torch.zeros_like(jobs)
+                ops._call("fg_raster_build_jobs", W, H, 16, ops._ptr(offs), ops._ptr(ref[0]), ops._ptr(ref[1]), int(shares),
+                          ctx.cfg(), ops._stream())  # fmt: skip
+                torch.cuda.synchronize()
+                cap = (words - 8) // 8
+                for l in range(2):
+                    assert torch.equal(jobs[l, :8], ref[l, :8]), "jobs per XCD differ"
+                    for x in range(8):
+                        n = int(ref[l, x])
+                        assert 0 < n <= cap
+                        assert torch.equal(jobs[l, 8 + x * cap : 8 + x * cap + n], ref[l, 8 + x * cap : 8 + x * cap + n])
+
+
+def test_rasterization_takes_the_job_lists_of_the_fill(monkeypatch):
+    """End to end: with the default context rasterization() issues fg_stbin_fill_jobs and NO fg_raster_build_jobs;
+    with jobs_in_fill off the other way round; same image bit for bit, same gradients up to atomic order."""
+    sc = _scene(n=40000, w=640, h=368, seed=21)  # 920 tiles: the mixed launches with job lists
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
+    outs, calls = [], []
+    real = ops._call
+    monkeypatch.setattr(ops, "_call", lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+    for in_fill in (True, False):
+        ctx = ops.RasterContext()
+        if ctx.binning != "supertile" or not ctx.jobs_in_fill or ctx.overlap_pack or not ctx.tight_rects:
+            pytest.skip("the environment selects another path")
+        ctx.jobs_in_fill = in_fill
+        for _ in range(2):  # exact lists, then speculative
+            del calls[:]
+            t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+            with ops.use(ctx):
+                r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True)
+                (r * vr).sum().backward()
+            assert ("fg_stbin_fill_jobs" in calls) == in_fill and ("fg_raster_build_jobs" in calls) == (not in_fill), calls
+            outs.append((r.detach(), a.detach(), [x.grad for x in t]))
+    for r, a, g in outs[1:]:
+        assert torch.equal(r, outs[0][0]) and torch.equal(a, outs[0][1])
+        for x, y in zip(g, outs[0][2]):
+            assert rel_l2(x, y) < 1e-5
+
+
 @pytest.mark.parametrize("seed", range(12))
 def test_supertile_binning_fuzz_against_depth_first(seed, monkeypatch):
     """Random image sizes (1 x 1 tiles ... 300 x 170), Gaussian counts (1 ... 200k), rectangle size mixes (points,
