@@ -1,6 +1,6 @@
 // Job lists of the raster launches: the device code that builds them and the plan the host derives from a
 // fg_raster_config.  Shared by raster.hip (fg_raster_build_jobs: a launch of its own) and stbin.hip
-// (fg_stbin_fill_jobs: sixteen extra workgroups at the head of the large-segment sort launch, so that no launch
+// (fg_stbin_fill_jobs: eight extra workgroups at the end of the scatter launch, so that no launch
 // stands between the sorted lists and the raster forward).
 #pragma once
 #include <hip/hip_runtime.h>

@@ -325,7 +325,22 @@ __global__ void __launch_bounds__(SC_BLOCK)
 sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
                   int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
-                  uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list) {
+                  uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list,
+                  int job_blocks, fgjobs::JobBuild jb) {
+  // fg_stbin_fill_jobs: the LAST job_blocks workgroups build the raster launches' job lists from the (exact) tile
+  // ranges -- each the forward's and the backward's list of one XCD band -- beside the scatter, with no launch of
+  // their own.  (STAGE only: one workgroup per CU by LDS, so the builder's 118 registers cost this kernel nothing;
+  // in the small-segment sort launch they halved the occupancy, 54 -> 62 us, and at the head of the large-segment
+  // one the builder outlasts the launch on light scenes.)
+  if constexpr (STAGE) {
+    const int first = (int)gridDim.x - job_blocks;
+    if ((int)blockIdx.x >= first) {
+      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first, jb, tile_offsets);
+      __syncthreads();
+      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first + 8, jb, tile_offsets);
+      return;
+    }
+  }
   extern __shared__ uint32_t s_cur[];  // [supertiles of the pass] (STAGE: + destination deltas + staging buffer)
   __shared__ int s_large;
   __shared__ uint32_t s_wave_tot[SC_WAVES];
@@ -904,8 +919,7 @@ sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
                      int32_t* __restrict__ flatten_ids, int job_blocks, fgjobs::JobBuild jb) {
   __shared__ SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS> sh;
   // fg_stbin_fill_jobs: the first job_blocks workgroups build the raster launches' job lists from the (exact) tile
-  // ranges, beside the large segments' sorts and with no launch of their own.  (This kernel, not the small-segment
-  // one: the builder's 118 registers are this kernel's anyway; there they halved the sort's occupancy, 54 -> 62 us.)
+  // ranges -- only when the scatter in front ran without its staging buffer (sb_scatter_kernel)
   if ((int)blockIdx.x < job_blocks) {
     fgjobs::build_jobs_block<64 * SB_LARGE_WAVES>((int)blockIdx.x, jb, tile_offsets);
     return;
@@ -1011,6 +1025,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
   const int s_pad = (S + 1) & ~1;
   int stage_cap = band_rows == g.sh && S <= 65535 ? ((int)SB_SCATTER_LDS_BYTES - 8 * s_pad) / 10 : 0;
   stage_cap = stage_cap >= SB_MIN_STAGE ? (stage_cap & ~63) : 0;
+  bool want_jobs = jobs && (jobs->jobs_fwd || jobs->jobs_bwd);
   if (stage_cap) {
     const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
     static bool attr_set = false;  // (dynamic LDS beyond 64 KB; benign if two threads race to set the same value)
@@ -1019,15 +1034,19 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SCATTER_LDS_BYTES);
       attr_set = true;
     }
-    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc), dim3(SC_BLOCK), lds, s, N,
+    // (the job lists ride here; without the staged scatter, in the large-segment sort launch)
+    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0)), dim3(SC_BLOCK), lds, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
-                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, want_jobs ? 8 : 0,
+                       want_jobs ? *jobs : fgjobs::JobBuild{});
+    want_jobs = false;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
-                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list);
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, 0,
+                       fgjobs::JobBuild{});
   }
-  const int job_blocks = jobs && (jobs->jobs_fwd || jobs->jobs_bwd) ? fgjobs::FG_JOB_BLOCKS : 0;
+  const int job_blocks = want_jobs ? fgjobs::FG_JOB_BLOCKS : 0;
   hipLaunchKernelGGL(sb_sort_large_kernel, dim3((S < SB_LARGE_GRID ? S : SB_LARGE_GRID) + job_blocks),
                      dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries,
                      scratch, (long long)capacity, flatten_ids, job_blocks, job_blocks ? *jobs : fgjobs::JobBuild{});

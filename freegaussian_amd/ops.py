@@ -161,7 +161,7 @@ class RasterContext:
         # FG_SH_JAC=0: the per-Gaussian backward reads the SH coefficient rows again (192 B per Gaussian) instead of
         # the 40-byte note (d colour / d direction + clamp mask) the forward leaves for it.
         self.sh_jacobian = e.get("FG_SH_JAC", "1") != "0"
-        # The raster job lists (fg_raster_build_jobs: 16 workgroups, 9 us) are built inside a sort launch of
+        # The raster job lists (fg_raster_build_jobs: 16 workgroups, 9 us) are built inside the scatter launch of
         # fg_stbin_fill_jobs when the caller of bin_tiles says what will be rastered (raster_hint);
         # FG_JOBS_IN_FILL=0: by a launch of their own in front of the raster forward, as before ABI version 5.
         self.jobs_in_fill = e.get("FG_JOBS_IN_FILL", "1") != "0"

@@ -452,7 +452,7 @@ def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
 
 @pytest.mark.parametrize("size", [(1920, 1080, 400_000), (960, 540, 100_000), (640, 368, 60_000)])
 def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size):
-    """fg_stbin_fill_jobs (ABI 5): sixteen extra workgroups of the large-segment sort launch build the raster job lists.
+    """fg_stbin_fill_jobs (ABI 5): eight extra workgroups of the scatter launch build the raster job lists.
     Same int32 words as fg_raster_build_jobs on the same tile ranges, for both kinds of backward list; and
     rasterize_splats takes the lists bin_tiles left on the offsets tensor (no launch of its own)."""
     from freegaussian_amd import _lib
