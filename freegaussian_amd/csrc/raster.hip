@@ -1343,9 +1343,12 @@ int launch_bwd(const Cfg& cfg, int width, int height, const float* splats, const
 #ifndef FG_TAIL2_TILES_BWD
 #define FG_TAIL2_TILES_BWD 300
 #endif
-// mixed launches (job lists, liveness, list shares) from this many tiles up; below: classic launches
+// mixed launches (job lists, liveness, list shares) from this many tiles up; below: classic launches.
+// (900 until late in round 3 -- set before the backward had list shares.  With them the reference's quarter-resolution
+// phase, 480x270 = 510 tiles / 100k Gaussians, runs its backward 0.140 -> 0.067 ms and the step's kernels 0.293 -> 0.222 ms
+// (forward 0.066 -> 0.072: four strip jobs per tile each stage the list); 320x192 = 240 tiles: 0.261 -> 0.231.)
 #ifndef FG_MIXED_MIN_TILES
-#define FG_MIXED_MIN_TILES 900
+#define FG_MIXED_MIN_TILES 200
 #endif
 // Returns tail4 | tail2 << 16 (both clamped to 16 bits); req4 >= 0: the caller's numbers (req2 < 0: 0).
 int raster_tail(const Cfg& cfg, int req4, int req2, int n_tiles, int dflt4, int dflt2) {

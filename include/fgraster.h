@@ -268,7 +268,7 @@ int fg_raster_composite_bwd(int channels, int width, int height, int tile_size, 
                             const float* v_alphas, float* v_splats, const fg_raster_config* config,
                     fg_stream_t stream);
 /* ---- Job lists for the raster launches ---------------------------------------------------------
- * At 900 tiles and more the library runs the raster kernels as one wavefront per JOB: a whole tile
+ * At 200 tiles and more the library runs the raster kernels as one wavefront per JOB: a whole tile
  * (4 pixels per lane), half a tile or a quarter.  Without a list the job sizes depend on the tile's
  * position only (the end of every XCD's tile sequence is split); with a list they also depend on
  * the tile's list length (tiles far longer than the mean are split wherever they are), which is
