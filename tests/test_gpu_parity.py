@@ -272,6 +272,36 @@ def test_mixed_launch_equals_classic_launch(monkeypatch):
         assert rel_l2(absg, outs[0][3]) < 1e-5
 
 
+@pytest.mark.parametrize("w,h", [(1600, 64), (3216, 48), (256, 832), (320, 192), (480, 270)])
+def test_default_mixed_launch_on_odd_tile_grids_equals_classic_launch(w, h, monkeypatch):
+    """From 200 tiles up the default is the mixed launch (strip jobs forward, list shares backward, liveness, job
+    lists built inside the binning).  Grids with fewer tile rows than XCD bands (100 x 4, 201 x 3: some bands own no
+    tile), a tall narrow one and the reference's quarter-resolution sizes against ONE classic launch shape: forward
+    bit-identical, backward equal up to the order of its float atomics."""
+    from freegaussian_amd import _lib
+
+    sc = _scene(n=15000, w=w, h=h, seed=31)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    if int(_lib.load().fg_raster_jobs_words(w, h, 16, ops.default_context.cfg())) == 0:
+        pytest.skip("classic launches forced by the environment")
+    outs = []
+    for tail in (None, "0"):
+        if tail is not None:
+            _setenv_policy(monkeypatch, "FG_RASTER_TAIL_FWD", tail)
+            _setenv_policy(monkeypatch, "FG_RASTER_TAIL_BWD", tail)
+            assert int(_lib.load().fg_raster_jobs_words(w, h, 16, ops.default_context.cfg())) == 0
+        t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, absgrad=True, packed=False)
+        info["means2d"].retain_grad()
+        (r * torch.randn(r.shape, generator=torch.Generator().manual_seed(0)).to(DEV)).sum().backward()
+        outs.append((r.detach(), a.detach(), [x.grad for x in t], info["means2d"].absgrad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert float(outs[0][1].max()) > 0.5  # something was rendered
+    for x, y in zip(outs[0][2], outs[1][2]):
+        assert rel_l2(x, y) < 1e-5
+    assert rel_l2(outs[0][3], outs[1][3]) < 1e-5
+
+
 @pytest.mark.parametrize("n,end_bit", [(5, 32), (4097, 13), (250_001, 32), (3_000_000, 13)])
 def test_sort_pairs32_bit_exact_and_stable(n, end_bit):
     g = torch.Generator().manual_seed(n)
