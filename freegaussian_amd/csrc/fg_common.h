@@ -224,4 +224,34 @@ __device__ __forceinline__ float wave_reduce_rows_lds(const float (&v)[16], floa
   return r;
 }
 
+// The same with the store addresses kept in registers by the caller: wr[i] = LDS byte address of
+// buf[4 * i * FG_RED_STRIDE + lane] (i < (ROWS + 3) / 4), made opaque once per job (lds_opaque) -- inside a
+// per-entry loop the compiler otherwise rebuilds them with a v_add each, every entry (rows beyond the 255-dword
+// reach of ds_write2_b32's offsets).
+typedef __attribute__((address_space(3))) float lds_float_t;
+__device__ __forceinline__ uint32_t lds_opaque(const void* p) {
+  uint32_t a = (uint32_t)(uintptr_t)p;  // (the low half of a shared-memory flat address is the LDS offset)
+  asm volatile("" : "+v"(a));
+  return a;
+}
+template <int ROWS>
+__device__ __forceinline__ float wave_reduce_rows_lds(const float (&v)[16], const uint32_t (&wr)[(ROWS + 3) / 4],
+                                                       const float* buf, int lane) {
+#pragma unroll
+  for (int q = 0; q < ROWS; ++q) reinterpret_cast<lds_float_t*>(wr[q >> 2])[(q & 3) * FG_RED_STRIDE] = v[q];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  float r = 0.f;
+  if ((lane >> 2) < ROWS) {
+    const float4* src = reinterpret_cast<const float4*>(buf + (lane >> 2) * FG_RED_STRIDE + (lane & 3) * 16);
+    const float4 a = src[0], b = src[1], c = src[2], d = src[3];
+    r = (((a.x + a.y) + (a.z + a.w)) + ((b.x + b.y) + (b.z + b.w))) +
+        (((c.x + c.y) + (c.z + c.w)) + ((d.x + d.y) + (d.z + d.w)));
+    r += dpp_mov<FG_DPP_QUAD_XOR1>(r);
+    r += dpp_mov<FG_DPP_QUAD_XOR2>(r);
+  }
+  return r;
+}
+
 }  // namespace fg

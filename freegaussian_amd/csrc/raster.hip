@@ -697,11 +697,13 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
 template <int C, int NT>
 struct BwdShared {
   float4 rec[NT][rec_vec4(C)];
+  // (gid and mask right behind the records: with three channels and one wavefront they start at multiples of 256
+  // bytes, which one ds_read2st64_b32 addresses from the entry's 4 * j without an add)
+  int32_t gid[NT];
+  uint32_t mask[NT];
   // per-wavefront reduction buffer; read with ds_read_b128: keep it 16-byte aligned (unaligned it
   // cost 0.46 -> 0.70 ms)
   alignas(16) float red[NT / 64][(8 + C) * fg::FG_RED_STRIDE];
-  int32_t gid[NT];
-  uint32_t mask[NT];
   int32_t mx[NT / 64];
 };
 
@@ -884,7 +886,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   FG_TL_MARK(2);  // pixel state loaded
   if (!share_job) {
     // last list entry any pixel of the tile used
-    bin_final = fg::wave_max_i32(my_max);
+    bin_final = __builtin_amdgcn_readfirstlane(fg::wave_max_i32(my_max));  // (uniform: batch bounds in scalar registers)
     if (NW > 1) {
       if (lane == 0) lds_max[wl] = bin_final;
       __syncthreads();
@@ -903,12 +905,16 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
   (void)n_used;
   const int n_batches = (hi - lo + NT - 1) / NT;
   if (threadIdx.x == 0) { FG_STAT(5, n_used); FG_STAT(6, end - start); }
+  // store addresses of the per-entry reduction, one register per four rows, built once per job
+  uint32_t red_wr[(8 + C + 3) / 4];
+#pragma unroll
+  for (int i = 0; i < (8 + C + 3) / 4; ++i) red_wr[i] = fg::lds_opaque(&lds_red[wl][4 * i * fg::FG_RED_STRIDE + lane]);
   float g[16];  // per-splat gradient accumulators of this lane (see the comment at their use)
 #pragma unroll
   for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
 
   for (int b = n_batches - 1; b >= 0; --b) {
-    const int batch = lo + b * NT;
+    const int batch = __builtin_amdgcn_readfirstlane(lo + b * NT);  // (uniform; the list index of an entry is then scalar arithmetic)
     __syncthreads();
     FG_TL_STAGE_BEGIN();
     const int tl = NW == 1 ? fresh_lane_id() : (int)threadIdx.x;  // this thread's staging slot
@@ -1080,7 +1086,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
         (void)lds_red;
         if (true) {  // 8 + C live accumulators: summed through LDS (the butterflies' swaps and DPP
                      // operations cost 4-8 issue clocks each, fg_common.h)
-          const float total = fg::wave_reduce_rows_lds<8 + C>(g, lds_red[wl], lane);
+          const float total = fg::wave_reduce_rows_lds<8 + C>(g, red_wr, lds_red[wl], lane);
           if ((lane & 3) == 0 && (lane >> 2) < 8 + C) {
             const int gid_s = __builtin_amdgcn_readfirstlane(gid_v);
             float* dst = v_splats + (size_t)gid_s * FG_SPLAT_FLOATS + (lane >> 2);
