@@ -480,7 +480,8 @@ def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
     assert ctx2.binning_fallbacks == 0 and not ctx2.heavy_shapes
 
 
-@pytest.mark.parametrize("size", [(1920, 1080, 400_000), (960, 540, 100_000), (640, 368, 60_000)])
+@pytest.mark.parametrize("size", [(1920, 1080, 400_000), (960, 540, 100_000), (640, 368, 60_000), (2560, 1440, 2_500_000),
+                                  (8192, 8192, 200_000)])  # (the last: no staged scatter -- the builders ride in the large-segment sort launch)
 def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size):
     """fg_stbin_fill_jobs (ABI 5): eight extra workgroups of the scatter launch build the raster job lists.
     Same int32 words as fg_raster_build_jobs on the same tile ranges, for both kinds of backward list; and
