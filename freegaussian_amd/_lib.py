@@ -47,6 +47,9 @@ SIGNATURES = {
     "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
                                    c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
+    "fg_l1_ssim_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
+    "fg_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, P, P]),
+    "fg_l1_ssim_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),
     "fg_pack_splats": (c_int, [c_int, c_int, P, P, P, P, P, P]),
     # (the pointer before the stream of every raster entry point is the `const fg_raster_config*`)
     "fg_raster_config_init": (None, [P]),
@@ -88,7 +91,7 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None
 

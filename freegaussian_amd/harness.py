@@ -26,7 +26,7 @@ def ssim(a: torch.Tensor, b: torch.Tensor, data_range: float = 1.0) -> torch.Ten
     """Mean SSIM of [B,C,H,W] images, 11x11 Gaussian window sigma 1.5, 'valid' borders -- the
     definition `pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3)` uses."""
     C = a.shape[1]
-    w = _gauss_window(device=a.device).expand(C, 1, 11, 11).contiguous()
+    w = _gauss_window(device=a.device).to(a.dtype).expand(C, 1, 11, 11).contiguous()
     mu_a, mu_b = F.conv2d(a, w, groups=C), F.conv2d(b, w, groups=C)
     s_aa = F.conv2d(a * a, w, groups=C) - mu_a * mu_a
     s_bb = F.conv2d(b * b, w, groups=C) - mu_b * mu_b
@@ -40,11 +40,21 @@ def psnr(pred: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
     return -10.0 * torch.log10(F.mse_loss(pred, gt))
 
 
+def l1_and_ssim(pred: torch.Tensor, gt: torch.Tensor):
+    """(mean |gt - pred|, mean SSIM) of two [H,W,C] images: on the GPU the fused kernels (ops.l1_ssim: one launch each
+    way instead of ~200, 10.4 ms -> 0.1 ms at 1080p); on the host the torch statement of the same definition (`ssim`),
+    which is also what the GPU tests check the kernels against."""
+    if pred.is_cuda:
+        from . import ops
+
+        return ops.l1_ssim(pred, gt)
+    return (gt - pred).abs().mean(), ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None])
+
+
 def main_loss(pred: torch.Tensor, gt: torch.Tensor, ssim_lambda: float = 0.2) -> torch.Tensor:
     """pred, gt: [H,W,3] in [0,1]."""
-    l1 = (gt - pred).abs().mean()
-    sim = 1 - ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None])
-    return (1 - ssim_lambda) * l1 + ssim_lambda * sim
+    l1, sim = l1_and_ssim(pred, gt)
+    return (1 - ssim_lambda) * l1 + ssim_lambda * (1 - sim)
 
 
 def build_optimizers(model: FreeGaussianModel, table: Optional[Dict[str, OptimSpec]] = None):

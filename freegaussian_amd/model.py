@@ -244,7 +244,7 @@ class FreeGaussianModel(nn.Module):
         optional mask (both images blacked out), the optional scale-ratio regulariser on every 10th step.  The
         camera-optimizer and bilateral-grid terms of the reference are not mirrored (both off in every shipped
         config)."""
-        from .harness import ssim
+        from .harness import l1_and_ssim
 
         gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
         pred_img = outputs["rgb"]
@@ -255,8 +255,8 @@ class FreeGaussianModel(nn.Module):
             assert mask.shape[:2] == gt_img.shape[:2] == pred_img.shape[:2]
             gt_img = gt_img * mask
             pred_img = pred_img * mask
-        l1 = torch.abs(gt_img - pred_img).mean()
-        simloss = 1 - ssim(gt_img.permute(2, 0, 1)[None, ...], pred_img.permute(2, 0, 1)[None, ...])
+        l1, sim = l1_and_ssim(pred_img, gt_img)  # (fused on the GPU: ops.l1_ssim)
+        simloss = 1 - sim
         if self.config.use_scale_regularization and self.step % 10 == 0:
             scale_exp = torch.exp(self.scales)
             ratio = scale_exp.amax(dim=-1) / scale_exp.amin(dim=-1)

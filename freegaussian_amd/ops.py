@@ -711,6 +711,48 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
+class _L1Ssim(torch.autograd.Function):
+    """mean |gt - pred| and mean SSIM(gt, pred) of two [H,W,C] images, one launch each way (csrc/loss.hip)."""
+
+    @staticmethod
+    def forward(ctx, pred, gt):
+        H, W, C = pred.shape
+        dev = pred.device
+        lib = _lib.load()
+        n_ws = int(lib.fg_l1_ssim_workspace_floats(H, W, C))
+        if n_ws == 0:
+            raise ValueError(f"SSIM needs images larger than its 11 x 11 window, got {H} x {W}")
+        maps = torch.empty(3, C, H - 10, W - 10, dtype=torch.float32, device=dev)
+        ws = torch.empty(n_ws, dtype=torch.float32, device=dev)
+        out = torch.empty(2, dtype=torch.float32, device=dev)
+        _call("fg_l1_ssim_fwd", H, W, C, _ptr(pred), _ptr(gt), _ptr(maps), _ptr(ws), n_ws, _ptr(out), _stream(),
+              stage="fg_l1_ssim_fwd")  # fmt: skip
+        ctx.save_for_backward(pred, gt, maps)
+        return out[0], out[1]
+
+    @staticmethod
+    def backward(ctx, v_l1, v_ssim):
+        pred, gt, maps = ctx.saved_tensors
+        H, W, C = pred.shape
+        zero = pred.new_zeros(())
+        v = torch.stack([zero if v_l1 is None else v_l1.float().reshape(()), zero if v_ssim is None else v_ssim.float().reshape(())])
+        v_pred = torch.empty_like(pred)
+        _call("fg_l1_ssim_bwd", H, W, C, _ptr(pred), _ptr(gt), _ptr(maps), _ptr(v), _ptr(v_pred), _stream(),
+              stage="fg_l1_ssim_bwd")  # fmt: skip
+        return v_pred, None
+
+
+def l1_ssim(pred: torch.Tensor, gt: torch.Tensor):
+    """(mean |gt - pred|, mean SSIM(gt, pred)) of two [H,W,C] float32 images on the GPU -- the two terms of the
+    reference's main loss (freegaussian_model.py:965-981, SSIM as pytorch_msssim.SSIM(data_range=1.0, size_average=True):
+    11 x 11 Gaussian window, sigma 1.5, 'valid' borders).  Differentiable with respect to ``pred`` only."""
+    if pred.dim() != 3 or pred.shape != gt.shape:
+        raise ValueError(f"two [H,W,C] images expected, got {tuple(pred.shape)} and {tuple(gt.shape)}")
+    if not pred.is_cuda:
+        raise _lib.FgRasterError("l1_ssim runs on the GPU only (harness.ssim is the torch statement of the same loss)")
+    return _L1Ssim.apply(_f32(pred, "pred"), _f32(gt.detach(), "gt"))
+
+
 @torch.no_grad()
 def isect_keys(tile_keys, flatten_ids, depths):
     """Reference-style 64-bit keys (tile << 32 | depth bits) of the sorted list."""

@@ -44,7 +44,7 @@ typedef void* fg_stream_t;
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
 #define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
-#define FG_ABI_VERSION 5
+#define FG_ABI_VERSION 6
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -518,6 +518,21 @@ int fg_flow_bwd(int N, const float* means2d, const float* depths, const int32_t*
                 const float* vel, const float* K, const float* veloc, const float* omega,
                 const float* v_u_gs, const float* v_u_cam, float* v_means2d, float* v_depths,
                 float* v_vel, fg_stream_t stream);
+
+/* ---- L: the image loss of the training step, fused (csrc/loss.hip) --------------------------------------
+ * mean|gt - pred| and mean SSIM(gt, pred) of two [H, W, C] images -- the two terms of the reference's main loss
+ * (freegaussian_model.py:965-981; SSIM = pytorch_msssim.SSIM(data_range=1.0, size_average=True, channel=3), :22, :211:
+ * 11-tap Gaussian window, sigma 1.5, 'valid' borders) -- in one launch forward and one backward instead of ~200 torch
+ * launches each way (10.4 ms per step at 1920 x 1080 on an MI355X, scripts/loss_time.py).  height, width > 10.
+ *   fg_l1_ssim_fwd: out[0] = mean |gt - pred|, out[1] = mean SSIM (device floats; reduced in a fixed order: reproducible);
+ *                   maps[3 * C * (H-10) * (W-10)]: the SSIM map's partial derivatives, for the backward (opaque);
+ *                   workspace[fg_l1_ssim_workspace_floats(H, W, C)] floats.
+ *   fg_l1_ssim_bwd: v_out[2] (device) = dL/d out[0], dL/d out[1]  ->  v_pred[H, W, C] (overwritten; gt gets no gradient). */
+size_t fg_l1_ssim_workspace_floats(int height, int width, int channels);
+int fg_l1_ssim_fwd(int height, int width, int channels, const float* pred, const float* gt, float* maps,
+                   float* workspace, size_t workspace_floats, float* out, fg_stream_t stream);
+int fg_l1_ssim_bwd(int height, int width, int channels, const float* pred, const float* gt, const float* maps,
+                   const float* v_out, float* v_pred, fg_stream_t stream);
 
 #ifdef __cplusplus
 }

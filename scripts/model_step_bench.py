@@ -44,11 +44,26 @@ vr = torch.randn(H, W, 3, device=dev)
 params = list(model.gauss_params.values())
 
 
+# FG_MODEL_LOSS=main: the reference's loss (get_loss_dict: L1 + SSIM against a ground-truth image) instead of a plain
+# weighted sum; =torch: the same loss through torch operators (harness.ssim), as it ran before csrc/loss.hip
+loss_kind = os.environ.get("FG_MODEL_LOSS", "")
+gt_img = torch.rand(H, W, 3, device=dev)
+if loss_kind == "torch":
+    from freegaussian_amd import harness
+
+    harness.l1_and_ssim = lambda pred, gt: ((gt - pred).abs().mean(),
+                                            harness.ssim(gt.permute(2, 0, 1)[None], pred.permute(2, 0, 1)[None]))
+
+
 def step():
     for p in params:
         p.grad = None
     out = model.get_outputs(cam)
-    (out["rgb"] * vr).sum().backward()
+    if loss_kind:
+        ld = model.get_loss_dict(out, {"image": gt_img})
+        (ld["main_loss"] + ld["scale_reg"]).backward()
+    else:
+        (out["rgb"] * vr).sum().backward()
 
 
 for _ in range(25):  # (the caching allocator and the list-capacity history settle over the first steps)
@@ -82,7 +97,7 @@ if gstep.applicable(cam):
         gstep.step(cam, vr)
     torch.cuda.synchronize()
     graphed_ms = (time.perf_counter() - t0) / steps * 1e3
-res = {"model_step_ms": dt, "graphed_model_step_ms": graphed_ms, "size": [n, W, H], "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
+res = {"loss": loss_kind or "weighted sum", "model_step_ms": dt, "graphed_model_step_ms": graphed_ms, "size": [n, W, H], "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
 if os.environ.get("FG_MODEL_PROFILE"):
     from torch.profiler import ProfilerActivity, profile
 

@@ -1508,6 +1508,36 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     assert all(p.grad is None for p in cm.deform.parameters())  # frozen (evaluated under no_grad)
 
 
+@pytest.mark.parametrize("H,W,C", [(11, 11, 3), (12, 37, 1), (64, 48, 3), (270, 480, 3), (135, 241, 3), (1080, 1920, 3)])
+def test_fused_l1_ssim_loss_equals_the_torch_statement(H, W, C):
+    """csrc/loss.hip (one launch forward, one backward) against `harness.ssim` -- the torch statement of
+    pytorch_msssim.SSIM(data_range=1, size_average=True): 11 x 11 Gaussian window, sigma 1.5, valid borders -- and
+    torch's |gt - pred|.mean(), values and the gradient with respect to pred; tile-edge sizes, one channel, the
+    smallest image SSIM is defined on; bit-identical on repetition (no float atomics)."""
+    from freegaussian_amd.harness import main_loss, ssim
+
+    g = torch.Generator().manual_seed(H * 1000 + W)
+    gt = torch.rand(H, W, C, generator=g)
+    pred = (gt + 0.15 * torch.randn(H, W, C, generator=g)).clamp(0, 1)  # (correlated, as a render is; clamped pixels tie with gt at 0 / 1)
+    pred[0, 0] = gt[0, 0]  # |.| at zero: gradient 0, as torch
+    ref_in = pred.double().requires_grad_(True)
+    l1_ref = (gt.double() - ref_in).abs().mean()
+    ss_ref = ssim(gt.double().permute(2, 0, 1)[None], ref_in.permute(2, 0, 1)[None])
+    (0.8 * l1_ref + 0.2 * (1 - ss_ref) + 0.3 * ss_ref * l1_ref).backward()  # (both outputs' gradients in use, non-trivially)
+    gpu_in = pred.to(DEV).requires_grad_(True)
+    l1, ss = ops.l1_ssim(gpu_in, gt.to(DEV))
+    (0.8 * l1 + 0.2 * (1 - ss) + 0.3 * ss * l1).backward()
+    assert abs(float(l1) - float(l1_ref)) < 1e-6 * max(float(l1_ref), 1e-3)
+    assert abs(float(ss) - float(ss_ref)) < 2e-6
+    assert rel_l2(gpu_in.grad.cpu().double(), ref_in.grad) < 2e-5
+    l1b, ssb = ops.l1_ssim(gpu_in, gt.to(DEV))
+    assert torch.equal(l1b, l1) and torch.equal(ssb, ss)
+    # the model's loss goes through it on the GPU
+    if C == 3:
+        m = main_loss(gpu_in, gt.to(DEV), 0.2)
+        assert abs(float(m) - float(0.8 * l1_ref + 0.2 * (1 - ss_ref))) < 2e-6
+
+
 def test_harness_training_steps_reduce_loss():
     """End to end: a few optimisation steps of the host harness (reference loss + optimizer table)
     through the HIP raster must fit a target rendered from perturbed parameters."""
