@@ -7,7 +7,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libfgraster.so")
@@ -47,6 +47,7 @@ SIGNATURES = {
     "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
                                    c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
+    "fg_adam_step": (c_int, [c_int64, P, P, P, P, c_double, c_double, c_double, c_double, c_int64, P]),
     "fg_l1_ssim_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "fg_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, P, P]),
     "fg_l1_ssim_bwd": (c_int, [c_int, c_int, c_int, P, P, P, P, P, P]),

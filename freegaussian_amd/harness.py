@@ -63,7 +63,15 @@ def build_optimizers(model: FreeGaussianModel, table: Optional[Dict[str, OptimSp
     opts = {}
     for name, spec in table.items():
         if name in groups:
-            opts[name] = torch.optim.Adam(groups[name], lr=spec.lr, eps=spec.eps)
+            # the Gaussian parameter groups (one big tensor each) on the GPU: the update in one launch per tensor
+            # (optim.FusedAdam IS a torch.optim.Adam with step() replaced); the MLP groups -- many small tensors --
+            # and anything on the host keep torch's multi-tensor step
+            if name in model.gauss_params and all(p.is_cuda for p in groups[name]):
+                from .optim import FusedAdam
+
+                opts[name] = FusedAdam(groups[name], lr=spec.lr, eps=spec.eps)
+            else:
+                opts[name] = torch.optim.Adam(groups[name], lr=spec.lr, eps=spec.eps)
     return opts
 
 

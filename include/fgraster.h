@@ -534,6 +534,15 @@ int fg_l1_ssim_fwd(int height, int width, int channels, const float* pred, const
 int fg_l1_ssim_bwd(int height, int width, int channels, const float* pred, const float* gt, const float* maps,
                    const float* v_out, float* v_pred, fg_stream_t stream);
 
+/* ---- A: one Adam update of a dense float32 tensor in one launch (csrc/adam.hip) ---------------------------
+ * torch.optim.Adam's defaults (no weight decay, no amsgrad), the same fp32 operations in the same order as torch's
+ * own step: param, exp_avg, exp_avg_sq updated in place from grad; step = the 1-based count of this update (bias
+ * corrections 1 - beta^step computed in double, as torch does; the hyper-parameters are doubles for the same reason).  All four arrays 16-byte aligned, n elements.
+ * Replaces optimizer.step() of the reference's six Gaussian parameter groups (freegaussian_config.py optimizers):
+ * 1.42 ms -> 0.35 ms per iteration at 1M Gaussians (scripts/train_step_bench.py). */
+int fg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
+                 double beta2, double eps, int64_t step, fg_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

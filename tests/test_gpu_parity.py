@@ -1538,6 +1538,37 @@ def test_fused_l1_ssim_loss_equals_the_torch_statement(H, W, C):
         assert abs(float(m) - float(0.8 * l1_ref + 0.2 * (1 - ss_ref))) < 2e-6
 
 
+def test_fused_adam_step_equals_torch_adam():
+    """optim.FusedAdam (csrc/adam.hip: one launch per tensor) against torch.optim.Adam on the same parameters and
+    gradients: 25 steps with a changing learning rate (the schedules write group["lr"]), the reference's eps = 1e-15,
+    tensor sizes around the float4 boundary; parameters and both moments agree to float rounding; the state layout
+    is torch's (the densification edits it in place)."""
+    from freegaussian_amd.optim import FusedAdam
+
+    g = torch.Generator().manual_seed(11)
+    shapes = [(1,), (3,), (1000, 3), (777, 15, 3), (4097, 4), (100_003,)]
+    a = [torch.randn(s, generator=g).to(DEV).requires_grad_(True) for s in shapes]
+    b = [x.detach().clone().requires_grad_(True) for x in a]
+    oa, ob = FusedAdam(a, lr=1.6e-4, eps=1e-15), torch.optim.Adam(b, lr=1.6e-4, eps=1e-15)
+    for step in range(25):
+        lr = 1.6e-4 * (0.9 ** step)
+        for o in (oa, ob):
+            o.param_groups[0]["lr"] = lr
+        for x, y in zip(a, b):
+            gr = (torch.randn(x.shape, generator=g) * (10.0 ** float(torch.randint(-6, 2, (1,), generator=g)))).to(DEV)
+            if step % 7 == 3:
+                gr[::2] = 0  # zero gradients (culled Gaussians): sqrt(v) -> tiny denominators with eps = 1e-15
+            x.grad, y.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for x, y in zip(a, b):
+        assert rel_l2(x.detach(), y.detach()) < 1e-6
+        sa, sb = oa.state[x], ob.state[y]
+        assert set(sa) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == float(sb["step"]) == 25
+        assert rel_l2(sa["exp_avg"], sb["exp_avg"]) < 1e-6 and rel_l2(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-6
+    assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
+
+
 def test_harness_training_steps_reduce_loss():
     """End to end: a few optimisation steps of the host harness (reference loss + optimizer table)
     through the HIP raster must fit a target rendered from perturbed parameters."""
