@@ -91,7 +91,7 @@ def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = Non
 
 def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
                grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None, graphed=None,
-               mask: Optional[torch.Tensor] = None) -> Dict[str, float]:  # fmt: skip
+               mask: Optional[torch.Tensor] = None, metrics_every: int = 1) -> Dict[str, float]:  # fmt: skip
     """One iteration in the reference's callback order: step_cb -> get_outputs ->
     loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter ->
     refinement_after every ``refine_every`` steps (freegaussian_model.py:575-590; needs
@@ -101,7 +101,9 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     launch-bound (the reference's first 6000 steps at 1/4 and 1/2 resolution) get_outputs + loss + backward
     replay as one hipGraph; the rest of the step is unchanged.  ``mask`` [H,W,1]: the batch's optional mask
     (freegaussian_model.py:956-963).  The loss is the sum of ``model.get_loss_dict`` (main loss + the optional
-    scale regulariser), as nerfstudio's trainer sums it."""
+    scale regulariser), as nerfstudio's trainer sums it.  ``metrics_every`` = k: loss / psnr are read back (one host
+    synchronisation) only on steps divisible by k, as a trainer that logs every k steps does; the other steps return
+    the Gaussian count alone and the host runs ahead of the GPU."""
     model.step_cb(step)
     plain_loss = mask is None and gt_image.shape[-1] == 3 and not model.config.use_scale_regularization
     if graphed is not None and plain_loss and graphed.applicable(camera):
@@ -131,5 +133,7 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
         if stats_sync is not None:  # view-DP: identical statistics and split samples on every rank
             stats_sync(model)
         refinement_after(model, opts, step, num_train_data)
+    if metrics_every > 1 and step % metrics_every != 0:
+        return {"gaussian_count": model.num_points}
     with torch.no_grad():
         return {"loss": float(loss), "psnr": float(psnr(out["rgb"], gt)), "gaussian_count": model.num_points}

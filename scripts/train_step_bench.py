@@ -39,16 +39,18 @@ gt = torch.rand(H, W, 3, device=dev)
 step0 = 3001  # SH degree 3; no refinement: num_train_data is not passed
 
 
-def run(k, sync_each=False):
+def run(k, metrics_every=1):
+    torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(k):
-        harness.train_step(model, opts, cam, gt, step0 + i)
+        harness.train_step(model, opts, cam, gt, step0 + i, metrics_every=metrics_every)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / k * 1e3
 
 
 run(10)
 total = run(steps)
+total_log10 = run(steps, metrics_every=10)  # loss / psnr read back every 10th step only
 # parts (each followed by a synchronize, so they add up to more than the pipelined step)
 def timed(fn, k=steps):
     torch.cuda.synchronize()
@@ -73,7 +75,7 @@ def optim():
 
 
 fwd_bwd()
-res = {"size": [n, W, H], "train_step_ms": round(total, 4), "outputs_loss_backward_ms": round(timed(fwd_bwd), 4),
+res = {"size": [n, W, H], "train_step_ms": round(total, 4), "train_step_ms_metrics_every_10": round(total_log10, 4), "outputs_loss_backward_ms": round(timed(fwd_bwd), 4),
        "optimizers_ms": round(timed(optim), 4), "after_train_iter_ms": round(timed(lambda: model.after_train_iter(model.step)), 4),
        "optimizers": {k: type(o).__name__ for k, o in opts.items()}}
 print(json.dumps(res))
