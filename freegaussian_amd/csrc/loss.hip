@@ -9,8 +9,9 @@
 // backward: 202 launches) this costs 10.4 ms per step at 1920 x 1080 on an MI355X -- fourteen times the whole
 // rasterizer step (scripts/loss_time.py).  Here: one launch forward, one backward, both HBM-bound.
 //
-//   forward   one 256-thread workgroup per 16 x 16 pixel tile and channel: the 26 x 26 input windows of pred and gt
-//             in LDS, the five windowed moments (x, y, xx, yy, xy) by a horizontal then a vertical 11-tap pass,
+//   forward   one 256-thread workgroup per 32 x 16 pixel tile and channel: the 42 x 26 input windows of pred and gt
+//             in LDS, the five windowed moments (x, y, xx, yy, xy) by a horizontal (four columns per thread) then a
+//             vertical (two rows per thread) 11-tap pass -- both passes are bound by instruction issue, not bytes --,
 //             the SSIM map value and its three partial derivatives (d/d mu_x, d/d E[xx], d/d E[xy], the first one
 //             total: including the paths through the variances) per map pixel -> maps[3, C, H-10, W-10];
 //             per-workgroup partial sums of |x - y| and of the map, reduced in a fixed order by a second,
@@ -24,11 +25,13 @@
 
 namespace {
 
-constexpr int LT = 16;            // tile edge
+constexpr int TW = 32, TH = 16;   // tile: 32 columns x 16 rows of pixels per 256-thread workgroup (two rows per thread)
 constexpr int WIN = 11;           // taps
 constexpr int HALO = WIN - 1;     // 10
-constexpr int IN = LT + HALO;     // 26: input rows / columns a tile needs
-constexpr int INP = IN + 1;       // padded LDS row
+constexpr int INW = TW + HALO;    // 42 input columns a tile needs
+constexpr int INH = TH + HALO;    // 26 input rows
+constexpr int INWP = INW + 1;     // padded LDS rows
+constexpr int TWP = TW + 1;
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;  // data_range = 1
 
 struct Window {
@@ -63,46 +66,46 @@ __device__ __forceinline__ float2 block_sum2_256(float a, float b, float2* scrat
 __global__ void __launch_bounds__(256)
 l1_ssim_fwd_kernel(int H, int W, int C, Window win, const float* __restrict__ pred, const float* __restrict__ gt,
                    float* __restrict__ maps, float* __restrict__ partials) {
-  __shared__ float sx[IN][INP], sy[IN][INP];
-  __shared__ float hm[5][IN][LT + 1];
+  __shared__ float sx[INH][INWP], sy[INH][INWP];
+  __shared__ float hm[5][INH][TWP];
   __shared__ float2 red[4];
-  const int c = blockIdx.z, x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  const int c = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int Hm = H - HALO, Wm = W - HALO;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-  // input window (zero outside the image: those taps only feed map pixels outside the map); thread (ty, tx) takes
-  // rows ty, ty + 16 and columns tx, tx + 16
-#pragma unroll
-  for (int dr = 0; dr < IN; dr += LT) {
-#pragma unroll
-    for (int dq = 0; dq < IN; dq += LT) {
-      const int r = ty + dr, q = tx + dq;
-      if (r < IN && q < IN) {
-        const int y = y0 + r, x = x0 + q;
-        float a = 0.f, b = 0.f;
-        if (y < H && x < W) {
-          const size_t o = ((size_t)y * W + x) * C + c;
-          a = pred[o];
-          b = gt[o];
-        }
-        sx[r][q] = a;
-        sy[r][q] = b;
-      }
+  // input window (zero outside the image: those taps only feed map pixels outside the map)
+  for (int i = threadIdx.x; i < INH * INW; i += 256) {
+    const int r = i / INW, q = i - r * INW;
+    const int y = y0 + r, x = x0 + q;
+    float a = 0.f, b = 0.f;
+    if (y < H && x < W) {
+      const size_t o = ((size_t)y * W + x) * C + c;
+      a = pred[o];
+      b = gt[o];
     }
+    sx[r][q] = a;
+    sy[r][q] = b;
   }
   __syncthreads();
+  // a thread's two pixels: column tx, rows 2 ty and 2 ty + 1 of the tile
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
   float l1 = 0.f;
-  if (y0 + ty < H && x0 + tx < W) l1 = fabsf(sy[ty][tx] - sx[ty][tx]);
-  // horizontal pass: 26 rows x 16 columns x five moments; a thread takes two neighbouring columns of a row (twelve
-  // inputs read once, their products formed once)
-  if (threadIdx.x < IN * (LT / 2)) {
-    const int r = threadIdx.x >> 3, q = (threadIdx.x & 7) * 2;
-    float m[2][5] = {{0.f, 0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
-    for (int j = 0; j < WIN + 1; ++j) {
+  for (int o = 0; o < 2; ++o)
+    if (y0 + 2 * ty + o < H && x0 + tx < W) l1 += fabsf(sy[2 * ty + o][tx] - sx[2 * ty + o][tx]);
+  // horizontal pass: 26 rows x 32 columns x five moments; a thread takes FOUR neighbouring columns of a row (fourteen
+  // inputs read once, their products formed once): the pass is bound by instruction issue, not by bytes
+  if (threadIdx.x < INH * (TW / 4)) {
+    const int r = threadIdx.x >> 3, q = (threadIdx.x & 7) * 4;
+    float m[4][5];
+#pragma unroll
+    for (int o = 0; o < 4; ++o)
+#pragma unroll
+      for (int v = 0; v < 5; ++v) m[o][v] = 0.f;
+#pragma unroll
+    for (int j = 0; j < WIN + 3; ++j) {
       const float a = sx[r][q + j], b = sy[r][q + j];
       const float aa = a * a, bb = b * b, ab = a * b;
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < 4; ++o) {
         const int k = j - o;
         if (k >= 0 && k < WIN) {
           const float g = win.g[k];
@@ -115,41 +118,55 @@ l1_ssim_fwd_kernel(int H, int W, int C, Window win, const float* __restrict__ pr
       }
     }
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int v = 0; v < 5; ++v) hm[v][r][q + o] = m[o][v];
   }
   __syncthreads();
-  // vertical pass: the map pixel (y0 + ty, x0 + tx)
-  float mu1 = 0.f, mu2 = 0.f, exx = 0.f, eyy = 0.f, exy = 0.f;
+  // vertical pass: the map pixels (y0 + 2 ty + {0, 1}, x0 + tx): twelve rows read once for the two
+  float acc[2][5];
 #pragma unroll
-  for (int k = 0; k < WIN; ++k) {
-    const float g = win.g[k];
-    mu1 = fmaf(g, hm[0][ty + k][tx], mu1);
-    mu2 = fmaf(g, hm[1][ty + k][tx], mu2);
-    exx = fmaf(g, hm[2][ty + k][tx], exx);
-    eyy = fmaf(g, hm[3][ty + k][tx], eyy);
-    exy = fmaf(g, hm[4][ty + k][tx], exy);
+  for (int o = 0; o < 2; ++o)
+#pragma unroll
+    for (int v = 0; v < 5; ++v) acc[o][v] = 0.f;
+#pragma unroll
+  for (int j = 0; j < WIN + 1; ++j) {
+    float h[5];
+#pragma unroll
+    for (int v = 0; v < 5; ++v) h[v] = hm[v][2 * ty + j][tx];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int k = j - o;
+      if (k >= 0 && k < WIN) {
+#pragma unroll
+        for (int v = 0; v < 5; ++v) acc[o][v] = fmaf(win.g[k], h[v], acc[o][v]);
+      }
+    }
   }
-  float ssim = 0.f;
-  const int my = y0 + ty, mx = x0 + tx;
-  if (my < Hm && mx < Wm) {
-    const float s1 = exx - mu1 * mu1, s2 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
-    const float A1 = 2.f * mu1 * mu2 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
-    const float B1 = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
-    const float iB1 = 1.f / B1, iB2 = 1.f / B2;
-    ssim = (A1 * iB1) * (A2 * iB2);
-    // partial derivatives of the map value: with respect to E[xx] (= d/d sigma_x^2), E[xy] (= d/d sigma_xy) and
-    // mu_x -- the last one total, i.e. including sigma_x^2 = E[xx] - mu_x^2 and sigma_xy = E[xy] - mu_x mu_y
-    const float d_xx = -ssim * iB2;
-    const float d_xy = 2.f * (A1 * iB1) * iB2;
-    const float d_mu = 2.f * mu2 * (A2 * iB2) * iB1 - 2.f * mu1 * ssim * iB1 - 2.f * mu1 * d_xx - mu2 * d_xy;
-    const size_t plane = (size_t)Hm * Wm, o = (size_t)c * plane + (size_t)my * Wm + mx;
-    maps[o] = d_mu;
-    maps[(size_t)C * plane + o] = d_xx;
-    maps[2 * (size_t)C * plane + o] = d_xy;
+  float ssim_sum = 0.f;
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int my = y0 + 2 * ty + o, mx = x0 + tx;
+    if (my < Hm && mx < Wm) {
+      const float mu1 = acc[o][0], mu2 = acc[o][1], exx = acc[o][2], eyy = acc[o][3], exy = acc[o][4];
+      const float s1 = exx - mu1 * mu1, s2 = eyy - mu2 * mu2, s12 = exy - mu1 * mu2;
+      const float A1 = 2.f * mu1 * mu2 + SSIM_C1, A2 = 2.f * s12 + SSIM_C2;
+      const float B1 = mu1 * mu1 + mu2 * mu2 + SSIM_C1, B2 = s1 + s2 + SSIM_C2;
+      const float iB1 = 1.f / B1, iB2 = 1.f / B2;
+      const float ssim = (A1 * iB1) * (A2 * iB2);
+      // partial derivatives of the map value: with respect to E[xx] (= d/d sigma_x^2), E[xy] (= d/d sigma_xy) and
+      // mu_x -- the last one total, i.e. including sigma_x^2 = E[xx] - mu_x^2 and sigma_xy = E[xy] - mu_x mu_y
+      const float d_xx = -ssim * iB2;
+      const float d_xy = 2.f * (A1 * iB1) * iB2;
+      const float d_mu = 2.f * mu2 * (A2 * iB2) * iB1 - 2.f * mu1 * ssim * iB1 - 2.f * mu1 * d_xx - mu2 * d_xy;
+      const size_t plane = (size_t)Hm * Wm, idx = (size_t)c * plane + (size_t)my * Wm + mx;
+      maps[idx] = d_mu;
+      maps[(size_t)C * plane + idx] = d_xx;
+      maps[2 * (size_t)C * plane + idx] = d_xy;
+      ssim_sum += ssim;
+    }
   }
-  const float2 sums = block_sum2_256(l1, ssim, red);
+  const float2 sums = block_sum2_256(l1, ssim_sum, red);
   if (threadIdx.x == 0) {
     const int b = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
     reinterpret_cast<float2*>(partials)[b] = sums;
@@ -194,44 +211,39 @@ __global__ void __launch_bounds__(256)
 l1_ssim_bwd_kernel(int H, int W, int C, Window win, const float* __restrict__ pred, const float* __restrict__ gt,
                    const float* __restrict__ maps, const float* __restrict__ v_out, float inv_l1, float inv_ssim,
                    float* __restrict__ v_pred) {
-  __shared__ float sm[3][IN][INP];
-  __shared__ float hm[3][IN][LT + 1];
-  const int c = blockIdx.z, x0 = blockIdx.x * LT, y0 = blockIdx.y * LT;
+  __shared__ float sm[3][INH][INWP];
+  __shared__ float hm[3][INH][TWP];
+  const int c = blockIdx.z, x0 = blockIdx.x * TW, y0 = blockIdx.y * TH;
   const int Hm = H - HALO, Wm = W - HALO;
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const size_t plane = (size_t)Hm * Wm;
   // map window: the map pixels q in [p - 10, p] of the tile's pixels p (zero outside the map: 'full' borders)
-#pragma unroll
-  for (int dr = 0; dr < IN; dr += LT) {
-#pragma unroll
-    for (int dq = 0; dq < IN; dq += LT) {
-      const int r = ty + dr, q = tx + dq;
-      if (r < IN && q < IN) {
-        const int y = y0 - HALO + r, x = x0 - HALO + q;
-        float d0 = 0.f, d1 = 0.f, d2 = 0.f;
-        if (y >= 0 && y < Hm && x >= 0 && x < Wm) {
-          const size_t o = (size_t)c * plane + (size_t)y * Wm + x;
-          d0 = maps[o];
-          d1 = maps[(size_t)C * plane + o];
-          d2 = maps[2 * (size_t)C * plane + o];
-        }
-        sm[0][r][q] = d0;
-        sm[1][r][q] = d1;
-        sm[2][r][q] = d2;
-      }
+  for (int i = threadIdx.x; i < INH * INW; i += 256) {
+    const int r = i / INW, q = i - r * INW;
+    const int y = y0 - HALO + r, x = x0 - HALO + q;
+    float d0 = 0.f, d1 = 0.f, d2 = 0.f;
+    if (y >= 0 && y < Hm && x >= 0 && x < Wm) {
+      const size_t o = (size_t)c * plane + (size_t)y * Wm + x;
+      d0 = maps[o];
+      d1 = maps[(size_t)C * plane + o];
+      d2 = maps[2 * (size_t)C * plane + o];
     }
+    sm[0][r][q] = d0;
+    sm[1][r][q] = d1;
+    sm[2][r][q] = d2;
   }
   __syncthreads();
   // tile column j holds map column x0 - 10 + j; pixel column x0 + q takes columns j = q .. q + 10 with weights
-  // w(p - q) = g[10 - k] = g[k] (the window is symmetric); two neighbouring columns per thread
-  if (threadIdx.x < IN * (LT / 2)) {
-    const int r = threadIdx.x >> 3, q = (threadIdx.x & 7) * 2;
-    float m[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+  // w(p - q) = g[10 - k] = g[k] (the window is symmetric); four neighbouring columns per thread
+  if (threadIdx.x < INH * (TW / 4)) {
+    const int r = threadIdx.x >> 3, q = (threadIdx.x & 7) * 4;
+    float m[4][3];
 #pragma unroll
-    for (int j = 0; j < WIN + 1; ++j) {
+    for (int o = 0; o < 4; ++o) m[o][0] = m[o][1] = m[o][2] = 0.f;
+#pragma unroll
+    for (int j = 0; j < WIN + 3; ++j) {
       const float d0 = sm[0][r][q + j], d1 = sm[1][r][q + j], d2 = sm[2][r][q + j];
 #pragma unroll
-      for (int o = 0; o < 2; ++o) {
+      for (int o = 0; o < 4; ++o) {
         const int k = j - o;
         if (k >= 0 && k < WIN) {
           const float g = win.g[k];
@@ -242,26 +254,38 @@ l1_ssim_bwd_kernel(int H, int W, int C, Window win, const float* __restrict__ pr
       }
     }
 #pragma unroll
-    for (int o = 0; o < 2; ++o)
+    for (int o = 0; o < 4; ++o)
 #pragma unroll
       for (int v = 0; v < 3; ++v) hm[v][r][q + o] = m[o][v];
   }
   __syncthreads();
-  const int y = y0 + ty, x = x0 + tx;
-  if (y >= H || x >= W) return;
-  float s_mu = 0.f, s_xx = 0.f, s_xy = 0.f;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  float acc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
 #pragma unroll
-  for (int k = 0; k < WIN; ++k) {
-    const float g = win.g[k];
-    s_mu = fmaf(g, hm[0][ty + k][tx], s_mu);
-    s_xx = fmaf(g, hm[1][ty + k][tx], s_xx);
-    s_xy = fmaf(g, hm[2][ty + k][tx], s_xy);
+  for (int j = 0; j < WIN + 1; ++j) {
+    const float h0 = hm[0][2 * ty + j][tx], h1 = hm[1][2 * ty + j][tx], h2 = hm[2][2 * ty + j][tx];
+#pragma unroll
+    for (int o = 0; o < 2; ++o) {
+      const int k = j - o;
+      if (k >= 0 && k < WIN) {
+        const float g = win.g[k];
+        acc[o][0] = fmaf(g, h0, acc[o][0]);
+        acc[o][1] = fmaf(g, h1, acc[o][1]);
+        acc[o][2] = fmaf(g, h2, acc[o][2]);
+      }
+    }
   }
-  const size_t o = ((size_t)y * W + x) * C + c;
-  const float a = pred[o], b = gt[o];
   const float v_l1 = v_out[0] * inv_l1, v_ssim = v_out[1] * inv_ssim;
-  const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);  // d|b - a| / da
-  v_pred[o] = v_l1 * sgn + v_ssim * (s_mu + 2.f * a * s_xx + b * s_xy);
+#pragma unroll
+  for (int o = 0; o < 2; ++o) {
+    const int y = y0 + 2 * ty + o, x = x0 + tx;
+    if (y < H && x < W) {
+      const size_t idx = ((size_t)y * W + x) * C + c;
+      const float a = pred[idx], b = gt[idx];
+      const float sgn = a > b ? 1.f : (a < b ? -1.f : 0.f);  // d|b - a| / da
+      v_pred[idx] = v_l1 * sgn + v_ssim * (acc[o][0] + 2.f * a * acc[o][1] + b * acc[o][2]);
+    }
+  }
 }
 
 bool bad_shape(int H, int W, int C) { return H <= HALO || W <= HALO || C <= 0 || C > 65535; }
@@ -270,7 +294,7 @@ bool bad_shape(int H, int W, int C) { return H <= HALO || W <= HALO || C <= 0 ||
 
 extern "C" size_t fg_l1_ssim_workspace_floats(int height, int width, int channels) {
   if (bad_shape(height, width, channels)) return 0;
-  const size_t nb = (size_t)((width + LT - 1) / LT) * ((height + LT - 1) / LT) * channels;
+  const size_t nb = (size_t)((width + TW - 1) / TW) * ((height + TH - 1) / TH) * channels;
   return 2 * nb;
 }
 
@@ -280,7 +304,7 @@ extern "C" int fg_l1_ssim_fwd(int height, int width, int channels, const float* 
   if (!pred || !gt || !maps || !workspace || !out) return FG_ERR_INVALID_ARG;
   if (workspace_floats < fg_l1_ssim_workspace_floats(height, width, channels)) return FG_ERR_WORKSPACE;
   static const Window win = gaussian_window();
-  const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
+  const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH, channels);
   if (grid.y > 65535) return FG_ERR_UNSUPPORTED;
   const int nb = (int)(grid.x * grid.y * grid.z);
   hipStream_t s = fg_hip_stream(stream);
@@ -298,7 +322,7 @@ extern "C" int fg_l1_ssim_bwd(int height, int width, int channels, const float* 
   if (bad_shape(height, width, channels)) return FG_ERR_INVALID_ARG;
   if (!pred || !gt || !maps || !v_out || !v_pred) return FG_ERR_INVALID_ARG;
   static const Window win = gaussian_window();
-  const dim3 grid((width + LT - 1) / LT, (height + LT - 1) / LT, channels);
+  const dim3 grid((width + TW - 1) / TW, (height + TH - 1) / TH, channels);
   if (grid.y > 65535) return FG_ERR_UNSUPPORTED;
   const float inv_l1 = (float)(1.0 / ((double)height * width * channels));
   const float inv_ssim = (float)(1.0 / ((double)(height - HALO) * (width - HALO) * channels));
