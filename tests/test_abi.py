@@ -85,6 +85,19 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_bin_prepare_keys(0, *(n * 7), 0, None) == 0
     # composite raster: clamp count within the channels, mask required
     assert lib.fg_raster_composite_fwd(3, 32, 32, 16, *(n * 4), 4, *(n * 6)) == -1
+    # fused loss: images no larger than the 11 x 11 window have no SSIM map; buffers required; workspace size is a query
+    assert lib.fg_l1_ssim_workspace_floats(10, 64, 3) == 0 and lib.fg_l1_ssim_workspace_floats(64, 10, 3) == 0
+    assert lib.fg_l1_ssim_workspace_floats(1080, 1920, 3) == 2 * 60 * 68 * 3  # a float2 per 32 x 16 tile and channel
+    assert lib.fg_l1_ssim_fwd(10, 64, 3, *(n * 4), 0, None, None) == -1
+    assert lib.fg_l1_ssim_fwd(64, 64, 3, *(n * 4), 0, None, None) == -1
+    assert lib.fg_l1_ssim_bwd(64, 64, 3, *(n * 6)) == -1
+    # Adam step: the update count starts at 1, betas in [0, 1), arrays required; nothing to do for n = 0
+    assert lib.fg_adam_step(16, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 0, None) == -1
+    assert lib.fg_adam_step(16, *(n * 4), 1e-3, 1.0, 0.999, 1e-15, 1, None) == -1
+    assert lib.fg_adam_step(16, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == -1
+    assert lib.fg_adam_step(0, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == 0
+    # fill with job lists: the image must give the tile grid
+    assert lib.fg_stbin_fill_jobs(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, None) == -1
 
 
 def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):

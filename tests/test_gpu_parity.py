@@ -1588,6 +1588,14 @@ def test_harness_training_steps_reduce_loss():
     hist = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 1500 + i) for i in range(25)]
     assert hist[-1]["loss"] < 0.7 * hist[0]["loss"] and hist[-1]["psnr"] > hist[0]["psnr"] + 1.0
     assert model.xys_grad_norm is not None and float(model.vis_counts.max()) == 26.0
+    # the Gaussian groups step through optim.FusedAdam, the MLP groups through torch's Adam
+    from freegaussian_amd.optim import FusedAdam
+
+    assert all(isinstance(opts[k], FusedAdam) for k in model.gauss_params) and not isinstance(opts["deform"], FusedAdam)
+    # metrics_every = 5: loss / psnr are read back on steps divisible by 5 only; training continues the same way
+    more = [Hn.train_step(model, opts, copy.deepcopy(cam), gt, 1525 + i, metrics_every=5) for i in range(10)]
+    assert [("loss" in m) for m in more] == [True, False, False, False, False, True, False, False, False, False]
+    assert more[5]["loss"] < hist[-1]["loss"] * 1.05 and all(m["gaussian_count"] == model.num_points for m in more)
 
 
 def test_edge_cases_zero_gaussians_and_short_sh_tables():
