@@ -39,11 +39,18 @@ gt = torch.rand(H, W, 3, device=dev)
 step0 = 3001  # SH degree 3; no refinement: num_train_data is not passed
 
 
+graphed = None
+if os.environ.get("FG_GRAPHED"):  # get_outputs + loss + backward as one hipGraph replay where the shape allows it
+    from freegaussian_amd.graphed import GraphedModelStep
+
+    graphed = GraphedModelStep(model, harness.main_loss)
+
+
 def run(k, metrics_every=1):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(k):
-        harness.train_step(model, opts, cam, gt, step0 + i, metrics_every=metrics_every)
+        harness.train_step(model, opts, cam, gt, step0 + i, metrics_every=metrics_every, graphed=graphed)
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / k * 1e3
 
@@ -75,7 +82,7 @@ def optim():
 
 
 fwd_bwd()
-res = {"size": [n, W, H], "train_step_ms": round(total, 4), "train_step_ms_metrics_every_10": round(total_log10, 4), "outputs_loss_backward_ms": round(timed(fwd_bwd), 4),
+res = {"graphed": bool(graphed is not None and graphed.applicable(cam)), "size": [n, W, H], "train_step_ms": round(total, 4), "train_step_ms_metrics_every_10": round(total_log10, 4), "outputs_loss_backward_ms": round(timed(fwd_bwd), 4),
        "optimizers_ms": round(timed(optim), 4), "after_train_iter_ms": round(timed(lambda: model.after_train_iter(model.step)), 4),
        "optimizers": {k: type(o).__name__ for k, o in opts.items()}}
 print(json.dumps(res))
