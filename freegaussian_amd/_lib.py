@@ -47,6 +47,7 @@ SIGNATURES = {
     "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
                                    c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
+    "fg_densify_stats": (c_int, [c_int, P, P, c_float, P, P, P, P]),
     "fg_adam_step": (c_int, [c_int64, P, P, P, P, c_double, c_double, c_double, c_double, c_int64, P]),
     "fg_l1_ssim_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "fg_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, P, P]),

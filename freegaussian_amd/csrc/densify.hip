@@ -137,6 +137,35 @@ split_children_kernel(int first, int count, const int32_t* __restrict__ sample_i
 
 }  // namespace
 
+namespace {
+// S1: the per-iteration densification statistics of after_train_iter (/root/reference freegaussian_model.py:369-392)
+// in one pass over the Gaussians: visible = radii > 0; vis_counts += visible; xys_grad_norm += visible ? |absgrad| : 0;
+// max_2Dsize = max(max_2Dsize, visible ? radii / max(W, H) : 0).  (As torch operators: nine launches, 65 us at any size.)
+__global__ void __launch_bounds__(256)
+densify_stats_kernel(int N, const float2* __restrict__ absgrad, const int32_t* __restrict__ radii, float max_dim,
+                     float* __restrict__ xys_grad_norm, float* __restrict__ vis_counts, float* __restrict__ max_2dsize) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int r = radii[i];
+  if (r <= 0) return;  // (invisible rows stay bit for bit as they were)
+  const float2 a = absgrad[i];
+  xys_grad_norm[i] += sqrtf(a.x * a.x + a.y * a.y);
+  vis_counts[i] += 1.f;
+  max_2dsize[i] = fmaxf(max_2dsize[i], (float)r / max_dim);
+}
+}  // namespace
+
+extern "C" int fg_densify_stats(int N, const float* absgrad, const int32_t* radii, float max_dim, float* xys_grad_norm,
+                                float* vis_counts, float* max_2dsize, fg_stream_t stream) {
+  if (N < 0 || !(max_dim > 0.f)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!absgrad || !radii || !xys_grad_norm || !vis_counts || !max_2dsize) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(densify_stats_kernel, dim3((N + 255) / 256), dim3(256), 0, fg_hip_stream(stream), N,
+                     reinterpret_cast<const float2*>(absgrad), radii, max_dim, xys_grad_norm, vis_counts, max_2dsize);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
 extern "C" int fg_densify_flags(int N, int do_densify, float max_dim, float densify_grad_thresh,
                                 float densify_size_thresh, float split_screen_size, float cull_alpha_thresh,
                                 float cull_scale_thresh, float cull_screen_size, const float* xys_grad_norm,

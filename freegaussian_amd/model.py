@@ -443,19 +443,26 @@ class FreeGaussianModel(nn.Module):
         if self.step >= self.config.stop_split_at:
             return
         with torch.no_grad():
-            # The reference indexes with the boolean mask (`x[visible] += ...`, :379-392): every such line is
-            # a nonzero() with a host sync and a gather / scatter pair.  The same numbers with fixed shapes:
-            # adding 0.0 and taking max(x, 0) with x >= 0 leave the invisible rows bit-for-bit as they were.
-            visible = (self.radii > 0).flatten()
-            grads = self.xys.absgrad[0].norm(dim=-1)
             if self.xys_grad_norm is None:
                 self.xys_grad_norm = torch.zeros(self.num_points, device=self.device)
                 self.vis_counts = torch.ones(self.num_points, device=self.device)
-            self.vis_counts += visible.to(self.vis_counts.dtype)
-            self.xys_grad_norm += torch.where(visible, grads, torch.zeros_like(grads))
             if self.max_2Dsize is None:
                 self.max_2Dsize = torch.zeros(self.num_points, device=self.device)
-            new = self.radii.float() / float(max(self.last_size))
+            absgrad, radii = self.xys.absgrad[0], self.radii.flatten()
+            if absgrad.is_cuda:
+                # one pass over the Gaussians (csrc/densify.hip) instead of nine torch launches
+                from . import ops
+
+                ops.densify_stats(absgrad, radii, float(max(self.last_size)), self.xys_grad_norm, self.vis_counts, self.max_2Dsize)
+                return
+            # The reference indexes with the boolean mask (`x[visible] += ...`, :379-392): every such line is
+            # a nonzero() with a host sync and a gather / scatter pair.  The same numbers with fixed shapes:
+            # adding 0.0 and taking max(x, 0) with x >= 0 leave the invisible rows bit-for-bit as they were.
+            visible = radii > 0
+            grads = absgrad.norm(dim=-1)
+            self.vis_counts += visible.to(self.vis_counts.dtype)
+            self.xys_grad_norm += torch.where(visible, grads, torch.zeros_like(grads))
+            new = radii.float() / float(max(self.last_size))
             self.max_2Dsize = torch.maximum(self.max_2Dsize, torch.where(visible, new, torch.zeros_like(new)))
 
     def get_gaussian_param_groups(self) -> Dict[str, List[nn.Parameter]]:

@@ -711,6 +711,20 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
+@torch.no_grad()
+def densify_stats(absgrad, radii, max_dim: float, xys_grad_norm, vis_counts, max_2dsize) -> None:
+    """after_train_iter's statistics (freegaussian_model.py:369-392) in one pass, in place: for visible Gaussians
+    (radii > 0) xys_grad_norm += |absgrad|, vis_counts += 1, max_2dsize = max(max_2dsize, radii / max_dim)."""
+    N = radii.numel()
+    if absgrad.shape != (N, 2) or any(t.numel() != N for t in (xys_grad_norm, vis_counts, max_2dsize)):
+        raise ValueError("absgrad [N,2], radii [N] and three [N] statistics expected")
+    for t in (xys_grad_norm, vis_counts, max_2dsize):
+        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+            raise ValueError("the statistics are updated in place: contiguous float32 GPU tensors")
+    _call("fg_densify_stats", N, _ptr(_f32(absgrad, "absgrad")), _ptr(radii.to(torch.int32).contiguous()), float(max_dim),
+          _ptr(xys_grad_norm), _ptr(vis_counts), _ptr(max_2dsize), _stream())  # fmt: skip
+
+
 class _L1Ssim(torch.autograd.Function):
     """mean |gt - pred| and mean SSIM(gt, pred) of two [H,W,C] images, one launch each way (csrc/loss.hip)."""
 

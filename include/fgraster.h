@@ -442,6 +442,11 @@ int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const
                           const float* payload, int64_t view_stride, int payload_floats, float scale,
                           float* v_coeffs, fg_stream_t stream);
 
+/* S1 in one pass: the densification statistics after_train_iter keeps (freegaussian_model.py:369-392), all in place:
+ * for radii[i] > 0: xys_grad_norm[i] += |absgrad[i]| (absgrad [N,2]), vis_counts[i] += 1,
+ * max_2dsize[i] = max(max_2dsize[i], radii[i] / max_dim); other rows untouched. */
+int fg_densify_stats(int N, const float* absgrad, const int32_t* radii, float max_dim, float* xys_grad_norm,
+                     float* vis_counts, float* max_2dsize, fg_stream_t stream);
 /* ---- D: adaptive density control ---------------------------------
  * The reference's refinement_after / split_gaussians / dup_gaussians / cull_gaussians and the
  * Adam-state surgery around them (freegaussian_model.py:313-367, :404-571), as: one decision

@@ -1538,6 +1538,27 @@ def test_fused_l1_ssim_loss_equals_the_torch_statement(H, W, C):
         assert abs(float(m) - float(0.8 * l1_ref + 0.2 * (1 - ss_ref))) < 2e-6
 
 
+def test_densification_statistics_kernel_equals_the_torch_lines():
+    """fg_densify_stats (S1, after_train_iter :369-392) against the masked torch updates it replaces: visible rows
+    accumulate |absgrad|, a visit count and the largest screen radius; invisible rows (radius 0, or negative) stay
+    bit for bit as they were."""
+    g = torch.Generator().manual_seed(3)
+    N = 100_003
+    absgrad = torch.rand(N, 2, generator=g) * 10.0 ** torch.randint(-6, 1, (N, 1), generator=g).float()
+    radii = torch.randint(-2, 60, (N,), generator=g, dtype=torch.int32)
+    stats = [torch.rand(N, generator=g), torch.randint(1, 9, (N,), generator=g).float(), torch.rand(N, generator=g) * 0.05]
+    ref = [t.clone() for t in stats]
+    vis = radii > 0
+    ref[0] += torch.where(vis, absgrad.norm(dim=-1), torch.zeros(N))
+    ref[1] += vis.float()
+    ref[2] = torch.maximum(ref[2], torch.where(vis, radii.float() / 1920.0, torch.zeros(N)))
+    dev = [t.to(DEV) for t in stats]
+    ops.densify_stats(absgrad.to(DEV), radii.to(DEV), 1920.0, *dev)
+    assert rel_l2(dev[0].cpu(), ref[0]) < 1e-7 and torch.equal(dev[1].cpu(), ref[1]) and torch.equal(dev[2].cpu(), ref[2])
+    for a, b in zip(dev, stats):
+        assert torch.equal(a.cpu()[~vis], b[~vis])
+
+
 def test_fused_adam_step_equals_torch_adam():
     """optim.FusedAdam (csrc/adam.hip: one launch per tensor) against torch.optim.Adam on the same parameters and
     gradients: 25 steps with a changing learning rate (the schedules write group["lr"]), the reference's eps = 1e-15,
