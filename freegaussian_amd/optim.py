@@ -45,6 +45,8 @@ class FusedAdam(torch.optim.Adam):
                 if not (m.is_contiguous() and v.is_contiguous()):  # (state surgery may leave views behind)
                     m, v = st["exp_avg"], st["exp_avg_sq"] = m.contiguous(), v.contiguous()
                 g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
+                if g.data_ptr() % 16:  # (a view into a flat gradient buffer -- viewdp.FlatGaussianParams -- at an odd offset)
+                    g = g.clone()
                 _call("fg_adam_step", p.numel(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), lr, float(beta1), float(beta2), eps,
                       int(st["step"]), _stream(), stage="fg_adam_step")  # fmt: skip
         return loss

@@ -1588,6 +1588,15 @@ def test_fused_adam_step_equals_torch_adam():
         assert set(sa) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == float(sb["step"]) == 25
         assert rel_l2(sa["exp_avg"], sb["exp_avg"]) < 1e-6 and rel_l2(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-6
     assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
+    # gradients that are views into one flat buffer at offsets that are not multiples of 16 bytes (viewdp's layout)
+    flat = torch.randn(3 + 7 * 3 + 5, generator=g).to(DEV)
+    p1, p2 = (torch.zeros(7, 3, device=DEV, requires_grad=True), torch.zeros(5, device=DEV, requires_grad=True))
+    q1, q2 = (x.detach().clone().requires_grad_(True) for x in (p1, p2))
+    p1.grad, p2.grad = flat[3:24].view(7, 3), flat[24:]
+    q1.grad, q2.grad = p1.grad.clone(), p2.grad.clone()
+    FusedAdam([p1, p2], lr=1e-2).step()
+    torch.optim.Adam([q1, q2], lr=1e-2).step()
+    assert rel_l2(p1.detach(), q1.detach()) < 1e-6 and rel_l2(p2.detach(), q2.detach()) < 1e-6
 
 
 def test_harness_training_steps_reduce_loss():
