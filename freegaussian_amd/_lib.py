@@ -48,6 +48,7 @@ SIGNATURES = {
                                    c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_densify_stats": (c_int, [c_int, P, P, c_float, P, P, P, P]),
+    "fg_adam_step_multi": (c_int, [c_int, P, P]),  # (count, fg_adam_tensor[count], stream)
     "fg_adam_step": (c_int, [c_int64, P, P, P, P, c_double, c_double, c_double, c_double, c_int64, P]),
     "fg_l1_ssim_workspace_floats": (c_size_t, [c_int, c_int, c_int]),
     "fg_l1_ssim_fwd": (c_int, [c_int, c_int, c_int, P, P, P, P, c_size_t, P, P]),

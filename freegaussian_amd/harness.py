@@ -124,8 +124,9 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     if grad_sync is not None:
         grad_sync(model)
     apply_schedules(opts, step, table)
-    for o in opts.values():
-        o.step()
+    from .optim import step_all
+
+    step_all(opts.values())  # (the FusedAdam groups in one launch, the others' own step())
     model.after_train_iter(step)
     if num_train_data is not None and step % model.config.refine_every == 0:
         from .densify import refinement_after

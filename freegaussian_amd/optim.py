@@ -11,10 +11,18 @@ The reference attaches ``AdamOptimizerConfig(lr=..., eps=1e-15)`` to every group
 weight decay and amsgrad stay at torch's defaults, which is what this step implements.  Anything else raises."""
 from __future__ import annotations
 
+import ctypes
+
 import torch
 
 from . import _lib
 from .ops import _call, _ptr, _stream
+
+
+class _AdamTensor(ctypes.Structure):  # fg_adam_tensor (include/fgraster.h)
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("exp_avg", ctypes.c_void_p),
+                ("exp_avg_sq", ctypes.c_void_p), ("n", ctypes.c_int64), ("lr", ctypes.c_double), ("beta1", ctypes.c_double),
+                ("beta2", ctypes.c_double), ("eps", ctypes.c_double), ("step", ctypes.c_int64)]
 
 
 class FusedAdam(torch.optim.Adam):
@@ -24,6 +32,15 @@ class FusedAdam(torch.optim.Adam):
         if closure is not None:
             with torch.enable_grad():
                 loss = closure()
+        work = self._collect()
+        if work:
+            _launch(work)
+        return loss
+
+    def _collect(self):
+        """Advance the step counters and return [(p, g, m, v, lr, beta1, beta2, eps, step)] of this optimizer's update;
+        the tensors in it are kept alive by the caller until the launch is enqueued."""
+        work = []
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise _lib.FgRasterError("FusedAdam implements torch.optim.Adam's defaults (no weight decay / amsgrad / maximize)")
@@ -47,6 +64,29 @@ class FusedAdam(torch.optim.Adam):
                 g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
                 if g.data_ptr() % 16:  # (a view into a flat gradient buffer -- viewdp.FlatGaussianParams -- at an odd offset)
                     g = g.clone()
-                _call("fg_adam_step", p.numel(), _ptr(p), _ptr(g), _ptr(m), _ptr(v), lr, float(beta1), float(beta2), eps,
-                      int(st["step"]), _stream(), stage="fg_adam_step")  # fmt: skip
-        return loss
+                work.append((p, g, m, v, lr, float(beta1), float(beta2), eps, int(st["step"])))
+        return work
+
+
+def _launch(work) -> None:
+    arr = (_AdamTensor * len(work))()
+    for a, (p, g, m, v, lr, b1, b2, eps, step) in zip(arr, work):
+        a.param, a.grad, a.exp_avg, a.exp_avg_sq = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr()
+        a.n, a.lr, a.beta1, a.beta2, a.eps, a.step = p.numel(), lr, b1, b2, eps, step
+    _call("fg_adam_step_multi", len(work), ctypes.cast(arr, ctypes.c_void_p), _stream(), stage="fg_adam_step")
+
+
+def step_all(optimizers) -> None:
+    """``step()`` of every optimizer; the tensors of all ``FusedAdam`` instances among them go into ONE launch (every 16
+    tensors one: ``fg_adam_step_multi``) -- the reference's six Gaussian parameter groups are six optimizers of one tensor
+    each, and at its low resolutions an iteration is bound by launches."""
+    work, others = [], []
+    for o in optimizers:
+        if isinstance(o, FusedAdam):
+            work += o._collect()
+        else:
+            others.append(o)
+    if work:
+        _launch(work)
+    for o in others:
+        o.step()

@@ -547,6 +547,20 @@ int fg_l1_ssim_bwd(int height, int width, int channels, const float* pred, const
  * 1.42 ms -> 0.35 ms per iteration at 1M Gaussians (scripts/train_step_bench.py). */
 int fg_adam_step(int64_t n, float* param, const float* grad, float* exp_avg, float* exp_avg_sq, double lr, double beta1,
                  double beta2, double eps, int64_t step, fg_stream_t stream);
+/* The same for several tensors in ONE launch (every 16 tensors one): each tensor with its own hyper-parameters and
+ * update count, results identical to fg_adam_step per tensor.  At the reference's low resolutions an iteration is bound
+ * by launches: six Gaussian parameter groups, six launches -> one. */
+#define FG_ADAM_MAX_TENSORS 16
+typedef struct fg_adam_tensor {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t n;
+  double lr, beta1, beta2, eps;
+  int64_t step;
+} fg_adam_tensor;
+int fg_adam_step_multi(int count, const fg_adam_tensor* tensors, fg_stream_t stream);
 
 #ifdef __cplusplus
 }

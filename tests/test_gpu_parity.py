@@ -1588,6 +1588,23 @@ def test_fused_adam_step_equals_torch_adam():
         assert set(sa) == {"step", "exp_avg", "exp_avg_sq"} and float(sa["step"]) == float(sb["step"]) == 25
         assert rel_l2(sa["exp_avg"], sb["exp_avg"]) < 1e-6 and rel_l2(sa["exp_avg_sq"], sb["exp_avg_sq"]) < 1e-6
     assert set(oa.state_dict()["state"][0]) == set(ob.state_dict()["state"][0])
+    # step_all: the tensors of several FusedAdam optimizers (one launch for every 16) and a torch optimizer beside them;
+    # per tensor the same bits as that optimizer's own step()
+    from freegaussian_amd.optim import step_all
+
+    ps = [torch.randn(s_, generator=g).to(DEV).requires_grad_(True) for s_ in [(5,), (64, 3), (1000,)] * 7]  # 21 tensors
+    qs = [x.detach().clone().requires_grad_(True) for x in ps]
+    for x, y in zip(ps, qs):
+        x.grad = torch.randn(x.shape, generator=g).to(DEV)
+        y.grad = x.grad.clone()
+    o1 = [FusedAdam([x], lr=1e-3 * (i + 1), eps=1e-15) for i, x in enumerate(ps[:20])] + [torch.optim.Adam([ps[20]], lr=1e-3)]
+    o2 = [FusedAdam([y], lr=1e-3 * (i + 1), eps=1e-15) for i, y in enumerate(qs[:20])] + [torch.optim.Adam([qs[20]], lr=1e-3)]
+    for _ in range(2):
+        step_all(o1)
+        for o in o2:
+            o.step()
+    assert all(torch.equal(x.detach(), y.detach()) for x, y in zip(ps, qs))
+    assert all(float(o.state[x]["step"]) == 2 for o, x in zip(o1, ps))
     # gradients that are views into one flat buffer at offsets that are not multiples of 16 bytes (viewdp's layout)
     flat = torch.randn(3 + 7 * 3 + 5, generator=g).to(DEV)
     p1, p2 = (torch.zeros(7, 3, device=DEV, requires_grad=True), torch.zeros(5, device=DEV, requires_grad=True))
