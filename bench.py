@@ -736,7 +736,7 @@ def main(argv=None):
             "binning": {
                 "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 8-byte element per "
                 "(Gaussian, 2x2-tile supertile) scattered into the supertile's segment -> one LDS sort per supertile by "
-                "(depth bits, id), four tile lists read off it; 7 launches",
+                "(depth bits, id), four tile lists read off it; 6 launches, the raster job lists built inside the scatter launch",
                 "depthfirst": f"depth-first: 4-pass 32-bit sort of N + {tile_passes}-pass tile sort of I; 26 launches",
             }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",

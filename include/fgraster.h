@@ -147,7 +147,7 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * Count per tile and per supertile (2 x 2 tiles) -> scans -> one 8-byte element (depth bits << 32 | id << 4 |
  * which of the four tiles) scattered per (Gaussian, supertile) pair into the supertile's segment -> every
  * segment sorted ONCE by (depth bits, Gaussian id) in LDS and the four tile lists read off the sorted run:
- * 7 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
+ * 6 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
  * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
  * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, TWO words with
