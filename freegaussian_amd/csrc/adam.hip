@@ -105,9 +105,7 @@ bool adam_scalars(double lr, double beta1, double beta2, double eps, int64_t ste
 extern "C" int fg_adam_step_multi(int count, const fg_adam_tensor* tensors, fg_stream_t stream) {
   if (count < 0 || (count > 0 && !tensors)) return FG_ERR_INVALID_ARG;
   for (int base = 0; base < count; base += FG_ADAM_MAX_TENSORS) {
-    AdamBatch b;
-    b.count = 0;
-    b.first[0] = 0;
+    AdamBatch b{};  // (count 0, first[0] 0)
     for (int i = base; i < count && i < base + FG_ADAM_MAX_TENSORS; ++i) {
       const fg_adam_tensor& t = tensors[i];
       if (t.n < 0) return FG_ERR_INVALID_ARG;
@@ -148,15 +146,14 @@ extern "C" int fg_adam_step(int64_t n, float* param, const float* grad, float* e
   // torch: bias corrections and step size as Python floats (double), handed to fp32 kernels
   // (the hyper-parameters arrive as doubles, as torch holds them: 1 - 0.999 rounded to float from the double is
   // 1.3e-5 away from 1 - float(0.999))
-  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
-  const float neg_step = (float)(-(lr / bc1)), bc2_sqrt = (float)sqrt(bc2);
-  const float w1 = (float)(1.0 - beta1), w2 = (float)(1.0 - beta2);
+  AdamDesc d{};
+  if (!adam_scalars(lr, beta1, beta2, eps, step, &d)) return FG_ERR_INVALID_ARG;
   const long long n4 = n >> 2;
   long long blocks = (n4 + 255) / 256;
   if (blocks < 1) blocks = 1;
   if (blocks > 256 * 32) blocks = 256 * 32;  // grid-stride beyond 32 workgroups per CU
   hipLaunchKernelGGL(adam_kernel, dim3((unsigned)blocks), dim3(256), 0, fg_hip_stream(stream), (long long)n, param, grad, exp_avg,
-                     exp_avg_sq, w1, (float)beta2, w2, neg_step, bc2_sqrt, (float)eps);
+                     exp_avg_sq, d.w1, d.beta2, d.w2, d.neg_step, d.bc2_sqrt, d.eps);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
