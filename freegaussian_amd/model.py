@@ -21,7 +21,7 @@ from torch import nn
 
 from .deform import FreeGaussianControllableModel, FreeGaussianDeformableModel
 from .rasterization import num_sh_bases, rasterization
-from .utils import from_homogenous, get_viewmat, random_quat_tensor, resize_image, to_homogenous
+from .utils import get_viewmat, random_quat_tensor, resize_image, transform_points
 
 
 @dataclass
@@ -425,7 +425,7 @@ class FreeGaussianModel(nn.Module):
             pts = self.means
             times = times.to(self.device).expand(pts.shape[0], -1)
             d_xyz, d_rotation, d_scaling = self.deform(pts.detach(), times)
-            means = from_homogenous(torch.bmm(d_xyz, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
+            means = transform_points(d_xyz, pts)  # (:840-843; not torch.bmm: utils.small_bmm)
         return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
 
     @torch.no_grad()
@@ -513,7 +513,7 @@ class FreeGaussianControlModel(FreeGaussianModel):
             with torch.no_grad():  # (:128-138)
                 def deformed(t):
                     T, _, _ = self.deform(pts, t.to(self.device).expand(pts.shape[0], -1))
-                    return from_homogenous(torch.bmm(T, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
+                    return transform_points(T, pts)
 
                 delta = deformed(camera.times) - deformed(self.init_camera.times)
                 d_avg = torch.stack([delta[pmask[:, i]].mean(0) for i in range(pmask.shape[1])])

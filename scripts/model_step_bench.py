@@ -22,7 +22,7 @@ W = int(sys.argv[3]) if len(sys.argv) > 3 else 1920
 H = int(sys.argv[4]) if len(sys.argv) > 4 else 1080
 dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
-cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9,
+cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=int(os.environ.get("FG_MODEL_WARM_UP", 10**9)),  # (0: the deformation MLP runs)
                               fused_front_end=not os.environ.get("FG_UNFUSED"))
 model = FreeGaussianModel(cfg, seed_points=sc.means)
 with torch.no_grad():

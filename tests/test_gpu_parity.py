@@ -1559,6 +1559,33 @@ def test_densification_statistics_kernel_equals_the_torch_lines():
         assert torch.equal(a.cpu()[~vis], b[~vis])
 
 
+def test_tall_linear_gradients_equal_nn_linear():
+    """deform._TallLinear: the MLP's linears over hundreds of thousands of rows with the weight gradient as a batched
+    product over row chunks + a sum (the library's one-kernel [out, N] x [N, in] product runs at a fraction of its rate):
+    same output bits, gradients equal to summation order; a row count that is not a multiple of the chunk."""
+    from freegaussian_amd.deform import _TallLinear, _linear
+
+    g = torch.Generator().manual_seed(9)
+    N = 4 * _TallLinear.CHUNK + 1234
+    lin = torch.nn.Linear(63, 256).to(DEV)
+    x = torch.randn(N, 63, generator=g).to(DEV)
+    go = torch.randn(N, 256, generator=g).to(DEV)
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = _linear(lin, xa)
+    assert ya.grad_fn is not None and "TallLinear" in type(ya.grad_fn).__name__
+    ya.backward(go)
+    ga = [xa.grad.clone(), lin.weight.grad.clone(), lin.bias.grad.clone()]
+    lin.zero_grad()
+    yb = lin(xb)
+    yb.backward(go)
+    assert torch.equal(ya.detach(), yb.detach())
+    for a, b in zip(ga, [xb.grad, lin.weight.grad, lin.bias.grad]):
+        assert rel_l2(a, b) < 1e-5  # (two fp32 summation orders over 34 000 rows)
+    exact = go.double().t() @ x.double()  # the weight gradient in double: the chunked sum is no further from it
+    assert rel_l2(ga[1].double(), exact) < max(2 * rel_l2(lin.weight.grad.double(), exact), 2e-6)
+    assert "TallLinear" not in type(_linear(lin, x[:100].requires_grad_(True)).grad_fn).__name__  # small inputs: nn.Linear
+
+
 def test_fused_adam_step_equals_torch_adam():
     """optim.FusedAdam (csrc/adam.hip: one launch per tensor) against torch.optim.Adam on the same parameters and
     gradients: 25 steps with a changing learning rate (the schedules write group["lr"]), the reference's eps = 1e-15,
