@@ -166,6 +166,34 @@ def test_flow_AB_sign_convention_is_the_codes():
     assert B[0, 0, 1].item() == pytest.approx(7.0 + 0.25 / 7.0)
 
 
+def test_small_matrix_products_equal_bmm_in_value_and_gradient():
+    """utils.small_bmm / transform_points (broadcast multiply + sum: what exp_se3 and the means' transform use instead
+    of N-batch torch.bmm, freegaussian_model.py:840-843) against bmm and the reference's to_homogenous / from_homogenous
+    composition, in double precision, with gradients."""
+    from freegaussian_amd.utils import from_homogenous, small_bmm, to_homogenous, transform_points
+
+    g = torch.Generator().manual_seed(2)
+    for shape in ((5, 3, 3, 3), (7, 3, 3, 1), (4, 4, 4, 4), (1, 2, 5, 3)):
+        n, a, b, c = shape
+        A = torch.randn(n, a, b, generator=g, dtype=torch.float64, requires_grad=True)
+        B = torch.randn(n, b, c, generator=g, dtype=torch.float64, requires_grad=True)
+        w = torch.randn(n, a, c, generator=g, dtype=torch.float64)
+        out = small_bmm(A, B)
+        ref = torch.bmm(A, B)
+        assert out.shape == ref.shape and torch.allclose(out, ref, rtol=1e-13, atol=1e-13)
+        ga = torch.autograd.grad((out * w).sum(), (A, B))
+        gb = torch.autograd.grad((ref * w).sum(), (A, B))
+        assert all(torch.allclose(x, y, rtol=1e-13, atol=1e-13) for x, y in zip(ga, gb))
+    T = torch.randn(9, 4, 4, generator=g, dtype=torch.float64, requires_grad=True)
+    pts = torch.randn(9, 3, generator=g, dtype=torch.float64, requires_grad=True)
+    out = transform_points(T, pts)
+    ref = from_homogenous(torch.bmm(T, to_homogenous(pts).unsqueeze(-1)).squeeze(-1))
+    assert torch.allclose(out, ref, rtol=1e-12, atol=1e-12)
+    ga = torch.autograd.grad(out.square().sum(), (T, pts))
+    gb = torch.autograd.grad(ref.square().sum(), (T, pts))
+    assert all(torch.allclose(x, y, rtol=1e-11, atol=1e-11) for x, y in zip(ga, gb))
+
+
 def test_gsplat_helper_replacements():
     assert [num_sh_bases(d) for d in range(4)] == [1, 4, 9, 16]
     q = torch.tensor([[2.0, 0, 0, 0], [0.5, 0.5, 0.5, 0.5]])
