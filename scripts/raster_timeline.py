@@ -4,7 +4,8 @@ Every job of raster_fwd_mixed_kernel / raster_bwd_mixed_kernel records its start
 wall clock and the SIMD it ran on.  Printed per kernel: the launch span, the jobs by kind with their
 durations, and -- in 20 time slices of the launch -- how many wavefronts were resident per SIMD and which
 share of the chip's 1024 SIMDs held 0 / 1 / 2-3 / >= 4 of them (a SIMD needs ~4 to issue at full rate).
-Usage: python scripts/raster_timeline.py [n_gauss] [out.json]"""
+Usage: python scripts/raster_timeline.py [n_gauss] [out.json] [frac:extent]
+(frac:extent: that fraction of the Gaussians pulled into a ball of that extent at the centre, scripts/clustered_check.py)"""
 import ctypes
 import json
 import os
@@ -21,6 +22,9 @@ from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 sc = synthetic_scene(n, 1920, 1080, n_views=8, sh_degree=3, seed=42)
+if len(sys.argv) > 3 and sys.argv[3]:
+    frac, ball = (float(v) for v in sys.argv[3].split(":"))
+    sc.means[: int(frac * n)] *= ball / 2.0
 dev = torch.device("cuda", 0)
 ins = [t.to(dev).requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
 lib = _lib.load()
@@ -30,7 +34,11 @@ CAP = 1 << 17
 buf = np.zeros((CAP, 6), dtype=np.uint64)
 
 
+info = None
+
+
 def step(view):
+    global info
     r, a, info = rasterization(*ins, sc.viewmats[view:view + 1].to(dev), sc.Ks[view:view + 1].to(dev), 1920, 1080,
                                sh_degree=3, absgrad=True)
     r.backward(torch.randn_like(r))
@@ -110,6 +118,23 @@ for kid, name in ((1, "raster_fwd_mixed"), (2, "raster_bwd_mixed")):
                                          "max": float(((first_start - lo) / 100.0).max())},
                  "per_xcd_finish_us": {int(x): float((b[xcc[m] == x].max() - lo) / 100.0) for x in np.unique(xcc[m])},
                  "kinds": kinds, "slices": slices}
+# the longest jobs of each launch: what they were and how long their tile's list is
+offs = info["raster_isect_offsets"].reshape(-1).long().cpu().numpy()  # [T + 1]: the lists the launches walked
+n_list = int(offs[-1])
+lens = offs[1:] - offs[:-1]
+out["lists"] = {"entries": n_list, "mean": float(lens.mean()), "p99": float(np.percentile(lens, 99)), "max": int(lens.max())}
+tile_id = ((what >> 16) & 0xFFFFFF).astype(np.int64)
+part_id = ((what >> 8) & 0xF).astype(int)
+for kid, name in ((1, "raster_fwd_mixed"), (2, "raster_bwd_mixed")):
+    m = np.nonzero(kernel == kid)[0]
+    if m.size == 0:
+        continue
+    lo = t0[m].min()
+    order = m[np.argsort(-(t1[m] - t0[m]))[:12]]
+    out[name]["longest_jobs"] = [{"us": float((t1[i] - t0[i]) / 100.0), "start_us": float((t0[i] - lo) / 100.0),
+                                  "tile": int(tile_id[i]), "strip": int(strip[i]), "part": int(part_id[i]),
+                                  "parts": int(parts[i]), "list_len": int(lens[tile_id[i]]) if tile_id[i] < lens.size else -1,
+                                  "staging_us": float(stage_us[i])} for i in order]
 text = json.dumps(out, indent=1)
 if len(sys.argv) > 2:
     open(sys.argv[2], "w").write(text)
