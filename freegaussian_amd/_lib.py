@@ -43,9 +43,9 @@ SIGNATURES = {
     "fg_stbin_count_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "fg_stbin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
     "fg_stbin_fill_workspace_bytes": (c_size_t, [c_int64]),
-    "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, P]),
+    "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, P]),
     "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
-                                   c_int, P, P]),
+                                   c_int, P, c_int, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_densify_stats": (c_int, [c_int, P, P, c_float, P, P, P, P]),
     "fg_adam_step_multi": (c_int, [c_int, P, P]),  # (count, fg_adam_tensor[count], stream)
@@ -94,7 +94,8 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 6
+ABI_VERSION = 7
+STBIN_LONG_SEGMENTS = 1  # FG_STBIN_LONG_SEGMENTS
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None
 

@@ -19,6 +19,8 @@
 // so that a segment's scattered stores met in one L2: count and scatter then each pulled the rectangles through
 // all eight L2s -- 62 + 95 MB of fabric reads for 12 MB of data, and that, not the stores, bounded both kernels.)
 // The sort deals supertiles to the XCDs round-robin.
+#include <atomic>
+
 #include "fg_common.h"
 #include "jobs_build.h"
 
@@ -42,6 +44,31 @@ constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the coun
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 constexpr int SB_SCATTER_LDS_BYTES = 132 * 1024;     // dynamic LDS of the staging scatter (+ 21 KB static: one workgroup per CU)
 constexpr int SB_MIN_STAGE = 4096;                   // staging buffers smaller than this are not worth the second sweep
+// LONG segments (more elements than the large launch sorts in LDS: a dense cluster over one supertile) are split by
+// SAMPLE SORT into buckets of ~LG_T elements that the LDS sort then takes one by one (FG_STBIN_LONG_SEGMENTS):
+constexpr int SB_LONG_MIN = 64 * 16 * 8 - 128;       // = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, ..>::MAXN (static_assert below)
+constexpr int LG_T = 2688;                           // target bucket size: a third of the LDS sort's capacity
+constexpr int LG_KMAX = 1008;                        // buckets per segment at most (splitters + counters in LDS)
+constexpr int LG_SA = 16;                            // samples per bucket (fewer when LG_SA * k exceeds one LDS sort)
+constexpr int LG_BLOCK = 512, LG_PER = 8, LG_CHUNK = LG_BLOCK * LG_PER;  // count / scatter passes over a long segment
+constexpr int LG_GRID = 1024, LG_SORT_GRID = 512;    // persistent workgroups of those passes / of the bucket sort
+__host__ __device__ __forceinline__ int long_buckets(int n) {
+  const int k = (n + LG_T - 1) / LG_T;
+  return k > LG_KMAX ? LG_KMAX : (k < 2 ? 2 : k);
+}
+__host__ __device__ __forceinline__ int long_samples(int k) {
+  const int s = LG_SA * k;
+  return s > SB_LONG_MIN ? SB_LONG_MIN : s;  // (a long segment has more elements than that)
+}
+// per bucket of every long segment (fill workspace, behind the two element arrays)
+struct LongTables {
+  uint64_t* split;   // [b] = smallest element of bucket b + 1 (bucket k - 1: unused)
+  uint32_t* cnt;     // elements per bucket
+  uint32_t* cursor;  // scatter cursors
+  uint32_t* boff;    // first slot of the bucket inside its segment
+  uint4* tcnt;       // elements per bucket that go to tile j of the supertile
+  uint4* tbase;      // ... in the buckets before this one
+};
 
 struct Geo {
   int tile_w, tile_h, sw, sh;
@@ -308,6 +335,83 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
   }
 }
 
+// ---- which segments the small sort launch leaves to the others ---------------------------------------------------
+// large_list: [0] = count, then the supertiles (any order) whose segment is longer than small_max -- and, with
+// long_mode, not longer than SB_LONG_MIN: those are the large launch's LDS sorts.  long_list (long_mode): the segments
+// beyond SB_LONG_MIN in supertile order as int4 {supertile, first chunk, first bucket, elements} behind a header
+// {count, chunks, buckets, 0} and in front of a sentinel {-1, chunks, buckets, 0}: the work items of the sample sort's
+// passes (chunks of LG_CHUNK elements; long_buckets(n) buckets) find their segment by bisection.
+template <int NTH>
+__device__ __forceinline__ void build_segment_lists(int S, const int32_t* __restrict__ st_offsets, int small_max,
+                                                    int32_t* __restrict__ large_list, int4* __restrict__ long_list,
+                                                    bool long_mode) {
+  constexpr int NWV = NTH / 64;
+  __shared__ int s_large;
+  __shared__ uint32_t s_tot[3][NWV];
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) s_large = 0;
+  __syncthreads();
+  const int per = (S + NTH - 1) / NTH, i0 = min((int)threadIdx.x * per, S), i1 = min(i0 + per, S);
+  uint32_t mine[3] = {0, 0, 0};  // long segments, their chunks, their buckets in [i0, i1)
+  for (int i = i0; i < i1; ++i) {
+    const int n = st_offsets[i + 1] - st_offsets[i];
+    if (long_mode && n > SB_LONG_MIN) {
+      mine[0] += 1;
+      mine[1] += (uint32_t)((n + LG_CHUNK - 1) / LG_CHUNK);
+      mine[2] += (uint32_t)long_buckets(n);
+    } else if (n > small_max) {
+      large_list[1 + atomicAdd(&s_large, 1)] = i;
+    }
+  }
+  uint32_t incl[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    incl[f] = wave_incl_scan(mine[f], lane);
+    if (lane == 63) s_tot[f][wave] = incl[f];
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) large_list[0] = s_large;
+  if (!long_mode) {
+    if (threadIdx.x == 0) long_list[0] = make_int4(0, 0, 0, 0);
+    return;
+  }
+  uint32_t run[3], all[3];
+#pragma unroll
+  for (int f = 0; f < 3; ++f) {
+    run[f] = incl[f] - mine[f];
+    all[f] = 0;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+      const uint32_t t = s_tot[f][w];
+      if (w < wave) run[f] += t;
+      all[f] += t;
+    }
+  }
+  for (int i = i0; i < i1; ++i) {
+    const int n = st_offsets[i + 1] - st_offsets[i];
+    if (n > SB_LONG_MIN) {
+      long_list[1 + run[0]] = make_int4(i, (int)run[1], (int)run[2], n);
+      run[0] += 1;
+      run[1] += (uint32_t)((n + LG_CHUNK - 1) / LG_CHUNK);
+      run[2] += (uint32_t)long_buckets(n);
+    }
+  }
+  if (threadIdx.x == 0) {
+    long_list[0] = make_int4((int)all[0], (int)all[1], (int)all[2], 0);
+    long_list[1 + all[0]] = make_int4(-1, (int)all[1], (int)all[2], 0);
+  }
+}
+// the long segment that holds work item w of a pass (field 1: chunks, 2: buckets): the last one whose first item <= w
+__device__ __forceinline__ int long_segment_of(const int4* __restrict__ long_list, int L, int w, int field) {
+  int lo = 0, hi = L;  // invariant: first(lo) <= w < first(hi)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    const int4 e = long_list[1 + mid];
+    if ((field == 1 ? e.y : e.z) <= w) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
 // ---- scatter --------------------------------------------------------------------------------------------
 // One workgroup per chunk; a wavefront takes 64 Gaussians a round: every lane finds the owner of its slot among
 // the round's (Gaussian, supertile) pairs and writes the element depth bits << 32 | id << 4 | tile mask (bit j:
@@ -326,14 +430,21 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
                   int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                   uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list,
-                  int job_blocks, fgjobs::JobBuild jb) {
+                  int4* __restrict__ long_list, int long_mode, int job_blocks, fgjobs::JobBuild jb) {
   // fg_stbin_fill_jobs: the LAST job_blocks workgroups build the raster launches' job lists from the (exact) tile
   // ranges -- each the forward's and the backward's list of one XCD band -- beside the scatter, with no launch of
   // their own.  (STAGE only: one workgroup per CU by LDS, so the builder's 118 registers cost this kernel nothing;
   // in the small-segment sort launch they halved the occupancy, 54 -> 62 us, and at the head of the large-segment
   // one the builder outlasts the launch on light scenes.)
+  // (STAGE: one more workgroup at the very end builds the segment lists for the sort launches -- off chunk 0's path)
   if constexpr (STAGE) {
-    const int first = (int)gridDim.x - job_blocks;
+    const int first = (int)gridDim.x - 1 - job_blocks;
+    if ((int)blockIdx.x == (int)gridDim.x - 1) {
+      const Geo gg = geo_of(tile_w, tile_h);
+      if ((long long)tile_offsets[tile_w * tile_h] <= capacity)
+        build_segment_lists<SC_BLOCK>(gg.sw * gg.sh, st_offsets, small_max, large_list, long_list, long_mode != 0);
+      return;
+    }
     if ((int)blockIdx.x >= first) {
       fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first, jb, tile_offsets);
       __syncthreads();
@@ -342,7 +453,6 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
     }
   }
   extern __shared__ uint32_t s_cur[];  // [supertiles of the pass] (STAGE: + destination deltas + staging buffer)
-  __shared__ int s_large;
   __shared__ uint32_t s_wave_tot[SC_WAVES];
   __shared__ int4 s_q[SC_WAVES][64];
   __shared__ int32_t s_excl[SC_WAVES][64];
@@ -351,14 +461,8 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   const int chunk = blockIdx.x, S = g.sw * g.sh;
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;  // the guess was too small: the host repeats the call
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  if (chunk == 0) {
-    // the supertiles too long for the small sort launch, for the large one's persistent workgroups (order: any)
-    if (threadIdx.x == 0) s_large = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < S; i += SC_BLOCK)
-      if (st_offsets[i + 1] - st_offsets[i] > small_max) large_list[1 + atomicAdd(&s_large, 1)] = i;
-    __syncthreads();
-    if (threadIdx.x == 0) large_list[0] = s_large;
+  if constexpr (!STAGE) {
+    if (chunk == 0) build_segment_lists<SC_BLOCK>(S, st_offsets, small_max, large_list, long_list, long_mode != 0);
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}
@@ -700,8 +804,9 @@ struct SortShared {
     if (qb_ < R)                                         \
       _Pragma("unroll") for (int q = qb_; q < qb_ + QB; ++q)
 
-template <int NW, int KPT, int BB>
-__device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, const uint64_t* __restrict__ src, int n,
+// (src_at(i): element i of the input, i < n; EMIT = false: stop with the n elements in order in sh.img)
+template <int NW, int KPT, int BB, bool EMIT = true, typename SrcAt>
+__device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, SrcAt src_at, int n,
                                               const int* tile_base, int32_t* __restrict__ flatten_ids) {
   constexpr int NT = 64 * NW, NB = 1 << BB, PER = NB / NT;
   static_assert(NB % NT == 0 && PER >= 1 && (PER % 4 == 0 || PER < 4), "buckets per thread");
@@ -717,7 +822,7 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   uint64_t e[KPT];
 #pragma unroll
   for (int q = 0; q < KPT; ++q) e[q] = 0;
-  SB_FOR_ROUNDS(q) e[q] = src[(valid >> q) & 1u ? ibase + q * 64 : 0];  // (R > 0 here: src[0] exists)
+  SB_FOR_ROUNDS(q) e[q] = src_at((valid >> q) & 1u ? ibase + q * 64 : 0);  // (R > 0 here: element 0 exists)
   uint32_t lo = 0xFFFFFFFFu, hi = 0u;
   SB_FOR_ROUNDS(q) {
     const bool v = (valid >> q) & 1u;
@@ -815,6 +920,7 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   SB_FOR_ROUNDS(q)
     if (pos[q] >= 0) sh.img[pos[q]] = e[q];  // (elements alone in their bucket are in place)
   __syncthreads();
+  if constexpr (!EMIT) return;
   // ---- emission ----
   uint32_t idm[KPT], ranks[KPT];
   uint32_t pre[KPT][4], c[4] = {0, 0, 0, 0};  // (wave-uniform: scalar registers)
@@ -859,6 +965,20 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
 // per supertile and takes all of them on the 1M / 1080p scene; the LARGE one (1024 threads, up to 8064 elements) is
 // SB_LARGE_GRID persistent workgroups over the list of longer segments the scatter kernel left (empty: they return);
 // beyond its capacity a segment goes through global memory.
+// first list slot of the supertile's four tiles (0 for tiles outside the image)
+__device__ __forceinline__ void supertile_tile_bases(int st, int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
+                                                     int (&tile_base)[4], int (&tile_id)[4]) {
+  const Geo g = geo_of(tile_w, tile_h);
+  const int sy = st / g.sw, sx = st - sy * g.sw;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int tx = 2 * sx + (j & 1), ty = 2 * sy + (j >> 1);
+    const bool inside = tx < tile_w && ty < tile_h;
+    tile_id[j] = inside ? ty * tile_w + tx : -1;
+    tile_base[j] = inside ? tile_offsets[tile_id[j]] : 0;
+  }
+}
+
 template <int NW, int KPT, int BB, bool SMALL>
 __device__ __forceinline__ void sort_supertile(SortShared<NW, KPT, BB>& sh, int st, int tile_w, int tile_h,
                                                const int32_t* __restrict__ tile_offsets,
@@ -868,32 +988,28 @@ __device__ __forceinline__ void sort_supertile(SortShared<NW, KPT, BB>& sh, int 
   constexpr int MAXN = SortShared<NW, KPT, BB>::MAXN;  // elements sorted in LDS by this variant
   uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
   static_assert((1 << BB) >= NW * 256, "the fallback's counters live in the bucket array");
-  const Geo g = geo_of(tile_w, tile_h);
-  const int sy = st / g.sw, sx = st - sy * g.sw;
-  const int tx0 = 2 * sx, ty0 = 2 * sy, T = tile_w * tile_h;
-  int tile_base[4];
+  const int T = tile_w * tile_h;
+  int tile_base[4], tile_id[4];
+  supertile_tile_bases(st, tile_w, tile_h, tile_offsets, tile_base, tile_id);
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-    const int tx = tx0 + (j & 1), ty = ty0 + (j >> 1);
-    const bool inside = tx < tile_w && ty < tile_h;
-    const int tile = ty * tile_w + tx;
-    tile_base[j] = inside ? tile_offsets[tile] : 0;
     // the ranges the CONSUMERS of flatten_ids read: the tile ranges when the list fits, empty lists when it
     // does not (nothing is filled then; whoever was enqueued speculatively behind this call walks nothing)
-    if (SMALL && inside && threadIdx.x == 0) {
-      list_offsets[tile] = over ? 0 : tile_base[j];
-      if (tile == T - 1) list_offsets[T] = over ? 0 : total;
+    if (SMALL && tile_id[j] >= 0 && threadIdx.x == 0) {
+      list_offsets[tile_id[j]] = over ? 0 : tile_base[j];
+      if (tile_id[j] == T - 1) list_offsets[T] = over ? 0 : total;
     }
   }
   const int off = st_offsets[st], n = st_offsets[st + 1] - off;
   if (over || n <= 0) return;
-  if (SMALL && n > MAXN) return;  // (on the large launch's list)
+  if (SMALL && n > MAXN) return;  // (on the large launch's list, or a long segment)
   if (n > MAXN) {
     const uint64_t* fin = sort_segment_global<NW>(entries + off, scratch + off, n, wave_cnt, sh.scan_tmp, sh.red);
     emit_tiles<NW>(fin, n, tile_base, flatten_ids, sh.tcnt);
     return;
   }
-  sort_emit_lds<NW, KPT, BB>(sh, (int)threadIdx.x, entries + off, n, tile_base, flatten_ids);
+  const uint64_t* __restrict__ src = entries + off;
+  sort_emit_lds<NW, KPT, BB>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n, tile_base, flatten_ids);
 }
 
 __global__ void __launch_bounds__(64 * SB_SMALL_WAVES)
@@ -912,12 +1028,46 @@ sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
       list_offsets);
 }
 
+// ---- long segments: sample sort ------------------------------------------------------------------------------------
+// A segment of n > SB_LONG_MIN elements (tens of thousands of splats over one 32 x 32-pixel supertile: a dense
+// cluster) is cut into k = long_buckets(n) buckets by k - 1 SPLITTERS taken from a sorted regular sample of the
+// segment; elements are unique 64-bit values (depth bits | id | mask), so any distribution of depths -- ties
+// included -- splits into buckets of about n / k elements.  Passes, every one of them many workgroups wide:
+//   sample   (a work item of the large sort launch) one workgroup per segment sorts LG_SA * k samples in LDS, writes the
+//            splitters, zeroes the bucket counters
+//   count    per chunk of LG_CHUNK elements: bucket of every element by bisection over the splitters in LDS, counts
+//            per bucket and per (bucket, tile of the supertile) -> global counters
+//   scatter  per chunk: the same buckets; a run per (chunk, bucket) reserved with ONE returning atomic on the bucket's
+//            cursor; elements to `scratch` at segment start + bucket start + run + rank.  Order inside a bucket: any.
+//   sort     per bucket: the LDS sort + emission used for whole segments, with the tile bases advanced by what the
+//            buckets in front send to each tile.  (A bucket beyond the LDS capacity -- the sample was unlucky by a
+//            factor of three -- goes through global memory in one workgroup, as whole segments did before.)
+// Same lists, bit for bit: inside a tile the order is the total order on (depth bits, id).
+template <int NW, int KPT, int BB>
+__device__ __forceinline__ void sample_long_segment(SortShared<NW, KPT, BB>& sh, const uint64_t* __restrict__ src, int n,
+                                                    int bucket_base, const LongTables& lt) {
+  constexpr int NT = 64 * NW;
+  const int k = long_buckets(n), s = long_samples(k);
+  const uint64_t step = ((uint64_t)n << 16) / (uint64_t)s;  // sample i = element floor(i n / s): distinct positions
+  sort_emit_lds<NW, KPT, BB, false>(sh, (int)threadIdx.x, [src, step](int i) { return src[((uint64_t)i * step) >> 16]; }, s,
+                                    nullptr, nullptr);
+  for (int t = threadIdx.x; t < k; t += NT) {
+    if (t + 1 < k) lt.split[bucket_base + t] = sh.img[(int)(((long long)(t + 1) * s) / k)];
+    lt.cnt[bucket_base + t] = 0u;
+    lt.cursor[bucket_base + t] = 0u;
+    lt.tcnt[bucket_base + t] = make_uint4(0, 0, 0, 0);
+  }
+  __syncthreads();  // (sh.img is the next work item's)
+}
+
 __global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
 sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
                      const int32_t* __restrict__ st_offsets, const int32_t* __restrict__ large_list,
-                     uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, long long capacity,
-                     int32_t* __restrict__ flatten_ids, int job_blocks, fgjobs::JobBuild jb) {
+                     const int4* __restrict__ long_list, LongTables lt, uint64_t* __restrict__ entries,
+                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
+                     int job_blocks, fgjobs::JobBuild jb) {
   __shared__ SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS> sh;
+  static_assert(SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>::MAXN == SB_LONG_MIN, "long = beyond this launch's LDS sort");
   // fg_stbin_fill_jobs: the first job_blocks workgroups build the raster launches' job lists from the (exact) tile
   // ranges -- only when the scatter in front ran without its staging buffer (sb_scatter_kernel)
   if ((int)blockIdx.x < job_blocks) {
@@ -926,11 +1076,214 @@ sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
   }
   const int total = tile_offsets[tile_w * tile_h];
   if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
-  const int count = large_list[0];
-  for (int k = (int)blockIdx.x - job_blocks; k < count; k += (int)gridDim.x - job_blocks) {
-    sort_supertile<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS, false>(
-        sh, large_list[1 + k], tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, false, total, flatten_ids,
-        nullptr);
+  // work items: the long segments' sample step first (the head of a chain of three more launches), then the LDS sorts
+  const int n_long = long_list[0].x, count = large_list[0];
+  for (int k = (int)blockIdx.x - job_blocks; k < n_long + count; k += (int)gridDim.x - job_blocks) {
+    if (k < n_long) {
+      const int4 ls = long_list[1 + k];
+      sample_long_segment(sh, entries + st_offsets[ls.x], ls.w, ls.z, lt);
+    } else {
+      sort_supertile<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS, false>(
+          sh, large_list[1 + k - n_long], tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, false, total,
+          flatten_ids, nullptr);
+    }
+    __syncthreads();
+  }
+}
+
+// bucket of element e among k: the number of splitters <= e (s_split[0 .. k - 1) ascending, in LDS)
+__device__ __forceinline__ int long_bucket_of(const uint64_t* s_split, int k, uint64_t e) {
+  int b = 0;
+#pragma unroll
+  for (int step = 512; step >= 1; step >>= 1) {
+    const int t = b + step;
+    const uint64_t v = s_split[min(t, k - 1) - 1];  // (k >= 2)
+    b = (t <= k - 1 && v <= e) ? t : b;
+  }
+  return b;
+}
+static_assert(LG_KMAX <= 1024, "long_bucket_of bisects 10 levels");
+
+__global__ void __launch_bounds__(LG_BLOCK)
+sb_long_count_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long long capacity,
+                     const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list,
+                     const uint64_t* __restrict__ entries, LongTables lt) {
+  __shared__ uint64_t s_split[LG_KMAX];
+  __shared__ uint32_t s_cnt[LG_KMAX];
+  __shared__ unsigned long long s_tc[LG_KMAX];  // four 16-bit counters: elements of this chunk per tile of the supertile
+  if ((long long)tile_offsets[n_tiles] > capacity) return;
+  const int4 hdr = long_list[0];
+  int cur = -1;
+  for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
+    const int seg = long_segment_of(long_list, hdr.x, w, 1);
+    const int4 ls = long_list[1 + seg];
+    const int n = ls.w, k = long_buckets(n), c = w - ls.y;
+    const uint64_t* __restrict__ src = entries + st_offsets[ls.x];
+    if (seg != cur) {
+      for (int t = threadIdx.x; t < k - 1; t += LG_BLOCK) s_split[t] = lt.split[ls.z + t];
+      cur = seg;
+    }
+    for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
+      s_cnt[t] = 0u;
+      s_tc[t] = 0ull;
+    }
+    __syncthreads();
+    uint64_t e[LG_PER];
+#pragma unroll
+    for (int q = 0; q < LG_PER; ++q) {
+      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
+      e[q] = src[min(i, n - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < LG_PER; ++q) {
+      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
+      if (i < n) {
+        const int b = long_bucket_of(s_split, k, e[q]);
+        const uint32_t m = (uint32_t)e[q] & 15u;
+        atomicAdd(&s_cnt[b], 1u);
+        atomicAdd(&s_tc[b], (unsigned long long)(m & 1u) | ((unsigned long long)((m >> 1) & 1u) << 16) |
+                                ((unsigned long long)((m >> 2) & 1u) << 32) | ((unsigned long long)((m >> 3) & 1u) << 48));
+      }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
+      const uint32_t cn = s_cnt[t];
+      if (cn) {
+        const unsigned long long tc = s_tc[t];
+        atomicAdd(&lt.cnt[ls.z + t], cn);
+        uint32_t* tg = reinterpret_cast<uint32_t*>(&lt.tcnt[ls.z + t]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t v = (uint32_t)(tc >> (16 * j)) & 0xFFFFu;
+          if (v) atomicAdd(&tg[j], v);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+static_assert(LG_CHUNK < 65536, "16-bit per-chunk tile counters");
+
+// exclusive prefix sums over k <= 2 * LG_BLOCK values in LDS, in place; returns nothing (all threads call)
+__device__ __forceinline__ void long_excl_scan(uint32_t* vals, int k, uint32_t* s_wtot) {
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int i = 2 * (int)threadIdx.x;
+  const uint32_t a = i < k ? vals[i] : 0u, b = i + 1 < k ? vals[i + 1] : 0u;
+  const uint32_t incl = wave_incl_scan(a + b, lane);
+  __syncthreads();
+  if (lane == 63) s_wtot[wave] = incl;
+  __syncthreads();
+  uint32_t run = incl - (a + b);
+#pragma unroll
+  for (int w = 0; w < LG_BLOCK / 64; ++w)
+    if (w < wave) run += s_wtot[w];
+  if (i < k) vals[i] = run;
+  if (i + 1 < k) vals[i + 1] = run + a;
+  __syncthreads();
+}
+static_assert(LG_KMAX <= 2 * LG_BLOCK, "long_excl_scan takes two values per thread");
+
+__global__ void __launch_bounds__(LG_BLOCK)
+sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long long capacity,
+                       const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list,
+                       const uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, LongTables lt) {
+  __shared__ uint64_t s_split[LG_KMAX];
+  __shared__ uint32_t s_boff[LG_KMAX], s_hist[LG_KMAX], s_tmp[LG_KMAX];
+  __shared__ uint32_t s_wtot[LG_BLOCK / 64];
+  if ((long long)tile_offsets[n_tiles] > capacity) return;
+  const int4 hdr = long_list[0];
+  int cur = -1;
+  for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
+    const int seg = long_segment_of(long_list, hdr.x, w, 1);
+    const int4 ls = long_list[1 + seg];
+    const int n = ls.w, k = long_buckets(n), c = w - ls.y;
+    const int off = st_offsets[ls.x];
+    const uint64_t* __restrict__ src = entries + off;
+    if (seg != cur) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
+        if (t + 1 < k) s_split[t] = lt.split[ls.z + t];
+        s_boff[t] = lt.cnt[ls.z + t];
+      }
+      __syncthreads();
+      long_excl_scan(s_boff, k, s_wtot);  // bucket starts inside the segment
+      cur = seg;
+    }
+    if (c == 0) {
+      // the segment's first chunk also leaves what the bucket sort needs: bucket starts, tile bases per bucket
+      for (int t = threadIdx.x; t < k; t += LG_BLOCK) lt.boff[ls.z + t] = s_boff[t];
+      uint32_t* tb = reinterpret_cast<uint32_t*>(lt.tbase + ls.z);
+      const uint32_t* tcn = reinterpret_cast<const uint32_t*>(lt.tcnt + ls.z);
+      for (int j = 0; j < 4; ++j) {
+        for (int t = threadIdx.x; t < k; t += LG_BLOCK) s_tmp[t] = tcn[4 * t + j];
+        __syncthreads();
+        long_excl_scan(s_tmp, k, s_wtot);
+        for (int t = threadIdx.x; t < k; t += LG_BLOCK) tb[4 * t + j] = s_tmp[t];
+        __syncthreads();
+      }
+    }
+    for (int t = threadIdx.x; t < k; t += LG_BLOCK) s_hist[t] = 0u;
+    __syncthreads();
+    uint64_t e[LG_PER];
+    int bk[LG_PER];
+    uint32_t rk[LG_PER];
+#pragma unroll
+    for (int q = 0; q < LG_PER; ++q) {
+      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
+      e[q] = src[min(i, n - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < LG_PER; ++q) {
+      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
+      bk[q] = -1;
+      rk[q] = 0u;
+      if (i < n) {
+        bk[q] = long_bucket_of(s_split, k, e[q]);
+        rk[q] = atomicAdd(&s_hist[bk[q]], 1u);
+      }
+    }
+    __syncthreads();
+    // one run per (chunk, bucket): s_tmp[b] = the run's first slot in the segment
+    for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
+      const uint32_t h = s_hist[t];
+      if (h) s_tmp[t] = s_boff[t] + atomicAdd(&lt.cursor[ls.z + t], h);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < LG_PER; ++q)
+      if (bk[q] >= 0) scratch[(size_t)off + s_tmp[bk[q]] + rk[q]] = e[q];
+    __syncthreads();
+  }
+}
+
+__global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
+sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
+                    const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list, LongTables lt,
+                    uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
+  using Sh = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>;
+  __shared__ Sh sh;
+  if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
+  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
+  const int4 hdr = long_list[0];
+  for (int item = blockIdx.x; item < hdr.z; item += gridDim.x) {
+    const int seg = long_segment_of(long_list, hdr.x, item, 2);
+    const int4 ls = long_list[1 + seg];
+    const int slot = item;  // (= ls.z + bucket)
+    const int n_b = (int)lt.cnt[slot];
+    if (n_b == 0) continue;  // (uniform)
+    const size_t off = (size_t)st_offsets[ls.x] + lt.boff[slot];
+    const uint4 tb = lt.tbase[slot];
+    int tile_base[4], tile_id[4];
+    supertile_tile_bases(ls.x, tile_w, tile_h, tile_offsets, tile_base, tile_id);
+    tile_base[0] += (int)tb.x; tile_base[1] += (int)tb.y; tile_base[2] += (int)tb.z; tile_base[3] += (int)tb.w;
+    if (n_b > Sh::MAXN) {
+      const uint64_t* fin = sort_segment_global<SB_LARGE_WAVES>(scratch + off, entries + off, n_b, wave_cnt, sh.scan_tmp, sh.red);
+      emit_tiles<SB_LARGE_WAVES>(fin, n_b, tile_base, flatten_ids, sh.tcnt);
+    } else {
+      const uint64_t* __restrict__ src = scratch + off;
+      sort_emit_lds<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>(sh, (int)threadIdx.x, [src](int i) { return src[i]; },
+                                                                         n_b, tile_base, flatten_ids);
+    }
     __syncthreads();
   }
 }
@@ -942,6 +1295,7 @@ struct CountWs {
   uint32_t *table_t, *table_s;
   int32_t* st_offsets;
   int32_t* large_list;  // [0] = how many supertiles the small sort launch leaves to the large one, then their indices
+  int4* long_list;      // build_segment_lists
   size_t bytes;
 };
 CountWs count_ws(void* base, int N, const Geo& g) {
@@ -957,6 +1311,8 @@ CountWs count_ws(void* base, int N, const Geo& g) {
   o += al256((S + 1) * 4);
   w.large_list = reinterpret_cast<int32_t*>(p + o);
   o += al256((S + 1) * 4);
+  w.long_list = reinterpret_cast<int4*>(p + o);
+  o += al256((S + 2) * 16);
   w.bytes = o;
   return w;
 }
@@ -997,29 +1353,64 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
   return FG_OK;
 }
 
+namespace {
+// buckets of all long segments together: sum of ceil(n / LG_T) over segments of more than SB_LONG_MIN elements
+size_t long_buckets_max(size_t capacity) { return capacity / LG_T + capacity / SB_LONG_MIN + 2; }
+struct FillWs {
+  uint64_t *entries, *scratch;
+  LongTables lt;
+  size_t bytes;
+};
+FillWs fill_ws(void* base, size_t capacity) {
+  char* p = static_cast<char*>(base);
+  const size_t kb = long_buckets_max(capacity);
+  FillWs w;
+  size_t o = 0;
+  w.entries = reinterpret_cast<uint64_t*>(p + o);
+  o += al256(capacity * 8);
+  w.scratch = reinterpret_cast<uint64_t*>(p + o);
+  o += al256(capacity * 8);
+  w.lt.split = reinterpret_cast<uint64_t*>(p + o);
+  o += al256(kb * 8);
+  w.lt.tcnt = reinterpret_cast<uint4*>(p + o);
+  o += al256(kb * 16);
+  w.lt.tbase = reinterpret_cast<uint4*>(p + o);
+  o += al256(kb * 16);
+  w.lt.cnt = reinterpret_cast<uint32_t*>(p + o);
+  o += al256(kb * 4);
+  w.lt.cursor = reinterpret_cast<uint32_t*>(p + o);
+  o += al256(kb * 4);
+  w.lt.boff = reinterpret_cast<uint32_t*>(p + o);
+  o += al256(kb * 4);
+  w.bytes = o;
+  return w;
+}
+}  // namespace
+
 extern "C" size_t fg_stbin_fill_workspace_bytes(int64_t capacity) {
-  const size_t c = (size_t)(capacity > 0 ? capacity : 1);
-  return 2 * al256(c * 8);
+  return fill_ws(nullptr, (size_t)(capacity > 0 ? capacity : 1)).bytes;
 }
 
 namespace {
 
 int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h, int64_t capacity,
                const int32_t* tile_offsets, const void* count_workspace, int32_t* flatten_ids, int32_t* list_offsets,
-               void* workspace, size_t workspace_bytes, const fgjobs::JobBuild* jobs, fg_stream_t stream) {
+               void* workspace, size_t workspace_bytes, const fgjobs::JobBuild* jobs, int flags, fg_stream_t stream) {
   if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
   if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !list_offsets || !workspace)
     return FG_ERR_INVALID_ARG;
+  if (flags & ~FG_STBIN_LONG_SEGMENTS) return FG_ERR_INVALID_ARG;
   if (!fg_stbin_supported(N, tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
   if (workspace_bytes < fg_stbin_fill_workspace_bytes(capacity)) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
   const Geo g = geo_of(tile_w, tile_h);
   const CountWs w = count_ws(const_cast<void*>(count_workspace), N, g);
+  const FillWs fw = fill_ws(workspace, (size_t)capacity);
   const int nc = n_chunks_of(N);
-  char* p = static_cast<char*>(workspace);
-  uint64_t* entries = reinterpret_cast<uint64_t*>(p);
-  uint64_t* scratch = reinterpret_cast<uint64_t*>(p + al256((size_t)capacity * 8));
-  const int band_rows = scatter_band_rows(g), S = g.sw * g.sh;
+  uint64_t* entries = fw.entries;
+  uint64_t* scratch = fw.scratch;
+  const int band_rows = scatter_band_rows(g), S = g.sw * g.sh, T = tile_w * tile_h;
+  const int long_mode = (flags & FG_STBIN_LONG_SEGMENTS) ? 1 : 0;
   constexpr int small_max = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>::MAXN;
   // staging buffer: whatever the LDS leaves beside the two [S] arrays, if that is worth it (10 bytes per element)
   const int s_pad = (S + 1) & ~1;
@@ -1027,29 +1418,48 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
   stage_cap = stage_cap >= SB_MIN_STAGE ? (stage_cap & ~63) : 0;
   bool want_jobs = jobs && (jobs->jobs_fwd || jobs->jobs_bwd);
   if (stage_cap) {
-    const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
-    static bool attr_set = false;  // (dynamic LDS beyond 64 KB; benign if two threads race to set the same value)
-    if (!attr_set) {
-      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel<true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SCATTER_LDS_BYTES);
-      attr_set = true;
+    // dynamic LDS beyond 64 KB is an opt-in per function AND per device: remember which devices have it
+    static std::atomic<uint64_t> attr_devices{0};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) {
+      stage_cap = 0;
+    } else if (!((attr_devices.load(std::memory_order_relaxed) >> dev) & 1u)) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(sb_scatter_kernel<true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)SB_SCATTER_LDS_BYTES) == hipSuccess) {
+        attr_devices.fetch_or(1ull << dev, std::memory_order_relaxed);
+      } else {
+        (void)hipGetLastError();
+        stage_cap = 0;  // the un-staged scatter needs no opt-in
+      }
     }
-    // (the job lists ride here; without the staged scatter, in the large-segment sort launch)
-    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0)), dim3(SC_BLOCK), lds, s, N,
+  }
+  if (stage_cap) {
+    const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
+    // (the job lists and the segment lists ride here; without the staged scatter: in the large-segment sort launch / chunk 0)
+    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
-                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, want_jobs ? 8 : 0,
-                       want_jobs ? *jobs : fgjobs::JobBuild{});
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
+                       long_mode, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{});
     want_jobs = false;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
-                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, 0,
-                       fgjobs::JobBuild{});
+                       tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
+                       long_mode, 0, fgjobs::JobBuild{});
   }
   const int job_blocks = want_jobs ? fgjobs::FG_JOB_BLOCKS : 0;
   hipLaunchKernelGGL(sb_sort_large_kernel, dim3((S < SB_LARGE_GRID ? S : SB_LARGE_GRID) + job_blocks),
-                     dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, entries,
-                     scratch, (long long)capacity, flatten_ids, job_blocks, job_blocks ? *jobs : fgjobs::JobBuild{});
+                     dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, w.long_list,
+                     fw.lt, entries, scratch, (long long)capacity, flatten_ids, job_blocks,
+                     job_blocks ? *jobs : fgjobs::JobBuild{});
+  if (long_mode) {
+    hipLaunchKernelGGL(sb_long_count_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
+                       w.st_offsets, w.long_list, entries, fw.lt);
+    hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
+                       w.st_offsets, w.long_list, entries, scratch, fw.lt);
+    hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h,
+                       (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
+  }
   hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h, tile_offsets,
                      w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets);
   FG_RETURN_IF_LAUNCH_FAILED();
@@ -1061,16 +1471,16 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
 extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                              int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                              int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
-                             fg_stream_t stream) {
+                             int flags, fg_stream_t stream) {
   return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
-                    list_offsets, workspace, workspace_bytes, nullptr, stream);
+                    list_offsets, workspace, workspace_bytes, nullptr, flags, stream);
 }
 
 extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                                   int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                                   int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
-                                  int bwd_list_shares, const fg_raster_config* config, fg_stream_t stream) {
+                                  int bwd_list_shares, const fg_raster_config* config, int flags, fg_stream_t stream) {
   if (width <= 0 || height <= 0 || tile_size <= 0) return FG_ERR_INVALID_ARG;
   if ((width + tile_size - 1) / tile_size != tile_w || (height + tile_size - 1) / tile_size != tile_h)
     return FG_ERR_INVALID_ARG;
@@ -1078,5 +1488,5 @@ extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32
   const int rc = fgjobs::plan_jobs(width, height, tile_size, jobs_fwd, jobs_bwd, bwd_list_shares, config, &jb);
   if (rc != FG_OK) return rc;
   return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
-                    list_offsets, workspace, workspace_bytes, &jb, stream);
+                    list_offsets, workspace, workspace_bytes, &jb, flags, stream);
 }

@@ -133,15 +133,20 @@ class RasterContext:
         if self.binning not in ("supertile", "depthfirst"):
             raise ValueError(f"FG_BINNING={self.binning!r}: supertile | depthfirst")
         # The supertile path sorts a segment in LDS up to 8064 elements; a longer one (a dense cluster: tens of
-        # thousands of splats over one 32 x 32-pixel supertile) goes through global memory in ONE workgroup --
-        # correct but slow (2.8 ms at a 111 000-entry tile).  fg_stbin_count reports the longest segment with the
-        # list length; a shape that showed such a segment is binned depth-first for the next
-        # `heavy_cooldown` calls, then probed again.  FG_ADAPTIVE_BINNING=0: always the configured path.
-        self.adaptive_binning = e.get("FG_ADAPTIVE_BINNING", "1") != "0"
-        self.heavy_segment = 8064
-        self.heavy_cooldown = 256
-        self.heavy_shapes = {}  # shape key -> calls left on the depth-first path
-        self.binning_fallbacks = 0  # calls that took the depth-first path because of a heavy segment seen earlier
+        # thousands of splats over one 32 x 32-pixel supertile) is cut into buckets by a multi-workgroup sample sort
+        # when fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS -- three more launches, so only for shapes that
+        # need them: fg_stbin_count reports the longest segment beside the list length, a shape that showed one
+        # beyond `long_segment` gets the flag for its next `long_cooldown` calls (renewed by every call that shows one
+        # again).  Without the flag such a segment is sorted by ONE workgroup through global memory: correct, slow
+        # (2.8 ms at a 111 000-entry tile) -- what the first call of a heavy shape pays.
+        # FG_LONG_SEGMENTS = auto (default) | always | never.
+        self.long_segments = e.get("FG_LONG_SEGMENTS", "auto")
+        if self.long_segments not in ("auto", "always", "never"):
+            raise ValueError(f"FG_LONG_SEGMENTS={self.long_segments!r}: auto | always | never")
+        self.long_segment = 8064
+        self.long_cooldown = 64
+        self.long_shapes = {}  # shape key -> calls left with the flag set
+        self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -501,14 +506,8 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     rctx = current()
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     if keys_rects is not None and rctx.binning == "supertile" and lib.fg_stbin_supported(N, tile_w, tile_h):
-        hkey = (dev, N, tile_w, tile_h)
-        left = rctx.heavy_shapes.get(hkey, 0) if rctx.adaptive_binning else 0
-        if left <= 0:
-            return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev,
-                                        raster_hint if tile_size == TILE_SIZE else None)
-        if static_capacity is None:  # (a captured graph keeps the path of the eager call that measured it)
-            rctx.heavy_shapes[hkey] = left - 1  # (0: the next call probes the supertile path again)
-        rctx.binning_fallbacks += 1
+        return _bin_tiles_supertile(rctx, "fg_stbin", N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev,
+                                    raster_hint if tile_size == TILE_SIZE else None)
     order = torch.empty(N, dtype=torch.int32, device=dev)
     cum = torch.empty(N, dtype=torch.int64, device=dev)
     ws = torch.empty(int(lib.fg_bin_prepare_workspace_bytes(N)), dtype=torch.uint8, device=dev)
@@ -640,18 +639,24 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
+    lkey = (dev, N, tile_w, tile_h)
+
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(getattr(lib, abi + "_fill_workspace_bytes")(cap)), dtype=torch.uint8, device=dev)
         args = (N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1), _ptr(ids),
                 _ptr(offsets), _ptr(ws2), ws2.numel())  # fmt: skip
+        # long segments seen on this shape lately (or FG_LONG_SEGMENTS=always): the multi-workgroup sample sort
+        long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
+        flags = _lib.STBIN_LONG_SEGMENTS if long_mode else 0
+        rctx.long_calls += int(long_mode)
         prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev) if rctx.jobs_in_fill else None
         if prebuilt is None:
-            _call(abi + "_fill", *args, _stream(), stage="fg_bin_emit_sort_capacity")
+            _call(abi + "_fill", *args, flags, _stream(), stage="fg_bin_emit_sort_capacity")
         else:
             jobs, shares, cfgp = prebuilt[0], prebuilt[1], rctx.cfg()
             _call(abi + "_fill_jobs", *args, int(raster_hint[1]), int(raster_hint[2]), TILE_SIZE, _ptr(jobs[0]),
-                  _ptr(jobs[1]), int(shares), cfgp, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+                  _ptr(jobs[1]), int(shares), cfgp, flags, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
         offsets._fg_jobs = prebuilt  # (for _RasterSplats.forward; None: it builds the lists itself)
         return ids
 
@@ -678,10 +683,14 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     def finish():
         if count_slot is not None:
             n_isects = _poll_count(count_slot)
-            if rctx.adaptive_binning and _poll_count(count_slot, 1) > rctx.heavy_segment:
-                if len(rctx.heavy_shapes) >= 256:
-                    rctx.heavy_shapes.pop(next(iter(rctx.heavy_shapes)))
-                rctx.heavy_shapes[(dev, N, tile_w, tile_h)] = rctx.heavy_cooldown
+            if _poll_count(count_slot, 1) > rctx.long_segment:
+                if lkey not in rctx.long_shapes and len(rctx.long_shapes) >= 256:
+                    rctx.long_shapes.pop(next(iter(rctx.long_shapes)))
+                rctx.long_shapes[lkey] = rctx.long_cooldown
+            elif lkey in rctx.long_shapes:
+                rctx.long_shapes[lkey] -= 1
+                if rctx.long_shapes[lkey] <= 0:
+                    del rctx.long_shapes[lkey]
         else:
             ready.synchronize()
             n_isects = int(count_host[0])

@@ -44,7 +44,7 @@ typedef void* fg_stream_t;
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
 #define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
-#define FG_ABI_VERSION 6
+#define FG_ABI_VERSION 7
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -152,8 +152,8 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
  * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, TWO words with
  * system scope (pinned host memory): count_out[0] the list length, count_out[1] the longest supertile segment
- * (segments beyond 8064 elements are sorted by one workgroup through global memory -- correct, slow: a host
- * that sees them can take fg_bin_prepare_keys + fg_bin_emit_sort for that scene, as rasterization() does).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
+ * (segments beyond 8064 elements are sorted by one workgroup through global memory -- correct, slow -- unless
+ * fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS, see below).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
  * list_offsets = 0 (empty lists: consumers enqueued speculatively behind the call walk nothing; the host then
  * repeats the call with exact buffers, the count workspace stays valid).  Consumers of flatten_ids read
@@ -165,10 +165,17 @@ size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
 int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
                    int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
 size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
+/* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond 8064 elements (a dense cluster: tens of
+ * thousands of splats over one 32 x 32-pixel supertile) are cut into buckets by a multi-workgroup sample sort
+ * (three more launches: count, scatter, one LDS sort per bucket) instead of being sorted by ONE workgroup through
+ * global memory.  Same lists bit for bit either way; a host sets the flag for shapes whose count_out[1] of an
+ * earlier call exceeded 8064 (ops.bin_tiles does) -- on scenes without such segments the flag only costs the three
+ * empty launches. */
+#define FG_STBIN_LONG_SEGMENTS 1
 int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                   int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
-                  fg_stream_t stream);
+                  int flags, fg_stream_t stream);
 /* (fg_stbin_fill_jobs, with the job lists further down: this call and fg_raster_build_jobs in the same launches) */
 
 /* tile_keys may be NULL in both emit entry points when the caller does not need the keys (up to
@@ -309,7 +316,7 @@ int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_re
                        int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                        int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                        int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
-                       int bwd_list_shares, const fg_raster_config* config, fg_stream_t stream);
+                       int bwd_list_shares, const fg_raster_config* config, int flags, fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,

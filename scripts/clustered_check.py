@@ -43,9 +43,9 @@ for _ in range(20):
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 20 * 1e3
 st = ops.default_context.stage_timer.summary()
-offs = info["isect_offsets"].reshape(-1).long()
-lens = (torch.cat([offs[1:], torch.tensor([info["flatten_ids"].numel()], device=offs.device)]) - offs).float() if offs.numel() == info["tile_width"] * info["tile_height"] else (offs[1:] - offs[:-1]).float()
-print(json.dumps({"tail_fwd": os.environ.get("FG_RASTER_TAIL_FWD"), "tail_bwd": os.environ.get("FG_RASTER_TAIL_BWD"),
-                  "I": info["flatten_ids"].numel(), "mean_len": float(lens.mean()), "max_len": float(lens.max()),
+offs = info["raster_isect_offsets"].reshape(-1).long()  # [T + 1]: the lists the raster launches walked
+lens = (offs[1:] - offs[:-1]).float()
+print(json.dumps({"scene": [frac, ball], "I_raster": int(offs[-1]), "mean_len": float(lens.mean()), "max_len": float(lens.max()),
                   "step_ms": round(dt, 4), "fwd": st.get("fg_raster_fwd"), "bwd": st.get("fg_raster_bwd"),
-                  "binning": os.environ.get("FG_BINNING", "supertile"), "stages": {k: round(v, 4) for k, v in st.items()}}))
+                  "binning": os.environ.get("FG_BINNING", "supertile"), "long_segments": os.environ.get("FG_LONG_SEGMENTS", "auto"),
+                  "long_calls": ops.default_context.long_calls, "stages": {k: round(v, 4) for k, v in st.items()}}))

@@ -12,7 +12,7 @@ for sc in "" "0.5:0.4" "0.8:0.2"; do
 done
 for sc in "0.5 0.4" "0.8 0.2"; do
   for b in supertile depthfirst; do
-    FG_ADAPTIVE_BINNING=0 FG_BINNING=$b timeout 300 python scripts/clustered_check.py $sc >> $out/clustered.jsonl 2>> $out/clustered.err
+    FG_BINNING=$b timeout 300 python scripts/clustered_check.py $sc >> $out/clustered.jsonl 2>> $out/clustered.err
   done
   timeout 300 python scripts/clustered_check.py $sc >> $out/clustered.jsonl 2>> $out/clustered.err
 done

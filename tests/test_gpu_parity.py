@@ -348,8 +348,10 @@ def _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False)
     z = torch.zeros(N, device=DEV)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     outs = []
-    for mode in ("depthfirst", "supertile"):
+    # (the supertile path twice: long segments through one workgroup / through the multi-workgroup sample sort)
+    for mode, long_segments in (("depthfirst", "auto"), ("supertile", "never"), ("supertile", "always")):
         monkeypatch.setattr(ops.default_context, "binning", mode)
+        monkeypatch.setattr(ops.default_context, "long_segments", long_segments)
         ops.default_context.isect_capacity.clear()
         runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
         if overflow:
@@ -359,9 +361,10 @@ def _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False)
         for _, f, o in runs[1:]:
             assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
         outs.append(runs[0])
-    (_, f0, o0), (_, f2, o2) = outs
-    assert torch.equal(o2, o0), "tile ranges differ"
-    assert torch.equal(f2, f0), "lists differ"
+    (_, f0, o0), (_, f1, o1), (_, f2, o2) = outs
+    assert torch.equal(o1, o0) and torch.equal(o2, o0), "tile ranges differ"
+    assert torch.equal(f1, f0), "lists differ"
+    assert torch.equal(f2, f0), "lists differ (long-segment sample sort)"
     return f2, o2
 
 
@@ -369,14 +372,17 @@ def _pack_rects(x0, y0, w, h):
     return torch.stack([x0 | (y0 << 16), w | (h << 16)], -1).to(torch.int32).contiguous()
 
 
-@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "one", "all_culled", "few_rows", "2160p", "2880p"])
+@pytest.mark.parametrize("case", ["scene", "ties", "heavy_tile", "huge_tile", "long_cluster", "long_ties", "one", "all_culled",
+                                  "few_rows", "2160p", "2880p"])
 def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     """csrc/stbin.hip (count -> scan -> scatter per supertile -> one sort per supertile, four tile lists read off
     it) against the depth-first binning on the same depth keys and footprint rectangles: `torch.equal` lists and
     ranges.
     Cases: a projected scene with a too-small capacity guess; thousands of EXACT depth ties (the id decides);
     tiles with more entries than fit the small LDS sort (the large one), than fit any (the pass through global
-    memory); one Gaussian; nothing visible; an image of three tile rows; 32 400 tiles (the count kernel's grids in four passes); 57 600 tiles (the scatter's
+    memory, or -- FG_STBIN_LONG_SEGMENTS -- the sample sort: 20 000 entries = 8 buckets); a cluster of 300 000 + 70 000
+    entries over two supertiles with depth ties (112 + 27 buckets) and one of 60 000 entries of ONE depth (the id alone
+    decides, in the splitters as in the buckets); one Gaussian; nothing visible; an image of three tile rows; 32 400 tiles (the count kernel's grids in four passes); 57 600 tiles (the scatter's
     cursors in two passes, elements stored directly)."""
     g = torch.Generator().manual_seed(31)
     W, H = 640, 400
@@ -398,8 +404,8 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     if case == "2880p":
         W, H = 5120, 2880  # 14 400 supertiles: the scatter's cursors in two passes, no staging; count grids in seven
     tw, th = (W + 15) // 16, (H + 15) // 16
-    N = {"ties": 30000, "heavy_tile": 20000, "huge_tile": 40000, "one": 1, "all_culled": 5000, "few_rows": 4000,
-         "2160p": 200_000, "2880p": 150_000}[case]
+    N = {"ties": 30000, "heavy_tile": 20000, "huge_tile": 40000, "long_cluster": 500_000, "long_ties": 100_000, "one": 1,
+         "all_culled": 5000, "few_rows": 4000, "2160p": 200_000, "2880p": 150_000}[case]
     x0 = torch.randint(0, tw, (N,), generator=g)
     y0 = torch.randint(0, th, (N,), generator=g)
     w = torch.minimum(torch.randint(1, 5, (N,), generator=g), tw - x0)
@@ -415,6 +421,14 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     if case == "huge_tile":
         x0[:20000], y0[:20000], w[:20000], h[:20000] = 8, 4, 2, 2  # 20000 entries in one supertile: the pass through global memory
         depth[3000:3400] = 1.75
+    if case == "long_cluster":
+        x0[:300_000], y0[:300_000], w[:300_000], h[:300_000] = 8, 4, 2, 2  # one supertile, all four tiles
+        x0[300_000:370_000], y0[300_000:370_000], w[300_000:370_000] = 11, 6, 1  # the right half of another, 1-2 tile rows
+        depth[:300_000] = 3.9 + 0.2 * torch.rand(300_000, generator=g)  # a narrow band of depths ...
+        depth[5000:9000] = 4.0  # ... with a run of ties
+    if case == "long_ties":
+        x0[:60_000], y0[:60_000], w[:60_000], h[:60_000] = 2, 2, 2, 1
+        depth[:60_000] = 2.25
     keys = depth.float().view(torch.int32).clone()
     if case == "all_culled":
         w[:], h[:] = 0, 0
@@ -438,10 +452,10 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
     assert torch.equal(o.cpu().long(), torch.searchsorted(tile[order].contiguous(), torch.arange(tw * th + 1)))
 
 
-def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
+def test_long_segments_switch_the_sample_sort_on_for_a_while():
     """fg_stbin_count reports the longest supertile segment beside the list length; a shape that showed one beyond
-    the LDS sorts' capacity (a dense cluster) is binned depth-first for the next `heavy_cooldown` calls, then
-    probed again.  Same lists either way."""
+    the LDS sorts' capacity (a dense cluster) gets FG_STBIN_LONG_SEGMENTS for its next `long_cooldown` calls, renewed
+    while such segments keep coming.  Same lists either way."""
     g = torch.Generator().manual_seed(77)
     W, H, N = 640, 400, 60_000
     tw, th = W // 16, H // 16
@@ -455,29 +469,38 @@ def test_heavy_segments_send_a_shape_to_the_depth_first_path_for_a_while():
     z = torch.zeros(N, device=DEV)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     ctx = ops.RasterContext()
-    if ctx.binning != "supertile" or not ctx.direct_count or not ctx.adaptive_binning:
-        pytest.skip("the environment selects another binning path / no count word / no adaptive choice")
-    ctx.heavy_cooldown = 3
-    light = ops.RasterContext()
-    light.adaptive_binning = False
-    with ops.use(light):
+    if ctx.binning != "supertile" or not ctx.direct_count or ctx.long_segments != "auto":
+        pytest.skip("the environment selects another binning path / no count word / a fixed long-segment mode")
+    ctx.long_cooldown = 3
+    never = ops.RasterContext()
+    never.long_segments = "never"
+    with ops.use(never):
         ref = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
-    assert light.binning_fallbacks == 0
+    assert never.long_calls == 0
     with ops.use(ctx):
-        runs = [ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False) for _ in range(6)]
-    # call 0 sees the heavy segment (supertile path), calls 1-3 run depth-first, call 4 probes again, call 5 depth-first
-    assert ctx.binning_fallbacks == 4 and len(ctx.heavy_shapes) == 1
+        runs = [ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False) for _ in range(4)]
+    # call 0 sizes its list after the count arrived and already knows (one fill, flagged); calls 1-3 fill speculatively
+    # with the flag the calls before left
+    assert ctx.long_calls == 4 and len(ctx.long_shapes) == 1
     for _, f, o in runs:
         assert torch.equal(f, ref[1]) and torch.equal(o, ref[2])
-    # a light scene never leaves the supertile path
+    # the cluster dissolves: the flag stays for `long_cooldown` more calls, then goes
     x0[:30000] = torch.randint(0, tw - 1, (30000,), generator=g)
     y0[:30000] = torch.randint(0, th - 1, (30000,), generator=g)
     rects = _pack_rects(x0, y0, w, h).to(DEV)
+    with ops.use(never):
+        ref = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
+    with ops.use(ctx):
+        runs = [ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False) for _ in range(5)]
+    assert ctx.long_calls == 4 + 3 and not ctx.long_shapes
+    for _, f, o in runs:
+        assert torch.equal(f, ref[1]) and torch.equal(o, ref[2])
+    # a light scene never sees the flag
     ctx2 = ops.RasterContext()
     with ops.use(ctx2):
         for _ in range(3):
             ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
-    assert ctx2.binning_fallbacks == 0 and not ctx2.heavy_shapes
+    assert ctx2.long_calls == 0 and not ctx2.long_shapes
 
 
 @pytest.mark.parametrize("size", [(1920, 1080, 400_000), (960, 540, 100_000), (640, 368, 60_000), (2560, 1440, 2_500_000),
@@ -504,7 +527,6 @@ def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size
         ctx = ops.RasterContext()
         if ctx.binning != "supertile" or not ctx.jobs_in_fill:
             pytest.skip("the environment selects another path")
-        ctx.adaptive_binning = False
         ctx.seg_ckpt_budget_bytes = budget_mb << 20
         with ops.use(ctx):
             for _ in range(2):  # exact, then speculative
