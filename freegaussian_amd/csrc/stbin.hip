@@ -1298,20 +1298,24 @@ struct CountWs {
   int4* long_list;      // build_segment_lists
   size_t bytes;
 };
+// (layouts are computed on offsets: a size query passes no base, and nullptr + offset is undefined behaviour)
+template <typename T>
+T* ws_at(void* base, size_t offset) {
+  return base ? reinterpret_cast<T*>(static_cast<char*>(base) + offset) : nullptr;
+}
 CountWs count_ws(void* base, int N, const Geo& g) {
   const size_t nc = (size_t)n_chunks_of(N > 0 ? N : 1), T = (size_t)g.tile_w * g.tile_h, S = (size_t)g.sw * g.sh;
-  char* p = static_cast<char*>(base);
   CountWs w;
   size_t o = 0;
-  w.table_t = reinterpret_cast<uint32_t*>(p + o);
+  w.table_t = ws_at<uint32_t>(base, o);
   o += al256(nc * T * 4);
-  w.table_s = reinterpret_cast<uint32_t*>(p + o);
+  w.table_s = ws_at<uint32_t>(base, o);
   o += al256(nc * S * 4);
-  w.st_offsets = reinterpret_cast<int32_t*>(p + o);
+  w.st_offsets = ws_at<int32_t>(base, o);
   o += al256((S + 1) * 4);
-  w.large_list = reinterpret_cast<int32_t*>(p + o);
+  w.large_list = ws_at<int32_t>(base, o);
   o += al256((S + 1) * 4);
-  w.long_list = reinterpret_cast<int4*>(p + o);
+  w.long_list = ws_at<int4>(base, o);
   o += al256((S + 2) * 16);
   w.bytes = o;
   return w;
@@ -1362,25 +1366,24 @@ struct FillWs {
   size_t bytes;
 };
 FillWs fill_ws(void* base, size_t capacity) {
-  char* p = static_cast<char*>(base);
   const size_t kb = long_buckets_max(capacity);
   FillWs w;
   size_t o = 0;
-  w.entries = reinterpret_cast<uint64_t*>(p + o);
+  w.entries = ws_at<uint64_t>(base, o);
   o += al256(capacity * 8);
-  w.scratch = reinterpret_cast<uint64_t*>(p + o);
+  w.scratch = ws_at<uint64_t>(base, o);
   o += al256(capacity * 8);
-  w.lt.split = reinterpret_cast<uint64_t*>(p + o);
+  w.lt.split = ws_at<uint64_t>(base, o);
   o += al256(kb * 8);
-  w.lt.tcnt = reinterpret_cast<uint4*>(p + o);
+  w.lt.tcnt = ws_at<uint4>(base, o);
   o += al256(kb * 16);
-  w.lt.tbase = reinterpret_cast<uint4*>(p + o);
+  w.lt.tbase = ws_at<uint4>(base, o);
   o += al256(kb * 16);
-  w.lt.cnt = reinterpret_cast<uint32_t*>(p + o);
+  w.lt.cnt = ws_at<uint32_t>(base, o);
   o += al256(kb * 4);
-  w.lt.cursor = reinterpret_cast<uint32_t*>(p + o);
+  w.lt.cursor = ws_at<uint32_t>(base, o);
   o += al256(kb * 4);
-  w.lt.boff = reinterpret_cast<uint32_t*>(p + o);
+  w.lt.boff = ws_at<uint32_t>(base, o);
   o += al256(kb * 4);
   w.bytes = o;
   return w;

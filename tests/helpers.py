@@ -76,3 +76,12 @@ def close_except_knife_edge(a: torch.Tensor, b: torch.Tensor, tol: float = REL_T
     _record("knife_edge_rel_l2", l2)
     allowed = max(KNIFE_EDGE_MIN_PIXELS, int(max_frac * per_pixel.numel()))
     return n_bad <= allowed and (err.numel() == 0 or err.max().item() <= 2.0 / 255.0) and l2 <= tol
+
+
+def last_ids_agree(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """The per-pixel index of the last contributing list entry: integers, equal except on knife-edge pixels (a 1/255
+    or 1e-4 decision within rounding of its threshold), whose NUMBER is bounded like close_except_knife_edge's."""
+    a, b = a.detach().cpu().long().reshape(-1), b.detach().cpu().long().reshape(-1)
+    n_bad = int((a != b).sum().item())
+    _record("last_ids_mismatches", n_bad)
+    return n_bad <= max(KNIFE_EDGE_MIN_PIXELS, int(KNIFE_EDGE_MAX_FRAC * a.numel()))

@@ -9,7 +9,7 @@ import torch
 
 from freegaussian_amd import _lib, ops, rasterization
 from freegaussian_amd.scenes import plumbing_scene, synthetic_scene
-from helpers import REL_TOL, close_except_knife_edge, psnr, rel_err, rel_l2
+from helpers import REL_TOL, close_except_knife_edge, last_ids_agree, psnr, rel_err, rel_l2
 from oracle import raster_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -730,8 +730,8 @@ def test_raster_forward_backward_vs_oracle(channels, ppt, monkeypatch):
     ((r * vr.to(DEV)).sum() + (a * va.to(DEV)).sum()).backward()
     assert rel_err(r, r_ref) < REL_TOL
     assert rel_err(a, a_ref) < REL_TOL
-    # last contributing index: integer, allow only knife-edge pixels to differ
-    assert (last.cpu() != last_ref).float().mean().item() < 1e-3
+    # last contributing index: integer, only knife-edge pixels may differ (helpers.KNIFE_EDGE_*: the observed bound)
+    assert last_ids_agree(last, last_ref)
     for name, x, y in [("means2d", m2.grad, gref[0]), ("absgrad", m2.absgrad, gref[1]), ("conics", con.grad, gref[2]),
                        ("features", ft.grad, gref[3]), ("opacities", op.grad, gref[4])]:  # fmt: skip
         assert rel_l2(x, y) < REL_TOL, name
@@ -759,7 +759,7 @@ def test_raster_dense_stack_hits_transmittance_stop():
     r, a, last = ops.rasterize_to_pixels(*t, W, H, 16, offs.to(DEV), vals.to(DEV), absgrad=True)
     ((r * vr.to(DEV)).sum() + (a * va.to(DEV)).sum()).backward()
     assert rel_err(r, r_ref) < REL_TOL and rel_err(a, a_ref) < REL_TOL
-    assert (last.cpu() != last_ref).float().mean().item() < 1e-3
+    assert last_ids_agree(last, last_ref)
     for x, y in zip([t[0].grad, t[0].absgrad, t[1].grad, t[2].grad, t[3].grad], gref):
         assert rel_l2(x, y) < REL_TOL
 
@@ -981,7 +981,7 @@ def test_model_get_outputs_training_step_matches_oracle():
         assert rel_l2(model.gauss_params[k].grad, ref.gauss_params[k].grad) < REL_TOL, k
     gd = torch.cat([p.grad.flatten() for p in model.deform.parameters()])
     gd0 = torch.cat([p.grad.flatten() for p in ref.deform.parameters()])
-    assert rel_l2(gd, gd0) < 2e-3  # GEMM chains in different orders on CPU/GPU
+    assert rel_l2(gd, gd0) < REL_TOL  # (GEMM chains in different orders on CPU / GPU: measured 1e-6)
     # S1: densification statistics consume xys.absgrad / radii exactly as the reference does
     model.after_train_iter(model.step)
     vis = model.radii > 0
@@ -1525,7 +1525,7 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     _smooth_loss(rgb0, gt).backward()
     gc = torch.cat([p.grad.flatten() for p in cm.control.parameters()])
     gc0 = torch.cat([p.grad.flatten() for p in cm_cpu.control.parameters()])
-    assert rel_l2(gc, gc0) < 2e-3
+    assert rel_l2(gc, gc0) < REL_TOL  # (measured 2e-6 at 1M Gaussians)
     assert rel_l2(cm.gauss_params["means"].grad, cm_cpu.gauss_params["means"].grad) < REL_TOL
     assert all(p.grad is None for p in cm.deform.parameters())  # frozen (evaluated under no_grad)
 
