@@ -44,14 +44,18 @@ constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the coun
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
 constexpr int SB_SCATTER_LDS_BYTES = 132 * 1024;     // dynamic LDS of the staging scatter (+ 21 KB static: one workgroup per CU)
 constexpr int SB_MIN_STAGE = 4096;                   // staging buffers smaller than this are not worth the second sweep
+#ifndef FG_SB_SKEW_MAX
+#define FG_SB_SKEW_MAX 96
+#endif
+constexpr int SB_SKEW_MAX = FG_SB_SKEW_MAX;                      // elements in one bucket of an LDS sort's counting pass beyond which the segment is re-bucketed by splitters
 // LONG segments (more elements than the large launch sorts in LDS: a dense cluster over one supertile) are split by
 // SAMPLE SORT into buckets of ~LG_T elements that the LDS sort then takes one by one (FG_STBIN_LONG_SEGMENTS):
-constexpr int SB_LONG_MIN = 64 * 16 * 8 - 128;       // = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, ..>::MAXN (static_assert below)
-constexpr int LG_T = 2688;                           // target bucket size: a third of the LDS sort's capacity
+constexpr int SB_LONG_MIN = 64 * 16 * 8 - 256;       // = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, ..>::MAXN (static_assert below)
+constexpr int LG_T = 1536;                           // target bucket size: half of the small LDS sort's capacity (sb_long_sort_kernel)
 constexpr int LG_KMAX = 1008;                        // buckets per segment at most (splitters + counters in LDS)
-constexpr int LG_SA = 16;                            // samples per bucket (fewer when LG_SA * k exceeds one LDS sort)
+constexpr int LG_SA = 32;                            // samples per bucket (fewer when LG_SA * k exceeds one LDS sort): a bucket twice its target is a 1e-6 event
 constexpr int LG_BLOCK = 512, LG_PER = 8, LG_CHUNK = LG_BLOCK * LG_PER;  // count / scatter passes over a long segment
-constexpr int LG_GRID = 1024, LG_SORT_GRID = 512;    // persistent workgroups of those passes / of the bucket sort
+constexpr int LG_GRID = 1024, LG_SORT_GRID = 1024;   // persistent workgroups of those passes / of the bucket sort
 __host__ __device__ __forceinline__ int long_buckets(int n) {
   const int k = (n + LG_T - 1) / LG_T;
   return k > LG_KMAX ? LG_KMAX : (k < 2 ? 2 : k);
@@ -62,13 +66,21 @@ __host__ __device__ __forceinline__ int long_samples(int k) {
 }
 // per bucket of every long segment (fill workspace, behind the two element arrays)
 struct LongTables {
-  uint64_t* split;   // [b] = smallest element of bucket b + 1 (bucket k - 1: unused)
-  uint32_t* cnt;     // elements per bucket
-  uint32_t* cursor;  // scatter cursors
-  uint32_t* boff;    // first slot of the bucket inside its segment
-  uint4* tcnt;       // elements per bucket that go to tile j of the supertile
-  uint4* tbase;      // ... in the buckets before this one
+  uint64_t* split;     // [b] = smallest element of bucket b + 1 (bucket k - 1: unused)
+  uint32_t* cnt;       // elements per bucket
+  uint32_t* cursor;    // scatter cursors
+  uint4* tcnt;         // elements per bucket that go to tile j of the supertile
+  // what a work item needs of its segment, one load (build_segment_lists): {first bucket slot, first element, elements,
+  // chunk in the segment} per chunk of the count / scatter passes, {first bucket slot, first element, supertile, bucket in the
+  // segment} per bucket slot of the sort
+  int4* chunk_seg;
+  int4* bucket_seg;
+  // [0] = skewed whole segments the small sort launch left, [1] = buckets beyond the LDS sort's capacity; the two lists
+  // follow: -(supertile + 1) at [2 ..], bucket slots at [2 + over_cap ..]
+  int32_t* over_list;
+  int over_cap;
 };
+__device__ __forceinline__ int n_slots_cap(const LongTables& lt) { return lt.over_cap; }
 
 struct Geo {
   int tile_w, tile_h, sw, sh;
@@ -344,7 +356,8 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
 template <int NTH>
 __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __restrict__ st_offsets, int small_max,
                                                     int32_t* __restrict__ large_list, int4* __restrict__ long_list,
-                                                    bool long_mode) {
+                                                    bool long_mode, int4* __restrict__ chunk_seg,
+                                                    int4* __restrict__ bucket_seg) {
   constexpr int NWV = NTH / 64;
   __shared__ int s_large;
   __shared__ uint32_t s_tot[3][NWV];
@@ -391,9 +404,14 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
     const int n = st_offsets[i + 1] - st_offsets[i];
     if (n > SB_LONG_MIN) {
       long_list[1 + run[0]] = make_int4(i, (int)run[1], (int)run[2], n);
+      // (the passes' work items find their segment with ONE load instead of a bisection of dependent loads)
+      const int nch = (n + LG_CHUNK - 1) / LG_CHUNK, nb = long_buckets(n);
+      const int off = st_offsets[i];
+      for (int c = 0; c < nch; ++c) chunk_seg[run[1] + c] = make_int4((int)run[2], off, n, c);
+      for (int b = 0; b < nb; ++b) bucket_seg[run[2] + b] = make_int4((int)run[2], off, i, b);
       run[0] += 1;
-      run[1] += (uint32_t)((n + LG_CHUNK - 1) / LG_CHUNK);
-      run[2] += (uint32_t)long_buckets(n);
+      run[1] += (uint32_t)nch;
+      run[2] += (uint32_t)nb;
     }
   }
   if (threadIdx.x == 0) {
@@ -401,17 +419,6 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
     long_list[1 + all[0]] = make_int4(-1, (int)all[1], (int)all[2], 0);
   }
 }
-// the long segment that holds work item w of a pass (field 1: chunks, 2: buckets): the last one whose first item <= w
-__device__ __forceinline__ int long_segment_of(const int4* __restrict__ long_list, int L, int w, int field) {
-  int lo = 0, hi = L;  // invariant: first(lo) <= w < first(hi)
-  while (hi - lo > 1) {
-    const int mid = (lo + hi) >> 1;
-    const int4 e = long_list[1 + mid];
-    if ((field == 1 ? e.y : e.z) <= w) lo = mid; else hi = mid;
-  }
-  return lo;
-}
-
 // ---- scatter --------------------------------------------------------------------------------------------
 // One workgroup per chunk; a wavefront takes 64 Gaussians a round: every lane finds the owner of its slot among
 // the round's (Gaussian, supertile) pairs and writes the element depth bits << 32 | id << 4 | tile mask (bit j:
@@ -430,7 +437,8 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
                   int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                   uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list,
-                  int4* __restrict__ long_list, int long_mode, int job_blocks, fgjobs::JobBuild jb) {
+                  int4* __restrict__ long_list, int long_mode, int4* __restrict__ chunk_seg,
+                  int4* __restrict__ bucket_seg, int job_blocks, fgjobs::JobBuild jb) {
   // fg_stbin_fill_jobs: the LAST job_blocks workgroups build the raster launches' job lists from the (exact) tile
   // ranges -- each the forward's and the backward's list of one XCD band -- beside the scatter, with no launch of
   // their own.  (STAGE only: one workgroup per CU by LDS, so the builder's 118 registers cost this kernel nothing;
@@ -442,7 +450,8 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
     if ((int)blockIdx.x == (int)gridDim.x - 1) {
       const Geo gg = geo_of(tile_w, tile_h);
       if ((long long)tile_offsets[tile_w * tile_h] <= capacity)
-        build_segment_lists<SC_BLOCK>(gg.sw * gg.sh, st_offsets, small_max, large_list, long_list, long_mode != 0);
+        build_segment_lists<SC_BLOCK>(gg.sw * gg.sh, st_offsets, small_max, large_list, long_list, long_mode != 0, chunk_seg,
+                                      bucket_seg);
       return;
     }
     if ((int)blockIdx.x >= first) {
@@ -462,7 +471,8 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;  // the guess was too small: the host repeats the call
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   if constexpr (!STAGE) {
-    if (chunk == 0) build_segment_lists<SC_BLOCK>(S, st_offsets, small_max, large_list, long_list, long_mode != 0);
+    if (chunk == 0)
+      build_segment_lists<SC_BLOCK>(S, st_offsets, small_max, large_list, long_list, long_mode != 0, chunk_seg, bucket_seg);
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}
@@ -778,9 +788,11 @@ __device__ uint64_t* sort_segment_global(uint64_t* a, uint64_t* b, int n, uint32
 // workgroup must call this the same number of times -- with n = 0 when they have nothing to do) ----------------
 template <int NW, int KPT, int BB>
 struct SortShared {
-  // (the large variant gives up 128 elements so that two workgroups -- 2 x 80 KB -- fit a CU's 160 KB of LDS)
-  static constexpr int MAXN = 64 * NW * KPT - (NW > 8 ? 128 : 0);
+  // (the large variant gives up 256 elements so that two workgroups -- 2 x 80 KB -- fit a CU's 160 KB of LDS)
+  static constexpr int MAXN = 64 * NW * KPT - (NW > 8 ? 256 : 0);
+  static constexpr int NSP = 127;  // splitters of the skew path (sort_emit_lds)
   uint64_t img[MAXN];
+  uint64_t sp[NSP + 1];
   alignas(16) uint32_t bucket[(1 << BB) + 4];  // counts -> exclusive bases; [1 << BB] = n
   uint32_t red[2 * NW];
   uint32_t wtot[NW];
@@ -804,10 +816,13 @@ struct SortShared {
     if (qb_ < R)                                         \
       _Pragma("unroll") for (int q = qb_; q < qb_ + QB; ++q)
 
-// (src_at(i): element i of the input, i < n; EMIT = false: stop with the n elements in order in sh.img)
-template <int NW, int KPT, int BB, bool EMIT = true, typename SrcAt>
-__device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, SrcAt src_at, int n,
-                                              const int* tile_base, int32_t* __restrict__ flatten_ids) {
+// (src_at(i): element i of the input, i < n; EMIT = false: stop with the n elements in order in sh.img;
+// SKEW = true: a skewed segment -- see below -- is re-bucketed by splitters here; false: it is sorted as it is unless
+// `defer_skew`, then nothing is written and the function returns true: the caller hands the segment to a launch that can)
+template <int NW, int KPT, int BB, bool EMIT = true, bool SKEW = true, typename SrcAt>
+__device__ __forceinline__ bool sort_emit_lds(SortShared<NW, KPT, BB>& sh, int gt, SrcAt src_at, int n,
+                                              const int* tile_base, int32_t* __restrict__ flatten_ids,
+                                              bool defer_skew = false) {
   constexpr int NT = 64 * NW, NB = 1 << BB, PER = NB / NT;
   static_assert(NB % NT == 0 && PER >= 1 && (PER % 4 == 0 || PER < 4), "buckets per thread");
   constexpr int QB = KPT % 4 == 0 ? 4 : 3;
@@ -855,14 +870,17 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   }
   const uint32_t range = n > 0 ? kmax - kmin : 0u;
   const int bits = range ? 32 - __builtin_clz(range) : 0, low = bits > BB ? bits - BB : 0;
-  uint32_t rk[KPT];
+  uint32_t rk[KPT], bk[KPT];  // an element's bucket and the slot inside it the counting pass handed out
 #pragma unroll
-  for (int q = 0; q < KPT; ++q) rk[q] = 0;
-  SB_FOR_ROUNDS(q)
-    if ((valid >> q) & 1u) rk[q] = atomicAdd(&sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low], 1u);
+  for (int q = 0; q < KPT; ++q) rk[q] = bk[q] = 0;
+  SB_FOR_ROUNDS(q) {
+    bk[q] = ((uint32_t)(e[q] >> 32) - kmin) >> low;
+    if ((valid >> q) & 1u) rk[q] = atomicAdd(&sh.bucket[bk[q]], 1u);
+  }
   __syncthreads();
-  {  // counts -> exclusive bases: thread t owns PER consecutive buckets
-    uint32_t c[PER], tot = 0;
+  // counts -> exclusive bases: thread t owns PER consecutive buckets; returns the fullest bucket's count
+  auto scan_buckets = [&]() -> uint32_t {
+    uint32_t c[PER], tot = 0, mx = 0;
     if constexpr (PER >= 4) {
 #pragma unroll
       for (int k = 0; k < PER; k += 4) {
@@ -874,14 +892,25 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
       for (int k = 0; k < PER; ++k) c[k] = sh.bucket[gt * PER + k];
     }
 #pragma unroll
-    for (int k = 0; k < PER; ++k) tot += c[k];
+    for (int k = 0; k < PER; ++k) {
+      tot += c[k];
+      mx = max(mx, c[k]);
+    }
     const uint32_t incl = wave_incl_scan(tot, lane);
-    if (lane == 63) sh.wtot[gw] = incl;
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, m));
+    if (lane == 63) {
+      sh.wtot[gw] = incl;
+      sh.red[gw] = mx;
+    }
     __syncthreads();
     uint32_t run = incl - tot;
+    mx = 0;
 #pragma unroll
-    for (int w = 0; w < NW; ++w)
+    for (int w = 0; w < NW; ++w) {
       if (w < gw) run += sh.wtot[w];
+      mx = max(mx, sh.red[w]);
+    }
 #pragma unroll
     for (int k = 0; k < PER; ++k) {
       const uint32_t x = c[k];
@@ -896,10 +925,57 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
       for (int k = 0; k < PER; ++k) sh.bucket[gt * PER + k] = c[k];
     }
     if (gt == NT - 1) sh.bucket[NB] = run;  // = n
+    __syncthreads();
+    return mx;
+  };
+  const uint32_t fullest = scan_buckets();
+  // SKEW: equal-width buckets fail a segment that is a sparse spread of depths plus a dense cluster (the rim of a
+  // ball of splats: half of the elements within a few hundred ulps) or a run of exact ties -- one bucket then holds
+  // hundreds of elements and the ranking below is quadratic in that (1500 in a bucket: 80 us for ONE workgroup).
+  // Such a segment is bucketed again by SPLITTERS: a regular sample of up to 127 elements, ranked all against all,
+  // and every element bisects them (full 64-bit comparisons: ties and skew alike end up ~n / 128 to a bucket).
+  if (!SKEW && defer_skew && fullest > SB_SKEW_MAX) return true;  // (uniform across the group)
+  if (SKEW && fullest > SB_SKEW_MAX) {
+    using Sh = SortShared<NW, KPT, BB>;
+    const int ns = min(Sh::NSP, n >> 2);  // (n > SB_SKEW_MAX here)
+    SB_FOR_ROUNDS(q)
+      if ((valid >> q) & 1u) sh.img[ibase + q * 64] = e[q];
+    if constexpr (PER >= 4) {
+#pragma unroll
+      for (int k = 0; k < PER; k += 4) *reinterpret_cast<uint4*>(&sh.bucket[gt * PER + k]) = make_uint4(0, 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int k = 0; k < PER; ++k) sh.bucket[gt * PER + k] = 0;
+    }
+    __syncthreads();
+    uint64_t x = 0;
+    if (gt < ns) {
+      x = sh.img[(gt * n) / ns];  // (gt < 128, n < 2^13)
+      sh.sp[gt] = x;
+    }
+    __syncthreads();
+    int smaller = 0;
+    if (gt < ns)
+      for (int u = 0; u < ns; ++u) smaller += sh.sp[u] < x;  // (all lanes read one address: a broadcast)
+    __syncthreads();
+    if (gt < ns) sh.sp[smaller] = x;  // (unique elements: a permutation)
+    __syncthreads();
+    SB_FOR_ROUNDS(q) {
+      uint32_t b = 0;
+#pragma unroll
+      for (int step = 64; step >= 1; step >>= 1) {
+        const uint32_t t = b + (uint32_t)step;
+        const uint64_t v = sh.sp[min(t, (uint32_t)ns) - 1];
+        b = (t <= (uint32_t)ns && v <= e[q]) ? t : b;
+      }
+      bk[q] = b;
+      if ((valid >> q) & 1u) rk[q] = atomicAdd(&sh.bucket[b], 1u);
+    }
+    __syncthreads();
+    (void)scan_buckets();
   }
-  __syncthreads();
   SB_FOR_ROUNDS(q)
-    if ((valid >> q) & 1u) sh.img[sh.bucket[((uint32_t)(e[q] >> 32) - kmin) >> low] + rk[q]] = e[q];
+    if ((valid >> q) & 1u) sh.img[sh.bucket[bk[q]] + rk[q]] = e[q];
   __syncthreads();
   // the order inside every bucket: an element's place = the bucket's base + the number of smaller elements in it
   int pos[KPT];
@@ -907,8 +983,7 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   for (int q = 0; q < KPT; ++q) pos[q] = -1;
   SB_FOR_ROUNDS(q) {
     if ((valid >> q) & 1u) {
-      const uint32_t bk = ((uint32_t)(e[q] >> 32) - kmin) >> low;
-      const int s0 = (int)sh.bucket[bk], s1 = (int)sh.bucket[bk + 1];
+      const int s0 = (int)sh.bucket[bk[q]], s1 = (int)sh.bucket[bk[q] + 1];
       if (s1 - s0 > 1) {
         int smaller = 0;
         for (int j = s0; j < s1; ++j) smaller += sh.img[j] < e[q];
@@ -920,7 +995,7 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
   SB_FOR_ROUNDS(q)
     if (pos[q] >= 0) sh.img[pos[q]] = e[q];  // (elements alone in their bucket are in place)
   __syncthreads();
-  if constexpr (!EMIT) return;
+  if constexpr (!EMIT) return false;
   // ---- emission ----
   uint32_t idm[KPT], ranks[KPT];
   uint32_t pre[KPT][4], c[4] = {0, 0, 0, 0};  // (wave-uniform: scalar registers)
@@ -958,6 +1033,7 @@ __device__ __forceinline__ void sort_emit_lds(SortShared<NW, KPT, BB>& sh, int g
     for (int j = 0; j < 4; ++j)
       if ((idm[q] >> j) & 1u) flatten_ids[base[j] + pre[q][j] + ((ranks[q] >> (8 * j)) & 0xFFu)] = (int32_t)id;
   }
+  return false;
 }
 #undef SB_FOR_ROUNDS
 
@@ -979,12 +1055,14 @@ __device__ __forceinline__ void supertile_tile_bases(int st, int tile_w, int til
   }
 }
 
+// (returns true when the small launch leaves a skewed segment to a later one -- `defer_skew`, sort_emit_lds)
 template <int NW, int KPT, int BB, bool SMALL>
-__device__ __forceinline__ void sort_supertile(SortShared<NW, KPT, BB>& sh, int st, int tile_w, int tile_h,
+__device__ __forceinline__ bool sort_supertile(SortShared<NW, KPT, BB>& sh, int st, int tile_w, int tile_h,
                                                const int32_t* __restrict__ tile_offsets,
                                                const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
                                                uint64_t* __restrict__ scratch, bool over, int total,
-                                               int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets) {
+                                               int32_t* __restrict__ flatten_ids, int32_t* __restrict__ list_offsets,
+                                               bool defer_skew = false) {
   constexpr int MAXN = SortShared<NW, KPT, BB>::MAXN;  // elements sorted in LDS by this variant
   uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
   static_assert((1 << BB) >= NW * 256, "the fallback's counters live in the bucket array");
@@ -1001,31 +1079,20 @@ __device__ __forceinline__ void sort_supertile(SortShared<NW, KPT, BB>& sh, int 
     }
   }
   const int off = st_offsets[st], n = st_offsets[st + 1] - off;
-  if (over || n <= 0) return;
-  if (SMALL && n > MAXN) return;  // (on the large launch's list, or a long segment)
-  if (n > MAXN) {
-    const uint64_t* fin = sort_segment_global<NW>(entries + off, scratch + off, n, wave_cnt, sh.scan_tmp, sh.red);
-    emit_tiles<NW>(fin, n, tile_base, flatten_ids, sh.tcnt);
-    return;
+  if (over || n <= 0) return false;
+  if (SMALL && n > MAXN) return false;  // (on the large launch's list, or a long segment)
+  if constexpr (!SMALL) {
+    if (n > MAXN) {
+      const uint64_t* fin = sort_segment_global<NW>(entries + off, scratch + off, n, wave_cnt, sh.scan_tmp, sh.red);
+      emit_tiles<NW>(fin, n, tile_base, flatten_ids, sh.tcnt);
+      return false;
+    }
   }
   const uint64_t* __restrict__ src = entries + off;
-  sort_emit_lds<NW, KPT, BB>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n, tile_base, flatten_ids);
-}
-
-__global__ void __launch_bounds__(64 * SB_SMALL_WAVES)
-sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
-                     const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
-                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
-                     int32_t* __restrict__ list_offsets) {
-  __shared__ SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS> sh;
-  // supertile = workgroup id: neighbours go to different XCDs.  (By band the long segments of a centre-weighted
-  // image all land on the two or three XCDs that own the middle rows.)
-  const int st = blockIdx.x;
-  if (st >= ((tile_w + 1) >> 1) * ((tile_h + 1) >> 1)) return;
-  const int total = tile_offsets[tile_w * tile_h];
-  sort_supertile<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS, true>(
-      sh, st, tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, (long long)total > capacity, total, flatten_ids,
-      list_offsets);
+  // (the small launch keeps its registers -- four workgroups per CU -- and leaves skew to others or, without
+  // FG_STBIN_LONG_SEGMENTS, sorts the crowded bucket the quadratic way)
+  return sort_emit_lds<NW, KPT, BB, true, !SMALL>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n, tile_base,
+                                                  flatten_ids, defer_skew);
 }
 
 // ---- long segments: sample sort ------------------------------------------------------------------------------------
@@ -1039,9 +1106,10 @@ sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
 //            per bucket and per (bucket, tile of the supertile) -> global counters
 //   scatter  per chunk: the same buckets; a run per (chunk, bucket) reserved with ONE returning atomic on the bucket's
 //            cursor; elements to `scratch` at segment start + bucket start + run + rank.  Order inside a bucket: any.
-//   sort     per bucket: the LDS sort + emission used for whole segments, with the tile bases advanced by what the
-//            buckets in front send to each tile.  (A bucket beyond the LDS capacity -- the sample was unlucky by a
-//            factor of three -- goes through global memory in one workgroup, as whole segments did before.)
+//   sort     (work items of the SMALL sort launch, beside the supertiles it takes whole) per bucket: where it starts
+//            and what the buckets in front send to each of the four tiles (a block reduction over the counters), then
+//            the LDS sort + emission used for whole segments.  (A bucket beyond the LDS capacity -- the sample was
+//            unlucky by a factor of three -- goes through global memory in one workgroup, as whole segments did before.)
 // Same lists, bit for bit: inside a tile the order is the total order on (depth bits, id).
 template <int NW, int KPT, int BB>
 __device__ __forceinline__ void sample_long_segment(SortShared<NW, KPT, BB>& sh, const uint64_t* __restrict__ src, int n,
@@ -1078,6 +1146,7 @@ sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
   if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
   // work items: the long segments' sample step first (the head of a chain of three more launches), then the LDS sorts
   const int n_long = long_list[0].x, count = large_list[0];
+  if ((int)blockIdx.x == job_blocks && threadIdx.x == 0) lt.over_list[0] = lt.over_list[1] = 0;
   for (int k = (int)blockIdx.x - job_blocks; k < n_long + count; k += (int)gridDim.x - job_blocks) {
     if (k < n_long) {
       const int4 ls = long_list[1 + k];
@@ -1115,10 +1184,10 @@ sb_long_count_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long
   const int4 hdr = long_list[0];
   int cur = -1;
   for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
-    const int seg = long_segment_of(long_list, hdr.x, w, 1);
-    const int4 ls = long_list[1 + seg];
-    const int n = ls.w, k = long_buckets(n), c = w - ls.y;
-    const uint64_t* __restrict__ src = entries + st_offsets[ls.x];
+    const int4 ci = lt.chunk_seg[w];
+    const int4 ls = make_int4(0, 0, ci.x, ci.z);  // (.z: first bucket slot, .w: elements)
+    const int n = ci.z, k = long_buckets(n), c = ci.w, seg = ci.x;
+    const uint64_t* __restrict__ src = entries + ci.y;
     if (seg != cur) {
       for (int t = threadIdx.x; t < k - 1; t += LG_BLOCK) s_split[t] = lt.split[ls.z + t];
       cur = seg;
@@ -1194,10 +1263,10 @@ sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, lo
   const int4 hdr = long_list[0];
   int cur = -1;
   for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
-    const int seg = long_segment_of(long_list, hdr.x, w, 1);
-    const int4 ls = long_list[1 + seg];
-    const int n = ls.w, k = long_buckets(n), c = w - ls.y;
-    const int off = st_offsets[ls.x];
+    const int4 ci = lt.chunk_seg[w];
+    const int4 ls = make_int4(0, 0, ci.x, ci.z);  // (.z: first bucket slot, .w: elements)
+    const int n = ci.z, k = long_buckets(n), c = ci.w, seg = ci.x;
+    const int off = ci.y;
     const uint64_t* __restrict__ src = entries + off;
     if (seg != cur) {
       __syncthreads();
@@ -1208,19 +1277,6 @@ sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, lo
       __syncthreads();
       long_excl_scan(s_boff, k, s_wtot);  // bucket starts inside the segment
       cur = seg;
-    }
-    if (c == 0) {
-      // the segment's first chunk also leaves what the bucket sort needs: bucket starts, tile bases per bucket
-      for (int t = threadIdx.x; t < k; t += LG_BLOCK) lt.boff[ls.z + t] = s_boff[t];
-      uint32_t* tb = reinterpret_cast<uint32_t*>(lt.tbase + ls.z);
-      const uint32_t* tcn = reinterpret_cast<const uint32_t*>(lt.tcnt + ls.z);
-      for (int j = 0; j < 4; ++j) {
-        for (int t = threadIdx.x; t < k; t += LG_BLOCK) s_tmp[t] = tcn[4 * t + j];
-        __syncthreads();
-        long_excl_scan(s_tmp, k, s_wtot);
-        for (int t = threadIdx.x; t < k; t += LG_BLOCK) tb[4 * t + j] = s_tmp[t];
-        __syncthreads();
-      }
     }
     for (int t = threadIdx.x; t < k; t += LG_BLOCK) s_hist[t] = 0u;
     __syncthreads();
@@ -1256,34 +1312,144 @@ sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, lo
   }
 }
 
-__global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
+// The SMALL sort launch: one workgroup per supertile, whole segments up to 3072 elements.  (Its registers -- four
+// workgroups per CU -- are the headline scene's binning time: the long segments' buckets have a launch of their own.)
+// long_mode: a skewed segment (sort_emit_lds) is left on over_list as -(supertile + 1) for sb_long_sort_kernel.
+__global__ void __launch_bounds__(64 * SB_SMALL_WAVES)
+sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
+                     const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
+                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
+                     int32_t* __restrict__ list_offsets, int32_t* __restrict__ over_list) {
+  __shared__ SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS> sh;
+  // supertile = workgroup id: neighbours go to different XCDs.  (By band the long segments of a centre-weighted
+  // image all land on the two or three XCDs that own the middle rows.)
+  const int st = blockIdx.x;
+  if (st >= ((tile_w + 1) >> 1) * ((tile_h + 1) >> 1)) return;
+  const int total = tile_offsets[tile_w * tile_h];
+  const bool skewed = sort_supertile<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS, true>(
+      sh, st, tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, (long long)total > capacity, total, flatten_ids,
+      list_offsets, over_list != nullptr);
+  if (skewed && threadIdx.x == 0) over_list[2 + atomicAdd(over_list, 1)] = -(st + 1);
+}
+
+// The buckets of the long segments (slot = work item) and the skewed segments the small launch left: LG_SORT_GRID
+// persistent workgroups, the small launch's LDS sort with the splitter path for skew.  A bucket beyond the LDS sort's
+// capacity (the sample was unlucky by a factor of two: with 32 samples per bucket a 1e-6 event per bucket) goes on
+// over_list's second list for sb_long_overflow_kernel.
+// (eight wavefronts per SIMD = four workgroups per CU, as the small launch: 9 spilled registers on the skew path)
+__global__ void __launch_bounds__(64 * SB_SMALL_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
                     const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list, LongTables lt,
-                    uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
+                    const uint64_t* __restrict__ entries, const uint64_t* __restrict__ scratch,
+                    int32_t* __restrict__ flatten_ids) {
+  using Sh = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>;
+  __shared__ Sh sh;
+  __shared__ int s_tile_base[4];
+  constexpr int NT = 64 * SB_SMALL_WAVES;
+  static_assert(2 * LG_T <= Sh::MAXN, "a bucket twice its target still fits the LDS sort");
+  if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int n_slots = long_list[0].z, n_items = n_slots + lt.over_list[0];
+  for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
+    const uint64_t* src;
+    int n, st, seg_off = 0;
+    uint32_t pre[5] = {0, 0, 0, 0, 0};
+    if (item >= n_slots) {  // a whole (skewed) segment
+      st = -lt.over_list[2 + item - n_slots] - 1;
+      const int off = st_offsets[st];
+      n = st_offsets[st + 1] - off;
+      src = entries + off;
+    } else {
+      // a bucket: where it starts in its segment and in each of the four tile lists = sums over the buckets in front
+      const int4 bi = lt.bucket_seg[item];
+      const int4 ls = make_int4(bi.z, 0, bi.x, 0);  // (.x: supertile, .z: first bucket slot)
+      st = ls.x;
+      seg_off = bi.y;
+      const int b = bi.w;
+      for (int t = threadIdx.x; t < b; t += NT) {
+        const uint4 tc = lt.tcnt[ls.z + t];
+        pre[0] += lt.cnt[ls.z + t];
+        pre[1] += tc.x; pre[2] += tc.y; pre[3] += tc.z; pre[4] += tc.w;
+      }
+#pragma unroll
+      for (int f = 0; f < 5; ++f) {
+#pragma unroll
+        for (int m = 1; m < 64; m <<= 1) pre[f] += (uint32_t)__shfl_xor((int)pre[f], m);
+        if (lane == 0) sh.bucket[f * SB_SMALL_WAVES + wave] = pre[f];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int f = 0; f < 5; ++f) {
+        pre[f] = 0;
+#pragma unroll
+        for (int w = 0; w < SB_SMALL_WAVES; ++w) pre[f] += sh.bucket[f * SB_SMALL_WAVES + w];
+      }
+      n = (int)lt.cnt[item];
+      src = scratch + (size_t)seg_off + pre[0];
+      if (n > Sh::MAXN) {
+        if (threadIdx.x == 0) lt.over_list[2 + n_slots_cap(lt) + atomicAdd(lt.over_list + 1, 1)] = item;
+        n = 0;
+      }
+    }
+    {  // the tile bases wait in LDS for the emission (registers: three workgroups per CU)
+      int tile_base[4], tile_id[4];
+      supertile_tile_bases(st, tile_w, tile_h, tile_offsets, tile_base, tile_id);
+      __syncthreads();  // (sh.bucket is the sort's from here; s_tile_base is free again)
+      if (threadIdx.x < 4) s_tile_base[threadIdx.x] = tile_base[threadIdx.x] + (int)pre[1 + threadIdx.x];
+    }
+    if (n > 0)  // (uniform; the sort's first barrier publishes s_tile_base)
+      sort_emit_lds<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n,
+                                                                         s_tile_base, flatten_ids);
+    __syncthreads();
+  }
+}
+
+// The buckets sb_long_sort_kernel left on over_list's second list, one workgroup each through global memory
+// (exact TIES of the whole 64-bit element cannot occur)
+__global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
+sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
+                        const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list, LongTables lt,
+                        uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
   using Sh = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>;
   __shared__ Sh sh;
+  constexpr int NT = 64 * SB_LARGE_WAVES;
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
   uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
-  const int4 hdr = long_list[0];
-  for (int item = blockIdx.x; item < hdr.z; item += gridDim.x) {
-    const int seg = long_segment_of(long_list, hdr.x, item, 2);
-    const int4 ls = long_list[1 + seg];
-    const int slot = item;  // (= ls.z + bucket)
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  const int count = lt.over_list[1];
+  for (int item = blockIdx.x; item < count; item += gridDim.x) {
+    const int slot = lt.over_list[2 + n_slots_cap(lt) + item];
+    const int4 bi = lt.bucket_seg[slot];
+    const int4 ls = make_int4(bi.z, 0, bi.x, 0);  // (.x: supertile, .z: first bucket slot)
+    const int b = bi.w;
+    uint32_t pre[5] = {0, 0, 0, 0, 0};
+    for (int t = threadIdx.x; t < b; t += NT) {
+      const uint4 tc = lt.tcnt[ls.z + t];
+      pre[0] += lt.cnt[ls.z + t];
+      pre[1] += tc.x; pre[2] += tc.y; pre[3] += tc.z; pre[4] += tc.w;
+    }
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) pre[f] += (uint32_t)__shfl_xor((int)pre[f], m);
+      if (lane == 0) sh.bucket[f * SB_LARGE_WAVES + wave] = pre[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int f = 0; f < 5; ++f) {
+      pre[f] = 0;
+#pragma unroll
+      for (int w = 0; w < SB_LARGE_WAVES; ++w) pre[f] += sh.bucket[f * SB_LARGE_WAVES + w];
+    }
+    __syncthreads();
     const int n_b = (int)lt.cnt[slot];
-    if (n_b == 0) continue;  // (uniform)
-    const size_t off = (size_t)st_offsets[ls.x] + lt.boff[slot];
-    const uint4 tb = lt.tbase[slot];
+    const size_t off = (size_t)bi.y + pre[0];
     int tile_base[4], tile_id[4];
     supertile_tile_bases(ls.x, tile_w, tile_h, tile_offsets, tile_base, tile_id);
-    tile_base[0] += (int)tb.x; tile_base[1] += (int)tb.y; tile_base[2] += (int)tb.z; tile_base[3] += (int)tb.w;
-    if (n_b > Sh::MAXN) {
-      const uint64_t* fin = sort_segment_global<SB_LARGE_WAVES>(scratch + off, entries + off, n_b, wave_cnt, sh.scan_tmp, sh.red);
-      emit_tiles<SB_LARGE_WAVES>(fin, n_b, tile_base, flatten_ids, sh.tcnt);
-    } else {
-      const uint64_t* __restrict__ src = scratch + off;
-      sort_emit_lds<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>(sh, (int)threadIdx.x, [src](int i) { return src[i]; },
-                                                                         n_b, tile_base, flatten_ids);
-    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) tile_base[j] += (int)pre[1 + j];
+    const uint64_t* fin = sort_segment_global<SB_LARGE_WAVES>(scratch + off, entries + off, n_b, wave_cnt, sh.scan_tmp, sh.red);
+    emit_tiles<SB_LARGE_WAVES>(fin, n_b, tile_base, flatten_ids, sh.tcnt);
     __syncthreads();
   }
 }
@@ -1359,7 +1525,7 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
 
 namespace {
 // buckets of all long segments together: sum of ceil(n / LG_T) over segments of more than SB_LONG_MIN elements
-size_t long_buckets_max(size_t capacity) { return capacity / LG_T + capacity / SB_LONG_MIN + 2; }
+size_t long_buckets_max(size_t capacity) { return capacity / LG_T + capacity / SB_LONG_MIN + 2; }  // (sum of ceil(n / LG_T))
 struct FillWs {
   uint64_t *entries, *scratch;
   LongTables lt;
@@ -1377,14 +1543,17 @@ FillWs fill_ws(void* base, size_t capacity) {
   o += al256(kb * 8);
   w.lt.tcnt = ws_at<uint4>(base, o);
   o += al256(kb * 16);
-  w.lt.tbase = ws_at<uint4>(base, o);
-  o += al256(kb * 16);
   w.lt.cnt = ws_at<uint32_t>(base, o);
   o += al256(kb * 4);
   w.lt.cursor = ws_at<uint32_t>(base, o);
   o += al256(kb * 4);
-  w.lt.boff = ws_at<uint32_t>(base, o);
-  o += al256(kb * 4);
+  w.lt.bucket_seg = ws_at<int4>(base, o);
+  o += al256(kb * 16);
+  w.lt.over_cap = (int)(capacity / SB_SKEW_MAX + 2);  // (a skewed segment has more elements than SB_SKEW_MAX)
+  w.lt.over_list = ws_at<int32_t>(base, o);
+  o += al256((2 + (size_t)w.lt.over_cap + kb) * 4);
+  w.lt.chunk_seg = ws_at<int4>(base, o);
+  o += al256((capacity / LG_CHUNK + capacity / SB_LONG_MIN + 2) * 16);
   w.bytes = o;
   return w;
 }
@@ -1442,13 +1611,13 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
     hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
-                       long_mode, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{});
+                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{});
     want_jobs = false;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
-                       long_mode, 0, fgjobs::JobBuild{});
+                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, 0, fgjobs::JobBuild{});
   }
   const int job_blocks = want_jobs ? fgjobs::FG_JOB_BLOCKS : 0;
   hipLaunchKernelGGL(sb_sort_large_kernel, dim3((S < SB_LARGE_GRID ? S : SB_LARGE_GRID) + job_blocks),
@@ -1460,11 +1629,16 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
                        w.st_offsets, w.long_list, entries, fw.lt);
     hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
                        w.st_offsets, w.long_list, entries, scratch, fw.lt);
-    hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h,
-                       (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
   }
   hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h, tile_offsets,
-                     w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets);
+                     w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
+                     long_mode ? fw.lt.over_list : nullptr);
+  if (long_mode) {
+    hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
+                       (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
+    hipLaunchKernelGGL(sb_long_overflow_kernel, dim3(64), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, (long long)capacity,
+                       tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
+  }
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -132,7 +132,7 @@ class RasterContext:
         self.binning = e.get("FG_BINNING", "supertile")
         if self.binning not in ("supertile", "depthfirst"):
             raise ValueError(f"FG_BINNING={self.binning!r}: supertile | depthfirst")
-        # The supertile path sorts a segment in LDS up to 8064 elements; a longer one (a dense cluster: tens of
+        # The supertile path sorts a segment in LDS up to 7936 elements; a longer one (a dense cluster: tens of
         # thousands of splats over one 32 x 32-pixel supertile) is cut into buckets by a multi-workgroup sample sort
         # when fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS -- three more launches, so only for shapes that
         # need them: fg_stbin_count reports the longest segment beside the list length, a shape that showed one
@@ -143,7 +143,7 @@ class RasterContext:
         self.long_segments = e.get("FG_LONG_SEGMENTS", "auto")
         if self.long_segments not in ("auto", "always", "never"):
             raise ValueError(f"FG_LONG_SEGMENTS={self.long_segments!r}: auto | always | never")
-        self.long_segment = 8064
+        self.long_segment = 7936
         self.long_cooldown = 64
         self.long_shapes = {}  # shape key -> calls left with the flag set
         self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag

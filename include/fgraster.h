@@ -152,7 +152,7 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
  * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, TWO words with
  * system scope (pinned host memory): count_out[0] the list length, count_out[1] the longest supertile segment
- * (segments beyond 8064 elements are sorted by one workgroup through global memory -- correct, slow -- unless
+ * (segments beyond 7936 elements are sorted by one workgroup through global memory -- correct, slow -- unless
  * fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS, see below).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
  * list_offsets = 0 (empty lists: consumers enqueued speculatively behind the call walk nothing; the host then
@@ -165,11 +165,12 @@ size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
 int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
                    int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
 size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
-/* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond 8064 elements (a dense cluster: tens of
- * thousands of splats over one 32 x 32-pixel supertile) are cut into buckets by a multi-workgroup sample sort
- * (three more launches: count, scatter, one LDS sort per bucket) instead of being sorted by ONE workgroup through
- * global memory.  Same lists bit for bit either way; a host sets the flag for shapes whose count_out[1] of an
- * earlier call exceeded 8064 (ops.bin_tiles does) -- on scenes without such segments the flag only costs the three
+/* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond 7936 elements (a dense cluster: tens of
+ * thousands of splats over one 32 x 32-pixel supertile) are cut into buckets of ~1024 elements by a multi-workgroup
+ * sample sort (splitters from a sorted sample inside the large-segment launch, two more launches -- count, scatter --
+ * and 1024 more workgroups of the small-segment launch that sort the buckets) instead of being sorted by ONE workgroup
+ * through global memory.  Same lists bit for bit either way; a host sets the flag for shapes whose count_out[1] of an
+ * earlier call exceeded 7936 (ops.bin_tiles does) -- on scenes without such segments the flag only costs the two
  * empty launches. */
 #define FG_STBIN_LONG_SEGMENTS 1
 int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,

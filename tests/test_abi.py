@@ -99,9 +99,9 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     # fill with job lists: the image must give the tile grid
     assert lib.fg_stbin_fill_jobs(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, 0, None) == -1
     # ... and (ABI 7) the flags word holds FG_STBIN_LONG_SEGMENTS or nothing; the workspace has room for the long
-    # segments' bucket tables (52 bytes per bucket, a bucket per 2688 list entries + one per possible long segment)
+    # segments' bucket tables (40 bytes per bucket, a bucket per 1536 list entries + one per possible long segment)
     assert lib.fg_stbin_fill(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 2, None) == -1
-    assert lib.fg_stbin_fill_workspace_bytes(1 << 23) >= 2 * 8 * (1 << 23) + 52 * ((1 << 23) // 2688 + (1 << 23) // 8064)
+    assert lib.fg_stbin_fill_workspace_bytes(1 << 23) >= 2 * 8 * (1 << 23) + 40 * ((1 << 23) // 1536 + (1 << 23) // 7936)
     assert _lib.STBIN_LONG_SEGMENTS == 1
 
 
