@@ -78,7 +78,85 @@ struct JobBuild {
   JobParams pf, pb;
   int32_t* jobs_fwd;
   int32_t* jobs_bwd;
+  // balanced row bands (nx == 1): an XCD's band holds up to rows_limit tile rows (what the launches' workgroups per XCD
+  // can take; 0 = the equal bands of band_of_xcd)
+  int rows_limit;
+  int balance_percent;  // ... when the heaviest equal band's cost exceeds this many percent of the mean band's
 };
+constexpr int FG_BAND_MAX_ROWS = 1024;
+
+// The eight XCDs' row bands by CONTENT: equal shares of the tiles' expected walking cost instead of equal numbers of
+// rows.  A cluster of splats under one XCD's band made that XCD the launch (half of the Gaussians in a ball: three XCDs
+// finish at 390 / 570 us, forward / backward, five at 280 / 420 and idle: profiles/r04_job_timeline.md section 2); a
+// workgroup taking jobs from a shared cursor instead costs every job a same-address atomic (57 ns each, serialised:
+// forward 0.20 -> 0.38 ms, profiles/r04_job_stealing.md).  Cost of a tile = its list length, capped at four times the
+// mean (a long list saturates its pixels and is not walked to its end) + a quarter of the mean (the job itself).  All
+// sixteen workgroups of a build compute the same boundaries from the same tile ranges.  The equal bands stay when the
+// heaviest of them is within balance_percent of the mean (the launch policy is tuned on them; on the uniform bench scene the
+// cost model's bands were 3% slower than the equal ones).  row0[0 .. 8] in LDS.
+template <int NTH>
+__device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int32_t* __restrict__ tile_offsets, int* row0) {
+  __shared__ uint32_t s_roww[FG_BAND_MAX_ROWS];
+  const int tile_w = jb.tile_w, tile_h = jb.tile_h, T = tile_w * tile_h;
+  const bool uniform = jb.nx != 1 || jb.rows_limit <= 0 || tile_h < 16 || tile_h > FG_BAND_MAX_ROWS;
+  if (!uniform) {
+    for (int r = threadIdx.x; r < tile_h; r += NTH) s_roww[r] = 0u;
+    __syncthreads();
+    const uint32_t total = (uint32_t)tile_offsets[T], mean = total / (uint32_t)T;
+    const uint32_t cap = 4u * mean + 16u, fixed = mean / 4u + 4u;
+    // (eight tiles per thread a trip, all loads in flight together; a thread's tiles are consecutive: mostly one row)
+    for (int t0 = 8 * (int)threadIdx.x; t0 < T; t0 += 8 * NTH) {
+      int32_t o[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) o[k] = tile_offsets[min(t0 + k, T)];
+      int row = t0 / tile_w, next = (row + 1) * tile_w;
+      uint32_t acc = 0;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (t0 + k >= T) break;
+        if (t0 + k == next) {
+          atomicAdd(&s_roww[row], acc);
+          acc = 0;
+          ++row;
+          next += tile_w;
+        }
+        acc += min((uint32_t)(o[k + 1] - o[k]), cap) + fixed;
+      }
+      atomicAdd(&s_roww[row], acc);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (uniform) {
+      for (int x = 0; x < 8; ++x) row0[x] = band_of_xcd(x, tile_w, tile_h, 1).r0;
+      row0[8] = tile_h;
+    } else {
+      unsigned long long W = 0, cum = 0, heaviest = 0;
+      for (int x = 0; x < 8; ++x) {  // the equal bands' shares: left alone unless one of them is well above the mean
+        const Band e = band_of_xcd(x, tile_w, tile_h, 1);
+        unsigned long long w = 0;
+        for (int r = e.r0; r < e.r0 + e.nrows; ++r) w += s_roww[r];
+        W += w;
+        heaviest = w > heaviest ? w : heaviest;
+        row0[x] = e.r0;
+      }
+      row0[8] = tile_h;
+      int r = 0;
+      if (8 * heaviest * 100 > W * (unsigned)jb.balance_percent)
+      for (int x = 0; x < 8; ++x) {
+        row0[x] = r;
+        const int left = tile_h - r, others = 7 - x;
+        const int most = min(jb.rows_limit, left - others);                 // leave a row for every XCD behind
+        const int least = max(1, left - others * jb.rows_limit);           // ... and no more than they can take
+        const unsigned long long target = W * (unsigned)(x + 1) / 8u;
+        int n = 0;
+        while (n < most && (n < least || cum + s_roww[r + n] / 2u <= target)) cum += s_roww[r + n++];
+        r += x == 7 ? left : n;
+      }
+    }
+  }
+  __syncthreads();
+}
 constexpr int FG_JOB_BLOCKS = 16;  // workgroups of one build: 8 XCD bands x (forward list, backward list)
 
 // host: fill `out` for fg_raster_build_jobs' arguments (raster.hip, where the launch policy lives);
@@ -87,11 +165,14 @@ __attribute__((visibility("hidden"))) int plan_jobs(int width, int height, int t
               const fg_raster_config* config, JobBuild* out);
 
 // workgroup `block` (0 .. FG_JOB_BLOCKS) of a build, NTH threads (a multiple of 64, all of the workgroup)
+// (reuse_bands: a workgroup's second call -- its other list -- takes the band boundaries its first call left in LDS)
 template <int NTH>
-__device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, const int32_t* __restrict__ tile_offsets) {
+__device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, const int32_t* __restrict__ tile_offsets,
+                                                 bool reuse_bands = false) {
   constexpr int NWV = NTH / 64;
   __shared__ int wave_tot[NWV];
   __shared__ int carry;
+  __shared__ int s_row0[9];
   const int xcd = block & 7;
   const bool bwd = block >= 8;
   const int tile_w = jb.tile_w, tile_h = jb.tile_h, cap = jb.cap;
@@ -99,7 +180,12 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   int32_t* jobs = bwd ? jb.jobs_bwd : jb.jobs_fwd;
   if (!jobs) return;
   const JobParams p = bwd ? pb : pf;
-  const Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);
+  Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);
+  if (jb.nx == 1) {
+    if (!reuse_bands) balanced_row_bands<NTH>(jb, tile_offsets, s_row0);
+    band.r0 = s_row0[xcd];
+    band.nrows = s_row0[xcd + 1] - s_row0[xcd];
+  }
   const int n = band.nrows * band.ncols;
   const int total = tile_offsets[tile_w * tile_h];
   const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);

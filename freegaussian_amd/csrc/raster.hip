@@ -1409,7 +1409,19 @@ int band_nx(const Cfg& c) {
   const int v = c.bands_nx;
   return (v == 1 || v == 2 || v == 4 || v == 8) ? v : 1;
 }
-int band_tiles_max(const Cfg& c, int tile_w, int tile_h) { return band_tiles_for(tile_w, tile_h, band_nx(c)); }
+// Tile rows an XCD's band may hold when the job builder balances the bands by content (fgjobs::balanced_row_bands): one
+// and a half times the equal share.  Everything below sizes grids and list segments for the LARGEST band, so this is
+// what lets a light XCD take rows off a heavy one; the workgroups it adds to a launch return at once (~1 ns each).
+int band_rows_limit(const Cfg& c, int tile_h) {
+  const int equal = (tile_h + 7) / 8;
+  if (band_nx(c) != 1 || c.balance_bands == 0) return 0;
+  const int lim = equal + (equal + 1) / 2;
+  return lim < tile_h ? lim : tile_h;
+}
+int band_tiles_max(const Cfg& c, int tile_w, int tile_h) {
+  const int rows = band_rows_limit(c, tile_h);
+  return rows > 0 ? rows * tile_w : band_tiles_for(tile_w, tile_h, band_nx(c));
+}
 int mixed_grid(const Cfg& c, int tile_w, int tile_h, int tail) {  // positional jobs only
   const int n_max = band_tiles_max(c, tile_w, tile_h);
   int t4 = tail & 0xFFFF, t2 = tail >> 16;
@@ -1716,6 +1728,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->seg_parts = c->seg_tail = c->seg_parts2 = c->seg_tail2 = -1;
   c->debug_only_xcd = -1;
   c->debug_k_mod = 0;
+  c->balance_bands = -1;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
@@ -1749,7 +1762,9 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(cfg, tile_w, tile_h, sp, st, true) / 8, sp, st,
                                           seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st}
                               : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
-  *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd};
+  const int rows_limit = band_rows_limit(cfg, tile_h);  // (the grids and list segments are sized for it: band_tiles_max)
+  *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd, rows_limit,
+                          cfg.balance_bands > 1 ? cfg.balance_bands : 115};
   return FG_OK;
 }
 

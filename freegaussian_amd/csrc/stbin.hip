@@ -457,7 +457,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
     if ((int)blockIdx.x >= first) {
       fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first, jb, tile_offsets);
       __syncthreads();
-      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first + 8, jb, tile_offsets);
+      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first + 8, jb, tile_offsets, jb.jobs_fwd != nullptr);
       return;
     }
   }

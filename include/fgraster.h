@@ -238,6 +238,11 @@ typedef struct fg_raster_config {
   int32_t seg_tail2;
   int32_t debug_only_xcd;  /* measurement hooks of the classic launches: only this XCD's workgroups work (-1 = off) */
   int32_t debug_k_mod;     /* ... only every m-th tile of each XCD (0 = off) */
+  int32_t balance_bands;   /* job lists (ABI 7): the XCDs' bands of tile rows hold equal shares of the tiles' expected cost
+                              (list lengths, capped) instead of equal numbers of rows -- a cluster of splats under one
+                              band no longer sets the launch time -- when the heaviest equal band is more than 15% above
+                              the mean; 0 = equal rows always; -1 / 1 = default; p >= 100: the threshold in percent of
+                              the mean (100 = always by cost) */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 

@@ -44,10 +44,12 @@ def test_workspace_queries_need_no_gpu():
     n = 5_000_000
     assert lib.fg_sort_workspace_bytes(n) >= n * 12
     # job lists: none below 200 tiles (classic launches), 8 counters + 8 segments of 8 entries per
-    # tile of the largest XCD band otherwise
+    # tile of the largest XCD band otherwise -- a band balanced by content holds up to 1.5 x the equal share of rows
     assert lib.fg_raster_jobs_words(208, 144, 16, None) == 0  # 13 x 9 = 117 tiles
-    assert lib.fg_raster_jobs_words(480, 270, 16, None) == 8 + 8 * 8 * 3 * 30  # 30 x 17 tiles: bands of up to 3 rows
-    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) == 8 + 8 * 8 * 9 * 120
+    assert lib.fg_raster_jobs_words(480, 270, 16, None) == 8 + 8 * 8 * 5 * 30  # 30 x 17 tiles: bands of up to 3 (+ 2) rows
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) == 8 + 8 * 8 * 14 * 120
+    from freegaussian_amd import ops
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, ops.launch_policy(balance_bands=0).ptr()) == 8 + 8 * 8 * 9 * 120
     assert lib.fg_raster_jobs_words(1920, 1080, 8, None) == 0  # unsupported tile size
     assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, 0, None, None) == -1
 
