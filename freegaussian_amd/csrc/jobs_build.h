@@ -45,6 +45,37 @@ __device__ __forceinline__ int band_tile(const Band& b, int idx, int tile_w) {
 // forward lists: bit 30 of an entry = "the backward will not cut this tile's list into shares": the
 // forward then writes no compositing checkpoints for it
 constexpr int FG_JOB_NO_CKPT = 1 << 30;
+// HEAVY tiles of the forward (raster.hip, raster_fwd_body MODE 1 / 2 / 3; JobParams::heavy_len): in the main list a
+// heavy tile is four single-strip jobs with bit 28 set -- they walk only the first FG_HEAVY_PREFIX entries of the list
+// (most long lists saturate their pixels well inside that: nothing more happens to such a tile) and leave the state there.
+// Two more lists of the same shape follow the main one, for the two launches behind it: the LOCAL jobs -- [0..7] jobs per
+// XCD, 8 segments of FG_LOCAL_CAP entries, entry = tile << 8 | part: batches [part, part + 1) x heavy_batches_per_job
+// of the list BEHIND the prefix, every 64-entry batch composited by itself -- and the COMBINE jobs -- 8 segments of
+// FG_HEAVY_CAP entries, four per heavy tile: tile << 3 | (strip + 1).
+constexpr int FG_JOB_PREFIX = 1 << 28;
+#ifndef FG_HEAVY_MIN_BATCHES
+#define FG_HEAVY_MIN_BATCHES 4
+#endif
+#ifndef FG_HEAVY_BWD_PARTS
+#define FG_HEAVY_BWD_PARTS 16
+#endif
+#ifndef FG_HEAVY_PREFIX_ENTRIES
+#define FG_HEAVY_PREFIX_ENTRIES 2048
+#endif
+constexpr int FG_HEAVY_PREFIX = FG_HEAVY_PREFIX_ENTRIES;  // entries the four strip jobs of a heavy tile walk serially
+constexpr int FG_LOCAL_CAP = 8192;         // local jobs per XCD at most
+constexpr int FG_HEAVY_CAP = 2048;         // combine jobs per XCD at most (512 heavy tiles in an XCD's band)
+constexpr int FG_LOCAL_WORDS = 8 + 8 * FG_LOCAL_CAP, FG_HEAVY_WORDS = 8 + 8 * FG_HEAVY_CAP;
+constexpr int FG_SEG_ENTRIES_H = 64;       // (= FG_SEG_ENTRIES of raster.hip: a batch)
+__host__ __device__ __forceinline__ int heavy_batches_per_job(int len) {
+  // (at most 64 jobs per tile: the longest lists -- a dense cluster seen end on -- are the ones the prefix finishes)
+  const int nb = (len - FG_HEAVY_PREFIX + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H, per = (nb + 63) / 64;
+  return per > FG_HEAVY_MIN_BATCHES ? per : FG_HEAVY_MIN_BATCHES;
+}
+__host__ __device__ __forceinline__ int heavy_local_jobs(int len) {
+  const int nb = (len - FG_HEAVY_PREFIX + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H, per = heavy_batches_per_job(len);
+  return (nb + per - 1) / per;
+}
 struct JobParams {
   int tail4, tail2, s4, s2;
   int max_jobs;  // workgroups per XCD of the launch that will read the list
@@ -56,18 +87,23 @@ struct JobParams {
   // graded tail: the last seg_tail2 (<= seg_tail) tiles get seg_parts2 (>= seg_parts) jobs -- the jobs
   // that run while the launch drains are the shortest ones
   int seg_parts2, seg_tail2;
+  // forward lists: a tile with a list longer than this is a HEAVY tile (0 = off); backward share lists: such a tile
+  // gets up to 64 shares (16 otherwise)
+  int heavy_len;
 };
+// (thr_h: the heavy threshold of this build round, 0x7fffffff = none)
 __device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
-                                         int thr2, int len) {
+                                         int thr2, int len, int thr_h = 0x7fffffff) {
   if (p.seg_parts > 1) {
     int c = idx >= n - min(p.seg_tail, n) ? p.seg_parts : 1;
     if (idx >= n - min(p.seg_tail2, n)) c = max(c, p.seg_parts2);
     if (len > thr2) {
       const int share = max(thr2 >> 1, 1);
-      c = max(c, min(16, (len + share - 1) / share));
+      c = max(c, min(len > thr_h ? FG_HEAVY_BWD_PARTS : 16, (len + share - 1) / share));
     }
     return c;
   }
+  if (len > thr_h) return 4;  // (a heavy tile: four strip jobs over the list's first FG_HEAVY_PREFIX entries)
   int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
   level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
   return 1 << level;
@@ -80,6 +116,7 @@ struct JobBuild {
   int32_t* jobs_bwd;
   // balanced row bands (nx == 1): an XCD's band holds up to rows_limit tile rows (what the launches' workgroups per XCD
   // can take; 0 = the equal bands of band_of_xcd)
+  int main_words;  // words of the main list: the heavy tiles' local and combine lists start there (forward list, heavy_len > 0)
   int rows_limit;
   int balance_percent;  // ... when the heaviest equal band's cost exceeds this many percent of the mean band's
 };
@@ -104,15 +141,15 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
     __syncthreads();
     const uint32_t total = (uint32_t)tile_offsets[T], mean = total / (uint32_t)T;
     const uint32_t cap = 4u * mean + 16u, fixed = mean / 4u + 4u;
-    // (eight tiles per thread a trip, all loads in flight together; a thread's tiles are consecutive: mostly one row)
-    for (int t0 = 8 * (int)threadIdx.x; t0 < T; t0 += 8 * NTH) {
-      int32_t o[9];
+    // (four tiles per thread a trip, all loads in flight together; a thread's tiles are consecutive: mostly one row)
+    for (int t0 = 4 * (int)threadIdx.x; t0 < T; t0 += 4 * NTH) {
+      int32_t o[5];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) o[k] = tile_offsets[min(t0 + k, T)];
+      for (int k = 0; k < 5; ++k) o[k] = tile_offsets[min(t0 + k, T)];
       int row = t0 / tile_w, next = (row + 1) * tile_w;
       uint32_t acc = 0;
 #pragma unroll
-      for (int k = 0; k < 8; ++k) {
+      for (int k = 0; k < 4; ++k) {
         if (t0 + k >= T) break;
         if (t0 + k == next) {
           atomicAdd(&s_roww[row], acc);
@@ -193,6 +230,9 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   int thr4 = p.s4 ? (int)(((int64_t)total * p.s4) >> 16) : 0x7fffffff;
   int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
   const int thr2_b = pb.s2 ? (int)(((int64_t)total * pb.s2) >> 16) : 0x7fffffff;  // the backward's, as given
+  int thr_h = p.heavy_len > 0 ? p.heavy_len : 0x7fffffff;
+  __shared__ int heavy_tot[NWV];
+  __shared__ int heavy_n, local_n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
   // it does; the positional jobs alone always fit
@@ -201,7 +241,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
+      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len, thr_h);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
@@ -211,21 +251,46 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     int all = 0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) all += wave_tot[w];
-    if (all <= p.max_jobs) break;  // uniform across the workgroup
+    bool fits = all <= p.max_jobs;  // uniform across the workgroup
+    if (!bwd && thr_h != 0x7fffffff) {
+      // (a pass of its own: the build rides in a 1024-thread launch, 128 registers)
+      int heavy = 0;  // heavy tiles | their local jobs << 12
+      for (int idx = threadIdx.x; idx < n; idx += NTH) {
+        const int tile = band_tile(band, idx, tile_w);
+        const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+        if (len > thr_h) heavy += 1 + (heavy_local_jobs(len) << 12);
+      }
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) heavy += __shfl_xor(heavy, m);
+      __syncthreads();
+      if (lane == 0) heavy_tot[wave] = heavy;
+      __syncthreads();
+      int all_heavy = 0;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) all_heavy += heavy_tot[w];
+      fits = fits && 4 * (all_heavy & 0xFFF) <= FG_HEAVY_CAP && (all_heavy >> 12) <= FG_LOCAL_CAP;
+    }
+    if (fits) break;
     thr4 = thr4 > 0x50000000 ? 0x7fffffff : thr4 + (thr4 >> 1) + 1;
     thr2 = thr2 > 0x50000000 ? 0x7fffffff : thr2 + (thr2 >> 1) + 1;
-    if (round == 10) thr4 = thr2 = 0x7fffffff;
+    thr_h = thr_h > 0x50000000 ? 0x7fffffff : thr_h + (thr_h >> 1) + 1;
+    if (round == 10) thr4 = thr2 = thr_h = 0x7fffffff;
   }
+  // (the backward's list gives heavy tiles finer shares: by the forward's threshold as given -- its own list is built
+  // by another workgroup, whose raised threshold this one does not see; more shares than heavy tiles need is harmless)
+  if (threadIdx.x == 0) heavy_n = local_n = 0;
   if (threadIdx.x == 0) carry = 0;
   __syncthreads();
   int32_t* seg = jobs + 8 + (size_t)xcd * cap;
   for (int base = 0; base < n; base += NTH) {
     const int idx = base + (int)threadIdx.x;
     int cnt = 0, tile = 0, flag = 0;
+    bool heavy_tile = false;
     if (idx < n) {
       tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len);
+      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len, thr_h);
+      heavy_tile = !bwd && len > thr_h;
       // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
       // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
       if (!bwd && pb.seg_parts > 1 && job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1) flag = FG_JOB_NO_CKPT;
@@ -243,7 +308,10 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     for (int w = 0; w < NWV; ++w)
       if (w < wave) pos += wave_tot[w];
     if (p.seg_parts > 1) {
-      for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 8 | ((j + idx) % cnt) << 4 | (cnt - 1);
+      for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 12 | ((j + idx) % cnt) << 6 | (cnt - 1);
+    } else if (heavy_tile) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1) | FG_JOB_PREFIX;  // (checkpoints: always)
     } else if (cnt == 1) seg[pos] = tile << 3 | flag;  // strip -1
     else if (cnt == 2) { seg[pos] = tile << 3 | 5 | flag; seg[pos + 1] = tile << 3 | 6 | flag; }  // strip 4, 5
     else if (cnt == 4) {
@@ -255,6 +323,28 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     __syncthreads();
   }
   if (threadIdx.x == 0) jobs[xcd] = carry;
+  if (!bwd && p.heavy_len > 0) {
+    // the heavy tiles' local jobs and their four combine jobs each, on the lists of the two launches behind the main one
+    // (a pass of its own: registers, see above; any order)
+    int32_t* lc = jobs + jb.main_words;
+    int32_t* hv = lc + FG_LOCAL_WORDS;
+    for (int idx = threadIdx.x; idx < n; idx += NTH) {
+      const int tile = band_tile(band, idx, tile_w);
+      const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+      if (len > thr_h) {
+        const int nl = heavy_local_jobs(len);
+        const int l0 = atomicAdd(&local_n, nl), h = atomicAdd(&heavy_n, 1);
+        for (int j = 0; j < nl; ++j) lc[8 + xcd * FG_LOCAL_CAP + l0 + j] = tile << 8 | j;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hv[8 + xcd * FG_HEAVY_CAP + 4 * h + j] = tile << 3 | (j + 1);
+      }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      lc[xcd] = local_n;
+      hv[xcd] = 4 * heavy_n;
+    }
+  }
 }
 
 }  // namespace fgjobs

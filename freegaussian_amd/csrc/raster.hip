@@ -128,15 +128,17 @@ build_jobs_kernel(fgjobs::JobBuild jb, const int32_t* __restrict__ tile_offsets)
   fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets);
 }
 
-// job k of XCD (b & 7) from a list; tile or -1
+// job k of XCD (b & 7) from a list; tile or -1.  *prefix: a strip job of a HEAVY tile (jobs_build.h: it walks the
+// first FG_HEAVY_PREFIX entries only)
 __device__ __forceinline__ int job_from_list(int b, const int32_t* __restrict__ jobs, int cap, int& strip,
-                                             bool* no_ckpt = nullptr) {
+                                             bool* no_ckpt = nullptr, bool* prefix = nullptr) {
   const int xcd = b & 7, k = b >> 3;
   if (k >= jobs[xcd]) return -1;
   const int e = jobs[8 + (size_t)xcd * cap + k];
   strip = (e & 7) - 1;
   if (no_ckpt) *no_ckpt = (e & FG_JOB_NO_CKPT) != 0;
-  return (e & ~FG_JOB_NO_CKPT) >> 3;
+  if (prefix) *prefix = (e & FG_JOB_PREFIX) != 0;
+  return (e & ~(FG_JOB_NO_CKPT | FG_JOB_PREFIX)) >> 3;
 }
 
 // the same from a list of list-share jobs (JobParams::seg_parts): tile, part, parts
@@ -144,9 +146,9 @@ __device__ __forceinline__ int share_from_list(int b, const int32_t* __restrict_
   const int xcd = b & 7, k = b >> 3;
   if (k >= jobs[xcd]) return -1;
   const int e = jobs[8 + (size_t)xcd * cap + k];
-  parts = (e & 15) + 1;
-  part = (e >> 4) & 15;
-  return e >> 8;
+  parts = (e & 63) + 1;
+  part = (e >> 6) & 63;
+  return e >> 12;
 }
 
 struct Splat {
@@ -204,6 +206,10 @@ struct Composite {
 #ifndef FG_SEG_ENTRIES
 #define FG_SEG_ENTRIES 64
 #endif
+static_assert(FG_SEG_ENTRIES == fgjobs::FG_SEG_ENTRIES_H, "a heavy tile's batch is a checkpoint segment");
+#ifndef FG_HEAVY_AHEAD
+#define FG_HEAVY_AHEAD 8
+#endif
 // measured on MI355X (1M Gaussians, 1080p, profiles/r02_backward_list_shares.md): the last 400 tiles of
 // every XCD's sequence as 3 shares each over 128-entry segments: 0.398 -> 0.374 ms against two-strip jobs
 // for the last 300; 4 shares over 64-entry segments: 0.370 -> 0.349 (the forward writes checkpoints only
@@ -231,8 +237,17 @@ __host__ __device__ __forceinline__ size_t seg_plane_offset4(int n_tiles) { retu
 __host__ __device__ __forceinline__ size_t seg_slots_offset4(int n_tiles, int width, int height) {
   return seg_plane_offset4(n_tiles) + ((size_t)width * height / 4 + 256) / 256 * 256;
 }
+// A checkpoint slot: 256 float4 (the tile's pixels, row-major) + 256 bytes (per pixel, HEAVY tiles only: the last entry
+// of the slot's 64-entry batch the pixel took, + 1; 0 = none) = 272 float4.
+constexpr int FG_SEG_SLOT4 = TILE * TILE + TILE * TILE / 16;
+// The slot of the batch that starts at list entry g = start + 64 c of `tile` (start = the tile's first entry): every
+// batch of every tile its own, the first (c = 0: a heavy tile's local composite; no checkpoint) and a short last one
+// included -- a tile of len entries has ceil(len / 64) <= floor(len / 64) + 1 batches, hence the "+ tile".
+__device__ __forceinline__ size_t seg_slot_index(int start, int tile, int g) {
+  return (size_t)(start / FG_SEG_ENTRIES) + (size_t)tile + (size_t)((g - start) / FG_SEG_ENTRIES);
+}
 struct Segments {
-  float4* ckpt;             // [slots][256 pixels of the tile, row-major]; nullptr = no segmentation
+  float4* ckpt;             // [slots][FG_SEG_SLOT4]; nullptr = no segmentation
   const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
                             // composite epilogue they are rebuilt from the finished image instead
   int parts;                // backward: jobs per split tile (1 = whole list)
@@ -413,23 +428,52 @@ struct FwdShared {
 // One tile job: NW cooperating wavefronts (threadIdx.x in [0, 64 NW)), PPT pixels per lane; the
 // job's first wavefront owns strip group `wave_base` (0 for a whole tile; the strip index for a
 // single-strip job of the mixed launch, PPT == 1 / NW == 1).
-template <int C, int PPT, int NW>
+//
+// HEAVY tiles (fg_raster_config::heavy_tiles; three channels, one wavefront per job): a list of thousands of entries
+// that does not saturate its pixels is a serial walk of 100 ns per entry for a wavefront alone on its SIMD (80% of the
+// Gaussians in a ball: four strip jobs of 1.5 ms each while the chip idles, profiles/r04_job_timeline.md).  Compositing
+// is associative, so such a tile takes three launches:
+//   MODE 3 (the main launch, four strip jobs as for any long list) walks only the list's first FG_HEAVY_PREFIX entries
+//          and leaves every pixel's state there in the checkpoint slot of that entry (T < 0: the pixel is finished).
+//          Most long lists -- a dense, opaque cluster -- saturate inside the prefix and nothing more happens to the tile.
+//   MODE 1 ("local" jobs, many per tile, any order; they return at once when the prefix finished the tile) composite each
+//          64-entry batch of their share of the rest of the list BY ITSELF -- from T = 1, C = 0 -- and leave (T_b, C_b)
+//          per pixel in the batch's slot (T_b < 0: the pixel met the stop rule inside the batch), the pixel's last entry
+//          in the slot's byte plane.
+//   MODE 2 ("combine" jobs, one per strip) continue from the prefix's state and take a batch in ONE step, C += T C_b,
+//          T *= T_b, unless some pixel could stop inside it (T T_b within 1e-5 of the stop threshold, or a local stop):
+//          that batch is walked entry by entry from the running state like any other job.  The running state before every
+//          batch goes into the slot: the backward's checkpoints.
+// Not bit-identical to the serial walk (products and sums are associated differently: 1e-7 relative); the stop decisions
+// are the serial walk's own.
+template <int C, int PPT, int NW, int MODE = 0>
 __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int tile, int wave_base, int width,
                                                 int height, int tile_w, const float4* __restrict__ splats,
                                                 const int32_t* __restrict__ tile_offsets,
                                                 const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                                                 float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                 const Composite& comp, float4* __restrict__ ckpt = nullptr,
-                                                uint32_t* __restrict__ live_words = nullptr) {
+                                                uint32_t* __restrict__ live_words = nullptr, int local_part = 0) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
+  static_assert(MODE == 0 || (C == 3 && NW == 1), "heavy-tile jobs: three channels, one wavefront");
   auto& lds = sh.rec;
   auto& lds_mask = sh.mask;
   auto& lds_list = sh.list;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
   const int n_tiles = tile_w * ((height + TILE - 1) / TILE);
-  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int start = tile_offsets[tile];
+  int end = tile_offsets[tile + 1];
+  int first = start;  // MODE 1: this job's share of the list behind the prefix, whole batches; MODE 2: all of it
+  if constexpr (MODE == 1) {
+    const int per = heavy_batches_per_job(end - start) * FG_SEG_ENTRIES;
+    first = start + FG_HEAVY_PREFIX + local_part * per;
+    end = min(end, first + per);
+  }
+  if constexpr (MODE == 2) first = start + FG_HEAVY_PREFIX;
+  if constexpr (MODE == 3) end = min(end, start + FG_HEAVY_PREFIX);
+  float4* const slots = (MODE != 0 || (C == 3 && NW == 1)) && ckpt ? ckpt + seg_slots_offset4(n_tiles, width, height) : nullptr;
   // one wavefront per workgroup (NW == 1, the mixed launches): the wave index is the constant 0 and
   // every per-wave LDS address folds into an instruction offset instead of a register
   const int lane = fg::lane_id(), wl = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
@@ -447,7 +491,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   // convert back and forth (ISA of the bool version: v_and/v_cmp_eq/v_cndmask per flag per slot).
   float T[PPT], acc[PPT][C];
   int last[PPT];
-  uint64_t done[PPT];
+  uint64_t done[PPT], outside[PPT];
   // the lane's row in the tile's FIRST strip (slot_dy adds the strip)
   const float pyb = (float)(tile_y * TILE + (int)(threadIdx.x >> 4) - 4 * wl) + 0.5f;
   const uint64_t full = __ballot(true);
@@ -456,21 +500,92 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     const int iy = tile_y * TILE + row0 + k * RSTEP;
     T[k] = 1.f;
     last[k] = start - 1;
-    done[k] = __ballot(!(ix < width && iy < height));
+    done[k] = outside[k] = __ballot(!(ix < width && iy < height));
 #pragma unroll
     for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
   }
 
-  for (int batch = start; batch < end; batch += NT) {
+  if constexpr (MODE == 1 || MODE == 2) {
+    // the state the prefix jobs left at entry start + FG_HEAVY_PREFIX -- in the slot of the tile's FIRST batch, which
+    // nothing else uses (no checkpoint in front of the first entry; the slot of entry start + FG_HEAVY_PREFIX takes that
+    // batch's local composite, then its checkpoint)
+    const float4* at = slots + seg_slot_index(start, tile, start) * FG_SEG_SLOT4;
+    bool open = false;
+#pragma unroll
+    for (int k = 0; k < PPT; ++k) {
+      const float4 v = at[(row0 + k * RSTEP) * TILE + col];
+      open = open || v.x > 0.f;
+      if constexpr (MODE == 2) {
+        const int iy = min(tile_y * TILE + row0 + k * RSTEP, height - 1);
+        T[k] = fabsf(v.x);
+        acc[k][0] = v.y; acc[k][1] = v.z; acc[k][2] = v.w;
+        done[k] |= __ballot(!(v.x > 0.f));
+        last[k] = last_ids[(size_t)iy * width + min(ix, width - 1)];
+      }
+    }
+    if (!__any(open)) return;  // the prefix finished every pixel: its outputs stand
+  }
+  int batch = first;
+  while (batch < end) {
     uint64_t all_done = full;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) all_done &= done[k];
-    // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
-    if (__syncthreads_and(all_done == full)) break;
-    if constexpr (C == 3 && NW == 1) {
+    if constexpr (MODE == 1) {
+      // a batch by itself: from T = 1, C = 0, nothing taken
+      __syncthreads();
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        T[k] = 1.f;
+        last[k] = batch - 1;
+        done[k] = outside[k];
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[k][c] = 0.f;
+      }
+    } else {
+      // barrier (protects the LDS batch of the previous iteration) + tile-wide early exit
+      if (__syncthreads_and(all_done == full)) break;
+    }
+    if constexpr (MODE == 2) {
+      // batches nobody can stop in, taken whole: FG_HEAVY_AHEAD slots are fetched together (one round trip), then
+      // applied in order up to the first that has to be walked
+      constexpr int D = FG_HEAVY_AHEAD;
+      static_assert(PPT == 1, "combine jobs: one strip, one pixel per lane");
+      const int pix = row0 * TILE + col;
+      float4 L[D];
+      uint32_t lb[D];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        const int bd = min(batch + d * FG_SEG_ENTRIES, end - 1);
+        const float4* slot = slots + seg_slot_index(start, tile, bd) * FG_SEG_SLOT4;
+        L[d] = slot[pix];
+        lb[d] = reinterpret_cast<const uint8_t*>(slot + TILE * TILE)[pix];
+      }
+      bool walk = false;
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        if (walk || batch >= end) break;  // (uniform)
+        const bool may_stop = L[d].x < 0.f || T[0] * L[d].x <= FG_T_STOP * 1.00001f;
+        const uint64_t stops = __ballot(may_stop) & ~done[0];
+        if (stops != 0ull) {
+          walk = true;
+          break;
+        }
+        // the state BEFORE the batch: the backward's checkpoint (over the local result just read)
+        if (batch > start) slots[seg_slot_index(start, tile, batch) * FG_SEG_SLOT4 + pix] = make_float4(T[0], acc[0][0], acc[0][1], acc[0][2]);
+        const float t_in = lane_select0(~done[0], T[0]);  // (finished pixels: nothing is added, nothing changes)
+        acc[0][0] = fmaf(t_in, L[d].y, acc[0][0]);
+        acc[0][1] = fmaf(t_in, L[d].z, acc[0][1]);
+        acc[0][2] = fmaf(t_in, L[d].w, acc[0][2]);
+        T[0] = lane_select(~done[0], T[0] * L[d].x, T[0]);
+        last[0] = (lb[d] != 0u && !((done[0] >> lane) & 1ull)) ? batch + (int)lb[d] - 1 : last[0];
+        batch += FG_SEG_ENTRIES;
+      }
+      if (!walk) continue;  // (all D taken, or the list's end reached: the loop condition decides)
+    }
+    if constexpr (C == 3 && NW == 1 && MODE != 1) {
       // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
-      if (ckpt && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
-        float4* slot = ckpt + seg_slots_offset4(n_tiles, width, height) + (size_t)(batch / FG_SEG_ENTRIES) * (TILE * TILE);
+      if (slots && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
+        float4* slot = slots + seg_slot_index(start, tile, batch) * FG_SEG_SLOT4;
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
@@ -592,6 +707,31 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         }
       }
     }
+    if constexpr (MODE == 1) {
+      // the batch's own composite; T < 0: the pixel met the stop rule inside (the combine job walks the batch then)
+      float4* slot = slots + seg_slot_index(start, tile, batch) * FG_SEG_SLOT4;
+      uint8_t* slot_last = reinterpret_cast<uint8_t*>(slot + TILE * TILE);
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const bool stopped = ((done[k] & ~outside[k]) >> lane) & 1ull;
+        const int pix = (row0 + k * RSTEP) * TILE + col;
+        slot[pix] = make_float4(stopped ? -1.f : T[k], acc[k][0], acc[k][1], acc[k][2]);
+        slot_last[pix] = (uint8_t)(last[k] >= batch ? last[k] - batch + 1 : 0);
+      }
+    }
+    batch += NT;
+  }
+  if constexpr (MODE == 1) return;
+  if constexpr (MODE == 3) {
+    // the state at the end of the prefix, for the local and combine jobs (T < 0: finished, or outside the image)
+    if (slots && tile_offsets[tile + 1] - start > FG_HEAVY_PREFIX) {
+      float4* at = slots + seg_slot_index(start, tile, start) * FG_SEG_SLOT4;
+#pragma unroll
+      for (int k = 0; k < PPT; ++k) {
+        const bool fin = (done[k] >> lane) & 1ull;
+        at[(row0 + k * RSTEP) * TILE + col] = make_float4(fin ? -T[k] : T[k], acc[k][0], acc[k][1], acc[k][2]);
+      }
+    }
   }
 
   if constexpr (C == 3 && NW == 1) {
@@ -654,8 +794,10 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 // Mixed launch (one wavefront per workgroup): every XCD walks its band column-major as above; the
 // first tiles of its sequence are whole-tile jobs (4 pixels per lane), the last `tail_tiles` are
 // split into four single-strip jobs (1 pixel per lane) -- see launch_fwd_mixed.
+// (three channels: eight wavefronts per SIMD asked for -- 64 registers, which the allocator meets without spilling; the
+// heavy tiles' local jobs would otherwise cost the launch its eighth wavefront, 66 registers)
 template <int C>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(C == 3 ? 8 : 4, 8)))
 raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, int tail_tiles,
                         const int32_t* __restrict__ jobs, int cap,
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
@@ -676,12 +818,20 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   // tile -- left tens of thousands of empty workgroups to dispatch: 2160p forward 0.52 -> 0.64 ms;
   // workgroups walking on through a longer list cost 12-19 registers in both kernels.)
   int strip;
-  bool no_ckpt = false;
-  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip, &no_ckpt)
+  bool no_ckpt = false, prefix = false;
+  const int tile = jobs ? job_from_list(blockIdx.x, jobs, cap, strip, &no_ckpt, &prefix)
                         : job_of_block(blockIdx.x, tile_w, tile_h, nx, tail_tiles, strip);
   if (tile < 0) return;
   if (no_ckpt) ckpt = nullptr;
   FG_TL_BEGIN();
+  if constexpr (C == 3) {
+    if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
+      raster_fwd_body<C, 1, 1, 3>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
+                                  last_ids, comp, ckpt, live_words);
+      FG_TL_END(1, tile, strip, 1, 1);
+      return;
+    }
+  }
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
                              last_ids, comp, ckpt, live_words);
@@ -692,6 +842,53 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
                              alphas, last_ids, comp, ckpt, live_words);
   FG_TL_END(1, tile, strip, 0, 1);
+}
+
+// entry v of the eight segments of a list taken as one (jobs[0..7] = entries per segment), or -1 behind the last
+__device__ __forceinline__ int job_of_all_segments(const int32_t* __restrict__ jobs, int cap, int v) {
+#pragma unroll
+  for (int x = 0; x < 8; ++x) {
+    const int n = jobs[x];
+    if (v < n) return jobs[8 + x * cap + v];
+    v -= n;
+  }
+  return -1;
+}
+// The heavy tiles' local jobs (raster_fwd_body MODE 1) and combine jobs (MODE 2): the two launches behind
+// raster_fwd_mixed_kernel.  jobs = the launch's own list behind the main one (jobs_build.h); workgroup b takes jobs
+// b, b + gridDim, ... of the eight segments taken as one list (the host cannot know how many there are).
+__global__ void __launch_bounds__(64)
+raster_fwd_local_kernel(int width, int height, int tile_w, const int32_t* __restrict__ jobs,
+                        const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+                        const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
+                        int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
+                        uint32_t* __restrict__ live_words) {
+  __shared__ FwdShared<3, 64> sh;
+  // (the eight XCD segments as ONE list: the heavy tiles sit under one or two XCDs' bands, their jobs are for the chip)
+  for (int v = blockIdx.x;; v += gridDim.x) {
+    const int e = job_of_all_segments(jobs, FG_LOCAL_CAP, v);
+    if (e < 0) break;
+    FG_TL_BEGIN();
+    raster_fwd_body<3, 4, 1, 1>(sh, e >> 8, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
+                                last_ids, comp, ckpt, live_words, e & 255);
+    FG_TL_END(1, e >> 8, 5, 0, 1);
+  }
+}
+__global__ void __launch_bounds__(64)
+raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __restrict__ jobs,
+                          const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+                          const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
+                          int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
+                          uint32_t* __restrict__ live_words) {
+  __shared__ FwdShared<3, 64> sh;
+  for (int v = blockIdx.x;; v += gridDim.x) {
+    const int e = job_of_all_segments(jobs, FG_HEAVY_CAP, v);
+    if (e < 0) break;
+    FG_TL_BEGIN();
+    raster_fwd_body<3, 1, 1, 2>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
+                                alphas, last_ids, comp, ckpt, live_words);
+    FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 2);
+  }
 }
 
 template <int C, int NT>
@@ -773,7 +970,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
       hi = start + c1 * FG_SEG_ENTRIES;
       from_ckpt = true;
       ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE), width, height) +
-                (size_t)(hi / FG_SEG_ENTRIES) * (TILE * TILE);
+                seg_slot_index(start, tile, hi) * FG_SEG_SLOT4;
     }
   }
   FG_TL_MARK(1);  // share bounds known
@@ -1464,6 +1661,10 @@ int seg_grid(const Cfg& c, int tile_w, int tile_h, int parts, int tail, bool lis
   const int cap = jobs_cap(c, tile_w, tile_h);
   return 8 * (listed && per_xcd > cap ? cap : per_xcd);
 }
+// heavy_tiles: list length beyond which a tile of the forward is a heavy tile (raster_fwd_body MODE 1 / 2); <= 0: off
+int heavy_len(const Cfg& c) {
+  return c.heavy_tiles > 0 ? (c.heavy_tiles < FG_HEAVY_PREFIX + 512 ? FG_HEAVY_PREFIX + 512 : c.heavy_tiles) : 0;
+}
 // use_liveness = 0: the backward ignores the forward's liveness bytes (A/B)
 const uint32_t* live_use(const Cfg& c, const uint32_t* live_words) { return c.use_liveness == 0 ? nullptr : live_words; }
 // seg_tail = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
@@ -1528,6 +1729,18 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
                      zero_buf ? zero_floats / 4 : 0ll);
+  if constexpr (C == 3) {
+    // heavy tiles: their combine jobs, once every local job has left its batches' composites
+    if (jobs && ckpt && heavy_len(cfg) > 0) {
+      const int32_t* local = jobs + 8 + 8 * (size_t)cap;
+      hipLaunchKernelGGL(raster_fwd_local_kernel, dim3(8 * 1024), dim3(64), 0, s, width, height, tile_w, local,
+                         reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
+                         reinterpret_cast<float4*>(ckpt), live_words);
+      hipLaunchKernelGGL(raster_fwd_combine_kernel, dim3(8 * 256), dim3(64), 0, s, width, height, tile_w,
+                         local + FG_LOCAL_WORDS, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
+                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words);
+    }
+  }
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
 }
 
@@ -1729,6 +1942,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->debug_only_xcd = -1;
   c->debug_k_mod = 0;
   c->balance_bands = -1;
+  c->heavy_tiles = 0;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
@@ -1738,7 +1952,8 @@ extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, co
   const Cfg cfg = resolve(config);
   if ((tile_order_mode(cfg) & 255) != 2 || (tile_order_mode(cfg) >> 8) != 0) return 0;
   if (mixed_tail_fwd(cfg, n_tiles) == 0 && mixed_tail_bwd(cfg, n_tiles) == 0) return 0;  // classic launches: no lists
-  return 8 + 8 * (int64_t)jobs_cap(cfg, tile_w, tile_h);
+  // (+ the heavy tiles' combine list behind the main one)
+  return 8 + 8 * (int64_t)jobs_cap(cfg, tile_w, tile_h) + (heavy_len(cfg) > 0 ? FG_LOCAL_WORDS + FG_HEAVY_WORDS : 0);
 }
 
 int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
@@ -1753,17 +1968,20 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   const int tf = mixed_tail_fwd(cfg, n_tiles), tb = mixed_tail_bwd(cfg, n_tiles);
   const int sf = raster_split(cfg.split4_fwd, cfg.split2_fwd, FG_SPLIT4_FWD, FG_SPLIT2_FWD);
   const int sb = raster_split(cfg.split4_bwd, cfg.split2_bwd, FG_SPLIT4_BWD, FG_SPLIT2_BWD);
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(cfg, tile_w, tile_h, tf) / 8, 0, 0, 0, 0};
-  // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
-  // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const int sp = seg_parts(cfg, n_tiles);
   const bool shares = bwd_list_shares && tb > 0 && sp > 1;
+  // heavy tiles need the checkpoint buffer (three channels, list shares on) and the forward's list
+  const int hl = shares && tf > 0 && jobs_fwd ? heavy_len(cfg) : 0;
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(cfg, tile_w, tile_h, tf) / 8, 0, 0, 0, 0, hl};
+  // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
+  // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const int st = seg_tail_fit(cfg, tile_w, tile_h, sp, seg_tail(cfg, n_tiles));
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(cfg, tile_w, tile_h, sp, st, true) / 8, sp, st,
-                                          seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st}
-                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0};
+                                          seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st, hl}
+                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0, 0};
   const int rows_limit = band_rows_limit(cfg, tile_h);  // (the grids and list segments are sized for it: band_tiles_max)
-  *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd, rows_limit,
+  *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd,
+                          8 + 8 * jobs_cap(cfg, tile_w, tile_h), rows_limit,
                           cfg.balance_bands > 1 ? cfg.balance_bands : 115};
   return FG_OK;
 }
@@ -1798,7 +2016,7 @@ extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const Cfg cfg = resolve(config);
   if (seg_parts(cfg, n_tiles) <= 1 || mixed_tail_bwd(cfg, n_tiles) == 0 || mixed_tail_fwd(cfg, n_tiles) == 0) return 0;
-  return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + 2) * (int64_t)(TILE * TILE)) * 4;
+  return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + n_tiles + 2) * (int64_t)FG_SEG_SLOT4) * 4;
 }
 
 extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,

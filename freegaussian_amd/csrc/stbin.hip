@@ -340,8 +340,11 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
     }
     return;
   }
-  const uint64_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot);
+  uint32_t longest_tile = 0;
+  const uint64_t total = scan_counts_in_place(T, tile_offsets, buf, wave_tot, &longest_tile);
   if (threadIdx.x == 0 && count_out) {  // the list length straight into the caller's host-visible word
+    // (and the longest tile list: a host enables the heavy-tile forward -- fg_raster_config::heavy_tiles -- from it)
+    __hip_atomic_store(count_out + 2, (int64_t)longest_tile, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(count_out, (int64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __threadfence_system();
   }
@@ -1095,6 +1098,13 @@ __device__ __forceinline__ bool sort_supertile(SortShared<NW, KPT, BB>& sh, int 
                                                   flatten_ids, defer_skew);
 }
 
+// fg_stbin_fill_jobs without the staged scatter (tile grids beyond 65535 supertiles: the builders have no launch to ride in --
+// inside the large-segment sort they cost it 35 spilled registers): the raster launches' job lists by a launch of their own
+__global__ void __launch_bounds__(1024)
+sb_build_jobs_kernel(fgjobs::JobBuild jb, const int32_t* __restrict__ tile_offsets) {
+  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets);
+}
+
 // ---- long segments: sample sort ------------------------------------------------------------------------------------
 // A segment of n > SB_LONG_MIN elements (tens of thousands of splats over one 32 x 32-pixel supertile: a dense
 // cluster) is cut into k = long_buckets(n) buckets by k - 1 SPLITTERS taken from a sorted regular sample of the
@@ -1132,16 +1142,10 @@ __global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
 sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
                      const int32_t* __restrict__ st_offsets, const int32_t* __restrict__ large_list,
                      const int4* __restrict__ long_list, LongTables lt, uint64_t* __restrict__ entries,
-                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
-                     int job_blocks, fgjobs::JobBuild jb) {
+                     uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids) {
   __shared__ SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS> sh;
   static_assert(SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>::MAXN == SB_LONG_MIN, "long = beyond this launch's LDS sort");
-  // fg_stbin_fill_jobs: the first job_blocks workgroups build the raster launches' job lists from the (exact) tile
-  // ranges -- only when the scatter in front ran without its staging buffer (sb_scatter_kernel)
-  if ((int)blockIdx.x < job_blocks) {
-    fgjobs::build_jobs_block<64 * SB_LARGE_WAVES>((int)blockIdx.x, jb, tile_offsets);
-    return;
-  }
+  constexpr int job_blocks = 0;
   const int total = tile_offsets[tile_w * tile_h];
   if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
   // work items: the long segments' sample step first (the head of a chain of three more launches), then the LDS sorts
@@ -1619,11 +1623,10 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
                        long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, 0, fgjobs::JobBuild{});
   }
-  const int job_blocks = want_jobs ? fgjobs::FG_JOB_BLOCKS : 0;
-  hipLaunchKernelGGL(sb_sort_large_kernel, dim3((S < SB_LARGE_GRID ? S : SB_LARGE_GRID) + job_blocks),
-                     dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, w.long_list,
-                     fw.lt, entries, scratch, (long long)capacity, flatten_ids, job_blocks,
-                     job_blocks ? *jobs : fgjobs::JobBuild{});
+  if (want_jobs) hipLaunchKernelGGL(sb_build_jobs_kernel, dim3(fgjobs::FG_JOB_BLOCKS), dim3(1024), 0, s, *jobs, tile_offsets);
+  hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
+                     tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, w.long_list, fw.lt, entries, scratch,
+                     (long long)capacity, flatten_ids);
   if (long_mode) {
     hipLaunchKernelGGL(sb_long_count_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
                        w.st_offsets, w.long_list, entries, fw.lt);

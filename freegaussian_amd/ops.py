@@ -148,6 +148,20 @@ class RasterContext:
         self.long_cooldown = 64
         self.long_shapes = {}  # shape key -> calls left with the flag set
         self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag
+        # HEAVY tiles (fg_raster_config::heavy_tiles): a tile list of thousands of entries that does not saturate is four
+        # serial walks of ~100 ns per entry in the forward (1.4 ms for the rim tiles of a dense ball while the chip
+        # idles); with the policy field set such a tile is composited by many jobs over shares of its list (+ one more
+        # launch).  Like the long segments: fg_stbin_count reports the longest tile list, a shape that showed one beyond
+        # `heavy_tile_len` runs with the field set for its next `heavy_cooldown` calls.
+        # FG_HEAVY_TILES = auto (default) | always | never.
+        self.heavy_tiles = e.get("FG_HEAVY_TILES", "auto")
+        if self.heavy_tiles not in ("auto", "always", "never"):
+            raise ValueError(f"FG_HEAVY_TILES={self.heavy_tiles!r}: auto | always | never")
+        self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "3072"))
+        self.heavy_cooldown = 64
+        self.heavy_shapes = {}
+        self.heavy_calls = 0  # raster steps planned with heavy tiles on
+        self._policy_heavy = None
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -181,9 +195,17 @@ class RasterContext:
         # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
         self.color_grad_sink = None
 
-    def cfg(self) -> int:
-        """Address of the launch policy (the `const fg_raster_config*` argument)."""
-        return self.policy.ptr()
+    def cfg(self, heavy: bool = False) -> int:
+        """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
+        ``heavy_tiles`` set (unless the policy sets it itself)."""
+        if not heavy or self.policy.heavy_tiles > 0:
+            return self.policy.ptr()
+        src = bytes(self.policy)  # (the policy may have been replaced or changed in place since the copy was made)
+        if self._policy_heavy is None or self._policy_heavy[0] != src or self._policy_heavy[1].heavy_tiles != self.heavy_tile_len:
+            copy = type(self.policy).from_buffer_copy(self.policy)
+            copy.heavy_tiles = self.heavy_tile_len
+            self._policy_heavy = (src, copy)
+        return self._policy_heavy[1].ptr()
 
 
 _default_context: Optional[RasterContext] = None
@@ -420,25 +442,24 @@ _count_ring_stream = [None] * _COUNT_RING  # the stream the store into slot i wa
 
 
 def _count_slot():
-    """A slot of two pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
-    segment (fg_stbin_count only; stays -1 otherwise)."""
+    """A slot of four pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
+    segment, [2] the longest tile list (fg_stbin_count only; they stay -1 otherwise), [3] unused."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
         if _count_ring is None:
-            _count_ring = torch.empty(2 * _COUNT_RING, dtype=torch.int64, pin_memory=True)
+            _count_ring = torch.empty(4 * _COUNT_RING, dtype=torch.int64, pin_memory=True)
             _count_ring_np = _count_ring.numpy()
         i = _count_ring_next
         _count_ring_next = (i + 1) % _COUNT_RING
-    _count_ring_np[2 * i] = -1
-    _count_ring_np[2 * i + 1] = -1
+    _count_ring_np[4 * i : 4 * i + 4] = -1
     _count_ring_stream[i] = torch.cuda.current_stream()
-    return i, _count_ring.data_ptr() + 16 * i
+    return i, _count_ring.data_ptr() + 32 * i
 
 
 def _poll_count(i: int, word: int = 0) -> int:
     """Spin on a word of ring slot i until the kernel's system-scope store arrives (it does while the GPU is
     still busy with the emission and the tile sort: the wait is microseconds).  No event in the stream."""
-    a, j = _count_ring_np, 2 * i + word
+    a, j = _count_ring_np, 4 * i + word
     v = int(a[j])
     if v >= 0:
         return v
@@ -599,28 +620,31 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list):
+def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list, cfgp=None):
     """Floats of the forward's compositing checkpoints for the backward's list shares; 0 = the step does without
     (off for this size / config, or beyond the context's budget)."""
     n_ck = int(_lib.load().fg_raster_seg_ckpt_floats(int(channels), int(width), int(height), int(tile_size), int(n_list),
-                                                     rctx.cfg()))  # fmt: skip
+                                                     cfgp if cfgp is not None else rctx.cfg()))  # fmt: skip
     # (64 bytes per list entry of CAPACITY -- 0.4 GB at 6M entries -- held from forward to backward: beyond the
     # context's budget the backward runs without list shares, i.e. as pixel-strip jobs)
     return n_ck if n_ck > 0 and 4 * n_ck <= rctx.seg_ckpt_budget_bytes else 0
 
 
-def _plan_job_lists(rctx, raster_hint, n_list, dev):
-    """(jobs[2, words], bwd_list_shares, key) for fg_stbin_fill_jobs, or None when the raster launches of this size /
-    config take no lists.  ``key`` is what _RasterSplats.forward compares before it trusts the lists."""
+def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False):
+    """(jobs[2, words], bwd_list_shares, key, cfg) for fg_stbin_fill_jobs, or None when the raster launches of this size /
+    config take no lists.  ``key`` is what _RasterSplats.forward compares before it trusts the lists; ``cfg`` the address
+    of the launch policy they were planned with (``heavy``: heavy tiles on), which both raster calls must be given."""
     if raster_hint is None:
         return None
     channels, width, height = (int(v) for v in raster_hint)
-    words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, rctx.cfg()))
+    cfgp = rctx.cfg(heavy)
+    words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
-    shares = _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, n_list) > 0
+    shares = _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, n_list, cfgp) > 0
     jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
-    return jobs, shares, (rctx, channels, width, height, TILE_SIZE)
+    rctx.heavy_calls += int(heavy and shares)
+    return jobs, shares, (rctx, channels, width, height, TILE_SIZE), cfgp
 
 
 def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defer, want_keys, dev, raster_hint=None):
@@ -651,11 +675,12 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
         flags = _lib.STBIN_LONG_SEGMENTS if long_mode else 0
         rctx.long_calls += int(long_mode)
-        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev) if rctx.jobs_in_fill else None
+        heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
+        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy) if rctx.jobs_in_fill else None
         if prebuilt is None:
             _call(abi + "_fill", *args, flags, _stream(), stage="fg_bin_emit_sort_capacity")
         else:
-            jobs, shares, cfgp = prebuilt[0], prebuilt[1], rctx.cfg()
+            jobs, shares, cfgp = prebuilt[0], prebuilt[1], prebuilt[3]
             _call(abi + "_fill_jobs", *args, int(raster_hint[1]), int(raster_hint[2]), TILE_SIZE, _ptr(jobs[0]),
                   _ptr(jobs[1]), int(shares), cfgp, flags, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
         offsets._fg_jobs = prebuilt  # (for _RasterSplats.forward; None: it builds the lists itself)
@@ -692,6 +717,14 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
                 rctx.long_shapes[lkey] -= 1
                 if rctx.long_shapes[lkey] <= 0:
                     del rctx.long_shapes[lkey]
+            if _poll_count(count_slot, 2) > rctx.heavy_tile_len:
+                if lkey not in rctx.heavy_shapes and len(rctx.heavy_shapes) >= 256:
+                    rctx.heavy_shapes.pop(next(iter(rctx.heavy_shapes)))
+                rctx.heavy_shapes[lkey] = rctx.heavy_cooldown
+            elif lkey in rctx.heavy_shapes:
+                rctx.heavy_shapes[lkey] -= 1
+                if rctx.heavy_shapes[lkey] <= 0:
+                    del rctx.heavy_shapes[lkey]
         else:
             ready.synchronize()
             n_isects = int(count_host[0])
@@ -1155,13 +1188,18 @@ class _RasterSplats(torch.autograd.Function):
         last_ids = torch.empty(height, width, dtype=torch.int32, device=dev)
         composite = background is not None or n_clamp > 0
         clamp_mask = torch.empty(height, width, dtype=torch.uint8, device=dev) if n_clamp > 0 else None
-        # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches
-        cfgp = ctx.rctx.cfg()
+        # job lists (content-aware job sizes of the mixed launches); 0 words = classic launches.  The launch policy is
+        # the one the lists bin_tiles left were planned with (heavy tiles on or off), else the context's
+        prebuilt = getattr(tile_offsets, "_fg_jobs", None)
+        key = (ctx.rctx, int(channels), int(width), int(height), int(tile_size))
+        if prebuilt is not None and prebuilt[2] != key:
+            prebuilt = None
+        cfgp = prebuilt[3] if prebuilt is not None else ctx.rctx.cfg()
         words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size), cfgp))
         jobs = seg_ckpt = live = v_splats = None
         if words > 0:
             # list segments of the backward: per-pixel compositing checkpoints written by the forward
-            n_ck = _seg_ckpt_floats(ctx.rctx, channels, width, height, tile_size, flatten_ids.numel())
+            n_ck = _seg_ckpt_floats(ctx.rctx, channels, width, height, tile_size, flatten_ids.numel(), cfgp)
             if n_ck > 0:
                 seg_ckpt = torch.empty(n_ck, dtype=torch.float32, device=dev)
             # liveness of every (list entry, strip) pair, noted by the forward for the backward
@@ -1171,11 +1209,12 @@ class _RasterSplats(torch.autograd.Function):
             if ctx.rctx.fill_in_forward and expect_backward:
                 v_splats = torch.empty(splats.shape[0], SPLAT_FLOATS, dtype=torch.float32, device=dev)
             # job lists: the ones fg_stbin_fill_jobs built for exactly this call, or a launch of our own
-            prebuilt = getattr(tile_offsets, "_fg_jobs", None)
-            key = (ctx.rctx, int(channels), int(width), int(height), int(tile_size))
-            if prebuilt is not None and prebuilt[1] == (seg_ckpt is not None) and prebuilt[2] == key:
+            if prebuilt is not None and prebuilt[1] == (seg_ckpt is not None):
                 jobs = prebuilt[0]
             else:
+                if prebuilt is not None:  # (planned with list shares, run without: the context's own policy again)
+                    cfgp = ctx.rctx.cfg()
+                    words = int(_lib.load().fg_raster_jobs_words(int(width), int(height), int(tile_size), cfgp))
                 jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
                 _call("fg_raster_build_jobs", width, height, tile_size, _ptr(tile_offsets), _ptr(jobs[0]), _ptr(jobs[1]),
                       int(seg_ckpt is not None), cfgp, _stream())  # fmt: skip
@@ -1194,6 +1233,7 @@ class _RasterSplats(torch.autograd.Function):
         ctx.save_for_backward(splats, tile_offsets, flatten_ids, alphas, last_ids, background, clamp_mask, seg_ckpt,
                               render if seg_ckpt is not None else None, live)  # fmt: skip
         ctx.jobs_bwd = jobs[1] if jobs is not None else None
+        ctx.cfgp = cfgp
         ctx.v_splats_zeroed = v_splats  # consumed by the first backward; a second one fills its own
         ctx.set_materialize_grads(False)  # an unused alpha / render must not cost a zero-fill launch
         ctx.composite = (composite, int(n_clamp))

@@ -150,8 +150,9 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * 6 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
  * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
- * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, TWO words with
- * system scope (pinned host memory): count_out[0] the list length, count_out[1] the longest supertile segment
+ * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, THREE words with
+ * system scope (pinned host memory): count_out[0] the list length, count_out[2] the longest tile list (a host
+ * turns fg_raster_config::heavy_tiles on from it), count_out[1] the longest supertile segment
  * (segments beyond 7936 elements are sorted by one workgroup through global memory -- correct, slow -- unless
  * fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS, see below).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
@@ -243,6 +244,13 @@ typedef struct fg_raster_config {
                               band no longer sets the launch time -- when the heaviest equal band is more than 15% above
                               the mean; 0 = equal rows always; -1 / 1 = default; p >= 100: the threshold in percent of
                               the mean (100 = always by cost) */
+  int32_t heavy_tiles;     /* forward, job lists + list segments (ABI 7): a tile whose list is longer than this many entries
+                              is walked serially for its first 2048 entries only; if pixels are still open there, the rest
+                              of the list is composited by MANY jobs over shares of it -- every 64-entry batch by itself
+                              -- and one combining pass per strip (two more launches) instead of four serial walks; the
+                              backward gives such a tile up to 64 shares.  For scenes with unsaturated lists of thousands
+                              of entries (a host turns it on when fg_stbin_count's count_out[2] says so); not bit-identical
+                              to the serial walk (1e-7 relative).  <= 0 = off (default); values below 2560 mean 2560 */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 

@@ -528,6 +528,7 @@ def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size
         if ctx.binning != "supertile" or not ctx.jobs_in_fill:
             pytest.skip("the environment selects another path")
         ctx.seg_ckpt_budget_bytes = budget_mb << 20
+        ctx.heavy_tiles = "never"  # (the heavy tiles' two extra lists are filled in atomic order: compared as images, below)
         with ops.use(ctx):
             for _ in range(2):  # exact, then speculative
                 _, ids, offs = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False,
@@ -536,7 +537,7 @@ def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size
                 if words == 0:
                     assert offs._fg_jobs is None
                     continue
-                jobs, shares, key = offs._fg_jobs
+                jobs, shares, key, _cfgp = offs._fg_jobs
                 assert key == (ctx, 3, W, H, 16) and jobs.shape == (2, words)
                 assert shares == (budget_mb > 0 and int(_lib.load().fg_raster_seg_ckpt_floats(3, W, H, 16, ids.numel(), ctx.cfg())) > 0)
                 ref = torch.zeros_like(jobs)
@@ -1315,6 +1316,86 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
     diff = {k: rel_l2(outs[0][1][k], outs[1][1][k]) for k in raw}
     print("share jobs vs whole-list walk (composite epilogue), rel-L2:", {k: f"{v:.1e}" for k, v in diff.items()})
     assert all(v < 1e-5 for v in diff.values()), diff
+
+
+def test_clustered_1m_scene_lists_equal_the_oracles_through_the_long_segment_sort(monkeypatch):
+    """80% of a million Gaussians in a ball of extent 0.2 at 1920 x 1080 (scripts/clustered_check.py: supertile
+    segments of 16 000 ... 158 000 elements, the longest tile list 111 000 entries): csrc/stbin.hip with the long
+    segments' sample sort, fed the REFERENCE's rectangles (the radius boxes of the oracle's projection), against the
+    oracle's (tile | depth bits)-sorted lists: `torch.equal` ids and ranges."""
+    sc = synthetic_scene(1_000_000, 1920, 1080, n_views=1, sh_degree=3, seed=42)
+    sc.means[:800_000] *= 0.1
+    W, H = sc.width, sc.height
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    ref = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], W, H)
+    _, keys_s, vals_s = O.isect_tiles(ref.means2d, ref.radii, ref.depths, 16, tw, th, sort=True)
+    offs_ref = O.isect_offsets(keys_s, tw * th)
+    x0, y0, x1, y1 = O.tile_rects(ref.means2d, ref.radii, 16, tw, th)
+    rects = _pack_rects(x0, y0, x1 - x0, y1 - y0).to(DEV)
+    keys = ref.depths.float().contiguous().view(torch.int32).clone()
+    keys[ref.radii <= 0] = -1
+    N = sc.means.shape[0]
+    z = torch.zeros(N, device=DEV)
+    args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
+    ctx = ops.RasterContext()
+    if ctx.binning != "supertile":
+        pytest.skip("the environment selects another binning path")
+    ctx.long_segments = "always"
+    with ops.use(ctx):
+        for _ in range(2):  # exact capacity, then speculative
+            _, ids, offs = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
+            assert torch.equal(offs.cpu(), offs_ref)
+            assert torch.equal(ids.cpu(), vals_s)
+    lens = torch.diff(offs_ref)
+    assert int(lens.max()) > 100_000 and ctx.long_calls == 2
+
+
+@pytest.mark.parametrize("bg", [False, True])
+def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(bg, monkeypatch):
+    """fg_raster_config::heavy_tiles: tiles with lists beyond the threshold are composited by local jobs over shares
+    of the list (every 64-entry batch by itself) + one combine job per strip in a second launch, and get up to 64
+    shares in the backward.  Two clusters -- an opaque one (pixels saturate within a few hundred entries: the combine
+    job walks those batches itself) and a faint one (lists of thousands that never saturate: every batch taken whole)
+    -- against the oracle (lists, image, every gradient at the bar) and against the serial walk (1e-6; last_ids equal
+    but for knife-edge pixels)."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = synthetic_scene(60_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    sc.means[:20_000] = sc.means[:20_000] * 0.1 + torch.tensor([-0.9, 0.3, 0.0])  # opaque cluster
+    sc.means[20_000:40_000] = sc.means[20_000:40_000] * 0.1 + torch.tensor([0.8, -0.2, 0.0])  # faint cluster
+    sc.opacities[20_000:40_000] *= 0.04
+    ctx = ops.default_context
+    if int(_lib.load().fg_raster_jobs_words(1920, 1080, 16, ctx.cfg())) == 0 or ctx.seg_ckpt_budget_bytes <= 0:
+        pytest.skip("classic launches / no list shares in this environment")
+    monkeypatch.setattr(ctx, "heavy_tile_len", 1024)
+    monkeypatch.setattr(ctx, "_policy_heavy", None)
+    outs = {}
+    for mode in ("always", "never"):
+        monkeypatch.setattr(ctx, "heavy_tiles", mode)
+        calls = ctx.heavy_calls
+        if not bg:
+            ref_in, gpu_in, o0, o1 = _oracle_full_res(sc, 1, "RGB", 3)
+            lens = torch.diff(o1[2]["raster_isect_offsets"].reshape(-1))
+            assert int(lens.max()) > 4096 and int((lens > 1024).sum()) >= 8
+            _assert_full_parity(ref_in, gpu_in, o0, o1, REL_TOL)
+            outs[mode] = (o1[0].detach(), o1[1].detach(), o1[2]["last_ids"], {k: v.grad for k, v in gpu_in.items()})
+        else:  # the composite epilogue in the combine jobs, its prologue in the shares of the backward
+            raw = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(),
+                       opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                       features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+            vr = torch.randn(1, 1080, 1920, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+            r, a, info = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                t["features_rest"], sc.viewmats[1:2].to(DEV), sc.Ks[1:2].to(DEV), 1920, 1080, 3,
+                                                background=torch.tensor([0.3, 0.9, 0.1], device=DEV), clamp=True, absgrad=True)  # fmt: skip
+            ((r * vr).sum() + a.sum()).backward()
+            outs[mode] = (r.detach(), a.detach(), info["last_ids"], {k: v.grad for k, v in t.items()})
+        assert (ctx.heavy_calls > calls) == (mode == "always")
+    (r1, a1, l1, g1), (r0, a0, l0, g0) = outs["always"], outs["never"]
+    assert rel_err(r1, r0) < 2e-6 and rel_err(a1, a0) < 2e-6
+    assert last_ids_agree(l1, l0)
+    for k in g1:
+        assert rel_l2(g1[k], g0[k]) < 1e-5, k
 
 
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
