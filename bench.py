@@ -62,6 +62,12 @@ def parse(argv=None):
                     help="HIP events in the timed region: around every C-ABI call, only around the dominant kernel "
                          "(the stage table then comes from an untimed pass before it), or none")
     ap.add_argument("--fixed-view", action="store_true", help="render view `rank` every step instead of cycling the ring")
+    ap.add_argument("--layout", type=str, default="uniform",
+                    help="uniform (the headline's U([-2,2]^3) cloud) | clustered:<frac>:<extent> -- that fraction of the Gaussians "
+                         "pulled into a ball of that extent at the centre (captured-scene-like: lists of thousands of entries, "
+                         "saturated and unsaturated; scripts/clustered_check.py).  The default run also measures two clustered "
+                         "layouts in child processes and reports them under `clustered_layouts`; the headline stays the uniform scene.")
+    ap.add_argument("--no-clustered", action="store_true", help="skip the clustered-layout child runs")
     ap.add_argument("--cpu-crop", type=str, default="480x272")  # ~4 s of oracle time per run on the GPU box
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the faster of 8 and 32 host threads")
     return ap.parse_args(argv)
@@ -221,6 +227,18 @@ def pmc_valu(stage, workload_key):
     return None if rec is None else rec.get("valu_wave_instr_per_launch")
 
 
+def isa_class_mix(stage):
+    """Instruction-class shares of `stage`'s kernel (profiles/rNN_isa_class_mix.json, scripts/isa_class_mix.py), or None."""
+    for fname in ("r04_isa_class_mix.json",):
+        path = os.path.join(ROOT, "profiles", fname)
+        if os.path.exists(path):
+            rec = json.load(open(path))
+            k = rec["kernels"].get(stage)
+            if k is not None:
+                return dict(k, cost_clocks=rec["cost_clocks"], source_file=f"profiles/{fname}")
+    return None
+
+
 def _rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
@@ -287,7 +305,6 @@ def _hip_parity(scene, view, K, cw, ch, sh_degree, vr, r_ref, ins_ref, info_ref)
         "psnr_hip_vs_oracle_db": 200.0 if mse == 0 else min(200.0, -10.0 * math.log10(mse)),
         # info["flatten_ids"] is the reference's radius-box list (rebuilt on demand); the compositing walks the
         # footprint lists info["raster_flatten_ids"], which info["last_ids"] indexes
-        "lists_bit_exact": bool(torch.equal(ginfo["flatten_ids"].cpu(), info_ref["flatten_ids"])),
         "reference_lists_bit_exact": bool(torch.equal(ginfo["flatten_ids"].cpu(), info_ref["flatten_ids"])),
         "raster_lists_order_preserving_subsequence_of_reference": sub_ok,
         "raster_list_entries": n_walked,
@@ -397,6 +414,11 @@ def graph_only(args):
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
+    if args.layout != "uniform":
+        kind, frac, extent = args.layout.split(":")
+        if kind != "clustered":
+            raise SystemExit(f"--layout {args.layout!r}: uniform | clustered:<frac>:<extent>")
+        scene.means[: int(float(frac) * args.n_gauss)] *= float(extent) / 2.0
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)
@@ -471,6 +493,11 @@ def main(argv=None):
             dist.init_process_group(backend, timeout=tmo)
 
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
+    if args.layout != "uniform":
+        kind, frac, extent = args.layout.split(":")
+        if kind != "clustered":
+            raise SystemExit(f"--layout {args.layout!r}: uniform | clustered:<frac>:<extent>")
+        scene.means[: int(float(frac) * args.n_gauss)] *= float(extent) / 2.0
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)  # flat parameter + flat gradient buffers
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)  # all 8 poses resident
@@ -651,6 +678,12 @@ def main(argv=None):
         "launch_counts": "I, V of the last timed step's view; duration averaged over the views of the timed region",
     }
     roof["frac"] = roof["achieved"] / roof["peak"]
+    if dom in ("fg_raster_bwd", "fg_raster_fwd"):
+        # the same figure on the bytes of the lists this library actually walks (I_raster entries: the footprint
+        # rectangles drop the reference's dead (splat, tile) pairs) -- the contract's `frac` prices the reference's I
+        walked = algorithmic_bytes(N, V, I_raster, P, T, k, p)[dom]
+        roof["algorithmic_bytes_on_walked_lists"] = walked
+        roof["frac_on_walked_lists"] = walked / (stages[dom] * 1e-3) / 1e9 / HBM_PEAK_GBS
     if no_events:
         roof = {"bound": "hbm", "kernel": dom, "note": "--stage-events none: no kernel was timed"}
         stages = {}
@@ -674,6 +707,19 @@ def main(argv=None):
             issue[st_name] = {"valu_wave_instr": vi, "avg_ms": stages[st_name],
                               "achieved_G_instr_per_s": rate / 1e9, "peak_G_instr_per_s": peak / 1e9,
                               "frac": rate / peak, "clocks_per_instr_per_simd": 1024 * 2.4e9 / rate}  # fmt: skip
+            mix = isa_class_mix(st_name)
+            if mix is not None:
+                # the cost-weighted floor: the counter's instruction total x the kernel's class mix x the measured cost
+                # of each class (profiles/r01_valu_issue_rates.md), spread over the chip's 1024 SIMDs at 2.4 GHz
+                floor_ms = vi * mix["weighted_clocks_per_valu_instr"] / (1024 * 2.4e9) * 1e3
+                issue[st_name]["cost_weighted_floor"] = {
+                    "floor_ms": floor_ms, "floor_over_measured": floor_ms / stages[st_name],
+                    "weighted_clocks_per_instr": mix["weighted_clocks_per_valu_instr"],
+                    "class_shares": mix["shares"], "class_cost_clocks": mix["cost_clocks"],
+                    "class_counts_static": {c: mix[c] for c in ("full", "half", "quarter")},
+                    "note": "class shares = every vector instruction of the kernel's ISA counted once (static, "
+                            "scripts/isa_class_mix.py -> " + mix["source_file"] + "); the instruction TOTAL is the hardware counter's",
+                }
     if dom in issue and not no_events:
         roof["valu_frac"] = issue[dom]["frac"]
         roof["valu_wave_instr_per_launch"] = issue[dom]["valu_wave_instr"]
@@ -727,6 +773,7 @@ def main(argv=None):
             "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank per step, "
             + ("view = rank (fixed)" if args.fixed_view else f"view = (rank + step) mod {N_VIEWS} around the 8-view ring")
             + ", fwd+bwd, RGB, absgrad" + (f", {'RCCL' if backend == 'nccl' else backend} gradient exchange ({exchange})" if world > 1 else ""),
+            "layout": args.layout,
             "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
             "I_raster": I_raster,
             "I_note": "I = tile intersections of the reference algorithm (radius-box rectangles; the formulas of SURVEY "
@@ -741,6 +788,9 @@ def main(argv=None):
             }[ops.default_context.binning] + f" (the 64-bit-key sort of the SURVEY formula would be {p} passes over I)",
             "parallelism": f"view-dp{world}",
             "list_capacity_redos_in_timed_region": redos,
+            "longest_tile_list": int((info["raster_isect_offsets"].reshape(-1)[1:] - info["raster_isect_offsets"].reshape(-1)[:-1]).max()),
+            "long_segment_calls": ops.default_context.long_calls,
+            "heavy_tile_steps": ops.default_context.heavy_calls,
             "untimed_steps_before_timed_region": {"warmup": args.warmup, "stage_pass": stage_steps, "settle": settle_steps,
                                                   "order": "warm-up, settle (no host sync inside), stage pass, shorter settle, fence, timed region"},
         },
@@ -748,6 +798,8 @@ def main(argv=None):
         "vector_issue_roofline": issue,
         "measured_hbm_traffic_by_stage": hbm_stages,
         "hip_event_times": event_times,
+        # SURVEY section 8d's protocol figure (hipEvent pairs around fwd and bwd, median), beside the wall-clock `value`
+        "hip_event_mpix_per_s": world * event_times["mpix_per_s_per_gpu_from_median"],
         "whole_step": {
             # headline: the bytes THIS path needs (SURVEY §8d total without the 24 p I term of a
             # 64-bit-key sort it does not run)
@@ -803,6 +855,25 @@ def main(argv=None):
             out["graphed"] = json.loads(res.stdout.strip().splitlines()[-1])
         except Exception as e:
             out["graphed"] = {"error": repr(e)[:200]}
+    if world == 1 and rank == 0 and args.layout == "uniform" and not args.no_clustered and not under_profiler():
+        # the same measurement on two clustered layouts (child processes; the headline above stays the uniform scene):
+        # what the path does on captured-scene-like content -- long lists, saturated and not -- and which machinery ran
+        import subprocess
+
+        out["clustered_layouts"] = {}
+        for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2"):
+            cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "30", "--warmup", "10", "--settle-s",
+                   "0.3", "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
+                   "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
+            try:
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+                c = json.loads(res.stdout.strip().splitlines()[-1])
+                out["clustered_layouts"][lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"], "stage_ms": c["stage_ms"],
+                                                 "I_raster": c["config"]["I_raster"], "longest_tile_list": c["config"].get("longest_tile_list"),
+                                                 "long_segment_calls": c["config"].get("long_segment_calls"),
+                                                 "heavy_tile_steps": c["config"].get("heavy_tile_steps")}  # fmt: skip
+            except Exception as e:
+                out["clustered_layouts"][lay] = {"error": repr(e)[:200]}
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)

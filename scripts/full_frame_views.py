@@ -15,7 +15,7 @@ worst = {}
 for view in range(bench.N_VIEWS):
     r = bench.cpu_full_frame(scene, view, 3)
     g = r["grad_rel_l2_hip_vs_oracle"]
-    print(json.dumps({"view": view, "psnr_db": round(r["psnr_hip_vs_oracle_db"], 1), "lists_bit_exact": r["lists_bit_exact"],
+    print(json.dumps({"view": view, "psnr_db": round(r["psnr_hip_vs_oracle_db"], 1), "reference_lists_bit_exact": r["reference_lists_bit_exact"],
                       **{k: float(f"{v:.3g}") for k, v in g.items()}}), flush=True)
     for k, v in g.items():
         worst[k] = max(worst.get(k, 0.0), v)
