@@ -79,6 +79,9 @@ SIGNATURES = {
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                            c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P]),
     "fg_sh_grad_accumulate": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P]),
+    "fg_sh_grad_accumulate_split": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P, P]),
+    "fg_preprocess_raw_bwd_factored": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
+                                               c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
     "fg_densify_flags": (c_int, [c_int, c_int, c_float, c_float, c_float, c_float, c_float, c_float, c_float, P, P, P,
                                  P, P, P, P]),
     "fg_densify_map": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, P]),

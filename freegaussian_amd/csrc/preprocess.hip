@@ -620,10 +620,12 @@ int launch_preprocess_bwd(int N, RawForm raw, float* v_d_quats, float* v_d_scale
   // v_colors may be null only in the factored form (SH colours, v_rgb given instead)
   if ((fl.n_color > 0 && (!colors || (!v_colors && !(v_rgb && sh_degree >= 0)))) || (n_extra > 0 && !v_extra))
     return FG_ERR_INVALID_ARG;
-  if (v_rgb && (sh_degree < 0 || raw.enabled)) return FG_ERR_UNSUPPORTED;
+  if (v_rgb && sh_degree < 0) return FG_ERR_UNSUPPORTED;
   if (v_rgb && v_rgb_floats != 3 && v_rgb_floats != 6) return FG_ERR_INVALID_ARG;
   if (raw.enabled) {
-    if (sh_degree < 0 || (k_stored > 1 && (!raw.features_rest || !v_features_rest))) return FG_ERR_INVALID_ARG;
+    // (factored form: neither coefficient gradient is written -- v_colors and v_features_rest are both null)
+    if (sh_degree < 0 || (k_stored > 1 && (!raw.features_rest || (!v_features_rest && !v_rgb)))) return FG_ERR_INVALID_ARG;
+    if (v_rgb && (v_colors || v_features_rest)) return FG_ERR_INVALID_ARG;
     if ((raw.d_quats != nullptr) != (v_d_quats != nullptr) || (raw.d_scales != nullptr) != (v_d_scales != nullptr))
       return FG_ERR_INVALID_ARG;
   }
@@ -702,6 +704,21 @@ extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* qua
                                k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
                                v_splats, v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats,
                                v_log_scales, v_opacity_logits, v_features_dc, v_extra, sh_jac, stream);
+}
+
+extern "C" int fg_preprocess_raw_bwd_factored(
+    int N, const float* means, const float* quats, const float* d_quats, const float* log_scales, const float* d_scales,
+    const float* opacity_logits, const float* features_dc, const float* features_rest, int sh_degree, int k_stored,
+    int with_depth, int n_extra, const float* viewmat, const float* K, int width, int height, float eps2d, int antialiased,
+    const int32_t* radii, const float* v_splats, const float* v_means2d, int v_means2d_stride, const float* v_depths,
+    const float* v_conics, float* v_means, float* v_quats, float* v_d_quats, float* v_log_scales, float* v_d_scales,
+    float* v_opacity_logits, float* v_rgb, int v_rgb_floats, float* v_extra, const float* sh_jac, fg_stream_t stream) {
+  if (!v_rgb) return FG_ERR_INVALID_ARG;
+  return launch_preprocess_bwd(N, RawForm{1, d_quats, d_scales, features_rest}, v_d_quats, v_d_scales, nullptr, v_rgb,
+                               v_rgb_floats, means, quats, log_scales, opacity_logits, features_dc, sh_degree, k_stored, 3,
+                               with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii, v_splats,
+                               v_means2d, v_means2d_stride, v_depths, v_conics, v_means, v_quats, v_log_scales,
+                               v_opacity_logits, nullptr, v_extra, sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, const float* scales,

@@ -129,7 +129,7 @@ sh_bwd_kernel(int N, int degree, int k_stored, const float* __restrict__ means, 
 __global__ void __launch_bounds__(BLOCK)
 sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const float* __restrict__ means,
                           const float* __restrict__ payload, int64_t view_stride, int payload_floats, float scale,
-                          float* __restrict__ v_coeffs) {
+                          float* __restrict__ v_coeffs, float* __restrict__ v_rest) {
   __shared__ float lds[BLOCK * ROW];
   const int row0 = blockIdx.x * BLOCK;
   const int nrows = min(BLOCK, N - row0);
@@ -171,14 +171,20 @@ sh_grad_accumulate_kernel(int N, int n_views, int degree, int k_stored, const fl
 #pragma unroll
   for (int q = 0; q < 48; ++q) row[q] = acc[q] * scale;
   __syncthreads();
-  lds_to_slab_at(v_coeffs + (size_t)row0 * 3 * k_stored, lds, 0, nrows, 3 * k_stored, 48);
+  if (v_rest) {  // the model's layout: features_dc [N,3] and features_rest [N,k_stored - 1,3] as two arrays
+    lds_to_slab_at(v_coeffs + (size_t)row0 * 3, lds, 0, nrows, 3, 3);
+    if (k_stored > 1) lds_to_slab_at(v_rest + (size_t)row0 * 3 * (k_stored - 1), lds, 3, nrows, 3 * (k_stored - 1), 45);
+  } else {
+    lds_to_slab_at(v_coeffs + (size_t)row0 * 3 * k_stored, lds, 0, nrows, 3 * k_stored, 48);
+  }
 }
 
 }  // namespace
 
-extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
-                                     const float* payload, int64_t view_stride, int payload_floats, float scale,
-                                     float* v_coeffs, fg_stream_t stream) {
+namespace {
+int sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means, const float* payload,
+                       int64_t view_stride, int payload_floats, float scale, float* v_coeffs, float* v_rest,
+                       fg_stream_t stream) {
   if (N < 0 || n_views < 1 || sh_degree < 0 || sh_degree > 3 || k_stored < (sh_degree + 1) * (sh_degree + 1) ||
       k_stored > 16 || (payload_floats != 3 && payload_floats != 6) ||
       view_stride < (payload_floats == 3 ? (int64_t)3 * N + 3 : (int64_t)6 * N))
@@ -186,9 +192,25 @@ extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_st
   if (N == 0) return FG_OK;
   if ((payload_floats == 3 && !means) || !payload || !v_coeffs) return FG_ERR_INVALID_ARG;
   hipLaunchKernelGGL(sh_grad_accumulate_kernel, dim3((N + BLOCK - 1) / BLOCK), dim3(BLOCK), 0, fg_hip_stream(stream),
-                     N, n_views, sh_degree, k_stored, means, payload, view_stride, payload_floats, scale, v_coeffs);
+                     N, n_views, sh_degree, k_stored, means, payload, view_stride, payload_floats, scale, v_coeffs, v_rest);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
+}
+}  // namespace
+
+extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
+                                     const float* payload, int64_t view_stride, int payload_floats, float scale,
+                                     float* v_coeffs, fg_stream_t stream) {
+  return sh_grad_accumulate(N, n_views, sh_degree, k_stored, means, payload, view_stride, payload_floats, scale, v_coeffs,
+                            nullptr, stream);
+}
+
+extern "C" int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored, const float* means,
+                                           const float* payload, int64_t view_stride, int payload_floats, float scale,
+                                           float* v_features_dc, float* v_features_rest, fg_stream_t stream) {
+  if (k_stored > 1 && !v_features_rest) return FG_ERR_INVALID_ARG;
+  return sh_grad_accumulate(N, n_views, sh_degree, k_stored, means, payload, view_stride, payload_floats, scale,
+                            v_features_dc, v_features_rest ? v_features_rest : v_features_dc, stream);
 }
 
 extern "C" int fg_sh_fwd(int N, int degree, int k_stored, const float* means, const float* viewmat,

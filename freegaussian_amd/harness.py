@@ -91,12 +91,14 @@ def apply_schedules(opts, step: int, table: Optional[Dict[str, OptimSpec]] = Non
 
 def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.Tensor, step: int, table=None,
                grad_sync=None, num_train_data: Optional[int] = None, stats_sync=None, graphed=None,
-               mask: Optional[torch.Tensor] = None, metrics_every: int = 1) -> Dict[str, float]:  # fmt: skip
+               mask: Optional[torch.Tensor] = None, metrics_every: int = 1, dp=None) -> Dict[str, float]:  # fmt: skip
     """One iteration in the reference's callback order: step_cb -> get_outputs ->
     loss -> backward -> [view-DP gradient exchange] -> optimizers -> after_train_iter ->
     refinement_after every ``refine_every`` steps (freegaussian_model.py:575-590; needs
     ``num_train_data``, the number of training cameras, :416).  View-sharded DP: pass
-    ``grad_sync=viewdp.all_reduce_model_grads`` and ``stats_sync=viewdp.sync_densify_stats``.
+    ``dp=viewdp.ModelViewDP(model)`` (the factored exchange: colour gradients all-gathered as 12-24 B per Gaussian from
+    inside the backward, the rest one all-reduce of a flat buffer the gradients are views of) or
+    ``grad_sync=viewdp.all_reduce_model_grads`` (one all-reduce of everything), and ``stats_sync=viewdp.sync_densify_stats``.
     ``graphed``: a ``graphed.GraphedModelStep(model, main_loss)``: while the scheduled resolution is
     launch-bound (the reference's first 6000 steps at 1/4 and 1/2 resolution) get_outputs + loss + backward
     replay as one hipGraph; the rest of the step is unchanged.  ``mask`` [H,W,1]: the batch's optional mask
@@ -106,7 +108,7 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     the Gaussian count alone and the host runs ahead of the GPU."""
     model.step_cb(step)
     plain_loss = mask is None and gt_image.shape[-1] == 3 and not model.config.use_scale_regularization
-    if graphed is not None and plain_loss and graphed.applicable(camera):
+    if graphed is not None and dp is None and plain_loss and graphed.applicable(camera):
         # (no zero_grad: the replay refills the .grad tensors, which are static buffers of the graph)
         out, loss = graphed.step(camera, gt_image)
         gt = graphed.static["gt"]
@@ -115,12 +117,15 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
             graphed.release()  # grads of a graph that is no longer replayed must not be mistaken for fresh ones
         for o in opts.values():
             o.zero_grad(set_to_none=True)
-        out = model.get_outputs(camera)
-        batch = {"image": gt_image} if mask is None else {"image": gt_image, "mask": mask}
-        loss_dict = model.get_loss_dict(out, batch)
-        loss = loss_dict["main_loss"] + loss_dict["scale_reg"]
-        gt = model.composite_with_background(model.get_gt_img(gt_image), out["background"])
-        loss.backward()
+        import contextlib
+
+        with (dp.step() if dp is not None else contextlib.nullcontext()):  # (view-DP: the exchange runs on exit)
+            out = model.get_outputs(camera)
+            batch = {"image": gt_image} if mask is None else {"image": gt_image, "mask": mask}
+            loss_dict = model.get_loss_dict(out, batch)
+            loss = loss_dict["main_loss"] + loss_dict["scale_reg"]
+            gt = model.composite_with_background(model.get_gt_img(gt_image), out["background"])
+            loss.backward()
     if grad_sync is not None:
         grad_sync(model)
     apply_schedules(opts, step, table)

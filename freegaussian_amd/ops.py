@@ -1093,6 +1093,8 @@ class _PreprocessRaw(torch.autograd.Function):
         sh_jac = None
         if sh_degree >= 1 and ctx.rctx.sh_jacobian:
             sh_jac = torch.empty(N, _lib.SH_JAC_FLOATS, dtype=torch.float32, device=dev)
+        if ctx.rctx.color_grad_sink is not None:
+            ctx.rctx.color_grad_sink("view", viewmat, dev)  # (view-DP: the factored exchange prepares its payload)
         _call("fg_preprocess_raw_fwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
               _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, near, far, radius_clip, tile_size,
@@ -1126,7 +1128,7 @@ class _PreprocessRaw(torch.autograd.Function):
         if v_means2d is None:
             v_means2d = torch.zeros(N, 2, dtype=torch.float32, device=dev)
         v_means, v_quats, v_ls = _alloc_grad(means), _alloc_grad(quats), _alloc_grad(log_scales)
-        v_ol, v_dc, v_rest = _alloc_grad(opacity_logits), _alloc_grad(features_dc), _alloc_grad(features_rest)
+        v_ol = _alloc_grad(opacity_logits)
         v_dq = torch.empty_like(d_quats) if d_quats is not None else None
         v_ds = torch.empty_like(d_scales) if d_scales is not None else None
         v_extra = torch.empty_like(extra) if extra is not None else None
@@ -1135,6 +1137,22 @@ class _PreprocessRaw(torch.autograd.Function):
             m2_stride = v_means2d.stride(0)
         else:
             v_means2d, m2_stride = v_means2d.contiguous(), 2
+        color_grad_sink = ctx.rctx.color_grad_sink
+        if color_grad_sink is not None:
+            # factored form (viewdp.ModelViewDP): 12 / 24 B of colour gradient per Gaussian instead of the two coefficient
+            # gradients (12 + 180 B); features_dc.grad / features_rest.grad are filled by the exchange, not by autograd
+            v_rgb = color_grad_sink("alloc", N, dev, means)
+            _call("fg_preprocess_raw_bwd_factored", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales),
+                  _ptr(d_scales), _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored,
+                  int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, int(antialiased), _ptr(radii),
+                  _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
+                  _ptr(None if v_depths is None else v_depths.contiguous()),
+                  _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats), _ptr(v_dq),
+                  _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _ptr(sh_jac),
+                  _stream())  # fmt: skip
+            color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, k_stored)
+            return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, None, None, v_extra, None, None, None
+        v_dc, v_rest = _alloc_grad(features_dc), _alloc_grad(features_rest)
         _call("fg_preprocess_raw_bwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
               n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, int(antialiased), _ptr(radii),

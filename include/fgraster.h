@@ -462,6 +462,20 @@ int fg_preprocess_bwd_factored(int N, const float* means, const float* quats, co
 int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
                           const float* payload, int64_t view_stride, int payload_floats, float scale,
                           float* v_coeffs, fg_stream_t stream);
+/* The same exchange for the MODEL's parameter layout (ABI 7; freegaussian_model.py:187-196: features_dc [N,3] and
+ * features_rest [N,K-1,3] are two tensors, the other gradients come out of fg_preprocess_raw_bwd):
+ * fg_preprocess_raw_bwd_factored = fg_preprocess_raw_bwd that writes v_rgb[N,v_rgb_floats] instead of the two
+ * coefficient gradients; fg_sh_grad_accumulate_split rebuilds them from the gathered payloads into the two arrays. */
+int fg_preprocess_raw_bwd_factored(
+    int N, const float* means, const float* quats, const float* d_quats, const float* log_scales, const float* d_scales,
+    const float* opacity_logits, const float* features_dc, const float* features_rest, int sh_degree, int k_stored,
+    int with_depth, int n_extra, const float* viewmat, const float* K, int width, int height, float eps2d, int antialiased,
+    const int32_t* radii, const float* v_splats, const float* v_means2d, int v_means2d_stride, const float* v_depths,
+    const float* v_conics, float* v_means, float* v_quats, float* v_d_quats, float* v_log_scales, float* v_d_scales,
+    float* v_opacity_logits, float* v_rgb, int v_rgb_floats, float* v_extra, const float* sh_jac, fg_stream_t stream);
+int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored, const float* means,
+                                const float* payload, int64_t view_stride, int payload_floats, float scale,
+                                float* v_features_dc, float* v_features_rest, fg_stream_t stream);
 
 /* S1 in one pass: the densification statistics after_train_iter keeps (freegaussian_model.py:369-392), all in place:
  * for radii[i] > 0: xys_grad_norm[i] += |absgrad[i]| (absgrad [N,2]), vis_counts[i] += 1,

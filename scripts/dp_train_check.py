@@ -1,5 +1,5 @@
 """View-sharded DP training of FreeGaussianModel, W ranks (torchrun): ranks render different views,
-exchange gradients (viewdp.all_reduce_model_grads) and densification statistics
+exchange gradients (viewdp.ModelViewDP: the factored exchange; FG_DP_EXCHANGE=plain: viewdp.all_reduce_model_grads) and densification statistics
 (viewdp.sync_densify_stats) and must stay in lockstep -- same Gaussian count and bit-identical
 parameters after a run that includes refinements.  On a 1-GPU box: FG_BENCH_BACKEND=gloo."""
 import copy
@@ -25,7 +25,9 @@ dist.init_process_group(backend, **({"device_id": dev} if backend == "nccl" else
 W, H, n = 160, 96, 4000
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=7)
 torch.manual_seed(0)
-cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=10**9, refine_start=10,
+# FG_DP_WARM_UP = n: the deformation MLP is active from step n on (default: never) -- every rank then renders its own
+# deformed means (the factored exchange sends the view direction along) and the MLP gradients ride in the small all-reduce
+cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=int(os.environ.get("FG_DP_WARM_UP", 10**9)), refine_start=10,
                               refine_every=10, reset_alpha_every=30, densify_grad_thresh=1e-4, stop_screen_size_at=0,
                               sh_degree_interval=1)
 model = FreeGaussianModel(cfg, seed_points=sc.means)
@@ -53,10 +55,43 @@ with torch.no_grad():
     gts = {v: target.get_outputs(camera(v))["rgb"].clamp(0, 1) for v in range(8)}
 opts = Hn.build_optimizers(model)
 hist = []
+
+
+def grads_of_one_step(dp_obj, step):
+    """Gradients of every parameter after one exchanged forward + backward of this rank's view (no optimizer step)."""
+    import contextlib
+
+    for p in model.parameters():
+        p.grad = None
+    model.step_cb(step)
+    v = rank % 8
+    with (dp_obj.step() if dp_obj is not None else contextlib.nullcontext()):
+        out = model.get_outputs(camera(v))
+        Hn.main_loss(out["rgb"], gts[v]).backward()
+    if dp_obj is None:
+        viewdp.all_reduce_model_grads(model)
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+# the two exchanges on the same model state: same averaged gradients up to fp32 summation order
+probe_step = max(cfg.warm_up, 10)
+g_f, g_p = grads_of_one_step(viewdp.ModelViewDP(model), probe_step), grads_of_one_step(None, probe_step)
+worst = max(float((g_f[k] - g_p[k]).norm() / g_p[k].norm().clamp_min(1e-30)) for k in g_p)
+if rank == 0:
+    print(f"factored vs plain exchange, worst relative L2 over {len(g_p)} gradients: {worst:.2e}")
+assert set(g_f) == set(g_p) and worst < 1e-5, worst
+for p in model.parameters():
+    p.grad = None
+# FG_DP_EXCHANGE = factored (default: viewdp.ModelViewDP) | plain (one all-reduce of every gradient)
+exchange = os.environ.get("FG_DP_EXCHANGE", "factored")
+dp = viewdp.ModelViewDP(model) if exchange == "factored" else None
 for i in range(25):
     v = (i * world + rank) % 8  # this rank's view of the step
-    hist.append(Hn.train_step(model, opts, camera(v), gts[v], 10 + i, num_train_data=2,
-                              grad_sync=viewdp.all_reduce_model_grads, stats_sync=viewdp.sync_densify_stats))
+    hist.append(Hn.train_step(model, opts, camera(v), gts[v], 10 + i, num_train_data=2, dp=dp,
+                              grad_sync=None if dp is not None else viewdp.all_reduce_model_grads,
+                              stats_sync=viewdp.sync_densify_stats))
+if rank == 0 and dp is not None:
+    print("exchange bytes per rank in the last step:", dp.bytes_last_step)
 torch.cuda.synchronize()
 sig = torch.cat([torch.tensor([float(model.num_points)], device=dev)] +
                 [p.detach().double().sum().float().reshape(1) for p in model.parameters()])

@@ -1848,20 +1848,29 @@ def test_world_size_8_exchange_and_bench_launcher_over_gloo_on_one_gpu():
     assert "gloo" in line["exchange"]["backend"] and "gloo gradient exchange" in line["config"]["workload"]
 
 
-def test_view_dp_training_keeps_two_ranks_in_lockstep():
-    """FreeGaussianModel trained view-sharded on 2 ranks sharing this GPU (gloo): gradient exchange,
-    densification-statistics exchange and shared split samples keep the replicas bit-identical
-    through refinements (scripts/dp_train_check.py, child processes)."""
+@pytest.mark.parametrize("world,exchange,warm_up", [(2, "factored", None), (2, "factored", 12), (2, "plain", None), (8, "factored", 12)])
+def test_view_dp_training_keeps_the_ranks_in_lockstep(world, exchange, warm_up):
+    """FreeGaussianModel trained view-sharded on 2 / 8 ranks sharing this GPU (gloo): the gradient exchange --
+    viewdp.ModelViewDP's factored form (colour gradients all-gathered from inside the backward, the rest one all-reduce
+    of a flat buffer; with the deformation MLP active the view directions travel along and the MLP gradients ride in
+    the all-reduce) or the plain all-reduce --, the densification-statistics exchange and shared split samples keep the
+    replicas bit-identical through refinements; the two exchanges give the same gradients on the same model state
+    (scripts/dp_train_check.py, child processes)."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FG_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-           "127.0.0.1", "--master-port", "29534", os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
-    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=400)
+    env = dict(os.environ, FG_BENCH_BACKEND="gloo", FG_DP_EXCHANGE=exchange)
+    if warm_up is not None:
+        env["FG_DP_WARM_UP"] = str(warm_up)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
+           "127.0.0.1", "--master-port", str(29534 + world), os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "dp lockstep ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "factored vs plain exchange" in out.stdout
+    if exchange == "factored":
+        assert "all_gather_received" in out.stdout
 
 
 def test_graphed_raster_replays_equal_eager_steps_and_recovers_from_overflow():
