@@ -79,6 +79,9 @@ SIGNATURES = {
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                            c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P]),
     "fg_sh_grad_accumulate": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P]),
+    "fg_step_layout_query": (c_int, [P, P, P]),
+    "fg_step_fwd": (c_int, [P, P, P, P, P, P, P]),
+    "fg_step_bwd": (c_int, [P, P, P, P, P, P]),
     "fg_sh_grad_accumulate_split": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P, P]),
     "fg_preprocess_raw_bwd_factored": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                                c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, c_int, P, P, P]),
@@ -126,6 +129,39 @@ class RasterConfig(ctypes.Structure):
 
     def ptr(self) -> int:
         return ctypes.addressof(self)
+
+
+STEP_BUFFERS = ("radii", "means2d", "depths", "conics", "comp", "tiles", "splats", "depth_keys", "tile_rects", "sh_jac",
+                "tile_offsets", "list_offsets", "flatten_ids", "jobs", "live", "seg_ckpt", "v_splats", "render", "alphas",
+                "last_ids", "clamp_mask", "count_ws", "fill_ws")  # the FG_STEP_* enum of include/fgraster.h, in order
+STEP_BUFFER = {n: i for i, n in enumerate(STEP_BUFFERS)}
+
+
+class StepDesc(ctypes.Structure):
+    """``fg_step_desc``: field order = the header's."""
+
+    _fields_ = [(n, ctypes.c_int32) for n in (
+        "size", "N", "width", "height", "tile_size", "raw", "sh_degree", "k_stored", "n_color", "with_depth", "n_extra",
+        "antialiased", "n_clamp", "want_backward", "list_shares", "flags")] + [
+        (n, ctypes.c_float) for n in ("eps2d", "near_plane", "far_plane", "radius_clip")] + [("capacity", ctypes.c_int64)]  # fmt: skip
+
+
+class StepIO(ctypes.Structure):
+    """``fg_step_io``: device pointers as integers."""
+
+    _fields_ = [(n, ctypes.c_void_p) for n in (
+        "means", "quats", "d_quats", "scales", "d_scales", "opacities", "colors", "features_rest", "extra", "viewmat", "K",
+        "background", "count_out", "v_render", "v_alphas", "v_depths", "v_conics", "v_means", "v_quats", "v_d_quats",
+        "v_scales", "v_d_scales", "v_opacities", "v_colors", "v_features_rest", "v_extra", "v_rgb")] + [
+        ("v_rgb_floats", ctypes.c_int32), ("ev_raster_begin", ctypes.c_void_p), ("ev_raster_end", ctypes.c_void_p)]  # fmt: skip
+
+
+class StepLayout(ctypes.Structure):
+    """``fg_step_layout``."""
+
+    _fields_ = [("keep_bytes", ctypes.c_int64), ("tmp_bytes", ctypes.c_int64),
+                ("offset", ctypes.c_int64 * len(STEP_BUFFERS)), ("nbytes", ctypes.c_int64 * len(STEP_BUFFERS)),
+                ("jobs_words", ctypes.c_int64), ("seg_ckpt_floats", ctypes.c_int64), ("channels", ctypes.c_int32)]  # fmt: skip
 
 
 def load() -> ctypes.CDLL:

@@ -8,6 +8,7 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import ctypes
 import os
 import threading
 import time
@@ -185,6 +186,10 @@ class RasterContext:
         # fg_stbin_fill_jobs when the caller of bin_tiles says what will be rastered (raster_hint);
         # FG_JOBS_IN_FILL=0: by a launch of their own in front of the raster forward, as before ABI version 5.
         self.jobs_in_fill = e.get("FG_JOBS_IN_FILL", "1") != "0"
+        # One C-ABI call per direction (fg_step_fwd / fg_step_bwd) for calls in the default configuration on a shape whose
+        # list capacity is known; FG_STEP_CALLS=0: always the stage-wise calls (the same kernels, ~6 calls and ~20
+        # allocations per view instead of 2 and 2)
+        self.step_calls = e.get("FG_STEP_CALLS", "1") != "0"
         # Optional hook: maps an input tensor of the fused backward to the buffer its gradient should be
         # written into (e.g. a slice of a flat all-reduce buffer, viewdp.FlatGaussianParams.direct_grads()).
         # The kernels overwrite their outputs densely, so the buffer needs no zeroing.
@@ -620,6 +625,41 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
+def _note_list_length(rctx, key, n_isects: int) -> int:
+    """The list length of a call of shape ``key``: checked against the int32 index range and entered into the history the
+    next call's speculative capacity comes from."""
+    if n_isects >= 2**31:
+        raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
+    cap, recent_all = rctx.isect_capacity, rctx.isect_recent
+    if key not in cap and len(cap) >= 256:
+        old = next(iter(cap))  # densification changes N: do not grow for ever
+        cap.pop(old)
+        recent_all.pop(old, None)
+    recent = recent_all.setdefault(key, [])
+    recent.append(n_isects)
+    del recent[:-16]
+    cap[key] = list_capacity_for(recent)
+    return n_isects
+
+
+def _note_counts(rctx, lkey, key, count_slot) -> int:
+    """Wait for the three words fg_stbin_count stores into pinned host memory (list length, longest supertile segment,
+    longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
+    binning, the heavy-tile policy of the raster.  -> the list length."""
+    n_isects = _poll_count(count_slot)
+    for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
+                                          (2, rctx.heavy_tile_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
+        if _poll_count(count_slot, word) > limit:
+            if lkey not in shapes and len(shapes) >= 256:
+                shapes.pop(next(iter(shapes)))
+            shapes[lkey] = cooldown
+        elif lkey in shapes:
+            shapes[lkey] -= 1
+            if shapes[lkey] <= 0:
+                del shapes[lkey]
+    return _note_list_length(rctx, key, n_isects)
+
+
 def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list, cfgp=None):
     """Floats of the forward's compositing checkpoints for the backward's list shares; 0 = the step does without
     (off for this size / config, or beyond the context's budget)."""
@@ -708,36 +748,10 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
 
     def finish():
         if count_slot is not None:
-            n_isects = _poll_count(count_slot)
-            if _poll_count(count_slot, 1) > rctx.long_segment:
-                if lkey not in rctx.long_shapes and len(rctx.long_shapes) >= 256:
-                    rctx.long_shapes.pop(next(iter(rctx.long_shapes)))
-                rctx.long_shapes[lkey] = rctx.long_cooldown
-            elif lkey in rctx.long_shapes:
-                rctx.long_shapes[lkey] -= 1
-                if rctx.long_shapes[lkey] <= 0:
-                    del rctx.long_shapes[lkey]
-            if _poll_count(count_slot, 2) > rctx.heavy_tile_len:
-                if lkey not in rctx.heavy_shapes and len(rctx.heavy_shapes) >= 256:
-                    rctx.heavy_shapes.pop(next(iter(rctx.heavy_shapes)))
-                rctx.heavy_shapes[lkey] = rctx.heavy_cooldown
-            elif lkey in rctx.heavy_shapes:
-                rctx.heavy_shapes[lkey] -= 1
-                if rctx.heavy_shapes[lkey] <= 0:
-                    del rctx.heavy_shapes[lkey]
+            n_isects = _note_counts(rctx, lkey, key, count_slot)
         else:
             ready.synchronize()
-            n_isects = int(count_host[0])
-        if n_isects >= 2**31:
-            raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
-        if key not in _isect_capacity and len(_isect_capacity) >= 256:
-            old = next(iter(_isect_capacity))
-            _isect_capacity.pop(old)
-            _isect_recent.pop(old, None)
-        recent = _isect_recent.setdefault(key, [])
-        recent.append(n_isects)
-        del recent[:-16]
-        _isect_capacity[key] = list_capacity_for(recent)
+            n_isects = _note_list_length(rctx, key, int(count_host[0]))
         if capacity is not None and n_isects <= capacity:
             return keys_for(n_isects), flatten_ids[:n_isects], False
         if capacity is not None:
@@ -1321,6 +1335,217 @@ def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_o
     expect_backward = torch.is_grad_enabled() and (splats.requires_grad or means2d.requires_grad)
     return _RasterSplats.apply(splats, means2d, int(channels), int(width), int(height), int(tile_size), tile_offsets,
                                flatten_ids, bool(absgrad), background, int(n_clamp), expect_backward)  # fmt: skip
+
+
+# --------------------------------------------------------------------------------------------
+# The whole step of one view as ONE C-ABI call per direction (fg_step_fwd / fg_step_bwd)
+
+_STEP_PLANS: dict = {}
+
+
+def _step_plan(rctx, key):
+    """(desc, layout, cfg) of a step shape, cached: one layout query per shape / capacity / launch policy."""
+    plan = _STEP_PLANS.get(key)
+    if plan is None:
+        (dev, N, W, H, raw, sh_degree, k_stored, n_color, with_depth, n_extra, antialiased, n_clamp, want_backward,
+         list_shares, flags, capacity, eps2d, near, far, radius_clip, cfgp, _policy_bytes) = key  # fmt: skip
+        d = _lib.StepDesc()
+        d.size = ctypes.sizeof(_lib.StepDesc)
+        d.N, d.width, d.height, d.tile_size, d.raw, d.sh_degree, d.k_stored, d.n_color = N, W, H, TILE_SIZE, raw, sh_degree, k_stored, n_color
+        d.with_depth, d.n_extra, d.antialiased, d.n_clamp, d.want_backward, d.list_shares, d.flags = (
+            with_depth, n_extra, antialiased, n_clamp, want_backward, list_shares, flags)
+        d.eps2d, d.near_plane, d.far_plane, d.radius_clip, d.capacity = eps2d, near, far, radius_clip, capacity
+        L = _lib.StepLayout()
+        rc = _lib.load().fg_step_layout_query(ctypes.addressof(d), cfgp, ctypes.addressof(L))
+        plan = (d, L, rc)
+        if len(_STEP_PLANS) >= 512:
+            _STEP_PLANS.pop(next(iter(_STEP_PLANS)))
+        _STEP_PLANS[key] = plan
+    return plan
+
+
+def step_path_available(rctx, N, width, height, tile_size, dev) -> bool:
+    """Can this call go through fg_step_fwd / fg_step_bwd?  The default configuration on a shape whose list capacity is
+    known (the first call of a shape measures it through the stage-wise path); every knob that selects another binning
+    path, a stage timer over ALL stages, a colour-gradient sink (the factored exchange hooks in between the stages),
+    graph capture and FG_STEP_CALLS=0 take the stage-wise calls."""
+    if not rctx.step_calls or tile_size != TILE_SIZE or N <= 0:
+        return False
+    if (rctx.binning != "supertile" or not rctx.tight_rects or not rctx.direct_count or not rctx.jobs_in_fill
+            or rctx.overlap_pack or not rctx.speculative_binning or not rctx.fill_in_forward or not rctx.sh_jacobian
+            or rctx.static_capacity is not None or rctx.color_grad_sink is not None):
+        return False
+    st = rctx.stage_timer
+    if st is not None and (st.only is None or not set(st.only) <= {"fg_raster_fwd", "fg_raster_bwd"}):
+        return False
+    tile_w, tile_h = (width + 15) // 16, (height + 15) // 16
+    if (dev, N, tile_w, tile_h, "fg_stbin") not in rctx.isect_capacity:
+        return False
+    # job-list launches and the supertile binning must take this image size (tiny images run the classic launches)
+    skey = (width, height, N >> 20, bytes(rctx.policy))
+    ok = _STEP_SIZES.get(skey)
+    if ok is None:
+        lib = _lib.load()
+        ok = bool(lib.fg_stbin_supported(N, tile_w, tile_h)) and int(lib.fg_raster_jobs_words(width, height, TILE_SIZE, rctx.cfg())) > 0
+        if len(_STEP_SIZES) >= 512:
+            _STEP_SIZES.clear()
+        _STEP_SIZES[skey] = ok
+    return ok
+
+
+_STEP_SIZES: dict = {}
+
+
+class _RasterStep(torch.autograd.Function):
+    """Everything between the parameters and the image as one node: fg_step_fwd in forward, fg_step_bwd in backward."""
+
+    @staticmethod
+    def forward(ctx, means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, extra, viewmat, K,
+                background, opts):  # fmt: skip
+        rctx = current()
+        ctx.rctx = rctx
+        (raw, width, height, eps2d, near, far, radius_clip, antialiased, sh_degree, with_depth, n_clamp, absgrad,
+         want_backward) = opts  # fmt: skip
+        N, dev = means.shape[0], means.device
+        lib = _lib.load()
+        tile_w, tile_h = (width + 15) // 16, (height + 15) // 16
+        if raw:
+            k_stored, n_color = 1 + features_rest.shape[1], 3
+        elif sh_degree >= 0:
+            k_stored, n_color = colors.shape[1], 3
+        else:
+            k_stored, n_color = 0, (0 if colors is None else colors.shape[1])
+        n_extra = 0 if extra is None else extra.shape[1]
+        channels = n_color + int(with_depth) + n_extra
+        lkey, ckey = (dev, N, tile_w, tile_h), (dev, N, tile_w, tile_h, "fg_stbin")
+        long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
+        heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
+        cfgp = rctx.cfg(heavy)
+        capacity = rctx.isect_capacity[ckey]
+        while True:
+            shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
+            key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
+                   n_clamp, int(want_backward), int(shares), _lib.STBIN_LONG_SEGMENTS if long_mode else 0, capacity, eps2d,
+                   near, far, radius_clip, cfgp, bytes(rctx.policy))  # fmt: skip
+            d, L, rc = _step_plan(rctx, key)
+            _lib.check(rc, "fg_step_layout_query")
+            keep = torch.empty(L.keep_bytes, dtype=torch.uint8, device=dev)
+            tmp = torch.empty(max(L.tmp_bytes, 8), dtype=torch.uint8, device=dev)
+            count_slot, count_ptr = _count_slot()
+            io = _lib.StepIO()
+            io.means, io.quats, io.d_quats, io.scales, io.d_scales = _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(scales), _ptr(d_scales)
+            io.opacities, io.colors, io.features_rest, io.extra = _ptr(opacities), _ptr(colors), _ptr(features_rest), _ptr(extra)
+            io.viewmat, io.K, io.background, io.count_out = _ptr(viewmat), _ptr(K), _ptr(background), count_ptr
+            st = rctx.stage_timer
+            ev = st.record("fg_raster_fwd") if st is not None else None
+            if ev:  # (the library records them around its raster launch; a torch event exists once it has been recorded)
+                ev[0].record(), ev[1].record()
+                io.ev_raster_begin, io.ev_raster_end = ev[0].cuda_event, ev[1].cuda_event
+            _lib.check(lib.fg_step_fwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(), tmp.data_ptr(),
+                                       ctypes.addressof(L), _stream()), "fg_step_fwd")  # fmt: skip
+            rctx.long_calls += int(long_mode)
+            rctx.heavy_calls += int(heavy and shares)
+            n_isects = _note_counts(rctx, lkey, ckey, count_slot)
+            if n_isects <= capacity:
+                break
+            rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length
+            capacity = max(n_isects, 1)
+
+        def view(name, dtype, *shape):
+            i = _lib.STEP_BUFFER[name]
+            n = L.nbytes[i]
+            return None if n == 0 else keep[L.offset[i] : L.offset[i] + n].view(dtype).view(*shape)
+
+        render = view("render", torch.float32, height, width, channels)
+        alphas = view("alphas", torch.float32, height, width, 1)
+        means2d = view("means2d", torch.float32, N, 2)
+        depths, conics = view("depths", torch.float32, N), view("conics", torch.float32, N, 3)
+        radii, tiles = view("radii", torch.int32, N), view("tiles", torch.int32, N)
+        last_ids = view("last_ids", torch.int32, height, width)
+        splats = view("splats", torch.float32, N, SPLAT_FLOATS)
+        flatten_ids = view("flatten_ids", torch.int32, capacity)[:n_isects]
+        list_offsets = view("list_offsets", torch.int32, tile_w * tile_h + 1)
+        ctx.save_for_backward(means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, extra, viewmat, K,
+                              background, keep)  # fmt: skip
+        ctx.plan = (d, L, cfgp, raw, N, sh_degree, absgrad)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(last_ids, radii, tiles, splats, flatten_ids, list_offsets)
+        return render, alphas, means2d, depths, conics, last_ids, radii, tiles, splats, flatten_ids, list_offsets
+
+    @staticmethod
+    def backward(ctx, *grads):
+        with use(ctx.rctx):
+            return _RasterStep._backward(ctx, *grads)
+
+    @staticmethod
+    def _backward(ctx, v_render, v_alphas, v_means2d, v_depths, v_conics, *_unused):
+        (means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, extra, viewmat, K, background,
+         keep) = ctx.saved_tensors  # fmt: skip
+        d, L, cfgp, raw, N, sh_degree, absgrad = ctx.plan
+        rctx = ctx.rctx
+        if not d.want_backward:
+            raise _lib.FgRasterError("this step was rendered without gradient buffers (no input required a gradient)")
+
+        def view(name, dtype, *shape):
+            i = _lib.STEP_BUFFER[name]
+            return keep[L.offset[i] : L.offset[i] + L.nbytes[i]].view(dtype).view(*shape)
+
+        v_splats = view("v_splats", torch.float32, N, SPLAT_FLOATS)  # zero-filled by the forward launch
+        if v_means2d is not None:  # a loss on info["means2d"] itself: it joins the raster's xy gradient in the records
+            v_splats[:, 0:2] += v_means2d.reshape(N, 2)
+        if v_render is None:
+            H, W = d.height, d.width
+            v_render = torch.zeros(H, W, L.channels, dtype=torch.float32, device=keep.device)
+        io = _lib.StepIO()
+        io.means, io.quats, io.d_quats, io.scales, io.d_scales = _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(scales), _ptr(d_scales)
+        io.opacities, io.colors, io.features_rest, io.extra = _ptr(opacities), _ptr(colors), _ptr(features_rest), _ptr(extra)
+        io.viewmat, io.K, io.background = _ptr(viewmat), _ptr(K), _ptr(background)
+        keepalive = [v_render.contiguous(), None if v_alphas is None else v_alphas.contiguous(),
+                     None if v_depths is None else v_depths.contiguous(), None if v_conics is None else v_conics.contiguous()]
+        io.v_render, io.v_alphas, io.v_depths, io.v_conics = (_ptr(t) for t in keepalive)
+        v_means, v_quats, v_scales, v_opac = _alloc_grad(means), _alloc_grad(quats), _alloc_grad(scales), _alloc_grad(opacities)
+        v_dq = torch.empty_like(d_quats) if d_quats is not None else None
+        v_ds = torch.empty_like(d_scales) if d_scales is not None else None
+        v_colors = _alloc_grad(colors) if colors is not None else None
+        v_rest = _alloc_grad(features_rest) if features_rest is not None else None
+        v_extra = torch.empty_like(extra) if extra is not None else None
+        io.v_means, io.v_quats, io.v_d_quats, io.v_scales, io.v_d_scales = _ptr(v_means), _ptr(v_quats), _ptr(v_dq), _ptr(v_scales), _ptr(v_ds)
+        io.v_opacities, io.v_colors, io.v_features_rest, io.v_extra = _ptr(v_opac), _ptr(v_colors), _ptr(v_rest), _ptr(v_extra)
+        st = rctx.stage_timer
+        ev = st.record("fg_raster_bwd") if st is not None else None
+        if ev:
+            ev[0].record(), ev[1].record()
+            io.ev_raster_begin, io.ev_raster_end = ev[0].cuda_event, ev[1].cuda_event
+        _lib.check(_lib.load().fg_step_bwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(),
+                                           ctypes.addressof(L), _stream()), "fg_step_bwd")  # fmt: skip
+        ref = getattr(ctx, "means2d_ref", None)
+        m2 = ref() if ref is not None else None
+        if m2 is not None:
+            # info["means2d"]: .grad as if it had been retain_grad()'ed on the way to the compositing, .absgrad beside it
+            # (reference freegaussian_model.py:869-872, :377); strided views of the record gradients, no copy
+            m2.grad = v_splats[:, 0:2].view(m2.shape)
+            if absgrad:
+                m2.absgrad = v_splats[:, 6:8].view(m2.shape)
+        return v_means, v_quats, v_dq, v_scales, v_ds, v_opac, v_colors, v_rest, v_extra, None, None, None, None
+
+
+def raster_step(means, quats, scales, opacities, colors, viewmat, K, width, height, *, raw=False, d_quats=None, d_scales=None,
+                features_rest=None, extra=None, background=None, n_clamp=0, eps2d=0.3, near_plane=0.01, far_plane=1e10,
+                radius_clip=0.0, antialiased=False, sh_degree=-1, with_depth=False, absgrad=False):  # fmt: skip
+    """One view through fg_step_fwd (and, on backward, fg_step_bwd).  ``raw``: the model's raw parameter forms (scales =
+    log-scales, opacities = logits, colors = features_dc, features_rest).  -> (render [H,W,C], alphas [H,W,1], means2d
+    [N,2], depths [N], conics [N,3], last_ids, radii, tiles_touched, splats [N,16], flatten_ids [n], list_offsets [T+1],
+    node) -- ``node`` takes ``node.means2d_ref = weakref.ref(t)`` for the tensor that is to receive .grad / .absgrad."""
+    f = [None if t is None else _f32(t, "input") for t in (means, quats, d_quats, scales, d_scales, opacities, colors,
+                                                           features_rest, extra, viewmat, K)]  # fmt: skip
+    if f[5].dim() != 1:
+        f[5] = f[5].reshape(-1)
+    bg = None if background is None else background.detach().to(device=f[0].device, dtype=torch.float32).contiguous()
+    want_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in f[:9])
+    opts = (bool(raw), int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
+            bool(antialiased), int(sh_degree), bool(with_depth), int(n_clamp), bool(absgrad), bool(want_backward))  # fmt: skip
+    out = _RasterStep.apply(*f, bg, opts)
+    return out + (out[0].grad_fn,)
 
 
 # --------------------------------------------------------------------------------------------

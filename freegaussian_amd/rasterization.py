@@ -193,12 +193,24 @@ def rasterization(
     antialiased = rasterize_mode == "antialiased"
     n_extra = 0 if extra_channels is None else extra_channels.shape[1]
 
+    step = None
     if fused:
         # one pass: projection + SH colour + 64-byte record per Gaussian
         n_color = (3 if sh_degree is not None else colors.shape[1]) if with_rgb else 0
         channels = n_color + int(with_depth) + n_extra
         if not 1 <= channels <= ops.MAX_CHANNELS:
             raise ValueError(f"1..{ops.MAX_CHANNELS} composited channels supported, got {channels}")
+        if ops.step_path_available(ops.current(), N, width, height, tile_size, means.device):
+            # the whole view as one C-ABI call per direction (fg_step_fwd / fg_step_bwd): same kernels, same results
+            step = ops.raster_step(means, quats, scales, opacities, colors if with_rgb else None, viewmat, K, width, height,
+                                   extra=extra_channels, eps2d=eps2d, near_plane=near_plane, far_plane=far_plane,
+                                   radius_clip=radius_clip, antialiased=antialiased,
+                                   sh_degree=(sh_degree if (sh_degree is not None and with_rgb) else -1),
+                                   with_depth=with_depth, absgrad=absgrad)  # fmt: skip
+    if step is not None:
+        (render, alpha, means2d_n, depths, conics, last_ids, radii, tiles, splats, flatten_ids, offsets, node) = step
+        opac, tile_keys, keys_rects = splats[:, 2], None, True
+    elif fused:
         radii, means2d_n, depths, conics, tiles, splats = ops.preprocess(
             means, quats, scales, opacities, colors if with_rgb else None, extra_channels, viewmat, K, width,
             height, eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased,
@@ -226,12 +238,13 @@ def rasterization(
             chans.append(extra_channels.float())
         feats = chans[0] if len(chans) == 1 else torch.cat(chans, dim=-1)
 
-    # speculative lists: the raster forward is enqueued before the host waits for the list length
-    keys_rects = getattr(splats, "_fg_bin", None) if fused else None
-    tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
-        means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
-        keys_rects=keys_rects, raster_hint=(channels, width, height) if fused else None,
-    )
+    if step is None:
+        # speculative lists: the raster forward is enqueued before the host waits for the list length
+        keys_rects = getattr(splats, "_fg_bin", None) if fused else None
+        tile_keys, flatten_ids, offsets, finish_lists = ops.bin_tiles(
+            means2d_n.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h, defer=True, want_keys=False,
+            keys_rects=keys_rects, raster_hint=(channels, width, height) if fused else None,
+        )
 
     if packed:
         # the reference's packed call sites (knn_gaussian.py:116-130) index these by nnz
@@ -249,11 +262,16 @@ def rasterization(
         return ops.rasterize_to_pixels(means2d_in, conics, feats, opac, width, height, tile_size, offsets, flatten_ids,
                                        absgrad=absgrad)  # fmt: skip
 
-    render, alpha, last_ids = composite()
-    if finish_lists is not None:
-        tile_keys, flatten_ids, redone = finish_lists()
-        if redone:  # the capacity guess was too small: lists were rebuilt exactly, composite again
-            render, alpha, last_ids = composite()
+    if step is None:
+        render, alpha, last_ids = composite()
+        if finish_lists is not None:
+            tile_keys, flatten_ids, redone = finish_lists()
+            if redone:  # the capacity guess was too small: lists were rebuilt exactly, composite again
+                render, alpha, last_ids = composite()
+    elif node is not None:
+        import weakref
+
+        node.means2d_ref = weakref.ref(means2d_in)  # the tensor that receives .grad / .absgrad after backward
     if backgrounds is not None:
         render = render + (1.0 - alpha) * backgrounds.reshape(1, 1, -1)
     if render_mode in ("ED", "RGB+ED"):
@@ -360,6 +378,34 @@ def rasterize_gauss_params(
     viewmat, K = viewmats[0], Ks[0]
     tile_w = (width + tile_size - 1) // tile_size
     tile_h = (height + tile_size - 1) // tile_size
+    bg = None
+    if background is not None:  # (RGB: the tensor itself; more channels: one pad op -- no zeros + slice copy)
+        bg = background.detach().reshape(-1).to(means.device, torch.float32)
+        if channels > 3:
+            bg = torch.nn.functional.pad(bg, (0, channels - 3))
+    if ops.step_path_available(ops.current(), N, width, height, tile_size, means.device):
+        # the whole view as one C-ABI call per direction (fg_step_fwd / fg_step_bwd): same kernels, same results
+        import weakref
+
+        (render, alpha, means2d_n, depths, conics, last_ids, radii, tiles, splats, flatten_ids, offsets, node) = ops.raster_step(
+            means, quats, log_scales, opacity_logits, features_dc, viewmat, K, width, height, raw=True, d_quats=d_quats,
+            d_scales=d_scales, features_rest=features_rest, extra=extra_channels, background=bg, n_clamp=(3 if clamp else 0),
+            eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
+            antialiased=(rasterize_mode == "antialiased"), sh_degree=sh_degree, with_depth=with_depth, absgrad=absgrad)  # fmt: skip
+        means2d_info = means2d_n.unsqueeze(0)
+        if node is not None:
+            node.means2d_ref = weakref.ref(means2d_info)
+        if with_depth:
+            d = render[..., 3:4] / alpha.clamp(min=1e-10)
+            render = torch.cat([render[..., :3], d, render[..., 4:]], dim=-1)
+        info = _Info({
+            "radii": radii[None], "means2d": means2d_info, "depths": depths[None], "conics": conics[None],
+            "opacities": splats[:, 2][None], "tile_width": tile_w, "tile_height": tile_h,
+            "tiles_per_gauss": tiles[None], "last_ids": last_ids, "width": width, "height": height,
+            "tile_size": tile_size, "n_cameras": 1,
+        })  # fmt: skip
+        _attach_lists(info, None, flatten_ids, offsets, False, means2d_n, radii, depths, tiles, tile_size, tile_w, tile_h)
+        return render[None], alpha[None], info
     radii, means2d_n, depths, conics, tiles, splats = ops.preprocess_raw(
         means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmat, K, width, height, sh_degree,
         d_quats=d_quats, d_scales=d_scales, extra=extra_channels, eps2d=eps2d, near_plane=near_plane,
@@ -372,11 +418,6 @@ def rasterize_gauss_params(
         keys_rects=keys_rects, raster_hint=(channels, width, height),
     )
     means2d_info = means2d_n.unsqueeze(0)
-    bg = None
-    if background is not None:  # (RGB: the tensor itself; more channels: one pad op -- no zeros + slice copy)
-        bg = background.detach().reshape(-1).to(means.device, torch.float32)
-        if channels > 3:
-            bg = torch.nn.functional.pad(bg, (0, channels - 3))
 
     def composite():
         return ops.rasterize_splats(splats, means2d_info, channels, width, height, tile_size, offsets, flatten_ids,

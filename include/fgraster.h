@@ -477,6 +477,70 @@ int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored,
                                 const float* payload, int64_t view_stride, int payload_floats, float scale,
                                 float* v_features_dc, float* v_features_rest, fg_stream_t stream);
 
+/* ---- One call per direction (ABI 7): the whole eager step of one view ------------------------------------------
+ * fg_step_fwd = fg_preprocess_fwd (raw = 0) or fg_preprocess_raw_fwd (raw = 1) -> fg_stbin_count -> fg_stbin_fill_jobs ->
+ * fg_raster_jobs_fwd; fg_step_bwd = fg_raster_jobs_bwd -> the matching per-Gaussian backward (the factored one when
+ * io->v_rgb is given).  Same kernels, same results as the stage-wise calls: what changes is the host's work per step
+ * -- three small structs instead of ~150 marshalled arguments, two workspace allocations instead of ~20 buffers -- which
+ * is the whole cost of a launch-bound step (the reference's quarter- and half-resolution phases,
+ * freegaussian_model.py:626-633).  Replaces, like those calls, the rasterization(...) of freegaussian_model.py:847-868
+ * and its autograd backward.
+ *   fg_step_desc    what is rendered (sizes, SH degree, channels, composite epilogue, list capacity, flags)
+ *   fg_step_io      device pointers: the inputs (plain or raw parameter forms, as the two preprocess entry points take
+ *                   them), count_out (pinned host memory, the three words of fg_stbin_count), and for the backward the
+ *                   upstream gradients and the output gradients
+ *   fg_step_layout  from fg_step_layout_query: offsets / sizes of every buffer inside the two caller-allocated
+ *                   workspaces -- `keep` (read by the backward and by the caller: FG_STEP_RADII .. FG_STEP_CLAMP_MASK;
+ *                   uninitialised) and `tmp` (FG_STEP_COUNT_WS, FG_STEP_FILL_WS: free again once the call's launches
+ *                   have run).  FG_ERR_UNSUPPORTED: shapes the supertile binning or the job-list launches do not take
+ *                   (use the stage-wise entry points).
+ * A list longer than desc->capacity leaves empty lists (see fg_stbin_fill) and an image of the background: the host
+ * sees it in count_out[0] and repeats fg_step_fwd with a larger capacity and fresh workspaces. */
+enum {
+  FG_STEP_RADII, FG_STEP_MEANS2D, FG_STEP_DEPTHS, FG_STEP_CONICS, FG_STEP_COMP, FG_STEP_TILES, FG_STEP_SPLATS,
+  FG_STEP_DEPTH_KEYS, FG_STEP_TILE_RECTS, FG_STEP_SH_JAC, FG_STEP_TILE_OFFSETS, FG_STEP_LIST_OFFSETS, FG_STEP_FLATTEN_IDS,
+  FG_STEP_JOBS, FG_STEP_LIVE, FG_STEP_SEG_CKPT, FG_STEP_V_SPLATS, FG_STEP_RENDER, FG_STEP_ALPHAS, FG_STEP_LAST_IDS,
+  FG_STEP_CLAMP_MASK, FG_STEP_COUNT_WS, FG_STEP_FILL_WS, FG_STEP_BUFFERS
+};
+typedef struct fg_step_desc {
+  int32_t size;           /* sizeof(fg_step_desc) */
+  int32_t N, width, height, tile_size;
+  int32_t raw;            /* 1: the raw parameter forms of fg_preprocess_raw_* (SH colours only) */
+  int32_t sh_degree;      /* -1: colors[N,n_color] direct channels */
+  int32_t k_stored, n_color, with_depth, n_extra, antialiased;
+  int32_t n_clamp;        /* composite epilogue: clamp the first n_clamp channels; io->background nullable */
+  int32_t want_backward;  /* 0: no liveness words / checkpoints / record-gradient array / SH note */
+  int32_t list_shares;    /* backward over shares of the tiles' lists (three channels; fg_raster_seg_ckpt_floats) */
+  int32_t flags;          /* FG_STBIN_LONG_SEGMENTS */
+  float eps2d, near_plane, far_plane, radius_clip;
+  int64_t capacity;       /* list entries the workspaces hold */
+} fg_step_desc;
+typedef struct fg_step_io {
+  const float *means, *quats, *d_quats, *scales, *d_scales, *opacities, *colors, *features_rest, *extra, *viewmat, *K,
+      *background;        /* raw = 1: scales = log-scales, opacities = logits, colors = features_dc */
+  int64_t* count_out;     /* nullable */
+  /* backward only */
+  const float *v_render, *v_alphas, *v_depths, *v_conics;  /* upstream gradients; all but v_render nullable */
+  float *v_means, *v_quats, *v_d_quats, *v_scales, *v_d_scales, *v_opacities, *v_colors, *v_features_rest, *v_extra;
+  float* v_rgb;           /* non-NULL: the factored form (v_colors / v_features_rest unused) */
+  int32_t v_rgb_floats;
+  /* optional hipEvent_t pair recorded on `stream` around the call's raster launch (forward call: the raster forward,
+     backward call: the raster backward): a host that times the dominant kernel of the step does not have to take the
+     stage-wise entry points for it */
+  void *ev_raster_begin, *ev_raster_end;
+} fg_step_io;
+typedef struct fg_step_layout {
+  int64_t keep_bytes, tmp_bytes;
+  int64_t offset[FG_STEP_BUFFERS], nbytes[FG_STEP_BUFFERS];  /* nbytes 0: the step has no such buffer */
+  int64_t jobs_words, seg_ckpt_floats;
+  int32_t channels;
+} fg_step_layout;
+int fg_step_layout_query(const fg_step_desc* desc, const fg_raster_config* config, fg_step_layout* out);
+int fg_step_fwd(const fg_step_desc* desc, const fg_raster_config* config, const fg_step_io* io, void* keep, void* tmp,
+                const fg_step_layout* layout, fg_stream_t stream);
+int fg_step_bwd(const fg_step_desc* desc, const fg_raster_config* config, const fg_step_io* io, void* keep,
+                const fg_step_layout* layout, fg_stream_t stream);
+
 /* S1 in one pass: the densification statistics after_train_iter keeps (freegaussian_model.py:369-392), all in place:
  * for radii[i] > 0: xys_grad_norm[i] += |absgrad[i]| (absgrad [N,2]), vis_counts[i] += 1,
  * max_2dsize[i] = max(max_2dsize[i], radii[i] / max_dim); other rows untouched. */

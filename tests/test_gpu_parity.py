@@ -569,6 +569,7 @@ def test_rasterization_takes_the_job_lists_of_the_fill(monkeypatch):
         if int(_lib.load().fg_raster_jobs_words(sc.width, sc.height, 16, ctx.cfg())) == 0:
             pytest.skip("classic launches forced by the environment: no job lists")
         ctx.jobs_in_fill = in_fill
+        ctx.step_calls = False  # (the stage-wise calls are what this test looks at; fg_step_fwd makes them inside the library)
         for _ in range(2):  # exact lists, then speculative
             del calls[:]
             t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
@@ -614,6 +615,65 @@ def test_supertile_binning_fuzz_against_depth_first(seed, monkeypatch):
     rects = _pack_rects(x0, y0, w, h).to(DEV)
     f, o = _supertile_vs_depth_first(N, W, H, rects, keys.to(DEV), monkeypatch, overflow=True)
     assert int(o[-1]) == int((w * h).sum()) == f.numel()
+
+
+@pytest.mark.parametrize("raw,mode", [(False, "RGB"), (False, "RGB+ED"), (True, "RGB"), (True, "RGB+ED")])
+def test_one_call_per_direction_equals_the_stage_wise_calls(raw, mode, monkeypatch):
+    """fg_step_fwd / fg_step_bwd (ABI 7: the whole view as one C-ABI call per direction, two workspaces) against the
+    stage-wise calls on the same inputs: the same kernels in the same order -- image, alpha, last_ids, radii, lists bit
+    for bit, every gradient, info["means2d"].grad and .absgrad up to the order of the backward's atomics.  Both front
+    ends (rasterization, rasterize_gauss_params with background + clamp), with and without a depth channel; a capacity
+    guess that is too small is redone inside the call."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = _scene(n=30000, w=640, h=368, seed=23)  # 920 tiles: job-list launches
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    C = 4 if mode.endswith("D") else 3
+    vr = torch.randn(1, sc.height, sc.width, C, generator=torch.Generator().manual_seed(1)).to(DEV)
+    ctx = ops.RasterContext()
+    if not ctx.step_calls or ctx.binning != "supertile" or int(_lib.load().fg_raster_jobs_words(640, 368, 16, ctx.cfg())) == 0:
+        pytest.skip("the environment selects the stage-wise path")
+    calls = []
+    real = ops._call
+    monkeypatch.setattr(ops, "_call", lambda name, *a, **k: (calls.append(name), real(name, *a, **k))[1])
+
+    def run():
+        if raw:
+            p = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                     features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+            r, a, info = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                t["features_rest"], vm, K, sc.width, sc.height, 3, render_mode=mode, absgrad=True,
+                                                background=torch.tensor([0.2, 0.7, 0.4], device=DEV), clamp=True, ctx=ctx)  # fmt: skip
+        else:
+            t = {k: getattr(sc, k).to(DEV).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+            r, a, info = rasterization(*t.values(), vm, K, sc.width, sc.height, sh_degree=3, packed=False, render_mode=mode,
+                                       absgrad=True, ctx=ctx)  # fmt: skip
+        info["means2d"].retain_grad()
+        ((r * vr).sum() + 0.5 * a.sum()).backward()
+        torch.cuda.synchronize()
+        return (r.detach(), a.detach(), info["last_ids"], info["radii"], info["raster_flatten_ids"], info["raster_isect_offsets"],
+                {k: v.grad for k, v in t.items()}, info["means2d"].grad.clone(), info["means2d"].absgrad.clone())  # fmt: skip
+
+    ctx.step_calls = False
+    ref = run()  # (also measures the shape's list capacity)
+    ref = run()
+    assert "fg_stbin_fill_jobs" in calls
+    ctx.step_calls = True
+    del calls[:]
+    outs = [run()]
+    assert not calls, calls  # no stage-wise entry point was called
+    for k in list(ctx.isect_capacity):
+        ctx.isect_capacity[k] = 2048  # far too small: an empty image, detected, the call repeated with the list's length
+    redos = ctx.capacity_redos
+    outs.append(run())
+    assert ctx.capacity_redos == redos + 1 and not calls
+    for o in outs:
+        for i in range(6):
+            assert torch.equal(o[i], ref[i]), i
+        for k in ref[6]:
+            assert rel_l2(o[6][k], ref[6][k]) < 1e-5, k
+        assert rel_l2(o[7], ref[7]) < 1e-5 and rel_l2(o[8], ref[8]) < 1e-5
 
 
 def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
