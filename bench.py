@@ -613,7 +613,9 @@ def main(argv=None):
         settle_steps += settle(max(args.settle_s / 3, 0.2), per_step)
     redo0 = ops.default_context.capacity_redos
     if ops.default_context.stage_timer is not None:
-        ops.default_context.stage_timer = ops.StageTimer(only=only)  # the settle steps' events are not part of the timed region's averages
+        # (the settle steps' events are not part of the timed region's averages; the timed region's own event pairs exist
+        # before it starts)
+        ops.default_context.stage_timer = ops.StageTimer(only=only, prewarm=(2 * args.steps + 4) if only else 0)
     fence()
     t0 = time.perf_counter()
     views_seen = []

@@ -37,16 +37,33 @@ class StageTimer:
     timed region).  Events are recorded on the stream the kernels are launched on; nothing
     synchronises until ``summary()``."""
 
-    def __init__(self, only=None):
+    def __init__(self, only=None, prewarm=0):
         self.events = {}
         self.only = only  # None = every stage; else the set of stage names that get events
+        # `prewarm` event pairs created (= recorded once) up front: fg_step_fwd / fg_step_bwd record the pair around
+        # their raster launch THEMSELVES and need existing events -- creating them inside a timed region would cost two
+        # extra records per pair
+        self._pool = []
+        for _ in range(prewarm):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record(), b.record()
+            self._pool.append((a, b))
 
     def record(self, name):
         if self.only is not None and name not in self.only:
             return None
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        self.events.setdefault(name, []).append((a, b))
-        return a, b
+        pair = self._pool.pop() if self._pool else (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        self.events.setdefault(name, []).append(pair)
+        return pair
+
+    @staticmethod
+    def handles(pair):
+        """The pair's raw hipEvent_t handles (for a library call that records them itself); events that do not exist yet
+        are created by recording them once here."""
+        for e in pair:
+            if not e.cuda_event:
+                e.record()
+        return int(pair[0].cuda_event), int(pair[1].cuda_event)
 
     def summary(self):
         torch.cuda.synchronize()
@@ -1438,9 +1455,8 @@ class _RasterStep(torch.autograd.Function):
             io.viewmat, io.K, io.background, io.count_out = _ptr(viewmat), _ptr(K), _ptr(background), count_ptr
             st = rctx.stage_timer
             ev = st.record("fg_raster_fwd") if st is not None else None
-            if ev:  # (the library records them around its raster launch; a torch event exists once it has been recorded)
-                ev[0].record(), ev[1].record()
-                io.ev_raster_begin, io.ev_raster_end = ev[0].cuda_event, ev[1].cuda_event
+            if ev:  # (the library records them around its raster launch)
+                io.ev_raster_begin, io.ev_raster_end = StageTimer.handles(ev)
             _lib.check(lib.fg_step_fwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(), tmp.data_ptr(),
                                        ctypes.addressof(L), _stream()), "fg_step_fwd")  # fmt: skip
             rctx.long_calls += int(long_mode)
@@ -1514,8 +1530,7 @@ class _RasterStep(torch.autograd.Function):
         st = rctx.stage_timer
         ev = st.record("fg_raster_bwd") if st is not None else None
         if ev:
-            ev[0].record(), ev[1].record()
-            io.ev_raster_begin, io.ev_raster_end = ev[0].cuda_event, ev[1].cuda_event
+            io.ev_raster_begin, io.ev_raster_end = StageTimer.handles(ev)
         _lib.check(_lib.load().fg_step_bwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(),
                                            ctypes.addressof(L), _stream()), "fg_step_bwd")  # fmt: skip
         ref = getattr(ctx, "means2d_ref", None)
