@@ -111,6 +111,25 @@ class FreeGaussianModelConfig:
     fused_front_end: bool = True
 
 
+_POSE_RING = None
+
+
+def _pose_slot():
+    """(tensor[25], its numpy view) of the next slot of a ring of pinned staging buffers for viewmat + K."""
+    global _POSE_RING
+    if _POSE_RING is None:
+        ring = torch.empty(64, 32, dtype=torch.float32).pin_memory()
+        _POSE_RING = [ring, ring.numpy(), 0]
+    ring, ring_np, i = _POSE_RING
+    _POSE_RING[2] = (i + 1) % ring.shape[0]
+    return ring[i, :25], ring_np[i, :25]
+
+
+# Per-step bookkeeping attributes (plain tensors / ints, never Parameters or sub-modules) are set past
+# nn.Module.__setattr__, whose parameter / buffer / module checks cost ~5 us a time, six times a step.
+_plain_set = object.__setattr__
+
+
 class FreeGaussianModel(nn.Module):
     """Gaussian parameter store + deform/control MLPs + ``get_outputs``."""
 
@@ -291,13 +310,15 @@ class FreeGaussianModel(nn.Module):
             # host-side pose: 25 floats through a pinned buffer, asynchronously.  A pageable
             # `.to(device)` blocks the host until the queue has drained, i.e. until the previous
             # step's backward has finished -- the host could then never run ahead of the GPU.
-            stage = torch.empty(25, dtype=torch.float32).pin_memory()
+            # The staging words come from a ring of pinned slots: a slot is written again 64 camera set-ups later, and
+            # the host is never that far ahead of the queue (every render waits for its own list length).
+            stage, stage_np = _pose_slot()
             stage[:16] = get_viewmat(c2w.float()).reshape(-1)
-            stage[16:] = camera.get_intrinsics_matrices().reshape(-1)
+            stage_np[16:] = (camera.fx, 0.0, camera.cx, 0.0, camera.fy, camera.cy, 0.0, 0.0, 1.0)
             dev = stage.to(self.device, non_blocking=True)
             viewmat, K = dev[:16].view(1, 4, 4), dev[16:].view(1, 3, 3)
         W, H = int(camera.width), int(camera.height)
-        self.last_size = (H, W)
+        _plain_set(self, "last_size", (H, W))
         for c, (fx, fy, cx, cy, w, h) in saved:
             c.fx, c.fy, c.cx, c.cy, c.width, c.height = fx, fy, cx, cy, w, h
         return viewmat, K, W, H
@@ -339,9 +360,9 @@ class FreeGaussianModel(nn.Module):
         )
         if self.training and info["means2d"].requires_grad:
             info["means2d"].retain_grad()
-        self.xys = info["means2d"]  # [1,N,2]
-        self.radii = info["radii"][0]  # [N]
-        self.last_list_length = int(info["raster_flatten_ids"].numel())  # (the capacity, in static-shape mode)
+        _plain_set(self, "xys", info["means2d"])  # [1,N,2]
+        _plain_set(self, "radii", info["radii"][0])  # [N]
+        _plain_set(self, "last_list_length", int(info["raster_flatten_ids"].numel()))  # (the capacity, in static-shape mode)
         background = self._get_background_color()
         rgb = torch.clamp(render[..., :3] + (1 - alpha) * background, 0.0, 1.0)
         if render_mode == "RGB+ED":
@@ -380,9 +401,9 @@ class FreeGaussianModel(nn.Module):
         )  # fmt: skip
         if self.training and info["means2d"].requires_grad:
             info["means2d"].retain_grad()
-        self.xys = info["means2d"]
-        self.radii = info["radii"][0]
-        self.last_list_length = int(info["raster_flatten_ids"].numel())  # (the capacity, in static-shape mode)
+        _plain_set(self, "xys", info["means2d"])
+        _plain_set(self, "radii", info["radii"][0])
+        _plain_set(self, "last_list_length", int(info["raster_flatten_ids"].numel()))  # (the capacity, in static-shape mode)
         if render_mode == "RGB+ED":
             depth = rgb[..., 3:4]
             depth = torch.where(alpha > 0, depth, depth.detach().max()).squeeze(0)
@@ -390,7 +411,8 @@ class FreeGaussianModel(nn.Module):
             depth = None
         if not self.training:
             background = background.expand(H, W, 3)
-        return {"rgb": rgb[..., :3].squeeze(0), "depth": depth, "accumulation": alpha.squeeze(0),
+        # (a full-width slice is still a SliceBackward node: a zeros + a copy launch in every backward)
+        return {"rgb": (rgb if rgb.shape[-1] == 3 else rgb[..., :3]).squeeze(0), "depth": depth, "accumulation": alpha.squeeze(0),
                 "background": background}  # fmt: skip
 
     # -- H1 + H4 -----------------------------------------------------------------------------------
@@ -405,11 +427,11 @@ class FreeGaussianModel(nn.Module):
         crop = self._crop_ids()
         if crop is not None and int(crop.sum()) == 0:  # (:781-782)
             return self.get_empty_outputs(int(camera.width), int(camera.height), self.background_color.to(self.device))
-        self._active_crop = crop
+        _plain_set(self, "_active_crop", crop)
         try:
             return self._get_outputs_on_active_rows(camera)
         finally:
-            self._active_crop = None
+            _plain_set(self, "_active_crop", None)
 
     def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)
@@ -494,11 +516,11 @@ class FreeGaussianControlModel(FreeGaussianModel):
         crop = self._crop_ids()  # (freegaussian_control_model.py:73-86: the mask is cropped alongside)
         if crop is not None and int(crop.sum()) == 0:
             return self.get_empty_outputs(int(camera.width), int(camera.height), self.background_color.to(self.device))
-        self._active_crop = crop
+        _plain_set(self, "_active_crop", crop)
         try:
             return self._get_outputs_on_active_rows(camera)
         finally:
-            self._active_crop = None
+            _plain_set(self, "_active_crop", None)
 
     def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)

@@ -1422,7 +1422,7 @@ class _RasterStep(torch.autograd.Function):
         rctx = current()
         ctx.rctx = rctx
         (raw, width, height, eps2d, near, far, radius_clip, antialiased, sh_degree, with_depth, n_clamp, absgrad,
-         want_backward) = opts  # fmt: skip
+         want_backward, batched) = opts  # fmt: skip
         N, dev = means.shape[0], means.device
         lib = _lib.load()
         tile_w, tile_h = (width + 15) // 16, (height + 15) // 16
@@ -1446,7 +1446,7 @@ class _RasterStep(torch.autograd.Function):
                    near, far, radius_clip, cfgp, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(rctx, key)
             _lib.check(rc, "fg_step_layout_query")
-            keep = torch.empty(L.keep_bytes, dtype=torch.uint8, device=dev)
+            keep = torch.empty((L.keep_bytes + 3) >> 2, dtype=torch.float32, device=dev)
             tmp = torch.empty(max(L.tmp_bytes, 8), dtype=torch.uint8, device=dev)
             count_slot, count_ptr = _count_slot()
             io = _lib.StepIO()
@@ -1461,26 +1461,35 @@ class _RasterStep(torch.autograd.Function):
                                        ctypes.addressof(L), _stream()), "fg_step_fwd")  # fmt: skip
             rctx.long_calls += int(long_mode)
             rctx.heavy_calls += int(heavy and shares)
+            # the outputs are views of the kept workspace: one as_strided each (built before the wait below, i.e. while the
+            # GPU runs the projection and the count pass)
+            k32, i32 = keep, keep.view(torch.int32)
+            strided, off, nb = torch.as_strided, L.offset, L.nbytes
+            SB = _lib.STEP_BUFFER
+
+            def view(base, name, shape, stride):
+                i = SB[name]
+                return None if nb[i] == 0 else strided(base, shape, stride, off[i] >> 2)
+
+            if batched:  # the leading camera axis of the reference's outputs, without an unsqueeze node each
+                render = view(k32, "render", (1, height, width, channels), (height * width * channels, width * channels, channels, 1))
+                alphas = view(k32, "alphas", (1, height, width, 1), (height * width, width, 1, 1))
+                means2d = view(k32, "means2d", (1, N, 2), (2 * N, 2, 1))
+            else:
+                render = view(k32, "render", (height, width, channels), (width * channels, channels, 1))
+                alphas = view(k32, "alphas", (height, width, 1), (width, 1, 1))
+                means2d = view(k32, "means2d", (N, 2), (2, 1))
+            depths, conics = view(k32, "depths", (N,), (1,)), view(k32, "conics", (N, 3), (3, 1))
+            radii, tiles = view(i32, "radii", (N,), (1,)), view(i32, "tiles", (N,), (1,))
+            last_ids = view(i32, "last_ids", (height, width), (width, 1))
+            splats = view(k32, "splats", (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1))
+            list_offsets = view(i32, "list_offsets", (tile_w * tile_h + 1,), (1,))
             n_isects = _note_counts(rctx, lkey, ckey, count_slot)
             if n_isects <= capacity:
                 break
             rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length
             capacity = max(n_isects, 1)
-
-        def view(name, dtype, *shape):
-            i = _lib.STEP_BUFFER[name]
-            n = L.nbytes[i]
-            return None if n == 0 else keep[L.offset[i] : L.offset[i] + n].view(dtype).view(*shape)
-
-        render = view("render", torch.float32, height, width, channels)
-        alphas = view("alphas", torch.float32, height, width, 1)
-        means2d = view("means2d", torch.float32, N, 2)
-        depths, conics = view("depths", torch.float32, N), view("conics", torch.float32, N, 3)
-        radii, tiles = view("radii", torch.int32, N), view("tiles", torch.int32, N)
-        last_ids = view("last_ids", torch.int32, height, width)
-        splats = view("splats", torch.float32, N, SPLAT_FLOATS)
-        flatten_ids = view("flatten_ids", torch.int32, capacity)[:n_isects]
-        list_offsets = view("list_offsets", torch.int32, tile_w * tile_h + 1)
+        flatten_ids = view(i32, "flatten_ids", (n_isects,), (1,))
         ctx.save_for_backward(means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, extra, viewmat, K,
                               background, keep)  # fmt: skip
         ctx.plan = (d, L, cfgp, raw, N, sh_degree, absgrad)
@@ -1502,11 +1511,8 @@ class _RasterStep(torch.autograd.Function):
         if not d.want_backward:
             raise _lib.FgRasterError("this step was rendered without gradient buffers (no input required a gradient)")
 
-        def view(name, dtype, *shape):
-            i = _lib.STEP_BUFFER[name]
-            return keep[L.offset[i] : L.offset[i] + L.nbytes[i]].view(dtype).view(*shape)
-
-        v_splats = view("v_splats", torch.float32, N, SPLAT_FLOATS)  # zero-filled by the forward launch
+        # (zero-filled by the forward launch)
+        v_splats = torch.as_strided(keep, (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1), L.offset[_lib.STEP_BUFFER["v_splats"]] >> 2)
         if v_means2d is not None:  # a loss on info["means2d"] itself: it joins the raster's xy gradient in the records
             v_splats[:, 0:2] += v_means2d.reshape(N, 2)
         if v_render is None:
@@ -1546,11 +1552,11 @@ class _RasterStep(torch.autograd.Function):
 
 def raster_step(means, quats, scales, opacities, colors, viewmat, K, width, height, *, raw=False, d_quats=None, d_scales=None,
                 features_rest=None, extra=None, background=None, n_clamp=0, eps2d=0.3, near_plane=0.01, far_plane=1e10,
-                radius_clip=0.0, antialiased=False, sh_degree=-1, with_depth=False, absgrad=False):  # fmt: skip
+                radius_clip=0.0, antialiased=False, sh_degree=-1, with_depth=False, absgrad=False, batched=False):  # fmt: skip
     """One view through fg_step_fwd (and, on backward, fg_step_bwd).  ``raw``: the model's raw parameter forms (scales =
     log-scales, opacities = logits, colors = features_dc, features_rest).  -> (render [H,W,C], alphas [H,W,1], means2d
     [N,2], depths [N], conics [N,3], last_ids, radii, tiles_touched, splats [N,16], flatten_ids [n], list_offsets [T+1],
-    node) -- ``node`` takes ``node.means2d_ref = weakref.ref(t)`` for the tensor that is to receive .grad / .absgrad."""
+    node; ``batched``: render [1,H,W,C], alphas [1,H,W,1], means2d [1,N,2]) -- ``node`` takes ``node.means2d_ref = weakref.ref(t)`` for the tensor that is to receive .grad / .absgrad."""
     f = [None if t is None else _f32(t, "input") for t in (means, quats, d_quats, scales, d_scales, opacities, colors,
                                                            features_rest, extra, viewmat, K)]  # fmt: skip
     if f[5].dim() != 1:
@@ -1558,7 +1564,8 @@ def raster_step(means, quats, scales, opacities, colors, viewmat, K, width, heig
     bg = None if background is None else background.detach().to(device=f[0].device, dtype=torch.float32).contiguous()
     want_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in f[:9])
     opts = (bool(raw), int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
-            bool(antialiased), int(sh_degree), bool(with_depth), int(n_clamp), bool(absgrad), bool(want_backward))  # fmt: skip
+            bool(antialiased), int(sh_degree), bool(with_depth), int(n_clamp), bool(absgrad), bool(want_backward),
+            bool(batched))  # fmt: skip
     out = _RasterStep.apply(*f, bg, opts)
     return out + (out[0].grad_fn,)
 

@@ -83,8 +83,9 @@ def _attach_lists(info: "_Info", tile_keys, flatten_ids, offsets, reference_list
 
     def full():
         if not cache:
-            tk, ids, offs = ops.bin_tiles(means2d.detach(), radii, depths.detach(), tiles, tile_size, tile_w, tile_h,
-                                          want_keys=True)  # fmt: skip
+            m2 = means2d.detach()
+            tk, ids, offs = ops.bin_tiles(m2[0] if m2.dim() == 3 else m2, radii, depths.detach(), tiles, tile_size, tile_w,
+                                          tile_h, want_keys=True)  # fmt: skip
             cache.update(tile_keys=tk, flatten_ids=ids, isect_offsets=offs)
         return cache
 
@@ -387,12 +388,12 @@ def rasterize_gauss_params(
         # the whole view as one C-ABI call per direction (fg_step_fwd / fg_step_bwd): same kernels, same results
         import weakref
 
-        (render, alpha, means2d_n, depths, conics, last_ids, radii, tiles, splats, flatten_ids, offsets, node) = ops.raster_step(
+        (render, alpha, means2d_info, depths, conics, last_ids, radii, tiles, splats, flatten_ids, offsets, node) = ops.raster_step(
             means, quats, log_scales, opacity_logits, features_dc, viewmat, K, width, height, raw=True, d_quats=d_quats,
             d_scales=d_scales, features_rest=features_rest, extra=extra_channels, background=bg, n_clamp=(3 if clamp else 0),
             eps2d=eps2d, near_plane=near_plane, far_plane=far_plane, radius_clip=radius_clip,
-            antialiased=(rasterize_mode == "antialiased"), sh_degree=sh_degree, with_depth=with_depth, absgrad=absgrad)  # fmt: skip
-        means2d_info = means2d_n.unsqueeze(0)
+            antialiased=(rasterize_mode == "antialiased"), sh_degree=sh_degree, with_depth=with_depth, absgrad=absgrad,
+            batched=True)  # fmt: skip
         if node is not None:
             node.means2d_ref = weakref.ref(means2d_info)
         if with_depth:
@@ -404,8 +405,8 @@ def rasterize_gauss_params(
             "tiles_per_gauss": tiles[None], "last_ids": last_ids, "width": width, "height": height,
             "tile_size": tile_size, "n_cameras": 1,
         })  # fmt: skip
-        _attach_lists(info, None, flatten_ids, offsets, False, means2d_n, radii, depths, tiles, tile_size, tile_w, tile_h)
-        return render[None], alpha[None], info
+        _attach_lists(info, None, flatten_ids, offsets, False, means2d_info, radii, depths, tiles, tile_size, tile_w, tile_h)
+        return render, alpha, info
     radii, means2d_n, depths, conics, tiles, splats = ops.preprocess_raw(
         means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmat, K, width, height, sh_degree,
         d_quats=d_quats, d_scales=d_scales, extra=extra_channels, eps2d=eps2d, near_plane=near_plane,

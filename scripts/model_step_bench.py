@@ -68,13 +68,27 @@ def step():
 
 for _ in range(25):  # (the caching allocator and the list-capacity history settle over the first steps)
     step()
-torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(steps):
-    step()
-issue = (time.perf_counter() - t0) / steps * 1e3  # host time to enqueue a step (includes the one host sync)
-torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / steps * 1e3
+# host-bound sizes follow the host's clock and whatever else the box is doing: several blocks, median and best reported;
+# FG_MODEL_AB=1 alternates blocks with and without the one-call-per-direction path (ops.RasterContext.step_calls)
+blocks = int(os.environ.get("FG_MODEL_BLOCKS", "5"))
+ab = bool(os.environ.get("FG_MODEL_AB"))
+block_ms = {True: [], False: []}
+issue_ms = []
+for b in range(blocks * (2 if ab else 1)):
+    calls = ops.default_context.step_calls if not ab else (b % 2 == 0)
+    saved, ops.default_context.step_calls = ops.default_context.step_calls, calls
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    issue_ms.append((time.perf_counter() - t0) / steps * 1e3)  # host time to enqueue a step (includes the one host sync)
+    torch.cuda.synchronize()
+    block_ms[bool(calls)].append((time.perf_counter() - t0) / steps * 1e3)
+    ops.default_context.step_calls = saved
+cur = block_ms[bool(ops.default_context.step_calls)]
+dt, issue = sorted(cur)[len(cur) // 2], sorted(issue_ms)[len(issue_ms) // 2]
 # stage times from a separate pass: the HIP events of the timer (two per C-ABI call) cost more host time than the
 # step itself at these sizes
 ops.default_context.stage_timer = ops.StageTimer()
@@ -97,7 +111,8 @@ if gstep.applicable(cam):
         gstep.step(cam, vr)
     torch.cuda.synchronize()
     graphed_ms = (time.perf_counter() - t0) / steps * 1e3
-res = {"loss": loss_kind or "weighted sum", "model_step_ms": dt, "graphed_model_step_ms": graphed_ms, "size": [n, W, H], "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
+res = {"loss": loss_kind or "weighted sum", "model_step_ms": dt, "model_step_ms_best": min(cur),
+       "blocks_ms": {("step_calls" if k else "stage_wise"): [round(x, 4) for x in v] for k, v in block_ms.items() if v}, "graphed_model_step_ms": graphed_ms, "size": [n, W, H], "host_issue_ms": issue, "fused_front_end": cfg.fused_front_end, "hip_stage_ms": sum(stages.values()), "stages": {k: round(v, 4) for k, v in stages.items()}}
 if os.environ.get("FG_MODEL_PROFILE"):
     from torch.profiler import ProfilerActivity, profile
 
