@@ -131,8 +131,11 @@ class GraphedModelStep:
     the reference (from step 3000, at 1/2 resolution) therefore stays eager; the 1/4-resolution phase, the most
     launch-bound one, has no deform net (``warm_up`` = 3000 = ``resolution_schedule``)."""
 
-    def __init__(self, model, loss_fn, max_tiles: int = 2200, headroom: float = 1.5,
+    def __init__(self, model, loss_fn=None, max_tiles: int = 2200, headroom: float = 1.5,
                  ctx: Optional[ops.RasterContext] = None):  # fmt: skip
+        # loss_fn None (or harness.main_loss itself): the model's own objective, (1 - l) L1 + l (1 - SSIM) with l =
+        # model.config.ssim_lambda -- the same one the eager branch of harness.train_step gets from get_loss_dict, so
+        # the objective does not change where the schedule leaves the graphed resolutions
         self.model, self.loss_fn = model, loss_fn
         self.max_tiles, self.headroom = int(max_tiles), float(headroom)
         self.ctx = ctx if ctx is not None else ops.current()
@@ -163,12 +166,20 @@ class GraphedModelStep:
         # the storage of EVERY Gaussian parameter: densification re-allocates all of them, the opacity reset
         # (freegaussian_model.py:475-490, `.data = clamp(...)`) only one -- a graph must never read a stale one
         ptrs = tuple(p.data_ptr() for p in m.gauss_params.values())
-        return (m.num_points, ptrs, W, H, deg, m.step >= m.config.warm_up, m._render_mode(), m.config.background_color)
+        return (m.num_points, ptrs, W, H, deg, m.step >= m.config.warm_up, m._render_mode(), m.config.background_color,
+                float(m.config.ssim_lambda))  # (the lambda is baked into the captured loss kernels' arguments)
+
+    def _loss(self, rgb, gt):
+        from . import harness
+
+        if self.loss_fn is None or self.loss_fn is harness.main_loss:
+            return harness.main_loss(rgb, gt, self.model.config.ssim_lambda)
+        return self.loss_fn(rgb, gt)
 
     def _forward_backward(self):
         m, st = self.model, self.static
         out = m._outputs_from(st["viewmat"], st["K"], st["W"], st["H"], st["times"])
-        loss = self.loss_fn(out["rgb"], st["gt"])
+        loss = self._loss(out["rgb"], st["gt"])
         loss.backward()
         return out, loss
 
@@ -237,7 +248,7 @@ class GraphedModelStep:
             self._capture()
             self.graph.replay()
         with torch.no_grad():  # the value, outside the graph (in-graph reductions are not replay-safe: docstring)
-            loss = self.loss_fn(st["out"]["rgb"], st["gt"])
+            loss = self._loss(st["out"]["rgb"], st["gt"])
         return st["out"], loss
 
     def release(self) -> None:

@@ -99,7 +99,7 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     ``dp=viewdp.ModelViewDP(model)`` (the factored exchange: colour gradients all-gathered as 12-24 B per Gaussian from
     inside the backward, the rest one all-reduce of a flat buffer the gradients are views of) or
     ``grad_sync=viewdp.all_reduce_model_grads`` (one all-reduce of everything), and ``stats_sync=viewdp.sync_densify_stats``.
-    ``graphed``: a ``graphed.GraphedModelStep(model, main_loss)``: while the scheduled resolution is
+    ``graphed``: a ``graphed.GraphedModelStep(model)`` (its loss is the model's: ``main_loss`` with ``config.ssim_lambda``): while the scheduled resolution is
     launch-bound (the reference's first 6000 steps at 1/4 and 1/2 resolution) get_outputs + loss + backward
     replay as one hipGraph; the rest of the step is unchanged.  ``mask`` [H,W,1]: the batch's optional mask
     (freegaussian_model.py:956-963).  The loss is the sum of ``model.get_loss_dict`` (main loss + the optional

@@ -38,9 +38,10 @@ class FusedAdam(torch.optim.Adam):
         return loss
 
     def _collect(self):
-        """Advance the step counters and return [(p, g, m, v, lr, beta1, beta2, eps, step)] of this optimizer's update;
-        the tensors in it are kept alive by the caller until the launch is enqueued."""
-        work = []
+        """Return [(p, g, m, v, lr, beta1, beta2, eps, step)] of this optimizer's update and advance the step counters --
+        after everything has been validated, so an error leaves no counter ahead of its moments.  The tensors in the list
+        are kept alive by the caller until the launch is enqueued."""
+        todo = []
         for group in self.param_groups:
             if group.get("weight_decay", 0) != 0 or group.get("amsgrad", False) or group.get("maximize", False):
                 raise _lib.FgRasterError("FusedAdam implements torch.optim.Adam's defaults (no weight decay / amsgrad / maximize)")
@@ -49,22 +50,29 @@ class FusedAdam(torch.optim.Adam):
             for p in group["params"]:
                 if p.grad is None:
                     continue
-                g = p.grad
-                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or g.is_sparse:
+                if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()) or p.grad.is_sparse:
                     raise _lib.FgRasterError("FusedAdam updates dense contiguous float32 parameters on the GPU")
-                st = self.state[p]
-                if len(st) == 0:  # (as torch: a host-side step counter, moments like the parameter)
-                    st["step"] = torch.tensor(0.0, dtype=torch.float32)
-                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
-                st["step"] += 1
-                m, v = st["exp_avg"], st["exp_avg_sq"]
-                if not (m.is_contiguous() and v.is_contiguous()):  # (state surgery may leave views behind)
-                    m, v = st["exp_avg"], st["exp_avg_sq"] = m.contiguous(), v.contiguous()
-                g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
-                if g.data_ptr() % 16:  # (a view into a flat gradient buffer -- viewdp.FlatGaussianParams -- at an odd offset)
-                    g = g.clone()
-                work.append((p, g, m, v, lr, float(beta1), float(beta2), eps, int(st["step"])))
+                if p.data_ptr() % 16:
+                    raise _lib.FgRasterError("FusedAdam: a parameter's storage must start on a 16-byte boundary (a view into a "
+                                             "flat buffer at an odd offset: pad the views, as viewdp.ModelViewDP does)")
+                todo.append((p, lr, float(beta1), float(beta2), eps))
+        work = []
+        for p, lr, beta1, beta2, eps in todo:
+            st = self.state[p]
+            if len(st) == 0:  # (as torch: a host-side step counter, moments like the parameter)
+                st["step"] = torch.tensor(0.0, dtype=torch.float32)
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.preserve_format)
+            m, v = st["exp_avg"], st["exp_avg_sq"]
+            if not (m.is_contiguous() and v.is_contiguous()) or m.data_ptr() % 16 or v.data_ptr() % 16:
+                # (state surgery may leave views behind)
+                m, v = st["exp_avg"], st["exp_avg_sq"] = m.contiguous().clone(), v.contiguous().clone()
+            g = p.grad
+            g = g.contiguous() if g.dtype == torch.float32 else g.float().contiguous()
+            if g.data_ptr() % 16:  # (a view into a flat gradient buffer -- viewdp.FlatGaussianParams -- at an odd offset)
+                g = g.clone()
+            st["step"] += 1
+            work.append((p, g, m, v, lr, beta1, beta2, eps, int(st["step"])))
         return work
 
 
@@ -79,11 +87,15 @@ def _launch(work) -> None:
 def step_all(optimizers) -> None:
     """``step()`` of every optimizer; the tensors of all ``FusedAdam`` instances among them go into ONE launch (every 16
     tensors one: ``fg_adam_step_multi``) -- the reference's six Gaussian parameter groups are six optimizers of one tensor
-    each, and at its low resolutions an iteration is bound by launches."""
+    each, and at its low resolutions an iteration is bound by launches.  This is the harness's own shortcut: it goes
+    past ``Optimizer.step``'s wrapper, so step pre/post hooks registered on a FusedAdam do not run here (a trainer that
+    relies on them calls ``FusedAdam.step()`` per optimizer, as INTEGRATION.md shows for nerfstudio); ``_opt_called``
+    is set, so torch's LR schedulers see the call order they check for."""
     work, others = [], []
     for o in optimizers:
         if isinstance(o, FusedAdam):
             work += o._collect()
+            o._opt_called = True
         else:
             others.append(o)
     if work:

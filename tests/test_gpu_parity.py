@@ -1994,6 +1994,39 @@ def test_graph_replays_with_classic_forward_and_listed_backward(live, monkeypatc
         del r0, a0
 
 
+def test_graphed_step_optimises_the_models_own_objective():
+    """config.ssim_lambda != 0.2: the graphed branch of harness.train_step and the eager one compute the
+    same loss -- (1 - l) L1 + l (1 - SSIM) with the model's l -- so its gradients equal the eager gradients of
+    get_loss_dict, and differ from those of the hard-coded 0.2."""
+    import copy
+
+    from freegaussian_amd import harness as Hn
+    from freegaussian_amd.graphed import GraphedModelStep
+
+    grads = {}
+    for kind in ("eager", "graphed", "eager_0.2"):
+        torch.manual_seed(5)
+        model, _, cam = _model_and_camera(n=4000, W=320, H=192, step=1, training=True)
+        model.config.ssim_lambda = 0.6
+        model.config.background_color = "black"
+        gt = torch.rand(192, 320, 3, generator=torch.Generator().manual_seed(9)).to(DEV)
+        model.step_cb(1)
+        if kind == "graphed":
+            g = GraphedModelStep(model)
+            assert g.applicable(cam)
+            g.step(copy.deepcopy(cam), gt)
+        else:
+            out = model.get_outputs(copy.deepcopy(cam))
+            if kind == "eager":
+                model.get_loss_dict(out, {"image": gt})["main_loss"].backward()
+            else:
+                Hn.main_loss(out["rgb"], gt).backward()
+        grads[kind] = {k: v.grad.detach().clone() for k, v in model.gauss_params.items()}
+    for k in ("means", "features_dc", "opacities", "scales"):
+        assert rel_l2(grads["graphed"][k], grads["eager"][k]) < 1e-5, k
+    assert rel_l2(grads["eager_0.2"]["features_dc"], grads["eager"]["features_dc"]) > 1e-2
+
+
 def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
     """harness.train_step(graphed=GraphedModelStep(...)): get_outputs + loss + backward replayed as one hipGraph
     at a launch-bound size, against the eager step: 200 steps with a refinement at step 100 (the Gaussian set is
