@@ -45,7 +45,7 @@ SIGNATURES = {
     "fg_stbin_fill_workspace_bytes": (c_size_t, [c_int64]),
     "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, P]),
     "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
-                                   c_int, P, c_int, P]),
+                                   c_int, P, c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_densify_stats": (c_int, [c_int, P, P, c_float, P, P, P, P]),
     "fg_adam_step_multi": (c_int, [c_int, P, P]),  # (count, fg_adam_tensor[count], stream)
@@ -117,7 +117,7 @@ class RasterConfig(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int32) for n in (
         "size", "ppt_fwd", "ppt_bwd", "tile_order", "bands_nx", "tail4_fwd", "tail2_fwd", "tail4_bwd", "tail2_bwd",
         "split4_fwd", "split2_fwd", "split4_bwd", "split2_bwd", "use_liveness", "seg_parts", "seg_tail", "seg_parts2",
-        "seg_tail2", "debug_only_xcd", "debug_k_mod", "balance_bands", "heavy_tiles")]  # fmt: skip
+        "seg_tail2", "debug_only_xcd", "debug_k_mod", "balance_bands", "heavy_tiles", "seg_slots")]  # fmt: skip
 
     FIELDS = tuple(n for n, _ in _fields_)[1:]
 
@@ -153,7 +153,8 @@ class StepIO(ctypes.Structure):
         "means", "quats", "d_quats", "scales", "d_scales", "opacities", "colors", "features_rest", "extra", "viewmat", "K",
         "background", "count_out", "v_render", "v_alphas", "v_depths", "v_conics", "v_means", "v_quats", "v_d_quats",
         "v_scales", "v_d_scales", "v_opacities", "v_colors", "v_features_rest", "v_extra", "v_rgb")] + [
-        ("v_rgb_floats", ctypes.c_int32), ("ev_raster_begin", ctypes.c_void_p), ("ev_raster_end", ctypes.c_void_p)]  # fmt: skip
+        ("v_rgb_floats", ctypes.c_int32), ("ev_raster_begin", ctypes.c_void_p), ("ev_raster_end", ctypes.c_void_p),
+        ("ckpt_need_out", ctypes.c_void_p)]  # fmt: skip
 
 
 class StepLayout(ctypes.Structure):

@@ -119,6 +119,15 @@ struct JobBuild {
   int main_words;  // words of the main list: the heavy tiles' local and combine lists start there (forward list, heavy_len > 0)
   int rows_limit;
   int balance_percent;  // ... when the heaviest equal band's cost exceeds this many percent of the mean band's
+  // COMPACT CHECKPOINT SLOTS (list shares; slot_budget > 0): the checkpoint buffer has 8 x slot_budget slots, an XCD's
+  // band owns slot_budget of them, and a tile the backward may cut into shares (or a heavy tile) gets ceil(len / 64)
+  // consecutive ones -- granted from the END of the band's sequence (the positional tail first) while they last; a
+  // tile without slots runs unsplit, without checkpoints.  slot_tab[tile] = first slot or -1, written into BOTH lists
+  // at word tab_offset (every workgroup of a build computes the same grants from the same ranges).  need_out
+  // (nullable; pinned host memory or device): word xcd = the slots the band's candidates would take together, for
+  // the host to size the next buffer by.  slot_budget = 0: no table, slot index by formula (raster.hip seg_slot_base).
+  int slot_budget, tab_offset;
+  long long* need_out;
 };
 constexpr int FG_BAND_MAX_ROWS = 1024;
 
@@ -234,6 +243,42 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   __shared__ int heavy_tot[NWV];
   __shared__ int heavy_n, local_n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // compact checkpoint slots: grants first (they do not depend on the thresholds the fit loop below raises)
+  int32_t* const slot_tab = jb.slot_budget > 0 && pb.seg_parts > 1 ? jobs + jb.tab_offset : nullptr;
+  // (without a budget the pass still runs where its total is asked for: the host sizes its first compact buffer by it)
+  if (slot_tab || (jb.need_out && !bwd && pb.seg_parts > 1)) {
+    const int hl = pf.heavy_len > 0 ? pf.heavy_len : 0x7fffffff;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += NTH) {
+      const int idx = n - 1 - (base + (int)threadIdx.x);  // from the end of the sequence: the positional tail first
+      int need = 0, tile = 0;
+      if (idx >= 0) {
+        tile = band_tile(band, idx, tile_w);
+        const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+        const bool cand = len > hl || job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) > 1;
+        need = cand ? (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H : 0;
+      }
+      int incl = need;
+#pragma unroll
+      for (int k = 1; k < 64; k <<= 1) {
+        const int o = __shfl_up(incl, k);
+        if (lane >= k) incl += o;
+      }
+      if (lane == 63) wave_tot[wave] = incl;
+      __syncthreads();
+      int pos = carry + incl - need;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w)
+        if (w < wave) pos += wave_tot[w];
+      if (idx >= 0 && slot_tab) slot_tab[tile] = need > 0 && pos + need <= jb.slot_budget ? xcd * jb.slot_budget + pos : -1;
+      __syncthreads();
+      if (threadIdx.x == NTH - 1) carry = pos + need;
+      __syncthreads();
+    }
+    if (!bwd && jb.need_out && threadIdx.x == 0) __hip_atomic_store(jb.need_out + xcd, (long long)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __syncthreads();  // (the table entries of this band are read back below, by other threads than wrote them)
+  }
   // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
   // it does; the positional jobs alone always fit
   for (int round = 0; round < 12; ++round) {
@@ -241,7 +286,8 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      mine += job_count(p, idx, n, tail4, tail2, thr4, thr2, len, thr_h);
+      const bool slots = !slot_tab || slot_tab[tile] >= 0;
+      mine += p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
@@ -258,7 +304,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
         const int tile = band_tile(band, idx, tile_w);
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-        if (len > thr_h) heavy += 1 + (heavy_local_jobs(len) << 12);
+        if (len > thr_h && (!slot_tab || slot_tab[tile] >= 0)) heavy += 1 + (heavy_local_jobs(len) << 12);
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) heavy += __shfl_xor(heavy, m);
@@ -289,11 +335,14 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     if (idx < n) {
       tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      cnt = job_count(p, idx, n, tail4, tail2, thr4, thr2, len, thr_h);
-      heavy_tile = !bwd && len > thr_h;
+      const bool slots = !slot_tab || slot_tab[tile] >= 0;
+      cnt = p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
+      heavy_tile = !bwd && len > thr_h && slots;
       // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
       // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
-      if (!bwd && pb.seg_parts > 1 && job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1) flag = FG_JOB_NO_CKPT;
+      // (compact slots: a tile without slots is such a tile)
+      if (!bwd && pb.seg_parts > 1 && (slot_tab ? !slots : job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1))
+        flag = FG_JOB_NO_CKPT;
     }
     int incl = cnt;
 #pragma unroll
@@ -331,7 +380,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      if (len > thr_h) {
+      if (len > thr_h && (!slot_tab || slot_tab[tile] >= 0)) {
         const int nl = heavy_local_jobs(len);
         const int l0 = atomicAdd(&local_n, nl), h = atomicAdd(&heavy_n, 1);
         for (int j = 0; j < nl; ++j) lc[8 + xcd * FG_LOCAL_CAP + l0 + j] = tile << 8 | j;

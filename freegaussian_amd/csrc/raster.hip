@@ -240,14 +240,21 @@ __host__ __device__ __forceinline__ size_t seg_slots_offset4(int n_tiles, int wi
 // A checkpoint slot: 256 float4 (the tile's pixels, row-major) + 256 bytes (per pixel, HEAVY tiles only: the last entry
 // of the slot's 64-entry batch the pixel took, + 1; 0 = none) = 272 float4.
 constexpr int FG_SEG_SLOT4 = TILE * TILE + TILE * TILE / 16;
-// The slot of the batch that starts at list entry g = start + 64 c of `tile` (start = the tile's first entry): every
-// batch of every tile its own, the first (c = 0: a heavy tile's local composite; no checkpoint) and a short last one
-// included -- a tile of len entries has ceil(len / 64) <= floor(len / 64) + 1 batches, hence the "+ tile".
-__device__ __forceinline__ size_t seg_slot_index(int start, int tile, int g) {
-  return (size_t)(start / FG_SEG_ENTRIES) + (size_t)tile + (size_t)((g - start) / FG_SEG_ENTRIES);
+// The slot of the batch that starts at list entry g = start + 64 c of `tile` (start = the tile's first entry) is slot0 + c.
+// slot0 by formula (no table): start / 64 + tile -- every batch of every tile its own, the first (c = 0: a heavy tile's
+// prefix state; no checkpoint) and a short last one included: a tile of len entries has ceil(len / 64) <= floor(len / 64)
+// + 1 batches, hence the "+ tile"; the buffer then has n_isects / 64 + n_tiles slots.  slot0 from the job lists' table
+// (compact slots, jobs_build.h JobBuild::slot_budget): only the tiles the backward may cut into shares own slots,
+// ceil(len / 64) each; -1 = none.
+__device__ __forceinline__ int seg_slot_base(const int32_t* __restrict__ slot_tab, int start, int tile) {
+  return slot_tab ? __builtin_amdgcn_readfirstlane(slot_tab[tile]) : start / FG_SEG_ENTRIES + tile;
+}
+__device__ __forceinline__ size_t seg_slot_index(int slot0, int start, int g) {
+  return (size_t)slot0 + (size_t)((g - start) / FG_SEG_ENTRIES);
 }
 struct Segments {
   float4* ckpt;             // [slots][FG_SEG_SLOT4]; nullptr = no segmentation
+  const int32_t* slot_tab;  // compact slots: first slot per tile (-1: none), nullptr = by formula (seg_slot_base)
   const float* render_raw;  // backward only: the forward's accumulated colours [H,W,3] (C_final); with a
                             // composite epilogue they are rebuilt from the finished image instead
   int parts;                // backward: jobs per split tile (1 = whole list)
@@ -453,7 +460,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                                                 float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                 const Composite& comp, float4* __restrict__ ckpt = nullptr,
-                                                uint32_t* __restrict__ live_words = nullptr, int local_part = 0) {
+                                                uint32_t* __restrict__ live_words = nullptr, int local_part = 0,
+                                                const int32_t* __restrict__ slot_tab = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -473,7 +481,11 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   }
   if constexpr (MODE == 2) first = start + FG_HEAVY_PREFIX;
   if constexpr (MODE == 3) end = min(end, start + FG_HEAVY_PREFIX);
-  float4* const slots = (MODE != 0 || (C == 3 && NW == 1)) && ckpt ? ckpt + seg_slots_offset4(n_tiles, width, height) : nullptr;
+  const int slot0 = (MODE != 0 || (C == 3 && NW == 1)) && ckpt ? seg_slot_base(slot_tab, start, tile) : -1;
+  float4* const slots = slot0 >= 0 ? ckpt + seg_slots_offset4(n_tiles, width, height) : nullptr;
+  if constexpr (MODE != 0) {
+    if (!slots) return;  // (a heavy tile always owns slots: jobs_build.h)
+  }
   // one wavefront per workgroup (NW == 1, the mixed launches): the wave index is the constant 0 and
   // every per-wave LDS address folds into an instruction offset instead of a register
   const int lane = fg::lane_id(), wl = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6),
@@ -509,7 +521,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     // the state the prefix jobs left at entry start + FG_HEAVY_PREFIX -- in the slot of the tile's FIRST batch, which
     // nothing else uses (no checkpoint in front of the first entry; the slot of entry start + FG_HEAVY_PREFIX takes that
     // batch's local composite, then its checkpoint)
-    const float4* at = slots + seg_slot_index(start, tile, start) * FG_SEG_SLOT4;
+    const float4* at = slots + seg_slot_index(slot0, start, start) * FG_SEG_SLOT4;
     bool open = false;
 #pragma unroll
     for (int k = 0; k < PPT; ++k) {
@@ -556,7 +568,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         const int bd = min(batch + d * FG_SEG_ENTRIES, end - 1);
-        const float4* slot = slots + seg_slot_index(start, tile, bd) * FG_SEG_SLOT4;
+        const float4* slot = slots + seg_slot_index(slot0, start, bd) * FG_SEG_SLOT4;
         L[d] = slot[pix];
         lb[d] = reinterpret_cast<const uint8_t*>(slot + TILE * TILE)[pix];
       }
@@ -571,7 +583,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
           break;
         }
         // the state BEFORE the batch: the backward's checkpoint (over the local result just read)
-        if (batch > start) slots[seg_slot_index(start, tile, batch) * FG_SEG_SLOT4 + pix] = make_float4(T[0], acc[0][0], acc[0][1], acc[0][2]);
+        if (batch > start) slots[seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4 + pix] = make_float4(T[0], acc[0][0], acc[0][1], acc[0][2]);
         const float t_in = lane_select0(~done[0], T[0]);  // (finished pixels: nothing is added, nothing changes)
         acc[0][0] = fmaf(t_in, L[d].y, acc[0][0]);
         acc[0][1] = fmaf(t_in, L[d].z, acc[0][1]);
@@ -585,7 +597,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if constexpr (C == 3 && NW == 1 && MODE != 1) {
       // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
       if (slots && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
-        float4* slot = slots + seg_slot_index(start, tile, batch) * FG_SEG_SLOT4;
+        float4* slot = slots + seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4;
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
@@ -709,7 +721,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     }
     if constexpr (MODE == 1) {
       // the batch's own composite; T < 0: the pixel met the stop rule inside (the combine job walks the batch then)
-      float4* slot = slots + seg_slot_index(start, tile, batch) * FG_SEG_SLOT4;
+      float4* slot = slots + seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4;
       uint8_t* slot_last = reinterpret_cast<uint8_t*>(slot + TILE * TILE);
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
@@ -725,7 +737,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   if constexpr (MODE == 3) {
     // the state at the end of the prefix, for the local and combine jobs (T < 0: finished, or outside the image)
     if (slots && tile_offsets[tile + 1] - start > FG_HEAVY_PREFIX) {
-      float4* at = slots + seg_slot_index(start, tile, start) * FG_SEG_SLOT4;
+      float4* at = slots + seg_slot_index(slot0, start, start) * FG_SEG_SLOT4;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const bool fin = (done[k] >> lane) & 1ull;
@@ -804,7 +816,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
                         float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
-                        float4* __restrict__ zero4, long long zero_n4) {
+                        float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab) {
   __shared__ FwdShared<C, 64> sh;
   // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
   // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
@@ -827,20 +839,20 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   if constexpr (C == 3) {
     if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
       raster_fwd_body<C, 1, 1, 3>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                                  last_ids, comp, ckpt, live_words);
+                                  last_ids, comp, ckpt, live_words, 0, slot_tab);
       FG_TL_END(1, tile, strip, 1, 1);
       return;
     }
   }
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                             last_ids, comp, ckpt, live_words);
+                             last_ids, comp, ckpt, live_words, 0, slot_tab);
   else if (strip >= 4)
     raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
   FG_TL_END(1, tile, strip, 0, 1);
 }
 
@@ -862,7 +874,7 @@ raster_fwd_local_kernel(int width, int height, int tile_w, const int32_t* __rest
                         const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
                         int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
-                        uint32_t* __restrict__ live_words) {
+                        uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab) {
   __shared__ FwdShared<3, 64> sh;
   // (the eight XCD segments as ONE list: the heavy tiles sit under one or two XCDs' bands, their jobs are for the chip)
   for (int v = blockIdx.x;; v += gridDim.x) {
@@ -870,7 +882,7 @@ raster_fwd_local_kernel(int width, int height, int tile_w, const int32_t* __rest
     if (e < 0) break;
     FG_TL_BEGIN();
     raster_fwd_body<3, 4, 1, 1>(sh, e >> 8, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                                last_ids, comp, ckpt, live_words, e & 255);
+                                last_ids, comp, ckpt, live_words, e & 255, slot_tab);
     FG_TL_END(1, e >> 8, 5, 0, 1);
   }
 }
@@ -879,14 +891,14 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
                           const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                           const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
                           int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
-                          uint32_t* __restrict__ live_words) {
+                          uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab) {
   __shared__ FwdShared<3, 64> sh;
   for (int v = blockIdx.x;; v += gridDim.x) {
     const int e = job_of_all_segments(jobs, FG_HEAVY_CAP, v);
     if (e < 0) break;
     FG_TL_BEGIN();
     raster_fwd_body<3, 1, 1, 2>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                                alphas, last_ids, comp, ckpt, live_words);
+                                alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
     FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 2);
   }
 }
@@ -913,7 +925,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ last_ids,
                                                 const float* __restrict__ v_render,
                                                 const float* __restrict__ v_alphas, float* __restrict__ v_splats,
-                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, 1, 0},
+                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, nullptr, 1, 0},
                                                 int part = 0, const uint32_t* __restrict__ live_words = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
@@ -970,7 +982,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
       hi = start + c1 * FG_SEG_ENTRIES;
       from_ckpt = true;
       ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE), width, height) +
-                seg_slot_index(start, tile, hi) * FG_SEG_SLOT4;
+                seg_slot_index(seg_slot_base(seg.slot_tab, start, tile), start, hi) * FG_SEG_SLOT4;
     }
   }
   FG_TL_MARK(1);  // share bounds known
@@ -1665,6 +1677,17 @@ int seg_grid(const Cfg& c, int tile_w, int tile_h, int parts, int tail, bool lis
 int heavy_len(const Cfg& c) {
   return c.heavy_tiles > 0 ? (c.heavy_tiles < FG_HEAVY_PREFIX + 512 ? FG_HEAVY_PREFIX + 512 : c.heavy_tiles) : 0;
 }
+// seg_slots: checkpoint slots of the buffer the raster calls are given, eight equal shares of them an XCD band's (compact
+// slots: jobs_build.h JobBuild::slot_budget); 0 = one slot per 64 list entries of every tile, by formula
+int seg_slots(const Cfg& c) { return c.seg_slots > 0 ? (c.seg_slots + 7) / 8 * 8 : 0; }
+int jobs_cap(const Cfg& c, int tile_w, int tile_h);
+// words of a list in front of its table of first slots (the main list, + the heavy tiles' two lists)
+int64_t slot_table_offset(const Cfg& c, int tile_w, int tile_h) {
+  return 8 + 8 * (int64_t)jobs_cap(c, tile_w, tile_h) + (heavy_len(c) > 0 ? FG_LOCAL_WORDS + FG_HEAVY_WORDS : 0);
+}
+const int32_t* slot_table(const Cfg& c, const int32_t* jobs, int tile_w, int tile_h) {
+  return jobs && seg_slots(c) > 0 ? jobs + slot_table_offset(c, tile_w, tile_h) : nullptr;
+}
 // use_liveness = 0: the backward ignores the forward's liveness bytes (A/B)
 const uint32_t* live_use(const Cfg& c, const uint32_t* live_words) { return c.use_liveness == 0 ? nullptr : live_words; }
 // seg_tail = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
@@ -1724,21 +1747,25 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
     if (zero_fill(zero_buf, zero_floats, s) != FG_OK) return FG_ERR_LAUNCH;
     zero_buf = nullptr;
   }
+  // compact checkpoint slots (seg_slots): the tiles' first slots are in the list's table; without a list there is no
+  // table and no checkpoints
+  const int32_t* slot_tab = slot_table(cfg, jobs, tile_w, tile_h);
+  if (seg_slots(cfg) > 0 && !slot_tab) ckpt = nullptr;
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(cfg, tile_w, tile_h, tail) : mixed_grid(cfg, tile_w, tile_h, tail)),
                      dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
-                     zero_buf ? zero_floats / 4 : 0ll);
+                     zero_buf ? zero_floats / 4 : 0ll, slot_tab);
   if constexpr (C == 3) {
     // heavy tiles: their combine jobs, once every local job has left its batches' composites
     if (jobs && ckpt && heavy_len(cfg) > 0) {
       const int32_t* local = jobs + 8 + 8 * (size_t)cap;
       hipLaunchKernelGGL(raster_fwd_local_kernel, dim3(8 * 1024), dim3(64), 0, s, width, height, tile_w, local,
                          reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
-                         reinterpret_cast<float4*>(ckpt), live_words);
+                         reinterpret_cast<float4*>(ckpt), live_words, slot_tab);
       hipLaunchKernelGGL(raster_fwd_combine_kernel, dim3(8 * 256), dim3(64), 0, s, width, height, tile_w,
                          local + FG_LOCAL_WORDS, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
-                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words);
+                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab);
     }
   }
   return hipGetLastError() == hipSuccess ? FG_OK : FG_ERR_LAUNCH;
@@ -1748,7 +1775,7 @@ template <int C>
 int launch_bwd_mixed(const Cfg& cfg, int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, 1, 0},
+                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, nullptr, 1, 0},
                      const uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(cfg, tile_w, tile_h);
@@ -1871,9 +1898,12 @@ int raster_bwd_any(const fg_raster_config* config, int channels, int width, int 
     seg_ckpt = nullptr;
   }
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
-  Segments seg{nullptr, nullptr, 1, 0};
+  Segments seg{nullptr, nullptr, nullptr, 1, 0};
+  // (compact checkpoint slots: the table of the tiles' first slots is in the list; no list, no shares)
+  const int32_t* slot_tab = slot_table(cfg, jobs, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE);
+  if (seg_slots(cfg) > 0 && !slot_tab) seg_ckpt = nullptr;
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts(cfg, n_tiles) > 1)
-    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), image, seg_parts(cfg, n_tiles),
+    seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), slot_tab, image, seg_parts(cfg, n_tiles),
                    seg_tail_fit(cfg, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(cfg, n_tiles),
                                 seg_tail(cfg, n_tiles))};
 #define CALL(CC)                                                                                            \
@@ -1943,6 +1973,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->debug_k_mod = 0;
   c->balance_bands = -1;
   c->heavy_tiles = 0;
+  c->seg_slots = 0;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
@@ -1952,8 +1983,8 @@ extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, co
   const Cfg cfg = resolve(config);
   if ((tile_order_mode(cfg) & 255) != 2 || (tile_order_mode(cfg) >> 8) != 0) return 0;
   if (mixed_tail_fwd(cfg, n_tiles) == 0 && mixed_tail_bwd(cfg, n_tiles) == 0) return 0;  // classic launches: no lists
-  // (+ the heavy tiles' combine list behind the main one)
-  return 8 + 8 * (int64_t)jobs_cap(cfg, tile_w, tile_h) + (heavy_len(cfg) > 0 ? FG_LOCAL_WORDS + FG_HEAVY_WORDS : 0);
+  // (+ the heavy tiles' two lists behind the main one, + the table of the tiles' first checkpoint slots)
+  return slot_table_offset(cfg, tile_w, tile_h) + n_tiles;
 }
 
 int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares,
@@ -1982,7 +2013,8 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   const int rows_limit = band_rows_limit(cfg, tile_h);  // (the grids and list segments are sized for it: band_tiles_max)
   *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd,
                           8 + 8 * jobs_cap(cfg, tile_w, tile_h), rows_limit,
-                          cfg.balance_bands > 1 ? cfg.balance_bands : 115};
+                          cfg.balance_bands > 1 ? cfg.balance_bands : 115,
+                          shares ? seg_slots(cfg) / 8 : 0, (int)slot_table_offset(cfg, tile_w, tile_h), nullptr};
   return FG_OK;
 }
 
@@ -2016,7 +2048,8 @@ extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height
   const int n_tiles = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE);
   const Cfg cfg = resolve(config);
   if (seg_parts(cfg, n_tiles) <= 1 || mixed_tail_bwd(cfg, n_tiles) == 0 || mixed_tail_fwd(cfg, n_tiles) == 0) return 0;
-  return ((int64_t)seg_slots_offset4(n_tiles, width, height) + (n_isects / FG_SEG_ENTRIES + n_tiles + 2) * (int64_t)FG_SEG_SLOT4) * 4;
+  const int64_t slots = seg_slots(cfg) > 0 ? seg_slots(cfg) : n_isects / FG_SEG_ENTRIES + n_tiles + 2;
+  return ((int64_t)seg_slots_offset4(n_tiles, width, height) + slots * (int64_t)FG_SEG_SLOT4) * 4;
 }
 
 extern "C" int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,

@@ -1660,13 +1660,15 @@ extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32
                                   int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                                   int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
-                                  int bwd_list_shares, const fg_raster_config* config, int flags, fg_stream_t stream) {
+                                  int bwd_list_shares, const fg_raster_config* config, int flags, int64_t* ckpt_need_out,
+                                  fg_stream_t stream) {
   if (width <= 0 || height <= 0 || tile_size <= 0) return FG_ERR_INVALID_ARG;
   if ((width + tile_size - 1) / tile_size != tile_w || (height + tile_size - 1) / tile_size != tile_h)
     return FG_ERR_INVALID_ARG;
   fgjobs::JobBuild jb;
   const int rc = fgjobs::plan_jobs(width, height, tile_size, jobs_fwd, jobs_bwd, bwd_list_shares, config, &jb);
   if (rc != FG_OK) return rc;
+  jb.need_out = reinterpret_cast<long long*>(ckpt_need_out);
   return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
                     list_offsets, workspace, workspace_bytes, &jb, flags, stream);
 }

@@ -127,7 +127,7 @@ extern "C" int fg_step_fwd(const fg_step_desc* d, const fg_raster_config* config
   float* seg_ckpt = at<float>(keep, L, FG_STEP_SEG_CKPT);
   rc = fg_stbin_fill_jobs(N, depth_keys, tile_rects, tile_w, tile_h, d->capacity, tile_offsets, count_ws, flatten_ids,
                           list_offsets, at<char>(tmp, L, FG_STEP_FILL_WS), (size_t)L->nbytes[FG_STEP_FILL_WS], W, H, 16, jobs,
-                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags, stream);
+                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags, io->ckpt_need_out, stream);
   if (rc != FG_OK) return rc;
   float* v_splats = at<float>(keep, L, FG_STEP_V_SPLATS);
   if (io->ev_raster_begin && hipEventRecord(static_cast<hipEvent_t>(io->ev_raster_begin), fg_hip_stream(stream)) != hipSuccess)

@@ -179,7 +179,13 @@ class RasterContext:
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
         self.heavy_calls = 0  # raster steps planned with heavy tiles on
-        self._policy_heavy = None
+        self._policy_copies = {}
+        # Compact checkpoint slots (FG_COMPACT_SLOTS=0: off): the buffer of the backward's list shares sized by what the tiles
+        # the backward may split need (reported by every list build, read one call late) instead of by the list's capacity
+        self.compact_slots = e.get("FG_COMPACT_SLOTS", "1") != "0"
+        self.last_seg_slots = 0  # what the last call with list shares ran with (0: a slot per 64 entries of the capacity)
+        self.ckpt_need = {}  # shape -> the last calls' needs (slots of the fullest XCD band)
+        self.ckpt_pending = {}  # shape -> (ring slot, generation) of the call whose report has not been read yet
         # FG_DIRECT_COUNT=0: read the list length back with a copy in the stream instead of the kernel's own
         # store into pinned host memory (A/B)
         self.direct_count = e.get("FG_DIRECT_COUNT", "1") != "0"
@@ -217,17 +223,38 @@ class RasterContext:
         # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
         self.color_grad_sink = None
 
-    def cfg(self, heavy: bool = False) -> int:
+    def cfg(self, heavy: bool = False, seg_slots: int = 0) -> int:
         """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
-        ``heavy_tiles`` set (unless the policy sets it itself)."""
-        if not heavy or self.policy.heavy_tiles > 0:
+        ``heavy_tiles`` set (unless the policy sets it itself); ``seg_slots`` > 0: with compact checkpoint slots, that many.
+        The copies live as long as the context: autograd nodes and cached step plans hold their addresses."""
+        heavy_len = self.heavy_tile_len if heavy and self.policy.heavy_tiles <= 0 else 0
+        if self.policy.seg_slots > 0:
+            seg_slots = 0  # (the policy's own value stands)
+        if not heavy_len and seg_slots <= 0:
             return self.policy.ptr()
-        src = bytes(self.policy)  # (the policy may have been replaced or changed in place since the copy was made)
-        if self._policy_heavy is None or self._policy_heavy[0] != src or self._policy_heavy[1].heavy_tiles != self.heavy_tile_len:
+        key = (bytes(self.policy), heavy_len, int(seg_slots))  # (the policy may have been replaced or changed in place)
+        copy = self._policy_copies.get(key)
+        if copy is None:
             copy = type(self.policy).from_buffer_copy(self.policy)
-            copy.heavy_tiles = self.heavy_tile_len
-            self._policy_heavy = (src, copy)
-        return self._policy_heavy[1].ptr()
+            if heavy_len:
+                copy.heavy_tiles = heavy_len
+            if seg_slots > 0:
+                copy.seg_slots = int(seg_slots)
+            self._policy_copies[key] = copy
+        return copy.ptr()
+
+    def seg_slots_for(self, lkey, capacity: int, n_tiles: int) -> int:
+        """Compact checkpoint slots for the next call of a shape (fg_raster_config::seg_slots), from what the list builds
+        of its last calls reported (fg_stbin_fill_jobs' ckpt_need_out): 8 x the fullest XCD band's need + an eighth, in
+        steps of 4096 slots; 0 (a slot per 64 entries of the list's capacity) while nothing is known or when that would
+        not be smaller."""
+        hist = self.ckpt_need.get(lkey) if self.compact_slots else None
+        if not hist:
+            return 0
+        per = int(max(hist) * 1.125) + 32
+        slots = -(-8 * per // 4096) * 4096
+        self.last_seg_slots = slots if slots < 0.9 * (capacity // 64 + n_tiles + 2) else 0
+        return self.last_seg_slots
 
 
 _default_context: Optional[RasterContext] = None
@@ -461,27 +488,49 @@ _count_ring_np = None
 _count_ring_next = 0
 _count_ring_lock = threading.Lock()
 _count_ring_stream = [None] * _COUNT_RING  # the stream the store into slot i was enqueued on
+_count_ring_gen = [0] * _COUNT_RING  # times slot i has been handed out
+_RING_WORDS = 16  # int64 words per slot
 
 
 def _count_slot():
-    """A slot of four pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
-    segment, [2] the longest tile list (fg_stbin_count only; they stay -1 otherwise), [3] unused."""
+    """A slot of sixteen pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
+    segment, [2] the longest tile list (fg_stbin_count only; they stay -1 otherwise), [4..11] the checkpoint slots the
+    eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late).  -> (slot, address)."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
         if _count_ring is None:
-            _count_ring = torch.empty(4 * _COUNT_RING, dtype=torch.int64, pin_memory=True)
+            _count_ring = torch.empty(_RING_WORDS * _COUNT_RING, dtype=torch.int64, pin_memory=True)
             _count_ring_np = _count_ring.numpy()
         i = _count_ring_next
         _count_ring_next = (i + 1) % _COUNT_RING
-    _count_ring_np[4 * i : 4 * i + 4] = -1
+        _count_ring_gen[i] += 1
+    _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 12] = -1
     _count_ring_stream[i] = torch.cuda.current_stream()
-    return i, _count_ring.data_ptr() + 32 * i
+    return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
+
+
+def _note_ckpt_need(rctx, lkey, count_slot, reported: bool) -> None:
+    """Read the checkpoint-slot needs the PREVIOUS call of this shape reported (they have landed: this call's list length,
+    which the caller has just waited for, was stored behind them), remember this call's slot for the next."""
+    prev = rctx.ckpt_pending.pop(lkey, None)
+    if prev is not None and _count_ring_gen[prev[0]] == prev[1]:
+        words = _count_ring_np[_RING_WORDS * prev[0] + 4 : _RING_WORDS * prev[0] + 12]
+        if int(words.min()) >= 0:
+            hist = rctx.ckpt_need.setdefault(lkey, [])
+            hist.append(int(words.max()))
+            del hist[:-8]
+            if len(rctx.ckpt_need) > 256:
+                rctx.ckpt_need.pop(next(iter(rctx.ckpt_need)))
+    if reported:
+        if len(rctx.ckpt_pending) > 256:
+            rctx.ckpt_pending.clear()
+        rctx.ckpt_pending[lkey] = (count_slot, _count_ring_gen[count_slot])
 
 
 def _poll_count(i: int, word: int = 0) -> int:
     """Spin on a word of ring slot i until the kernel's system-scope store arrives (it does while the GPU is
     still busy with the emission and the tile sort: the wait is microseconds).  No event in the stream."""
-    a, j = _count_ring_np, 4 * i + word
+    a, j = _count_ring_np, _RING_WORDS * i + word
     v = int(a[j])
     if v >= 0:
         return v
@@ -659,7 +708,7 @@ def _note_list_length(rctx, key, n_isects: int) -> int:
     return n_isects
 
 
-def _note_counts(rctx, lkey, key, count_slot) -> int:
+def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> int:
     """Wait for the three words fg_stbin_count stores into pinned host memory (list length, longest supertile segment,
     longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
     binning, the heavy-tile policy of the raster.  -> the list length."""
@@ -674,6 +723,7 @@ def _note_counts(rctx, lkey, key, count_slot) -> int:
             shapes[lkey] -= 1
             if shapes[lkey] <= 0:
                 del shapes[lkey]
+    _note_ckpt_need(rctx, lkey, count_slot, need_reported)
     return _note_list_length(rctx, key, n_isects)
 
 
@@ -687,14 +737,16 @@ def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list, cfgp=None
     return n_ck if n_ck > 0 and 4 * n_ck <= rctx.seg_ckpt_budget_bytes else 0
 
 
-def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False):
+def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None):
     """(jobs[2, words], bwd_list_shares, key, cfg) for fg_stbin_fill_jobs, or None when the raster launches of this size /
     config take no lists.  ``key`` is what _RasterSplats.forward compares before it trusts the lists; ``cfg`` the address
-    of the launch policy they were planned with (``heavy``: heavy tiles on), which both raster calls must be given."""
+    of the launch policy they were planned with (``heavy``: heavy tiles on; compact checkpoint slots when the shape
+    ``lkey``'s needs are known), which both raster calls must be given."""
     if raster_hint is None:
         return None
     channels, width, height = (int(v) for v in raster_hint)
-    cfgp = rctx.cfg(heavy)
+    n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
+    cfgp = rctx.cfg(heavy, rctx.seg_slots_for(lkey, n_list, n_tiles) if lkey is not None and channels == 3 else 0)
     words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
@@ -722,6 +774,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
     lkey = (dev, N, tile_w, tile_h)
+    need_reported = [False]
 
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
@@ -733,13 +786,15 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
         flags = _lib.STBIN_LONG_SEGMENTS if long_mode else 0
         rctx.long_calls += int(long_mode)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
-        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy) if rctx.jobs_in_fill else None
+        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy, lkey) if rctx.jobs_in_fill else None
         if prebuilt is None:
             _call(abi + "_fill", *args, flags, _stream(), stage="fg_bin_emit_sort_capacity")
         else:
             jobs, shares, cfgp = prebuilt[0], prebuilt[1], prebuilt[3]
+            need_ptr = count_ptr + 32 if count_ptr is not None else None  # (words 4..11 of the ring slot)
+            need_reported[0] = need_ptr is not None and shares
             _call(abi + "_fill_jobs", *args, int(raster_hint[1]), int(raster_hint[2]), TILE_SIZE, _ptr(jobs[0]),
-                  _ptr(jobs[1]), int(shares), cfgp, flags, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
+                  _ptr(jobs[1]), int(shares), cfgp, flags, need_ptr, _stream(), stage="fg_bin_emit_sort_capacity")  # fmt: skip
         offsets._fg_jobs = prebuilt  # (for _RasterSplats.forward; None: it builds the lists itself)
         return ids
 
@@ -765,7 +820,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
 
     def finish():
         if count_slot is not None:
-            n_isects = _note_counts(rctx, lkey, key, count_slot)
+            n_isects = _note_counts(rctx, lkey, key, count_slot, need_reported[0])
         else:
             ready.synchronize()
             n_isects = _note_list_length(rctx, key, int(count_host[0]))
@@ -1312,17 +1367,17 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_jobs_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(ctx.jobs_bwd), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas),
                   _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), _ptr(seg_ckpt),
-                  _ptr(image), _ptr(live), ctx.rctx.cfg(), _stream(),
+                  _ptr(image), _ptr(live), ctx.cfgp, _stream(),
                   stage="fg_raster_composite_bwd" if composite else "fg_raster_bwd")  # fmt: skip
             ctx.jobs_bwd = None
         elif composite:
             _call("fg_raster_composite_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(background), n_clamp, _ptr(clamp_mask), _ptr(alphas), _ptr(last_ids),
-                  _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
+                  _ptr(v_render.contiguous()), _ptr(v_alphas), _ptr(v_splats), ctx.cfgp, _stream())  # fmt: skip
         else:
             _call("fg_raster_bwd", C, width, height, tile_size, _ptr(splats), _ptr(tile_offsets), _ptr(flatten_ids),
                   _ptr(alphas), _ptr(last_ids), _ptr(v_render.contiguous()), _ptr(v_alphas),
-                  _ptr(v_splats), ctx.rctx.cfg(), _stream())  # fmt: skip
+                  _ptr(v_splats), ctx.cfgp, _stream())  # fmt: skip
         if ctx.rctx.color_grad_sink is not None and C >= 3:
             ctx.rctx.color_grad_sink("records", splats, v_splats)  # (view-DP: the colour gradient can leave now)
         # strided views of the record array: no 64 MB re-read just to compact 8 bytes per row
@@ -1437,9 +1492,10 @@ class _RasterStep(torch.autograd.Function):
         lkey, ckey = (dev, N, tile_w, tile_h), (dev, N, tile_w, tile_h, "fg_stbin")
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
-        cfgp = rctx.cfg(heavy)
         capacity = rctx.isect_capacity[ckey]
         while True:
+            seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h) if channels == 3 and want_backward else 0
+            cfgp = rctx.cfg(heavy, seg_slots)
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
                    n_clamp, int(want_backward), int(shares), _lib.STBIN_LONG_SEGMENTS if long_mode else 0, capacity, eps2d,
@@ -1453,6 +1509,7 @@ class _RasterStep(torch.autograd.Function):
             io.means, io.quats, io.d_quats, io.scales, io.d_scales = _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(scales), _ptr(d_scales)
             io.opacities, io.colors, io.features_rest, io.extra = _ptr(opacities), _ptr(colors), _ptr(features_rest), _ptr(extra)
             io.viewmat, io.K, io.background, io.count_out = _ptr(viewmat), _ptr(K), _ptr(background), count_ptr
+            io.ckpt_need_out = count_ptr + 32 if shares else None
             st = rctx.stage_timer
             ev = st.record("fg_raster_fwd") if st is not None else None
             if ev:  # (the library records them around its raster launch)
@@ -1484,7 +1541,7 @@ class _RasterStep(torch.autograd.Function):
             last_ids = view(i32, "last_ids", (height, width), (width, 1))
             splats = view(k32, "splats", (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1))
             list_offsets = view(i32, "list_offsets", (tile_w * tile_h + 1,), (1,))
-            n_isects = _note_counts(rctx, lkey, ckey, count_slot)
+            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares)
             if n_isects <= capacity:
                 break
             rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length

@@ -251,6 +251,15 @@ typedef struct fg_raster_config {
                               backward gives such a tile up to 64 shares.  For scenes with unsaturated lists of thousands
                               of entries (a host turns it on when fg_stbin_count's count_out[2] says so); not bit-identical
                               to the serial walk (1e-7 relative).  <= 0 = off (default); values below 2560 mean 2560 */
+  int32_t seg_slots;       /* list segments, job lists (ABI 7): COMPACT checkpoint slots -- the buffer of
+                              fg_raster_seg_ckpt_floats holds this many slots (4352 B each; rounded up to a multiple of 8)
+                              instead of one per 64 entries of the list's capacity: only the tiles the backward may cut
+                              into shares own slots, ceil(list length / 64) each, granted by the list build per XCD band
+                              (an eighth of the slots each) from the end of the band's sequence while they last; a tile
+                              without slots runs as one job, without checkpoints -- slower, never wrong.  What the bands
+                              would take together is reported by fg_stbin_fill_jobs (ckpt_need_out): size the next call's
+                              buffer as 8 x the largest word + a margin.  The SAME value must reach the list build, the size
+                              query and both raster calls.  <= 0 = off (default): a slot per 64 entries of every tile */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 
@@ -325,12 +334,17 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
  * between the sorted lists and fg_raster_jobs_fwd (10 us of a 0.75 ms step on the 1M / 1080p scene).  width, height,
  * tile_size must give tile_w x tile_h; jobs_fwd / jobs_bwd / bwd_list_shares / config as for fg_raster_build_jobs
  * (both lists NULL: identical to fg_stbin_fill).  The lists depend on tile_offsets only: they stay valid when the
- * call is repeated with a larger capacity. */
+ * call is repeated with a larger capacity.
+ * ckpt_need_out (nullable; int64[8], pinned host memory or device memory, written by the launch): with
+ * bwd_list_shares and a forward list, word x = the checkpoint slots the tiles of XCD x's band that the backward may
+ * split would take together (whether or not they got them; whatever fg_raster_config::seg_slots is): 8 x the largest
+ * word, + a margin, is the seg_slots that leaves no tile without. */
 int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                        int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                        int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                        int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
-                       int bwd_list_shares, const fg_raster_config* config, int flags, fg_stream_t stream);
+                       int bwd_list_shares, const fg_raster_config* config, int flags, int64_t* ckpt_need_out,
+                       fg_stream_t stream);
 int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,
@@ -528,6 +542,7 @@ typedef struct fg_step_io {
      backward call: the raster backward): a host that times the dominant kernel of the step does not have to take the
      stage-wise entry points for it */
   void *ev_raster_begin, *ev_raster_end;
+  int64_t* ckpt_need_out; /* nullable, forward only: fg_stbin_fill_jobs' ckpt_need_out (int64[8]) */
 } fg_step_io;
 typedef struct fg_step_layout {
   int64_t keep_bytes, tmp_bytes;

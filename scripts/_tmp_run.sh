@@ -1,5 +1,10 @@
-python scripts/host_issue.py 100000 480 270 300
-python scripts/host_issue.py 1000000 1920 1080 100
-FG_MODEL_AB=1 python scripts/model_step_bench.py 100000 200 480 270 2>/dev/null | tr -d '\n' | cut -c1-560; echo
-FG_MODEL_AB=1 python scripts/model_step_bench.py 300000 100 960 540 2>/dev/null | tr -d '\n' | cut -c1-560; echo
-python -m pytest tests -m gpu -x -q -k "one_call or model or densify or step or rasteriz" 2>&1 | tail -3
+for i in 1 2; do
+for c in 1 0; do
+FG_COMPACT_SLOTS=$c python bench.py --no-clustered --steps 100 2>/dev/null | tail -1 > gpurun_out/bench_ab_${c}_$i.json
+python - <<PY
+import json
+d=json.load(open('gpurun_out/bench_ab_${c}_$i.json'))
+print('compact=$c', round(d['value'],1), round(d['ms_per_step'],4), round(d['hip_event_mpix_per_s'],1), d['stage_ms'], d['host_step_ms'])
+PY
+done
+done

@@ -24,7 +24,7 @@ lens = torch.diff(offs.reshape(-1).cpu())
 cfgp = offs._fg_jobs[3]
 words = int(_lib.load().fg_raster_jobs_words(1920, 1080, 16, cfgp))
 LOCAL_WORDS, HEAVY_WORDS = 8 + 8 * 8192, 8 + 8 * 2048
-main_words = words - LOCAL_WORDS - HEAVY_WORDS
+main_words = words - LOCAL_WORDS - HEAVY_WORDS - 120 * 68  # (behind them: the table of first checkpoint slots, a word per tile)
 cap = (main_words - 8) // 8
 print("main jobs per XCD", jobs[:8].tolist())
 print("local jobs per XCD", jobs[main_words : main_words + 8].tolist())

@@ -29,6 +29,18 @@ def test_header_symbols_are_bound_and_exported():
     assert set(_lib.SIGNATURES) == set(syms)
 
 
+_POLICIES = []
+
+
+def _policy_ptr(**fields):
+    """Address of a launch policy that stays alive (RasterConfig.ptr() is the address of the Python object's buffer: a
+    temporary would be freed before the call it is an argument of)."""
+    from freegaussian_amd import ops
+
+    _POLICIES.append(ops.launch_policy(**fields))
+    return _POLICIES[-1].ptr()
+
+
 def test_abi_version_and_error_strings():
     lib = _lib.load()
     assert lib.fg_abi_version() == _lib.ABI_VERSION
@@ -44,12 +56,19 @@ def test_workspace_queries_need_no_gpu():
     n = 5_000_000
     assert lib.fg_sort_workspace_bytes(n) >= n * 12
     # job lists: none below 200 tiles (classic launches), 8 counters + 8 segments of 8 entries per
-    # tile of the largest XCD band otherwise -- a band balanced by content holds up to 1.5 x the equal share of rows
+    # tile of the largest XCD band otherwise -- a band balanced by content holds up to 1.5 x the equal share of rows --
+    # + a word per tile (the table of first checkpoint slots, fg_raster_config::seg_slots)
     assert lib.fg_raster_jobs_words(208, 144, 16, None) == 0  # 13 x 9 = 117 tiles
-    assert lib.fg_raster_jobs_words(480, 270, 16, None) == 8 + 8 * 8 * 5 * 30  # 30 x 17 tiles: bands of up to 3 (+ 2) rows
-    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) == 8 + 8 * 8 * 14 * 120
+    assert lib.fg_raster_jobs_words(480, 270, 16, None) == 8 + 8 * 8 * 5 * 30 + 30 * 17  # bands of up to 3 (+ 2) rows
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, None) == 8 + 8 * 8 * 14 * 120 + 120 * 68
     from freegaussian_amd import ops
-    assert lib.fg_raster_jobs_words(1920, 1080, 16, ops.launch_policy(balance_bands=0).ptr()) == 8 + 8 * 8 * 9 * 120
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, _policy_ptr(balance_bands=0)) == 8 + 8 * 8 * 9 * 120 + 120 * 68
+    # checkpoint buffer of the list shares: a slot (4352 B) per 64 entries of the list's capacity and per tile, or -- compact
+    # slots -- as many as the policy says; in front of them the strip table and the T_final plane
+    full = lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 6_400_000, None)
+    policy = ops.launch_policy(seg_slots=40960)  # (kept alive across the call: ptr() is the object's own address)
+    compact = lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 6_400_000, policy.ptr())
+    assert full - compact == (6_400_000 // 64 + 8160 + 2 - 40960) * 1088 and compact * 4 < 190e6 < 470e6 < full * 4
     assert lib.fg_raster_jobs_words(1920, 1080, 8, None) == 0  # unsupported tile size
     assert lib.fg_raster_build_jobs(1920, 1080, 16, None, None, None, 0, None, None) == -1
 
@@ -99,12 +118,65 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_adam_step(16, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == -1
     assert lib.fg_adam_step(0, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == 0
     # fill with job lists: the image must give the tile grid
-    assert lib.fg_stbin_fill_jobs(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, 0, None) == -1
+    assert lib.fg_stbin_fill_jobs(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, 0, None, None) == -1
     # ... and (ABI 7) the flags word holds FG_STBIN_LONG_SEGMENTS or nothing; the workspace has room for the long
     # segments' bucket tables (40 bytes per bucket, a bucket per 1536 list entries + one per possible long segment)
     assert lib.fg_stbin_fill(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 2, None) == -1
     assert lib.fg_stbin_fill_workspace_bytes(1 << 23) >= 2 * 8 * (1 << 23) + 40 * ((1 << 23) // 1536 + (1 << 23) // 7936)
     assert _lib.STBIN_LONG_SEGMENTS == 1
+
+
+def test_step_api_layout_and_argument_validation_without_gpu():
+    """fg_step_* (ABI 7): one workspace query per step shape, every buffer 256-byte aligned inside the two
+    caller-allocated workspaces; descriptors and pointers are checked before any launch."""
+    import ctypes
+
+    from freegaussian_amd import ops
+
+    lib = _lib.load()
+    d = _lib.StepDesc()
+    d.size = ctypes.sizeof(_lib.StepDesc)
+    d.N, d.width, d.height, d.tile_size, d.raw, d.sh_degree, d.k_stored, d.n_color = 1_000_000, 1920, 1080, 16, 1, 3, 16, 3
+    d.n_clamp, d.want_backward, d.list_shares, d.capacity = 3, 1, 1, 6_400_000
+    d.eps2d, d.near_plane, d.far_plane = 0.3, 0.01, 1e10
+    L = _lib.StepLayout()
+    assert lib.fg_step_layout_query(ctypes.addressof(d), None, ctypes.addressof(L)) == 0
+    B = _lib.STEP_BUFFER
+    assert L.channels == 3 and L.jobs_words == lib.fg_raster_jobs_words(1920, 1080, 16, None)
+    assert L.seg_ckpt_floats == lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 6_400_000, None)
+    assert L.nbytes[B["render"]] == 1920 * 1080 * 3 * 4 and L.nbytes[B["flatten_ids"]] == 6_400_000 * 4
+    assert L.nbytes[B["splats"]] == L.nbytes[B["v_splats"]] == 1_000_000 * 64 and L.nbytes[B["comp"]] == 0
+    kept = [i for n, i in B.items() if n not in ("count_ws", "fill_ws")]
+    assert all(L.offset[i] % 256 == 0 for i in range(len(B)))
+    ends = sorted((L.offset[i], L.offset[i] + L.nbytes[i]) for i in kept if L.nbytes[i])
+    assert all(a[1] <= b[0] for a, b in zip(ends, ends[1:])) and ends[-1][1] <= L.keep_bytes  # disjoint, inside
+    assert L.nbytes[B["count_ws"]] == lib.fg_stbin_count_workspace_bytes(1_000_000, 120, 68)
+    assert L.nbytes[B["fill_ws"]] == lib.fg_stbin_fill_workspace_bytes(6_400_000) and L.tmp_bytes >= L.nbytes[B["count_ws"]] + L.nbytes[B["fill_ws"]]
+    # compact checkpoint slots: the same query, the policy's slots
+    Lc = _lib.StepLayout()
+    policy = ops.launch_policy(seg_slots=40960)
+    assert lib.fg_step_layout_query(ctypes.addressof(d), policy.ptr(), ctypes.addressof(Lc)) == 0
+    assert Lc.keep_bytes < L.keep_bytes - 250e6
+    # no gradient buffers without a backward
+    d.want_backward = 0
+    assert lib.fg_step_layout_query(ctypes.addressof(d), None, ctypes.addressof(Lc)) == 0
+    assert Lc.nbytes[B["v_splats"]] == Lc.nbytes[B["seg_ckpt"]] == Lc.nbytes[B["live"]] == 0
+    d.want_backward = 1
+    # rejected before any launch: a short descriptor, a raw step without SH, more clamped channels than channels, a tiny
+    # image (classic launches: the stage-wise entry points), missing pointers
+    io = _lib.StepIO()
+    for field, value, rc in (("size", 8, -1), ("sh_degree", -1, -1), ("n_clamp", 4, -1), ("capacity", 0, -1), ("tile_size", 8, -1)):
+        saved = getattr(d, field)
+        setattr(d, field, value)
+        assert lib.fg_step_layout_query(ctypes.addressof(d), None, ctypes.addressof(Lc)) == rc, field
+        setattr(d, field, saved)
+    d.width, d.height = 160, 96
+    assert lib.fg_step_layout_query(ctypes.addressof(d), None, ctypes.addressof(Lc)) == -4
+    d.width, d.height = 1920, 1080
+    assert lib.fg_step_layout_query(None, None, ctypes.addressof(L)) == -1
+    assert lib.fg_step_layout_query(ctypes.addressof(d), None, None) == -1
+    assert lib.fg_step_fwd(ctypes.addressof(d), None, ctypes.addressof(io), None, None, ctypes.addressof(L), None) == -1
+    assert lib.fg_step_bwd(ctypes.addressof(d), None, None, None, ctypes.addressof(L), None) == -1
 
 
 def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):
@@ -129,8 +201,8 @@ def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):
     forced = ops.launch_policy_from_env()
     assert forced.ppt_fwd == 1 and forced.ppt_bwd == 1
     assert lib.fg_raster_jobs_words(1920, 1080, 16, forced.ptr()) == 0
-    assert lib.fg_raster_jobs_words(1920, 1080, 16, ops.launch_policy(bands_nx=8).ptr()) == 8 + 8 * 8 * 15 * 68
-    assert lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 10**6, ops.launch_policy(seg_parts=1).ptr()) == 0
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, _policy_ptr(bands_nx=8)) == 8 + 8 * 8 * 15 * 68 + 120 * 68
+    assert lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 10**6, _policy_ptr(seg_parts=1)) == 0
     assert lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, 10**6, None) > 0
     env = {"FG_RASTER_TAIL_BWD": "7,9", "FG_RASTER_SPLIT_BWD": "2", "FG_RASTER_LIVE": "0", "FG_TILE_ORDER": "rows",
            "FG_RASTER_SEG_GRADE": "8,100", "FG_DEBUG_ONLY_XCD": "3"}  # fmt: skip

@@ -542,9 +542,9 @@ def test_job_lists_built_inside_the_fill_equal_those_of_the_separate_launch(size
                 assert shares == (budget_mb > 0 and int(_lib.load().fg_raster_seg_ckpt_floats(3, W, H, 16, ids.numel(), ctx.cfg())) > 0)
                 ref = torch.zeros_like(jobs)
                 ops._call("fg_raster_build_jobs", W, H, 16, ops._ptr(offs), ops._ptr(ref[0]), ops._ptr(ref[1]), int(shares),
-                          ctx.cfg(), ops._stream())  # fmt: skip
+                          _cfgp, ops._stream())  # fmt: skip
                 torch.cuda.synchronize()
-                cap = (words - 8) // 8
+                cap = (words - 8 - tw * th) // 8  # (behind the eight segments: the table of first checkpoint slots)
                 for l in range(2):
                     assert torch.equal(jobs[l, :8], ref[l, :8]), "jobs per XCD differ"
                     for x in range(8):
@@ -1378,6 +1378,58 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
     assert all(v < 1e-5 for v in diff.values()), diff
 
 
+@pytest.mark.parametrize("step_calls", [True, False])
+def test_compact_checkpoint_slots_same_gradients_a_fraction_of_the_buffer(step_calls):
+    """Compact checkpoint slots (fg_raster_config::seg_slots, VERDICT r3 #5): the list build reports what the tiles the
+    backward may split need, the host sizes the NEXT call's buffer by that -- slots for those tiles only, first slot per
+    tile in the job lists' table -- instead of a slot per 64 entries of the list's capacity.  Same image, same gradients
+    (float atomics' order apart) as with the full buffer, through the one-call-per-direction path and the stage-wise
+    calls; with far too few slots (a policy of 64) the tiles without run unsplit: still the same gradients."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = synthetic_scene(150_000, 1920, 1080, n_views=1, sh_degree=3, seed=11, log_scale_mean=math.log(0.02))
+    raw = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+               features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, 1080, 1920, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(ctx, calls=3):
+        out = None
+        for _ in range(calls):
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+            with ops.use(ctx):
+                r, a, info = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                    t["features_rest"], vm, K, 1920, 1080, 3, absgrad=True)  # fmt: skip
+                ((r * vr).sum() + a.sum()).backward()
+            out = (r.detach(), {k: v.grad for k, v in t.items()}, int(info["raster_flatten_ids"].numel()))
+        return out
+
+    full = ops.RasterContext(env={"FG_COMPACT_SLOTS": "0"})
+    full.step_calls = step_calls
+    r_full, g_full, n_list = run(full)
+    assert full.last_seg_slots == 0  # (the needs are reported and noted all the same)
+    compact = ops.RasterContext(env={})
+    compact.step_calls = step_calls
+    r_c, g_c, _ = run(compact, calls=4)
+    lib = _lib.load()
+    (need,) = [max(v) for v in compact.ckpt_need.values()]
+    slots = compact.last_seg_slots
+    assert 0 < 8 * need <= slots < 0.9 * (n_list // 64 + 8160), (need, slots, n_list)
+    b_full = 4 * lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, n_list, full.cfg())
+    b_compact = 4 * lib.fg_raster_seg_ckpt_floats(3, 1920, 1080, 16, n_list, compact.cfg(False, slots))
+    print(f"checkpoint buffer: {b_full / 1e6:.0f} MB -> {b_compact / 1e6:.0f} MB ({slots} slots, need {need} per XCD band)")
+    assert b_compact < 0.7 * b_full
+    assert torch.equal(r_c, r_full)
+    diff = {k: rel_l2(g_c[k], g_full[k]) for k in g_full}
+    assert all(v < 1e-5 for v in diff.values()), diff
+    starved = ops.RasterContext(env={}, policy=ops.launch_policy(seg_slots=64))
+    starved.step_calls = step_calls
+    r_s, g_s, _ = run(starved)
+    assert torch.equal(r_s, r_full)
+    diff = {k: rel_l2(g_s[k], g_full[k]) for k in g_full}
+    assert all(v < 1e-5 for v in diff.values()), diff
+
+
 def test_clustered_1m_scene_lists_equal_the_oracles_through_the_long_segment_sort(monkeypatch):
     """80% of a million Gaussians in a ball of extent 0.2 at 1920 x 1080 (scripts/clustered_check.py: supertile
     segments of 16 000 ... 158 000 elements, the longest tile list 111 000 entries): csrc/stbin.hip with the long
@@ -1428,7 +1480,6 @@ def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(b
     if int(_lib.load().fg_raster_jobs_words(1920, 1080, 16, ctx.cfg())) == 0 or ctx.seg_ckpt_budget_bytes <= 0:
         pytest.skip("classic launches / no list shares in this environment")
     monkeypatch.setattr(ctx, "heavy_tile_len", 1024)
-    monkeypatch.setattr(ctx, "_policy_heavy", None)
     outs = {}
     for mode in ("always", "never"):
         monkeypatch.setattr(ctx, "heavy_tiles", mode)
