@@ -243,60 +243,91 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   __shared__ int heavy_tot[NWV];
   __shared__ int heavy_n, local_n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  // compact checkpoint slots: grants first (they do not depend on the thresholds the fit loop below raises)
+  // Compact checkpoint slots.  A CANDIDATE is a tile the backward may cut into shares (by its un-raised content
+  // threshold: a superset of what its own list ends up splitting) or a heavy tile (by the threshold as given); it needs
+  // ceil(len / 64) slots.  Normally the band's candidates fit its budget together: then every candidate has slots, the
+  // first-slot table is written by the list pass below (a second prefix sum riding in the same shuffles) and the only
+  // extra work is a sum in the first round of the fit loop.  When they do not fit, a pass of its own grants the slots
+  // from the END of the sequence (the positional tail first) and leaves the table for the other passes to read.
   int32_t* const slot_tab = jb.slot_budget > 0 && pb.seg_parts > 1 ? jobs + jb.tab_offset : nullptr;
-  // (without a budget the pass still runs where its total is asked for: the host sizes its first compact buffer by it)
-  if (slot_tab || (jb.need_out && !bwd && pb.seg_parts > 1)) {
-    const int hl = pf.heavy_len > 0 ? pf.heavy_len : 0x7fffffff;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int base = 0; base < n; base += NTH) {
-      const int idx = n - 1 - (base + (int)threadIdx.x);  // from the end of the sequence: the positional tail first
-      int need = 0, tile = 0;
-      if (idx >= 0) {
-        tile = band_tile(band, idx, tile_w);
-        const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-        const bool cand = len > hl || job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) > 1;
-        need = cand ? (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H : 0;
-      }
-      int incl = need;
-#pragma unroll
-      for (int k = 1; k < 64; k <<= 1) {
-        const int o = __shfl_up(incl, k);
-        if (lane >= k) incl += o;
-      }
-      if (lane == 63) wave_tot[wave] = incl;
-      __syncthreads();
-      int pos = carry + incl - need;
-#pragma unroll
-      for (int w = 0; w < NWV; ++w)
-        if (w < wave) pos += wave_tot[w];
-      if (idx >= 0 && slot_tab) slot_tab[tile] = need > 0 && pos + need <= jb.slot_budget ? xcd * jb.slot_budget + pos : -1;
-      __syncthreads();
-      if (threadIdx.x == NTH - 1) carry = pos + need;
-      __syncthreads();
-    }
-    if (!bwd && jb.need_out && threadIdx.x == 0) __hip_atomic_store(jb.need_out + xcd, (long long)carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __syncthreads();  // (the table entries of this band are read back below, by other threads than wrote them)
-  }
+  const bool track = slot_tab || (jb.need_out && !bwd && pb.seg_parts > 1);
+  const int hl = pf.heavy_len > 0 ? pf.heavy_len : 0x7fffffff;
+  __shared__ int need_tot[NWV];
+  __shared__ int carry_need;
+  bool all_granted = true;  // (uniform)
+  auto candidate = [&](int idx, int len) {
+    return len > 0 && (len > hl || job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) > 1);
+  };
+  // has this tile checkpoint slots?  (no table: the question is not asked -- the forward's flag goes by its own rule)
+  auto has_slots = [&](int idx, int tile, int len) {
+    return !slot_tab || (all_granted ? candidate(idx, len) : slot_tab[tile] >= 0);
+  };
   // the list must fit the launch's workgroups: raise the content thresholds (x1.5 per round) until
   // it does; the positional jobs alone always fit
   for (int round = 0; round < 12; ++round) {
-    int mine = 0;
+    int mine = 0, need = 0;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      const bool slots = !slot_tab || slot_tab[tile] >= 0;
+      const bool slots = has_slots(idx, tile, len);
       mine += p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
+      if (track && round == 0 && candidate(idx, len)) need += (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H;
     }
 #pragma unroll
-    for (int m = 1; m < 64; m <<= 1) mine += __shfl_xor(mine, m);
+    for (int m = 1; m < 64; m <<= 1) {
+      mine += __shfl_xor(mine, m);
+      need += __shfl_xor(need, m);
+    }
     __syncthreads();
-    if (lane == 0) wave_tot[wave] = mine;
+    if (lane == 0) {
+      wave_tot[wave] = mine;
+      need_tot[wave] = need;
+    }
     __syncthreads();
     int all = 0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) all += wave_tot[w];
+    if (track && round == 0 && all_granted) {
+      int all_need = 0;
+#pragma unroll
+      for (int w = 0; w < NWV; ++w) all_need += need_tot[w];
+      // (stored early: the write to pinned host memory completes while the lists are being written)
+      if (!bwd && jb.need_out && threadIdx.x == 0)
+        __hip_atomic_store(jb.need_out + xcd, (long long)all_need, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if (slot_tab && all_need > jb.slot_budget) {
+        // not enough slots for all: grants from the end of the sequence while they last
+        if (threadIdx.x == 0) carry = 0;
+        __syncthreads();
+        for (int base = 0; base < n; base += NTH) {
+          const int idx = n - 1 - (base + (int)threadIdx.x);
+          int nd = 0, tile = 0;
+          if (idx >= 0) {
+            tile = band_tile(band, idx, tile_w);
+            const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+            nd = candidate(idx, len) ? (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H : 0;
+          }
+          int incl = nd;
+#pragma unroll
+          for (int k = 1; k < 64; k <<= 1) {
+            const int o = __shfl_up(incl, k);
+            if (lane >= k) incl += o;
+          }
+          if (lane == 63) wave_tot[wave] = incl;
+          __syncthreads();
+          int pos = carry + incl - nd;
+#pragma unroll
+          for (int w = 0; w < NWV; ++w)
+            if (w < wave) pos += wave_tot[w];
+          if (idx >= 0) slot_tab[tile] = nd > 0 && pos + nd <= jb.slot_budget ? xcd * jb.slot_budget + pos : -1;
+          __syncthreads();
+          if (threadIdx.x == NTH - 1) carry = pos + nd;
+          __syncthreads();
+        }
+        all_granted = false;
+        --round;  // this round again, counted by the grants (the thresholds stay)
+        continue;
+      }
+    }
     bool fits = all <= p.max_jobs;  // uniform across the workgroup
     if (!bwd && thr_h != 0x7fffffff) {
       // (a pass of its own: the build rides in a 1024-thread launch, 128 registers)
@@ -304,7 +335,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
         const int tile = band_tile(band, idx, tile_w);
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-        if (len > thr_h && (!slot_tab || slot_tab[tile] >= 0)) heavy += 1 + (heavy_local_jobs(len) << 12);
+        if (len > thr_h && has_slots(idx, tile, len)) heavy += 1 + (heavy_local_jobs(len) << 12);
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) heavy += __shfl_xor(heavy, m);
@@ -325,37 +356,48 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   // (the backward's list gives heavy tiles finer shares: by the forward's threshold as given -- its own list is built
   // by another workgroup, whose raised threshold this one does not see; more shares than heavy tiles need is harmless)
   if (threadIdx.x == 0) heavy_n = local_n = 0;
-  if (threadIdx.x == 0) carry = 0;
+  if (threadIdx.x == 0) carry = carry_need = 0;
   __syncthreads();
+  const bool write_tab = slot_tab && all_granted;  // (else the grant pass has written it)
   int32_t* seg = jobs + 8 + (size_t)xcd * cap;
   for (int base = 0; base < n; base += NTH) {
     const int idx = base + (int)threadIdx.x;
-    int cnt = 0, tile = 0, flag = 0;
+    int cnt = 0, tile = 0, flag = 0, need = 0;
     bool heavy_tile = false;
     if (idx < n) {
       tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      const bool slots = !slot_tab || slot_tab[tile] >= 0;
+      const bool slots = has_slots(idx, tile, len);
       cnt = p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
       heavy_tile = !bwd && len > thr_h && slots;
+      if (write_tab && slots) need = (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H;
       // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
       // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
       // (compact slots: a tile without slots is such a tile)
       if (!bwd && pb.seg_parts > 1 && (slot_tab ? !slots : job_count(pb, idx, n, 0, 0, 0x7fffffff, thr2_b, len) <= 1))
         flag = FG_JOB_NO_CKPT;
     }
-    int incl = cnt;
+    // two prefix sums in one: the jobs in front of this tile's (low word), the slots in front of its own (high word)
+    long long incl = (long long)cnt | (long long)need << 32;
+    const long long own = incl;
 #pragma unroll
     for (int k = 1; k < 64; k <<= 1) {
-      const int o = __shfl_up(incl, k);
+      const long long o = __shfl_up(incl, k);
       if (lane >= k) incl += o;
     }
-    if (lane == 63) wave_tot[wave] = incl;
+    if (lane == 63) {
+      wave_tot[wave] = (int)(incl & 0xFFFFFFFFll);
+      need_tot[wave] = (int)(incl >> 32);
+    }
     __syncthreads();
-    int pos = carry + incl - cnt;
+    int pos = carry + (int)((incl - own) & 0xFFFFFFFFll), npos = carry_need + (int)((incl - own) >> 32);
 #pragma unroll
     for (int w = 0; w < NWV; ++w)
-      if (w < wave) pos += wave_tot[w];
+      if (w < wave) {
+        pos += wave_tot[w];
+        npos += need_tot[w];
+      }
+    if (write_tab && idx < n) slot_tab[tile] = need > 0 ? xcd * jb.slot_budget + npos : -1;
     if (p.seg_parts > 1) {
       for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 12 | ((j + idx) % cnt) << 6 | (cnt - 1);
     } else if (heavy_tile) {
@@ -368,7 +410,10 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       for (int j = 0; j < 4; ++j) seg[pos + j] = tile << 3 | (j + 1) | flag;  // strip 0..3
     }
     __syncthreads();
-    if (threadIdx.x == NTH - 1) carry = pos + cnt;
+    if (threadIdx.x == NTH - 1) {
+      carry = pos + cnt;
+      carry_need = npos + need;
+    }
     __syncthreads();
   }
   if (threadIdx.x == 0) jobs[xcd] = carry;
@@ -380,7 +425,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = band_tile(band, idx, tile_w);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-      if (len > thr_h && (!slot_tab || slot_tab[tile] >= 0)) {
+      if (len > thr_h && has_slots(idx, tile, len)) {
         const int nl = heavy_local_jobs(len);
         const int l0 = atomicAdd(&local_n, nl), h = atomicAdd(&heavy_n, 1);
         for (int j = 0; j < nl; ++j) lc[8 + xcd * FG_LOCAL_CAP + l0 + j] = tile << 8 | j;
