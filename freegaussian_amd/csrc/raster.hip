@@ -806,6 +806,26 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 // Mixed launch (one wavefront per workgroup): every XCD walks its band column-major as above; the
 // first tiles of its sequence are whole-tile jobs (4 pixels per lane), the last `tail_tiles` are
 // split into four single-strip jobs (1 pixel per lane) -- see launch_fwd_mixed.
+// ISSUE PRIORITY by expected job length (experiment, FG_PRIO_LO / FG_PRIO_HI in percent of the mean single-strip job;
+// 0 = off): the launches end when their longest jobs end, and those start in the first microsecond and then share
+// their SIMD's issue slots evenly with 5-7 shorter jobs (profiles/r04_job_timeline.md).  s_setprio raises a wavefront's
+// priority at its SIMD's instruction arbiter: the long jobs get through sooner, the short ones -- which have slack --
+// a little later; the work is the same.  weight8: cost per list entry of the job's kind in eighths of a single strip's.
+#ifndef FG_PRIO_LO
+#define FG_PRIO_LO 0
+#endif
+#ifndef FG_PRIO_HI
+#define FG_PRIO_HI 0
+#endif
+__device__ __forceinline__ void job_priority(const int32_t* __restrict__ tile_offsets, int n_tiles, int len, int weight8) {
+  if constexpr (FG_PRIO_LO > 0) {
+    const long long total = tile_offsets[n_tiles];
+    const long long lhs = (long long)len * weight8 * n_tiles * 100, ref = total * 8;
+    if (FG_PRIO_HI > 0 && lhs > ref * FG_PRIO_HI) __builtin_amdgcn_s_setprio(3);
+    else if (lhs > ref * FG_PRIO_LO) __builtin_amdgcn_s_setprio(2);
+  }
+}
+
 // (three channels: eight wavefronts per SIMD asked for -- 64 registers, which the allocator meets without spilling; the
 // heavy tiles' local jobs would otherwise cost the launch its eighth wavefront, 66 registers)
 template <int C>
@@ -836,6 +856,10 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   if (tile < 0) return;
   if (no_ckpt) ckpt = nullptr;
   FG_TL_BEGIN();
+  if constexpr (FG_PRIO_LO > 0) {
+    const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+    job_priority(tile_offsets, tile_w * tile_h, prefix ? min(len, FG_HEAVY_PREFIX) : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8));
+  }
   if constexpr (C == 3) {
     if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
       raster_fwd_body<C, 1, 1, 3>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
@@ -1393,6 +1417,10 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   }
   if (tile < 0) return;
   FG_TL_BEGIN();
+  if constexpr (FG_PRIO_LO > 0) {
+    const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+    job_priority(tile_offsets, tile_w * tile_h, seg.parts > 1 ? len / seg.parts : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8));
+  }
   if (strip < 0)
     raster_bwd_body<C, 4, 1, LIVE>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
                                    last_ids, v_render, v_alphas, v_splats, comp, seg, part, live_words);

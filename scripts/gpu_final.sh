@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round visit: the driver's bench command on the cold box first, then scripts/gpu_check.sh, then the PMC passes.
-tag=${1:-r03_final}
+tag=${1:-r04_final}
 mkdir -p gpurun_out/$tag
 timeout 600 python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/$tag/driver_command_cold.json 2> gpurun_out/$tag/driver_command_cold.err
 python3 -c "

@@ -34,7 +34,7 @@ for k,c in agg.items():
         traffic[k.replace("void ","")]={"FETCH_SIZE_KiB":f,"WRITE_SIZE_KiB":w,"hbm_bytes_per_launch":(2*f+w)*1024}
         if "SQ_INSTS_VALU" in c:
             traffic[k.replace("void ","")]["valu_wave_instr_per_launch"]=sum(c["SQ_INSTS_VALU"])/len(c["SQ_INSTS_VALU"])
-json.dump({"workload_key":"1000000x1920x1080xsh3","round":"r03","source":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph",
+json.dump({"workload_key":"1000000x1920x1080xsh3","round":"$tag".split("_")[0],"source":"rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-graph",
            "correction":"bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024","kernels":traffic}, open(out+"/pmc_traffic.json","w"), indent=1)
 with open(out+"/pmc_summary.txt","w") as fo:
     for k in sorted(agg):

@@ -2075,7 +2075,8 @@ def test_graphed_step_optimises_the_models_own_objective():
         grads[kind] = {k: v.grad.detach().clone() for k, v in model.gauss_params.items()}
     for k in ("means", "features_dc", "opacities", "scales"):
         assert rel_l2(grads["graphed"][k], grads["eager"][k]) < 1e-5, k
-    assert rel_l2(grads["eager_0.2"]["features_dc"], grads["eager"]["features_dc"]) > 1e-2
+    a, b = grads["eager_0.2"]["features_dc"], grads["eager"]["features_dc"]
+    assert float((a - b).norm() / b.norm()) > 1e-2  # (not a parity comparison: the other lambda is another objective)
 
 
 def test_graphed_model_step_trains_like_the_eager_step_through_refinements():
