@@ -259,6 +259,7 @@ struct Segments {
                             // composite epilogue they are rebuilt from the finished image instead
   int parts;                // backward: jobs per split tile (1 = whole list)
   int tail;                 // backward: the last `tail` tiles of every XCD's sequence are split (0 = all)
+  int prio;                 // backward: issue priority thresholds of the jobs (job_priority), 0 = off
 };
 
 // Optional work counters (make stats -> libfgraster_stats.so; never in the product library).
@@ -806,24 +807,21 @@ raster_fwd_kernel(int width, int height, int tile_w, int tile_h, int order_mode,
 // Mixed launch (one wavefront per workgroup): every XCD walks its band column-major as above; the
 // first tiles of its sequence are whole-tile jobs (4 pixels per lane), the last `tail_tiles` are
 // split into four single-strip jobs (1 pixel per lane) -- see launch_fwd_mixed.
-// ISSUE PRIORITY by expected job length (experiment, FG_PRIO_LO / FG_PRIO_HI in percent of the mean single-strip job;
-// 0 = off): the launches end when their longest jobs end, and those start in the first microsecond and then share
-// their SIMD's issue slots evenly with 5-7 shorter jobs (profiles/r04_job_timeline.md).  s_setprio raises a wavefront's
-// priority at its SIMD's instruction arbiter: the long jobs get through sooner, the short ones -- which have slack --
-// a little later; the work is the same.  weight8: cost per list entry of the job's kind in eighths of a single strip's.
-#ifndef FG_PRIO_LO
-#define FG_PRIO_LO 0
-#endif
-#ifndef FG_PRIO_HI
-#define FG_PRIO_HI 0
-#endif
-__device__ __forceinline__ void job_priority(const int32_t* __restrict__ tile_offsets, int n_tiles, int len, int weight8) {
-  if constexpr (FG_PRIO_LO > 0) {
-    const long long total = tile_offsets[n_tiles];
-    const long long lhs = (long long)len * weight8 * n_tiles * 100, ref = total * 8;
-    if (FG_PRIO_HI > 0 && lhs > ref * FG_PRIO_HI) __builtin_amdgcn_s_setprio(3);
-    else if (lhs > ref * FG_PRIO_LO) __builtin_amdgcn_s_setprio(2);
-  }
+// ISSUE PRIORITY by expected job length (fg_raster_config::prio_fwd / prio_bwd: lo | hi << 16 in percent of the mean
+// single-strip job; 0 = off).  The launches end when their longest jobs end; those start in the first microsecond and
+// then share their SIMD's issue slots evenly with 5-7 shorter jobs (profiles/r04_job_timeline.md).  s_setprio raises
+// a wavefront's priority at its SIMD's instruction arbiter: the long jobs get through sooner, the short ones -- which
+// have slack -- a little later; the work is the same.  weight8: cost per list entry of the job's kind in eighths of a
+// single strip's.  Measured (profiles/r04_job_priority.md): uniform scene +-0, clustered scenes -2.5 % / -5 % per step;
+// with low thresholds in the forward (every whole-tile job raised) the uniform forward loses 9 %.
+__device__ __forceinline__ void job_priority(const int32_t* __restrict__ tile_offsets, int n_tiles, int len, int weight8,
+                                             int prio) {
+  if (prio <= 0) return;
+  const long long total = tile_offsets[n_tiles];
+  const long long lhs = (long long)len * weight8 * n_tiles * 100, ref = total * 8;
+  const int lo = prio & 0xFFFF, hi = prio >> 16;
+  if (hi > 0 && lhs > ref * hi) __builtin_amdgcn_s_setprio(3);
+  else if (lhs > ref * lo) __builtin_amdgcn_s_setprio(2);
 }
 
 // (three channels: eight wavefronts per SIMD asked for -- 64 registers, which the allocator meets without spilling; the
@@ -836,7 +834,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
                         float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
-                        float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab) {
+                        float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab, int prio) {
   __shared__ FwdShared<C, 64> sh;
   // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
   // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
@@ -856,9 +854,9 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   if (tile < 0) return;
   if (no_ckpt) ckpt = nullptr;
   FG_TL_BEGIN();
-  if constexpr (FG_PRIO_LO > 0) {
+  if (prio > 0) {
     const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-    job_priority(tile_offsets, tile_w * tile_h, prefix ? min(len, FG_HEAVY_PREFIX) : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8));
+    job_priority(tile_offsets, tile_w * tile_h, prefix ? min(len, FG_HEAVY_PREFIX) : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8), prio);
   }
   if constexpr (C == 3) {
     if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
@@ -949,7 +947,7 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
                                                 const int32_t* __restrict__ last_ids,
                                                 const float* __restrict__ v_render,
                                                 const float* __restrict__ v_alphas, float* __restrict__ v_splats,
-                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, nullptr, 1, 0},
+                                                const Composite& comp, const Segments& seg = Segments{nullptr, nullptr, nullptr, 1, 0, 0},
                                                 int part = 0, const uint32_t* __restrict__ live_words = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
@@ -1417,9 +1415,9 @@ raster_bwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   }
   if (tile < 0) return;
   FG_TL_BEGIN();
-  if constexpr (FG_PRIO_LO > 0) {
+  if (seg.prio > 0) {
     const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-    job_priority(tile_offsets, tile_w * tile_h, seg.parts > 1 ? len / seg.parts : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8));
+    job_priority(tile_offsets, tile_w * tile_h, seg.parts > 1 ? len / seg.parts : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8), seg.prio);
   }
   if (strip < 0)
     raster_bwd_body<C, 4, 1, LIVE>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, alphas,
@@ -1716,6 +1714,15 @@ int64_t slot_table_offset(const Cfg& c, int tile_w, int tile_h) {
 const int32_t* slot_table(const Cfg& c, const int32_t* jobs, int tile_w, int tile_h) {
   return jobs && seg_slots(c) > 0 ? jobs + slot_table_offset(c, tile_w, tile_h) : nullptr;
 }
+// prio_fwd / prio_bwd: issue priority thresholds of the mixed launches' jobs (job_priority), lo | hi << 16 in percent of
+// the mean single-strip job; -1 = the measured default, 0 = off
+#ifndef FG_PRIO_FWD_DEFAULT
+#define FG_PRIO_FWD_DEFAULT (250 | 350 << 16)
+#endif
+#ifndef FG_PRIO_BWD_DEFAULT
+#define FG_PRIO_BWD_DEFAULT (120 | 160 << 16)
+#endif
+int job_prio(int v, int dflt) { return v < 0 ? dflt : v; }
 // use_liveness = 0: the backward ignores the forward's liveness bytes (A/B)
 const uint32_t* live_use(const Cfg& c, const uint32_t* live_words) { return c.use_liveness == 0 ? nullptr : live_words; }
 // seg_tail = tiles per XCD, at the end of its sequence, whose lists are split (0 = every tile)
@@ -1783,7 +1790,7 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
                      dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
-                     zero_buf ? zero_floats / 4 : 0ll, slot_tab);
+                     zero_buf ? zero_floats / 4 : 0ll, slot_tab, job_prio(cfg.prio_fwd, FG_PRIO_FWD_DEFAULT));
   if constexpr (C == 3) {
     // heavy tiles: their combine jobs, once every local job has left its batches' composites
     if (jobs && ckpt && heavy_len(cfg) > 0) {
@@ -1803,7 +1810,7 @@ template <int C>
 int launch_bwd_mixed(const Cfg& cfg, int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, const float* alphas,
                      const int32_t* last_ids, const float* v_render, const float* v_alphas, float* v_splats,
-                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, nullptr, 1, 0},
+                     Composite comp, hipStream_t s, Segments seg = Segments{nullptr, nullptr, nullptr, 1, 0, 0},
                      const uint32_t* live_words = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(cfg, tile_w, tile_h);
@@ -1926,14 +1933,15 @@ int raster_bwd_any(const fg_raster_config* config, int channels, int width, int 
     seg_ckpt = nullptr;
   }
   // list segmentation: 3 channels, checkpoints written by the forward of this very image
-  Segments seg{nullptr, nullptr, nullptr, 1, 0};
+  Segments seg{nullptr, nullptr, nullptr, 1, 0, 0};
   // (compact checkpoint slots: the table of the tiles' first slots is in the list; no list, no shares)
   const int32_t* slot_tab = slot_table(cfg, jobs, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE);
   if (seg_slots(cfg) > 0 && !slot_tab) seg_ckpt = nullptr;
   if (channels == 3 && seg_ckpt && image && tail > 0 && seg_parts(cfg, n_tiles) > 1)
     seg = Segments{reinterpret_cast<float4*>(const_cast<float*>(seg_ckpt)), slot_tab, image, seg_parts(cfg, n_tiles),
                    seg_tail_fit(cfg, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(cfg, n_tiles),
-                                seg_tail(cfg, n_tiles))};
+                                seg_tail(cfg, n_tiles)), 0};
+  seg.prio = job_prio(cfg.prio_bwd, FG_PRIO_BWD_DEFAULT);
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(cfg, width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -2002,6 +2010,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->balance_bands = -1;
   c->heavy_tiles = 0;
   c->seg_slots = 0;
+  c->prio_fwd = c->prio_bwd = -1;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {

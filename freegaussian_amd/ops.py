@@ -91,7 +91,8 @@ def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
     reads no environment) as an ``fg_raster_config``.  FG_RASTER_PPT_FWD / _BWD = 1|2|4;
     FG_RASTER_TAIL_FWD / _BWD = "t4[,t2]"; FG_RASTER_SPLIT_FWD / _BWD = "a4[,a2]"; FG_RASTER_BANDS = 1|2|4|8;
     FG_RASTER_LIVE = 0; FG_RASTER_SEG_PARTS, FG_RASTER_SEG_TAIL = n; FG_RASTER_SEG_GRADE = "parts2,tail2";
-    FG_TILE_ORDER = rows|bands|cols|split|x|y; FG_DEBUG_ONLY_XCD = 0..7; FG_DEBUG_K_MOD = m; FG_RASTER_BALANCE = 0|1."""
+    FG_TILE_ORDER = rows|bands|cols|split|x|y; FG_DEBUG_ONLY_XCD = 0..7; FG_DEBUG_K_MOD = m; FG_RASTER_BALANCE = 0|1;
+    FG_RASTER_PRIO_FWD / _BWD = "lo,hi" (percent of the mean single-strip job; "0" = off)."""
     env = os.environ if env is None else env
     f = {}
 
@@ -108,6 +109,10 @@ def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
                         ("FG_RASTER_BALANCE", "balance_bands")):  # fmt: skip
         if env.get(name) is not None:
             f[field] = int(env[name])
+    for name, field in (("FG_RASTER_PRIO_FWD", "prio_fwd"), ("FG_RASTER_PRIO_BWD", "prio_bwd")):  # "lo,hi" percent; "0" = off
+        if env.get(name) is not None:
+            parts = [int(x) for x in env[name].split(",")]
+            f[field] = parts[0] | ((parts[1] if len(parts) > 1 else 0) << 16)
     pair("FG_RASTER_TAIL_FWD", "tail4_fwd", "tail2_fwd")
     pair("FG_RASTER_TAIL_BWD", "tail4_bwd", "tail2_bwd")
     pair("FG_RASTER_SPLIT_FWD", "split4_fwd", "split2_fwd")

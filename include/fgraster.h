@@ -260,6 +260,12 @@ typedef struct fg_raster_config {
                               would take together is reported by fg_stbin_fill_jobs (ckpt_need_out): size the next call's
                               buffer as 8 x the largest word + a margin.  The SAME value must reach the list build, the size
                               query and both raster calls.  <= 0 = off (default): a slot per 64 entries of every tile */
+  int32_t prio_fwd;        /* job lists / mixed launches (ABI 7): issue priority of a job's wavefront by its expected length,
+                              lo | hi << 16 in percent of the launch's mean single-strip job (list length x the job kind's
+                              cost per entry): above lo the wavefront runs at priority 2, above hi at 3 (s_setprio) -- the
+                              launch's longest jobs, which start first and set its end, get through sooner; -1 = default
+                              (forward 250 | 350 << 16, backward 120 | 160 << 16), 0 = off */
+  int32_t prio_bwd;
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 

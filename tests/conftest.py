@@ -27,6 +27,12 @@ def _built_library():
         import __graft_entry__ as g
 
         g.build()
+    # The process-wide default context takes its launch policy from the environment when it is first used: make that
+    # moment NOW, not inside the first test that happens to touch it with FG_RASTER_* variables monkeypatched (the
+    # patched policy would then be what `monkeypatch` restores for the rest of the session: order-dependent tests).
+    from freegaussian_amd import ops
+
+    ops.default_context
     yield
 
 

@@ -1480,6 +1480,10 @@ def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(b
     if int(_lib.load().fg_raster_jobs_words(1920, 1080, 16, ctx.cfg())) == 0 or ctx.seg_ckpt_budget_bytes <= 0:
         pytest.skip("classic launches / no list shares in this environment")
     monkeypatch.setattr(ctx, "heavy_tile_len", 1024)
+    # (what earlier tests learned about this shape -- a list capacity of tens of millions of entries puts the checkpoint
+    # buffer beyond the context's budget, and without list shares there are no heavy tiles)
+    for name in ("isect_capacity", "isect_recent", "ckpt_need", "ckpt_pending"):
+        monkeypatch.setattr(ctx, name, {})
     outs = {}
     for mode in ("always", "never"):
         monkeypatch.setattr(ctx, "heavy_tiles", mode)
