@@ -51,6 +51,16 @@ constexpr int SB_SKEW_MAX = FG_SB_SKEW_MAX;                      // elements in 
 // LONG segments (more elements than the large launch sorts in LDS: a dense cluster over one supertile) are split by
 // SAMPLE SORT into buckets of ~LG_T elements that the LDS sort then takes one by one (FG_STBIN_LONG_SEGMENTS):
 constexpr int SB_LONG_MIN = 64 * 16 * 8 - 256;       // = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, ..>::MAXN (static_assert below)
+// ... and (long mode) every segment of more than SB_LONG_SPLIT elements -- the small launch's LDS capacity -- goes that way:
+// the large launch sorts one segment per 1024-thread workgroup, two workgroups per CU; where hundreds of segments are of
+// that size the bucket passes -- more, smaller workgroups -- are faster (fill 0.207 -> 0.137 ms with half of the Gaussians
+// in a ball of 0.4, 0.224 -> 0.173 with 80 % in a ball of 0.2; profiles/r04_binning.md).  The large launch's own sorts
+// remain what runs without the flag.
+#ifndef FG_SB_LONG_SPLIT
+#define FG_SB_LONG_SPLIT 3072
+#endif
+constexpr int SB_LONG_SPLIT = FG_SB_LONG_SPLIT;
+static_assert(SB_LONG_SPLIT <= SB_LONG_MIN && SB_LONG_SPLIT >= 2 * 1536, "long segments: at least two buckets, at most the large sort's capacity");
 constexpr int LG_T = 1536;                           // target bucket size: half of the small LDS sort's capacity (sb_long_sort_kernel)
 constexpr int LG_KMAX = 1008;                        // buckets per segment at most (splitters + counters in LDS)
 constexpr int LG_SA = 32;                            // samples per bucket (fewer when LG_SA * k exceeds one LDS sort): a bucket twice its target is a 1e-6 event
@@ -260,9 +270,10 @@ sb_columns_kernel(int T, int S, int n_chunks, int wg_t, const uint32_t* __restri
 // threads x 8 values: the 8160 tiles of a 1080p frame are one trip through memory, not two ----------------------
 constexpr int SO_BLOCK = 1024, SO_WAVES = SO_BLOCK / 64, SO_PER = 8;
 __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restrict__ offs, uint32_t* buf,
-                                                         uint32_t* wave_tot, uint32_t* largest = nullptr) {
+                                                         uint32_t* wave_tot, uint32_t* largest = nullptr,
+                                                         uint32_t over_thr = 0xFFFFFFFFu, uint32_t* n_over = nullptr) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  uint32_t carry = 0, big = 0;
+  uint32_t carry = 0, big = 0, over = 0;
   uint64_t total = 0;  // (the offsets are 32-bit; the total is reported in full so that the host can refuse a list it cannot index)
   for (int base = 0; base < n; base += SO_BLOCK * SO_PER) {
     uint32_t in[SO_PER];
@@ -275,6 +286,7 @@ __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restr
     for (int k = 0; k < SO_PER; ++k) {
       buf[k * SO_BLOCK + threadIdx.x] = in[k];
       big = max(big, in[k]);
+      over += in[k] > over_thr ? 1u : 0u;
     }
     __syncthreads();
     uint32_t v[SO_PER], sum = 0;
@@ -324,6 +336,17 @@ __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restr
     for (int k = 0; k < SO_WAVES; ++k) big = max(big, wave_tot[k]);
     *largest = big;
   }
+  if (n_over) {  // how many counts exceed over_thr (for thread 0)
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) over += (uint32_t)__shfl_xor((int)over, m);
+    __syncthreads();
+    if (lane == 0) wave_tot[wave] = over;
+    __syncthreads();
+    over = 0;
+#pragma unroll
+    for (int k = 0; k < SO_WAVES; ++k) over += wave_tot[k];
+    *n_over = over;
+  }
   return total;
 }
 __global__ void __launch_bounds__(SO_BLOCK)
@@ -332,9 +355,11 @@ sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __r
   __shared__ alignas(16) uint32_t buf[SO_BLOCK * SO_PER];
   __shared__ uint32_t wave_tot[SO_WAVES];
   if (blockIdx.x == 1) {  // (two workgroups: the two scans side by side)
-    uint32_t longest = 0;
-    scan_counts_in_place(S, st_offsets, buf, wave_tot, &longest);
+    uint32_t longest = 0, n_over = 0;
+    scan_counts_in_place(S, st_offsets, buf, wave_tot, &longest, (uint32_t)SB_LONG_SPLIT, &n_over);
     if (threadIdx.x == 0 && count_out) {  // the longest supertile segment, beside the list length (the host's path choice)
+      // ... and how many segments are beyond the small launch's LDS sort: many of them are better off with the bucket passes
+      __hip_atomic_store(count_out + 3, (int64_t)n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __hip_atomic_store(count_out + 1, (int64_t)longest, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
       __threadfence_system();
     }
@@ -371,7 +396,7 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
   uint32_t mine[3] = {0, 0, 0};  // long segments, their chunks, their buckets in [i0, i1)
   for (int i = i0; i < i1; ++i) {
     const int n = st_offsets[i + 1] - st_offsets[i];
-    if (long_mode && n > SB_LONG_MIN) {
+    if (long_mode && n > SB_LONG_SPLIT) {
       mine[0] += 1;
       mine[1] += (uint32_t)((n + LG_CHUNK - 1) / LG_CHUNK);
       mine[2] += (uint32_t)long_buckets(n);
@@ -405,7 +430,7 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
   }
   for (int i = i0; i < i1; ++i) {
     const int n = st_offsets[i + 1] - st_offsets[i];
-    if (n > SB_LONG_MIN) {
+    if (n > SB_LONG_SPLIT) {
       long_list[1 + run[0]] = make_int4(i, (int)run[1], (int)run[2], n);
       // (the passes' work items find their segment with ONE load instead of a bisection of dependent loads)
       const int nch = (n + LG_CHUNK - 1) / LG_CHUNK, nb = long_buckets(n);
@@ -1529,7 +1554,7 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
 
 namespace {
 // buckets of all long segments together: sum of ceil(n / LG_T) over segments of more than SB_LONG_MIN elements
-size_t long_buckets_max(size_t capacity) { return capacity / LG_T + capacity / SB_LONG_MIN + 2; }  // (sum of ceil(n / LG_T))
+size_t long_buckets_max(size_t capacity) { return capacity / LG_T + capacity / SB_LONG_SPLIT + 2; }  // (sum of ceil(n / LG_T))
 struct FillWs {
   uint64_t *entries, *scratch;
   LongTables lt;
@@ -1557,7 +1582,7 @@ FillWs fill_ws(void* base, size_t capacity) {
   w.lt.over_list = ws_at<int32_t>(base, o);
   o += al256((2 + (size_t)w.lt.over_cap + kb) * 4);
   w.lt.chunk_seg = ws_at<int4>(base, o);
-  o += al256((capacity / LG_CHUNK + capacity / SB_LONG_MIN + 2) * 16);
+  o += al256((capacity / LG_CHUNK + capacity / SB_LONG_SPLIT + 2) * 16);
   w.bytes = o;
   return w;
 }

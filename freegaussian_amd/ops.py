@@ -167,7 +167,10 @@ class RasterContext:
         self.long_segments = e.get("FG_LONG_SEGMENTS", "auto")
         if self.long_segments not in ("auto", "always", "never"):
             raise ValueError(f"FG_LONG_SEGMENTS={self.long_segments!r}: auto | always | never")
+        # (the flag is set for a shape while its calls report a segment beyond the large launch's LDS capacity, or more
+        # than `long_many` beyond the small launch's: there the bucket passes beat one-segment-per-workgroup sorts)
         self.long_segment = 7936
+        self.long_many = int(e.get("FG_LONG_MANY", "16"))
         self.long_cooldown = 64
         self.long_shapes = {}  # shape key -> calls left with the flag set
         self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag
@@ -499,7 +502,8 @@ _RING_WORDS = 16  # int64 words per slot
 
 def _count_slot():
     """A slot of sixteen pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
-    segment, [2] the longest tile list (fg_stbin_count only; they stay -1 otherwise), [4..11] the checkpoint slots the
+    segment, [2] the longest tile list, [3] the segments beyond the small sort's capacity (fg_stbin_count only; they stay
+    -1 otherwise), [4..11] the checkpoint slots the
     eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late).  -> (slot, address)."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
@@ -720,7 +724,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> in
     n_isects = _poll_count(count_slot)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
                                           (2, rctx.heavy_tile_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
-        if _poll_count(count_slot, word) > limit:
+        if _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many):
             if lkey not in shapes and len(shapes) >= 256:
                 shapes.pop(next(iter(shapes)))
             shapes[lkey] = cooldown

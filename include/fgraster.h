@@ -150,9 +150,10 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * 6 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
  * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
- * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, THREE words with
+ * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, FOUR words with
  * system scope (pinned host memory): count_out[0] the list length, count_out[2] the longest tile list (a host
- * turns fg_raster_config::heavy_tiles on from it), count_out[1] the longest supertile segment
+ * turns fg_raster_config::heavy_tiles on from it), count_out[1] the longest supertile segment and count_out[3] the
+ * number of segments of more than 3072 elements
  * (segments beyond 7936 elements are sorted by one workgroup through global memory -- correct, slow -- unless
  * fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS, see below).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and
@@ -166,13 +167,14 @@ size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
 int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
                    int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
 size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
-/* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond 7936 elements (a dense cluster: tens of
- * thousands of splats over one 32 x 32-pixel supertile) are cut into buckets of ~1024 elements by a multi-workgroup
- * sample sort (splitters from a sorted sample inside the large-segment launch, two more launches -- count, scatter --
- * and 1024 more workgroups of the small-segment launch that sort the buckets) instead of being sorted by ONE workgroup
- * through global memory.  Same lists bit for bit either way; a host sets the flag for shapes whose count_out[1] of an
- * earlier call exceeded 7936 (ops.bin_tiles does) -- on scenes without such segments the flag only costs the two
- * empty launches. */
+/* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond the small-segment launch's LDS capacity (3072
+ * elements; a dense cluster: thousands to hundreds of thousands of splats over one 32 x 32-pixel supertile) are cut
+ * into buckets of ~1536 elements by a multi-workgroup sample sort (splitters from a sorted sample inside the
+ * large-segment launch, then a count, a scatter, a bucket-sort and an overflow launch) instead of being sorted one
+ * segment per 1024-thread workgroup in LDS (up to 7936 elements) or by ONE workgroup through global memory (beyond).
+ * Same lists bit for bit either way; a host sets the flag for shapes whose earlier calls reported a segment beyond
+ * 7936 elements (count_out[1]) or more than a handful beyond 3072 (count_out[3]) -- ops.bin_tiles does -- on scenes
+ * without such segments the flag only costs the four empty launches. */
 #define FG_STBIN_LONG_SEGMENTS 1
 int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                   int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
@@ -507,7 +509,7 @@ int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored,
  * and its autograd backward.
  *   fg_step_desc    what is rendered (sizes, SH degree, channels, composite epilogue, list capacity, flags)
  *   fg_step_io      device pointers: the inputs (plain or raw parameter forms, as the two preprocess entry points take
- *                   them), count_out (pinned host memory, the three words of fg_stbin_count), and for the backward the
+ *                   them), count_out (pinned host memory, the four words of fg_stbin_count), and for the backward the
  *                   upstream gradients and the output gradients
  *   fg_step_layout  from fg_step_layout_query: offsets / sizes of every buffer inside the two caller-allocated
  *                   workspaces -- `keep` (read by the backward and by the caller: FG_STEP_RADII .. FG_STEP_CLAMP_MASK;
