@@ -210,6 +210,9 @@ static_assert(FG_SEG_ENTRIES == fgjobs::FG_SEG_ENTRIES_H, "a heavy tile's batch 
 #ifndef FG_HEAVY_AHEAD
 #define FG_HEAVY_AHEAD 8
 #endif
+#ifndef FG_HEAVY_SUB
+#define FG_HEAVY_SUB 4  // workgroups per listed local job
+#endif
 // measured on MI355X (1M Gaussians, 1080p, profiles/r02_backward_list_shares.md): the last 400 tiles of
 // every XCD's sequence as 3 shares each over 128-entry segments: 0.398 -> 0.374 ms against two-strip jobs
 // for the last 300; 4 shares over 64-entry segments: 0.370 -> 0.349 (the forward writes checkpoints only
@@ -476,9 +479,13 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   int end = tile_offsets[tile + 1];
   int first = start;  // MODE 1: this job's share of the list behind the prefix, whole batches; MODE 2: all of it
   if constexpr (MODE == 1) {
-    const int per = heavy_batches_per_job(end - start) * FG_SEG_ENTRIES;
-    first = start + FG_HEAVY_PREFIX + local_part * per;
-    end = min(end, first + per);
+    // local_part = part | sub << 8: a listed job's batches are taken by FG_HEAVY_SUB workgroups, a quarter each -- the
+    // local pass lasts as long as its longest job (19 batches for a 79 000-entry list) while most of the chip idles
+    const int per_b = heavy_batches_per_job(end - start), per = per_b * FG_SEG_ENTRIES, off = (local_part & 255) * per;
+    const int sub_b = (per_b + FG_HEAVY_SUB - 1) / FG_HEAVY_SUB;
+    first = start + FG_HEAVY_PREFIX + off + (local_part >> 8) * sub_b * FG_SEG_ENTRIES;
+    end = min(min(end, start + FG_HEAVY_PREFIX + off + per), first + sub_b * FG_SEG_ENTRIES);
+    if (first >= end) return;
   }
   if constexpr (MODE == 2) first = start + FG_HEAVY_PREFIX;
   if constexpr (MODE == 3) end = min(end, start + FG_HEAVY_PREFIX);
@@ -900,11 +907,11 @@ raster_fwd_local_kernel(int width, int height, int tile_w, const int32_t* __rest
   __shared__ FwdShared<3, 64> sh;
   // (the eight XCD segments as ONE list: the heavy tiles sit under one or two XCDs' bands, their jobs are for the chip)
   for (int v = blockIdx.x;; v += gridDim.x) {
-    const int e = job_of_all_segments(jobs, FG_LOCAL_CAP, v);
+    const int e = job_of_all_segments(jobs, FG_LOCAL_CAP, v / FG_HEAVY_SUB);
     if (e < 0) break;
     FG_TL_BEGIN();
     raster_fwd_body<3, 4, 1, 1>(sh, e >> 8, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                                last_ids, comp, ckpt, live_words, e & 255, slot_tab);
+                                last_ids, comp, ckpt, live_words, (e & 255) | (v % FG_HEAVY_SUB) << 8, slot_tab);
     FG_TL_END(1, e >> 8, 5, 0, 1);
   }
 }
