@@ -130,13 +130,19 @@ struct JobBuild {
   long long* need_out;
 };
 constexpr int FG_BAND_MAX_ROWS = 1024;
+#ifndef FG_BAND_COST_CAP4
+#define FG_BAND_COST_CAP4 10  // a tile's list length counts up to this many quarters of the mean (a longer list saturates)
+#endif
 
 // The eight XCDs' row bands by CONTENT: equal shares of the tiles' expected walking cost instead of equal numbers of
 // rows.  A cluster of splats under one XCD's band made that XCD the launch (half of the Gaussians in a ball: three XCDs
 // finish at 390 / 570 us, forward / backward, five at 280 / 420 and idle: profiles/r04_job_timeline.md section 2); a
 // workgroup taking jobs from a shared cursor instead costs every job a same-address atomic (57 ns each, serialised:
-// forward 0.20 -> 0.38 ms, profiles/r04_job_stealing.md).  Cost of a tile = its list length, capped at four times the
-// mean (a long list saturates its pixels and is not walked to its end) + a quarter of the mean (the job itself).  All
+// forward 0.20 -> 0.38 ms, profiles/r04_job_stealing.md).  Cost of a tile = its list length, capped at 2.5 times the
+// mean (a long list saturates its pixels and is not walked to its end; the forward alone would like 6 x, the backward
+// 2.5-3 x: half of the Gaussians in a ball of 0.4, forward / backward ms at 6 x 0.261 / 0.395, 4 x 0.288 / 0.370, 3 x
+// 0.288 / 0.339, 2.5 x 0.283 / 0.334, 2 x 0.283 / 0.336 -- one set of bands serves both lists, the checkpoint slots are
+// granted per band) + a quarter of the mean (the job itself).  All
 // sixteen workgroups of a build compute the same boundaries from the same tile ranges.  The equal bands stay when the
 // heaviest of them is within balance_percent of the mean (the launch policy is tuned on them; on the uniform bench scene the
 // cost model's bands were 3% slower than the equal ones).  row0[0 .. 8] in LDS.
@@ -149,7 +155,7 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
     for (int r = threadIdx.x; r < tile_h; r += NTH) s_roww[r] = 0u;
     __syncthreads();
     const uint32_t total = (uint32_t)tile_offsets[T], mean = total / (uint32_t)T;
-    const uint32_t cap = 4u * mean + 16u, fixed = mean / 4u + 4u;
+    const uint32_t cap = (uint32_t)FG_BAND_COST_CAP4 * mean / 4u + 16u, fixed = mean / 4u + 4u;
     // (four tiles per thread a trip, all loads in flight together; a thread's tiles are consecutive: mostly one row)
     for (int t0 = 4 * (int)threadIdx.x; t0 < T; t0 += 4 * NTH) {
       int32_t o[5];
