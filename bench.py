@@ -873,7 +873,9 @@ def main(argv=None):
                 out["clustered_layouts"][lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"], "stage_ms": c["stage_ms"],
                                                  "I_raster": c["config"]["I_raster"], "longest_tile_list": c["config"].get("longest_tile_list"),
                                                  "long_segment_calls": c["config"].get("long_segment_calls"),
-                                                 "heavy_tile_steps": c["config"].get("heavy_tile_steps")}  # fmt: skip
+                                                 "heavy_tile_steps": c["config"].get("heavy_tile_steps"),
+                                                 "host_step_ms": c.get("host_step_ms"),
+                                                 "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region")}  # fmt: skip
             except Exception as e:
                 out["clustered_layouts"][lay] = {"error": repr(e)[:200]}
     if rank == 0:
