@@ -31,7 +31,46 @@ __device__ __forceinline__ int band_tile(const Band& b, int idx, int tile_w) {
   const int col = idx / b.nrows;
   return (b.r0 + idx - col * b.nrows) * tile_w + b.c0 + col;
 }
-
+// Whole-row bands (nx = 1) of the job lists are SPANS of the row-major tile sequence: [t0, t1) may begin and end inside
+// a row, so that the eight XCDs hold equal numbers of tiles (68 tile rows of a 1080p frame are 8 or 9 rows a band: the
+// XCDs with 9 finished 4 % after the others in both launches, profiles/r04_job_timeline.md).  Order inside a span:
+// column-major over its rows (a tile and its vertical neighbours back to back in one L2), the columns ragged at the top
+// and at the bottom.
+struct Span {
+  int t0, t1;
+};
+__device__ __forceinline__ int span_tile(const Span& s, int idx, int tile_w) {
+  // column-major over the span's rows r0 .. r1 (r1 = the row of its last tile): column c holds the complete rows between
+  // them, row r0 if c >= c0 and row r1 if c <= c1 -- three runs of columns of constant height
+  const int r0 = s.t0 / tile_w, c0 = s.t0 - r0 * tile_w;
+  const int last = s.t1 - 1, r1 = last / tile_w, c1 = last - r1 * tile_w;
+  if (r0 == r1) return s.t0 + idx;  // (within one row)
+  const int mid = r1 - r0 - 1;  // complete rows
+  // runs: [0, a) , [a, b) , [b, W) with a = min(c0, c1 + 1), b = max(c0, c1 + 1)
+  const int a = min(c0, c1 + 1), b = max(c0, c1 + 1);
+  const int h0 = mid + 1;                              // columns < a: row r1 only (c <= c1) ... or row r0 only (c >= c0): see below
+  const int h1 = mid + (c0 <= c1 + 1 ? 2 : 0);         // columns in [a, b): both partial rows (c0 <= c <= c1) or neither
+  const int h2 = mid + 1;                              // columns >= b
+  // columns < a have c < c0 (no row r0) and c <= c1 (row r1) when a = c0 <= c1 + 1; when a = c1 + 1 < c0 they have c <= c1
+  // too: in both cases exactly row r1 of the two.  Columns >= b have c >= c0 (row r0) and c > c1 (no row r1).
+  int col, k;  // k: position inside the column, top to bottom
+  const int n0 = a * h0, n1 = (b - a) * h1;
+  if (idx < n0) {
+    col = idx / h0;
+    k = idx - col * h0;
+    return (r0 + 1 + k) * tile_w + col;  // rows r0 + 1 .. r1
+  }
+  if (idx < n0 + n1) {
+    const int j = idx - n0;
+    col = a + j / h1;
+    k = j - (col - a) * h1;
+    return (c0 <= c1 + 1 ? r0 + k : r0 + 1 + k) * tile_w + col;  // rows r0 .. r1, or the complete rows only
+  }
+  const int j = idx - n0 - n1;
+  col = b + j / h2;
+  k = j - (col - b) * h2;
+  return (r0 + k) * tile_w + col;  // rows r0 .. r1 - 1
+}
 
 // Job lists (fg_raster_build_jobs): job sizes chosen by POSITION as above and by CONTENT -- a tile
 // whose list is longer than total * a4 / 65536 becomes four single-strip jobs, longer than
@@ -147,7 +186,8 @@ constexpr int FG_BAND_MAX_ROWS = 1024;
 // heaviest of them is within balance_percent of the mean (the launch policy is tuned on them; on the uniform bench scene the
 // cost model's bands were 3% slower than the equal ones).  row0[0 .. 8] in LDS.
 template <int NTH>
-__device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int32_t* __restrict__ tile_offsets, int* row0) {
+__device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int32_t* __restrict__ tile_offsets, int* tile0) {
+  __shared__ int row0[9];
   __shared__ uint32_t s_roww[FG_BAND_MAX_ROWS];
   const int tile_w = jb.tile_w, tile_h = jb.tile_h, T = tile_w * tile_h;
   const bool uniform = jb.nx != 1 || jb.rows_limit <= 0 || tile_h < 16 || tile_h > FG_BAND_MAX_ROWS;
@@ -179,10 +219,12 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    if (uniform) {
+    bool by_rows = false;  // the boundaries are rows (balanced by cost) / equal numbers of tiles
+    if (jb.nx == 1 && jb.rows_limit <= 0) {  // balance_bands = 0: the equal row bands of rounds 1-3 (A/B)
       for (int x = 0; x < 8; ++x) row0[x] = band_of_xcd(x, tile_w, tile_h, 1).r0;
       row0[8] = tile_h;
-    } else {
+      by_rows = true;
+    } else if (!uniform) {
       unsigned long long W = 0, cum = 0, heaviest = 0;
       for (int x = 0; x < 8; ++x) {  // the equal bands' shares: left alone unless one of them is well above the mean
         const Band e = band_of_xcd(x, tile_w, tile_h, 1);
@@ -194,7 +236,8 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
       }
       row0[8] = tile_h;
       int r = 0;
-      if (8 * heaviest * 100 > W * (unsigned)jb.balance_percent)
+      by_rows = 8 * heaviest * 100 > W * (unsigned)jb.balance_percent;
+      if (by_rows)
       for (int x = 0; x < 8; ++x) {
         row0[x] = r;
         const int left = tile_h - r, others = 7 - x;
@@ -206,6 +249,7 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
         r += x == 7 ? left : n;
       }
     }
+    for (int x = 0; x <= 8; ++x) tile0[x] = by_rows ? row0[x] * tile_w : (int)((long long)x * T / 8);
   }
   __syncthreads();
 }
@@ -232,13 +276,15 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   int32_t* jobs = bwd ? jb.jobs_bwd : jb.jobs_fwd;
   if (!jobs) return;
   const JobParams p = bwd ? pb : pf;
-  Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);
+  const Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);  // (nx != 1: rectangles, an A/B knob)
+  Span span{0, 0};
   if (jb.nx == 1) {
     if (!reuse_bands) balanced_row_bands<NTH>(jb, tile_offsets, s_row0);
-    band.r0 = s_row0[xcd];
-    band.nrows = s_row0[xcd + 1] - s_row0[xcd];
+    span = Span{s_row0[xcd], s_row0[xcd + 1]};
   }
-  const int n = band.nrows * band.ncols;
+  const bool spans = jb.nx == 1;
+  const int n = spans ? span.t1 - span.t0 : band.nrows * band.ncols;
+  auto tile_at = [&](int idx) { return spans ? span_tile(span, idx, tile_w) : band_tile(band, idx, tile_w); };
   const int total = tile_offsets[tile_w * tile_h];
   const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
   // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
@@ -273,7 +319,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   for (int round = 0; round < 12; ++round) {
     int mine = 0, need = 0;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
-      const int tile = band_tile(band, idx, tile_w);
+      const int tile = tile_at(idx);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       const bool slots = has_slots(idx, tile, len);
       mine += p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
@@ -308,7 +354,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
           const int idx = n - 1 - (base + (int)threadIdx.x);
           int nd = 0, tile = 0;
           if (idx >= 0) {
-            tile = band_tile(band, idx, tile_w);
+            tile = tile_at(idx);
             const int len = tile_offsets[tile + 1] - tile_offsets[tile];
             nd = candidate(idx, len) ? (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H : 0;
           }
@@ -339,7 +385,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       // (a pass of its own: the build rides in a 1024-thread launch, 128 registers)
       int heavy = 0;  // heavy tiles | their local jobs << 12
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
-        const int tile = band_tile(band, idx, tile_w);
+        const int tile = tile_at(idx);
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
         if (len > thr_h && has_slots(idx, tile, len)) heavy += 1 + (heavy_local_jobs(len) << 12);
       }
@@ -371,7 +417,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     int cnt = 0, tile = 0, flag = 0, need = 0;
     bool heavy_tile = false;
     if (idx < n) {
-      tile = band_tile(band, idx, tile_w);
+      tile = tile_at(idx);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       const bool slots = has_slots(idx, tile, len);
       cnt = p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
@@ -429,7 +475,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     int32_t* lc = jobs + jb.main_words;
     int32_t* hv = lc + FG_LOCAL_WORDS;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
-      const int tile = band_tile(band, idx, tile_w);
+      const int tile = tile_at(idx);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       if (len > thr_h && has_slots(idx, tile, len)) {
         const int nl = heavy_local_jobs(len);

@@ -241,11 +241,13 @@ typedef struct fg_raster_config {
   int32_t seg_tail2;
   int32_t debug_only_xcd;  /* measurement hooks of the classic launches: only this XCD's workgroups work (-1 = off) */
   int32_t debug_k_mod;     /* ... only every m-th tile of each XCD (0 = off) */
-  int32_t balance_bands;   /* job lists (ABI 7): the XCDs' bands of tile rows hold equal shares of the tiles' expected cost
-                              (list lengths, capped) instead of equal numbers of rows -- a cluster of splats under one
-                              band no longer sets the launch time -- when the heaviest equal band is more than 15% above
-                              the mean; 0 = equal rows always; -1 / 1 = default; p >= 100: the threshold in percent of
-                              the mean (100 = always by cost) */
+  int32_t balance_bands;   /* job lists (ABI 7): the XCDs' shares of the tile grid are SPANS of the row-major tile sequence
+                              with equal numbers of tiles (a span may begin and end inside a row; walked column-major) --
+                              or, when the heaviest such share would be more than 15% above the mean, bands of whole tile
+                              rows holding equal shares of the tiles' expected cost (list lengths, capped): a cluster of
+                              splats under one band no longer sets the launch time; 0 = equal numbers of ROWS always
+                              (rounds 1-3: 8 or 9 of a 1080p frame's 68); -1 / 1 = default; p >= 100: the threshold in
+                              percent of the mean (100 = always by cost) */
   int32_t heavy_tiles;     /* forward, job lists + list segments (ABI 7): a tile whose list is longer than this many entries
                               is walked serially for its first 2048 entries only; if pixels are still open there, the rest
                               of the list is composited by MANY jobs over shares of it -- every 64-entry batch by itself
