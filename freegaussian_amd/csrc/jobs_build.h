@@ -157,7 +157,8 @@ struct JobBuild {
   // can take; 0 = the equal bands of band_of_xcd)
   int main_words;  // words of the main list: the heavy tiles' local and combine lists start there (forward list, heavy_len > 0)
   int rows_limit;
-  int balance_percent;  // ... when the heaviest equal band's cost exceeds this many percent of the mean band's
+  int balance_percent;  // ... when the heaviest equal span's cost exceeds this many percent of the mean's; 0: equal ROW bands
+                        // (rounds 1-3, A/B); -1: equal spans, the cost is not looked at (a host that knows the scene is even)
   // COMPACT CHECKPOINT SLOTS (list shares; slot_budget > 0): the checkpoint buffer has 8 x slot_budget slots, an XCD's
   // band owns slot_budget of them, and a tile the backward may cut into shares (or a heavy tile) gets ceil(len / 64)
   // consecutive ones -- granted from the END of the band's sequence (the positional tail first) while they last; a
@@ -190,7 +191,7 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
   __shared__ int row0[9];
   __shared__ uint32_t s_roww[FG_BAND_MAX_ROWS];
   const int tile_w = jb.tile_w, tile_h = jb.tile_h, T = tile_w * tile_h;
-  const bool uniform = jb.nx != 1 || jb.rows_limit <= 0 || tile_h < 16 || tile_h > FG_BAND_MAX_ROWS;
+  const bool uniform = jb.nx != 1 || jb.balance_percent <= 0 || jb.rows_limit <= 0 || tile_h < 16 || tile_h > FG_BAND_MAX_ROWS;
   if (!uniform) {
     for (int r = threadIdx.x; r < tile_h; r += NTH) s_roww[r] = 0u;
     __syncthreads();
@@ -220,19 +221,25 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
   }
   if (threadIdx.x == 0) {
     bool by_rows = false;  // the boundaries are rows (balanced by cost) / equal numbers of tiles
-    if (jb.nx == 1 && jb.rows_limit <= 0) {  // balance_bands = 0: the equal row bands of rounds 1-3 (A/B)
+    if (jb.nx == 1 && jb.balance_percent == 0) {  // balance_bands = 0: the equal row bands of rounds 1-3 (A/B)
       for (int x = 0; x < 8; ++x) row0[x] = band_of_xcd(x, tile_w, tile_h, 1).r0;
       row0[8] = tile_h;
       by_rows = true;
     } else if (!uniform) {
       unsigned long long W = 0, cum = 0, heaviest = 0;
-      for (int x = 0; x < 8; ++x) {  // the equal bands' shares: left alone unless one of them is well above the mean
-        const Band e = band_of_xcd(x, tile_w, tile_h, 1);
-        unsigned long long w = 0;
-        for (int r = e.r0; r < e.r0 + e.nrows; ++r) w += s_roww[r];
+      for (int x = 0; x < 8; ++x) {  // the equal spans' shares: left alone unless one of them is well above the mean
+        // (a span's cost from the row sums: its partial first and last rows count by the fraction of the row it holds)
+        const long long t0 = (long long)x * T / 8, t1 = (long long)(x + 1) * T / 8;
+        unsigned long long w8 = 0;  // in 1/tile_w of a row's cost
+        for (int r = (int)(t0 / tile_w); r <= (int)((t1 - 1) / tile_w); ++r) {
+          const long long a = r * (long long)tile_w > t0 ? r * (long long)tile_w : t0;
+          const long long b = (r + 1) * (long long)tile_w < t1 ? (r + 1) * (long long)tile_w : t1;
+          w8 += (unsigned long long)s_roww[r] * (unsigned long long)(b - a);
+        }
+        const unsigned long long w = w8 / (unsigned)tile_w;
         W += w;
         heaviest = w > heaviest ? w : heaviest;
-        row0[x] = e.r0;
+        row0[x] = band_of_xcd(x, tile_w, tile_h, 1).r0;
       }
       row0[8] = tile_h;
       int r = 0;

@@ -191,6 +191,9 @@ class RasterContext:
         # Compact checkpoint slots (FG_COMPACT_SLOTS=0: off): the buffer of the backward's list shares sized by what the tiles
         # the backward may split need (reported by every list build, read one call late) instead of by the list's capacity
         self.compact_slots = e.get("FG_COMPACT_SLOTS", "1") != "0"
+        # FG_EVEN_BANDS=0: never skip the cost pass of the XCD shares (cfg(even=True))
+        self.even_bands = e.get("FG_EVEN_BANDS", "1") != "0"
+        self.even_calls = {}  # shape -> consecutive calls without a tile list beyond three times the mean
         self.last_seg_slots = 0  # what the last call with list shares ran with (0: a slot per 64 entries of the capacity)
         self.ckpt_need = {}  # shape -> the last calls' needs (slots of the fullest XCD band)
         self.ckpt_pending = {}  # shape -> (ring slot, generation) of the call whose report has not been read yet
@@ -231,16 +234,19 @@ class RasterContext:
         # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
         self.color_grad_sink = None
 
-    def cfg(self, heavy: bool = False, seg_slots: int = 0) -> int:
+    def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False) -> int:
         """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
-        ``heavy_tiles`` set (unless the policy sets it itself); ``seg_slots`` > 0: with compact checkpoint slots, that many.
-        The copies live as long as the context: autograd nodes and cached step plans hold their addresses."""
+        ``heavy_tiles`` set (unless the policy sets it itself); ``seg_slots`` > 0: with compact checkpoint slots, that many;
+        ``even``: with ``balance_bands = 2`` (equal numbers of tiles per XCD without looking at the costs: a shape whose
+        recent calls had no tile list far above the mean).  The copies live as long as the context: autograd nodes and
+        cached step plans hold their addresses."""
         heavy_len = self.heavy_tile_len if heavy and self.policy.heavy_tiles <= 0 else 0
         if self.policy.seg_slots > 0:
             seg_slots = 0  # (the policy's own value stands)
-        if not heavy_len and seg_slots <= 0:
+        even = bool(even) and self.policy.balance_bands in (-1, 1) and not heavy_len
+        if not heavy_len and seg_slots <= 0 and not even:
             return self.policy.ptr()
-        key = (bytes(self.policy), heavy_len, int(seg_slots))  # (the policy may have been replaced or changed in place)
+        key = (bytes(self.policy), heavy_len, int(seg_slots), even)  # (the policy may have been replaced or changed in place)
         copy = self._policy_copies.get(key)
         if copy is None:
             copy = type(self.policy).from_buffer_copy(self.policy)
@@ -248,8 +254,15 @@ class RasterContext:
                 copy.heavy_tiles = heavy_len
             if seg_slots > 0:
                 copy.seg_slots = int(seg_slots)
+            if even:
+                copy.balance_bands = 2
             self._policy_copies[key] = copy
         return copy.ptr()
+
+    def even_shape(self, lkey) -> bool:
+        """Has this shape shown only even scenes lately (no tile list beyond three times the mean in its last eight
+        calls)?  Then the job lists take equal numbers of tiles per XCD without the cost pass (``balance_bands = 2``)."""
+        return self.even_bands and self.even_calls.get(lkey, 0) >= 8
 
     def seg_slots_for(self, lkey, capacity: int, n_tiles: int) -> int:
         """Compact checkpoint slots for the next call of a shape (fg_raster_config::seg_slots), from what the list builds
@@ -733,6 +746,10 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> in
             if shapes[lkey] <= 0:
                 del shapes[lkey]
     _note_ckpt_need(rctx, lkey, count_slot, need_reported)
+    longest, n_tiles = _poll_count(count_slot, 2), max(lkey[2] * lkey[3], 1)
+    if len(rctx.even_calls) > 256 and lkey not in rctx.even_calls:
+        rctx.even_calls.pop(next(iter(rctx.even_calls)))
+    rctx.even_calls[lkey] = min(rctx.even_calls.get(lkey, 0) + 1, 1 << 20) if longest * n_tiles <= 3 * n_isects + 32 * n_tiles else 0
     return _note_list_length(rctx, key, n_isects)
 
 
@@ -755,7 +772,8 @@ def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None):
         return None
     channels, width, height = (int(v) for v in raster_hint)
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
-    cfgp = rctx.cfg(heavy, rctx.seg_slots_for(lkey, n_list, n_tiles) if lkey is not None and channels == 3 else 0)
+    cfgp = rctx.cfg(heavy, rctx.seg_slots_for(lkey, n_list, n_tiles) if lkey is not None and channels == 3 else 0,
+                    lkey is not None and rctx.even_shape(lkey))
     words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
@@ -1504,7 +1522,7 @@ class _RasterStep(torch.autograd.Function):
         capacity = rctx.isect_capacity[ckey]
         while True:
             seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h) if channels == 3 and want_backward else 0
-            cfgp = rctx.cfg(heavy, seg_slots)
+            cfgp = rctx.cfg(heavy, seg_slots, rctx.even_shape(lkey))
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
                    n_clamp, int(want_backward), int(shares), _lib.STBIN_LONG_SEGMENTS if long_mode else 0, capacity, eps2d,

@@ -246,8 +246,10 @@ typedef struct fg_raster_config {
                               or, when the heaviest such share would be more than 15% above the mean, bands of whole tile
                               rows holding equal shares of the tiles' expected cost (list lengths, capped): a cluster of
                               splats under one band no longer sets the launch time; 0 = equal numbers of ROWS always
-                              (rounds 1-3: 8 or 9 of a 1080p frame's 68); -1 / 1 = default; p >= 100: the threshold in
-                              percent of the mean (100 = always by cost) */
+                              (rounds 1-3: 8 or 9 of a 1080p frame's 68); 2 = equal numbers of tiles always, the costs are
+                              not looked at and lists and grids are sized for equal shares (for a host that knows the
+                              scene is even: fg_stbin_count's count_out[2] against the mean list; 5-10 us less per step);
+                              -1 / 1 = default; p >= 100: the threshold in percent of the mean (100 = always by cost) */
   int32_t heavy_tiles;     /* forward, job lists + list segments (ABI 7): a tile whose list is longer than this many entries
                               is walked serially for its first 2048 entries only; if pixels are still open there, the rest
                               of the list is composited by MANY jobs over shares of it -- every 64-entry batch by itself
