@@ -187,9 +187,9 @@ constexpr int FG_BAND_MAX_ROWS = 1024;
 // heaviest of them is within balance_percent of the mean (the launch policy is tuned on them; on the uniform bench scene the
 // cost model's bands were 3% slower than the equal ones).  row0[0 .. 8] in LDS.
 template <int NTH>
-__device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int32_t* __restrict__ tile_offsets, int* tile0) {
+__device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int32_t* __restrict__ tile_offsets, int* tile0,
+                                                   uint32_t* s_roww) {  // s_roww: FG_BAND_MAX_ROWS words of LDS
   __shared__ int row0[9];
-  __shared__ uint32_t s_roww[FG_BAND_MAX_ROWS];
   const int tile_w = jb.tile_w, tile_h = jb.tile_h, T = tile_w * tile_h;
   const bool uniform = jb.nx != 1 || jb.balance_percent <= 0 || jb.rows_limit <= 0 || tile_h < 16 || tile_h > FG_BAND_MAX_ROWS;
   if (!uniform) {
@@ -269,9 +269,10 @@ __attribute__((visibility("hidden"))) int plan_jobs(int width, int height, int t
 
 // workgroup `block` (0 .. FG_JOB_BLOCKS) of a build, NTH threads (a multiple of 64, all of the workgroup)
 // (reuse_bands: a workgroup's second call -- its other list -- takes the band boundaries its first call left in LDS)
+// (scratch: FG_BAND_MAX_ROWS words of LDS the caller can spare for the duration of the call)
 template <int NTH>
 __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, const int32_t* __restrict__ tile_offsets,
-                                                 bool reuse_bands = false) {
+                                                 uint32_t* scratch, bool reuse_bands = false) {
   constexpr int NWV = NTH / 64;
   __shared__ int wave_tot[NWV];
   __shared__ int carry;
@@ -286,7 +287,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   const Band band = band_of_xcd(xcd, tile_w, tile_h, jb.nx);  // (nx != 1: rectangles, an A/B knob)
   Span span{0, 0};
   if (jb.nx == 1) {
-    if (!reuse_bands) balanced_row_bands<NTH>(jb, tile_offsets, s_row0);
+    if (!reuse_bands) balanced_row_bands<NTH>(jb, tile_offsets, s_row0, scratch);
     span = Span{s_row0[xcd], s_row0[xcd + 1]};
   }
   const bool spans = jb.nx == 1;

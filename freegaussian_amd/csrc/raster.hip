@@ -125,7 +125,8 @@ __device__ __forceinline__ int job_of_block(int b, int tile_w, int tile_h, int n
 
 __global__ void __launch_bounds__(1024)
 build_jobs_kernel(fgjobs::JobBuild jb, const int32_t* __restrict__ tile_offsets) {
-  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets);
+  __shared__ uint32_t s_rows[fgjobs::FG_BAND_MAX_ROWS];
+  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets, s_rows);
 }
 
 // job k of XCD (b & 7) from a list; tile or -1.  *prefix: a strip job of a HEAVY tile (jobs_build.h: it walks the

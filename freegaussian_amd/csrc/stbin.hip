@@ -483,9 +483,11 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
       return;
     }
     if ((int)blockIdx.x >= first) {
-      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first, jb, tile_offsets);
-      __syncthreads();
-      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first + 8, jb, tile_offsets, jb.jobs_fwd != nullptr);
+      // (the forward's list here; the backward's -- not needed before the backward -- by eight workgroups at the end of
+      // the small-segment sort launch: two builds one after the other made these workgroups the launch's longest, 36 us
+      // on a clustered scene against 26 for the scatter itself)
+      extern __shared__ uint32_t s_dyn[];  // (this launch's staging buffer: 132 KB, unused by this workgroup)
+      fgjobs::build_jobs_block<SC_BLOCK>((int)blockIdx.x - first, jb, tile_offsets, s_dyn);
       return;
     }
   }
@@ -1127,7 +1129,8 @@ __device__ __forceinline__ bool sort_supertile(SortShared<NW, KPT, BB>& sh, int 
 // inside the large-segment sort they cost it 35 spilled registers): the raster launches' job lists by a launch of their own
 __global__ void __launch_bounds__(1024)
 sb_build_jobs_kernel(fgjobs::JobBuild jb, const int32_t* __restrict__ tile_offsets) {
-  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets);
+  __shared__ uint32_t s_rows[fgjobs::FG_BAND_MAX_ROWS];
+  fgjobs::build_jobs_block<1024>((int)blockIdx.x, jb, tile_offsets, s_rows);
 }
 
 // ---- long segments: sample sort ------------------------------------------------------------------------------------
@@ -1348,11 +1351,20 @@ __global__ void __launch_bounds__(64 * SB_SMALL_WAVES)
 sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_offsets,
                      const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
                      uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
-                     int32_t* __restrict__ list_offsets, int32_t* __restrict__ over_list) {
+                     int32_t* __restrict__ list_offsets, int32_t* __restrict__ over_list, int job_blocks,
+                     fgjobs::JobBuild jb) {
   __shared__ SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS> sh;
   // supertile = workgroup id: neighbours go to different XCDs.  (By band the long segments of a centre-weighted
   // image all land on the two or three XCDs that own the middle rows.)
-  const int st = blockIdx.x;
+  // fg_stbin_fill_jobs: the backward's job list, one XCD's a workgroup, in FRONT of the supertiles (behind them they
+  // would start when the launch is nearly over: 26 -> 30 us); the builder's ~60 registers fit this launch's 64, its row
+  // sums lie in the sort's element buffer
+  if ((int)blockIdx.x < job_blocks) {
+    static_assert(sizeof(sh.img) >= fgjobs::FG_BAND_MAX_ROWS * sizeof(uint32_t), "row sums in the element buffer");
+    fgjobs::build_jobs_block<64 * SB_SMALL_WAVES>((int)blockIdx.x + 8, jb, tile_offsets, reinterpret_cast<uint32_t*>(sh.img));
+    return;
+  }
+  const int st = (int)blockIdx.x - job_blocks;
   if (st >= ((tile_w + 1) >> 1) * ((tile_h + 1) >> 1)) return;
   const int total = tile_offsets[tile_w * tile_h];
   const bool skewed = sort_supertile<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS, true>(
@@ -1617,7 +1629,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
   const int s_pad = (S + 1) & ~1;
   int stage_cap = band_rows == g.sh && S <= 65535 ? ((int)SB_SCATTER_LDS_BYTES - 8 * s_pad) / 10 : 0;
   stage_cap = stage_cap >= SB_MIN_STAGE ? (stage_cap & ~63) : 0;
-  bool want_jobs = jobs && (jobs->jobs_fwd || jobs->jobs_bwd);
+  bool want_jobs = jobs && (jobs->jobs_fwd || jobs->jobs_bwd), bwd_jobs_in_sort = false;
   if (stage_cap) {
     // dynamic LDS beyond 64 KB is an opt-in per function AND per device: remember which devices have it
     static std::atomic<uint64_t> attr_devices{0};
@@ -1642,6 +1654,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
                        long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{});
     want_jobs = false;
+    bwd_jobs_in_sort = jobs && jobs->jobs_bwd;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
@@ -1658,9 +1671,10 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
     hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
                        w.st_offsets, w.long_list, entries, scratch, fw.lt);
   }
-  hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h, tile_offsets,
-                     w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
-                     long_mode ? fw.lt.over_list : nullptr);
+  hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S + (bwd_jobs_in_sort ? 8 : 0)), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
+                     tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
+                     long_mode ? fw.lt.over_list : nullptr, bwd_jobs_in_sort ? 8 : 0,
+                     bwd_jobs_in_sort ? *jobs : fgjobs::JobBuild{});
   if (long_mode) {
     hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
                        (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);

@@ -342,7 +342,8 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
                          int32_t* jobs_fwd, int32_t* jobs_bwd, int bwd_list_shares, const fg_raster_config* config,
                     fg_stream_t stream);
 /* fg_stbin_fill + fg_raster_build_jobs in the same launches: eight extra workgroups at the end of the
- * scatter launch build the raster job lists from tile_offsets beside the scatter -- no launch
+ * scatter launch build the forward's job list from tile_offsets beside the scatter, eight at the head of the
+ * small-segment sort launch the backward's -- no launch
  * between the sorted lists and fg_raster_jobs_fwd (10 us of a 0.75 ms step on the 1M / 1080p scene).  width, height,
  * tile_size must give tile_w x tile_h; jobs_fwd / jobs_bwd / bwd_list_shares / config as for fg_raster_build_jobs
  * (both lists NULL: identical to fg_stbin_fill).  The lists depend on tile_offsets only: they stay valid when the
