@@ -864,8 +864,10 @@ def main(argv=None):
 
         out["clustered_layouts"] = {}
         for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2"):
-            cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "30", "--warmup", "10", "--settle-s",
-                   "0.3", "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
+            # (the parent's own settle time: on some boxes a 15-25 ms host stall sits ~0.5 s into a fresh process's
+            # device activity -- with a 0.3 s settle it was the second timed step of these children)
+            cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "40", "--warmup", "10", "--settle-s",
+                   str(max(args.settle_s, 1.0)), "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
                    "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
             try:
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
