@@ -447,6 +447,34 @@ def graph_only(args):
                               "idles between replays)"}))  # fmt: skip
 
 
+def clustered_children(args):
+    """The same measurement on two clustered layouts, each in a process of its own (the headline stays the uniform
+    scene): what the path does on captured-scene-like content -- long lists, saturated and not -- and which machinery
+    ran.  Run BEFORE this process touches the GPU: with the parent's (idle) queues on the device beside the child's, the
+    second timed step of a child stalled 16-23 ms on some boxes (multiples of 15.6 ms, never in a process alone on the
+    device)."""
+    import subprocess
+
+    res_all = {}
+    for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "40", "--warmup", "10", "--settle-s",
+               str(max(args.settle_s, 1.0)), "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
+               "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
+        try:
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            c = json.loads(res.stdout.strip().splitlines()[-1])
+            # (ms_per_step: the child's wall-clock mean over its 40 timed steps; the median host time per step beside it)
+            res_all[lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"],
+                            "ms_per_step_median": (c.get("host_step_ms") or {}).get("median"), "stage_ms": c["stage_ms"],
+                            "I_raster": c["config"]["I_raster"], "longest_tile_list": c["config"].get("longest_tile_list"),
+                            "long_segment_calls": c["config"].get("long_segment_calls"),
+                            "heavy_tile_steps": c["config"].get("heavy_tile_steps"), "host_step_ms": c.get("host_step_ms"),
+                            "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region")}  # fmt: skip
+        except Exception as e:
+            res_all[lay] = {"error": repr(e)[:200]}
+    return res_all
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     args = parse(argv)
@@ -459,6 +487,13 @@ def main(argv=None):
         print(json.dumps({k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
                          | {"n_gpus": int(os.environ.get("WORLD_SIZE", "1")), "gpus_arg": args.gpus}), flush=True)  # fmt: skip
         return
+
+    clustered = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.layout == "uniform" and not args.no_clustered and not under_profiler()):
+        import torch  # (importing torch and counting devices does not initialise the GPU)
+
+        if torch.cuda.device_count() > 0:
+            clustered = clustered_children(args)  # (before this process initialises the GPU)
 
     import datetime
 
@@ -857,32 +892,8 @@ def main(argv=None):
             out["graphed"] = json.loads(res.stdout.strip().splitlines()[-1])
         except Exception as e:
             out["graphed"] = {"error": repr(e)[:200]}
-    if world == 1 and rank == 0 and args.layout == "uniform" and not args.no_clustered and not under_profiler():
-        # the same measurement on two clustered layouts (child processes; the headline above stays the uniform scene):
-        # what the path does on captured-scene-like content -- long lists, saturated and not -- and which machinery ran
-        import subprocess
-
-        out["clustered_layouts"] = {}
-        for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2"):
-            # (the parent's own settle time: on some boxes a 15-25 ms host stall sits ~0.5 s into a fresh process's
-            # device activity -- with a 0.3 s settle it was the second timed step of these children)
-            cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "40", "--warmup", "10", "--settle-s",
-                   str(max(args.settle_s, 1.0)), "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
-                   "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
-            try:
-                res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-                c = json.loads(res.stdout.strip().splitlines()[-1])
-                # (ms_per_step: the child's wall-clock mean over its 40 timed steps -- on some boxes one step at the head of a
-                # fresh process's timed region stalls 16-23 ms on the host; the median host time per step is beside it)
-                out["clustered_layouts"][lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"],
-                                                 "ms_per_step_median": (c.get("host_step_ms") or {}).get("median"), "stage_ms": c["stage_ms"],
-                                                 "I_raster": c["config"]["I_raster"], "longest_tile_list": c["config"].get("longest_tile_list"),
-                                                 "long_segment_calls": c["config"].get("long_segment_calls"),
-                                                 "heavy_tile_steps": c["config"].get("heavy_tile_steps"),
-                                                 "host_step_ms": c.get("host_step_ms"),
-                                                 "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region")}  # fmt: skip
-            except Exception as e:
-                out["clustered_layouts"][lay] = {"error": repr(e)[:200]}
+    if clustered is not None:
+        out["clustered_layouts"] = clustered
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)
