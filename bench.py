@@ -494,6 +494,24 @@ def main(argv=None):
 
         if torch.cuda.device_count() > 0:
             clustered = clustered_children(args)  # (before this process initialises the GPU)
+    graphed = None
+    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and not args.no_graph and not under_profiler():
+        # the same step captured in one hipGraph (graphed.GraphedRaster), measured in a CHILD process (a failed capture
+        # aborts the process; the headline line must survive), alone on the device like the children above.
+        # Informational: the headline is the eager path, whose kernels can be timed individually.
+        import subprocess
+
+        import torch
+
+        if torch.cuda.device_count() > 0:
+            cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--n-gauss",
+                   str(args.n_gauss), "--width", str(args.width), "--height", str(args.height), "--sh-degree",
+                   str(args.sh_degree), "--layout", args.layout] + (["--fixed-view"] if args.fixed_view else [])  # fmt: skip
+            try:
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                graphed = json.loads(res.stdout.strip().splitlines()[-1])
+            except Exception as e:
+                graphed = {"error": repr(e)[:200]}
 
     import datetime
 
@@ -878,20 +896,8 @@ def main(argv=None):
         out["per_rank_mpix_per_s"] = [args.steps * P / float(x.item()) / 1e6 for x in per_rank]
     if rank == 0:
         out["clocks_after_timed_region"] = gpu_clocks()
-    if world == 1 and not args.no_graph and rank == 0 and not under_profiler():
-        # the same step captured in one hipGraph (graphed.GraphedRaster), measured in a CHILD process
-        # (a failed capture aborts the process; the headline line must survive).  Informational:
-        # the headline above is the eager path, whose kernels can be timed individually.
-        import subprocess
-
-        cmd = [sys.executable, os.path.abspath(__file__), "--graph-only", "--steps", str(args.steps), "--n-gauss",
-               str(args.n_gauss), "--width", str(args.width), "--height", str(args.height), "--sh-degree",
-               str(args.sh_degree)] + (["--fixed-view"] if args.fixed_view else [])  # fmt: skip
-        try:
-            res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-            out["graphed"] = json.loads(res.stdout.strip().splitlines()[-1])
-        except Exception as e:
-            out["graphed"] = {"error": repr(e)[:200]}
+    if graphed is not None:
+        out["graphed"] = graphed
     if clustered is not None:
         out["clustered_layouts"] = clustered
     if rank == 0:
