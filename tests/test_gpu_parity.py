@@ -1430,6 +1430,44 @@ def test_compact_checkpoint_slots_same_gradients_a_fraction_of_the_buffer(step_c
     assert all(v < 1e-5 for v in diff.values()), diff
 
 
+def test_launch_policies_the_host_picks_per_shape_change_no_result():
+    """Round-4 policies that depend on what a shape's earlier calls reported: equal numbers of tiles per XCD without the
+    cost pass (`balance_bands = 2`, after eight calls without a long tile list), issue priorities for the longest jobs
+    (`prio_fwd` / `prio_bwd`), equal ROW bands (`balance_bands = 0`, rounds 1-3).  Same image bit for bit, same
+    gradients up to the order of float atomics, whichever is on."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = synthetic_scene(120_000, 1920, 1080, n_views=1, sh_degree=3, seed=13, log_scale_mean=math.log(0.02))
+    raw = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+               features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, 1080, 1920, 3, generator=torch.Generator().manual_seed(3)).to(DEV)
+
+    def run(ctx, calls):
+        out = None
+        for _ in range(calls):
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}
+            with ops.use(ctx):
+                r, a, _ = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                 t["features_rest"], vm, K, 1920, 1080, 3, absgrad=True)  # fmt: skip
+                ((r * vr).sum() + a.sum()).backward()
+            out = (r.detach(), {k: v.grad for k, v in t.items()})
+        return out
+
+    base = ops.RasterContext(env={"FG_EVEN_BANDS": "0"}, policy=ops.launch_policy(prio_fwd=0, prio_bwd=0))
+    r0, g0 = run(base, 2)
+    even = ops.RasterContext(env={})
+    r1, g1 = run(even, 11)
+    (lkey,) = list(even.even_calls)
+    assert even.even_calls[lkey] >= 8 and even.even_shape(lkey) and not base.even_shape(lkey)
+    rows = ops.RasterContext(env={}, policy=ops.launch_policy(balance_bands=0))
+    r2, g2 = run(rows, 2)
+    for r, g in ((r1, g1), (r2, g2)):
+        assert torch.equal(r, r0)
+        diff = {k: rel_l2(g[k], g0[k]) for k in g0}
+        assert all(v < 1e-5 for v in diff.values()), diff
+
+
 def test_clustered_1m_scene_lists_equal_the_oracles_through_the_long_segment_sort(monkeypatch):
     """80% of a million Gaussians in a ball of extent 0.2 at 1920 x 1080 (scripts/clustered_check.py: supertile
     segments of 16 000 ... 158 000 elements, the longest tile list 111 000 entries): csrc/stbin.hip with the long
