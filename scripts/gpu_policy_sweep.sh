@@ -5,7 +5,7 @@ tag=${1:-policy}
 out=gpurun_out/$tag
 mkdir -p $out
 run() {
-  env $1 timeout 300 python bench.py --steps 48 --warmup 8 --no-cpu-baseline --no-graph 2>/dev/null | python3 -c "
+  env $1 timeout 300 python bench.py --no-clustered --steps 48 --warmup 8 --no-cpu-baseline --no-graph 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms']
 print('$1'.ljust(34), round(d['value'],1), round(d['ms_per_step'],4), 'bwd', s['fg_raster_bwd'], 'fwd', s['fg_raster_fwd'])" | tee -a $out/sweep.txt
