@@ -526,8 +526,8 @@ def _count_slot():
         i = _count_ring_next
         _count_ring_next = (i + 1) % _COUNT_RING
         _count_ring_gen[i] += 1
-    _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 12] = -1
-    _count_ring_stream[i] = torch.cuda.current_stream()
+        _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 12] = -1
+        _count_ring_stream[i] = torch.cuda.current_stream()  # (under the lock: slot i is this caller's from here on)
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
 
 
