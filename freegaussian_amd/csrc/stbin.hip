@@ -70,9 +70,10 @@ __host__ __device__ __forceinline__ int long_buckets(int n) {
   const int k = (n + LG_T - 1) / LG_T;
   return k > LG_KMAX ? LG_KMAX : (k < 2 ? 2 : k);
 }
-__host__ __device__ __forceinline__ int long_samples(int k) {
+// (cap: what the sampler's LDS sort takes; a long segment has more elements than that)
+__host__ __device__ __forceinline__ int long_samples(int k, int cap) {
   const int s = LG_SA * k;
-  return s > SB_LONG_MIN ? SB_LONG_MIN : s;  // (a long segment has more elements than that)
+  return s > cap ? cap : s;
 }
 // per bucket of every long segment (fill workspace, behind the two element arrays)
 struct LongTables {
@@ -385,9 +386,10 @@ template <int NTH>
 __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __restrict__ st_offsets, int small_max,
                                                     int32_t* __restrict__ large_list, int4* __restrict__ long_list,
                                                     bool long_mode, int4* __restrict__ chunk_seg,
-                                                    int4* __restrict__ bucket_seg) {
+                                                    int4* __restrict__ bucket_seg, int32_t* __restrict__ over_list = nullptr) {
   constexpr int NWV = NTH / 64;
   __shared__ int s_large;
+  if (long_mode && over_list && threadIdx.x == 0) over_list[0] = over_list[1] = 0;  // (the sort launches append to them)
   __shared__ uint32_t s_tot[3][NWV];
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   if (threadIdx.x == 0) s_large = 0;
@@ -466,7 +468,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                   uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list,
                   int4* __restrict__ long_list, int long_mode, int4* __restrict__ chunk_seg,
-                  int4* __restrict__ bucket_seg, int job_blocks, fgjobs::JobBuild jb) {
+                  int4* __restrict__ bucket_seg, int job_blocks, fgjobs::JobBuild jb, int32_t* __restrict__ over_list) {
   // fg_stbin_fill_jobs: the LAST job_blocks workgroups build the raster launches' job lists from the (exact) tile
   // ranges -- each the forward's and the backward's list of one XCD band -- beside the scatter, with no launch of
   // their own.  (STAGE only: one workgroup per CU by LDS, so the builder's 118 registers cost this kernel nothing;
@@ -479,7 +481,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
       const Geo gg = geo_of(tile_w, tile_h);
       if ((long long)tile_offsets[tile_w * tile_h] <= capacity)
         build_segment_lists<SC_BLOCK>(gg.sw * gg.sh, st_offsets, small_max, large_list, long_list, long_mode != 0, chunk_seg,
-                                      bucket_seg);
+                                      bucket_seg, over_list);
       return;
     }
     if ((int)blockIdx.x >= first) {
@@ -502,7 +504,8 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   if constexpr (!STAGE) {
     if (chunk == 0)
-      build_segment_lists<SC_BLOCK>(S, st_offsets, small_max, large_list, long_list, long_mode != 0, chunk_seg, bucket_seg);
+      build_segment_lists<SC_BLOCK>(S, st_offsets, small_max, large_list, long_list, long_mode != 0, chunk_seg, bucket_seg,
+                                    over_list);
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}
@@ -1153,7 +1156,7 @@ template <int NW, int KPT, int BB>
 __device__ __forceinline__ void sample_long_segment(SortShared<NW, KPT, BB>& sh, const uint64_t* __restrict__ src, int n,
                                                     int bucket_base, const LongTables& lt) {
   constexpr int NT = 64 * NW;
-  const int k = long_buckets(n), s = long_samples(k);
+  const int k = long_buckets(n), s = long_samples(k, SortShared<NW, KPT, BB>::MAXN);
   const uint64_t step = ((uint64_t)n << 16) / (uint64_t)s;  // sample i = element floor(i n / s): distinct positions
   sort_emit_lds<NW, KPT, BB, false>(sh, (int)threadIdx.x, [src, step](int i) { return src[((uint64_t)i * step) >> 16]; }, s,
                                     nullptr, nullptr);
@@ -1178,7 +1181,6 @@ sb_sort_large_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
   if ((long long)total > capacity) return;  // (the scatter kernel wrote no list then)
   // work items: the long segments' sample step first (the head of a chain of three more launches), then the LDS sorts
   const int n_long = long_list[0].x, count = large_list[0];
-  if ((int)blockIdx.x == job_blocks && threadIdx.x == 0) lt.over_list[0] = lt.over_list[1] = 0;
   for (int k = (int)blockIdx.x - job_blocks; k < n_long + count; k += (int)gridDim.x - job_blocks) {
     if (k < n_long) {
       const int4 ls = long_list[1 + k];
@@ -1352,7 +1354,7 @@ sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
                      const int32_t* __restrict__ st_offsets, uint64_t* __restrict__ entries,
                      uint64_t* __restrict__ scratch, long long capacity, int32_t* __restrict__ flatten_ids,
                      int32_t* __restrict__ list_offsets, int32_t* __restrict__ over_list, int job_blocks,
-                     fgjobs::JobBuild jb) {
+                     fgjobs::JobBuild jb, const int4* __restrict__ long_list, LongTables lt) {
   __shared__ SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS> sh;
   // supertile = workgroup id: neighbours go to different XCDs.  (By band the long segments of a centre-weighted
   // image all land on the two or three XCDs that own the middle rows.)
@@ -1371,6 +1373,27 @@ sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
       sh, st, tile_w, tile_h, tile_offsets, st_offsets, entries, scratch, (long long)total > capacity, total, flatten_ids,
       list_offsets, over_list != nullptr);
   if (skewed && threadIdx.x == 0) over_list[2 + atomicAdd(over_list, 1)] = -(st + 1);
+  // long mode: a segment beyond this launch's LDS sort is a LONG segment -- its own workgroup, which has nothing else to
+  // do, takes the sample step (splitters from a sorted regular sample; it used to be a work item of the large-segment
+  // launch, which long mode now does without: every segment beyond SB_LONG_SPLIT = this launch's capacity is long)
+  if (over_list && (long long)total <= capacity) {
+    using Sh = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>;
+    static_assert(Sh::MAXN == SB_LONG_SPLIT, "in long mode no segment is left for the large launch");
+    const int n = st_offsets[st + 1] - st_offsets[st];
+    if (n > Sh::MAXN) {
+      __shared__ int s_long;
+      if (threadIdx.x == 0) s_long = -1;
+      __syncthreads();
+      const int n_long = long_list[0].x;  // (the list is in supertile order; a look at every entry is one round trip)
+      for (int t = threadIdx.x; t < n_long; t += 64 * SB_SMALL_WAVES)
+        if (long_list[1 + t].x == st) s_long = t;
+      __syncthreads();
+      if (s_long >= 0) {
+        const int4 ls = long_list[1 + s_long];
+        sample_long_segment(sh, entries + st_offsets[st], ls.w, ls.z, lt);
+      }
+    }
+  }
 }
 
 // The buckets of the long segments (slot = work item) and the skewed segments the small launch left: LG_SORT_GRID
@@ -1652,30 +1675,32 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
     hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
-                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{});
+                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{},
+                       fw.lt.over_list);
     want_jobs = false;
     bwd_jobs_in_sort = jobs && jobs->jobs_bwd;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
                        reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
-                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, 0, fgjobs::JobBuild{});
+                       long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, 0, fgjobs::JobBuild{}, fw.lt.over_list);
   }
   if (want_jobs) hipLaunchKernelGGL(sb_build_jobs_kernel, dim3(fgjobs::FG_JOB_BLOCKS), dim3(1024), 0, s, *jobs, tile_offsets);
-  hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
-                     tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, w.long_list, fw.lt, entries, scratch,
-                     (long long)capacity, flatten_ids);
+  // (long mode: every segment beyond the small launch's capacity is a long segment -- no large launch; the small launch's
+  // workgroups of those segments take their sample step, the bucket passes follow it)
+  if (!long_mode)
+    hipLaunchKernelGGL(sb_sort_large_kernel, dim3(S < SB_LARGE_GRID ? S : SB_LARGE_GRID), dim3(64 * SB_LARGE_WAVES), 0, s,
+                       tile_w, tile_h, tile_offsets, w.st_offsets, w.large_list, w.long_list, fw.lt, entries, scratch,
+                       (long long)capacity, flatten_ids);
+  hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S + (bwd_jobs_in_sort ? 8 : 0)), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
+                     tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
+                     long_mode ? fw.lt.over_list : nullptr, bwd_jobs_in_sort ? 8 : 0,
+                     bwd_jobs_in_sort ? *jobs : fgjobs::JobBuild{}, w.long_list, fw.lt);
   if (long_mode) {
     hipLaunchKernelGGL(sb_long_count_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
                        w.st_offsets, w.long_list, entries, fw.lt);
     hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
                        w.st_offsets, w.long_list, entries, scratch, fw.lt);
-  }
-  hipLaunchKernelGGL(sb_sort_small_kernel, dim3(S + (bwd_jobs_in_sort ? 8 : 0)), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
-                     tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
-                     long_mode ? fw.lt.over_list : nullptr, bwd_jobs_in_sort ? 8 : 0,
-                     bwd_jobs_in_sort ? *jobs : fgjobs::JobBuild{});
-  if (long_mode) {
     hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
                        (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
     hipLaunchKernelGGL(sb_long_overflow_kernel, dim3(64), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, (long long)capacity,
