@@ -193,6 +193,12 @@ def test_launch_policy_comes_through_the_abi_not_the_environment(monkeypatch):
     lib = _lib.load()
     dflt = _lib.RasterConfig.defaults()
     assert dflt.size == ctypes.sizeof(_lib.RasterConfig) and dflt.seg_parts == -1 and dflt.use_liveness == 1
+    # the fields round 4 appended: their defaults leave every new path to the library's / the host's own choice
+    assert (dflt.balance_bands, dflt.heavy_tiles, dflt.seg_slots, dflt.prio_fwd, dflt.prio_bwd) == (-1, 0, 0, -1, -1)
+    pr = ops.launch_policy_from_env({"FG_RASTER_PRIO_FWD": "250,350", "FG_RASTER_PRIO_BWD": "0", "FG_RASTER_BALANCE": "2"})
+    assert (pr.prio_fwd, pr.prio_bwd, pr.balance_bands) == (250 | 350 << 16, 0, 2)
+    # equal shares without the cost pass: lists sized for equal bands (no band beyond its share), like balance_bands = 0
+    assert lib.fg_raster_jobs_words(1920, 1080, 16, _policy_ptr(balance_bands=2)) == lib.fg_raster_jobs_words(1920, 1080, 16, _policy_ptr(balance_bands=0))
     # the environment no longer reaches the library ...
     monkeypatch.setenv("FG_RASTER_PPT_FWD", "1")
     monkeypatch.setenv("FG_RASTER_PPT_BWD", "1")
