@@ -164,8 +164,8 @@ struct JobBuild {
   // consecutive ones -- granted from the END of the band's sequence (the positional tail first) while they last; a
   // tile without slots runs unsplit, without checkpoints.  slot_tab[tile] = first slot or -1, written into BOTH lists
   // at word tab_offset (every workgroup of a build computes the same grants from the same ranges).  need_out
-  // (nullable; pinned host memory or device): word xcd = the slots the band's candidates would take together, for
-  // the host to size the next buffer by.  slot_budget = 0: no table, slot index by formula (raster.hip seg_slot_base).
+  // (nullable; pinned host memory or device, NINE words): word xcd = the slots the band's candidates would take together,
+  // for the host to size the next buffer by; word 8 = what the cost pass of the shares decided (1 by cost, 0 equal, -1 not run).  slot_budget = 0: no table, slot index by formula (raster.hip seg_slot_base).
   int slot_budget, tab_offset;
   long long* need_out;
 };
@@ -257,6 +257,8 @@ __device__ __forceinline__ void balanced_row_bands(const JobBuild& jb, const int
       }
     }
     for (int x = 0; x <= 8; ++x) tile0[x] = by_rows ? row0[x] * tile_w : (int)((long long)x * T / 8);
+    // [9]: what the cost pass decided (1: bands by cost, 0: the equal spans stood), -1 when it did not run
+    tile0[9] = uniform || jb.balance_percent <= 0 ? -1 : (by_rows ? 1 : 0);
   }
   __syncthreads();
 }
@@ -276,7 +278,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   constexpr int NWV = NTH / 64;
   __shared__ int wave_tot[NWV];
   __shared__ int carry;
-  __shared__ int s_row0[9];
+  __shared__ int s_row0[10];
   const int xcd = block & 7;
   const bool bwd = block >= 8;
   const int tile_w = jb.tile_w, tile_h = jb.tile_h, cap = jb.cap;
@@ -290,6 +292,9 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     if (!reuse_bands) balanced_row_bands<NTH>(jb, tile_offsets, s_row0, scratch);
     span = Span{s_row0[xcd], s_row0[xcd + 1]};
   }
+  // (the host may skip the cost pass for a shape whose last calls all kept the equal spans: word 8 of need_out)
+  if (jb.nx == 1 && !bwd && xcd == 0 && jb.need_out && threadIdx.x == 0 && !reuse_bands)
+    __hip_atomic_store(jb.need_out + 8, (long long)s_row0[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool spans = jb.nx == 1;
   const int n = spans ? span.t1 - span.t0 : band.nrows * band.ncols;
   auto tile_at = [&](int idx) { return spans ? span_tile(span, idx, tile_w) : band_tile(band, idx, tile_w); };

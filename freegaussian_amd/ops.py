@@ -194,6 +194,8 @@ class RasterContext:
         # FG_EVEN_BANDS=0: never skip the cost pass of the XCD shares (cfg(even=True))
         self.even_bands = e.get("FG_EVEN_BANDS", "1") != "0"
         self.even_calls = {}  # shape -> consecutive calls without a tile list beyond three times the mean
+        self.equal_stood = {}  # shape -> consecutive cost passes of the list build that kept the equal spans
+        self.shape_calls = {}  # shape -> calls so far
         self.last_seg_slots = 0  # what the last call with list shares ran with (0: a slot per 64 entries of the capacity)
         self.ckpt_need = {}  # shape -> the last calls' needs (slots of the fullest XCD band)
         self.ckpt_pending = {}  # shape -> (ring slot, generation) of the call whose report has not been read yet
@@ -243,7 +245,7 @@ class RasterContext:
         heavy_len = self.heavy_tile_len if heavy and self.policy.heavy_tiles <= 0 else 0
         if self.policy.seg_slots > 0:
             seg_slots = 0  # (the policy's own value stands)
-        even = bool(even) and self.policy.balance_bands in (-1, 1) and not heavy_len
+        even = bool(even) and self.policy.balance_bands in (-1, 1)
         if not heavy_len and seg_slots <= 0 and not even:
             return self.policy.ptr()
         key = (bytes(self.policy), heavy_len, int(seg_slots), even)  # (the policy may have been replaced or changed in place)
@@ -262,7 +264,14 @@ class RasterContext:
     def even_shape(self, lkey) -> bool:
         """Has this shape shown only even scenes lately (no tile list beyond three times the mean in its last eight
         calls)?  Then the job lists take equal numbers of tiles per XCD without the cost pass (``balance_bands = 2``)."""
-        return self.even_bands and self.even_calls.get(lkey, 0) >= 8
+        if not self.even_bands:
+            return False
+        if self.even_calls.get(lkey, 0) >= 8:
+            return True
+        # ... or the cost pass itself kept the equal spans in the shape's last eight calls that ran it (a few long lists, the
+        # shares even all the same); it runs again every 64th call of the shape
+        n = self.shape_calls.get(lkey, 0)
+        return self.equal_stood.get(lkey, 0) >= 8 and n % 64 != 0
 
     def seg_slots_for(self, lkey, capacity: int, n_tiles: int) -> int:
         """Compact checkpoint slots for the next call of a shape (fg_raster_config::seg_slots), from what the list builds
@@ -516,7 +525,7 @@ _RING_WORDS = 16  # int64 words per slot
 def _count_slot():
     """A slot of sixteen pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
     segment, [2] the longest tile list, [3] the segments beyond the small sort's capacity (fg_stbin_count only; they stay
-    -1 otherwise), [4..11] the checkpoint slots the
+    -1 otherwise), [12] what the cost pass over the XCDs' shares decided, [4..11] the checkpoint slots the
     eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late).  -> (slot, address)."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
@@ -526,7 +535,7 @@ def _count_slot():
         i = _count_ring_next
         _count_ring_next = (i + 1) % _COUNT_RING
         _count_ring_gen[i] += 1
-        _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 12] = -1
+        _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 13] = -1
         _count_ring_stream[i] = torch.cuda.current_stream()  # (under the lock: slot i is this caller's from here on)
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
 
@@ -543,6 +552,11 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool) -> None:
             del hist[:-8]
             if len(rctx.ckpt_need) > 256:
                 rctx.ckpt_need.pop(next(iter(rctx.ckpt_need)))
+        decided = int(_count_ring_np[_RING_WORDS * prev[0] + 12])
+        if decided >= 0:  # (the cost pass ran: 1 = it balanced the shares by cost, 0 = the equal spans stood)
+            if len(rctx.equal_stood) > 256 and lkey not in rctx.equal_stood:
+                rctx.equal_stood.pop(next(iter(rctx.equal_stood)))
+            rctx.equal_stood[lkey] = rctx.equal_stood.get(lkey, 0) + 1 if decided == 0 else 0
     if reported:
         if len(rctx.ckpt_pending) > 256:
             rctx.ckpt_pending.clear()
@@ -746,6 +760,9 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> in
             if shapes[lkey] <= 0:
                 del shapes[lkey]
     _note_ckpt_need(rctx, lkey, count_slot, need_reported)
+    if len(rctx.shape_calls) > 256 and lkey not in rctx.shape_calls:
+        rctx.shape_calls.pop(next(iter(rctx.shape_calls)))
+    rctx.shape_calls[lkey] = rctx.shape_calls.get(lkey, 0) + 1
     longest, n_tiles = _poll_count(count_slot, 2), max(lkey[2] * lkey[3], 1)
     if len(rctx.even_calls) > 256 and lkey not in rctx.even_calls:
         rctx.even_calls.pop(next(iter(rctx.even_calls)))

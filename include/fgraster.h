@@ -348,10 +348,12 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
  * tile_size must give tile_w x tile_h; jobs_fwd / jobs_bwd / bwd_list_shares / config as for fg_raster_build_jobs
  * (both lists NULL: identical to fg_stbin_fill).  The lists depend on tile_offsets only: they stay valid when the
  * call is repeated with a larger capacity.
- * ckpt_need_out (nullable; int64[8], pinned host memory or device memory, written by the launch): with
- * bwd_list_shares and a forward list, word x = the checkpoint slots the tiles of XCD x's band that the backward may
+ * ckpt_need_out (nullable; int64[9], pinned host memory or device memory, written by the launch): with
+ * bwd_list_shares and a forward list, word x < 8 = the checkpoint slots the tiles of XCD x's band that the backward may
  * split would take together (whether or not they got them; whatever fg_raster_config::seg_slots is): 8 x the largest
- * word, + a margin, is the seg_slots that leaves no tile without. */
+ * word, + a margin, is the seg_slots that leaves no tile without.  Word 8 (whenever the forward list is built): what the
+ * cost pass over the XCDs' shares decided -- 1 = bands balanced by cost, 0 = the equal spans stood, -1 = it did not run
+ * (balance_bands 0 / 2, small or huge grids): a host whose last calls of a shape all read 0 can set balance_bands = 2. */
 int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
                        int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                        int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
@@ -555,7 +557,7 @@ typedef struct fg_step_io {
      backward call: the raster backward): a host that times the dominant kernel of the step does not have to take the
      stage-wise entry points for it */
   void *ev_raster_begin, *ev_raster_end;
-  int64_t* ckpt_need_out; /* nullable, forward only: fg_stbin_fill_jobs' ckpt_need_out (int64[8]) */
+  int64_t* ckpt_need_out; /* nullable, forward only: fg_stbin_fill_jobs' ckpt_need_out (int64[9]) */
 } fg_step_io;
 typedef struct fg_step_layout {
   int64_t keep_bytes, tmp_bytes;
