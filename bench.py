@@ -668,7 +668,7 @@ def main(argv=None):
     if ops.default_context.stage_timer is not None:
         # (the settle steps' events are not part of the timed region's averages; the timed region's own event pairs exist
         # before it starts)
-        ops.default_context.stage_timer = ops.StageTimer(only=only, prewarm=(2 * args.steps + 4) if only else 0)
+        ops.default_context.stage_timer = ops.StageTimer(only=only, prewarm=(args.steps + 2) * max(len(only), 1) if only else 0)
     fence()
     t0 = time.perf_counter()
     views_seen = []
