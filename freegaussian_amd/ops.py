@@ -248,7 +248,8 @@ class RasterContext:
         even = bool(even) and self.policy.balance_bands in (-1, 1)
         if not heavy_len and seg_slots <= 0 and not even:
             return self.policy.ptr()
-        key = (bytes(self.policy), heavy_len, int(seg_slots), even)  # (the policy may have been replaced or changed in place)
+        # (the policy may have been replaced or changed in place; few keys per policy: seg_slots comes in steps of 4096 slots)
+        key = (bytes(self.policy), heavy_len, int(seg_slots), even)
         copy = self._policy_copies.get(key)
         if copy is None:
             copy = type(self.policy).from_buffer_copy(self.policy)
