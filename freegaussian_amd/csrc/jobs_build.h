@@ -305,7 +305,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   int thr2 = p.s2 ? (int)(((int64_t)total * p.s2) >> 16) : 0x7fffffff;
   const int thr2_b = pb.s2 ? (int)(((int64_t)total * pb.s2) >> 16) : 0x7fffffff;  // the backward's, as given
   int thr_h = p.heavy_len > 0 ? p.heavy_len : 0x7fffffff;
-  __shared__ int heavy_tot[NWV];
+  __shared__ long long heavy_tot[NWV];
   __shared__ int heavy_n, local_n;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // Compact checkpoint slots.  A CANDIDATE is a tile the backward may cut into shares (by its un-raised content
@@ -396,21 +396,21 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     bool fits = all <= p.max_jobs;  // uniform across the workgroup
     if (!bwd && thr_h != 0x7fffffff) {
       // (a pass of its own: the build rides in a 1024-thread launch, 128 registers)
-      int heavy = 0;  // heavy tiles | their local jobs << 12
+      long long heavy = 0;  // heavy tiles | their local jobs << 32 (a band of an 8K frame holds more than 4096 tiles)
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
         const int tile = tile_at(idx);
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-        if (len > thr_h && has_slots(idx, tile, len)) heavy += 1 + (heavy_local_jobs(len) << 12);
+        if (len > thr_h && has_slots(idx, tile, len)) heavy += 1ll + ((long long)heavy_local_jobs(len) << 32);
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) heavy += __shfl_xor(heavy, m);
       __syncthreads();
       if (lane == 0) heavy_tot[wave] = heavy;
       __syncthreads();
-      int all_heavy = 0;
+      long long all_heavy = 0;
 #pragma unroll
       for (int w = 0; w < NWV; ++w) all_heavy += heavy_tot[w];
-      fits = fits && 4 * (all_heavy & 0xFFF) <= FG_HEAVY_CAP && (all_heavy >> 12) <= FG_LOCAL_CAP;
+      fits = fits && 4 * (all_heavy & 0xFFFFFFFFll) <= FG_HEAVY_CAP && (all_heavy >> 32) <= FG_LOCAL_CAP;
     }
     if (fits) break;
     thr4 = thr4 > 0x50000000 ? 0x7fffffff : thr4 + (thr4 >> 1) + 1;
@@ -482,6 +482,12 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     __syncthreads();
   }
   if (threadIdx.x == 0) jobs[xcd] = carry;
+  if (!bwd && p.heavy_len <= 0 && jb.tab_offset > jb.main_words && threadIdx.x == 0) {
+    // the policy has heavy tiles on (the two lists are in the layout and launch_fwd_mixed reads their counts) but this
+    // build runs without them (no list shares: no checkpoint buffer): empty lists, not uninitialised ones
+    jobs[jb.main_words + xcd] = 0;
+    jobs[jb.main_words + FG_LOCAL_WORDS + xcd] = 0;
+  }
   if (!bwd && p.heavy_len > 0) {
     // the heavy tiles' local jobs and their four combine jobs each, on the lists of the two launches behind the main one
     // (a pass of its own: registers, see above; any order)

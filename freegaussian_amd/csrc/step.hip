@@ -174,8 +174,8 @@ extern "C" int fg_step_bwd(const fg_step_desc* d, const fg_raster_config* config
                                             io->v_extra, sh_jac, stream);
     return fg_preprocess_raw_bwd(N, io->means, io->quats, io->d_quats, io->scales, io->d_scales, io->opacities, io->colors,
                                  io->features_rest, d->sh_degree, d->k_stored, d->with_depth, d->n_extra, io->viewmat, io->K, W,
-                                 H, d->eps2d, d->antialiased, radii, v_splats, v_splats, FG_SPLAT_FLOATS, nullptr, nullptr,
-                                 io->v_means, io->v_quats, io->v_d_quats, io->v_scales, io->v_d_scales, io->v_opacities,
+                                 H, d->eps2d, d->antialiased, radii, v_splats, v_splats, FG_SPLAT_FLOATS, io->v_depths,
+                                 io->v_conics, io->v_means, io->v_quats, io->v_d_quats, io->v_scales, io->v_d_scales, io->v_opacities,
                                  io->v_colors, io->v_features_rest, io->v_extra, sh_jac, stream);
   }
   if (io->v_rgb)

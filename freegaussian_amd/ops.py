@@ -242,12 +242,20 @@ class RasterContext:
         ``even``: with ``balance_bands = 2`` (equal numbers of tiles per XCD without looking at the costs: a shape whose
         recent calls had no tile list far above the mean).  The copies live as long as the context: autograd nodes and
         cached step plans hold their addresses."""
+        return self.cfg_variant(heavy, seg_slots, even)[0]
+
+    def cfg_variant(self, heavy: bool = False, seg_slots: int = 0, even: bool = False):
+        """``cfg`` and the VALUES that tell the variant from the context's own policy: (address, (heavy_len, seg_slots,
+        even)) -- what a cache of anything derived from the policy is keyed on (an address can be reused by another
+        context's copy)."""
         heavy_len = self.heavy_tile_len if heavy and self.policy.heavy_tiles <= 0 else 0
         if self.policy.seg_slots > 0:
             seg_slots = 0  # (the policy's own value stands)
+        seg_slots = max(int(seg_slots), 0)
         even = bool(even) and self.policy.balance_bands in (-1, 1)
+        variant = (heavy_len, seg_slots, even)
         if not heavy_len and seg_slots <= 0 and not even:
-            return self.policy.ptr()
+            return self.policy.ptr(), variant
         # (the policy may have been replaced or changed in place; few keys per policy: seg_slots comes in steps of 4096 slots)
         key = (bytes(self.policy), heavy_len, int(seg_slots), even)
         copy = self._policy_copies.get(key)
@@ -260,7 +268,7 @@ class RasterContext:
             if even:
                 copy.balance_bands = 2
             self._policy_copies[key] = copy
-        return copy.ptr()
+        return copy.ptr(), variant
 
     def even_shape(self, lkey) -> bool:
         """Has this shape shown only even scenes lately (no tile list beyond three times the mean in its last eight
@@ -1460,12 +1468,13 @@ def rasterize_splats(splats, means2d, channels, width, height, tile_size, tile_o
 _STEP_PLANS: dict = {}
 
 
-def _step_plan(rctx, key):
-    """(desc, layout, cfg) of a step shape, cached: one layout query per shape / capacity / launch policy."""
+def _step_plan(key, cfgp):
+    """(desc, layout, rc) of a step shape, cached: one layout query per shape / capacity / launch policy (``key`` holds the
+    policy by value; ``cfgp``: the address of an fg_raster_config with exactly those values, for the query)."""
     plan = _STEP_PLANS.get(key)
     if plan is None:
         (dev, N, W, H, raw, sh_degree, k_stored, n_color, with_depth, n_extra, antialiased, n_clamp, want_backward,
-         list_shares, flags, capacity, eps2d, near, far, radius_clip, cfgp, _policy_bytes) = key  # fmt: skip
+         list_shares, flags, capacity, eps2d, near, far, radius_clip, _variant, _policy_bytes) = key  # fmt: skip
         d = _lib.StepDesc()
         d.size = ctypes.sizeof(_lib.StepDesc)
         d.N, d.width, d.height, d.tile_size, d.raw, d.sh_degree, d.k_stored, d.n_color = N, W, H, TILE_SIZE, raw, sh_degree, k_stored, n_color
@@ -1540,12 +1549,14 @@ class _RasterStep(torch.autograd.Function):
         capacity = rctx.isect_capacity[ckey]
         while True:
             seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h) if channels == 3 and want_backward else 0
-            cfgp = rctx.cfg(heavy, seg_slots, rctx.even_shape(lkey))
+            cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey))
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
+            # (the launch policy enters the key by VALUE -- its bytes and the variant's fields -- never by the address of a
+            # context's copy, which another context's copy may reuse)
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
                    n_clamp, int(want_backward), int(shares), _lib.STBIN_LONG_SEGMENTS if long_mode else 0, capacity, eps2d,
-                   near, far, radius_clip, cfgp, bytes(rctx.policy))  # fmt: skip
-            d, L, rc = _step_plan(rctx, key)
+                   near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
+            d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")
             keep = torch.empty((L.keep_bytes + 3) >> 2, dtype=torch.float32, device=dev)
             tmp = torch.empty(max(L.tmp_bytes, 8), dtype=torch.uint8, device=dev)
@@ -1613,8 +1624,21 @@ class _RasterStep(torch.autograd.Function):
         if not d.want_backward:
             raise _lib.FgRasterError("this step was rendered without gradient buffers (no input required a gradient)")
 
-        # (zero-filled by the forward launch)
+        # (zero-filled by the forward launch -- for the FIRST backward through this node; a later one (retain_graph=True:
+        # per-loss gradients) finds the first one's sums there and clears them itself.  info["means2d"].grad of the earlier
+        # pass is a view of this very array: it is copied out first and the new result added to it, as a retain_grad()'ed
+        # tensor accumulates)
         v_splats = torch.as_strided(keep, (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1), L.offset[_lib.STEP_BUFFER["v_splats"]] >> 2)
+        ref = getattr(ctx, "means2d_ref", None)
+        m2 = ref() if ref is not None else None
+        earlier_m2_grad = None
+        if getattr(ctx, "v_splats_consumed", False):
+            if m2 is not None and m2.grad is not None and m2.grad.untyped_storage().data_ptr() == keep.untyped_storage().data_ptr():
+                earlier_m2_grad = m2.grad.clone()
+                if getattr(m2, "absgrad", None) is not None:
+                    m2.absgrad = m2.absgrad.clone()
+            v_splats.zero_()
+        ctx.v_splats_consumed = True
         if v_means2d is not None:  # a loss on info["means2d"] itself: it joins the raster's xy gradient in the records
             v_splats[:, 0:2] += v_means2d.reshape(N, 2)
         if v_render is None:
@@ -1641,12 +1665,12 @@ class _RasterStep(torch.autograd.Function):
             io.ev_raster_begin, io.ev_raster_end = StageTimer.handles(ev)
         _lib.check(_lib.load().fg_step_bwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(),
                                            ctypes.addressof(L), _stream()), "fg_step_bwd")  # fmt: skip
-        ref = getattr(ctx, "means2d_ref", None)
-        m2 = ref() if ref is not None else None
         if m2 is not None:
             # info["means2d"]: .grad as if it had been retain_grad()'ed on the way to the compositing, .absgrad beside it
             # (reference freegaussian_model.py:869-872, :377); strided views of the record gradients, no copy
             m2.grad = v_splats[:, 0:2].view(m2.shape)
+            if earlier_m2_grad is not None:
+                m2.grad = earlier_m2_grad + m2.grad
             if absgrad:
                 m2.absgrad = v_splats[:, 6:8].view(m2.shape)
         return v_means, v_quats, v_dq, v_scales, v_ds, v_opac, v_colors, v_rest, v_extra, None, None, None, None

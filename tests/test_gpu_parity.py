@@ -676,6 +676,105 @@ def test_one_call_per_direction_equals_the_stage_wise_calls(raw, mode, monkeypat
         assert rel_l2(o[7], ref[7]) < 1e-5 and rel_l2(o[8], ref[8]) < 1e-5
 
 
+@pytest.mark.parametrize("raw", [False, True])
+def test_one_call_per_direction_carries_losses_on_info_depths_and_conics(raw):
+    """A loss on the differentiable per-Gaussian outputs (info["depths"], info["conics"]: the flow terms read them) must
+    reach the parameters through fg_step_bwd exactly as through the stage-wise calls -- all four branches of fg_step_bwd
+    forward v_depths / v_conics (round 4's raw branch passed null for both: the gradient vanished from the second call
+    of a shape on)."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    sc = _scene(n=30000, w=640, h=368, seed=29)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    ctx = ops.RasterContext()
+    if not ctx.step_calls or ctx.binning != "supertile" or int(_lib.load().fg_raster_jobs_words(640, 368, 16, ctx.cfg())) == 0:
+        pytest.skip("the environment selects the stage-wise path")
+    g = torch.Generator().manual_seed(5)
+    wd, wc = torch.randn(1, sc.means.shape[0], generator=g).to(DEV), torch.randn(1, sc.means.shape[0], 3, generator=g).to(DEV)
+
+    def run():
+        if raw:
+            p = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+                     features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+            t = {k: v.to(DEV).requires_grad_(True) for k, v in p.items()}
+            r, a, info = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                t["features_rest"], vm, K, sc.width, sc.height, 3, ctx=ctx)  # fmt: skip
+        else:
+            t = {k: getattr(sc, k).to(DEV).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")}
+            r, a, info = rasterization(*t.values(), vm, K, sc.width, sc.height, sh_degree=3, packed=False, ctx=ctx)
+        # ONLY the per-Gaussian outputs carry the loss: nothing but v_depths / v_conics can move the parameters
+        ((info["depths"] * wd).sum() + 1e-3 * (info["conics"] * wc).sum() + 0.0 * r.sum()).backward()
+        torch.cuda.synchronize()
+        return {k: v.grad for k, v in t.items()}
+
+    ctx.step_calls = False
+    run()
+    ref = run()
+    ctx.step_calls = True
+    calls_before = ctx.capacity_redos
+    got = run()
+    assert ctx.capacity_redos == calls_before
+    for k in ("means", "quats", "log_scales" if raw else "scales"):
+        assert float(ref[k].abs().max()) > 0, k
+        assert rel_l2(got[k], ref[k]) < 1e-6, k
+
+
+def test_second_backward_through_the_one_call_node_is_a_gradient_not_a_sum():
+    """retain_graph=True and a second backward through the same fg_step_bwd node (per-loss gradients): the record-gradient
+    array of the kept workspace is zero-filled by the forward launch ONCE -- the second pass must clear it itself, and
+    info["means2d"].grad (a view of that array after the first pass) accumulates like any retain_grad()'ed tensor."""
+    sc = _scene(n=30000, w=640, h=368, seed=31)
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    ctx = ops.RasterContext()
+    if not ctx.step_calls or ctx.binning != "supertile" or int(_lib.load().fg_raster_jobs_words(640, 368, 16, ctx.cfg())) == 0:
+        pytest.skip("the environment selects the stage-wise path")
+    g = torch.Generator().manual_seed(2)
+    v1 = torch.randn(1, sc.height, sc.width, 3, generator=g).to(DEV)
+    v2 = torch.randn(1, sc.height, sc.width, 3, generator=g).to(DEV)
+
+    def leaves():
+        return [getattr(sc, k).to(DEV).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
+
+    def single(v):
+        t = leaves()
+        r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True, ctx=ctx)
+        info["means2d"].retain_grad()
+        (r * v).sum().backward()
+        return [x.grad.clone() for x in t], info["means2d"].grad.clone(), info["means2d"].absgrad.clone()
+
+    single(v1)  # (measures the capacity: the next calls take fg_step_*)
+    g1, m1, _ = single(v1)
+    g2, m2, abs2 = single(v2)
+    t = leaves()
+    r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True, ctx=ctx)
+    assert type(r.grad_fn).__name__ != "_RasterSplatsBackward"
+    info["means2d"].retain_grad()
+    (r * v1).sum().backward(retain_graph=True)
+    first = [x.grad.clone() for x in t]
+    m_first = info["means2d"].grad.clone()
+    for x in t:
+        x.grad = None
+    (r * v2).sum().backward()
+    torch.cuda.synchronize()
+    for a_, b_ in zip(first, g1):
+        assert rel_l2(a_, b_) < 1e-5
+    for x, b_ in zip(t, g2):
+        assert rel_l2(x.grad, b_) < 1e-5  # the second loss's gradient alone, not the sum of the two
+    assert rel_l2(m_first, m1) < 1e-5
+    assert rel_l2(info["means2d"].grad, m1 + m2) < 1e-5  # accumulated, as retain_grad() does
+    assert rel_l2(info["means2d"].absgrad, abs2) < 1e-5
+
+
+def test_camera_gradients_are_refused_not_dropped():
+    sc = _scene(n=500, w=64, h=48)
+    t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    vm = sc.viewmats[:1].to(DEV).requires_grad_(True)
+    with pytest.raises(NotImplementedError, match="camera"):
+        rasterization(*t, vm, sc.Ks[:1].to(DEV), sc.width, sc.height, sh_degree=3, packed=False)
+    with torch.no_grad():  # (no tape, nothing to drop)
+        rasterization(*t, vm, sc.Ks[:1].to(DEV), sc.width, sc.height, sh_degree=3, packed=False)
+
+
 def test_rasterization_redoes_the_composite_when_the_list_guess_was_too_small():
     sc = _scene(n=20000, w=256, h=160, seed=17)
     t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
