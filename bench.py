@@ -65,8 +65,11 @@ def parse(argv=None):
     ap.add_argument("--layout", type=str, default="uniform",
                     help="uniform (the headline's U([-2,2]^3) cloud) | clustered:<frac>:<extent> -- that fraction of the Gaussians "
                          "pulled into a ball of that extent at the centre (captured-scene-like: lists of thousands of entries, "
-                         "saturated and unsaturated; scripts/clustered_check.py).  The default run also measures two clustered "
-                         "layouts in child processes and reports them under `clustered_layouts`; the headline stays the uniform scene.")
+                         "saturated and unsaturated; scripts/clustered_check.py) | needles:<frac>:<ratio> -- that fraction made "
+                         "anisotropic (one axis x ratio, one / 3: the needles and plates densification leaves) | parts joined "
+                         "by + (freegaussian_amd.scenes.apply_layout).  The default run also measures two clustered and two "
+                         "needle layouts in child processes and reports them under `clustered_layouts`; the headline stays the "
+                         "uniform scene.")
     ap.add_argument("--no-clustered", action="store_true", help="skip the clustered-layout child runs")
     ap.add_argument("--cpu-crop", type=str, default="480x272")  # ~4 s of oracle time per run on the GPU box
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = pick the faster of 8 and 32 host threads")
@@ -408,17 +411,16 @@ def graph_only(args):
     import torch
 
     from freegaussian_amd.graphed import GraphedRaster
-    from freegaussian_amd.scenes import synthetic_scene
+    from freegaussian_amd.scenes import apply_layout, synthetic_scene
     from freegaussian_amd.viewdp import FlatGaussianParams
 
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
-    if args.layout != "uniform":
-        kind, frac, extent = args.layout.split(":")
-        if kind != "clustered":
-            raise SystemExit(f"--layout {args.layout!r}: uniform | clustered:<frac>:<extent>")
-        scene.means[: int(float(frac) * args.n_gauss)] *= float(extent) / 2.0
+    try:
+        apply_layout(scene, args.layout)
+    except ValueError as e:
+        raise SystemExit(f"--layout: {e}")
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)
@@ -447,6 +449,18 @@ def graph_only(args):
                               "idles between replays)"}))  # fmt: skip
 
 
+# The auxiliary child runs (clustered / needle layouts, the graphed replay) come BEFORE the headline measurement -- alone on
+# the device, see clustered_children -- so they share one bounded budget: a hung or slow child must not eat the caller's
+# outer timeout before the headline line is printed (each child at most 120 s, all of them FG_BENCH_CHILD_BUDGET_S, 300 s).
+_CHILD_T0 = [None]
+
+
+def child_budget_left() -> float:
+    if _CHILD_T0[0] is None:
+        _CHILD_T0[0] = time.perf_counter()
+    return float(os.environ.get("FG_BENCH_CHILD_BUDGET_S", "300")) - (time.perf_counter() - _CHILD_T0[0])
+
+
 def clustered_children(args):
     """The same measurement on two clustered layouts, each in a process of its own (the headline stays the uniform
     scene): what the path does on captured-scene-like content -- long lists, saturated and not -- and which machinery
@@ -456,12 +470,16 @@ def clustered_children(args):
     import subprocess
 
     res_all = {}
-    for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2"):
+    for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2", "needles:0.3:10", "clustered:0.5:0.4+needles:0.3:10"):
+        left = child_budget_left()
+        if left < 20:
+            res_all[lay] = {"error": "skipped: the children's shared time budget is spent (FG_BENCH_CHILD_BUDGET_S)"}
+            continue
         cmd = [sys.executable, os.path.abspath(__file__), "--layout", lay, "--steps", "40", "--warmup", "10", "--settle-s",
                str(max(args.settle_s, 1.0)), "--no-cpu-baseline", "--no-graph", "--n-gauss", str(args.n_gauss), "--width", str(args.width),
                "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
         try:
-            res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+            res = subprocess.run(cmd, capture_output=True, text=True, timeout=min(120, left))
             c = json.loads(res.stdout.strip().splitlines()[-1])
             # (ms_per_step: the child's wall-clock mean over its 40 timed steps; the median host time per step beside it)
             res_all[lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"],
@@ -508,7 +526,10 @@ def main(argv=None):
                    str(args.n_gauss), "--width", str(args.width), "--height", str(args.height), "--sh-degree",
                    str(args.sh_degree), "--layout", args.layout] + (["--fixed-view"] if args.fixed_view else [])  # fmt: skip
             try:
-                res = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+                left = child_budget_left()
+                if left < 20:
+                    raise TimeoutError("skipped: the children's shared time budget is spent (FG_BENCH_CHILD_BUDGET_S)")
+                res = subprocess.run(cmd, capture_output=True, text=True, timeout=min(180, left))
                 graphed = json.loads(res.stdout.strip().splitlines()[-1])
             except Exception as e:
                 graphed = {"error": repr(e)[:200]}
@@ -519,7 +540,7 @@ def main(argv=None):
     import torch.distributed as dist
 
     from freegaussian_amd import ops, rasterization
-    from freegaussian_amd.scenes import synthetic_scene
+    from freegaussian_amd.scenes import apply_layout, synthetic_scene
     from freegaussian_amd.viewdp import FlatGaussianParams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -546,11 +567,10 @@ def main(argv=None):
             dist.init_process_group(backend, timeout=tmo)
 
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
-    if args.layout != "uniform":
-        kind, frac, extent = args.layout.split(":")
-        if kind != "clustered":
-            raise SystemExit(f"--layout {args.layout!r}: uniform | clustered:<frac>:<extent>")
-        scene.means[: int(float(frac) * args.n_gauss)] *= float(extent) / 2.0
+    try:
+        apply_layout(scene, args.layout)
+    except ValueError as e:
+        raise SystemExit(f"--layout: {e}")
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)  # flat parameter + flat gradient buffers
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)  # all 8 poses resident

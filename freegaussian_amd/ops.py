@@ -137,13 +137,20 @@ class RasterContext:
         e = os.environ if env is None else env
         self.policy = policy if policy is not None else launch_policy_from_env(e)
         self.stage_timer: Optional[StageTimer] = None
-        # list capacity: guesses per (device, N, tile grid) and the lengths of the last calls
         self.speculative_binning = e.get("FG_SPECULATIVE_BINNING", "1") != "0"
         self.static_capacity: Optional[int] = None  # set by graphed.GraphedRaster around capture / eager re-runs
         self.last_overflow: Optional[torch.Tensor] = None
-        self.isect_capacity: dict = {}
-        self.isect_recent: dict = {}
+        # What a shape's calls have taught the host is keyed by (device, tile grid) -- NOT by the number of Gaussians: the
+        # reference changes N every `refine_every` steps for the whole run (freegaussian_model.py:404-571) and every
+        # learned quantity would start from nothing each time.  Quantities that grow with N (list lengths, checkpoint
+        # slots) are kept with the N they were seen at and scaled by the ratio; a jump of N beyond a factor of two is
+        # another scene, and starts over.
+        self.isect_capacity: dict = {}  # (dev, tile_w, tile_h, path) -> capacity, valid for isect_n[key] Gaussians
+        self.isect_n: dict = {}
+        self.isect_recent: dict = {}  # ... -> [(list length, N)] of the last calls
         self.capacity_redos = 0  # times a speculative list turned out too small and the fill was repeated
+        self.stagewise_raster_calls = 0  # views that went through the stage-wise calls (not fg_step_*) although step_calls is on
+        self.full_ckpt_allocs = 0  # steps with list shares whose checkpoint buffer was sized by the list capacity (no compact slots)
         # Footprint rectangles (FG_TIGHT_RECTS=0 turns them off): the fused preprocess passes also write the
         # depth sort keys and, per Gaussian, the tile rectangle shrunk to the tiles where the splat can reach
         # alpha >= 1/255; the raster lists are then binned from those.  Same images and gradients, ~30% fewer
@@ -270,6 +277,26 @@ class RasterContext:
             self._policy_copies[key] = copy
         return copy.ptr(), variant
 
+    def capacity_for(self, key, N: int):
+        """The speculative list capacity for a call with ``N`` Gaussians of the shape ``key``; None when nothing (usable)
+        is known.  The same N as the history's: the stored figure (tests overwrite it to force the overflow path).  Another
+        N within a factor of two -- the call after a refinement: the history scaled by the ratio of the counts, 5 % on top
+        (clones and split children sit where the lists are already long)."""
+        if not self.speculative_binning:
+            return None
+        cap = self.isect_capacity.get(key)
+        if cap is None:
+            return None
+        n_ref = self.isect_n.get(key, N)
+        if n_ref == N:
+            return cap
+        if not (n_ref <= 2 * N and N <= 2 * n_ref):
+            return None
+        recent = self.isect_recent.get(key)
+        if not recent:
+            return min(int(cap * (N / n_ref) * 1.05) + 4096, 2**31 - 1)
+        return list_capacity_for([int(n * (N / n_i) * 1.05) for n, n_i in recent])
+
     def even_shape(self, lkey) -> bool:
         """Has this shape shown only even scenes lately (no tile list beyond three times the mean in its last eight
         calls)?  Then the job lists take equal numbers of tiles per XCD without the cost pass (``balance_bands = 2``)."""
@@ -282,15 +309,17 @@ class RasterContext:
         n = self.shape_calls.get(lkey, 0)
         return self.equal_stood.get(lkey, 0) >= 8 and n % 64 != 0
 
-    def seg_slots_for(self, lkey, capacity: int, n_tiles: int) -> int:
+    def seg_slots_for(self, lkey, capacity: int, n_tiles: int, N: int = 0) -> int:
         """Compact checkpoint slots for the next call of a shape (fg_raster_config::seg_slots), from what the list builds
         of its last calls reported (fg_stbin_fill_jobs' ckpt_need_out): 8 x the fullest XCD band's need + an eighth, in
         steps of 4096 slots; 0 (a slot per 64 entries of the list's capacity) while nothing is known or when that would
-        not be smaller."""
+        not be smaller.  ``N``: this call's Gaussian count -- needs reported at another count are scaled by the ratio (a
+        slot per 64 list entries, and the lists grow with N)."""
         hist = self.ckpt_need.get(lkey) if self.compact_slots else None
         if not hist:
             return 0
-        per = int(max(hist) * 1.125) + 32
+        need = max(nd if (N <= 0 or n_i == N) else int(nd * (N / n_i) * 1.05) + 8 for nd, n_i in hist)
+        per = int(need * 1.125) + 32
         slots = -(-8 * per // 4096) * 4096
         self.last_seg_slots = slots if slots < 0.9 * (capacity // 64 + n_tiles + 2) else 0
         return self.last_seg_slots
@@ -549,7 +578,7 @@ def _count_slot():
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
 
 
-def _note_ckpt_need(rctx, lkey, count_slot, reported: bool) -> None:
+def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0) -> None:
     """Read the checkpoint-slot needs the PREVIOUS call of this shape reported (they have landed: this call's list length,
     which the caller has just waited for, was stored behind them), remember this call's slot for the next."""
     prev = rctx.ckpt_pending.pop(lkey, None)
@@ -557,7 +586,7 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool) -> None:
         words = _count_ring_np[_RING_WORDS * prev[0] + 4 : _RING_WORDS * prev[0] + 12]
         if int(words.min()) >= 0:
             hist = rctx.ckpt_need.setdefault(lkey, [])
-            hist.append(int(words.max()))
+            hist.append((int(words.max()), prev[2]))  # (the need, the Gaussian count it was seen at)
             del hist[:-8]
             if len(rctx.ckpt_need) > 256:
                 rctx.ckpt_need.pop(next(iter(rctx.ckpt_need)))
@@ -569,7 +598,7 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool) -> None:
     if reported:
         if len(rctx.ckpt_pending) > 256:
             rctx.ckpt_pending.clear()
-        rctx.ckpt_pending[lkey] = (count_slot, _count_ring_gen[count_slot])
+        rctx.ckpt_pending[lkey] = (count_slot, _count_ring_gen[count_slot], N)
 
 
 def _poll_count(i: int, word: int = 0) -> int:
@@ -683,14 +712,14 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
               _stream())  # fmt: skip
         rctx.last_overflow = cum[N - 1 :] > cap
         return (tile_keys, flatten_ids, offsets, None) if defer else (tile_keys, flatten_ids, offsets)
-    key = (dev, N, tile_w, tile_h, keys_rects is not None)
+    key = (dev, tile_w, tile_h, keys_rects is not None)
     count_host = ready = None
     if count_slot is None:
         count_host = _count_buffer(dev)
         count_host.copy_(cum[N - 1 :], non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
-    capacity = _isect_capacity.get(key) if rctx.speculative_binning else None
+    capacity = rctx.capacity_for(key, N)
     tile_keys = flatten_ids = None
     if capacity is not None:
         tile_keys = torch.empty(capacity, dtype=torch.int32, device=dev) if want_keys else None
@@ -705,20 +734,7 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
         else:
             ready.synchronize()
             n_isects = int(count_host[0])
-        if n_isects >= 2**31:
-            raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
-        if key not in _isect_capacity and len(_isect_capacity) >= 256:
-            old = next(iter(_isect_capacity))  # densification changes N: do not grow for ever
-            _isect_capacity.pop(old)
-            _isect_recent.pop(old, None)
-        # 25% headroom over the heaviest of the last 16 views of this shape, rounded up to 1/32..1/16 of
-        # its magnitude: a camera moving between light and heavy views neither overflows on every
-        # return nor asks the allocator for a new block size every step (every list-sized buffer of
-        # the step -- ids, sort workspace, liveness words, checkpoints -- is sized from this number)
-        recent = _isect_recent.setdefault(key, [])
-        recent.append(n_isects)
-        del recent[:-16]
-        _isect_capacity[key] = list_capacity_for(recent)
+        _note_list_length(rctx, key, n_isects, N)
         if capacity is not None and n_isects <= capacity:
             return (tile_keys[:n_isects] if want_keys else None), flatten_ids[:n_isects], False
         if capacity is not None:
@@ -736,24 +752,33 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     return (tk, ids, offsets, None) if defer else (tk, ids, offsets)
 
 
-def _note_list_length(rctx, key, n_isects: int) -> int:
-    """The list length of a call of shape ``key``: checked against the int32 index range and entered into the history the
-    next call's speculative capacity comes from."""
+def _note_list_length(rctx, key, n_isects: int, N: int) -> int:
+    """The list length of a call with ``N`` Gaussians of shape ``key``: checked against the int32 index range and entered
+    into the history the next call's speculative capacity comes from (entries seen at another N count scaled)."""
     if n_isects >= 2**31:
         raise _lib.FgRasterError(f"{n_isects} tile intersections exceed the int32 list index range")
     cap, recent_all = rctx.isect_capacity, rctx.isect_recent
     if key not in cap and len(cap) >= 256:
-        old = next(iter(cap))  # densification changes N: do not grow for ever
+        old = next(iter(cap))
         cap.pop(old)
         recent_all.pop(old, None)
+        rctx.isect_n.pop(old, None)
+    n_ref = rctx.isect_n.get(key)
+    if n_ref is not None and not (n_ref <= 2 * N and N <= 2 * n_ref):
+        recent_all.pop(key, None)  # another scene on the same tile grid: its lengths say nothing about this one
     recent = recent_all.setdefault(key, [])
-    recent.append(n_isects)
+    recent.append((n_isects, N))
     del recent[:-16]
-    cap[key] = list_capacity_for(recent)
+    # 25% headroom over the heaviest of the last 16 views of this shape, rounded up to 1/32..1/16 of its magnitude: a
+    # camera moving between light and heavy views neither overflows on every return nor asks the allocator for a new block
+    # size every step (every list-sized buffer of the step -- ids, sort workspace, liveness words, checkpoints -- is sized
+    # from this number)
+    cap[key] = list_capacity_for([n if n_i == N else int(n * (N / n_i)) for n, n_i in recent])
+    rctx.isect_n[key] = N
     return n_isects
 
 
-def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> int:
+def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: int = 0) -> int:
     """Wait for the three words fg_stbin_count stores into pinned host memory (list length, longest supertile segment,
     longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
     binning, the heavy-tile policy of the raster.  -> the list length."""
@@ -768,15 +793,15 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False) -> in
             shapes[lkey] -= 1
             if shapes[lkey] <= 0:
                 del shapes[lkey]
-    _note_ckpt_need(rctx, lkey, count_slot, need_reported)
+    _note_ckpt_need(rctx, lkey, count_slot, need_reported, N)
     if len(rctx.shape_calls) > 256 and lkey not in rctx.shape_calls:
         rctx.shape_calls.pop(next(iter(rctx.shape_calls)))
     rctx.shape_calls[lkey] = rctx.shape_calls.get(lkey, 0) + 1
-    longest, n_tiles = _poll_count(count_slot, 2), max(lkey[2] * lkey[3], 1)
+    longest, n_tiles = _poll_count(count_slot, 2), max(lkey[1] * lkey[2], 1)
     if len(rctx.even_calls) > 256 and lkey not in rctx.even_calls:
         rctx.even_calls.pop(next(iter(rctx.even_calls)))
     rctx.even_calls[lkey] = min(rctx.even_calls.get(lkey, 0) + 1, 1 << 20) if longest * n_tiles <= 3 * n_isects + 32 * n_tiles else 0
-    return _note_list_length(rctx, key, n_isects)
+    return _note_list_length(rctx, key, n_isects, N)
 
 
 def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list, cfgp=None):
@@ -789,7 +814,7 @@ def _seg_ckpt_floats(rctx, channels, width, height, tile_size, n_list, cfgp=None
     return n_ck if n_ck > 0 and 4 * n_ck <= rctx.seg_ckpt_budget_bytes else 0
 
 
-def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None):
+def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None, N=0):
     """(jobs[2, words], bwd_list_shares, key, cfg) for fg_stbin_fill_jobs, or None when the raster launches of this size /
     config take no lists.  ``key`` is what _RasterSplats.forward compares before it trusts the lists; ``cfg`` the address
     of the launch policy they were planned with (``heavy``: heavy tiles on; compact checkpoint slots when the shape
@@ -798,14 +823,15 @@ def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None):
         return None
     channels, width, height = (int(v) for v in raster_hint)
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
-    cfgp = rctx.cfg(heavy, rctx.seg_slots_for(lkey, n_list, n_tiles) if lkey is not None and channels == 3 else 0,
-                    lkey is not None and rctx.even_shape(lkey))
+    seg_slots = rctx.seg_slots_for(lkey, n_list, n_tiles, N) if lkey is not None and channels == 3 else 0
+    cfgp = rctx.cfg(heavy, seg_slots, lkey is not None and rctx.even_shape(lkey))
     words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
     shares = _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, n_list, cfgp) > 0
     jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
     rctx.heavy_calls += int(heavy and shares)
+    rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and lkey is not None and channels == 3)
     return jobs, shares, (rctx, channels, width, height, TILE_SIZE), cfgp
 
 
@@ -826,7 +852,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
-    lkey = (dev, N, tile_w, tile_h)
+    lkey = (dev, tile_w, tile_h)
     need_reported = [False]
 
     def fill(cap):
@@ -839,7 +865,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
         flags = _lib.STBIN_LONG_SEGMENTS if long_mode else 0
         rctx.long_calls += int(long_mode)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
-        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy, lkey) if rctx.jobs_in_fill else None
+        prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy, lkey, N) if rctx.jobs_in_fill else None
         if prebuilt is None:
             _call(abi + "_fill", *args, flags, _stream(), stage="fg_bin_emit_sort_capacity")
         else:
@@ -861,22 +887,24 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
         rctx.last_overflow = tile_offsets[n_tiles:] > cap
         tk = None  # (keys: tile_keys_from_offsets on demand)
         return (tk, flatten_ids, offsets, None) if defer else (tk, flatten_ids, offsets)
-    key = (dev, N, tile_w, tile_h, abi)
+    key = (dev, tile_w, tile_h, abi)
     count_host = ready = None
     if count_slot is None:
         count_host = _count_buffer(dev)
         count_host.copy_(tile_offsets[n_tiles:], non_blocking=True)
         ready = torch.cuda.Event()
         ready.record()
-    capacity = _isect_capacity.get(key) if rctx.speculative_binning else None
+    capacity = rctx.capacity_for(key, N)
     flatten_ids = fill(capacity) if capacity is not None else None
+    if raster_hint is not None and rctx.step_calls:
+        rctx.stagewise_raster_calls += 1
 
     def finish():
         if count_slot is not None:
-            n_isects = _note_counts(rctx, lkey, key, count_slot, need_reported[0])
+            n_isects = _note_counts(rctx, lkey, key, count_slot, need_reported[0], N)
         else:
             ready.synchronize()
-            n_isects = _note_list_length(rctx, key, int(count_host[0]))
+            n_isects = _note_list_length(rctx, key, int(count_host[0]), N)
         if capacity is not None and n_isects <= capacity:
             return keys_for(n_isects), flatten_ids[:n_isects], False
         if capacity is not None:
@@ -1505,7 +1533,7 @@ def step_path_available(rctx, N, width, height, tile_size, dev) -> bool:
     if st is not None and (st.only is None or not set(st.only) <= {"fg_raster_fwd", "fg_raster_bwd"}):
         return False
     tile_w, tile_h = (width + 15) // 16, (height + 15) // 16
-    if (dev, N, tile_w, tile_h, "fg_stbin") not in rctx.isect_capacity:
+    if rctx.capacity_for((dev, tile_w, tile_h, "fg_stbin"), N) is None:
         return False
     # job-list launches and the supertile binning must take this image size (tiny images run the classic launches)
     skey = (width, height, N >> 20, bytes(rctx.policy))
@@ -1543,12 +1571,12 @@ class _RasterStep(torch.autograd.Function):
             k_stored, n_color = 0, (0 if colors is None else colors.shape[1])
         n_extra = 0 if extra is None else extra.shape[1]
         channels = n_color + int(with_depth) + n_extra
-        lkey, ckey = (dev, N, tile_w, tile_h), (dev, N, tile_w, tile_h, "fg_stbin")
+        lkey, ckey = (dev, tile_w, tile_h), (dev, tile_w, tile_h, "fg_stbin")
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
-        capacity = rctx.isect_capacity[ckey]
+        capacity = rctx.capacity_for(ckey, N)
         while True:
-            seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h) if channels == 3 and want_backward else 0
+            seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h, N) if channels == 3 and want_backward else 0
             cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey))
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
             # (the launch policy enters the key by VALUE -- its bytes and the variant's fields -- never by the address of a
@@ -1574,6 +1602,7 @@ class _RasterStep(torch.autograd.Function):
                                        ctypes.addressof(L), _stream()), "fg_step_fwd")  # fmt: skip
             rctx.long_calls += int(long_mode)
             rctx.heavy_calls += int(heavy and shares)
+            rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and channels == 3)
             # the outputs are views of the kept workspace: one as_strided each (built before the wait below, i.e. while the
             # GPU runs the projection and the count pass)
             k32, i32 = keep, keep.view(torch.int32)
@@ -1597,7 +1626,7 @@ class _RasterStep(torch.autograd.Function):
             last_ids = view(i32, "last_ids", (height, width), (width, 1))
             splats = view(k32, "splats", (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1))
             list_offsets = view(i32, "list_offsets", (tile_w * tile_h + 1,), (1,))
-            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares)
+            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares, N)
             if n_isects <= capacity:
                 break
             rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length

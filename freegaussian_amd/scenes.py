@@ -97,3 +97,33 @@ def synthetic_scene(n_gauss: int, width: int, height: int, n_views: int = 1, sh_
 def north_star_scene(n_views: int = 8, seed: int = 42) -> Scene:
     """cfg4: 1M Gaussians, 1920x1080, fx=fy=1200, 8 views 45 degrees apart."""
     return synthetic_scene(1_000_000, 1920, 1080, n_views=n_views, sh_degree=3, seed=seed)
+
+
+def apply_layout(scene: Scene, layout: str, seed: int = 7) -> Scene:
+    """Reshape a ``synthetic_scene`` in place into one of the non-uniform test distributions; parts joined by ``+``:
+
+    * ``uniform`` -- as generated (U([-2,2]^3), near-isotropic Gaussians: three independent log-normal axes);
+    * ``clustered:<frac>:<extent>`` -- the first ``frac`` of the Gaussians pulled into a ball of that extent at the centre
+      (tile lists of tens of thousands of entries next to empty ones);
+    * ``needles:<frac>:<ratio>`` -- a random ``frac`` of the Gaussians made anisotropic the way densification leaves a
+      trained scene (reference freegaussian_model.py:524-571: splits shrink all axes alike, so an elongated parent breeds
+      elongated children): one axis x ``ratio``, one / 3, the third kept -- needles and plates at random orientations (the
+      quaternions are already uniform on the sphere), clipped to 0.3 scene units."""
+    N = scene.means.shape[0]
+    for part in layout.split("+"):
+        if part in ("", "uniform"):
+            continue
+        f = part.split(":")
+        if f[0] == "clustered" and len(f) == 3:
+            scene.means[: int(float(f[1]) * N)] *= float(f[2]) / 2.0
+        elif f[0] == "needles" and len(f) == 3:
+            g = torch.Generator().manual_seed(seed)
+            pick = torch.rand(N, generator=g) < float(f[1])
+            axes = torch.argsort(torch.rand(N, 3, generator=g), dim=1)  # a random (long, short, kept) assignment per Gaussian
+            factor = torch.ones(N, 3)
+            factor.scatter_(1, axes[:, 0:1], float(f[2]))
+            factor.scatter_(1, axes[:, 1:2], 1.0 / 3.0)
+            scene.scales[pick] = (scene.scales[pick] * factor[pick]).clamp(max=0.3)
+        else:
+            raise ValueError(f"layout {part!r}: uniform | clustered:<frac>:<extent> | needles:<frac>:<ratio> (joined by +)")
+    return scene

@@ -1,7 +1,8 @@
 """How many (Gaussian, tile) pairs of the footprint rectangles does an EXACT ellipse-vs-tile test drop?
 Bench scene family (CPU, oracle projection), subsample of the Gaussians at full resolution.
 Pair kept iff min over the tile's pixel-centre box of d^T Q d <= 2 ln(255 o)  (some pixel centre region reaches
-alpha >= 1/255; box relaxation of the pixel grid: conservative).  Usage: python scripts/exact_tile_estimate.py [n] [W] [H]"""
+alpha >= 1/255; box relaxation of the pixel grid: conservative).
+Usage: python scripts/exact_tile_estimate.py [n] [W] [H] [layout] [view]   (layout: freegaussian_amd.scenes.apply_layout)"""
 import math
 import os
 import sys
@@ -10,15 +11,17 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
+from freegaussian_amd.scenes import apply_layout, synthetic_scene  # noqa: E402
 from oracle import raster_oracle as O  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 100_000
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 1920
 H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
-sc = synthetic_scene(1_000_000, W, H, n_views=8, sh_degree=3, seed=42)
+layout = sys.argv[4] if len(sys.argv) > 4 else "uniform"
+view = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+sc = apply_layout(synthetic_scene(1_000_000, W, H, n_views=8, sh_degree=3, seed=42), layout)
 idx = torch.randperm(1_000_000, generator=torch.Generator().manual_seed(0))[:n]
-p = O.project(sc.means[idx], sc.quats[idx], sc.scales[idx], sc.viewmats[4], sc.Ks[4], W, H)
+p = O.project(sc.means[idx], sc.quats[idx], sc.scales[idx], sc.viewmats[view], sc.Ks[view], W, H)
 vis = p.radii > 0
 mu, Q, o, rad = p.means2d[vis], p.conics[vis], sc.opacities[idx][vis], p.radii[vis].float()
 tau = 2 * torch.log(255 * o)
@@ -60,6 +63,9 @@ for ye in (by0, by1):
     x = torch.minimum(torch.maximum(-B * ye / A, bx0), bx1)
     best = torch.minimum(best, qf(x, ye))
 hit = inside | (best <= T)
+ref_pairs = int((((torch.clamp(torch.floor((mu[:, 0] + rad) / 16) + 1, 0, tw) - torch.clamp(torch.floor((mu[:, 0] - rad) / 16), 0, tw)).clamp_min(0))
+                 * ((torch.clamp(torch.floor((mu[:, 1] + rad) / 16) + 1, 0, th) - torch.clamp(torch.floor((mu[:, 1] - rad) / 16), 0, th)).clamp_min(0))).sum())
+print(f"layout {layout} view {view}: radius-box pairs (the reference's lists, alpha-capable Gaussians) {ref_pairs}")
 print(f"visible {int(vis.sum())} of {n}; footprint pairs {tot} ({tot / int(keep.sum()):.2f} per Gaussian); exact test keeps {int(hit.sum())} = {float(hit.float().mean()):.3f}")
 sw = (tw + 1) // 2
 st_rect = ((x1 - 1) // 2 - x0 // 2 + 1).clamp_min(0) * ((y1 - 1) // 2 - y0 // 2 + 1).clamp_min(0) * (area > 0)

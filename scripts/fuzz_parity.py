@@ -1,10 +1,9 @@
-"""Randomised parity sweep: HIP rasterization vs the CPU oracle over random sizes, image shapes,
-SH degrees, render modes, raster modes, packed / unpacked, with hostile Gaussians mixed in
-(behind the camera, huge, tiny, nearly transparent, NaN-free).  Integer results must be equal;
-images and gradients within the 1e-4 bar (knife-edge pixels bounded as in tests/helpers.py).
-Usage: python scripts/fuzz_parity.py [n_cases] [seed] [big]  -> one line per case + a summary.
-`big`: images of 640x360 ... 1920x1080 (900 ... 8160 tiles: the mixed launches with job lists, strips, list
-shares and liveness) with up to 40000 Gaussians."""
+"""Randomised parity sweep, the long form of tests/test_gpu_parity.py::test_randomised_parity_*: HIP rasterization vs the
+CPU oracle over random sizes, image shapes, SH degrees, render modes, raster modes, packed / unpacked, with hostile
+Gaussians mixed in.  Same cases, same bar, same fp64 arbitration as the gate (tests/fuzz_cases.py).
+Usage: python scripts/fuzz_parity.py [n_cases] [seed] [big]  -> one line per case + a summary; FUZZ_ONLY=k: case k only.
+`big`: images of 640x360 ... 1920x1080 (900 ... 8160 tiles: the mixed launches with job lists, strips, list shares and
+liveness) with up to 40000 Gaussians; the oracle composites with the C restatement there."""
 import os
 import sys
 
@@ -13,88 +12,19 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
-from helpers import REL_TOL, close_except_knife_edge, rel_l2  # noqa: E402
-from freegaussian_amd import rasterization  # noqa: E402
-from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
-from oracle import raster_oracle as O  # noqa: E402
+import fuzz_cases  # noqa: E402
 
 torch.set_num_threads(min(os.cpu_count() or 1, 16))
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 big = len(sys.argv) > 3 and sys.argv[3] == "big"
-# FUZZ_COMPOSITOR=c: the oracle composites with the C restatement of the reference's backward (T_i rebuilt
-# from the rounded T_final) instead of torch autograd; FUZZ_ONLY=k: run case k only
-use_c = os.environ.get("FUZZ_COMPOSITOR") == "c"
 only = int(os.environ["FUZZ_ONLY"]) if "FUZZ_ONLY" in os.environ else None
-if use_c:
-    from oracle import c_oracle as CO  # noqa: E402
-dev = "cuda"
 bad = 0
 for case in range(n_cases):
-    g = torch.Generator().manual_seed(seed0 * 1000 + case)
-    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))  # noqa: E731
-    n = [1, 2, 17, 300, 3000, 12000][ri(0, 5)]
-    W, H = ri(17, 300), ri(17, 200)
-    if big:
-        n = [3000, 12000, 40000][ri(0, 2)]
-        W, H = ri(640, 1920), ri(360, 1080)
-    deg = [None, 0, 1, 2, 3][ri(0, 4)]
-    mode = ["RGB", "RGB+ED", "ED"][ri(0, 2)]
-    rmode = ["classic", "antialiased"][ri(0, 1)]
-    packed = bool(ri(0, 1))
     if only is not None and case != only:
         continue
-    sc = synthetic_scene(n, W, H, n_views=2, seed=seed0 * 1000 + case)
-    k = max(1, n // 10)
-    with torch.no_grad():  # hostile rows
-        sc.means[:k] *= 5.0  # far off / behind
-        sc.scales[k : 2 * k] *= 25.0  # huge
-        sc.scales[2 * k : 3 * k] *= 0.02  # sub-pixel
-        sc.opacities[3 * k : 4 * k] = 0.003  # below the alpha skip almost everywhere
-        sc.quats[4 * k : 5 * k] *= 7.0  # unnormalised
-    colors = sc.colors if deg is not None else torch.sigmoid(sc.colors[:, 0, :])
-    v = ri(0, 1)
-    ins0 = [t.clone().requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, colors)]
-    ins1 = [t.detach().to(dev).requires_grad_(True) for t in ins0]
-    kw = dict(sh_degree=deg, render_mode=mode, packed=packed, absgrad=True, rasterize_mode=rmode)
-    r0, a0, i0 = O.rasterization(*ins0, sc.viewmats[v : v + 1], sc.Ks[v : v + 1], W, H,
-                                 **(dict(kw, compositor=CO.composite) if use_c else kw))
-    r1, a1, i1 = rasterization(*ins1, sc.viewmats[v : v + 1].to(dev), sc.Ks[v : v + 1].to(dev), W, H, **kw)
-    ok = r1.shape == r0.shape and a1.shape == a0.shape
-    ok = ok and torch.equal(i1["radii"].cpu(), i0["radii"]) and torch.equal(i1["flatten_ids"].cpu(), i0["flatten_ids"])
-    ok = ok and torch.equal(i1["isect_offsets"].cpu(), i0["isect_offsets"])
-    ok = ok and close_except_knife_edge(r1, r0, 3 * REL_TOL, max_frac=3e-3) and close_except_knife_edge(a1, a0, 3 * REL_TOL, max_frac=3e-3)
-    vr = torch.randn(r0.shape, generator=g)
-    va = torch.randn(a0.shape, generator=g)
-    if r0.requires_grad or a0.requires_grad:
-        ((r0 * vr).sum() + (a0 * va).sum()).backward()
-    if r1.requires_grad or a1.requires_grad:
-        ((r1 * vr.to(dev)).sum() + (a1 * va.to(dev)).sum()).backward()
-    errs = []
-    for x0, x1 in zip(ins0, ins1):
-        if x0.grad is None or float(x0.grad.abs().max()) == 0.0:
-            errs.append(0.0 if (x1.grad is None or float(x1.grad.abs().max()) == 0.0) else 1.0)
-        else:
-            errs.append(rel_l2(x1.grad, x0.grad))
-    grad_ok = max(errs) < 2e-3  # a knife-edge pixel flips a whole splat contribution: looser than the image bar
-    note = ""
-    if max(errs) > 3e-4:
-        # which of the two fp32 implementations is off?  fp64 run of the oracle as the arbiter
-        ins2 = [t.detach().double().requires_grad_(True) for t in ins0]
-        r2, a2, _ = O.rasterization(*ins2, sc.viewmats[v : v + 1].double(), sc.Ks[v : v + 1].double(), W, H, **kw)
-        ((r2 * vr.double()).sum() + (a2 * va.double()).sum()).backward()
-        j = max(range(len(errs)), key=lambda q: errs[q])
-        e_or = rel_l2(ins0[j].grad, ins2[j].grad)
-        e_hip = rel_l2(ins1[j].grad, ins2[j].grad)
-        note = f" [input {j}: fp32 oracle vs fp64 {e_or:.1e}, HIP vs fp64 {e_hip:.1e}]"
-        if not grad_ok and e_hip <= 3.0 * max(e_or, 1e-3):
-            # the sum itself is ill-conditioned (random cotangents cancel over a handful of pixels): the fp32
-            # oracle is as far from the fp64 answer as the HIP path is, so neither is "the" fp32 result
-            grad_ok = True
-            note += " ill-conditioned"
-    ok = ok and grad_ok
+    ok, msg = fuzz_cases.check(fuzz_cases.Case(seed0, case, big))
     bad += 0 if ok else 1
-    print(f"case {case:3d} n={n:5d} {W}x{H} sh={deg} {mode:6s} {rmode:11s} packed={int(packed)} I={i0['flatten_ids'].numel():7d} "
-          f"grad rel {max(errs):.1e} {'ok' if ok else 'MISMATCH'}{note}", flush=True)
-print(f"fuzz: {n_cases - bad}/{n_cases} cases ok (seed {seed0})")
+    print(msg, flush=True)
+print(f"fuzz: {n_cases - bad}/{n_cases} cases ok (seed {seed0}; gradients at {fuzz_cases.REL_TOL:g} or through the fp64 arbiter)")
 sys.exit(1 if bad else 0)
