@@ -41,10 +41,10 @@ SIGNATURES = {
                                           P]),
     "fg_stbin_supported": (c_int, [c_int, c_int, c_int]),
     "fg_stbin_count_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
-    "fg_stbin_count": (c_int, [c_int, P, c_int, c_int, P, P, P, c_size_t, P]),
+    "fg_stbin_count": (c_int, [c_int, P, P, c_int, c_int, P, P, P, c_size_t, P]),
     "fg_stbin_fill_workspace_bytes": (c_size_t, [c_int64]),
-    "fg_stbin_fill": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, P]),
-    "fg_stbin_fill_jobs": (c_int, [c_int, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
+    "fg_stbin_fill": (c_int, [c_int, P, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, P]),
+    "fg_stbin_fill_jobs": (c_int, [c_int, P, P, P, c_int, c_int, c_int64, P, P, P, P, P, c_size_t, c_int, c_int, c_int, P, P,
                                    c_int, P, c_int, P, P]),
     "fg_isect_keys": (c_int, [c_int64, P, P, P, P, P]),
     "fg_densify_stats": (c_int, [c_int, P, P, c_float, P, P, P, P]),
@@ -67,13 +67,13 @@ SIGNATURES = {
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
-                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P]),
+                                  c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_sh_pack_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                   c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_raw_fwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, P, c_int, P, P, c_int,
                                       c_int, c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P,
-                                      P, P, P, P]),
+                                      P, P, P, P, P]),
     "fg_preprocess_raw_bwd": (c_int, [c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                       c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
@@ -100,8 +100,9 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 STBIN_LONG_SEGMENTS = 1  # FG_STBIN_LONG_SEGMENTS
+STEP_NO_FOOTPRINT_MASKS = 2  # FG_STEP_NO_FOOTPRINT_MASKS
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None
 
@@ -131,7 +132,7 @@ class RasterConfig(ctypes.Structure):
         return ctypes.addressof(self)
 
 
-STEP_BUFFERS = ("radii", "means2d", "depths", "conics", "comp", "tiles", "splats", "depth_keys", "tile_rects", "sh_jac",
+STEP_BUFFERS = ("radii", "means2d", "depths", "conics", "comp", "tiles", "splats", "depth_keys", "tile_rects", "tile_masks", "sh_jac",
                 "tile_offsets", "list_offsets", "flatten_ids", "jobs", "live", "seg_ckpt", "v_splats", "render", "alphas",
                 "last_ids", "clamp_mask", "count_ws", "fill_ws")  # the FG_STEP_* enum of include/fgraster.h, in order
 STEP_BUFFER = {n: i for i, n in enumerate(STEP_BUFFERS)}

@@ -52,6 +52,63 @@ __device__ __forceinline__ int alpha_extent(float o, float a, float b, float c, 
   ey = __fadd_rn(__fmul_rn(ey, 1.0005f), 0.02f);
   return 1;
 }
+// FOOTPRINT MASK (round 5).  The footprint rectangle is the axis-aligned box of the ellipse sigma <= ln(255 o): tight for a
+// round splat, mostly empty for a needle lying diagonally (trained scenes are full of those: a rectangle of 12 x 12 tiles
+// of which the ellipse touches 20).  The mask says which parts of the rectangle the ELLIPSE reaches: the rectangle's
+// w x h tiles are cut into at most 8 x 8 blocks of bs x bs tiles (bs = 1 up to 8 x 8 tiles, then 2, 4, ...), bit 8 by + bx
+// is set iff some pixel centre of block (bx, by) lies inside the (inflated) ellipse.  Exact for the block -- for a block row,
+// the x-range of the ellipse over the row's strip of pixel centres is closed-form (the ellipse cut by a strip is convex) --
+// and conservative the way alpha_extent is: tau and the ranges are inflated so that rounding only ever keeps more.  The
+// binning counts and scatters the set blocks' tiles only: lists stay an order-preserving subsequence of the reference's,
+// every dropped entry is one no pixel of the tile would have taken.
+__host__ __device__ __forceinline__ int footprint_block(int w, int h) {
+  const int m = w > h ? w : h;
+  int bs = 1;
+  while (8 * bs < m) bs <<= 1;
+  return bs;
+}
+// (x0, y0, w, h: the footprint rectangle in tiles, w, h > 0; ts: the tile side in pixels)
+__device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, float c, float gx, float gy, int x0, int y0,
+                                                   int w, int h, float ts) {
+  const int bs = footprint_block(w, h);
+  const int nbx = (w + bs - 1) / bs, nby = (h + bs - 1) / bs;
+  const uint32_t row_all = (1u << nbx) - 1u;
+  uint64_t all = 0;
+  for (int by = 0; by < nby; ++by) all |= (uint64_t)row_all << (8 * by);
+  const float t255 = 255.f * o, det = a * c - b * b;
+  if (!(o == o) || !(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(t255 >= 1.f)) return all;  // (no culling possible: alpha_extent kinds 2 / 0)
+  // tau2 = 2 ln(255 o), inflated by 0.1 % + 2e-3 (the pixel test's own rounding is ~1e-5 of it)
+  const float tau2 = (1.3862943611f * __builtin_amdgcn_logf(t255)) * 1.001f + 2e-3f;
+  const float ex = __builtin_amdgcn_sqrtf(tau2 * c / det), ey = __builtin_amdgcn_sqrtf(tau2 * a / det);
+  if (!(ex == ex) || !(ey == ey)) return all;
+  const float dy_right = -b * ex / c;  // where the ellipse is widest to the right (to the left: at -dy_right)
+  const float at = a * tau2, m = 0.02f, span = ts * (float)bs;
+  uint64_t mask = 0;
+  for (int by = 0; by < nby; ++by) {
+    const int ya = y0 + by * bs, yb = min(ya + bs, y0 + h);
+    // the block row's strip of pixel centres, relative to the centre, with a margin
+    const float dlo = (ts * (float)ya + 0.5f) - gy - m, dhi = (ts * (float)yb - 0.5f) - gy + m;
+    if (dlo > ey * 1.0005f || dhi < -ey * 1.0005f) continue;  // the ellipse does not reach the strip
+    // (the strip's edges may lie beyond the ellipse's top / bottom by the margins: the widest point is then AT +-ey)
+    const float dr = fminf(fmaxf(fminf(fmaxf(dy_right, dlo), dhi), -ey), ey);
+    const float dl = fminf(fmaxf(fminf(fmaxf(-dy_right, dlo), dhi), -ey), ey);
+    float xr = (-b * dr + __builtin_amdgcn_sqrtf(fmaxf(at - det * dr * dr, 0.f))) / a;
+    float xl = (-b * dl - __builtin_amdgcn_sqrtf(fmaxf(at - det * dl * dl, 0.f))) / a;
+    xr = gx + xr + (fabsf(xr) * 0.0005f + m);
+    xl = gx + xl - (fabsf(xl) * 0.0005f + m);
+    // blocks whose pixel centres [ts (x0 + bx bs) + 0.5, ts (x0 + (bx + 1) bs) - 0.5] meet [xl, xr]
+    const float org = ts * (float)x0;
+    const float fa = ceilf((xl + 0.5f - org) / span) - 1.f, fb = floorf((xr - 0.5f - org) / span);
+    if (!(fa == fa) || !(fb == fb)) {  // (NaN: keep the whole row)
+      mask |= (uint64_t)row_all << (8 * by);
+      continue;
+    }
+    const int ba = (int)fmaxf(fa, 0.f), bb = (int)fminf(fb, (float)(nbx - 1));
+    if (bb < ba) continue;
+    mask |= (uint64_t)((row_all >> (nbx - 1 - (bb - ba))) << ba) << (8 * by);
+  }
+  return mask;
+}
 // does the extent [g - e, g + e] reach a pixel centre of [lo + 0.5, lo + span - 0.5]?  (the comparison
 // form both users share; span = 16 for a tile side, 4 for a strip)
 __device__ __forceinline__ bool extent_reaches(float g, float e, float lo, float span) {

@@ -174,8 +174,8 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
                       int tile_h, int antialiased, int32_t* __restrict__ radii, float* __restrict__ means2d,
                       float* __restrict__ depths, float* __restrict__ conics, float* __restrict__ compensations,
                       int32_t* __restrict__ tiles_touched, float* __restrict__ splats,
-                      uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects, float* __restrict__ sh_jac,
-                      int skip_culled) {
+                      uint32_t* __restrict__ depth_keys, int2* __restrict__ tile_rects,
+                      unsigned long long* __restrict__ tile_masks, float* __restrict__ sh_jac, int skip_culled) {
   __shared__ float lds[HROWS * ROW];  // half the coefficient slab at a time, then the record slab, then the Jacobian slab
   __shared__ uint8_t row_live[BLOCK];
   const int row0 = blockIdx.x * BLOCK;
@@ -264,6 +264,11 @@ preprocess_fwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict
         if (a1 > a0 && b1 > b0) rc = make_int2(a0 | (b0 << 16), (a1 - a0) | ((b1 - b0) << 16));
       }
       tile_rects[i] = rc;
+      // ... and which blocks of that rectangle the ellipse itself reaches (fg::footprint_mask)
+      if (tile_masks)
+        tile_masks[i] = rc.y == 0 ? 0ull
+                                  : fg::footprint_mask(rec[2], rec[3], rec[4], rec[5], rec[0], rec[1], rc.x & 0xFFFF, rc.x >> 16,
+                                                       rc.y & 0xFFFF, rc.y >> 16, (float)tile_size);
     }
   }
 
@@ -583,9 +588,11 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
                           int width, int height, float eps2d, float near_plane, float far_plane, float radius_clip,
                           int tile_size, int antialiased, int32_t* radii, float* means2d, float* depths,
                           float* conics, float* compensations, int32_t* tiles_touched, float* splats,
-                          uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
+                          uint32_t* depth_keys, int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac,
+                          fg_stream_t stream) {
   FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
   if (N < 0 || width <= 0 || height <= 0 || tile_size <= 0 || !layout_ok(fl)) return FG_ERR_INVALID_ARG;
+  if (tile_masks && !tile_rects) return FG_ERR_INVALID_ARG;  // (the masks are relative to the rectangles)
   if (N == 0) return FG_OK;
   if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !means2d || !depths || !conics ||
       !tiles_touched || !splats)
@@ -597,7 +604,8 @@ int launch_preprocess_fwd(int N, RawForm raw, const float* means, const float* q
                      fl, raw, means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d,
                      near_plane, far_plane, radius_clip, tile_size, tile_w, tile_h, antialiased, radii, means2d,
                      depths, conics, compensations, tiles_touched, splats, depth_keys,
-                     reinterpret_cast<int2*>(tile_rects), sh_jac, skip_culled_rows());
+                     reinterpret_cast<int2*>(tile_rects), reinterpret_cast<unsigned long long*>(tile_masks), sh_jac,
+                     skip_culled_rows());
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }
@@ -648,12 +656,13 @@ extern "C" int fg_preprocess_fwd(int N, const float* means, const float* quats, 
                                  float near_plane, float far_plane, float radius_clip, int tile_size,
                                  int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                                  float* compensations, int32_t* tiles_touched, float* splats,
-                                 uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
+                                 uint32_t* depth_keys, int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac,
+                                 fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{0, nullptr, nullptr, nullptr}, means, quats, scales, opacities, colors,
                                sh_degree, k_stored, n_color, with_depth, extra, n_extra, viewmat, K, width, height,
                                eps2d, near_plane, far_plane, radius_clip, tile_size, antialiased, radii, means2d,
-                               depths, conics, compensations, tiles_touched, splats, depth_keys, tile_rects, sh_jac,
-                               stream);
+                               depths, conics, compensations, tiles_touched, splats, depth_keys, tile_rects, tile_masks,
+                               sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_bwd(int N, const float* means, const float* quats, const float* scales,
@@ -680,12 +689,12 @@ extern "C" int fg_preprocess_raw_fwd(int N, const float* means, const float* qua
                                      float radius_clip, int tile_size, int antialiased, int32_t* radii,
                                      float* means2d, float* depths, float* conics, float* compensations,
                                      int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
-                                     int32_t* tile_rects, float* sh_jac, fg_stream_t stream) {
+                                     int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac, fg_stream_t stream) {
   return launch_preprocess_fwd(N, RawForm{1, d_quats, d_scales, features_rest}, means, quats, log_scales,
                                opacity_logits, features_dc, sh_degree, k_stored, 3, with_depth, extra, n_extra,
                                viewmat, K, width, height, eps2d, near_plane, far_plane, radius_clip, tile_size,
                                antialiased, radii, means2d, depths, conics, compensations, tiles_touched, splats,
-                               depth_keys, tile_rects, sh_jac, stream);
+                               depth_keys, tile_rects, tile_masks, sh_jac, stream);
 }
 
 extern "C" int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
@@ -751,7 +760,7 @@ extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities,
                      N, fl, RawForm{0, nullptr, nullptr, nullptr}, means, nullptr, nullptr, opacities, colors, extra,
                      viewmat, nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 16, 0, 0, antialiased, const_cast<int32_t*>(radii),
                      const_cast<float*>(means2d), const_cast<float*>(depths), const_cast<float*>(conics),
-                     const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, nullptr, 0);
+                     const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, nullptr, nullptr, 0);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

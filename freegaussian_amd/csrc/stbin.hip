@@ -42,7 +42,7 @@ constexpr int SB_SMALL_KPT = FG_SB_SMALL_KPT, SB_LARGE_KPT = 8;  // elements per
 constexpr int SB_LARGE_GRID = 512;                   // persistent workgroups of the large launch (two per CU)
 constexpr int SB_SMALL_BUCKET_BITS = 11, SB_LARGE_BUCKET_BITS = 12;  // the counting pass of the LDS sorts
 constexpr int SB_MAX_LDS_WORDS = 12288;              // grid words of the count kernel / cursors of the scatter
-constexpr int SB_SCATTER_LDS_BYTES = 132 * 1024;     // dynamic LDS of the staging scatter (+ 21 KB static: one workgroup per CU)
+constexpr int SB_SCATTER_LDS_BYTES = 124 * 1024;     // dynamic LDS of the staging scatter (+ 29 KB static: one workgroup per CU)
 constexpr int SB_MIN_STAGE = 4096;                   // staging buffers smaller than this are not worth the second sweep
 #ifndef FG_SB_SKEW_MAX
 #define FG_SB_SKEW_MAX 96
@@ -127,8 +127,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 // corner marks -> counts, both grids in the same two phases: prefix along x (a wavefront per row, 64 cells a
 // step), then along y with the result written out (thread = column); grids [rows + 1][cols + 1]
+// (st_rowwise: the supertile marks are differences along x only -- one pair per row a footprint mask reaches --, so the
+// second phase copies the supertile rows out instead of summing down the columns)
 __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w, uint32_t* __restrict__ out_t,
-                                                int32_t* gs, int nsr, int sw, uint32_t* __restrict__ out_s) {
+                                                int32_t* gs, int nsr, int sw, uint32_t* __restrict__ out_s,
+                                                bool st_rowwise = false) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   for (int r = wave; r < ntr + nsr; r += SC_WAVES) {
     const bool tiles = r < ntr;
@@ -149,6 +152,10 @@ __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w
     const int32_t* col = (tiles ? gt : gs) + x;
     uint32_t* out = (tiles ? out_t : out_s) + x;
     int run = 0, row = 0;
+    if (!tiles && st_rowwise) {
+      for (; row < rows; ++row) out[(size_t)row * cols] = (uint32_t)col[row * (cols + 1)];
+      continue;
+    }
     for (; row + 4 <= rows; row += 4) {
       int v[4];
 #pragma unroll
@@ -167,9 +174,22 @@ __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w
 }
 
 // ---- count --------------------------------------------------------------------------------------------
+// runs of set bits among the low 8 bits of `bits`: f(first, one past the last)
+template <typename F>
+__device__ __forceinline__ void for_bit_runs(uint32_t bits, F f) {
+  bits &= 0xFFu;
+  while (bits) {
+    const int s = __builtin_ctz(bits);
+    const int len = __builtin_ctz(~(bits >> s));
+    f(s, s + len);
+    bits &= ~(((1u << len) - 1u) << s);
+  }
+}
+// masks (nullable): fg::footprint_mask of every rectangle -- which blocks of it the ellipse reaches; counted (and
+// scattered, sb_scatter_kernel) are the set blocks' tiles only.  NULL: whole rectangles.
 __global__ void __launch_bounds__(SC_BLOCK)
-sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, int band_rows,
-                uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
+sb_count_kernel(int N, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks, int tile_w, int tile_h,
+                int band_rows, uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
   extern __shared__ int32_t s_grid[];  // tile grid [(tile rows + 1)][tile_w + 1], then supertile grid
   const Geo g = geo_of(tile_w, tile_h);
   const int chunk = blockIdx.x;
@@ -177,8 +197,13 @@ sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, i
   const int T = tile_w * tile_h, S = g.sw * g.sh;
   const int g0 = chunk * SB_CHUNK + threadIdx.x;
   int2 rc[SC_PER];
+  unsigned long long mk[SC_PER];
 #pragma unroll
-  for (int r = 0; r < SC_PER; ++r) rc[r] = (g0 + r * SC_BLOCK < N) ? rects[g0 + r * SC_BLOCK] : make_int2(0, 0);
+  for (int r = 0; r < SC_PER; ++r) {
+    const bool in = g0 + r * SC_BLOCK < N;
+    rc[r] = in ? rects[g0 + r * SC_BLOCK] : make_int2(0, 0);
+    mk[r] = in && masks ? masks[g0 + r * SC_BLOCK] : 0ull;
+  }
   for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's grids fit the LDS)
     const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
     const int ntr = tr1 - tr0, nsr = sr1 - sr0;
@@ -190,7 +215,35 @@ sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, i
     for (int r = 0; r < SC_PER; ++r) {
       const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
       const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
-      if (w > 0 && yb > ya) {
+      if (masks) {
+        if (w > 0 && yb > ya) {
+          const unsigned long long m = mk[r];
+          const int bs = fg::footprint_block(w, h), sh = 31 - __builtin_clz((unsigned)bs), nby = (h + bs - 1) >> sh;
+          // tiles: one rectangle of corner marks per run of set blocks of a block row
+          for (int by = 0; by < nby; ++by) {
+            const int ba = max(y0 + by * bs, tr0), bb = min(min(y0 + (by + 1) * bs, y0 + h), tr1);
+            if (bb <= ba) continue;
+            for_bit_runs((uint32_t)(m >> (8 * by)), [&](int s0, int s1) {
+              const int xa = x0 + s0 * bs, xb = min(x0 + s1 * bs, x0 + w);
+              atomicAdd(&gt[(ba - tr0) * gwt + xa], 1);
+              atomicAdd(&gt[(ba - tr0) * gwt + xb], -1);
+              atomicAdd(&gt[(bb - tr0) * gwt + xa], -1);
+              atomicAdd(&gt[(bb - tr0) * gwt + xb], 1);
+            });
+          }
+          // supertiles: row by row, the blocks of the row's two tile rows together
+          for (int R = max(y0 >> 1, sr0); R < min(((y0 + h - 1) >> 1) + 1, sr1); ++R) {
+            uint32_t bits = 0;
+            if (2 * R >= y0) bits |= (uint32_t)(m >> (8 * ((2 * R - y0) >> sh)));
+            if (2 * R + 1 < y0 + h) bits |= (uint32_t)(m >> (8 * ((2 * R + 1 - y0) >> sh)));
+            for_bit_runs(bits, [&](int s0, int s1) {
+              const int xa = x0 + s0 * bs, xb = min(x0 + s1 * bs, x0 + w);
+              atomicAdd(&gs[(R - sr0) * gws + (xa >> 1)], 1);
+              atomicAdd(&gs[(R - sr0) * gws + ((xb - 1) >> 1) + 1], -1);
+            });
+          }
+        }
+      } else if (w > 0 && yb > ya) {
         const int ra = ya - tr0, rb = yb - tr0;
         atomicAdd(&gt[ra * gwt + x0], 1);
         atomicAdd(&gt[ra * gwt + x0 + w], -1);
@@ -206,7 +259,7 @@ sb_count_kernel(int N, const int2* __restrict__ rects, int tile_w, int tile_h, i
     }
     __syncthreads();
     marks_to_counts(gt, ntr, tile_w, table_t + (size_t)chunk * T + tr0 * tile_w, gs, nsr, g.sw,
-                    table_s + (size_t)chunk * S + sr0 * g.sw);
+                    table_s + (size_t)chunk * S + sr0 * g.sw, masks != nullptr);
     __syncthreads();
   }
 }
@@ -463,7 +516,8 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
 // (a chunk of huge rectangles) are stored directly, as without STAGE.
 template <bool STAGE>
 __global__ void __launch_bounds__(SC_BLOCK)
-sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restrict__ depth_keys, int tile_w,
+sb_scatter_kernel(int N, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks,
+                  const uint32_t* __restrict__ depth_keys, int tile_w,
                   int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
                   uint64_t* __restrict__ entries, long long capacity, int small_max, int32_t* __restrict__ large_list,
@@ -496,6 +550,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   extern __shared__ uint32_t s_cur[];  // [supertiles of the pass] (STAGE: + destination deltas + staging buffer)
   __shared__ uint32_t s_wave_tot[SC_WAVES];
   __shared__ int4 s_q[SC_WAVES][64];
+  __shared__ unsigned long long s_qm[SC_WAVES][64];  // the owners' footprint masks
   __shared__ int32_t s_excl[SC_WAVES][64];
   __shared__ unsigned long long s_marks[SC_WAVES];
   const Geo g = geo_of(tile_w, tile_h);
@@ -509,17 +564,20 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   int4* q = s_q[wave];  // {id, depth bits, rect.x, rect.y}
+  unsigned long long* qm = s_qm[wave];
   int32_t* ex = s_excl[wave];
   unsigned long long* marks = &s_marks[wave];
   // the wavefront's rectangles and depth bits: all loads in flight together
   const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SC_WAVES) + lane;
   int2 rc[SC_PER];
   uint32_t dk[SC_PER];
+  unsigned long long mk[SC_PER];
 #pragma unroll
   for (int r = 0; r < SC_PER; ++r) {
     const bool in = g0 + r * 64 < N;
     rc[r] = in ? rects[g0 + r * 64] : make_int2(0, 0);
     dk[r] = in ? depth_keys[g0 + r * 64] : 0u;
+    mk[r] = in && masks ? masks[g0 + r * 64] : 0ull;
   }
   // STAGE: s_cur = local cursors, s_gd[st] = (global slot) - (local slot) of the chunk's run in supertile st
   const int s_pad = (S + 1) & ~1;
@@ -575,6 +633,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
       const int ci = __popcll(hm & lt_mask);
       if (hit) {
         q[ci] = make_int4(g0 + r * 64, (int)dk[r], rc[r].x, rc[r].y);
+        if (masks) qm[ci] = mk[r];
         ex[ci] = (int)(incl - cnt);
       }
       __builtin_amdgcn_wave_barrier();
@@ -602,20 +661,33 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const uint32_t* __restr
           ty += ((ty + 1) * onx <= t);
           const int tx = t - ty * onx;
           const int local = (oya + ty - sr0) * g.sw + oxa + tx;
-          const uint32_t pos = atomicAdd(&s_cur[local], 1u);
           // which of the supertile's four tiles the rectangle covers (bit j: tile 2 * row + column)
           const int c0 = 2 * (oxa + tx), r0 = 2 * (oya + ty);
           const uint32_t cols = (uint32_t)(c0 >= ox0) | ((uint32_t)(c0 + 1 < ox0 + ow) << 1);
           const uint32_t rows = (uint32_t)(r0 >= oy0) | ((uint32_t)(r0 + 1 < oy0 + oh) << 1);
-          const uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
-          const uint64_t element = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
-          if (!STAGE) {
-            entries[pos] = element;
-          } else if (pos < (uint32_t)stage_cap) {
-            stage[pos] = element;
-            stage_st[pos] = (uint16_t)local;
-          } else {
-            entries[pos + s_gd[local]] = element;
+          uint32_t mask = ((rows & 1u) ? cols : 0u) | ((rows & 2u) ? cols << 2 : 0u);
+          if (masks) {
+            // ... and the footprint mask's blocks hold (the pairs sb_count_kernel counted: a pair none of whose tiles is
+            // reached has no element)
+            const unsigned long long om = qm[lo];
+            const int sh = 31 - __builtin_clz((unsigned)fg::footprint_block(ow, oh));
+            // (columns / rows outside the rectangle are masked off above: their shifted indices may be anything in 0..7)
+            const int bx0 = ((c0 - ox0) >> sh) & 7, bx1 = ((c0 + 1 - ox0) >> sh) & 7;
+            const int by0 = ((r0 - oy0) >> sh) & 7, by1 = ((r0 + 1 - oy0) >> sh) & 7;
+            const uint32_t ra = (uint32_t)(om >> (8 * by0)), rb = (uint32_t)(om >> (8 * by1));
+            mask &= ((ra >> bx0) & 1u) | (((ra >> bx1) & 1u) << 1) | (((rb >> bx0) & 1u) << 2) | (((rb >> bx1) & 1u) << 3);
+          }
+          if (mask != 0u) {
+            const uint32_t pos = atomicAdd(&s_cur[local], 1u);
+            const uint64_t element = ((uint64_t)(uint32_t)o.y << 32) | ((uint64_t)(uint32_t)o.x << 4) | mask;
+            if (!STAGE) {
+              entries[pos] = element;
+            } else if (pos < (uint32_t)stage_cap) {
+              stage[pos] = element;
+              stage_st[pos] = (uint16_t)local;
+            } else {
+              entries[pos + s_gd[local]] = element;
+            }
           }
         }
       }
@@ -1568,8 +1640,9 @@ extern "C" size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h) 
   return count_ws(nullptr, N, geo_of(tile_w, tile_h)).bytes;
 }
 
-extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
-                              int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w, int tile_h,
+                              int32_t* tile_offsets, int64_t* count_out, void* workspace, size_t workspace_bytes,
+                              fg_stream_t stream) {
   if (N <= 0 || tile_w <= 0 || tile_h <= 0 || !tile_rects || !tile_offsets || !workspace) return FG_ERR_INVALID_ARG;
   if (!fg_stbin_supported(N, tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
   const Geo g = geo_of(tile_w, tile_h);
@@ -1578,7 +1651,8 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int 
   hipStream_t s = fg_hip_stream(stream);
   const int T = tile_w * tile_h, S = g.sw * g.sh, nc = n_chunks_of(N);
   hipLaunchKernelGGL(sb_count_kernel, dim3(nc), dim3(SC_BLOCK), count_lds_bytes(g), s, N,
-                     reinterpret_cast<const int2*>(tile_rects), tile_w, tile_h, count_band_rows(g), w.table_t, w.table_s);
+                     reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks), tile_w,
+                     tile_h, count_band_rows(g), w.table_t, w.table_s);
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
   hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
                      tile_offsets, w.st_offsets);
@@ -1629,7 +1703,8 @@ extern "C" size_t fg_stbin_fill_workspace_bytes(int64_t capacity) {
 
 namespace {
 
-int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h, int64_t capacity,
+int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w, int tile_h,
+               int64_t capacity,
                const int32_t* tile_offsets, const void* count_workspace, int32_t* flatten_ids, int32_t* list_offsets,
                void* workspace, size_t workspace_bytes, const fgjobs::JobBuild* jobs, int flags, fg_stream_t stream) {
   if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
@@ -1673,7 +1748,8 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
     const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
     // (the job lists and the segment lists ride here; without the staged scatter: in the large-segment sort launch / chunk 0)
     hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N,
-                       reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
+                       reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks),
+                       depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
                        long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, want_jobs ? 8 : 0, want_jobs ? *jobs : fgjobs::JobBuild{},
                        fw.lt.over_list);
@@ -1681,7 +1757,8 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
     bwd_jobs_in_sort = jobs && jobs->jobs_bwd;
   } else {
     hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
-                       reinterpret_cast<const int2*>(tile_rects), depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
+                       reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks),
+                       depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
                        long_mode, fw.lt.chunk_seg, fw.lt.bucket_seg, 0, fgjobs::JobBuild{}, fw.lt.over_list);
   }
@@ -1712,16 +1789,17 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int
 
 }  // namespace
 
-extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
+extern "C" int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks,
+                             int tile_w, int tile_h,
                              int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                              int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                              int flags, fg_stream_t stream) {
-  return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
+  return stbin_fill(N, depth_keys, tile_rects, tile_masks, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
                     list_offsets, workspace, workspace_bytes, nullptr, flags, stream);
 }
 
-extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
-                                  int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks,
+                                  int tile_w, int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                                   int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
                                   int bwd_list_shares, const fg_raster_config* config, int flags, int64_t* ckpt_need_out,
@@ -1733,6 +1811,6 @@ extern "C" int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32
   const int rc = fgjobs::plan_jobs(width, height, tile_size, jobs_fwd, jobs_bwd, bwd_list_shares, config, &jb);
   if (rc != FG_OK) return rc;
   jb.need_out = reinterpret_cast<long long*>(ckpt_need_out);
-  return stbin_fill(N, depth_keys, tile_rects, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
+  return stbin_fill(N, depth_keys, tile_rects, tile_masks, tile_w, tile_h, capacity, tile_offsets, count_workspace, flatten_ids,
                     list_offsets, workspace, workspace_bytes, &jb, flags, stream);
 }

@@ -1,4 +1,4 @@
-// One C-ABI call per direction for the eager training step (ABI 7): fg_step_fwd = the per-Gaussian forward ->
+// One C-ABI call per direction for the eager training step (ABI 7; footprint masks: ABI 8): fg_step_fwd = the per-Gaussian forward ->
 // supertile count -> fill + job lists -> raster forward; fg_step_bwd = raster backward -> per-Gaussian backward.
 //
 // What it replaces: the four + two calls a host otherwise makes per view around the rasterization(...) of
@@ -57,6 +57,7 @@ extern "C" int fg_step_layout_query(const fg_step_desc* d, const fg_raster_confi
   n[FG_STEP_SPLATS] = (size_t)N * FG_SPLAT_FLOATS * 4;
   n[FG_STEP_DEPTH_KEYS] = (size_t)N * 4;
   n[FG_STEP_TILE_RECTS] = (size_t)N * 8;
+  n[FG_STEP_TILE_MASKS] = (d->flags & FG_STEP_NO_FOOTPRINT_MASKS) ? 0 : (size_t)N * 8;
   n[FG_STEP_SH_JAC] = d->sh_degree >= 1 && d->want_backward ? (size_t)N * FG_SH_JAC_FLOATS * 4 : 0;
   n[FG_STEP_TILE_OFFSETS] = (size_t)(T + 1) * 4;
   n[FG_STEP_LIST_OFFSETS] = (size_t)(T + 1) * 4;
@@ -103,31 +104,33 @@ extern "C" int fg_step_fwd(const fg_step_desc* d, const fg_raster_config* config
   float* splats = at<float>(keep, L, FG_STEP_SPLATS);
   uint32_t* depth_keys = at<uint32_t>(keep, L, FG_STEP_DEPTH_KEYS);
   int32_t* tile_rects = at<int32_t>(keep, L, FG_STEP_TILE_RECTS);
+  uint64_t* tile_masks = at<uint64_t>(keep, L, FG_STEP_TILE_MASKS);
   float* sh_jac = at<float>(keep, L, FG_STEP_SH_JAC);
   int rc;
   if (d->raw)
     rc = fg_preprocess_raw_fwd(N, io->means, io->quats, io->d_quats, io->scales, io->d_scales, io->opacities, io->colors,
                                io->features_rest, d->sh_degree, d->k_stored, d->with_depth, io->extra, d->n_extra, io->viewmat,
                                io->K, W, H, d->eps2d, d->near_plane, d->far_plane, d->radius_clip, 16, d->antialiased, radii,
-                               means2d, depths, conics, comp, tiles, splats, depth_keys, tile_rects, sh_jac, stream);
+                               means2d, depths, conics, comp, tiles, splats, depth_keys, tile_rects, tile_masks, sh_jac, stream);
   else
     rc = fg_preprocess_fwd(N, io->means, io->quats, io->scales, io->opacities, io->colors, d->sh_degree, d->k_stored,
                            d->n_color, d->with_depth, io->extra, d->n_extra, io->viewmat, io->K, W, H, d->eps2d, d->near_plane,
                            d->far_plane, d->radius_clip, 16, d->antialiased, radii, means2d, depths, conics, comp, tiles,
-                           splats, depth_keys, tile_rects, sh_jac, stream);
+                           splats, depth_keys, tile_rects, tile_masks, sh_jac, stream);
   if (rc != FG_OK) return rc;
   int32_t* tile_offsets = at<int32_t>(keep, L, FG_STEP_TILE_OFFSETS);
   int32_t* list_offsets = at<int32_t>(keep, L, FG_STEP_LIST_OFFSETS);
   void* count_ws = at<char>(tmp, L, FG_STEP_COUNT_WS);
-  rc = fg_stbin_count(N, tile_rects, tile_w, tile_h, tile_offsets, io->count_out, count_ws, (size_t)L->nbytes[FG_STEP_COUNT_WS],
-                      stream);
+  rc = fg_stbin_count(N, tile_rects, tile_masks, tile_w, tile_h, tile_offsets, io->count_out, count_ws,
+                      (size_t)L->nbytes[FG_STEP_COUNT_WS], stream);
   if (rc != FG_OK) return rc;
   int32_t* flatten_ids = at<int32_t>(keep, L, FG_STEP_FLATTEN_IDS);
   int32_t* jobs = at<int32_t>(keep, L, FG_STEP_JOBS);
   float* seg_ckpt = at<float>(keep, L, FG_STEP_SEG_CKPT);
-  rc = fg_stbin_fill_jobs(N, depth_keys, tile_rects, tile_w, tile_h, d->capacity, tile_offsets, count_ws, flatten_ids,
+  rc = fg_stbin_fill_jobs(N, depth_keys, tile_rects, tile_masks, tile_w, tile_h, d->capacity, tile_offsets, count_ws, flatten_ids,
                           list_offsets, at<char>(tmp, L, FG_STEP_FILL_WS), (size_t)L->nbytes[FG_STEP_FILL_WS], W, H, 16, jobs,
-                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags, io->ckpt_need_out, stream);
+                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags & FG_STBIN_LONG_SEGMENTS, io->ckpt_need_out,
+                          stream);
   if (rc != FG_OK) return rc;
   float* v_splats = at<float>(keep, L, FG_STEP_V_SPLATS);
   if (io->ev_raster_begin && hipEventRecord(static_cast<hipEvent_t>(io->ev_raster_begin), fg_hip_stream(stream)) != hipSuccess)

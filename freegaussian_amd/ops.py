@@ -150,13 +150,21 @@ class RasterContext:
         self.isect_recent: dict = {}  # ... -> [(list length, N)] of the last calls
         self.capacity_redos = 0  # times a speculative list turned out too small and the fill was repeated
         self.stagewise_raster_calls = 0  # views that went through the stage-wise calls (not fg_step_*) although step_calls is on
-        self.full_ckpt_allocs = 0  # steps with list shares whose checkpoint buffer was sized by the list capacity (no compact slots)
+        self.full_ckpt_allocs = 0  # steps with list shares whose checkpoint buffer was sized by the list capacity because
+        # nothing was known of the shape's needs (a scene whose every tile is split takes the full size knowingly: not counted)
+        self.seg_slots_known = False
         # Footprint rectangles (FG_TIGHT_RECTS=0 turns them off): the fused preprocess passes also write the
         # depth sort keys and, per Gaussian, the tile rectangle shrunk to the tiles where the splat can reach
         # alpha >= 1/255; the raster lists are then binned from those.  Same images and gradients, ~30% fewer
         # list entries on the 1M / 1080p scene.  The reference-exact lists (info["flatten_ids"] etc.) are
         # rebuilt on demand from the radius boxes.
         self.tight_rects = e.get("FG_TIGHT_RECTS", "1") != "0"
+        # FOOTPRINT MASKS (FG_EXACT_TILES=0 turns them off): beside the rectangle, the preprocess passes write which blocks
+        # of it the ELLIPSE alpha >= 1/255 reaches (8 bytes per Gaussian, fg::footprint_mask); the supertile binning counts and
+        # scatters those only.  Nothing for a round splat, most of the rectangle for a needle lying diagonally -- the shape
+        # densification fills a trained scene with: 57 % fewer list entries with 30 % needles of axis ratio 10 in the
+        # 1M / 1080p scene, 12 % on the isotropic bench scene.  Same images and gradients.
+        self.exact_tiles = e.get("FG_EXACT_TILES", "1") != "0"
         # FG_BINNING = supertile (default: fg_stbin_*, count / scatter per 2x2-tile supertile / one sort per
         # supertile) | depthfirst (rounds 1-2: fg_bin_prepare_keys + fg_bin_emit_sort, also the fallback beyond
         # fg_stbin_supported).  Identical lists.
@@ -316,6 +324,7 @@ class RasterContext:
         not be smaller.  ``N``: this call's Gaussian count -- needs reported at another count are scaled by the ratio (a
         slot per 64 list entries, and the lists grow with N)."""
         hist = self.ckpt_need.get(lkey) if self.compact_slots else None
+        self.seg_slots_known = bool(hist)
         if not hist:
             return 0
         need = max(nd if (N <= 0 or n_i == N) else int(nd * (N / n_i) * 1.05) + 8 for nd, n_i in hist)
@@ -634,11 +643,13 @@ def tile_keys_from_offsets(offsets: torch.Tensor, n: int) -> torch.Tensor:
 
 
 def _binning_side_outputs(N, tile_size, width, height, dev):
-    """(depth_keys, tile_rects) buffers for the preprocess passes, or (None, None)."""
+    """(depth_keys, tile_rects, tile_masks) buffers for the preprocess passes, or Nones."""
     tile_w, tile_h = (width + tile_size - 1) // tile_size, (height + tile_size - 1) // tile_size
-    if not current().tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
-        return None, None
-    return torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 2, dtype=torch.int32, device=dev)
+    rctx = current()
+    if not rctx.tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
+        return None, None, None
+    masks = torch.empty(N, dtype=torch.int64, device=dev) if rctx.exact_tiles and rctx.binning == "supertile" else None
+    return torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 2, dtype=torch.int32, device=dev), masks
 
 
 def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, defer=False, want_keys=True,
@@ -655,9 +666,10 @@ def bin_tiles(means2d, radii, depths, tiles_touched, tile_size, tile_w, tile_h, 
     on exact buffers (``redone=True``: consumers must be re-run too).  ``finish`` is None when
     nothing was deferred.  ``want_keys=False``: tile_keys comes back as None (16-bit keys stay inside
     the kernels' workspace; ``tile_keys_from_offsets`` rebuilds them on demand).
-    ``keys_rects=(depth_keys[N], tile_rects[N,2])`` from the fused preprocess pass: the lists are binned
-    from those rectangles (footprint rectangles: a subsequence of the reference's lists); depth_keys
-    is consumed (sorted in place).
+    ``keys_rects=(depth_keys[N], tile_rects[N,2][, tile_masks[N]])`` from the fused preprocess pass: the lists are binned
+    from those rectangles (footprint rectangles: a subsequence of the reference's lists) -- by the supertile path, from the
+    set blocks of the footprint masks only when they are given (int64 [N], fg::footprint_mask; None = whole rectangles);
+    depth_keys is consumed (sorted in place) by the depth-first path.
     ``raster_hint=(channels, width, height)``: what ``rasterize_splats`` will be called with -- the supertile path then
     builds the raster job lists inside one of its own launches (``fg_stbin_fill_jobs``) and leaves them on the returned
     offsets tensor for it (``_fg_jobs``)."""
@@ -831,7 +843,7 @@ def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None, N=0)
     shares = _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, n_list, cfgp) > 0
     jobs = torch.empty(2, words, dtype=torch.int32, device=dev)
     rctx.heavy_calls += int(heavy and shares)
-    rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and lkey is not None and channels == 3)
+    rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and not rctx.seg_slots_known and lkey is not None and channels == 3)
     return jobs, shares, (rctx, channels, width, height, TILE_SIZE), cfgp
 
 
@@ -842,14 +854,15 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     handed to the consumers (``list_offsets``, the returned offsets tensor) are the tile ranges when the list
     fitted and all-zero when it did not, so a raster launch enqueued on a too-small guess walks nothing."""
     lib = _lib.load()
-    depth_keys, rects = keys_rects
+    depth_keys, rects = keys_rects[0], keys_rects[1]
+    masks = keys_rects[2] if len(keys_rects) > 2 else None
     n_tiles = tile_w * tile_h
     tile_offsets, offsets = offsets, torch.empty_like(offsets)  # exact ranges / the ranges consumers read
     ws1 = torch.empty(int(getattr(lib, abi + "_count_workspace_bytes")(N, tile_w, tile_h)), dtype=torch.uint8, device=dev)
     static_capacity, _isect_capacity, _isect_recent = rctx.static_capacity, rctx.isect_capacity, rctx.isect_recent
     static = static_capacity is not None
     count_slot, count_ptr = (None, None) if (static or not rctx.direct_count) else _count_slot()
-    _call(abi + "_count", N, _ptr(rects), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
+    _call(abi + "_count", N, _ptr(rects), _ptr(masks), tile_w, tile_h, _ptr(tile_offsets), count_ptr, _ptr(ws1), ws1.numel(),
           _stream(), stage="fg_bin_prepare")  # fmt: skip
 
     lkey = (dev, tile_w, tile_h)
@@ -858,7 +871,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
     def fill(cap):
         ids = torch.empty(cap, dtype=torch.int32, device=dev)
         ws2 = torch.empty(int(getattr(lib, abi + "_fill_workspace_bytes")(cap)), dtype=torch.uint8, device=dev)
-        args = (N, _ptr(depth_keys), _ptr(rects), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1), _ptr(ids),
+        args = (N, _ptr(depth_keys), _ptr(rects), _ptr(masks), tile_w, tile_h, cap, _ptr(tile_offsets), _ptr(ws1), _ptr(ids),
                 _ptr(offsets), _ptr(ws2), ws2.numel())  # fmt: skip
         # long segments seen on this shape lately (or FG_LONG_SEGMENTS=always): the multi-workgroup sample sort
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
@@ -1130,7 +1143,7 @@ class _Preprocess(torch.autograd.Function):
         comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
-        depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
+        depth_keys, tile_rects, tile_masks = _binning_side_outputs(N, tile_size, width, height, dev)
         if ctx.rctx.color_grad_sink is not None and sh_degree >= 0 and colors is not None:
             ctx.rctx.color_grad_sink("view", viewmat, dev)  # (view-DP: the factored exchange prepares its payload)
         sh_jac = None  # the forward's note for the backward of the SH colour (include/fgraster.h, fg_preprocess_fwd)
@@ -1159,9 +1172,9 @@ class _Preprocess(torch.autograd.Function):
                   sh_degree, k_stored, n_color, int(with_depth), _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width,
                   height, eps2d, near, far, radius_clip, tile_size, int(antialiased), _ptr(radii), _ptr(means2d),
                   _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles), _ptr(splats), _ptr(depth_keys),
-                  _ptr(tile_rects), _ptr(sh_jac), _stream())  # fmt: skip
+                  _ptr(tile_rects), _ptr(tile_masks), _ptr(sh_jac), _stream())  # fmt: skip
             if depth_keys is not None:
-                splats._fg_bin = (depth_keys, tile_rects)  # for ops.bin_tiles(keys_rects=...)
+                splats._fg_bin = (depth_keys, tile_rects, tile_masks)  # for ops.bin_tiles(keys_rects=...)
         ctx.save_for_backward(means, quats, scales, opacities, colors, extra, viewmat, K, radii, sh_jac)
         ctx.set_materialize_grads(False)  # unused depths / conics gradients arrive as None, not as zero tensors
         ctx.cfg = cfg
@@ -1256,7 +1269,7 @@ class _PreprocessRaw(torch.autograd.Function):
         comp = torch.empty(N, dtype=torch.float32, device=dev) if antialiased else None
         tiles = torch.empty(N, dtype=torch.int32, device=dev)
         splats = torch.empty(N, SPLAT_FLOATS, dtype=torch.float32, device=dev)
-        depth_keys, tile_rects = _binning_side_outputs(N, tile_size, width, height, dev)
+        depth_keys, tile_rects, tile_masks = _binning_side_outputs(N, tile_size, width, height, dev)
         sh_jac = None
         if sh_degree >= 1 and ctx.rctx.sh_jacobian:
             sh_jac = torch.empty(N, _lib.SH_JAC_FLOATS, dtype=torch.float32, device=dev)
@@ -1266,9 +1279,9 @@ class _PreprocessRaw(torch.autograd.Function):
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
               _ptr(extra), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d, near, far, radius_clip, tile_size,
               int(antialiased), _ptr(radii), _ptr(means2d), _ptr(depths), _ptr(conics), _ptr(comp), _ptr(tiles),
-              _ptr(splats), _ptr(depth_keys), _ptr(tile_rects), _ptr(sh_jac), _stream())  # fmt: skip
+              _ptr(splats), _ptr(depth_keys), _ptr(tile_rects), _ptr(tile_masks), _ptr(sh_jac), _stream())  # fmt: skip
         if depth_keys is not None:
-            splats._fg_bin = (depth_keys, tile_rects)
+            splats._fg_bin = (depth_keys, tile_rects, tile_masks)
         ctx.save_for_backward(means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc,
                               features_rest, extra, viewmat, K, radii, sh_jac)  # fmt: skip
         ctx.set_materialize_grads(False)
@@ -1582,7 +1595,8 @@ class _RasterStep(torch.autograd.Function):
             # (the launch policy enters the key by VALUE -- its bytes and the variant's fields -- never by the address of a
             # context's copy, which another context's copy may reuse)
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
-                   n_clamp, int(want_backward), int(shares), _lib.STBIN_LONG_SEGMENTS if long_mode else 0, capacity, eps2d,
+                   n_clamp, int(want_backward), int(shares),
+                   (_lib.STBIN_LONG_SEGMENTS if long_mode else 0) | (0 if rctx.exact_tiles else _lib.STEP_NO_FOOTPRINT_MASKS), capacity, eps2d,
                    near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")
@@ -1602,7 +1616,7 @@ class _RasterStep(torch.autograd.Function):
                                        ctypes.addressof(L), _stream()), "fg_step_fwd")  # fmt: skip
             rctx.long_calls += int(long_mode)
             rctx.heavy_calls += int(heavy and shares)
-            rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and channels == 3)
+            rctx.full_ckpt_allocs += int(shares and rctx.compact_slots and seg_slots == 0 and not rctx.seg_slots_known and channels == 3)
             # the outputs are views of the kept workspace: one as_strided each (built before the wait below, i.e. while the
             # GPU runs the projection and the count pass)
             k32, i32 = keep, keep.view(torch.int32)

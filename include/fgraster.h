@@ -44,7 +44,7 @@ typedef void* fg_stream_t;
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
 #define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
-#define FG_ABI_VERSION 7
+#define FG_ABI_VERSION 8
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -164,8 +164,16 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * Replaces the binning + sort implied by tile_size=16 at freegaussian_model.py:806,857. */
 int fg_stbin_supported(int N, int tile_w, int tile_h);
 size_t fg_stbin_count_workspace_bytes(int N, int tile_w, int tile_h);
-int fg_stbin_count(int N, const int32_t* tile_rects, int tile_w, int tile_h, int32_t* tile_offsets,
-                   int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
+/* tile_masks (ABI 8; nullable, the optional output of fg_preprocess_fwd): per Gaussian which blocks of its footprint
+ * rectangle the ELLIPSE alpha >= 1/255 reaches -- the rectangle's w x h tiles in at most 8 x 8 blocks of b x b tiles
+ * (b = 1 up to 8 x 8 tiles, then the next power of two with ceil(max(w, h) / b) <= 8), bit 8 by + bx.  Counted and
+ * scattered are the set blocks' tiles only: a needle lying diagonally across a 12 x 12-tile rectangle enters 20 lists, not
+ * 144 (30 % needles of axis ratio 10 in the 1M / 1080p scene: 57 % fewer list entries, profiles/r05_exact_tiles.md); the
+ * lists stay an order-preserving subsequence of the reference's and every dropped entry is one no pixel of the tile would
+ * have taken.  The SAME array must be given to fg_stbin_count and fg_stbin_fill (the scatter drops exactly the pairs the
+ * count did not count).  NULL: whole rectangles, as before ABI 8. */
+int fg_stbin_count(int N, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w, int tile_h,
+                   int32_t* tile_offsets, int64_t* count_out, void* workspace, size_t workspace_bytes, fg_stream_t stream);
 size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
 /* flags (ABI 7): FG_STBIN_LONG_SEGMENTS -- supertile segments beyond the small-segment launch's LDS capacity (3072
  * elements; a dense cluster: thousands to hundreds of thousands of splats over one 32 x 32-pixel supertile) are cut
@@ -176,8 +184,9 @@ size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
  * 7936 elements (count_out[1]) or more than a handful beyond 3072 (count_out[3]) -- ops.bin_tiles does -- on scenes
  * without such segments the flag only costs the four empty launches. */
 #define FG_STBIN_LONG_SEGMENTS 1
-int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
-                  int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+#define FG_STEP_NO_FOOTPRINT_MASKS 2 /* (fg_step_desc::flags only) */
+int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w,
+                  int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                   int flags, fg_stream_t stream);
 /* (fg_stbin_fill_jobs, with the job lists further down: this call and fg_raster_build_jobs in the same launches) */
@@ -354,8 +363,8 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
  * word, + a margin, is the seg_slots that leaves no tile without.  Word 8 (whenever the forward list is built): what the
  * cost pass over the XCDs' shares decided -- 1 = bands balanced by cost, 0 = the equal spans stood, -1 = it did not run
  * (balance_bands 0 / 2, small or huge grids): a host whose last calls of a shape all read 0 can set balance_bands = 2. */
-int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, int tile_w, int tile_h,
-                       int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
+int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks,
+                       int tile_w, int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                        int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
                        int width, int height, int tile_size, int32_t* jobs_fwd, int32_t* jobs_bwd,
                        int bwd_list_shares, const fg_raster_config* config, int flags, int64_t* ckpt_need_out,
@@ -394,6 +403,8 @@ int fg_unpack_grads(int N, int channels, const float* v_splats, float* v_means2d
  *   sigma <= ln(255 o), inflated so that rounding only ever keeps more).  Lists binned from it are
  *   the reference's lists minus entries that contribute to no pixel, in the same order; images and
  *   gradients are unchanged.  (0, 0) when culled or when nothing is reached.
+ *   tile_masks[N] u64 (ABI 8; nullable, needs tile_rects) = the FOOTPRINT MASK of the rectangle, see fg_stbin_count: which
+ *   of its (at most 8 x 8) blocks the ellipse itself reaches with a pixel centre; 0 when the rectangle is empty.
  * Optional output for the backward (nullable; SH colours of degree >= 1 only, ignored otherwise):
  *   sh_jac[N,FG_SH_JAC_FLOATS] f32 = d colour_c / d direction_d before the clamp (9 floats, c-major) and the
  *   clamp mask (bit c of the 10th float's bits: channel c passed max(. + 0.5, 0)).  Handed to
@@ -406,7 +417,7 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       float near_plane, float far_plane, float radius_clip, int tile_size,
                       int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                       float* compensations, int32_t* tiles_touched, float* splats,
-                      uint32_t* depth_keys, int32_t* tile_rects, float* sh_jac, fg_stream_t stream);
+                      uint32_t* depth_keys, int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac, fg_stream_t stream);
 /* The colour + record half of fg_preprocess_fwd on its own: inputs are the projection outputs of
  * fg_project_fwd (radii, means2d, depths, conics; compensations when antialiased).  Splitting the
  * forward this way lets a host run this HBM-bound half on a second stream while the
@@ -456,7 +467,7 @@ int fg_preprocess_raw_fwd(int N, const float* means, const float* quats, const f
                           float radius_clip, int tile_size, int antialiased, int32_t* radii,
                           float* means2d, float* depths, float* conics, float* compensations,
                           int32_t* tiles_touched, float* splats, uint32_t* depth_keys,
-                          int32_t* tile_rects, float* sh_jac, fg_stream_t stream);
+                          int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac, fg_stream_t stream);
 int fg_preprocess_raw_bwd(int N, const float* means, const float* quats, const float* d_quats,
                           const float* log_scales, const float* d_scales,
                           const float* opacity_logits, const float* features_dc,
@@ -527,7 +538,7 @@ int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored,
  * sees it in count_out[0] and repeats fg_step_fwd with a larger capacity and fresh workspaces. */
 enum {
   FG_STEP_RADII, FG_STEP_MEANS2D, FG_STEP_DEPTHS, FG_STEP_CONICS, FG_STEP_COMP, FG_STEP_TILES, FG_STEP_SPLATS,
-  FG_STEP_DEPTH_KEYS, FG_STEP_TILE_RECTS, FG_STEP_SH_JAC, FG_STEP_TILE_OFFSETS, FG_STEP_LIST_OFFSETS, FG_STEP_FLATTEN_IDS,
+  FG_STEP_DEPTH_KEYS, FG_STEP_TILE_RECTS, FG_STEP_TILE_MASKS, FG_STEP_SH_JAC, FG_STEP_TILE_OFFSETS, FG_STEP_LIST_OFFSETS, FG_STEP_FLATTEN_IDS,
   FG_STEP_JOBS, FG_STEP_LIVE, FG_STEP_SEG_CKPT, FG_STEP_V_SPLATS, FG_STEP_RENDER, FG_STEP_ALPHAS, FG_STEP_LAST_IDS,
   FG_STEP_CLAMP_MASK, FG_STEP_COUNT_WS, FG_STEP_FILL_WS, FG_STEP_BUFFERS
 };
@@ -540,7 +551,8 @@ typedef struct fg_step_desc {
   int32_t n_clamp;        /* composite epilogue: clamp the first n_clamp channels; io->background nullable */
   int32_t want_backward;  /* 0: no liveness words / checkpoints / record-gradient array / SH note */
   int32_t list_shares;    /* backward over shares of the tiles' lists (three channels; fg_raster_seg_ckpt_floats) */
-  int32_t flags;          /* FG_STBIN_LONG_SEGMENTS */
+  int32_t flags;          /* FG_STBIN_LONG_SEGMENTS | FG_STEP_NO_FOOTPRINT_MASKS (ABI 8: the step bins by footprint masks -- see
+                             fg_stbin_count -- unless this is set: whole rectangles, as before) */
   float eps2d, near_plane, far_plane, radius_clip;
   int64_t capacity;       /* list entries the workspaces hold */
 } fg_step_desc;

@@ -21,7 +21,7 @@ sc.means[: int(frac * N)] *= ball / 2.0
 dev = torch.device("cuda", 0)
 t = [x.to(dev) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
 _, _, _, _, _, splats = ops.preprocess(*t, None, sc.viewmats[0].to(dev), sc.Ks[0].to(dev), W, H, sh_degree=3)
-keys, rects = splats._fg_bin
+keys, rects = splats._fg_bin[:2]
 lib = _lib.load()
 tw, th = (W + 15) // 16, (H + 15) // 16
 T, S = tw * th, ((tw + 1) // 2) * ((th + 1) // 2)

@@ -20,7 +20,7 @@ dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
 t = [x.to(dev) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
 out = ops.preprocess(*t, None, sc.viewmats[0].to(dev), sc.Ks[0].to(dev), W, H, sh_degree=3)
-keys, rects = out[-1]._fg_bin
+keys, rects = out[-1]._fg_bin[:2]
 lib = _lib.load()
 tw, th = (W + 15) // 16, (H + 15) // 16
 T = tw * th

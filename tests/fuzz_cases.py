@@ -7,13 +7,16 @@ The bar (tests/helpers.py): integers ``torch.equal``; images through ``close_exc
 run of the oracle.  The gradient is linear in the cotangents, so K draws of (v_render, v_alpha) on the same forward give K
 samples of each fp32 implementation's distance from the fp64 gradient; the HIP path passes iff
 
-    rms_K(HIP - fp64) <= 1.5 * max(rms_K(fp32 oracle - fp64), REL_TOL)        (both relative to |fp64 gradient|)
+    rel_K(HIP) <= 1.5 * max(rel_K(fp32 oracle), REL_TOL),
+    rel_K(x) = sqrt(sum_k |g_x,k - g_fp64,k|^2) / sqrt(sum_k |g_fp64,k|^2)   (the K draws' gradients as ONE stacked vector)
 
-and both numbers are recorded (``FG_PARITY_REPORT``).  Why K draws and not the one the case was caught with: the cases
+and both numbers are recorded (``FG_PARITY_REPORT``).  (Pooled, not a mean of per-draw ratios: a draw whose fp64 gradient
+happens to be small has a huge ratio on both sides and would decide the comparison by itself.)  Why K draws and not the one the case was caught with: the cases
 that need arbitration are one- or two-Gaussian scenes rendered as expected depth, where d = D / alpha_out is constant over
 the splat and its gradient is a sum of per-pixel rounding residues of ``alpha_out = 1 - T`` (ulp(1) / alpha each); a single
 draw of that sum lands anywhere between 0.01 and 3 times its RMS -- for EITHER implementation (profiles/r05_ed_outlier.md:
-seed 11 case 1, the fp32 oracle's own draw was at 0.06 of its RMS, the HIP path's at 2.2; over 24 draws 1.22e-3 / 1.47e-3)."""
+seed 11 case 1, the fp32 oracle's own draw was at 0.06 of its RMS, the HIP path's at 2.2; over 24 draws 1.22e-3 / 1.47e-3).
+"""
 import os
 import sys
 
@@ -95,14 +98,14 @@ def _grad_errors(g_hip, g_ref):
 
 
 def arbitrate(case: Case, ins32, r32, a32, ins_hip, r_hip, a_hip, inputs, draws: int):
-    """RMS over ``draws`` cotangent draws of the relative L2 distance to the fp64 oracle's gradient, for the inputs listed:
-    -> {input index: (rms of the fp32 oracle, rms of the HIP path)}."""
+    """Relative L2 distance to the fp64 oracle's gradient pooled over ``draws`` cotangent draws (module docstring), for the
+    inputs listed: -> {input index: (the fp32 oracle's, the HIP path's)}."""
     from oracle import raster_oracle as O
 
     ins64 = case.leaves(torch.float64)
     r64, a64, _ = O.rasterization(*ins64, *case.cameras(torch.float64), case.W, case.H, **case.kw)
     gd = torch.Generator().manual_seed(77_000 + 1000 * case.seed0 + case.case)
-    sq = {j: [0.0, 0.0] for j in inputs}
+    sq = {j: [0.0, 0.0, 0.0] for j in inputs}
     for _ in range(draws):
         vr = torch.randn(r64.shape, generator=gd)
         va = torch.randn(a64.shape, generator=gd)
@@ -110,13 +113,13 @@ def arbitrate(case: Case, ins32, r32, a32, ins_hip, r_hip, a_hip, inputs, draws:
         g32 = _backward(ins32, r32, a32, vr, va)
         gh = _backward(ins_hip, r_hip, a_hip, vr, va)
         for j in inputs:
-            den = max(float(g64[j].norm()), 1e-30)
-            sq[j][0] += (float((g32[j] - g64[j]).norm()) / den) ** 2
-            sq[j][1] += (float((gh[j] - g64[j]).norm()) / den) ** 2
-    return {j: ((sq[j][0] / draws) ** 0.5, (sq[j][1] / draws) ** 0.5) for j in inputs}
+            sq[j][0] += float((g32[j] - g64[j]).norm()) ** 2
+            sq[j][1] += float((gh[j] - g64[j]).norm()) ** 2
+            sq[j][2] += float(g64[j].norm()) ** 2
+    return {j: ((sq[j][0] / max(sq[j][2], 1e-60)) ** 0.5, (sq[j][1] / max(sq[j][2], 1e-60)) ** 0.5) for j in inputs}
 
 
-def check(case: Case, device="cuda", draws: int = 16, log=print):
+def check(case: Case, device="cuda", draws: int = 32, log=print):
     """Run the case through the oracle and (twice: the second call of a shape may take the one-call-per-direction path)
     through the HIP path; -> (ok, message).  Comparisons are recorded through tests/helpers.py."""
     from freegaussian_amd import rasterization
@@ -169,10 +172,10 @@ def check(case: Case, device="cuda", draws: int = 16, log=print):
             for j in over:
                 rms_or, rms_hip = res[j]
                 helpers._record("arbiter_single_draw_hip_vs_oracle32", errs[j])
-                helpers._record("arbiter_oracle32_vs_fp64_rms", rms_or)
-                helpers._record("arbiter_hip_vs_fp64_rms", rms_hip)
+                helpers._record("arbiter_oracle32_vs_fp64_pooled", rms_or)
+                helpers._record("arbiter_hip_vs_fp64_pooled", rms_hip)
                 verdict = rms_hip <= ARBITER_FACTOR * max(rms_or, REL_TOL)
-                notes.append(f"[{NAMES[j]}: {errs[j]:.1e} -> fp64 arbiter, rms over draws: oracle32 {rms_or:.1e}, HIP {rms_hip:.1e}"
+                notes.append(f"[{NAMES[j]}: {errs[j]:.1e} -> fp64 arbiter, pooled over draws: oracle32 {rms_or:.1e}, HIP {rms_hip:.1e}"
                              f"{'' if verdict else ' FAILS'}]")
                 if not verdict:
                     problems.append(f"{NAMES[j]} gradient {errs[j]:.1e} and HIP further from fp64 than {ARBITER_FACTOR} x the fp32 oracle")

@@ -101,7 +101,7 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_bin_prepare_rects(4, *(n * 3), 16, 4, 4, *(n * 4), 0, None) == -1
     # raw preprocess is SH-only
     assert lib.fg_preprocess_raw_fwd(4, *(n * 8), -1, 16, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
-                                     *(n * 11)) == -1  # fmt: skip
+                                     *(n * 12)) == -1  # fmt: skip
     assert lib.fg_bin_prepare_keys(4, *(n * 7), 0, None) == -1  # keys / rectangles / outputs missing
     assert lib.fg_bin_prepare_keys(0, *(n * 7), 0, None) == 0
     # composite raster: clamp count within the channels, mask required
@@ -118,10 +118,15 @@ def test_argument_validation_of_the_newer_entry_points_without_gpu():
     assert lib.fg_adam_step(16, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == -1
     assert lib.fg_adam_step(0, *(n * 4), 1e-3, 0.9, 0.999, 1e-15, 1, None) == 0
     # fill with job lists: the image must give the tile grid
-    assert lib.fg_stbin_fill_jobs(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, 0, None, None) == -1
+    assert lib.fg_stbin_fill_jobs(4, *(n * 3), 4, 4, 100, *(n * 5), 0, 100, 64, 16, None, None, 0, None, 0, None, None) == -1
     # ... and (ABI 7) the flags word holds FG_STBIN_LONG_SEGMENTS or nothing; the workspace has room for the long
     # segments' bucket tables (40 bytes per bucket, a bucket per 1536 list entries + one per possible long segment)
-    assert lib.fg_stbin_fill(4, *(n * 2), 4, 4, 100, *(n * 5), 0, 2, None) == -1
+    assert lib.fg_stbin_fill(4, *(n * 3), 4, 4, 100, *(n * 5), 0, 2, None) == -1
+    # (ABI 8) footprint masks are relative to the footprint rectangles: no masks without rectangles
+    assert lib.fg_preprocess_fwd(4, *(n * 5), -1, 0, 3, 0, None, 0, None, None, 32, 32, 0.3, 0.01, 1e10, 0.0, 16, 0,
+                                 *(n * 8), None, 1, None, None) == -1  # fmt: skip
+    assert lib.fg_stbin_count(4, None, None, 4, 4, None, None, None, 0, None) == -1
+    assert _lib.STEP_NO_FOOTPRINT_MASKS == 2
     assert lib.fg_stbin_fill_workspace_bytes(1 << 23) >= 2 * 8 * (1 << 23) + 40 * ((1 << 23) // 1536 + (1 << 23) // 7936)
     assert _lib.STBIN_LONG_SEGMENTS == 1
 

@@ -153,59 +153,147 @@ def test_depth_first_binning_equals_full_key_sort():
     assert torch.equal(ops.isect_keys(tk, ids, d).cpu(), keys_s)
 
 
-@pytest.mark.parametrize("mode", ["classic", "antialiased"])
-def test_footprint_rectangles_cull_only_dead_entries(mode, monkeypatch):
-    """The lists the compositing walks (binned from the preprocess pass's footprint rectangles) are
-    the reference's lists minus (splat, tile) pairs in which the splat reaches alpha >= 1/255 at no
-    pixel centre: a subsequence, tile by tile, of the radius-box lists; every dropped entry is dead
-    by the oracle's own alpha test; image bit-identical, gradients equal up to atomic order; and
-    info["flatten_ids"] / ["isect_offsets"] / ["isect_ids"] still are the reference's full lists."""
+@pytest.mark.parametrize("mode,layout", [("classic", "isotropic"), ("antialiased", "isotropic"), ("classic", "needles"),
+                                         ("antialiased", "needles")])
+def test_footprint_rectangles_cull_only_dead_entries(mode, layout, monkeypatch):
+    """The lists the compositing walks are the reference's lists minus (splat, tile) pairs in which the splat reaches
+    alpha >= 1/255 at no pixel centre -- binned from the preprocess pass's footprint RECTANGLES (round 2) and, inside those,
+    from its footprint MASKS (round 5: the blocks of the rectangle the ellipse itself reaches): each a subsequence, tile by
+    tile, of the one before; every dropped entry is dead by the oracle's own alpha test; image bit-identical, gradients
+    equal up to atomic order; and info["flatten_ids"] / ["isect_offsets"] / ["isect_ids"] still are the reference's full
+    lists.  ``needles``: half of the Gaussians with one axis x 10 and one / 3, the shapes densification leaves
+    (freegaussian_model.py:524-571) -- there the masks must drop at least a third of what the rectangles keep."""
+    from freegaussian_amd.scenes import apply_layout
+
     if ops.default_context.overlap_pack:
         pytest.skip("FG_OVERLAP_PACK=1: the two-stream forward bins from the radius boxes")
     sc = _scene(n=30000, w=400, h=240, seed=13)
+    if layout == "needles":
+        apply_layout(sc, "needles:0.5:10")
     sc.opacities[::3] *= 0.05  # many faint splats: their 3-sigma boxes are mostly dead area
     sc.scales[:40] *= 12.0
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(0)).to(DEV)
     outs = []
-    for tight in (True, False):
+    for tight, exact in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(ops.default_context, "tight_rects", tight)
+        monkeypatch.setattr(ops.default_context, "exact_tiles", exact)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True,
                                    rasterize_mode=mode)  # fmt: skip
         (r * vr).sum().backward()
         outs.append((r.detach(), a.detach(), [x.grad for x in t], info))
-    (r1, a1, g1, i1), (r0, a0, g0, i0) = outs
-    assert torch.equal(r1, r0) and torch.equal(a1, a0)
-    for x, y in zip(g1, g0):
-        assert rel_l2(x, y) < 1e-5
+    (r2, a2, g2, i2), (r1, a1, g1, i1), (r0, a0, g0, i0) = outs
+    assert torch.equal(r1, r0) and torch.equal(a1, a0) and torch.equal(r2, r0) and torch.equal(a2, a0)
+    for x, y, z in zip(g1, g0, g2):
+        assert rel_l2(x, y) < 1e-5 and rel_l2(z, y) < 1e-5
     # without footprint rectangles the raster lists ARE the reference lists
     assert i0["raster_flatten_ids"] is i0["flatten_ids"]
     full_ids, full_offs = i0["flatten_ids"].cpu(), i0["isect_offsets"].cpu()
     ids, offs = i1["raster_flatten_ids"].cpu(), i1["raster_isect_offsets"].cpu()
+    ids_m, offs_m = i2["raster_flatten_ids"].cpu(), i2["raster_isect_offsets"].cpu()
     assert ids.numel() < 0.9 * full_ids.numel()  # the culling is not a no-op here
-    # the lazily rebuilt reference lists of the tight run are the same lists
-    assert torch.equal(i1["flatten_ids"].cpu(), full_ids) and torch.equal(i1["isect_offsets"].cpu(), full_offs)
+    assert ids_m.numel() < (0.67 if layout == "needles" else 0.97) * ids.numel(), (ids_m.numel(), ids.numel())
+    print(f"{layout}: radius boxes {full_ids.numel()}, footprint rectangles {ids.numel()}, footprint masks {ids_m.numel()}")
+    # the lazily rebuilt reference lists of the tight runs are the same lists
+    for i in (i1, i2):
+        assert torch.equal(i["flatten_ids"].cpu(), full_ids) and torch.equal(i["isect_offsets"].cpu(), full_offs)
     assert torch.equal(i1["isect_ids"].cpu(), i0["isect_ids"].cpu())
     ref = O.project(sc.means, sc.quats, sc.scales, sc.viewmats[0], sc.Ks[0], sc.width, sc.height)
     opac = sc.opacities * ref.compensations if mode == "antialiased" else sc.opacities
     tw = i1["tile_width"]
-    dropped_total = 0
+    dropped_total = [0, 0]
     for tile in range(0, tw * i1["tile_height"], 7):
         f = full_ids[int(full_offs[tile]) : int(full_offs[tile + 1])].tolist()
         c = ids[int(offs[tile]) : int(offs[tile + 1])].tolist()
-        it = iter(f)
-        assert all(x in it for x in c), tile  # subsequence, order kept
-        dropped = sorted(set(f) - set(c))
-        assert len(f) - len(c) == len(dropped)
-        if dropped:
-            dropped_total += len(dropped)
-            ty, tx = divmod(tile, tw)
-            yy, xx = torch.meshgrid(torch.arange(16.0) + ty * 16 + 0.5, torch.arange(16.0) + tx * 16 + 0.5, indexing="ij")
-            d = torch.tensor(dropped)
-            _, _, _, alpha, valid = O._tile_terms(xx.reshape(-1), yy.reshape(-1), ref.means2d[d], ref.conics[d], opac[d])
-            assert not bool(valid.any()), (tile, "a dropped entry reaches 1/255 somewhere")
-    assert dropped_total > 0
+        m = ids_m[int(offs_m[tile]) : int(offs_m[tile + 1])].tolist()
+        for k, (outer, inner) in enumerate(((f, c), (c, m))):
+            it = iter(outer)
+            assert all(x in it for x in inner), (tile, k)  # subsequence, order kept
+            dropped = sorted(set(outer) - set(inner))
+            assert len(outer) - len(inner) == len(dropped)
+            if dropped:
+                dropped_total[k] += len(dropped)
+                ty, tx = divmod(tile, tw)
+                yy, xx = torch.meshgrid(torch.arange(16.0) + ty * 16 + 0.5, torch.arange(16.0) + tx * 16 + 0.5, indexing="ij")
+                d = torch.tensor(dropped)
+                _, _, _, alpha, valid = O._tile_terms(xx.reshape(-1), yy.reshape(-1), ref.means2d[d], ref.conics[d], opac[d])
+                assert not bool(valid.any()), (tile, k, "a dropped entry reaches 1/255 somewhere")
+    assert dropped_total[0] > 0 and dropped_total[1] > 0
+
+
+def _enumerate_masked_lists(keys, rects, masks, tw, th):
+    """The lists fg_stbin_* must produce from (depth key, rectangle, footprint mask) triples, by plain enumeration: the
+    tiles of every set block, sorted by (tile, key, id)."""
+    entries = []
+    for i, ((rx, ry), m, k) in enumerate(zip(rects.tolist(), masks.tolist(), keys.tolist())):
+        x0, y0, w, h = rx & 0xFFFF, rx >> 16, ry & 0xFFFF, ry >> 16
+        if w == 0 or h == 0:
+            continue
+        bs = 1
+        while 8 * bs < max(w, h):
+            bs *= 2
+        m &= (1 << 64) - 1
+        for y in range(y0, y0 + h):
+            for x in range(x0, x0 + w):
+                if (m >> (8 * ((y - y0) // bs) + (x - x0) // bs)) & 1:
+                    entries.append((y * tw + x, k & 0xFFFFFFFF, i))
+    entries.sort()
+    ids = torch.tensor([e[2] for e in entries], dtype=torch.int32)
+    counts = torch.bincount(torch.tensor([e[0] for e in entries], dtype=torch.int64), minlength=tw * th)
+    offs = torch.cat([torch.zeros(1, dtype=torch.int64), torch.cumsum(counts, 0)]).to(torch.int32)
+    return ids, offs
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_footprint_mask_binning_equals_plain_enumeration(seed, monkeypatch):
+    """fg_stbin_count / fg_stbin_fill with footprint masks (ABI 8) against a plain enumeration of the set blocks' tiles:
+    `torch.equal` lists and ranges.  ARBITRARY masks -- not only the convex ones fg_preprocess_fwd writes: holes, several
+    runs per block row, empty masks, rectangles of every block size (1 ... 16 tiles per block), depth ties, capacity guesses
+    that are too small -- so that the count's and the scatter's reading of a mask can never disagree."""
+    g = torch.Generator().manual_seed(500 + seed)
+    W, H = [(640, 400), (1920, 1080), (333, 777), (2560, 1440), (160, 96), (4000, 64)][seed]
+    tw, th = (W + 15) // 16, (H + 15) // 16
+    N = [3000, 20000, 5000, 8000, 300, 4000][seed]
+    big = torch.rand(N, generator=g) < 0.1
+    w = torch.where(big, torch.randint(1, 130, (N,), generator=g), torch.randint(1, 10, (N,), generator=g)).clamp(max=tw)
+    h = torch.where(big, torch.randint(1, 130, (N,), generator=g), torch.randint(1, 10, (N,), generator=g)).clamp(max=th)
+    x0 = (torch.rand(N, generator=g) * (tw - w + 1).float()).long().clamp(min=0)
+    y0 = (torch.rand(N, generator=g) * (th - h + 1).float()).long().clamp(min=0)
+    empty = torch.rand(N, generator=g) < 0.05
+    w, h = torch.where(empty, torch.zeros_like(w), w), torch.where(empty, torch.zeros_like(h), h)
+    rects = _pack_rects(x0, y0, w, h)
+    dense = torch.randint(0, 2**31, (N, 2), generator=g)  # ~half of the blocks
+    sparse = dense & torch.randint(0, 2**31, (N, 2), generator=g) & torch.randint(0, 2**31, (N, 2), generator=g)
+    kind = torch.randint(0, 4, (N,), generator=g)
+    bits = torch.where((kind == 0)[:, None], dense, torch.where((kind == 1)[:, None], sparse, torch.full_like(dense, 2**31 - 1)))
+    masks = (bits[:, 0] | (bits[:, 1] << 32)) | (torch.randint(0, 2, (N,), generator=g) << 31) | (torch.randint(0, 2, (N,), generator=g) << 63)
+    masks = torch.where(kind == 3, torch.zeros_like(masks), masks)
+    # only bits of existing blocks may be set (what fg::footprint_mask guarantees)
+    bs = torch.ones(N, dtype=torch.int64)
+    for _ in range(8):
+        bs = torch.where(8 * bs < torch.maximum(w, h), bs * 2, bs)
+    nbx, nby = (w + bs - 1) // bs, (h + bs - 1) // bs
+    valid = torch.zeros(N, dtype=torch.int64)
+    for by in range(8):
+        row = torch.where(by < nby, (1 << nbx) - 1, torch.zeros_like(nbx))
+        valid |= row << (8 * by)
+    masks = masks & valid
+    keys = torch.randint(0, 50 if seed % 2 else 2**31 - 1, (N,), generator=g).to(torch.int32)  # (odd seeds: depth ties)
+    want_ids, want_offs = _enumerate_masked_lists(keys, rects, masks, tw, th)
+    z = torch.zeros(N, device=DEV)
+    args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
+    monkeypatch.setattr(ops.default_context, "binning", "supertile")
+    for long_segments in ("never", "always"):
+        monkeypatch.setattr(ops.default_context, "long_segments", long_segments)
+        ops.default_context.isect_capacity.clear()
+        runs = [ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects.to(DEV), masks.to(DEV)), want_keys=False) for _ in range(2)]
+        for k in list(ops.default_context.isect_capacity):
+            ops.default_context.isect_capacity[k] = 1024  # far too small: the fill writes nothing, the host refills exactly
+        runs.append(ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects.to(DEV), masks.to(DEV)), want_keys=False))
+        for _, f, o in runs:
+            assert torch.equal(o.cpu(), want_offs), long_segments
+            assert torch.equal(f.cpu(), want_ids), long_segments
 
 
 def test_more_than_65536_tiles_takes_the_32bit_tile_key_path():
@@ -392,7 +480,7 @@ def test_supertile_binning_equals_depth_first_binning(case, monkeypatch):
         _, _, _, _, _, splats = ops.preprocess(*t, None, sc.viewmats[0].to(DEV), sc.Ks[0].to(DEV), W, H, sh_degree=3)
         if not hasattr(splats, "_fg_bin"):
             pytest.skip("FG_TIGHT_RECTS=0: the preprocess pass writes no keys / rectangles")
-        keys, rects = splats._fg_bin
+        keys, rects = splats._fg_bin[:2]
         N = 50000
         f, o = _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=True)
         assert f.numel() > 50_000
