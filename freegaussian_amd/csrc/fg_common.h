@@ -78,11 +78,14 @@ __device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, fl
   const float t255 = 255.f * o, det = a * c - b * b;
   if (!(o == o) || !(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(t255 >= 1.f)) return all;  // (no culling possible: alpha_extent kinds 2 / 0)
   // tau2 = 2 ln(255 o), inflated by 0.1 % + 2e-3 (the pixel test's own rounding is ~1e-5 of it)
+  if (w == 1 && h == 1) return all;  // (the rectangle itself was tightened against the ellipse's extents)
+  // (hardware reciprocals, 1 ulp: the inflations below are thousands of ulps)
   const float tau2 = (1.3862943611f * __builtin_amdgcn_logf(t255)) * 1.001f + 2e-3f;
-  const float ex = __builtin_amdgcn_sqrtf(tau2 * c / det), ey = __builtin_amdgcn_sqrtf(tau2 * a / det);
+  const float rdet = __builtin_amdgcn_rcpf(det), ra = __builtin_amdgcn_rcpf(a);
+  const float ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet), ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
   if (!(ex == ex) || !(ey == ey)) return all;
-  const float dy_right = -b * ex / c;  // where the ellipse is widest to the right (to the left: at -dy_right)
-  const float at = a * tau2, m = 0.02f, span = ts * (float)bs;
+  const float dy_right = -b * ex * __builtin_amdgcn_rcpf(c);  // where the ellipse is widest to the right (to the left: at -dy_right)
+  const float at = a * tau2, m = 0.02f, rspan = __builtin_amdgcn_rcpf(ts * (float)bs);
   uint64_t mask = 0;
   for (int by = 0; by < nby; ++by) {
     const int ya = y0 + by * bs, yb = min(ya + bs, y0 + h);
@@ -92,13 +95,13 @@ __device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, fl
     // (the strip's edges may lie beyond the ellipse's top / bottom by the margins: the widest point is then AT +-ey)
     const float dr = fminf(fmaxf(fminf(fmaxf(dy_right, dlo), dhi), -ey), ey);
     const float dl = fminf(fmaxf(fminf(fmaxf(-dy_right, dlo), dhi), -ey), ey);
-    float xr = (-b * dr + __builtin_amdgcn_sqrtf(fmaxf(at - det * dr * dr, 0.f))) / a;
-    float xl = (-b * dl - __builtin_amdgcn_sqrtf(fmaxf(at - det * dl * dl, 0.f))) / a;
+    float xr = (-b * dr + __builtin_amdgcn_sqrtf(fmaxf(at - det * dr * dr, 0.f))) * ra;
+    float xl = (-b * dl - __builtin_amdgcn_sqrtf(fmaxf(at - det * dl * dl, 0.f))) * ra;
     xr = gx + xr + (fabsf(xr) * 0.0005f + m);
     xl = gx + xl - (fabsf(xl) * 0.0005f + m);
     // blocks whose pixel centres [ts (x0 + bx bs) + 0.5, ts (x0 + (bx + 1) bs) - 0.5] meet [xl, xr]
     const float org = ts * (float)x0;
-    const float fa = ceilf((xl + 0.5f - org) / span) - 1.f, fb = floorf((xr - 0.5f - org) / span);
+    const float fa = ceilf((xl + 0.5f - org) * rspan) - 1.f, fb = floorf((xr - 0.5f - org) * rspan);
     if (!(fa == fa) || !(fb == fb)) {  // (NaN: keep the whole row)
       mask |= (uint64_t)row_all << (8 * by);
       continue;

@@ -1265,8 +1265,10 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     const float vsdy = v_sigma * dy;                                                                    \
     g[4] += vsdy;                                                                                       \
     g[5] = fmaf(vsdy, dy, g[5]);                                                                        \
-    g[6] += fabsf(v_sigma * fmaf(s.b, dy, adx)); /* absgrad sums |.| per pixel: not a moment */         \
-    g[7] += fabsf(v_sigma * fmaf(s.c, dy, bdx));                                                        \
+    /* absgrad sums |.| per pixel: not a moment.  |v_sigma| |h| + g as ONE fma with abs source modifiers (as     \
+       g += |v_sigma h| the compiler issued a multiply and an add: 2 of the slot's 37 vector instructions) */    \
+    g[6] = fmaf(fabsf(v_sigma), fabsf(fmaf(s.b, dy, adx)), g[6]);                                       \
+    g[7] = fmaf(fabsf(v_sigma), fabsf(fmaf(s.c, dy, bdx)), g[7]);                                       \
   } while (0)
         bool contributed = false;
         const float adx = s.a * dx, bdx = s.b * dx;

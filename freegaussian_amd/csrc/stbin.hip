@@ -127,11 +127,11 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
 
 // corner marks -> counts, both grids in the same two phases: prefix along x (a wavefront per row, 64 cells a
 // step), then along y with the result written out (thread = column); grids [rows + 1][cols + 1]
-// (st_rowwise: the supertile marks are differences along x only -- one pair per row a footprint mask reaches --, so the
-// second phase copies the supertile rows out instead of summing down the columns)
+// (rowwise: the marks are differences along x only -- a pair per run of blocks a footprint mask sets in a row --, so the
+// second phase copies the rows out instead of summing down the columns)
 __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w, uint32_t* __restrict__ out_t,
                                                 int32_t* gs, int nsr, int sw, uint32_t* __restrict__ out_s,
-                                                bool st_rowwise = false) {
+                                                bool rowwise = false) {
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   for (int r = wave; r < ntr + nsr; r += SC_WAVES) {
     const bool tiles = r < ntr;
@@ -152,7 +152,14 @@ __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w
     const int32_t* col = (tiles ? gt : gs) + x;
     uint32_t* out = (tiles ? out_t : out_s) + x;
     int run = 0, row = 0;
-    if (!tiles && st_rowwise) {
+    if (rowwise) {
+      for (; row + 4 <= rows; row += 4) {
+        int v[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = col[(row + k) * (cols + 1)];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) out[(size_t)(row + k) * cols] = (uint32_t)v[k];
+      }
       for (; row < rows; ++row) out[(size_t)row * cols] = (uint32_t)col[row * (cols + 1)];
       continue;
     }
@@ -217,29 +224,28 @@ sb_count_kernel(int N, const int2* __restrict__ rects, const unsigned long long*
       const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
       if (masks) {
         if (w > 0 && yb > ya) {
+          // One pass over the rectangle's supertile rows: each of a row's two tile rows marks its runs of set blocks on the
+          // tile grid, the two together theirs on the supertile grid -- differences along x ONLY (marks_to_counts rowwise),
+          // two LDS atomics a run: 2.4 tile rows + 1.7 supertile rows per Gaussian on the 1M / 1080p scene = as many atomics
+          // as the eight corner marks of a whole rectangle, and no pass down the columns afterwards.
           const unsigned long long m = mk[r];
-          const int bs = fg::footprint_block(w, h), sh = 31 - __builtin_clz((unsigned)bs), nby = (h + bs - 1) >> sh;
-          // tiles: one rectangle of corner marks per run of set blocks of a block row
-          for (int by = 0; by < nby; ++by) {
-            const int ba = max(y0 + by * bs, tr0), bb = min(min(y0 + (by + 1) * bs, y0 + h), tr1);
-            if (bb <= ba) continue;
-            for_bit_runs((uint32_t)(m >> (8 * by)), [&](int s0, int s1) {
-              const int xa = x0 + s0 * bs, xb = min(x0 + s1 * bs, x0 + w);
-              atomicAdd(&gt[(ba - tr0) * gwt + xa], 1);
-              atomicAdd(&gt[(ba - tr0) * gwt + xb], -1);
-              atomicAdd(&gt[(bb - tr0) * gwt + xa], -1);
-              atomicAdd(&gt[(bb - tr0) * gwt + xb], 1);
-            });
-          }
-          // supertiles: row by row, the blocks of the row's two tile rows together
+          const int sh = 31 - __builtin_clz((unsigned)fg::footprint_block(w, h)), bs = 1 << sh;
           for (int R = max(y0 >> 1, sr0); R < min(((y0 + h - 1) >> 1) + 1, sr1); ++R) {
-            uint32_t bits = 0;
-            if (2 * R >= y0) bits |= (uint32_t)(m >> (8 * ((2 * R - y0) >> sh)));
-            if (2 * R + 1 < y0 + h) bits |= (uint32_t)(m >> (8 * ((2 * R + 1 - y0) >> sh)));
-            for_bit_runs(bits, [&](int s0, int s1) {
-              const int xa = x0 + s0 * bs, xb = min(x0 + s1 * bs, x0 + w);
-              atomicAdd(&gs[(R - sr0) * gws + (xa >> 1)], 1);
-              atomicAdd(&gs[(R - sr0) * gws + ((xb - 1) >> 1) + 1], -1);
+            uint32_t both = 0;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int ty = 2 * R + i;
+              if (ty < y0 || ty >= y0 + h) continue;
+              const uint32_t bits = (uint32_t)(m >> (8 * ((ty - y0) >> sh))) & 0xFFu;
+              both |= bits;
+              for_bit_runs(bits, [&](int s0, int s1) {
+                atomicAdd(&gt[(ty - tr0) * gwt + x0 + s0 * bs], 1);
+                atomicAdd(&gt[(ty - tr0) * gwt + min(x0 + s1 * bs, x0 + w)], -1);
+              });
+            }
+            for_bit_runs(both, [&](int s0, int s1) {
+              atomicAdd(&gs[(R - sr0) * gws + ((x0 + s0 * bs) >> 1)], 1);
+              atomicAdd(&gs[(R - sr0) * gws + ((min(x0 + s1 * bs, x0 + w) - 1) >> 1) + 1], -1);
             });
           }
         }

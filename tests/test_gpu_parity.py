@@ -185,16 +185,21 @@ def test_footprint_rectangles_cull_only_dead_entries(mode, layout, monkeypatch):
         outs.append((r.detach(), a.detach(), [x.grad for x in t], info))
     (r2, a2, g2, i2), (r1, a1, g1, i1), (r0, a0, g0, i0) = outs
     assert torch.equal(r1, r0) and torch.equal(a1, a0) and torch.equal(r2, r0) and torch.equal(a2, a0)
-    for x, y, z in zip(g1, g0, g2):
-        assert rel_l2(x, y) < 1e-5 and rel_l2(z, y) < 1e-5
+    # (the same sums in another order: the dropped entries shift the 64-entry batches and with them which job adds a
+    # splat's share first.  Round tiles: < 1e-5; the needles' gradients are sums over hundreds of tiles per splat)
+    worst = max(max(rel_l2(x, y), rel_l2(z, y)) for x, y, z in zip(g1, g0, g2))
+    print(f"{layout}: gradients of the three runs within {worst:.1e}")
+    assert worst < (1e-5 if layout == "isotropic" else REL_TOL)
     # without footprint rectangles the raster lists ARE the reference lists
     assert i0["raster_flatten_ids"] is i0["flatten_ids"]
     full_ids, full_offs = i0["flatten_ids"].cpu(), i0["isect_offsets"].cpu()
     ids, offs = i1["raster_flatten_ids"].cpu(), i1["raster_isect_offsets"].cpu()
     ids_m, offs_m = i2["raster_flatten_ids"].cpu(), i2["raster_isect_offsets"].cpu()
     assert ids.numel() < 0.9 * full_ids.numel()  # the culling is not a no-op here
-    assert ids_m.numel() < (0.67 if layout == "needles" else 0.97) * ids.numel(), (ids_m.numel(), ids.numel())
     print(f"{layout}: radius boxes {full_ids.numel()}, footprint rectangles {ids.numel()}, footprint masks {ids_m.numel()}")
+    # (small round splats -- this scene's rectangles are mostly 1 x 1 and 2 x 2 tiles -- lose a corner now and then; needles
+    # most of their rectangle)
+    assert ids_m.numel() < (0.67 if layout == "needles" else 0.99) * ids.numel(), (ids_m.numel(), ids.numel())
     # the lazily rebuilt reference lists of the tight runs are the same lists
     for i in (i1, i2):
         assert torch.equal(i["flatten_ids"].cpu(), full_ids) and torch.equal(i["isect_offsets"].cpu(), full_offs)
