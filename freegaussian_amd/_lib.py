@@ -68,6 +68,9 @@ SIGNATURES = {
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_fwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, P, c_int, c_int,
                                   c_float, c_float, c_float, c_float, c_int, c_int, P, P, P, P, P, P, P, P, P, P, P, P]),
+    "fg_viewmat_bwd_workspace_bytes": (c_size_t, [c_int]),
+    "fg_viewmat_bwd": (c_int, [c_int, c_int, P, P, P, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
+                               c_float, c_int, P, P, P, c_int, P, P, P, P, P, c_size_t, P]),
     "fg_sh_pack_fwd": (c_int, [c_int, P, P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P, P, P, P, P, P]),
     "fg_preprocess_bwd": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                   c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P]),

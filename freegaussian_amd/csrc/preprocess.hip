@@ -560,6 +560,161 @@ preprocess_bwd_kernel(int N, FeatLayout fl, RawForm raw, float* __restrict__ v_d
   }
 }
 
+// ---- camera-pose gradient ---------------------------------------------------------------------------------------------
+// dL/d viewmat of one view, from the cotangents the per-Gaussian backward consumes (the record gradients of the raster
+// backward, + gradients on means2d / depths / conics).  The reference keeps a CameraOptimizer in the loop
+// (freegaussian_model.py:120 -- "off" in every shipped config --, applied at :774); gsplat returns v_viewmats from its
+// projection backward and lets autograd carry the SH colour's share through `dirs = means - inverse(viewmats)[:3, 3]`.
+// Three paths from the pose W | t to the loss:  p = W m + t (camera-space mean),  CC = W C W^T (camera-space covariance),
+// and the camera position -W^-1 t inside the SH view direction -- the last leaves here as dL/d campos (3 floats) and the
+// host applies the inverse's derivative (a 4 x 4 matter).  A pass of its own, taken only when the pose requires a gradient:
+// the hot per-Gaussian backward stays as it is.  Deterministic: per-workgroup partial sums, summed in a fixed order.
+constexpr int VM_BLOCK = 256, VM_GRID_MAX = 1024, VM_VALUES = 15;  // dL/dW (9), dL/dt (3), dL/d campos (3)
+__global__ void __launch_bounds__(VM_BLOCK)
+viewmat_bwd_kernel(int N, FeatLayout fl, RawForm raw, const float* __restrict__ means, const float* __restrict__ quats,
+                   const float* __restrict__ scales, const float* __restrict__ opacities, const float* __restrict__ colors,
+                   const float* __restrict__ viewmat, const float* __restrict__ K, int width, int height, float eps2d,
+                   int antialiased, const int32_t* __restrict__ radii, const float* __restrict__ v_splats,
+                   const float* __restrict__ v_means2d, int m2_stride, const float* __restrict__ v_depths,
+                   const float* __restrict__ v_conics, const float* __restrict__ sh_jac, float* __restrict__ partials) {
+  __shared__ float red[VM_BLOCK / 64][16];
+  float acc[VM_VALUES];
+#pragma unroll
+  for (int k = 0; k < VM_VALUES; ++k) acc[k] = 0.f;
+  const Cam cam = load_cam(viewmat, K);
+  const int kk = fl.sh_degree >= 0 ? (fl.sh_degree + 1) * (fl.sh_degree + 1) : 0;
+  const int ncol = kk > 0 ? 3 : fl.n_color;
+  for (int i = blockIdx.x * VM_BLOCK + threadIdx.x; i < N; i += gridDim.x * VM_BLOCK) {
+    if (radii[i] <= 0) continue;
+    const float m[3] = {means[3 * i], means[3 * i + 1], means[3 * i + 2]};
+    const Activated a = load_activated(raw, i, quats, scales, opacities);
+    const Fwd f = project_core(cam, m[0], m[1], m[2], a.q[0], a.q[1], a.q[2], a.q[3], a.s[0], a.s[1], a.s[2], width, height,
+                               eps2d);
+    float rec[REC];
+    const float4* rp = reinterpret_cast<const float4*>(v_splats) + (size_t)i * (REC / 4);
+#pragma unroll
+    for (int q4 = 0; q4 < REC / 4; ++q4) {
+      const float4 v = rp[q4];
+      rec[4 * q4] = v.x; rec[4 * q4 + 1] = v.y; rec[4 * q4 + 2] = v.z; rec[4 * q4 + 3] = v.w;
+    }
+    float v_depth = v_depths ? v_depths[i] : 0.f;
+#pragma unroll
+    for (int c = 0; c < FG_MAX_CHANNELS; ++c)
+      if (fl.with_depth && c == ncol) v_depth += rec[8 + c];
+    const float vcomp = antialiased ? rec[2] * a.o : 0.f;
+    const float vca = rec[3] + (v_conics ? v_conics[3 * i] : 0.f);
+    const float vcb = rec[4] + (v_conics ? v_conics[3 * i + 1] : 0.f);
+    const float vcc = rec[5] + (v_conics ? v_conics[3 * i + 2] : 0.f);
+    float vp[3], vCC[3][3];
+    project_backward_camera(cam, f, eps2d, v_means2d[(size_t)m2_stride * i], v_means2d[(size_t)m2_stride * i + 1], v_depth,
+                            vca, vcb, vcc, antialiased != 0, vcomp, vp, vCC);
+    // p = W m + t
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) acc[3 * r + c] += vp[r] * m[c];
+      acc[9 + r] += vp[r];
+    }
+    // CC = W C W^T with C = M M^T:  dL/dW = (vCC + vCC^T) W C = 2 vCC (W C)
+    {
+      float C[3][3], T[3][3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) C[r][c] = f.M[r][0] * f.M[c][0] + f.M[r][1] * f.M[c][1] + f.M[r][2] * f.M[c][2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[r][c] = cam.W[r][0] * C[0][c] + cam.W[r][1] * C[1][c] + cam.W[r][2] * C[2][c];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) acc[3 * r + c] += 2.f * (vCC[r][0] * T[0][c] + vCC[r][1] * T[1][c] + vCC[r][2] * T[2][c]);
+    }
+    // SH colour: direction = normalize(mean - campos); d colour / d direction from the forward's note, or from the row
+    if (kk > 1) {
+      float dx, dy, dz, inv;
+      view_dir(viewmat, m[0], m[1], m[2], dx, dy, dz, inv);
+      float j[JAC];
+      if (sh_jac) {
+#pragma unroll
+        for (int c = 0; c < JAC; ++c) j[c] = sh_jac[(size_t)i * JAC + c];
+      } else {
+        float row[48];
+#pragma unroll
+        for (int c = 0; c < 48; ++c) row[c] = 0.f;
+        if (raw.enabled) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) row[c] = colors[(size_t)i * 3 + c];
+#pragma unroll
+          for (int c = 3; c < 48; ++c)
+            if (c < 3 * kk) row[c] = raw.features_rest[(size_t)i * 3 * (fl.k_stored - 1) + (c - 3)];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 48; ++c)
+            if (c < 3 * kk) row[c] = colors[(size_t)i * 3 * fl.k_stored + c];
+        }
+        ShSums sums;
+        sh_row_sums(sums, row, fl.sh_degree, kk, dx, dy, dz, true);
+#pragma unroll
+        for (int c = 0; c < 9; ++c) j[c] = sums.jac[c];
+        j[9] = __int_as_float((int)(sums.col[0] + 0.5f > 0.f) | ((int)(sums.col[1] + 0.5f > 0.f) << 1) |
+                              ((int)(sums.col[2] + 0.5f > 0.f) << 2));
+      }
+      const int mk = __float_as_int(j[9]);
+      const float vr = (mk & 1) ? rec[8] : 0.f, vg = (mk & 2) ? rec[9] : 0.f, vb = (mk & 4) ? rec[10] : 0.f;
+      const float vdx = vr * j[0] + vg * j[3] + vb * j[6];
+      const float vdy = vr * j[1] + vg * j[4] + vb * j[7];
+      const float vdz = vr * j[2] + vg * j[5] + vb * j[8];
+      const float dp = vdx * dx + vdy * dy + vdz * dz;
+      // d/d(mean - campos), and campos enters with a minus sign
+      acc[12] -= (vdx - dp * dx) * inv;
+      acc[13] -= (vdy - dp * dy) * inv;
+      acc[14] -= (vdz - dp * dz) * inv;
+    }
+  }
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < VM_VALUES; ++k) {
+    float v = acc[k];
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) v += __shfl_xor(v, d);
+    if (lane == 0) red[wave][k] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float v = 0.f;
+    if (threadIdx.x < VM_VALUES)
+      for (int w = 0; w < VM_BLOCK / 64; ++w) v += red[w][threadIdx.x];
+    partials[(size_t)blockIdx.x * 16 + threadIdx.x] = v;
+  }
+}
+// out[0 .. 15] = dL/d viewmat (row-major 4 x 4, last row 0), out[16 .. 18] = dL/d campos
+__global__ void __launch_bounds__(256) viewmat_sum_kernel(const float* __restrict__ partials, int n_blocks, float* __restrict__ out) {
+  __shared__ float part[16][16];
+  const int k = threadIdx.x & 15, s = threadIdx.x >> 4;
+  float v = 0.f;
+  for (int b = s; b < n_blocks; b += 16) v += partials[(size_t)b * 16 + k];
+  part[s][k] = v;
+  __syncthreads();
+  if (threadIdx.x < 16) {
+    float t = 0.f;
+    for (int q = 0; q < 16; ++q) t += part[q][threadIdx.x];
+    part[0][threadIdx.x] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < 19) {
+    float o = 0.f;
+    if (threadIdx.x < 12) {
+      const int r = threadIdx.x >> 2, c = threadIdx.x & 3;
+      o = c < 3 ? part[0][3 * r + c] : part[0][9 + r];
+    } else if (threadIdx.x >= 16) {
+      o = part[0][12 + (threadIdx.x - 16)];
+    }
+    out[threadIdx.x] = o;
+  }
+}
+
 // -DFG_PREPROCESS_SKIP_CULLED=1 (a build-time A/B switch; the library reads no environment): fetch the
 // coefficient rows of visible Gaussians only, after the projection / the radii are known.  OFF: measured on
 // MI355X (1M / 1080p, 16% culled, profiles/r02_preprocess_skip_culled.md) it saves the 30 MB of dead rows and
@@ -761,6 +916,45 @@ extern "C" int fg_sh_pack_fwd(int N, const float* means, const float* opacities,
                      viewmat, nullptr, 0, 0, 0.f, 0.f, 0.f, 0.f, 16, 0, 0, antialiased, const_cast<int32_t*>(radii),
                      const_cast<float*>(means2d), const_cast<float*>(depths), const_cast<float*>(conics),
                      const_cast<float*>(compensations), nullptr, splats, nullptr, nullptr, nullptr, nullptr, 0);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+namespace {
+int viewmat_grid(int N) {
+  const int g = (N + VM_BLOCK - 1) / VM_BLOCK;
+  return g < VM_GRID_MAX ? (g > 0 ? g : 1) : VM_GRID_MAX;
+}
+}  // namespace
+
+extern "C" size_t fg_viewmat_bwd_workspace_bytes(int N) { return N > 0 ? (size_t)viewmat_grid(N) * 16 * sizeof(float) : 0; }
+
+extern "C" int fg_viewmat_bwd(int N, int raw, const float* means, const float* quats, const float* d_quats,
+                              const float* scales, const float* d_scales, const float* opacities, const float* colors,
+                              const float* features_rest, int sh_degree, int k_stored, int n_color, int with_depth,
+                              int n_extra, const float* viewmat, const float* K, int width, int height, float eps2d,
+                              int antialiased, const int32_t* radii, const float* v_splats, const float* v_means2d,
+                              int v_means2d_stride, const float* v_depths, const float* v_conics, const float* sh_jac,
+                              float* out, void* workspace, size_t workspace_bytes, fg_stream_t stream) {
+  FeatLayout fl{sh_degree, k_stored, sh_degree >= 0 ? 3 : n_color, with_depth ? 1 : 0, n_extra};
+  if (N < 0 || width <= 0 || height <= 0 || !layout_ok(fl) || v_means2d_stride < 2 || !out) return FG_ERR_INVALID_ARG;
+  hipStream_t s = fg_hip_stream(stream);
+  if (N == 0) {
+    if (hipMemsetAsync(out, 0, 19 * sizeof(float), s) != hipSuccess) return FG_ERR_LAUNCH;
+    return FG_OK;
+  }
+  if (!means || !quats || !scales || !opacities || !viewmat || !K || !radii || !v_splats || !v_means2d || !workspace)
+    return FG_ERR_INVALID_ARG;
+  if (raw && (sh_degree < 0 || (k_stored > 1 && !features_rest))) return FG_ERR_INVALID_ARG;
+  if (sh_degree >= 1 && !sh_jac && !colors) return FG_ERR_INVALID_ARG;
+  if (workspace_bytes < fg_viewmat_bwd_workspace_bytes(N)) return FG_ERR_WORKSPACE;
+  const int grid = viewmat_grid(N);
+  hipLaunchKernelGGL(viewmat_bwd_kernel, dim3(grid), dim3(VM_BLOCK), 0, s, N, fl,
+                     RawForm{raw ? 1 : 0, raw ? d_quats : nullptr, raw ? d_scales : nullptr, raw ? features_rest : nullptr},
+                     means, quats, scales, opacities, colors, viewmat, K, width, height, eps2d, antialiased, radii, v_splats,
+                     v_means2d, v_means2d_stride, v_depths, v_conics, sh_degree >= 1 ? sh_jac : nullptr,
+                     static_cast<float*>(workspace));
+  hipLaunchKernelGGL(viewmat_sum_kernel, dim3(1), dim3(256), 0, s, static_cast<const float*>(workspace), grid, out);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -132,14 +132,13 @@ __device__ __forceinline__ Fwd project_core(const Cam& cam, float mx, float my, 
   return f;
 }
 
-// Backward of project_core for one visible Gaussian.  Inputs: gradients w.r.t. means2d (vmx,vmy),
-// depth (vdepth), the three conic values (vca,vcb,vcc) and the compensation (vcomp, used when
-// with_comp).  Outputs are ADDED into g_m[3], g_q[4], g_s[3].
-__device__ __forceinline__ void project_backward(const Cam& cam, const Fwd& f, const float (&s)[3], float eps2d,
-                                                 float vmx, float vmy, float vdepth, float vca, float vcb_full,
-                                                 float vcc, bool with_comp, float vcomp, float (&g_m)[3],
-                                                 float (&g_q)[4], float (&g_s)[3]) {
-  const float(&W)[3][3] = cam.W;
+// Backward of project_core for one visible Gaussian, first half: from the gradients w.r.t. means2d (vmx, vmy), depth
+// (vdepth), the three conic values (vca, vcb_full, vcc) and the compensation (vcomp, used when with_comp) to the gradients
+// w.r.t. the CAMERA-space mean (vp) and covariance (vCC, symmetric).  Everything in front of the world->camera transform:
+// shared by the parameter gradients (project_backward) and the camera-pose gradient (viewmat.hip).
+__device__ __forceinline__ void project_backward_camera(const Cam& cam, const Fwd& f, float eps2d, float vmx, float vmy,
+                                                        float vdepth, float vca, float vcb_full, float vcc, bool with_comp,
+                                                        float vcomp, float (&vp)[3], float (&vCC)[3][3]) {
   {
     // conic = inverse(blurred cov2d):  G_cov = -Q G_Q Q  with G_Q = [[va, vb/2],[vb/2, vc]]
     const float va = vca, vb = 0.5f * vcb_full, vc = vcc;
@@ -164,7 +163,6 @@ __device__ __forceinline__ void project_backward(const Cam& cam, const Fwd& f, c
     }
     // cov2d = J CC J^T with J = [[ja,0,jb],[0,jc,jd]]
     // v_CC = J^T G J
-    float vCC[3][3];
     {
       const float J[2][3] = {{f.ja, 0.f, f.jb}, {0.f, f.jc, f.jd}};
       const float G[2][2] = {{g00, g01}, {g01, g11}};
@@ -196,7 +194,7 @@ __device__ __forceinline__ void project_backward(const Cam& cam, const Fwd& f, c
       }
     }
     // camera-space mean gradient
-        float vpx = cam.fx * f.rz * vmx;
+    float vpx = cam.fx * f.rz * vmx;
     float vpy = cam.fy * f.rz * vmy;
     float vpz = -(cam.fx * f.px * vmx + cam.fy * f.py * vmy) * f.rz2 + vdepth;
     // through J: ja = fx rz; jc = fy rz; jb = -fx cl_x rz; jd = -fy cl_y rz (cl = clamp(p/z))
@@ -209,6 +207,22 @@ __device__ __forceinline__ void project_backward(const Cam& cam, const Fwd& f, c
       vpy += -cam.fy * f.rz2 * myf * vJ[1][2];
       vpz += cam.fy * f.rz2 * (cly + myf * f.py * f.rz) * vJ[1][2];
     }
+    vp[0] = vpx; vp[1] = vpy; vp[2] = vpz;
+  }
+}
+
+// Backward of project_core for one visible Gaussian.  Inputs: gradients w.r.t. means2d (vmx,vmy),
+// depth (vdepth), the three conic values (vca,vcb,vcc) and the compensation (vcomp, used when
+// with_comp).  Outputs are ADDED into g_m[3], g_q[4], g_s[3].
+__device__ __forceinline__ void project_backward(const Cam& cam, const Fwd& f, const float (&s)[3], float eps2d,
+                                                 float vmx, float vmy, float vdepth, float vca, float vcb_full,
+                                                 float vcc, bool with_comp, float vcomp, float (&g_m)[3],
+                                                 float (&g_q)[4], float (&g_s)[3]) {
+  const float(&W)[3][3] = cam.W;
+  {
+    float vp[3], vCC[3][3];
+    project_backward_camera(cam, f, eps2d, vmx, vmy, vdepth, vca, vcb_full, vcc, with_comp, vcomp, vp, vCC);
+    const float vpx = vp[0], vpy = vp[1], vpz = vp[2];
     // world mean: p = W m + t
 #pragma unroll
     for (int j = 0; j < 3; ++j) g_m[j] += W[0][j] * vpx + W[1][j] * vpy + W[2][j] * vpz;

@@ -185,6 +185,14 @@ __device__ __forceinline__ void marks_to_counts(int32_t* gt, int ntr, int tile_w
 template <typename F>
 __device__ __forceinline__ void for_bit_runs(uint32_t bits, F f) {
   bits &= 0xFFu;
+  if (bits == 0u) return;
+  {  // one run -- what a convex footprint gives in every row -- without the loop
+    const int s = __builtin_ctz(bits), e = 32 - __builtin_clz(bits);
+    if (bits == (((1u << (e - s)) - 1u) << s)) {
+      f(s, e);
+      return;
+    }
+  }
   while (bits) {
     const int s = __builtin_ctz(bits);
     const int len = __builtin_ctz(~(bits >> s));

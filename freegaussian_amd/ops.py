@@ -1124,6 +1124,31 @@ def _wait_ready(t: torch.Tensor) -> None:
         torch.cuda.current_stream().wait_event(ev)
 
 
+def _viewmat_grad(raw, means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, sh_degree, k_stored, n_color,
+                  with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d, m2_stride,
+                  v_depths, v_conics, sh_jac):  # fmt: skip
+    """dL/d viewmat [4,4] of a view (fg_viewmat_bwd) from the cotangents of its per-Gaussian backward: the direct paths
+    through the camera-space mean and covariance, plus the pull-back of dL/d campos -- the SH view direction's share --
+    through campos = inverse(viewmat)[:3, 3] (torch, a 4 x 4 matter), as gsplat's autograd routes it."""
+    lib = _lib.load()
+    N, dev = means.shape[0], means.device
+    out = torch.empty(19, dtype=torch.float32, device=dev)
+    ws = torch.empty(max(int(lib.fg_viewmat_bwd_workspace_bytes(N)), 16), dtype=torch.uint8, device=dev)
+    _call("fg_viewmat_bwd", N, int(raw), _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(scales), _ptr(d_scales), _ptr(opacities),
+          _ptr(colors), _ptr(features_rest), int(sh_degree), int(k_stored), int(n_color), int(with_depth), int(n_extra),
+          _ptr(viewmat), _ptr(K), int(width), int(height), float(eps2d), int(antialiased), _ptr(radii), _ptr(v_splats),
+          _ptr(v_means2d), int(m2_stride), _ptr(v_depths), _ptr(v_conics), _ptr(sh_jac), _ptr(out), _ptr(ws), ws.numel(),
+          _stream())  # fmt: skip
+    v = out[:16].view(4, 4)
+    if sh_degree >= 1:
+        with torch.enable_grad():
+            vm = viewmat.detach().clone().requires_grad_(True)
+            campos = torch.linalg.inv(vm)[:3, 3]
+            (pull,) = torch.autograd.grad(campos, vm, out[16:19])
+        v = v + pull
+    return v
+
+
 class _Preprocess(torch.autograd.Function):
     @staticmethod
     def forward(ctx, means, quats, scales, opacities, colors, extra, viewmat, K, cfg):
@@ -1208,6 +1233,16 @@ class _Preprocess(torch.autograd.Function):
             m2_stride = v_means2d.stride(0)
         else:
             v_means2d, m2_stride = v_means2d.contiguous(), 2
+        v_splats = v_splats.contiguous()
+
+        def pose_grad():  # (the camera pose requires a gradient: a pass of its own over the same cotangents)
+            if not ctx.needs_input_grad[6]:
+                return None
+            return _viewmat_grad(False, means, quats, None, scales, None, opacities, colors, None, sh_degree, k_stored, n_color,
+                                 with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii, v_splats, v_means2d,
+                                 m2_stride, None if v_depths is None else v_depths.contiguous(),
+                                 None if v_conics is None else v_conics.contiguous(), sh_jac)  # fmt: skip
+
         color_grad_sink = ctx.rctx.color_grad_sink
         if color_grad_sink is not None and sh_degree >= 0 and colors is not None:
             # factored form: 12 B of colour gradient per Gaussian instead of the 192-B coefficient row
@@ -1220,7 +1255,7 @@ class _Preprocess(torch.autograd.Function):
                   _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _ptr(sh_jac),
                   _stream())  # fmt: skip
             color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, colors)
-            return v_means, v_quats, v_scales, v_opac, None, v_extra, None, None, None
+            return v_means, v_quats, v_scales, v_opac, None, v_extra, pose_grad(), None, None
         v_colors = _alloc_grad(colors) if colors is not None else None
         _call("fg_preprocess_bwd", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities), _ptr(colors),
               sh_degree, k_stored, n_color, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height, eps2d,
@@ -1228,7 +1263,7 @@ class _Preprocess(torch.autograd.Function):
               _ptr(None if v_depths is None else v_depths.contiguous()),
               _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
               _ptr(v_scales), _ptr(v_opac), _ptr(v_colors), _ptr(v_extra), _ptr(sh_jac), _stream())  # fmt: skip
-        return v_means, v_quats, v_scales, v_opac, v_colors, v_extra, None, None, None
+        return v_means, v_quats, v_scales, v_opac, v_colors, v_extra, pose_grad(), None, None
 
 
 def preprocess(means, quats, scales, opacities, colors, extra, viewmat, K, width, height, eps2d=0.3,
@@ -1317,6 +1352,16 @@ class _PreprocessRaw(torch.autograd.Function):
             m2_stride = v_means2d.stride(0)
         else:
             v_means2d, m2_stride = v_means2d.contiguous(), 2
+        v_splats = v_splats.contiguous()
+
+        def pose_grad():
+            if not ctx.needs_input_grad[9]:
+                return None
+            return _viewmat_grad(True, means, quats, d_quats, log_scales, d_scales, opacity_logits, features_dc, features_rest,
+                                 sh_degree, k_stored, 3, with_depth, n_extra, viewmat, K, width, height, eps2d, antialiased, radii,
+                                 v_splats, v_means2d, m2_stride, None if v_depths is None else v_depths.contiguous(),
+                                 None if v_conics is None else v_conics.contiguous(), sh_jac)  # fmt: skip
+
         color_grad_sink = ctx.rctx.color_grad_sink
         if color_grad_sink is not None:
             # factored form (viewdp.ModelViewDP): 12 / 24 B of colour gradient per Gaussian instead of the two coefficient
@@ -1331,7 +1376,7 @@ class _PreprocessRaw(torch.autograd.Function):
                   _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _ptr(sh_jac),
                   _stream())  # fmt: skip
             color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, k_stored)
-            return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, None, None, v_extra, None, None, None
+            return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, None, None, v_extra, pose_grad(), None, None
         v_dc, v_rest = _alloc_grad(features_dc), _alloc_grad(features_rest)
         _call("fg_preprocess_raw_bwd", N, _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(log_scales), _ptr(d_scales),
               _ptr(opacity_logits), _ptr(features_dc), _ptr(features_rest), sh_degree, k_stored, int(with_depth),
@@ -1341,7 +1386,7 @@ class _PreprocessRaw(torch.autograd.Function):
               _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats), _ptr(v_dq),
               _ptr(v_ls), _ptr(v_ds), _ptr(v_ol), _ptr(v_dc), _ptr(v_rest), _ptr(v_extra), _ptr(sh_jac),
               _stream())  # fmt: skip
-        return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, v_dc, v_rest, v_extra, None, None, None
+        return v_means, v_quats, v_dq, v_ls, v_ds, v_ol, v_dc, v_rest, v_extra, pose_grad(), None, None
 
 
 def preprocess_raw(means, quats, log_scales, opacity_logits, features_dc, features_rest, viewmat, K, width, height,
@@ -1708,6 +1753,23 @@ class _RasterStep(torch.autograd.Function):
             io.ev_raster_begin, io.ev_raster_end = StageTimer.handles(ev)
         _lib.check(_lib.load().fg_step_bwd(ctypes.addressof(d), cfgp, ctypes.addressof(io), keep.data_ptr(),
                                            ctypes.addressof(L), _stream()), "fg_step_bwd")  # fmt: skip
+        v_viewmat = None
+        if ctx.needs_input_grad[9]:  # the camera pose requires a gradient: a pass of its own over the same cotangents
+            SBF = _lib.STEP_BUFFER
+
+            def kept(name, dtype, shape):  # a buffer of the kept workspace (None: the step has none)
+                i = SBF[name]
+                if L.nbytes[i] == 0:
+                    return None
+                base = keep if dtype is torch.float32 else keep.view(torch.int32)
+                return torch.as_strided(base, shape, (shape[1], 1) if len(shape) == 2 else (1,), L.offset[i] >> 2)
+
+            k_stored = (1 + features_rest.shape[1]) if raw else (colors.shape[1] if sh_degree >= 0 else 0)
+            n_color = 3 if (raw or sh_degree >= 0) else (0 if colors is None else colors.shape[1])
+            v_viewmat = _viewmat_grad(raw, means, quats, d_quats, scales, d_scales, opacities, colors, features_rest, sh_degree,
+                                      k_stored, n_color, d.with_depth, d.n_extra, viewmat, K, d.width, d.height, d.eps2d,
+                                      d.antialiased, kept("radii", torch.int32, (N,)), v_splats, v_splats, SPLAT_FLOATS,
+                                      keepalive[2], keepalive[3], kept("sh_jac", torch.float32, (N, _lib.SH_JAC_FLOATS)))  # fmt: skip
         if m2 is not None:
             # info["means2d"]: .grad as if it had been retain_grad()'ed on the way to the compositing, .absgrad beside it
             # (reference freegaussian_model.py:869-872, :377); strided views of the record gradients, no copy
@@ -1716,7 +1778,7 @@ class _RasterStep(torch.autograd.Function):
                 m2.grad = earlier_m2_grad + m2.grad
             if absgrad:
                 m2.absgrad = v_splats[:, 6:8].view(m2.shape)
-        return v_means, v_quats, v_dq, v_scales, v_ds, v_opac, v_colors, v_rest, v_extra, None, None, None, None
+        return v_means, v_quats, v_dq, v_scales, v_ds, v_opac, v_colors, v_rest, v_extra, v_viewmat, None, None, None
 
 
 def raster_step(means, quats, scales, opacities, colors, viewmat, K, width, height, *, raw=False, d_quats=None, d_scales=None,
@@ -1731,7 +1793,7 @@ def raster_step(means, quats, scales, opacities, colors, viewmat, K, width, heig
     if f[5].dim() != 1:
         f[5] = f[5].reshape(-1)
     bg = None if background is None else background.detach().to(device=f[0].device, dtype=torch.float32).contiguous()
-    want_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in f[:9])
+    want_backward = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in f[:10])  # (f[9]: the pose)
     opts = (bool(raw), int(width), int(height), float(eps2d), float(near_plane), float(far_plane), float(radius_clip),
             bool(antialiased), int(sh_degree), bool(with_depth), int(n_clamp), bool(absgrad), bool(want_backward),
             bool(batched))  # fmt: skip

@@ -117,14 +117,20 @@ def _empty_result(means, width, height, tile_size, render_mode, sh_degree, color
     return means.new_zeros(1, height, width, C), means.new_zeros(1, height, width, 1), info
 
 
-def _refuse_camera_gradients(viewmats: torch.Tensor, Ks: torch.Tensor) -> None:
-    """The raster path returns no gradient for the camera: say so instead of handing back a silent zero.  The reference
-    keeps a ``CameraOptimizer`` in the loop (freegaussian_model.py:120: ``camera_optimizer`` mode "off" in every shipped
-    config; applied at :774) -- with a mode other than "off" ``viewmats`` requires a gradient and ends up here."""
-    if torch.is_grad_enabled() and (viewmats.requires_grad or Ks.requires_grad):
+def _refuse_camera_gradients(viewmats: torch.Tensor, Ks: torch.Tensor, fused: bool = True) -> None:
+    """What the raster path does NOT differentiate, said out loud instead of handed back as a silent zero.  The camera
+    POSE is differentiable on the fused path (``fg_viewmat_bwd``: the reference keeps a ``CameraOptimizer`` in the loop,
+    freegaussian_model.py:120 -- mode "off" in every shipped config --, applied at :774; with another mode ``viewmats``
+    requires a gradient); the intrinsics never are, and the stage-by-stage operators (``fused=False``) have no pose
+    gradient either."""
+    if not torch.is_grad_enabled():
+        return
+    if Ks.requires_grad:
+        raise NotImplementedError("Ks requires a gradient: the raster path does not differentiate the intrinsics; detach() them")
+    if viewmats.requires_grad and not fused:
         raise NotImplementedError(
-            "viewmats / Ks require a gradient: camera-pose gradients (camera_optimizer mode != 'off', "
-            "freegaussian_model.py:120,774) are not produced by this raster path; detach() the camera")
+            "viewmats requires a gradient: camera-pose gradients (camera_optimizer mode != 'off', "
+            "freegaussian_model.py:120,774) come from the fused path only; call with fused=True or detach() the camera")
 
 
 def rasterization(
@@ -172,7 +178,7 @@ def rasterization(
         raise NotImplementedError("sparse_grad=True is never used by the reference (freegaussian_model.py:863)")
     if viewmats.dim() != 3 or viewmats.shape[0] != 1 or Ks.shape[0] != 1:
         raise ValueError("exactly one camera per call (reference asserts camera.shape[0]==1)")
-    _refuse_camera_gradients(viewmats, Ks)
+    _refuse_camera_gradients(viewmats, Ks, fused and not ops.current().overlap_pack)
     N = means.shape[0]
     if not (means.shape == (N, 3) and quats.shape == (N, 4) and scales.shape == (N, 3) and opacities.shape == (N,)):
         raise ValueError("means[N,3] quats[N,4] scales[N,3] opacities[N] expected")

@@ -418,6 +418,27 @@ int fg_preprocess_fwd(int N, const float* means, const float* quats, const float
                       int antialiased, int32_t* radii, float* means2d, float* depths, float* conics,
                       float* compensations, int32_t* tiles_touched, float* splats,
                       uint32_t* depth_keys, int32_t* tile_rects, uint64_t* tile_masks, float* sh_jac, fg_stream_t stream);
+/* Camera-pose gradient (ABI 8): dL/d viewmat of the view from the SAME cotangents fg_preprocess_bwd /
+ * fg_preprocess_raw_bwd consume -- v_splats (the raster backward's record gradients), v_means2d (+ stride), v_depths,
+ * v_conics (nullable) -- for a host whose camera pose requires a gradient (the reference's CameraOptimizer,
+ * freegaussian_model.py:120: "off" in every shipped config, applied at :774; gsplat returns v_viewmats from its projection
+ * backward and lets autograd carry the SH colour's share through dirs = means - inverse(viewmats)[:3, 3]).  raw != 0: the
+ * parameter forms of fg_preprocess_raw_fwd (quats + d_quats, log-scales + d_scales, opacity logits, colors = features_dc,
+ * features_rest); raw == 0: those of fg_preprocess_fwd (d_quats, d_scales, features_rest ignored).  sh_jac: the forward's
+ * note (nullable: the coefficient rows are read instead).
+ * out[19] f32: out[0..15] = dL/d viewmat, row-major 4 x 4 (through the camera-space mean p = W m + t and covariance
+ * W C W^T; last row 0), out[16..18] = dL/d campos, the gradient w.r.t. the camera POSITION -W^-1 t that the SH view
+ * direction is taken from -- the host adds its pull-back through the matrix inverse (d(A^-1) = -A^-1 dA A^-1) to out[0..15].
+ * Deterministic (per-workgroup partial sums in `workspace`, summed in a fixed order).  A pass of its own, ~the cost of the
+ * projection backward: the per-Gaussian backward is unchanged when the pose needs no gradient. */
+size_t fg_viewmat_bwd_workspace_bytes(int N);
+int fg_viewmat_bwd(int N, int raw, const float* means, const float* quats, const float* d_quats, const float* scales,
+                   const float* d_scales, const float* opacities, const float* colors, const float* features_rest,
+                   int sh_degree, int k_stored, int n_color, int with_depth, int n_extra, const float* viewmat,
+                   const float* K, int width, int height, float eps2d, int antialiased, const int32_t* radii,
+                   const float* v_splats, const float* v_means2d, int v_means2d_stride, const float* v_depths,
+                   const float* v_conics, const float* sh_jac, float* out, void* workspace, size_t workspace_bytes,
+                   fg_stream_t stream);
 /* The colour + record half of fg_preprocess_fwd on its own: inputs are the projection outputs of
  * fg_project_fwd (radii, means2d, depths, conics; compensations when antialiased).  Splitting the
  * forward this way lets a host run this HBM-bound half on a second stream while the
