@@ -713,9 +713,16 @@ def main(argv=None):
     redos = ops.default_context.capacity_redos - redo0
     t = torch.tensor([dt_local], device=dev, dtype=torch.float64)
     per_rank = [t.clone() for _ in range(world)]
+    rank_devices = None
     if world > 1:
         dist.all_gather(per_rank, t)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        # which physical device every rank ran on (a SCALE record then shows that RCCL saw `world` distinct GPUs)
+        props = torch.cuda.get_device_properties(dev)
+        mine = {"rank": rank, "local_device": dev.index, "uuid": str(getattr(props, "uuid", "")),
+                "pci_bus_id": getattr(props, "pci_bus_id", None), "name": props.name}
+        rank_devices = [None] * world
+        dist.all_gather_object(rank_devices, mine)
     dt = float(t.item())
 
     N = args.n_gauss
@@ -914,6 +921,8 @@ def main(argv=None):
             "fallback": fallback_note,
         }  # fmt: skip
         out["per_rank_mpix_per_s"] = [args.steps * P / float(x.item()) / 1e6 for x in per_rank]
+        out["per_rank_device"] = rank_devices
+        out["distinct_devices"] = len({(d or {}).get("uuid") or (d or {}).get("local_device") for d in rank_devices or []})
     if rank == 0:
         out["clocks_after_timed_region"] = gpu_clocks()
     if graphed is not None:

@@ -82,6 +82,8 @@ SIGNATURES = {
     "fg_preprocess_bwd_factored": (c_int, [c_int, P, P, P, P, P, c_int, c_int, c_int, c_int, P, P, c_int, c_int,
                                            c_float, c_int, P, P, P, c_int, P, P, P, P, P, P, P, c_int, P, P, P]),
     "fg_sh_grad_accumulate": (c_int, [c_int, c_int, c_int, c_int, P, P, c_int64, c_int, c_float, P, P]),
+    "fg_payload_compact": (c_int, [c_int, c_int, P, P, c_int64, P, P]),
+    "fg_payload_expand": (c_int, [c_int, c_int, c_int, P, c_int64, c_int64, P, c_int64, P]),
     "fg_step_layout_query": (c_int, [P, P, P]),
     "fg_step_fwd": (c_int, [P, P, P, P, P, P, P]),
     "fg_step_bwd": (c_int, [P, P, P, P, P, P]),

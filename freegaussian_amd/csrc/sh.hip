@@ -198,6 +198,74 @@ int sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const fl
 }
 }  // namespace
 
+// ---- view-DP exchange, sparse payload (round 5) ----------------------------------------------------------------------
+// Only Gaussians that took part in a pixel of the view carry a colour gradient: on a captured scene under a real frustum that
+// is a fraction of N (and 0.5-0.6 N even on the bench's everything-in-view cube).  The all-gathered block of a rank can then
+// be [header: count, camera position | capacity rows of (id, g[3] (, direction[3]))] instead of N dense rows; every rank
+// EXPANDS the gathered blocks into dense ones locally (HBM traffic, not link traffic) and rebuilds as before.
+// compact: rows with a non-zero g, in id order (incl = the inclusive scan of the row flags: row i goes to slot
+// incl[i] - 1); rows beyond `capacity` are dropped -- the header's count says so (count > capacity: the receiver must
+// not use the block).  out: [4 + capacity * (1 + payload_floats)] floats; out[0] = count (as int bits), out[1..3] are
+// the caller's (camera position).
+namespace {
+__global__ void __launch_bounds__(256)
+payload_compact_kernel(int N, int pf, const float* __restrict__ dense, const int32_t* __restrict__ incl, int64_t capacity,
+                       float* __restrict__ out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N) return;
+  const int here = incl[i], before = i > 0 ? incl[i - 1] : 0;
+  if (i == N - 1) out[0] = __int_as_float(here);
+  if (here == before || (int64_t)here > capacity) return;
+  float* row = out + 4 + (size_t)(here - 1) * (1 + pf);
+  row[0] = __int_as_float(i);
+  for (int c = 0; c < pf; ++c) row[1 + c] = dense[(size_t)i * pf + c];
+}
+// expand: n_views compact blocks (block_stride floats apart) -> n_views dense blocks of dense_stride floats, laid out as
+// fg_sh_grad_accumulate reads them (payload_floats 3: [g (3N) | camera position (3)]; 6: N rows of [g | direction]).  The
+// dense blocks must be ZERO on entry (rows without an entry stay zero = "no gradient in that view").
+__global__ void __launch_bounds__(256)
+payload_expand_kernel(int N, int pf, int n_views, const float* __restrict__ compact, int64_t block_stride, int64_t capacity,
+                      float* __restrict__ dense, int64_t dense_stride) {
+  const int v = blockIdx.y;
+  const float* blk = compact + (size_t)v * block_stride;
+  float* out = dense + (size_t)v * dense_stride;
+  const int64_t count = min((int64_t)__float_as_int(blk[0]), capacity);
+  if (pf == 3 && blockIdx.x == 0 && threadIdx.x < 3) out[(size_t)3 * N + threadIdx.x] = blk[1 + threadIdx.x];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < count; e += (int64_t)gridDim.x * 256) {
+    const float* row = blk + 4 + (size_t)e * (1 + pf);
+    const int id = __float_as_int(row[0]);
+    if (id < 0 || id >= N) continue;
+    for (int c = 0; c < pf; ++c) out[(size_t)id * pf + c] = row[1 + c];
+  }
+}
+}  // namespace
+
+extern "C" int fg_payload_compact(int N, int payload_floats, const float* dense, const int32_t* incl_scan, int64_t capacity,
+                                  float* out, fg_stream_t stream) {
+  if (N < 0 || capacity < 0 || (payload_floats != 3 && payload_floats != 6)) return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!dense || !incl_scan || !out) return FG_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(payload_compact_kernel, dim3((N + 255) / 256), dim3(256), 0, fg_hip_stream(stream), N, payload_floats, dense,
+                     incl_scan, capacity, out);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
+extern "C" int fg_payload_expand(int N, int payload_floats, int n_views, const float* compact, int64_t block_stride,
+                                 int64_t capacity, float* dense, int64_t dense_stride, fg_stream_t stream) {
+  if (N < 0 || n_views < 1 || capacity < 0 || (payload_floats != 3 && payload_floats != 6) ||
+      block_stride < 4 + capacity * (1 + payload_floats) ||
+      dense_stride < (payload_floats == 3 ? (int64_t)3 * N + 3 : (int64_t)6 * N))
+    return FG_ERR_INVALID_ARG;
+  if (N == 0) return FG_OK;
+  if (!compact || !dense) return FG_ERR_INVALID_ARG;
+  const int64_t blocks = (capacity + 255) / 256;
+  hipLaunchKernelGGL(payload_expand_kernel, dim3((unsigned)(blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks)), n_views), dim3(256), 0,
+                     fg_hip_stream(stream), N, payload_floats, n_views, compact, block_stride, capacity, dense, dense_stride);
+  FG_RETURN_IF_LAUNCH_FAILED();
+  return FG_OK;
+}
+
 extern "C" int fg_sh_grad_accumulate(int N, int n_views, int sh_degree, int k_stored, const float* means,
                                      const float* payload, int64_t view_stride, int payload_floats, float scale,
                                      float* v_coeffs, fg_stream_t stream) {

@@ -307,11 +307,24 @@ class ModelViewDP:
 
     COLOUR = ("features_dc", "features_rest")
 
-    def __init__(self, model: torch.nn.Module, average: bool = True, group=None):
+    def __init__(self, model: torch.nn.Module, average: bool = True, group=None, sparse: Optional[str] = None):
+        """``sparse`` (default: FG_DP_SPARSE, else "auto"): the gathered block of a rank holds only the Gaussians whose
+        colour gradient is non-zero in its view -- [count, camera position | rows of (id, g (, direction))] at a capacity
+        of 1.25 x the largest count any rank reported in the PREVIOUS step -- whenever that is at most 85 % of the dense
+        block ("auto"), always, or never.  A count beyond the capacity is seen by every rank in the gathered headers and
+        the step's gather is repeated densely; every rank expands the blocks locally (fg_payload_expand) and rebuilds as
+        from dense ones: same gradients, bit for bit."""
+        import os
+
         self.model, self.average, self.group = model, average, group
         self._flat: Optional[torch.Tensor] = None
         self._layout = None  # [(param, offset, numel)] of the flat buffer; the key it was built for
         self.bytes_last_step: Dict[str, int] = {}
+        self.sparse = sparse if sparse is not None else os.environ.get("FG_DP_SPARSE", "auto")
+        if self.sparse not in ("auto", "always", "never"):
+            raise ValueError(f"sparse={self.sparse!r}: auto | always | never")
+        self._sparse_plan = None  # (rows per rank, payload floats per row, N) of the next step's sparse blocks
+        self.sparse_steps = self.dense_steps = self.sparse_overflows = 0
 
     def _others(self):
         gp = getattr(self.model, "gauss_params", {})
@@ -348,30 +361,54 @@ class ModelViewDP:
         n = gp["means"].shape[0]
         state: Dict[str, object] = {}
 
+        def gather(payload):
+            if world > 1:
+                gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=torch.float32)
+                if dist.get_backend(group) == "nccl":
+                    work = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
+                else:
+                    work = dist.all_gather(list(gathered.view(world, -1).unbind(0)), payload, group=group, async_op=True)
+                return gathered, work
+            return payload, None
+
+        def dense_payload():
+            """[g (pf N) (| camera position (3))| count] -- the count rides behind the block fg_sh_grad_accumulate reads"""
+            pf, payload = state["pf"], state["payload"]  # (g is a view of its head: the backward wrote it in place)
+            if pf == 3:
+                payload[3 * n : 3 * n + 3] = state["campos"]
+            payload[-1:].view(torch.int32).copy_(state["count"])
+            return payload
+
         def sink(what, *a):
             if what == "alloc":
                 _n, dev, means = a
                 # deformed means: every rank renders its own positions, so the direction travels with the gradient
                 pf = 3 if means.data_ptr() == gp["means"].data_ptr() else 6
                 stride = n * 6 if pf == 6 else (n + 1) * 3
-                state.update(pf=pf, stride=stride, payload=torch.empty(stride, device=dev, dtype=torch.float32))
-                return state["payload"][: pf * n].view(n, pf)
+                payload = torch.empty(stride + 1, device=dev, dtype=torch.float32)
+                state.update(pf=pf, stride=stride, payload=payload, g=payload[: pf * n].view(n, pf))
+                return state["g"]
             if what == "ready":
                 _v_rgb, _means, viewmat, sh_degree, k_stored = a
                 state.update(sh_degree=int(sh_degree), k_stored=int(k_stored))
-                payload = state["payload"]
-                if state["pf"] == 3:
-                    vm = viewmat.reshape(-1, 4)[:3]
-                    payload[3 * n :] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view
-                if world > 1:  # issued from inside the backward: the MLPs' backward runs under it
-                    gathered = torch.empty(world * state["stride"], device=payload.device, dtype=torch.float32)
-                    if dist.get_backend(group) == "nccl":
-                        state["work"] = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
-                    else:
-                        state["work"] = dist.all_gather(list(gathered.view(world, -1).unbind(0)), payload, group=group, async_op=True)
-                    state["gathered"] = gathered
+                pf, g = state["pf"], state["g"]
+                vm = viewmat.reshape(-1, 4)[:3]
+                state["campos"] = -(vm[:, :3].T @ vm[:, 3])  # camera position of this rank's view (shared means)
+                # which Gaussians took part in a pixel of this view (a non-zero colour gradient), and how many
+                incl = torch.cumsum((g[:, :3] != 0).any(dim=1), 0, dtype=torch.int32)
+                state["count"] = incl[-1:]
+                plan = self._sparse_plan
+                if plan is not None and plan[1:] == (pf, n):  # issued from inside the backward: the MLPs' backward runs under it
+                    cap = plan[0]
+                    block = torch.empty(4 + cap * (1 + pf), device=g.device, dtype=torch.float32)
+                    _lib.check(_lib.load().fg_payload_compact(n, pf, g.data_ptr(), incl.data_ptr(), cap, block.data_ptr(),
+                                                              torch.cuda.current_stream().cuda_stream), "fg_payload_compact")  # fmt: skip
+                    block[1:4] = state["campos"]
+                    state.update(form="sparse", cap=cap)
+                    state["gathered"], state["work"] = gather(block)
                 else:
-                    state["gathered"] = payload
+                    state["form"] = "dense"
+                    state["gathered"], state["work"] = gather(dense_payload())
             return None  # ("view" / "records": nothing to do here)
 
         @contextlib.contextmanager
@@ -390,21 +427,51 @@ class ModelViewDP:
                 raise RuntimeError("ModelViewDP.step: no SH-coloured raster backward ran inside the context")
             flat = self._flat
             work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
-            if "work" in state:
+            if state["work"] is not None:
                 state["work"].wait()
+            pf, stride, lib = state["pf"], state["stride"], _lib.load()
+            stream = torch.cuda.current_stream().cuda_stream
+            blocks = state["gathered"].view(world, -1)
+            # every rank's count, from the gathered headers / trailers: the same numbers on every rank
+            counts = (blocks[:, 0] if state["form"] == "sparse" else blocks[:, -1]).contiguous().view(torch.int32).tolist()
+            received = (world - 1) * blocks.shape[1] * 4
+            if state["form"] == "sparse" and max(counts) > state["cap"]:
+                # a block was truncated: all ranks see it, all repeat this step's gather densely
+                self.sparse_overflows += 1
+                state["form"] = "dense"
+                state["gathered"], w2 = gather(dense_payload())
+                if w2 is not None:
+                    w2.wait()
+                blocks = state["gathered"].view(world, -1)
+                received += (world - 1) * blocks.shape[1] * 4
+            if state["form"] == "sparse":
+                self.sparse_steps += 1
+                dense = torch.zeros(world * stride, device=blocks.device, dtype=torch.float32)
+                _lib.check(lib.fg_payload_expand(n, pf, world, blocks.data_ptr(), blocks.shape[1], state["cap"], dense.data_ptr(),
+                                                 stride, stream), "fg_payload_expand")  # fmt: skip
+                src, src_stride = dense, stride
+            else:
+                self.dense_steps += 1
+                src, src_stride = blocks, blocks.shape[1]
             scale = 1.0 / world if self.average else 1.0
             v_dc, v_rest = torch.empty_like(gp["features_dc"]), torch.empty_like(gp["features_rest"])
-            _lib.check(_lib.load().fg_sh_grad_accumulate_split(
+            _lib.check(lib.fg_sh_grad_accumulate_split(
                 n, world, state["sh_degree"], state["k_stored"], gp["means"].detach().contiguous().data_ptr(),
-                state["gathered"].data_ptr(), state["stride"], state["pf"], scale, v_dc.data_ptr(), v_rest.data_ptr(),
-                torch.cuda.current_stream().cuda_stream), "fg_sh_grad_accumulate_split")  # fmt: skip
+                src.data_ptr(), src_stride, pf, scale, v_dc.data_ptr(), v_rest.data_ptr(), stream), "fg_sh_grad_accumulate_split")  # fmt: skip
             gp["features_dc"].grad, gp["features_rest"].grad = v_dc, v_rest
             if work is not None:
                 work.wait()
                 if self.average:
                     flat.div_(world)
-            self.bytes_last_step = {"all_gather_received": (world - 1) * state["stride"] * 4, "all_reduce": flat.numel() * 4,
-                                    "plain_all_reduce_would_be": (flat.numel() + v_dc.numel() + v_rest.numel()) * 4}
+            # the next step's form: sparse blocks at 1.25 x the largest count, if that is clearly smaller than dense ones
+            cap = int(max(counts) * 1.25) + 1024
+            sparse_floats, dense_floats = 4 + cap * (1 + pf), stride + 1
+            use = self.sparse == "always" or (self.sparse == "auto" and sparse_floats < 0.85 * dense_floats)
+            self._sparse_plan = (cap, pf, n) if use else None
+            self.bytes_last_step = {"all_gather_received": received, "all_reduce": flat.numel() * 4,
+                                    "plain_all_reduce_would_be": (flat.numel() + v_dc.numel() + v_rest.numel()) * 4,
+                                    "payload_form": state["form"], "rows_with_colour_gradient": counts, "gaussians": n,
+                                    "dense_block_bytes": dense_floats * 4, "sparse_block_bytes_at_these_counts": sparse_floats * 4}
 
         return cm()
 

@@ -537,6 +537,19 @@ int fg_preprocess_raw_bwd_factored(
 int fg_sh_grad_accumulate_split(int N, int n_views, int sh_degree, int k_stored, const float* means,
                                 const float* payload, int64_t view_stride, int payload_floats, float scale,
                                 float* v_features_dc, float* v_features_rest, fg_stream_t stream);
+/* Sparse payload of the factored view-DP exchange (ABI 8).  Only Gaussians that took part in a pixel of the view have a
+ * colour gradient; a rank's all-gathered block can be [count, camera position(3) | capacity rows of (id, g[3] (, unit
+ * direction[3]))] instead of N dense rows (the reference is single-GPU, scripts/run.sh:58: new capability).
+ * fg_payload_compact: the rows of dense[N, payload_floats] with a non-zero g, in id order -- incl_scan[N] (int32) is the
+ * inclusive scan of the caller's row flags, row i goes to slot incl_scan[i] - 1 --, into out[4 + capacity * (1 +
+ * payload_floats)]; out[0] = the count as int bits (rows beyond capacity are dropped: count > capacity tells the receiver
+ * not to use the block), out[1..3] are left to the caller.
+ * fg_payload_expand: n_views such blocks (block_stride floats apart) back into dense blocks of dense_stride floats laid out
+ * as fg_sh_grad_accumulate[_split] reads them; the dense blocks must be zero on entry. */
+int fg_payload_compact(int N, int payload_floats, const float* dense, const int32_t* incl_scan, int64_t capacity,
+                       float* out, fg_stream_t stream);
+int fg_payload_expand(int N, int payload_floats, int n_views, const float* compact, int64_t block_stride,
+                      int64_t capacity, float* dense, int64_t dense_stride, fg_stream_t stream);
 
 /* ---- One call per direction (ABI 7): the whole eager step of one view ------------------------------------------
  * fg_step_fwd = fg_preprocess_fwd (raw = 0) or fg_preprocess_raw_fwd (raw = 1) -> fg_stbin_count -> fg_stbin_fill_jobs ->

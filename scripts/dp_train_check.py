@@ -75,11 +75,27 @@ def grads_of_one_step(dp_obj, step):
 
 # the two exchanges on the same model state: same averaged gradients up to fp32 summation order
 probe_step = max(cfg.warm_up, 10)
-g_f, g_p = grads_of_one_step(viewdp.ModelViewDP(model), probe_step), grads_of_one_step(None, probe_step)
+dp_probe = viewdp.ModelViewDP(model)  # (FG_DP_SPARSE = auto | always | never: the gathered blocks' form)
+g_f, g_p = grads_of_one_step(dp_probe, probe_step), grads_of_one_step(None, probe_step)
 worst = max(float((g_f[k] - g_p[k]).norm() / g_p[k].norm().clamp_min(1e-30)) for k in g_p)
 if rank == 0:
     print(f"factored vs plain exchange, worst relative L2 over {len(g_p)} gradients: {worst:.2e}")
 assert set(g_f) == set(g_p) and worst < 1e-5, worst
+# the same step again: the first one's counts have decided the blocks' form (sparse: rows of (id, g (, direction)) at 1.25 x
+# the largest count) -- the SAME gradients bit for bit, the expansion is exact; then with a capacity that is far too small:
+# every rank sees the overflow in the gathered headers and the gather is repeated densely
+g_2 = grads_of_one_step(dp_probe, probe_step)
+assert all(torch.equal(g_2[k], g_f[k]) for k in g_f), "sparse blocks changed a gradient"
+form_2 = dp_probe.bytes_last_step["payload_form"]
+if dp_probe._sparse_plan is not None:
+    dp_probe._sparse_plan = (8,) + dp_probe._sparse_plan[1:]
+    g_3 = grads_of_one_step(dp_probe, probe_step)
+    assert dp_probe.sparse_overflows == 1 and all(torch.equal(g_3[k], g_f[k]) for k in g_f), "overflow path"
+if rank == 0:
+    print(f"second probe step: {form_2} blocks, {dp_probe.bytes_last_step['rows_with_colour_gradient']} rows of "
+          f"{dp_probe.bytes_last_step['gaussians']}; sparse steps {dp_probe.sparse_steps}, overflows {dp_probe.sparse_overflows}")
+if os.environ.get("FG_DP_SPARSE") == "always":
+    assert form_2 == "sparse" and dp_probe.sparse_steps >= 1
 for p in model.parameters():
     p.grad = None
 # FG_DP_EXCHANGE = factored (default: viewdp.ModelViewDP) | plain (one all-reduce of every gradient)
@@ -92,6 +108,7 @@ for i in range(25):
                               stats_sync=viewdp.sync_densify_stats))
 if rank == 0 and dp is not None:
     print("exchange bytes per rank in the last step:", dp.bytes_last_step)
+    print(f"steps with sparse / dense blocks: {dp.sparse_steps} / {dp.dense_steps}, overflows {dp.sparse_overflows}")
 torch.cuda.synchronize()
 sig = torch.cat([torch.tensor([float(model.num_points)], device=dev)] +
                 [p.detach().double().sum().float().reshape(1) for p in model.parameters()])

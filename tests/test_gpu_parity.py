@@ -2275,24 +2275,30 @@ def test_world_size_8_exchange_and_bench_launcher_over_gloo_on_one_gpu():
     assert "gloo" in line["exchange"]["backend"] and "gloo gradient exchange" in line["config"]["workload"]
 
 
-@pytest.mark.parametrize("world,exchange,warm_up", [(2, "factored", None), (2, "factored", 12), (2, "plain", None), (8, "factored", 12)])
-def test_view_dp_training_keeps_the_ranks_in_lockstep(world, exchange, warm_up):
+@pytest.mark.parametrize("world,exchange,warm_up,sparse", [(2, "factored", None, "never"), (2, "factored", 12, "never"),
+                                                          (2, "plain", None, "never"), (8, "factored", 12, "never"),
+                                                          (2, "factored", None, "always"), (2, "factored", 12, "always"),
+                                                          (8, "factored", 12, "always"), (2, "factored", 12, "auto")])
+def test_view_dp_training_keeps_the_ranks_in_lockstep(world, exchange, warm_up, sparse):
     """FreeGaussianModel trained view-sharded on 2 / 8 ranks sharing this GPU (gloo): the gradient exchange --
     viewdp.ModelViewDP's factored form (colour gradients all-gathered from inside the backward, the rest one all-reduce
     of a flat buffer; with the deformation MLP active the view directions travel along and the MLP gradients ride in
     the all-reduce) or the plain all-reduce --, the densification-statistics exchange and shared split samples keep the
     replicas bit-identical through refinements; the two exchanges give the same gradients on the same model state
-    (scripts/dp_train_check.py, child processes)."""
+    (scripts/dp_train_check.py, child processes).  ``sparse``: the gathered blocks hold only the Gaussians with a colour
+    gradient in the rank's view (round 5: fg_payload_compact / fg_payload_expand) -- bit-identical gradients, an overflowing
+    block detected by every rank and repeated densely."""
     import os
     import subprocess
     import sys
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, FG_BENCH_BACKEND="gloo", FG_DP_EXCHANGE=exchange)
+    env = dict(os.environ, FG_BENCH_BACKEND="gloo", FG_DP_EXCHANGE=exchange, FG_DP_SPARSE=sparse)
     if warm_up is not None:
         env["FG_DP_WARM_UP"] = str(warm_up)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr",
-           "127.0.0.1", "--master-port", str(29534 + world), os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
+           "127.0.0.1", "--master-port", str(29534 + world + 16 * ("never", "always", "auto").index(sparse)),
+           os.path.join(root, "scripts", "dp_train_check.py")]  # fmt: skip
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "dp lockstep ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
     assert "factored vs plain exchange" in out.stdout
