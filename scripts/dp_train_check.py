@@ -82,15 +82,22 @@ if rank == 0:
     print(f"factored vs plain exchange, worst relative L2 over {len(g_p)} gradients: {worst:.2e}")
 assert set(g_f) == set(g_p) and worst < 1e-5, worst
 # the same step again: the first one's counts have decided the blocks' form (sparse: rows of (id, g (, direction)) at 1.25 x
-# the largest count) -- the SAME gradients bit for bit, the expansion is exact; then with a capacity that is far too small:
-# every rank sees the overflow in the gathered headers and the gather is repeated densely
+# the largest count) -- the same gradients (the expansion is exact; two backward passes differ by the order of their float
+# atomics); then with a capacity that is far too small: every rank sees the overflow in the gathered headers and the gather
+# is repeated densely
+
+
+def same(a, b):
+    return max(float((a[k] - b[k]).norm() / b[k].norm().clamp_min(1e-30)) for k in b) < 1e-5
+
+
 g_2 = grads_of_one_step(dp_probe, probe_step)
-assert all(torch.equal(g_2[k], g_f[k]) for k in g_f), "sparse blocks changed a gradient"
+assert same(g_2, g_p), "sparse blocks changed a gradient"
 form_2 = dp_probe.bytes_last_step["payload_form"]
 if dp_probe._sparse_plan is not None:
     dp_probe._sparse_plan = (8,) + dp_probe._sparse_plan[1:]
     g_3 = grads_of_one_step(dp_probe, probe_step)
-    assert dp_probe.sparse_overflows == 1 and all(torch.equal(g_3[k], g_f[k]) for k in g_f), "overflow path"
+    assert dp_probe.sparse_overflows == 1 and same(g_3, g_p), "overflow path"
 if rank == 0:
     print(f"second probe step: {form_2} blocks, {dp_probe.bytes_last_step['rows_with_colour_gradient']} rows of "
           f"{dp_probe.bytes_last_step['gaussians']}; sparse steps {dp_probe.sparse_steps}, overflows {dp_probe.sparse_overflows}")
