@@ -171,7 +171,10 @@ struct JobBuild {
 };
 constexpr int FG_BAND_MAX_ROWS = 1024;
 #ifndef FG_BAND_COST_CAP4
-#define FG_BAND_COST_CAP4 10  // a tile's list length counts up to this many quarters of the mean (a longer list saturates)
+#define FG_BAND_COST_CAP4 12  // a tile's list length counts up to this many quarters of the mean (a longer list saturates)
+// (round 4: 10, tuned on lists that still held the entries the footprint masks drop since round 5 -- 12 % of a round splat's:
+// the mean fell, the saturated tiles' real cost did not; re-swept, profiles/r05_clustered_thresholds.md: 80 % of the
+// Gaussians in a ball of 0.2, backward 0.47 -> 0.36 ms)
 #endif
 
 // The eight XCDs' row bands by CONTENT: equal shares of the tiles' expected walking cost instead of equal numbers of

@@ -198,7 +198,10 @@ class RasterContext:
         self.heavy_tiles = e.get("FG_HEAVY_TILES", "auto")
         if self.heavy_tiles not in ("auto", "always", "never"):
             raise ValueError(f"FG_HEAVY_TILES={self.heavy_tiles!r}: auto | always | never")
-        self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "3072"))
+        # (2560 = the prefix the four strip jobs walk + 512: the smallest the library takes; round 4's 3072 was tuned on lists
+        # with the entries the footprint masks drop -- lists of 2900-3030 entries, just below it, had become the forward's
+        # longest jobs on the 80 % / 0.2 layout: 0.79 -> 0.69 ms, profiles/r05_clustered_thresholds.md)
+        self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "2560"))
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
         self.heavy_calls = 0  # raster steps planned with heavy tiles on
