@@ -547,13 +547,6 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if (!__any(open)) return;  // the prefix finished every pixel: its outputs stand
   }
   int batch = first;
-  // The ids of batch b + 1 are fetched while batch b is staged and walked (one register): a batch's staging was two
-  // DEPENDENT round trips -- the id, then the record it points to --, a third of the life of a strip job on a long list
-  // once its SIMD's other wavefronts have gone (104 of 315 us on a 1776-entry list, profiles/r05_job_timeline.md).  (The
-  // combine jobs move `batch` by their own rule and keep the plain loads.)
-  constexpr bool PREFETCH_IDS = (MODE == 0 || MODE == 3) && NW == 1;
-  int next_gid = 0;
-  if constexpr (PREFETCH_IDS) next_gid = first + (int)threadIdx.x < end ? flatten_ids[first + (int)threadIdx.x] : 0;
   while (batch < end) {
     uint64_t all_done = full;
 #pragma unroll
@@ -623,11 +616,10 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     const int idx = batch + (int)threadIdx.x;
     unsigned mask = 0;
     if (idx < end) {
-      const float4* rec = splats + (size_t)(PREFETCH_IDS ? next_gid : flatten_ids[idx]) * (FG_SPLAT_FLOATS / 4);
+      const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
       float4 v[NV];
 #pragma unroll
       for (int q = 0; q < NV; ++q) v[q] = rec[q];
-      if constexpr (PREFETCH_IDS) next_gid = idx + NT < end ? flatten_ids[idx + NT] : 0;  // (behind the record loads: in flight with them)
       mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
       // the forward only ever uses the conic inside the exponent: stage it pre-scaled
       v[0].w *= 0.5f * FG_NEG_LOG2E;
@@ -1160,8 +1152,6 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
 #pragma unroll
   for (int q = 0; q < 16; ++q) asm volatile("v_mov_b32 %0, 0" : "=v"(g[q]));
 
-  // (Fetching the id and the liveness word of batch b - 1 while batch b is walked -- what the forward does with its ids --
-  // costs this kernel two registers it does not have: 73 VGPRs + 16 bytes of scratch; not done.)
   for (int b = n_batches - 1; b >= 0; --b) {
     const int batch = __builtin_amdgcn_readfirstlane(lo + b * NT);  // (uniform; the list index of an entry is then scalar arithmetic)
     __syncthreads();
