@@ -547,6 +547,10 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if (!__any(open)) return;  // the prefix finished every pixel: its outputs stand
   }
   int batch = first;
+  // (Round 5, measured and dropped: the ids of batch b + 1 fetched while batch b is walked -- one register, 62 -> 64 VGPRs.  A
+  // batch's staging is two dependent round trips, the id, then the record: a third of a strip job's life on a long list once
+  // its SIMD's other wavefronts have gone.  Forward +-0 on the uniform scene and on half of the Gaussians in a ball, +8 us
+  // with 30 % needles: the exposed part is the record gather and the barrier, not the id.)
   while (batch < end) {
     uint64_t all_done = full;
 #pragma unroll
