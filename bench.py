@@ -860,7 +860,9 @@ def main(argv=None):
             "I_raster": I_raster,
             "I_note": "I = tile intersections of the reference algorithm (radius-box rectangles; the formulas of SURVEY "
             "section 8d use it); I_raster = entries of the lists actually binned and composited: the footprint rectangles "
-            "drop (splat, tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
+            "and, inside them, the footprint masks (the blocks of the rectangle the ellipse itself reaches) drop (splat, "
+            "tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
+            "footprint_masks": bool(ops.current().exact_tiles),
             "counts_are_for_view": view,
             "binning": {
                 "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 8-byte element per "
