@@ -78,7 +78,9 @@ __device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, fl
   const float t255 = 255.f * o, det = a * c - b * b;
   if (!(o == o) || !(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(t255 >= 1.f)) return all;  // (no culling possible: alpha_extent kinds 2 / 0)
   // tau2 = 2 ln(255 o), inflated by 0.1 % + 2e-3 (the pixel test's own rounding is ~1e-5 of it)
-  if (w == 1 && h == 1) return all;  // (the rectangle itself was tightened against the ellipse's extents)
+  // one tile wide or high: the rectangle was tightened against the ellipse's extents axis by axis, and a connected shape
+  // that reaches the first and the last tile of a row of tiles crosses the ones in between
+  if (w == 1 || h == 1) return all;
   // (hardware reciprocals, 1 ulp: the inflations below are thousands of ulps)
   const float tau2 = (1.3862943611f * __builtin_amdgcn_logf(t255)) * 1.001f + 2e-3f;
   const float rdet = __builtin_amdgcn_rcpf(det), ra = __builtin_amdgcn_rcpf(a);
