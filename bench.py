@@ -37,7 +37,7 @@ sys.path.insert(0, ROOT)
 # process can have touched the GPU.
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-PMC_FILES = ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
+PMC_FILES = ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json")  # newest first
 N_VIEWS = 8
 
 
@@ -232,7 +232,7 @@ def pmc_valu(stage, workload_key):
 
 def isa_class_mix(stage):
     """Instruction-class shares of `stage`'s kernel (profiles/rNN_isa_class_mix.json, scripts/isa_class_mix.py), or None."""
-    for fname in ("r04_isa_class_mix.json",):
+    for fname in ("r05_isa_class_mix.json", "r04_isa_class_mix.json"):
         path = os.path.join(ROOT, "profiles", fname)
         if os.path.exists(path):
             rec = json.load(open(path))
