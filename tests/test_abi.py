@@ -252,3 +252,42 @@ def test_ops_refuse_cpu_tensors():
     with pytest.raises(_lib.FgRasterError):
         rasterization(torch.zeros(N, 3), torch.ones(N, 4), torch.ones(N, 3), torch.ones(N), torch.ones(N, 3),
                       torch.eye(4)[None], torch.eye(3)[None], 32, 32, packed=False)  # fmt: skip
+
+
+def test_learned_launch_state_scales_with_the_gaussian_count_host_logic():
+    """ops.RasterContext keeps what a shape's calls taught it per (device, tile grid); quantities that grow with N are kept
+    with the N they were seen at and scaled by the ratio (the reference changes N every `refine_every` steps,
+    freegaussian_model.py:404-571).  Pure host logic: no GPU call."""
+    from freegaussian_amd import ops
+
+    ctx = ops.RasterContext(env={})
+    key = ("dev", 120, 68, "fg_stbin")
+    assert ctx.capacity_for(key, 1_000_000) is None  # nothing known: the first call of a shape measures
+    for n_isects in (4_400_000, 4_500_000, 4_300_000):
+        ops._note_list_length(ctx, key, n_isects, 1_000_000)
+    cap = ctx.capacity_for(key, 1_000_000)
+    assert cap == ctx.isect_capacity[key] >= int(4_500_000 * 1.25)
+    up, down = ctx.capacity_for(key, 1_030_000), ctx.capacity_for(key, 930_000)
+    assert up >= int(4_500_000 * 1.03 * 1.25) and down < cap and down >= int(4_500_000 * 0.93 * 1.25)
+    assert ctx.capacity_for(key, 2_500_000) is None and ctx.capacity_for(key, 400_000) is None  # another scene altogether
+    ctx.isect_capacity[key] = 1234  # (tests force the overflow path this way: the stored figure stands for the same N)
+    assert ctx.capacity_for(key, 1_000_000) == 1234
+    # a refinement later: the history is re-read at the new count
+    ops._note_list_length(ctx, key, 4_200_000, 950_000)
+    assert ctx.isect_n[key] == 950_000 and ctx.capacity_for(key, 950_000) >= int(4_500_000 * 0.95 * 1.25)
+    # a jump beyond a factor of two forgets the history
+    ops._note_list_length(ctx, key, 900_000, 200_000)
+    assert ctx.isect_recent[key] == [(900_000, 200_000)]
+    # checkpoint-slot needs: (need, N) pairs, scaled the same way
+    lkey = ("dev", 120, 68)
+    assert ctx.seg_slots_for(lkey, 6_000_000, 8160, 1_000_000) == 0 and not ctx.seg_slots_known
+    ctx.ckpt_need[lkey] = [(4000, 1_000_000), (4100, 1_000_000)]
+    same = ctx.seg_slots_for(lkey, 6_000_000, 8160, 1_000_000)
+    more = ctx.seg_slots_for(lkey, 6_000_000, 8160, 1_100_000)
+    assert ctx.seg_slots_known and same >= 8 * 4100 and same % 4096 == 0 and more > same
+    assert ctx.seg_slots_for(lkey, 100_000, 8160, 1_000_000) == 0  # not smaller than a slot per 64 entries: by formula
+    # the policy variant enters a cache key by VALUE (an address may be reused by another context's copy)
+    p0, v0 = ctx.cfg_variant(False, 0, False)
+    p1, v1 = ctx.cfg_variant(True, 8192, True)
+    assert v0 == (0, 0, False) and v1 == (ctx.heavy_tile_len, 8192, True) and p1 != p0
+    assert ctx.cfg_variant(True, 8192, True)[0] == p1 and ctx.cfg(True, 8192, True) == p1
