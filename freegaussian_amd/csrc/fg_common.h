@@ -87,22 +87,36 @@ __device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, fl
   const float ex = __builtin_amdgcn_sqrtf(tau2 * c * rdet), ey = __builtin_amdgcn_sqrtf(tau2 * a * rdet);
   if (!(ex == ex) || !(ey == ey)) return all;
   const float dy_right = -b * ex * __builtin_amdgcn_rcpf(c);  // where the ellipse is widest to the right (to the left: at -dy_right)
-  const float at = a * tau2, m = 0.02f, rspan = __builtin_amdgcn_rcpf(ts * (float)bs);
+  const float at = a * tau2, m = 0.02f, rspan = __builtin_amdgcn_rcpf(ts * (float)bs), org = ts * (float)x0;
+  // The x-range of the ellipse over a block row's strip: x_right(dy) = (-b dy + sqrt(a tau2 - det dy^2)) / a is concave, so
+  // its maximum over the strip is at the ellipse's own rightmost point when that lies inside, else at the strip edge nearer
+  // to it; likewise x_left.  The strips are taken from tile boundary to tile boundary (half a pixel more than the pixel
+  // centres on either side: conservative), so that a boundary's cross-section -- ONE square root -- serves the row above
+  // and the row below.
+  auto cross = [&](float dy, float& xl, float& xr) {  // the ellipse's x-range at height dy (relative to the centre)
+    const float d = fminf(fmaxf(dy, -ey), ey);  // (beyond the top / bottom: the tangent point)
+    const float root = __builtin_amdgcn_sqrtf(fmaxf(at - det * d * d, 0.f));
+    xr = (-b * d + root) * ra;
+    xl = (-b * d - root) * ra;
+  };
   uint64_t mask = 0;
+  float y_top = ts * (float)y0 - gy, tl, tr;  // (the half pixel between a tile boundary and its first pixel centres is the margin in y)
+  cross(y_top, tl, tr);
   for (int by = 0; by < nby; ++by) {
-    const int ya = y0 + by * bs, yb = min(ya + bs, y0 + h);
-    // the block row's strip of pixel centres, relative to the centre, with a margin
-    const float dlo = (ts * (float)ya + 0.5f) - gy - m, dhi = (ts * (float)yb - 0.5f) - gy + m;
-    if (dlo > ey * 1.0005f || dhi < -ey * 1.0005f) continue;  // the ellipse does not reach the strip
-    // (the strip's edges may lie beyond the ellipse's top / bottom by the margins: the widest point is then AT +-ey)
-    const float dr = fminf(fmaxf(fminf(fmaxf(dy_right, dlo), dhi), -ey), ey);
-    const float dl = fminf(fmaxf(fminf(fmaxf(-dy_right, dlo), dhi), -ey), ey);
-    float xr = (-b * dr + __builtin_amdgcn_sqrtf(fmaxf(at - det * dr * dr, 0.f))) * ra;
-    float xl = (-b * dl - __builtin_amdgcn_sqrtf(fmaxf(at - det * dl * dl, 0.f))) * ra;
+    const float y_bot = ts * (float)min(y0 + (by + 1) * bs, y0 + h) - gy;
+    float bl, br;
+    cross(y_bot, bl, br);
+    const bool reached = !(y_top > ey * 1.0005f || y_bot < -ey * 1.0005f);  // the ellipse reaches the strip at all
+    float xr = fmaxf(tr, br), xl = fminf(tl, bl);
+    if (dy_right >= y_top && dy_right <= y_bot) xr = ex;     // its rightmost point lies inside the strip
+    if (-dy_right >= y_top && -dy_right <= y_bot) xl = -ex;  // ... its leftmost
+    y_top = y_bot;
+    tl = bl;
+    tr = br;
+    if (!reached) continue;
     xr = gx + xr + (fabsf(xr) * 0.0005f + m);
     xl = gx + xl - (fabsf(xl) * 0.0005f + m);
     // blocks whose pixel centres [ts (x0 + bx bs) + 0.5, ts (x0 + (bx + 1) bs) - 0.5] meet [xl, xr]
-    const float org = ts * (float)x0;
     const float fa = ceilf((xl + 0.5f - org) * rspan) - 1.f, fb = floorf((xr - 0.5f - org) * rspan);
     if (!(fa == fa) || !(fb == fb)) {  // (NaN: keep the whole row)
       mask |= (uint64_t)row_all << (8 * by);
