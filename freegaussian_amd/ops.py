@@ -306,7 +306,10 @@ class RasterContext:
         recent = self.isect_recent.get(key)
         if not recent:
             return min(int(cap * (N / n_ref) * 1.05) + 4096, 2**31 - 1)
-        return list_capacity_for([int(n * (N / n_i) * 1.05) for n, n_i in recent])
+        scaled = list_capacity_for([int(n * (N / n_i) * 1.05) for n, n_i in recent])
+        # (a capacity that is still enough and not 25 % too large stays: every list-sized buffer of the step keeps its size
+        # and the caching allocator its blocks -- a fresh gigabyte block is 15 ms of hipMalloc on the step after a refinement)
+        return cap if scaled <= cap <= scaled + scaled // 4 else scaled
 
     def even_shape(self, lkey) -> bool:
         """Has this shape shown only even scenes lately (no tile list beyond three times the mean in its last eight
@@ -788,7 +791,10 @@ def _note_list_length(rctx, key, n_isects: int, N: int) -> int:
     # camera moving between light and heavy views neither overflows on every return nor asks the allocator for a new block
     # size every step (every list-sized buffer of the step -- ids, sort workspace, liveness words, checkpoints -- is sized
     # from this number)
-    cap[key] = list_capacity_for([n if n_i == N else int(n * (N / n_i)) for n, n_i in recent])
+    want = list_capacity_for([n if n_i == N else int(n * (N / n_i)) for n, n_i in recent])
+    have = cap.get(key)
+    if have is None or not (want <= have <= want + want // 4):  # (hysteresis: see RasterContext.capacity_for)
+        cap[key] = want
     rctx.isect_n[key] = N
     return n_isects
 
@@ -1719,7 +1725,10 @@ class _RasterStep(torch.autograd.Function):
         # per-loss gradients) finds the first one's sums there and clears them itself.  info["means2d"].grad of the earlier
         # pass is a view of this very array: it is copied out first and the new result added to it, as a retain_grad()'ed
         # tensor accumulates)
-        v_splats = torch.as_strided(keep, (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1), L.offset[_lib.STEP_BUFFER["v_splats"]] >> 2)
+        # (through `.data`: the record gradients are written in place -- by the kernels, by the two lines below -- and share
+        # their storage with the node's OUTPUTS (as_strided views of `keep`); in-place torch operations on a tensor that shares
+        # their version counter would make autograd refuse the next backward through the graph)
+        v_splats = torch.as_strided(keep.data, (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1), L.offset[_lib.STEP_BUFFER["v_splats"]] >> 2)
         ref = getattr(ctx, "means2d_ref", None)
         m2 = ref() if ref is not None else None
         earlier_m2_grad = None
@@ -1764,7 +1773,7 @@ class _RasterStep(torch.autograd.Function):
                 i = SBF[name]
                 if L.nbytes[i] == 0:
                     return None
-                base = keep if dtype is torch.float32 else keep.view(torch.int32)
+                base = keep.data if dtype is torch.float32 else keep.data.view(torch.int32)
                 return torch.as_strided(base, shape, (shape[1], 1) if len(shape) == 2 else (1,), L.offset[i] >> 2)
 
             k_stored = (1 + features_rest.shape[1]) if raw else (colors.shape[1] if sh_degree >= 0 else 0)

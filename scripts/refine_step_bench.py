@@ -101,7 +101,7 @@ for i in range(steps):
     if refined[i] or i == steps - 1:
         segments.append((start, i + 1))
         start = i + 1
-out_segments, total_plain, total_steady = [], 0.0, 0.0
+out_segments, total_plain, total_steady, total_calm, stalls = [], 0.0, 0.0, 0.0, []
 for a, b in segments:
     seg = ms[a:b]
     plain = [t for t, r in zip(seg, refined[a:b]) if not r]  # without the refinement step itself
@@ -115,8 +115,16 @@ for a, b in segments:
                          "refinement_step_ms": round(seg[-1], 3) if refined[b - 1] else None})  # fmt: skip
     total_plain += sum(plain)
     total_steady += steady * len(plain)
+    # (this platform's sporadic host stalls -- multiples of 15.6 ms, DESIGN.md section 4 -- land anywhere: listed, and a second
+    # figure without them)
+    for k, t in enumerate(plain):
+        if t > 5.0 * steady:
+            stalls.append({"step": step0 + a + k, "ms": round(t, 2)})
+    total_calm += sum(t if t <= 5.0 * steady else steady for t in plain)
 print(json.dumps({"layout": layout, "size": [n, W, H], "steps": steps, "split_frac": split_frac, "segments": out_segments,
                   "series_mean_over_steady_state": round(total_plain / max(total_steady, 1e-9), 4),
+                  "steps_over_5x_steady": stalls,
+                  "series_mean_over_steady_state_without_those": round(total_calm / max(total_steady, 1e-9), 4),
                   "counters_after_the_first_calls": {k: end[k] - base[k] for k in end},
                   "counters_of_the_first_calls": base,
                   "note": "train_step = step_cb, get_outputs, L1+SSIM loss, backward, six Adam groups, after_train_iter; "

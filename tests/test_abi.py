@@ -267,8 +267,10 @@ def test_learned_launch_state_scales_with_the_gaussian_count_host_logic():
         ops._note_list_length(ctx, key, n_isects, 1_000_000)
     cap = ctx.capacity_for(key, 1_000_000)
     assert cap == ctx.isect_capacity[key] >= int(4_500_000 * 1.25)
-    up, down = ctx.capacity_for(key, 1_030_000), ctx.capacity_for(key, 930_000)
-    assert up >= int(4_500_000 * 1.03 * 1.25) and down < cap and down >= int(4_500_000 * 0.93 * 1.25)
+    up, down, far_down = ctx.capacity_for(key, 1_030_000), ctx.capacity_for(key, 930_000), ctx.capacity_for(key, 600_000)
+    assert up >= int(4_500_000 * 1.03 * 1.25) and down >= int(4_500_000 * 0.93 * 1.25)
+    assert down == cap  # still enough and not 25 % too large: the buffers keep their sizes (hysteresis)
+    assert int(4_500_000 * 0.6 * 1.25) <= far_down < cap
     assert ctx.capacity_for(key, 2_500_000) is None and ctx.capacity_for(key, 400_000) is None  # another scene altogether
     ctx.isect_capacity[key] = 1234  # (tests force the overflow path this way: the stored figure stands for the same N)
     assert ctx.capacity_for(key, 1_000_000) == 1234
