@@ -1733,9 +1733,10 @@ class _RasterStep(torch.autograd.Function):
         m2 = ref() if ref is not None else None
         earlier_m2_grad = None
         if getattr(ctx, "v_splats_consumed", False):
-            if m2 is not None and m2.grad is not None and m2.grad.untyped_storage().data_ptr() == keep.untyped_storage().data_ptr():
-                earlier_m2_grad = m2.grad.clone()
-                if getattr(m2, "absgrad", None) is not None:
+            if m2 is not None and m2.grad is not None:
+                aliased = m2.grad.untyped_storage().data_ptr() == keep.untyped_storage().data_ptr()
+                earlier_m2_grad = m2.grad.clone() if aliased else m2.grad  # (the first pass's view of this array / a sum of passes)
+                if aliased and getattr(m2, "absgrad", None) is not None:
                     m2.absgrad = m2.absgrad.clone()
             v_splats.zero_()
         ctx.v_splats_consumed = True

@@ -110,7 +110,10 @@ for a, b in segments:
     half = sorted(plain[len(plain) // 2 :])
     steady = half[len(half) // 2]
     mean_plain = sum(plain) / len(plain)
+    srt = sorted(plain)
     out_segments.append({"steps": [step0 + a, step0 + b - 1], "n_gauss": counts[a], "mean_ms": round(mean_plain, 4),
+                         "median_ms": round(srt[len(srt) // 2], 4), "p90_ms": round(srt[int(0.9 * len(srt))], 4),
+                         "steps_over_1.5x_steady": sum(t > 1.5 * steady for t in plain),
                          "steady_ms": round(steady, 4), "first8_ms": [round(t, 3) for t in plain[:8]],
                          "refinement_step_ms": round(seg[-1], 3) if refined[b - 1] else None})  # fmt: skip
     total_plain += sum(plain)
