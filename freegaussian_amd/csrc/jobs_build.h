@@ -129,6 +129,9 @@ struct JobParams {
   // forward lists: a tile with a list longer than this is a HEAVY tile (0 = off); backward share lists: such a tile
   // gets up to 64 shares (16 otherwise)
   int heavy_len;
+  // forward lists: what is left of a heavy tile behind its prefix jobs goes to WIDE jobs (raster.hip raster_fwd_wide_kernel):
+  // four (tile, strip) entries in the heavy tiles' list, no local jobs
+  int heavy_wide;
 };
 // (thr_h: the heavy threshold of this build round, 0x7fffffff = none)
 __device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int tail4, int tail2, int thr4,
@@ -142,7 +145,7 @@ __device__ __forceinline__ int job_count(const JobParams& p, int idx, int n, int
     }
     return c;
   }
-  if (len > thr_h) return 4;  // (a heavy tile: four strip jobs over the list's first FG_HEAVY_PREFIX entries)
+  if (len > thr_h) return 4;  // (a heavy tile: four strip jobs over the list's first FG_HEAVY_PREFIX / FG_WIDE_PREFIX entries)
   int level = idx >= n - tail4 ? 2 : (idx >= n - tail4 - tail2 ? 1 : 0);
   level = max(level, len > thr4 ? 2 : (len > thr2 ? 1 : 0));
   return 1 << level;
@@ -403,7 +406,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
         const int tile = tile_at(idx);
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-        if (len > thr_h && has_slots(idx, tile, len)) heavy += 1ll + ((long long)heavy_local_jobs(len) << 32);
+        if (len > thr_h && has_slots(idx, tile, len)) heavy += 1ll + ((long long)(p.heavy_wide ? 0 : heavy_local_jobs(len)) << 32);
       }
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) heavy += __shfl_xor(heavy, m);
@@ -500,7 +503,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       const int tile = tile_at(idx);
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       if (len > thr_h && has_slots(idx, tile, len)) {
-        const int nl = heavy_local_jobs(len);
+        const int nl = p.heavy_wide ? 0 : heavy_local_jobs(len);
         const int l0 = atomicAdd(&local_n, nl), h = atomicAdd(&heavy_n, 1);
         for (int j = 0; j < nl; ++j) lc[8 + xcd * FG_LOCAL_CAP + l0 + j] = tile << 8 | j;
 #pragma unroll

@@ -24,6 +24,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "jobs_build.h"
 
 namespace {
@@ -466,7 +468,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                 const Composite& comp, float4* __restrict__ ckpt = nullptr,
                                                 uint32_t* __restrict__ live_words = nullptr, int local_part = 0,
-                                                const int32_t* __restrict__ slot_tab = nullptr) {
+                                                const int32_t* __restrict__ slot_tab = nullptr,
+                                                int32_t* __restrict__ open_list = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -489,7 +492,9 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if (first >= end) return;
   }
   if constexpr (MODE == 2) first = start + FG_HEAVY_PREFIX;
-  if constexpr (MODE == 3) end = min(end, start + FG_HEAVY_PREFIX);
+  // (MODE 3: local_part = the prefix length when the caller has its own -- the wide jobs' prefix -- else FG_HEAVY_PREFIX)
+  const int prefix_len = MODE == 3 && local_part > 0 ? local_part : FG_HEAVY_PREFIX;
+  if constexpr (MODE == 3) end = min(end, start + prefix_len);
   const int slot0 = (MODE != 0 || (C == 3 && NW == 1)) && ckpt ? seg_slot_base(slot_tab, start, tile) : -1;
   float4* const slots = slot0 >= 0 ? ckpt + seg_slots_offset4(n_tiles, width, height) : nullptr;
   if constexpr (MODE != 0) {
@@ -749,13 +754,17 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   if constexpr (MODE == 1) return;
   if constexpr (MODE == 3) {
     // the state at the end of the prefix, for the local and combine jobs (T < 0: finished, or outside the image)
-    if (slots && tile_offsets[tile + 1] - start > FG_HEAVY_PREFIX) {
+    if (slots && tile_offsets[tile + 1] - start > prefix_len) {
       float4* at = slots + seg_slot_index(slot0, start, start) * FG_SEG_SLOT4;
+      uint64_t all_done = full;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const bool fin = (done[k] >> lane) & 1ull;
         at[(row0 + k * RSTEP) * TILE + col] = make_float4(fin ? -T[k] : T[k], acc[k][0], acc[k][1], acc[k][2]);
+        all_done &= done[k];
       }
+      // wide jobs: the strips still open, as a list for the launch behind this one ([0] = how many, entries from [8])
+      if (open_list && all_done != full && lane == 0) open_list[8 + atomicAdd(&open_list[0], 1)] = tile << 3 | (wave_base + 1);
     }
   }
 
@@ -846,7 +855,8 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
                         const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
                         float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
-                        float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab, int prio) {
+                        float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab, int prio,
+                        int prefix_len, int32_t* __restrict__ open_list) {
   __shared__ FwdShared<C, 64> sh;
   // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
   // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
@@ -868,12 +878,12 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   FG_TL_BEGIN();
   if (prio > 0) {
     const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-    job_priority(tile_offsets, tile_w * tile_h, prefix ? min(len, FG_HEAVY_PREFIX) : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8), prio);
+    job_priority(tile_offsets, tile_w * tile_h, prefix ? min(len, prefix_len) : len, strip < 0 ? 13 : (strip >= 4 ? 10 : 8), prio);
   }
   if constexpr (C == 3) {
     if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
       raster_fwd_body<C, 1, 1, 3>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                                  last_ids, comp, ckpt, live_words, 0, slot_tab);
+                                  last_ids, comp, ckpt, live_words, prefix_len, slot_tab, open_list);
       FG_TL_END(1, tile, strip, 1, 1);
       return;
     }
@@ -934,6 +944,359 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
     raster_fwd_body<3, 1, 1, 2>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
                                 alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
     FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 2);
+  }
+}
+
+// WIDE jobs (fg_raster_config::heavy_wide, round 5): what a heavy tile's prefix jobs leave open, by ONE workgroup of
+// FG_WIDE_WAVES wavefronts per strip in a launch behind the main one -- instead of round 4's local + combine launches.
+//   main launch               four single-strip PREFIX jobs per heavy tile (MODE 3) walk the list's first FG_WIDE_PREFIX entries as
+//                             any strip job would -- about what a lone wavefront walks while the main launch lasts, so a tile
+//                             that closes its pixels there (a dense, opaque cluster) costs what it costs without heavy tiles --
+//                             and leave every pixel's state in the tile's first checkpoint slot.
+//   raster_fwd_wide_kernel    a strip with pixels still open continues in ROUNDS of FG_WIDE_WAVES 64-entry batches.  In a round
+//                             every wavefront
+//     1. stages ITS batch (its own LDS copy) and composites it by itself -- from T = 1, C = 0 -- for the pixels open at the
+//        round's start, and leaves (T_b, C_b, last entry taken) per pixel in LDS (T_b < 0: the pixel met the stop rule inside
+//        the batch);
+//     2. folds the batches in front of its own onto the round's starting state ("base"), per pixel: the state BEFORE its batch
+//        -- the backward's checkpoint -- unless an earlier batch of the round MAY STOP the pixel (a local stop, or the running
+//        T within 1e-5 of the threshold: the combine jobs' rule);
+//     3. the wavefront of the FIRST batch that may stop a pixel walks its batch again for those pixels, from the true state,
+//        entry by entry -- every wavefront for its own pixels at the same time -- and publishes the outcome as the pixel's new
+//        base (stopped, or the state behind that batch); 2-3 repeat until no pixel has a batch that may stop it (normally one
+//        walk: a pixel stops once);
+//     4. writes its batch's liveness bytes: an entry is live iff it passed the alpha test of a pixel that had not stopped.
+//   The round's end state is the next round's base; the job ends with the round in which its last pixel stops: at most one
+//   round of batches is composited in vain and nothing goes through memory but the checkpoints.  A round costs about two batch
+//   walks of latency whatever its length -- 1024 entries in 10-15 us against 110-170 us of a lone wavefront's serial walk --
+//   but holds half a CU meanwhile (measured: every strip of every list beyond 2560 entries as a wide job from its first entry,
+//   beside the main launch on a second stream, took 80 % of the Gaussians in a ball of 0.2 from 0.69 to 0.34 ms forward and
+//   cost every other layout 20-120 %, profiles/r05_wide_jobs.md): a tool for the lists that are long AND stay open, which is
+//   what the prefix finds out.  Stop decisions are the serial walk's own (step 3 is the serial walk); sums and products
+//   associate as in the three-launch form (1e-7 relative to the serial walk).
+#ifndef FG_WIDE_WAVES
+#define FG_WIDE_WAVES 16
+#endif
+#ifndef FG_WIDE_GRID
+#define FG_WIDE_GRID 256  // workgroups of the launch (an empty launch of 512 cost 11 us)
+#endif
+#ifndef FG_WIDE_PREFIX
+#define FG_WIDE_PREFIX 1536  // entries of a heavy tile's list the four serial strip jobs walk first (a multiple of 64)
+#endif
+static_assert(FG_WIDE_PREFIX % FG_SEG_ENTRIES == 0 && FG_WIDE_PREFIX >= FG_SEG_ENTRIES, "whole batches");
+template <int NWV>
+struct WideShared {
+  FwdShared<3, 64> stage[NWV];  // a wavefront's batch
+  float4 part[NWV][64];         // (T_b | -1, C_b) of the batch by itself, per pixel of the strip
+  int32_t part_last[NWV][64];   // the last entry the pixel took in the batch, -1: none
+  float4 base[64];              // per pixel (T, C) behind batch base_w of the round (-1: at the round's start)
+  int32_t base_last[64];
+  int32_t base_w[64];
+  int32_t base_fin[64];         // the pixel has stopped (or lies outside the image)
+  uint32_t live_or[NWV][2];     // step 4's OR over the lanes
+};
+
+template <int NWV>
+__device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int tile, int strip, int width, int height,
+                                                     int tile_w, const float4* __restrict__ splats,
+                                                     const int32_t* __restrict__ tile_offsets,
+                                                     const int32_t* __restrict__ flatten_ids, float* __restrict__ render,
+                                                     float* __restrict__ alphas, int32_t* __restrict__ last_ids,
+                                                     const Composite& comp, float4* __restrict__ ckpt,
+                                                     uint32_t* __restrict__ live_words,
+                                                     const int32_t* __restrict__ slot_tab) {
+  constexpr int C = 3, NV = rec_vec4(C);
+  constexpr float MAY_STOP = FG_T_STOP * 1.00001f;
+  const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
+  const int n_tiles = tile_w * ((height + TILE - 1) / TILE);
+  const int start = tile_offsets[tile], end = tile_offsets[tile + 1];
+  const int slot0 = ckpt ? seg_slot_base(slot_tab, start, tile) : -1;
+  if (slot0 < 0 || end - start <= FG_WIDE_PREFIX) return;  // (a heavy tile owns slots and is longer than its prefix: jobs_build.h)
+  float4* const slots = ckpt + seg_slots_offset4(n_tiles, width, height);
+  const int lane = fg::lane_id(), w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  FwdShared<3, 64>& st = sh.stage[w];
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  const int col = lane & 15, row = 4 * strip + (lane >> 4);
+  const int ix = tile_x * TILE + col, iy = tile_y * TILE + row;
+  const bool inside = ix < width && iy < height;
+  const size_t pix = (size_t)min(iy, height - 1) * width + min(ix, width - 1);
+  const float px = (float)ix + 0.5f;
+  const StripBounds sb = strip_bounds((float)(tile_x * TILE), (float)(tile_y * TILE));
+  // (the lane's row in the tile's FIRST strip: the pixel's dy by the same two subtractions as in every other job, slot_dy)
+  const float pyb = (float)(tile_y * TILE + (lane >> 4)) + 0.5f;
+  const float strip_off = (float)(4 * strip);
+  const uint64_t full = __ballot(true);
+  {
+    // the state the prefix job of this strip left (T < 0: finished there, or outside the image)
+    const float4 v = slots[seg_slot_index(slot0, start, start) * FG_SEG_SLOT4 + row * TILE + col];
+    if (!__any(v.x > 0.f)) return;  // (every wavefront reads the same words) the prefix closed the strip: its outputs stand
+    if (w == 0) {
+      sh.base[lane] = make_float4(fabsf(v.x), v.y, v.z, v.w);
+      sh.base_last[lane] = last_ids[pix];
+      sh.base_w[lane] = -1;
+      sh.base_fin[lane] = !(v.x > 0.f);
+    }
+  }
+  int cnt = 0;  // entries of this wavefront's batch that reach the strip (its private list)
+  // one batch, entry by entry, from the state given (raster_fwd_body's loop, one pixel per lane).  BITS: bit j of
+  // vlo | vhi << 32 = "entry batch + j passed this lane's alpha test" (step 4)
+  uint32_t vlo = 0, vhi = 0;
+  auto walk = [&](int batch, float& T, float (&acc)[C], int& last, uint64_t& done, auto bits) {
+    for (int n0 = 0; n0 < cnt; n0 += 8) {
+      if (done == full) break;
+      const int n1 = min(n0 + 8, cnt);
+      unsigned next_v = st.list[0][n0];
+      for (int n = n0; n < n1; ++n) {
+        const unsigned packed = __builtin_amdgcn_readfirstlane(next_v);
+        next_v = st.list[0][min(n + 1, 63)];
+        const int j = packed & 255u;
+        Splat s;
+        float f[C];
+        read_record<C>(st.rec[j], s, f);
+        const float dx = s.x - px, dy_base = s.y - pyb;
+        const SigmaTerms sg = sigma_terms_prescaled(s.a, s.b, s.c, dx);
+        const float dy = dy_base - strip_off;
+        const float e2 = neg_sigma_log2e(sg, dy);
+        const float alpha = fminf(FG_ALPHA_MAX, s.o * __builtin_amdgcn_exp2f(e2));
+        const uint64_t valid = lanes_ule(e2, 0.f) & lanes_oge(alpha, FG_ALPHA_SKIP) & ~done;
+        if (valid == 0ull) continue;
+        if constexpr (decltype(bits)::value) {
+          if (j < 32) vlo |= (uint32_t)lane_select(valid, 1 << j, 0);
+          else vhi |= (uint32_t)lane_select(valid, 1 << (j - 32), 0);
+        }
+        const float next_T = T * (1.f - alpha);
+        const uint64_t stop = valid & lanes_ole(next_T, FG_T_STOP);
+        const uint64_t take = valid & ~stop;
+        const float vis = lane_select0(take, alpha * T);
+#pragma unroll
+        for (int c = 0; c < C; ++c) acc[c] += f[c] * vis;
+        last = lane_select(take, batch + j, last);
+        T = lane_select(take, next_T, T);
+        done |= stop;
+      }
+    }
+  };
+
+  // This wavefront's entry of the NEXT round is fetched a round ahead -- the id at the head of a round, the record behind the
+  // walk, while the round's folding and voting go on: a round was two dependent round trips to memory before anything else
+  // (a third of its 15 us).
+  float4 v_next[NV];
+  {
+    const int idx = start + FG_WIDE_PREFIX + 64 * w + lane;
+    if (idx < end) {
+      const float4* rec = splats + (size_t)flatten_ids[idx] * (FG_SPLAT_FLOATS / 4);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v_next[q] = rec[q];
+    }
+  }
+  for (int r0 = start + FG_WIDE_PREFIX; r0 < end; r0 += 64 * NWV) {
+    __syncthreads();  // the base is settled (and nobody reads the last round's parts any more)
+    const uint64_t done0 = __ballot(sh.base_fin[lane] != 0);
+    if (done0 == full) break;  // (the same words for every wavefront: uniform over the workgroup)
+    const int batch = r0 + 64 * w;
+    const int idx_next = batch + 64 * NWV + lane;
+    const int gid_next = idx_next < end ? flatten_ids[idx_next] : 0;
+    // 1. the batch by itself
+    float T = 1.f, acc[C] = {0.f, 0.f, 0.f};
+    int last = -1;
+    uint64_t done = done0;
+    cnt = 0;
+    vlo = vhi = 0;
+    if (batch < end) {
+      const int idx = batch + lane;
+      unsigned mask = 0;
+      if (idx < end) {
+        float4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) v[q] = v_next[q];
+        mask = strip_mask(v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, sb);
+        v[0].w *= 0.5f * FG_NEG_LOG2E;
+        v[1].x *= FG_NEG_LOG2E;
+        v[1].y *= 0.5f * FG_NEG_LOG2E;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) st.rec[lane][q] = v[q];
+      }
+      const bool rel = (mask >> strip) & 1u;
+      const uint64_t bal = __ballot(rel);
+      if (rel) st.list[0][__popcll(bal & lt_mask)] = (uint16_t)(lane | (mask << 8));
+      cnt = __popcll(bal);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();  // records and list are private to this wavefront
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      walk(batch, T, acc, last, done, std::true_type{});
+    }
+    if (idx_next < end) {
+      const float4* rec = splats + (size_t)gid_next * (FG_SPLAT_FLOATS / 4);
+#pragma unroll
+      for (int q = 0; q < NV; ++q) v_next[q] = rec[q];
+    }
+    {
+      const bool stopped = ((done & ~done0) >> lane) & 1ull;
+      sh.part[w][lane] = make_float4(stopped ? -1.f : T, acc[0], acc[1], acc[2]);
+      sh.part_last[w][lane] = last;
+    }
+    if (lane < 2) sh.live_or[w][lane] = 0u;
+    // 2. + 3.
+    float t_in = 1.f, c_in[C] = {0.f, 0.f, 0.f};
+    int l_in = start - 1, bw = -1;
+    bool fin = false;
+    float4 ck = make_float4(1.f, 0.f, 0.f, 0.f);  // the state before this wavefront's batch
+    float4 mp = make_float4(1.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    for (;;) {
+      bw = sh.base_w[lane];
+      fin = sh.base_fin[lane] != 0;
+      l_in = sh.base_last[lane];
+      {
+        const float4 b = sh.base[lane];
+        t_in = b.x; c_in[0] = b.y; c_in[1] = b.z; c_in[2] = b.w;
+      }
+      bool earlier = false;  // a batch in front of this one may stop the pixel: its wavefront's business
+      // (five batches' loads at a time, in front of their arithmetic: they do not depend on the running state)
+      for (int q0 = 0; q0 < w; q0 += 5) {
+        float4 pq[5];
+        int plq[5];
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int qq = min(q0 + u, NWV - 1);
+          pq[u] = sh.part[qq][lane];
+          plq[u] = sh.part_last[qq][lane];
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const float4 p = pq[u];
+          const int q = q0 + u;
+          const bool use = q < w && q > bw && !fin && !earlier;
+          const bool ms = use && (p.x < 0.f || t_in * p.x <= MAY_STOP);
+          earlier = earlier || ms;
+          if (use && !ms) {
+            c_in[0] = fmaf(t_in, p.y, c_in[0]);
+            c_in[1] = fmaf(t_in, p.z, c_in[1]);
+            c_in[2] = fmaf(t_in, p.w, c_in[2]);
+            t_in *= p.x;
+            l_in = plq[u] >= 0 ? plq[u] : l_in;
+          }
+        }
+      }
+      mp = sh.part[w][lane];
+      const bool reached = w > bw && !fin && !earlier;
+      if (reached) ck = make_float4(t_in, c_in[0], c_in[1], c_in[2]);
+      const bool mine = reached && (mp.x < 0.f || t_in * mp.x <= MAY_STOP);
+      const uint64_t active = __ballot(mine);
+      if (!__syncthreads_or(active != 0ull)) break;
+      bool went_on = false;  // a pixel walked on through the batch that might have stopped it: the fold behind it has to be redone
+      if (active != 0ull) {
+        uint64_t d2 = ~active;
+        walk(batch, t_in, c_in, l_in, d2, std::false_type{});
+        if (mine) {
+          sh.base[lane] = make_float4(t_in, c_in[0], c_in[1], c_in[2]);
+          sh.base_last[lane] = l_in;
+          sh.base_w[lane] = w;
+          sh.base_fin[lane] = (int)((d2 >> lane) & 1ull);
+          went_on = !((d2 >> lane) & 1ull);
+        }
+      }
+      if (!__syncthreads_or(went_on)) {
+        // every walked pixel stopped: the states folded above stand for the others; the stopped ones' last entries for step 4
+        fin = sh.base_fin[lane] != 0;
+        if (fin) l_in = sh.base_last[lane];
+        if (fin) bw = sh.base_w[lane];
+        break;
+      }
+    }
+    // (nobody reads another wavefront's words behind the last vote)
+    if (batch > start && batch < end)
+      slots[seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4 + row * TILE + col] = ck;
+    // 4. liveness for the backward, exact: entry batch + j is live iff it passed the alpha test of a pixel that had not
+    // stopped by then -- the bits of step 1 (taken from T = 1: a superset), cut at the pixel's last entry if it has stopped
+    if (live_words && batch < end) {
+      const int rel_last = fin ? l_in - batch : 63;  // (fin: l_in = the pixel's last entry, read from the base above)
+      const uint32_t klo = rel_last < 0 ? 0u : (rel_last >= 31 ? ~0u : (2u << rel_last) - 1u);
+      const uint32_t khi = rel_last < 32 ? 0u : (rel_last >= 63 ? ~0u : (2u << (rel_last - 32)) - 1u);
+      if (vlo & klo) atomicOr(&sh.live_or[w][0], vlo & klo);
+      if (vhi & khi) atomicOr(&sh.live_or[w][1], vhi & khi);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const uint32_t word = sh.live_or[w][lane >> 5];
+      if (batch + lane < end) reinterpret_cast<uint8_t*>(live_words + (batch + lane))[strip] = (uint8_t)((word >> (lane & 31)) & 1u);
+    }
+    if (w == NWV - 1) {  // the round's end state: the next round's base
+      if (!fin) {
+        if (w > bw) {  // (no stop in this batch: that was settled above)
+          c_in[0] = fmaf(t_in, mp.y, c_in[0]);
+          c_in[1] = fmaf(t_in, mp.z, c_in[1]);
+          c_in[2] = fmaf(t_in, mp.w, c_in[2]);
+          t_in *= mp.x;
+          const int pl = sh.part_last[w][lane];
+          l_in = pl >= 0 ? pl : l_in;
+        }
+        sh.base[lane] = make_float4(t_in, c_in[0], c_in[1], c_in[2]);
+        sh.base_last[lane] = l_in;
+      }
+      sh.base_w[lane] = -1;
+    }
+  }
+  __syncthreads();
+  if (w != 0) return;
+  // the strip's outputs, as raster_fwd_body's epilogue
+  const float4 b = sh.base[lane];
+  const int last = sh.base_last[lane];
+  float accf[C] = {b.y, b.z, b.w};
+  {
+    const int m = fg::wave_max_i32(last);
+    if (lane == 0) reinterpret_cast<int32_t*>(ckpt)[4 * tile + strip] = m;
+  }
+  if (inside) {
+    const float alpha_out = 1.f - b.x;
+    reinterpret_cast<float*>(ckpt + seg_plane_offset4(n_tiles))[pix] = b.x;  // exact T_final
+    if (comp.background || comp.n_clamp > 0) {
+      const float om = 1.f - alpha_out;
+      unsigned blocked = 0;
+#pragma unroll
+      for (int c = 0; c < C; ++c) {
+        float v = accf[c];
+        if (comp.background) v += om * comp.background[c];
+        if (c < comp.n_clamp) {
+          if (v < 0.f || v > 1.f) blocked |= 1u << c;
+          v = fminf(fmaxf(v, 0.f), 1.f);
+        }
+        accf[c] = v;
+      }
+      if (comp.n_clamp > 0) comp.clamp_mask[pix] = (uint8_t)blocked;
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) render[pix * C + c] = accf[c];
+    alphas[pix] = alpha_out;
+    last_ids[pix] = last;
+  }
+}
+
+// open_list: [0] = the strips the prefix jobs of the main launch left open, [8 ...] = tile << 3 | (strip + 1) each; [1] = a
+// ticket: the last workgroup to leave zeroes both words (the list build zeroes them too; a second forward over the same
+// lists must not find the first one's entries)
+__global__ void __launch_bounds__(64 * FG_WIDE_WAVES)
+raster_fwd_wide_kernel(int width, int height, int tile_w, int32_t* __restrict__ open_list,
+                       const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
+                       const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
+                       int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
+                       uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab) {
+  __shared__ WideShared<FG_WIDE_WAVES> sh;
+  const int n_open = __builtin_amdgcn_readfirstlane(open_list[0]);
+  for (int v = blockIdx.x; v < n_open; v += gridDim.x) {
+    const int e = open_list[8 + v];
+    FG_TL_BEGIN();
+    raster_fwd_wide_body<FG_WIDE_WAVES>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids,
+                                        render, alphas, last_ids, comp, ckpt, live_words, slot_tab);
+    __syncthreads();  // (the next job's first words go where wavefront 0 has just read)
+    FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 3);
+  }
+  if (threadIdx.x == 0) {
+    __threadfence();
+    if (atomicAdd(&open_list[1], 1) == (int)gridDim.x - 1) {
+      open_list[0] = 0;
+      open_list[1] = 0;
+    }
   }
 }
 
@@ -1714,8 +2077,13 @@ int seg_grid(const Cfg& c, int tile_w, int tile_h, int parts, int tail, bool lis
   return 8 * (listed && per_xcd > cap ? cap : per_xcd);
 }
 // heavy_tiles: list length beyond which a tile of the forward is a heavy tile (raster_fwd_body MODE 1 / 2); <= 0: off
+// heavy_wide: 1 (default, -1) = what a heavy tile's prefix jobs (FG_WIDE_PREFIX entries, in the main launch) leave open goes to
+// WIDE jobs (raster_fwd_wide_kernel, one launch behind the main one); 0 = round 4's form (prefix of FG_HEAVY_PREFIX entries,
+// local jobs, combine jobs: A/B)
+bool heavy_wide(const Cfg& c) { return c.heavy_wide != 0; }
 int heavy_len(const Cfg& c) {
-  return c.heavy_tiles > 0 ? (c.heavy_tiles < FG_HEAVY_PREFIX + 512 ? FG_HEAVY_PREFIX + 512 : c.heavy_tiles) : 0;
+  const int least = heavy_wide(c) ? FG_WIDE_PREFIX + 256 : FG_HEAVY_PREFIX + 512;
+  return c.heavy_tiles > 0 ? (c.heavy_tiles < least ? least : c.heavy_tiles) : 0;
 }
 // seg_slots: checkpoint slots of the buffer the raster calls are given, eight equal shares of them an XCD band's (compact
 // slots: jobs_build.h JobBuild::slot_budget); 0 = one slot per 64 list entries of every tile, by formula
@@ -1800,14 +2168,24 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
   // table and no checkpoints
   const int32_t* slot_tab = slot_table(cfg, jobs, tile_w, tile_h);
   if (seg_slots(cfg) > 0 && !slot_tab) ckpt = nullptr;
+  // wide jobs: the open strips' list lives where the local jobs' list would (unused in this form; its eight count words are
+  // zeroed by every list build): written by this launch's prefix jobs, read and reset by the launch behind it
+  const bool wide = C == 3 && jobs && ckpt && heavy_len(cfg) > 0 && heavy_wide(cfg);
+  int32_t* const open_list = wide ? const_cast<int32_t*>(jobs) + 8 + 8 * (size_t)cap : nullptr;
   hipLaunchKernelGGL((raster_fwd_mixed_kernel<C>), dim3(jobs ? listed_grid(cfg, tile_w, tile_h, tail) : mixed_grid(cfg, tile_w, tile_h, tail)),
                      dim3(64), 0, s, width, height, tile_w, tile_h, band_nx(cfg), tail, jobs, cap,
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
-                     zero_buf ? zero_floats / 4 : 0ll, slot_tab, job_prio(cfg.prio_fwd, FG_PRIO_FWD_DEFAULT));
+                     zero_buf ? zero_floats / 4 : 0ll, slot_tab, job_prio(cfg.prio_fwd, FG_PRIO_FWD_DEFAULT),
+                     heavy_wide(cfg) ? FG_WIDE_PREFIX : FG_HEAVY_PREFIX, wide ? open_list : nullptr);
   if constexpr (C == 3) {
     // heavy tiles: their combine jobs, once every local job has left its batches' composites
-    if (jobs && ckpt && heavy_len(cfg) > 0) {
+    if (wide) {
+      // heavy tiles: the strips their prefix jobs left open, as wide jobs
+      hipLaunchKernelGGL(raster_fwd_wide_kernel, dim3(FG_WIDE_GRID), dim3(64 * FG_WIDE_WAVES), 0, s, width, height, tile_w,
+                         open_list, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
+                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab);
+    } else if (jobs && ckpt && heavy_len(cfg) > 0) {
       const int32_t* local = jobs + 8 + 8 * (size_t)cap;
       hipLaunchKernelGGL(raster_fwd_local_kernel, dim3(8 * 1024), dim3(64), 0, s, width, height, tile_w, local,
                          reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
@@ -2025,6 +2403,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->heavy_tiles = 0;
   c->seg_slots = 0;
   c->prio_fwd = c->prio_bwd = -1;
+  c->heavy_wide = -1;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
@@ -2054,13 +2433,14 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   const bool shares = bwd_list_shares && tb > 0 && sp > 1;
   // heavy tiles need the checkpoint buffer (three channels, list shares on) and the forward's list
   const int hl = shares && tf > 0 && jobs_fwd ? heavy_len(cfg) : 0;
-  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(cfg, tile_w, tile_h, tf) / 8, 0, 0, 0, 0, hl};
+  const int hw = hl > 0 && heavy_wide(cfg);
+  const JobParams pf{tf & 0xFFFF, tf >> 16, sf & 0xFFFF, sf >> 16, listed_grid(cfg, tile_w, tile_h, tf) / 8, 0, 0, 0, 0, hl, hw};
   // the backward's list: pixel strips, or (bwd_list_shares: the caller will hand the checkpoint buffer
   // of fg_raster_seg_ckpt_floats to both raster calls) shares of the tiles' lists
   const int st = seg_tail_fit(cfg, tile_w, tile_h, sp, seg_tail(cfg, n_tiles));
   const JobParams pb = shares ? JobParams{0, 0, 0, sb >> 16, seg_grid(cfg, tile_w, tile_h, sp, st, true) / 8, sp, st,
-                                          seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st, hl}
-                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0, 0};
+                                          seg_parts2(cfg), seg_tail2(cfg) < st ? seg_tail2(cfg) : st, hl, hw}
+                              : JobParams{tb & 0xFFFF, tb >> 16, sb & 0xFFFF, sb >> 16, listed_grid(cfg, tile_w, tile_h, tb) / 8, 0, 0, 0, 0, 0, 0};
   const int rows_limit = band_rows_limit(cfg, tile_h);  // (the grids and list segments are sized for it: band_tiles_max)
   *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd,
                           8 + 8 * jobs_cap(cfg, tile_w, tile_h), rows_limit,

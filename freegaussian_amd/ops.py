@@ -92,7 +92,8 @@ def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
     FG_RASTER_TAIL_FWD / _BWD = "t4[,t2]"; FG_RASTER_SPLIT_FWD / _BWD = "a4[,a2]"; FG_RASTER_BANDS = 1|2|4|8;
     FG_RASTER_LIVE = 0; FG_RASTER_SEG_PARTS, FG_RASTER_SEG_TAIL = n; FG_RASTER_SEG_GRADE = "parts2,tail2";
     FG_TILE_ORDER = rows|bands|cols|split|x|y; FG_DEBUG_ONLY_XCD = 0..7; FG_DEBUG_K_MOD = m; FG_RASTER_BALANCE = 0|1;
-    FG_RASTER_PRIO_FWD / _BWD = "lo,hi" (percent of the mean single-strip job; "0" = off)."""
+    FG_RASTER_PRIO_FWD / _BWD = "lo,hi" (percent of the mean single-strip job; "0" = off); FG_RASTER_HEAVY_WIDE = 0 (heavy
+    tiles by round 4's three launches)."""
     env = os.environ if env is None else env
     f = {}
 
@@ -106,7 +107,7 @@ def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
     for name, field in (("FG_RASTER_PPT_FWD", "ppt_fwd"), ("FG_RASTER_PPT_BWD", "ppt_bwd"), ("FG_RASTER_BANDS", "bands_nx"),
                         ("FG_RASTER_SEG_PARTS", "seg_parts"), ("FG_RASTER_SEG_TAIL", "seg_tail"),
                         ("FG_DEBUG_ONLY_XCD", "debug_only_xcd"), ("FG_DEBUG_K_MOD", "debug_k_mod"),
-                        ("FG_RASTER_BALANCE", "balance_bands")):  # fmt: skip
+                        ("FG_RASTER_BALANCE", "balance_bands"), ("FG_RASTER_HEAVY_WIDE", "heavy_wide")):  # fmt: skip
         if env.get(name) is not None:
             f[field] = int(env[name])
     for name, field in (("FG_RASTER_PRIO_FWD", "prio_fwd"), ("FG_RASTER_PRIO_BWD", "prio_bwd")):  # "lo,hi" percent; "0" = off

@@ -265,7 +265,8 @@ typedef struct fg_raster_config {
                               -- and one combining pass per strip (two more launches) instead of four serial walks; the
                               backward gives such a tile up to 64 shares.  For scenes with unsaturated lists of thousands
                               of entries (a host turns it on when fg_stbin_count's count_out[2] says so); not bit-identical
-                              to the serial walk (1e-7 relative).  <= 0 = off (default); values below 2560 mean 2560 */
+                              to the serial walk (1e-7 relative).  <= 0 = off (default); values below 2560 mean 2560
+                              (heavy_wide, below: the one-launch form that replaced this in round 5, from 256 entries) */
   int32_t seg_slots;       /* list segments, job lists (ABI 7): COMPACT checkpoint slots -- the buffer of
                               fg_raster_seg_ckpt_floats holds this many slots (4352 B each; rounded up to a multiple of 8)
                               instead of one per 64 entries of the list's capacity: only the tiles the backward may cut
@@ -281,6 +282,13 @@ typedef struct fg_raster_config {
                               launch's longest jobs, which start first and set its end, get through sooner; -1 = default
                               (forward 250 | 350 << 16, backward 120 | 160 << 16), 0 = off */
   int32_t prio_bwd;
+  int32_t heavy_wide;      /* forward, heavy tiles (ABI 8): 1 / -1 (default) = the four strip jobs of a heavy tile walk its list's
+                              first 1536 entries; a strip with pixels still open there continues as ONE job of a 16-wavefront
+                              workgroup in a launch behind the main one: the list in rounds of 16 64-entry batches, every
+                              wavefront its batch by itself, the batches folded in LDS, a batch in which a pixel may stop
+                              walked again from the true state; the job ends with the round in which its last pixel stops.
+                              heavy_tiles may then be as low as 1792.  0 = round 4's form (2048 entries serially, then local
+                              jobs and combine jobs in two launches; heavy_tiles >= 2560) */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 

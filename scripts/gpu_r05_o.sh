@@ -1,0 +1,40 @@
+#!/bin/bash
+# round 5, visit O: heavy tiles = serial prefix + wide jobs on a side stream beside the main launch -- parity, then layouts x
+# thresholds, for two prefix lengths
+out=gpurun_out/r05_o
+mkdir -p $out
+export TMPDIR=/tmp
+timeout 1200 python -m pytest tests/test_gpu_parity.py -q --timeout 600 -k "heavy_tiles or clustered or long_segments or graph or segmented" > $out/pytest_wide.log 2>&1
+tail -4 $out/pytest_wide.log
+run() {  # name, layout, env...
+  local tag=$1 lay=$2; shift 2
+  local f=$out/b_${tag}_${lay//[:.+]/_}
+  env "$@" timeout 200 python bench.py --layout $lay --steps 32 --warmup 8 --settle-s 0.5 --no-cpu-baseline --no-graph --no-clustered > $f.json 2> $f.err
+  python3 -c "
+import json,sys; d=json.loads(open('$f.json').read().strip().splitlines()[-1]); s=d['stage_ms']; print('$tag $lay', 'median', round(d['host_step_ms']['median'],4), 'fwd', s.get('fg_raster_fwd'), 'bwd', s.get('fg_raster_bwd'), 'fill', s.get('fg_bin_emit_sort_capacity'), 'heavy_steps', d['config'].get('heavy_tile_steps'))" || tail -2 $f.err
+}
+sweep() {
+  for lay in clustered:0.8:0.2 clustered:0.5:0.4 clustered:0.5:0.4+needles:0.3:10 needles:0.3:10; do
+    for heavy in 4096 2560 2048 1536 1024; do
+      run $1_$heavy $lay FG_HEAVY_TILE_LEN=$heavy
+    done
+  done
+}
+for lay in clustered:0.8:0.2 clustered:0.5:0.4 clustered:0.5:0.4+needles:0.3:10 needles:0.3:10 uniform; do
+  run three_2560 $lay FG_RASTER_HEAVY_WIDE=0 FG_HEAVY_TILE_LEN=2560
+  run never $lay FG_HEAVY_TILES=never
+done
+run p512_behind_2560 clustered:0.8:0.2 FG_RASTER_HEAVY_WIDE=2
+run p512_behind_2560 clustered:0.5:0.4 FG_RASTER_HEAVY_WIDE=2
+sweep p512
+R=$GRAFT_REPO_ROOT
+(cd /tmp; for lay in clustered:0.8:0.2 clustered:0.5:0.4 needles:0.3:10; do
+    tag=${lay//[:.+]/_}
+    rocprofv3 --kernel-trace -d $R/$out/prof_$tag -o p -- python3 $R/bench.py --layout $lay --steps 32 --warmup 8 --no-cpu-baseline --no-graph --no-clustered > $R/$out/prof_$tag.json 2> $R/$out/prof_$tag.err
+    echo "== $tag (prefix 512, heavy 2560)"; python3 $R/scripts/rocprof_top.py $R/$out/prof_$tag/p_results.db 4 raster; rm -rf $R/$out/prof_$tag
+  done)
+cd freegaussian_amd/csrc
+touch raster.hip
+make HIPCC="/opt/rocm/bin/hipcc -DFG_WIDE_PREFIX=1024" -j16 > ../../$out/make_1024.log 2>&1
+cd ../..
+sweep p1024

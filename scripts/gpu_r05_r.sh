@@ -1,0 +1,25 @@
+#!/bin/bash
+# round 5, visit R: prefix length x heavy threshold, 256 workgroups
+out=gpurun_out/r05_r
+mkdir -p $out
+export TMPDIR=/tmp
+run() {  # name, layout, env...
+  local tag=$1 lay=$2; shift 2
+  local f=$out/b_${tag}_${lay//[:.+]/_}
+  env "$@" timeout 200 python bench.py --layout $lay --steps 32 --warmup 8 --settle-s 0.5 --no-cpu-baseline --no-graph --no-clustered > $f.json 2> $f.err
+  python3 -c "
+import json,sys; d=json.loads(open('$f.json').read().strip().splitlines()[-1]); s=d['stage_ms']; print('$tag $lay', 'median', round(d['host_step_ms']['median'],4), 'fwd', s.get('fg_raster_fwd'), 'bwd', s.get('fg_raster_bwd'), 'fill', s.get('fg_bin_emit_sort_capacity'), 'heavy_steps', d['config'].get('heavy_tile_steps'))" || tail -2 $f.err
+}
+LAYS="clustered:0.8:0.2 clustered:0.5:0.4 clustered:0.5:0.4+needles:0.3:10 needles:0.3:10"
+for lay in $LAYS; do
+  for thr in 1792 2048 2560; do run p1536_$thr $lay FG_HEAVY_TILE_LEN=$thr; done
+done
+for P in 1024; do
+  cd freegaussian_amd/csrc
+  touch raster.hip
+  make HIPCC="/opt/rocm/bin/hipcc -DFG_WIDE_PREFIX=$P" -j16 > ../../$out/make_$P.log 2>&1
+  cd ../..
+  for lay in $LAYS; do
+    for thr in 1280 1536 1792 2048 2560; do run p${P}_$thr $lay FG_HEAVY_TILE_LEN=$thr; done
+  done
+done

@@ -1635,7 +1635,9 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
         seg_grads = {k: v.grad.clone() for k, v in gpu_in.items()}
         _setenv_policy(monkeypatch, "FG_RASTER_SEG_PARTS", "1")
         _, gpu_in1, _, o2 = _oracle_full_res(sc, 1, "RGB", 3)
-        assert torch.equal(o2[0], o1[0])  # the forward does not depend on it
+        # the forward does not depend on it -- but for heavy tiles (lists beyond ops.RasterContext.heavy_tile_len: on the
+        # clustered scene), which exist only with list shares and associate the same sums and products differently
+        assert torch.equal(o2[0], o1[0]) or (layout == "clustered" and rel_err(o2[0], o1[0]) < 2e-6)
         diff = {k: rel_l2(seg_grads[k], gpu_in1[k].grad) for k in seg_grads}
         print("share jobs vs whole-list walk, rel-L2:", {k: f"{v:.1e}" for k, v in diff.items()})
         assert all(v < 1e-5 for v in diff.values()), diff  # observed 2-5e-7: atomic order only
@@ -1655,7 +1657,7 @@ def test_segmented_backward_vs_oracle_and_vs_whole_list_walk(parts, layout, bg, 
                                          t["features_rest"], vm, K, 1920, 1080, 3, background=bgc, clamp=True, absgrad=True)  # fmt: skip
         ((r * vr).sum() + a.sum()).backward()
         outs.append((r.detach(), {k: v.grad for k, v in t.items()}))
-    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][0], outs[1][0]) or (layout == "clustered" and rel_err(outs[0][0], outs[1][0]) < 2e-6)  # (heavy tiles: as above)
     diff = {k: rel_l2(outs[0][1][k], outs[1][1][k]) for k in raw}
     print("share jobs vs whole-list walk (composite epilogue), rel-L2:", {k: f"{v:.1e}" for k, v in diff.items()})
     assert all(v < 1e-5 for v in diff.values()), diff
@@ -1783,15 +1785,21 @@ def test_clustered_1m_scene_lists_equal_the_oracles_through_the_long_segment_sor
     assert int(lens.max()) > 100_000 and ctx.long_calls == 2
 
 
+@pytest.mark.parametrize("form", ["wide", "three"])
 @pytest.mark.parametrize("bg", [False, True])
-def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(bg, monkeypatch):
-    """fg_raster_config::heavy_tiles: tiles with lists beyond the threshold are composited by local jobs over shares
-    of the list (every 64-entry batch by itself) + one combine job per strip in a second launch, and get up to 64
-    shares in the backward.  Two clusters -- an opaque one (pixels saturate within a few hundred entries: the combine
-    job walks those batches itself) and a faint one (lists of thousands that never saturate: every batch taken whole)
-    -- against the oracle (lists, image, every gradient at the bar) and against the serial walk (1e-6; last_ids equal
-    but for knife-edge pixels)."""
+def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(bg, form, monkeypatch):
+    """fg_raster_config::heavy_tiles: a tile with a list beyond the threshold is walked serially for a prefix only; the
+    strips still open there go on as WIDE jobs (``form`` "wide", fg_raster_config::heavy_wide: one 16-wavefront workgroup
+    per strip, rounds of 16 batches composited by themselves, folded in LDS, the batches in which a pixel may stop walked
+    again) or, round 4's form ("three"), as local jobs over shares of the list + one combine job per strip in two more
+    launches; the backward gives such a tile up to 64 shares.  Two clusters -- an opaque one (pixels saturate within a
+    few hundred entries: inside the prefix, or in walked batches) and a faint one (lists of thousands that never saturate:
+    every batch taken whole, many rounds) -- against the oracle (lists, image, every gradient at the bar) and against the
+    serial walk (1e-6; last_ids equal but for knife-edge pixels)."""
     from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    if form == "three":
+        _setenv_policy(monkeypatch, "FG_RASTER_HEAVY_WIDE", "0")
 
     sc = synthetic_scene(60_000, 1920, 1080, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
     sc.means[:20_000] = sc.means[:20_000] * 0.1 + torch.tensor([-0.9, 0.3, 0.0])  # opaque cluster
@@ -1832,6 +1840,39 @@ def test_heavy_tiles_forward_over_list_shares_vs_oracle_and_vs_the_serial_walk(b
     assert last_ids_agree(l1, l0)
     for k in g1:
         assert rel_l2(g1[k], g0[k]) < 1e-5, k
+
+
+def test_wide_jobs_leave_their_list_of_open_strips_empty_for_a_second_forward(monkeypatch):
+    """The prefix jobs of heavy tiles append the strips they leave open to a list inside the job-list buffer, the wide
+    launch behind the main one reads it and its last workgroup resets it: a second forward over the SAME lists (the ones
+    bin_tiles left on the offsets tensor) must find it empty and give the same image, bit for bit."""
+    W, H = 1920, 1080
+    sc = synthetic_scene(60_000, W, H, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    sc.means[20_000:40_000] = sc.means[20_000:40_000] * 0.1 + torch.tensor([0.8, -0.2, 0.0])  # faint cluster: long open lists
+    sc.opacities[20_000:40_000] *= 0.04
+    ctx = ops.RasterContext()
+    if int(_lib.load().fg_raster_jobs_words(W, H, 16, ctx.cfg())) == 0 or ctx.policy.heavy_wide == 0 or not ctx.jobs_in_fill:
+        pytest.skip("classic launches / the three-launch form in this environment")
+    ctx.heavy_tiles, ctx.heavy_tile_len = "always", 1792
+    with ops.use(ctx), torch.no_grad():
+        t = [x.to(DEV) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+        radii, m2, depths, conics, tiles, splats = ops.preprocess(*t, None, sc.viewmats[1].to(DEV), sc.Ks[1].to(DEV), W, H,
+                                                                  0.3, 0.01, 1e10, 0.0, 16, False, 3, False)  # fmt: skip
+        _, ids, offs = ops.bin_tiles(m2, radii, depths, tiles, 16, W // 16, (H + 15) // 16, want_keys=False,
+                                     keys_rects=getattr(splats, "_fg_bin", None), raster_hint=(3, W, H))  # fmt: skip
+        assert getattr(offs, "_fg_jobs", None) is not None and offs._fg_jobs[1], "list shares expected (checkpoint budget)"
+        lens = torch.diff(offs)
+        assert int(lens.max()) > 2560  # (the faint cluster's lists never close: open strips behind the prefix of 1536)
+        jobs = offs._fg_jobs[0]
+        # words of a list: 8 + 8 cap | local list 8 + 8 * 8192 (wide jobs: the open strips' list) | heavy list 8 + 8 * 2048 | slot table
+        cap = (jobs.shape[1] - 8 - (8 + 8 * 8192) - (8 + 8 * 2048) - (W // 16) * ((H + 15) // 16)) // 8
+        outs = []
+        for _ in range(2):
+            r, a, last = ops.rasterize_splats(splats, m2[None], 3, W, H, 16, offs, ids)
+            torch.cuda.synchronize()
+            outs.append((r.clone(), a.clone(), last.clone()))
+            assert int(jobs[0, 8 + 8 * cap]) == 0 and int(jobs[0, 8 + 8 * cap + 1]) == 0, "open list / ticket not reset"
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
