@@ -1,0 +1,21 @@
+#!/bin/bash
+# round 5, visit U: medium tiles on a high-priority stream
+out=gpurun_out/r05_u
+mkdir -p $out
+export TMPDIR=/tmp
+run() {  # name, layout, env...
+  local tag=$1 lay=$2; shift 2
+  local f=$out/b_${tag}_${lay//[:.+]/_}
+  env "$@" timeout 200 python bench.py --layout $lay --steps 32 --warmup 8 --settle-s 0.5 --no-cpu-baseline --no-graph --no-clustered > $f.json 2> $f.err
+  python3 -c "
+import json,sys; d=json.loads(open('$f.json').read().strip().splitlines()[-1]); s=d['stage_ms']; print('$tag $lay', 'median', round(d['host_step_ms']['median'],4), 'fwd', s.get('fg_raster_fwd'), 'bwd', s.get('fg_raster_bwd'), 'fill', s.get('fg_bin_emit_sort_capacity'), 'heavy_steps', d['config'].get('heavy_tile_steps'))" || tail -2 $f.err
+}
+for lay in clustered:0.5:0.4 clustered:0.8:0.2 needles:0.3:10 uniform; do
+  for m in 0 2048 1536 1024; do run m$m $lay FG_WIDE_TILE_LEN=$m; done
+done
+R=$GRAFT_REPO_ROOT
+(cd /tmp; for lay in clustered:0.5:0.4 uniform; do
+    tag=${lay//[:.+]/_}
+    FG_WIDE_TILE_LEN=1024 rocprofv3 --kernel-trace -d $R/$out/prof_$tag -o p -- python3 $R/bench.py --layout $lay --steps 32 --warmup 8 --no-cpu-baseline --no-graph --no-clustered > $R/$out/prof_$tag.json 2> $R/$out/prof_$tag.err
+    echo "== $tag (medium from 1024)"; python3 $R/scripts/rocprof_top.py $R/$out/prof_$tag/p_results.db 4 raster; rm -rf $R/$out/prof_$tag
+  done)
