@@ -62,7 +62,7 @@ SIGNATURES = {
     "fg_raster_composite_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, c_int, P, P, P, P, P, P, P, P]),
     "fg_raster_jobs_words": (c_int64, [c_int, c_int, c_int, P]),
     "fg_raster_build_jobs": (c_int, [c_int, c_int, c_int, P, P, P, c_int, P, P]),
-    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, P, P]),
+    "fg_raster_jobs_fwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, c_int64, P, P, P]),
     "fg_raster_seg_ckpt_floats": (c_int64, [c_int, c_int, c_int, c_int, c_int64, P]),
     "fg_raster_jobs_bwd": (c_int, [c_int, c_int, c_int, c_int, P, P, P, P, P, c_int, P, P, P, P, P, P, P, P, P, P, P]),
     "fg_unpack_grads": (c_int, [c_int, c_int, P, P, P, P, P, P, P]),

@@ -213,6 +213,9 @@ static_assert(FG_SEG_ENTRIES == fgjobs::FG_SEG_ENTRIES_H, "a heavy tile's batch 
 #ifndef FG_HEAVY_AHEAD
 #define FG_HEAVY_AHEAD 8
 #endif
+#ifndef FG_WALK_REPORT
+#define FG_WALK_REPORT 2560  // entries a strip walked before a forward job reports it (fg_raster_jobs_fwd walk_out)
+#endif
 #ifndef FG_HEAVY_SUB
 #define FG_HEAVY_SUB 4  // workgroups per listed local job
 #endif
@@ -469,7 +472,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 const Composite& comp, float4* __restrict__ ckpt = nullptr,
                                                 uint32_t* __restrict__ live_words = nullptr, int local_part = 0,
                                                 const int32_t* __restrict__ slot_tab = nullptr,
-                                                int32_t* __restrict__ open_list = nullptr) {
+                                                int32_t* __restrict__ open_list = nullptr,
+                                                long long* __restrict__ walk_out = nullptr) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -771,11 +775,17 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
   if constexpr (C == 3 && NW == 1) {
     if (ckpt) {  // the table in front of the checkpoint slots (seg_slots_offset4)
       int32_t* tl = reinterpret_cast<int32_t*>(ckpt) + 4 * tile;
+      int walked = 0;
 #pragma unroll
       for (int k = 0; k < PPT; ++k) {
         const int m = fg::wave_max_i32(last[k]);
         if (lane == 0) tl[wave + k * (4 / PPT)] = m;
+        walked = max(walked, m - start + 1);
       }
+      // LONG WALKS reported to the host (nullable; pinned memory, system scope; any of them, not the longest): a strip
+      // that needed more than FG_WALK_REPORT entries is what heavy tiles are for -- the host turns them on by it
+      if (MODE == 0 && walk_out && walked > FG_WALK_REPORT && lane == 0)
+        __hip_atomic_store(walk_out, (long long)walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 #pragma unroll
@@ -856,7 +866,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
                         float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
                         float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab, int prio,
-                        int prefix_len, int32_t* __restrict__ open_list) {
+                        int prefix_len, int32_t* __restrict__ open_list, long long* __restrict__ walk_out) {
   __shared__ FwdShared<C, 64> sh;
   // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
   // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
@@ -890,13 +900,13 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   }
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                             last_ids, comp, ckpt, live_words, 0, slot_tab);
+                             last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
   else if (strip >= 4)
     raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
   FG_TL_END(1, tile, strip, 0, 1);
 }
 
@@ -1004,7 +1014,7 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
                                                      float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                      const Composite& comp, float4* __restrict__ ckpt,
                                                      uint32_t* __restrict__ live_words,
-                                                     const int32_t* __restrict__ slot_tab) {
+                                                     const int32_t* __restrict__ slot_tab, long long* __restrict__ walk_out) {
   constexpr int C = 3, NV = rec_vec4(C);
   constexpr float MAY_STOP = FG_T_STOP * 1.00001f;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
@@ -1246,6 +1256,8 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
   {
     const int m = fg::wave_max_i32(last);
     if (lane == 0) reinterpret_cast<int32_t*>(ckpt)[4 * tile + strip] = m;
+    if (walk_out && m - start + 1 > FG_WALK_REPORT && lane == 0)
+      __hip_atomic_store(walk_out, (long long)(m - start + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (inside) {
     const float alpha_out = 1.f - b.x;
@@ -1280,14 +1292,15 @@ raster_fwd_wide_kernel(int width, int height, int tile_w, int32_t* __restrict__ 
                        const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,
                        const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
                        int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
-                       uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab) {
+                       uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab,
+                       long long* __restrict__ walk_out) {
   __shared__ WideShared<FG_WIDE_WAVES> sh;
   const int n_open = __builtin_amdgcn_readfirstlane(open_list[0]);
   for (int v = blockIdx.x; v < n_open; v += gridDim.x) {
     const int e = open_list[8 + v];
     FG_TL_BEGIN();
     raster_fwd_wide_body<FG_WIDE_WAVES>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids,
-                                        render, alphas, last_ids, comp, ckpt, live_words, slot_tab);
+                                        render, alphas, last_ids, comp, ckpt, live_words, slot_tab, walk_out);
     __syncthreads();  // (the next job's first words go where wavefront 0 has just read)
     FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 3);
   }
@@ -2157,7 +2170,8 @@ template <int C>
 int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int32_t* jobs, const float* splats,
                      const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                      int32_t* last_ids, Composite comp, hipStream_t s, float* ckpt = nullptr,
-                     uint32_t* live_words = nullptr, float* zero_buf = nullptr, long long zero_floats = 0) {
+                     uint32_t* live_words = nullptr, float* zero_buf = nullptr, long long zero_floats = 0,
+                     long long* walk_out = nullptr) {
   const int tile_w = (width + TILE - 1) / TILE, tile_h = (height + TILE - 1) / TILE;
   const int cap = jobs_cap(cfg, tile_w, tile_h);
   if (zero_buf && ((zero_floats & 3) || (reinterpret_cast<uintptr_t>(zero_buf) & 15))) {
@@ -2177,14 +2191,14 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
                      zero_buf ? zero_floats / 4 : 0ll, slot_tab, job_prio(cfg.prio_fwd, FG_PRIO_FWD_DEFAULT),
-                     heavy_wide(cfg) ? FG_WIDE_PREFIX : FG_HEAVY_PREFIX, wide ? open_list : nullptr);
+                     heavy_wide(cfg) ? FG_WIDE_PREFIX : FG_HEAVY_PREFIX, wide ? open_list : nullptr, walk_out);
   if constexpr (C == 3) {
     // heavy tiles: their combine jobs, once every local job has left its batches' composites
     if (wide) {
       // heavy tiles: the strips their prefix jobs left open, as wide jobs
       hipLaunchKernelGGL(raster_fwd_wide_kernel, dim3(FG_WIDE_GRID), dim3(64 * FG_WIDE_WAVES), 0, s, width, height, tile_w,
                          open_list, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
-                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab);
+                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab, walk_out);
     } else if (jobs && ckpt && heavy_len(cfg) > 0) {
       const int32_t* local = jobs + 8 + 8 * (size_t)cap;
       hipLaunchKernelGGL(raster_fwd_local_kernel, dim3(8 * 1024), dim3(64), 0, s, width, height, tile_w, local,
@@ -2269,7 +2283,7 @@ int raster_fwd_any(const fg_raster_config* config, int channels, int width, int 
                    const int32_t* tile_offsets, const int32_t* flatten_ids, float* render, float* alphas,
                    int32_t* last_ids, Composite comp, fg_stream_t stream, const int32_t* jobs = nullptr,
                    float* seg_ckpt = nullptr, uint32_t* live_words = nullptr, float* zero_buf = nullptr,
-                   long long zero_floats = 0) {
+                   long long zero_floats = 0, long long* walk_out = nullptr) {
   if (width <= 0 || height <= 0 || zero_floats < 0) return FG_ERR_INVALID_ARG;
   if (tile_size != TILE) return FG_ERR_UNSUPPORTED;
   if (!splats || !tile_offsets || !render || !alphas || !last_ids) return FG_ERR_INVALID_ARG;
@@ -2289,7 +2303,7 @@ int raster_fwd_any(const fg_raster_config* config, int channels, int width, int 
 #define CALL(CC)                                                                                                    \
   rc = (tail > 0)   ? launch_fwd_mixed<CC>(cfg, width, height, tail, jobs, splats, tile_offsets, flatten_ids, render,    \
                                          alphas, last_ids, comp, s, CC == 3 ? seg_ckpt : nullptr, live_words,       \
-                                         zero_buf, zero_floats)                                                     \
+                                         zero_buf, zero_floats, walk_out)                                           \
        : (ppt == 4) ? launch_fwd<CC, 4>(cfg, width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
                                       comp, s)                                                                      \
        : (ppt == 2) ? launch_fwd<CC, 2>(cfg, width, height, splats, tile_offsets, flatten_ids, render, alphas, last_ids, \
@@ -2466,11 +2480,11 @@ extern "C" int fg_raster_jobs_fwd(int channels, int width, int height, int tile_
                                   const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                                   const float* background, int n_clamp, float* image, float* alphas,
                                   int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                                  float* zero_buf, int64_t zero_floats, const fg_raster_config* config,
-                                  fg_stream_t stream) {
+                                  float* zero_buf, int64_t zero_floats, int64_t* walk_out,
+                                  const fg_raster_config* config, fg_stream_t stream) {
   return raster_fwd_any(config, channels, width, height, tile_size, splats, tile_offsets, flatten_ids, image, alphas,
                         last_ids, Composite{background, n_clamp, clamp_mask}, stream, jobs, seg_ckpt, live_words,
-                        zero_buf, (long long)zero_floats);
+                        zero_buf, (long long)zero_floats, reinterpret_cast<long long*>(walk_out));
 }
 
 extern "C" int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects,

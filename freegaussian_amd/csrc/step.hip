@@ -138,8 +138,8 @@ extern "C" int fg_step_fwd(const fg_step_desc* d, const fg_raster_config* config
   rc = fg_raster_jobs_fwd(C, W, H, 16, splats, list_offsets, flatten_ids, jobs, io->background, d->n_clamp,
                           at<float>(keep, L, FG_STEP_RENDER), at<float>(keep, L, FG_STEP_ALPHAS),
                           at<int32_t>(keep, L, FG_STEP_LAST_IDS), at<uint8_t>(keep, L, FG_STEP_CLAMP_MASK), seg_ckpt,
-                          at<uint32_t>(keep, L, FG_STEP_LIVE), v_splats, v_splats ? (int64_t)N * FG_SPLAT_FLOATS : 0, config,
-                          stream);
+                          at<uint32_t>(keep, L, FG_STEP_LIVE), v_splats, v_splats ? (int64_t)N * FG_SPLAT_FLOATS : 0,
+                          io->ckpt_need_out ? io->ckpt_need_out + 9 : nullptr, config, stream);
   if (io->ev_raster_end && hipEventRecord(static_cast<hipEvent_t>(io->ev_raster_end), fg_hip_stream(stream)) != hipSuccess)
     return FG_ERR_LAUNCH;
   return rc;

@@ -205,6 +205,18 @@ class RasterContext:
         self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "2560"))
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
+        self.long_walks = {}  # shape -> calls left for which a reported long walk (a strip beyond 2560 entries) counts
+        # The forward's content thresholds (fg_raster_config::split4_fwd / split2_fwd: a tile is cut into four / two strip
+        # jobs when its list is longer than that many 65536ths of all lists: 20 / 16 = 2.5 x / 2.0 x the mean at 8160 tiles)
+        # are tuned on even scenes, where finer cuts only repeat the staging.  On a scene with a cluster the launch is full
+        # for half of its time and then waits for whole-tile and two-strip jobs over lists of 1.6-2.2 x the mean that
+        # started in its first microsecond (profiles/r05_uneven_splits.md): a shape that has shown a list beyond three
+        # times the mean lately gets 12 / 8 (half of the Gaussians in a ball of 0.4: forward 0.255 -> 0.226 ms; the even
+        # bench scene would lose 4 %).  FG_UNEVEN_SPLIT_FWD="a4,a2" ("0" = off); a policy that sets its own thresholds wins.
+        sp = [int(x) for x in e.get("FG_UNEVEN_SPLIT_FWD", "12,8").split(",")]
+        self.uneven_split_fwd = (sp[0], sp[1] if len(sp) > 1 else 0)
+        # (the backward's share threshold with them: 16 -> 12, backward 0.334 -> 0.330 / 0.352 -> 0.344 ms on the two clustered layouts)
+        self.uneven_split2_bwd = int(e.get("FG_UNEVEN_SPLIT2_BWD", "12"))
         self.heavy_calls = 0  # raster steps planned with heavy tiles on
         self._policy_copies = {}
         # Compact checkpoint slots (FG_COMPACT_SLOTS=0: off): the buffer of the backward's list shares sized by what the tiles
@@ -255,15 +267,20 @@ class RasterContext:
         # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
         self.color_grad_sink = None
 
-    def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False) -> int:
+    def uneven_shape(self, lkey) -> bool:
+        """Has one of the shape's last eight calls shown a tile list beyond three times the mean?  Then the forward's content
+        thresholds are the finer ones (`uneven_split_fwd`)."""
+        return self.shape_calls.get(lkey, 0) > 0 and self.even_calls.get(lkey, 0) < 8
+
+    def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False) -> int:
         """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
         ``heavy_tiles`` set (unless the policy sets it itself); ``seg_slots`` > 0: with compact checkpoint slots, that many;
         ``even``: with ``balance_bands = 2`` (equal numbers of tiles per XCD without looking at the costs: a shape whose
         recent calls had no tile list far above the mean).  The copies live as long as the context: autograd nodes and
         cached step plans hold their addresses."""
-        return self.cfg_variant(heavy, seg_slots, even)[0]
+        return self.cfg_variant(heavy, seg_slots, even, uneven)[0]
 
-    def cfg_variant(self, heavy: bool = False, seg_slots: int = 0, even: bool = False):
+    def cfg_variant(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False):
         """``cfg`` and the VALUES that tell the variant from the context's own policy: (address, (heavy_len, seg_slots,
         even)) -- what a cache of anything derived from the policy is keyed on (an address can be reused by another
         context's copy)."""
@@ -272,14 +289,19 @@ class RasterContext:
             seg_slots = 0  # (the policy's own value stands)
         seg_slots = max(int(seg_slots), 0)
         even = bool(even) and self.policy.balance_bands in (-1, 1)
-        variant = (heavy_len, seg_slots, even)
-        if not heavy_len and seg_slots <= 0 and not even:
+        split = self.uneven_split_fwd if uneven and not even and self.policy.split4_fwd < 0 and self.uneven_split_fwd[0] > 0 else None
+        variant = (heavy_len, seg_slots, even, split)
+        if not heavy_len and seg_slots <= 0 and not even and split is None:
             return self.policy.ptr(), variant
         # (the policy may have been replaced or changed in place; few keys per policy: seg_slots comes in steps of 4096 slots)
-        key = (bytes(self.policy), heavy_len, int(seg_slots), even)
+        key = (bytes(self.policy), heavy_len, int(seg_slots), even, split)
         copy = self._policy_copies.get(key)
         if copy is None:
             copy = type(self.policy).from_buffer_copy(self.policy)
+            if split is not None:
+                copy.split4_fwd, copy.split2_fwd = split
+                if self.policy.split4_bwd < 0 and self.uneven_split2_bwd > 0:  # (list shares: only the second threshold counts)
+                    copy.split4_bwd, copy.split2_bwd = 20, self.uneven_split2_bwd
             if heavy_len:
                 copy.heavy_tiles = heavy_len
             if seg_slots > 0:
@@ -580,7 +602,8 @@ def _count_slot():
     """A slot of sixteen pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
     segment, [2] the longest tile list, [3] the segments beyond the small sort's capacity (fg_stbin_count only; they stay
     -1 otherwise), [12] what the cost pass over the XCDs' shares decided, [4..11] the checkpoint slots the
-    eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late).  -> (slot, address)."""
+    eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late), [13] a long walk of the
+    raster forward (fg_raster_jobs_fwd's walk_out; 0 = none; read one call late).  -> (slot, address)."""
     global _count_ring, _count_ring_np, _count_ring_next
     with _count_ring_lock:
         if _count_ring is None:
@@ -590,11 +613,12 @@ def _count_slot():
         _count_ring_next = (i + 1) % _COUNT_RING
         _count_ring_gen[i] += 1
         _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 13] = -1
+        _count_ring_np[_RING_WORDS * i + 13] = 0  # (fg_raster_jobs_fwd's walk_out: strips that walked more than 2560 entries)
         _count_ring_stream[i] = torch.cuda.current_stream()  # (under the lock: slot i is this caller's from here on)
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
 
 
-def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0) -> None:
+def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0, walks: bool = False) -> None:
     """Read the checkpoint-slot needs the PREVIOUS call of this shape reported (they have landed: this call's list length,
     which the caller has just waited for, was stored behind them), remember this call's slot for the next."""
     prev = rctx.ckpt_pending.pop(lkey, None)
@@ -606,6 +630,13 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0) -> None:
             del hist[:-8]
             if len(rctx.ckpt_need) > 256:
                 rctx.ckpt_need.pop(next(iter(rctx.ckpt_need)))
+        # long walks of that call's raster forward (when it was asked to report them: the one-call path): the shape's
+        # heavy tiles stay on (or come on) while they are reported
+        if len(prev) > 3 and prev[3]:
+            if len(rctx.long_walks) > 256 and lkey not in rctx.long_walks:
+                rctx.long_walks.pop(next(iter(rctx.long_walks)))
+            left = rctx.long_walks.get(lkey, 0)
+            rctx.long_walks[lkey] = rctx.heavy_cooldown if int(_count_ring_np[_RING_WORDS * prev[0] + 13]) > 0 else max(left - 1, 0)
         decided = int(_count_ring_np[_RING_WORDS * prev[0] + 12])
         if decided >= 0:  # (the cost pass ran: 1 = it balanced the shares by cost, 0 = the equal spans stood)
             if len(rctx.equal_stood) > 256 and lkey not in rctx.equal_stood:
@@ -614,7 +645,7 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0) -> None:
     if reported:
         if len(rctx.ckpt_pending) > 256:
             rctx.ckpt_pending.clear()
-        rctx.ckpt_pending[lkey] = (count_slot, _count_ring_gen[count_slot], N)
+        rctx.ckpt_pending[lkey] = (count_slot, _count_ring_gen[count_slot], N, walks)
 
 
 def _poll_count(i: int, word: int = 0) -> int:
@@ -800,14 +831,20 @@ def _note_list_length(rctx, key, n_isects: int, N: int) -> int:
     return n_isects
 
 
-def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: int = 0) -> int:
+def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: int = 0, walks: bool = False) -> int:
     """Wait for the three words fg_stbin_count stores into pinned host memory (list length, longest supertile segment,
     longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
     binning, the heavy-tile policy of the raster.  -> the list length."""
     n_isects = _poll_count(count_slot)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
                                           (2, rctx.heavy_tile_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
-        if _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many):
+        over = _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many)
+        # (heavy tiles: a long list AND, where the forward reports them -- the one-call path -- a long WALK lately: a dense
+        # opaque cluster has lists of ten thousand entries that close after a few hundred, and heavy tiles cost it 15 us)
+        if over and word == 2 and rctx.long_walks.get(lkey, rctx.heavy_cooldown) <= 0:
+            shapes.pop(lkey, None)  # (at once: nothing walked that far in the shape's last `heavy_cooldown` reporting calls)
+            over = False
+        if over:
             if lkey not in shapes and len(shapes) >= 256:
                 shapes.pop(next(iter(shapes)))
             shapes[lkey] = cooldown
@@ -815,7 +852,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
             shapes[lkey] -= 1
             if shapes[lkey] <= 0:
                 del shapes[lkey]
-    _note_ckpt_need(rctx, lkey, count_slot, need_reported, N)
+    _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)
     if len(rctx.shape_calls) > 256 and lkey not in rctx.shape_calls:
         rctx.shape_calls.pop(next(iter(rctx.shape_calls)))
     rctx.shape_calls[lkey] = rctx.shape_calls.get(lkey, 0) + 1
@@ -846,7 +883,7 @@ def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None, N=0)
     channels, width, height = (int(v) for v in raster_hint)
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
     seg_slots = rctx.seg_slots_for(lkey, n_list, n_tiles, N) if lkey is not None and channels == 3 else 0
-    cfgp = rctx.cfg(heavy, seg_slots, lkey is not None and rctx.even_shape(lkey))
+    cfgp = rctx.cfg(heavy, seg_slots, lkey is not None and rctx.even_shape(lkey), lkey is not None and rctx.uneven_shape(lkey))
     words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
@@ -1474,7 +1511,7 @@ class _RasterSplats(torch.autograd.Function):
             _call("fg_raster_jobs_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
                   _ptr(flatten_ids), _ptr(jobs[0]), _ptr(background), int(n_clamp), _ptr(render), _ptr(alphas),
                   _ptr(last_ids), _ptr(clamp_mask), _ptr(seg_ckpt), _ptr(live), _ptr(v_splats),
-                  0 if v_splats is None else v_splats.numel(), cfgp, _stream(),
+                  0 if v_splats is None else v_splats.numel(), None, cfgp, _stream(),
                   stage="fg_raster_composite_fwd" if composite else "fg_raster_fwd")  # fmt: skip
         elif composite:  # O1 folded into the kernel epilogue: render is the finished image
             _call("fg_raster_composite_fwd", channels, width, height, tile_size, _ptr(splats), _ptr(tile_offsets),
@@ -1645,7 +1682,7 @@ class _RasterStep(torch.autograd.Function):
         capacity = rctx.capacity_for(ckey, N)
         while True:
             seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h, N) if channels == 3 and want_backward else 0
-            cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey))
+            cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey), rctx.uneven_shape(lkey))
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
             # (the launch policy enters the key by VALUE -- its bytes and the variant's fields -- never by the address of a
             # context's copy, which another context's copy may reuse)
@@ -1695,7 +1732,7 @@ class _RasterStep(torch.autograd.Function):
             last_ids = view(i32, "last_ids", (height, width), (width, 1))
             splats = view(k32, "splats", (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1))
             list_offsets = view(i32, "list_offsets", (tile_w * tile_h + 1,), (1,))
-            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares, N)
+            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares, N, walks=shares)
             if n_isects <= capacity:
                 break
             rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length

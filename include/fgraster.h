@@ -370,7 +370,12 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
  * split would take together (whether or not they got them; whatever fg_raster_config::seg_slots is): 8 x the largest
  * word, + a margin, is the seg_slots that leaves no tile without.  Word 8 (whenever the forward list is built): what the
  * cost pass over the XCDs' shares decided -- 1 = bands balanced by cost, 0 = the equal spans stood, -1 = it did not run
- * (balance_bands 0 / 2, small or huge grids): a host whose last calls of a shape all read 0 can set balance_bands = 2. */
+ * (balance_bands 0 / 2, small or huge grids): a host whose last calls of a shape all read 0 can set balance_bands = 2.  * walk_out (ABI 8; nullable; one int64 in pinned host or device memory, zeroed by the caller): a forward job whose strip
+ * walked more than 2560 list entries stores that number there (system scope; any such job's, not the largest) -- lists
+ * that are long AND stay open, which is what fg_raster_config::heavy_tiles is for: a host turns the policy on by it
+ * instead of by the longest LIST alone (a dense opaque cluster has lists of ten thousand entries and closes after a few
+ * hundred).
+ */
 int fg_stbin_fill_jobs(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks,
                        int tile_w, int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                        int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,
@@ -381,8 +386,8 @@ int fg_raster_jobs_fwd(int channels, int width, int height, int tile_size, const
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
                        const float* background, int n_clamp, float* image, float* alphas,
                        int32_t* last_ids, uint8_t* clamp_mask, float* seg_ckpt, uint32_t* live_words,
-                       float* zero_buf, int64_t zero_floats, const fg_raster_config* config,
-                    fg_stream_t stream);
+                       float* zero_buf, int64_t zero_floats, int64_t* walk_out, const fg_raster_config* config,
+                       fg_stream_t stream);
 int64_t fg_raster_seg_ckpt_floats(int channels, int width, int height, int tile_size, int64_t n_isects, const fg_raster_config* config);
 int fg_raster_jobs_bwd(int channels, int width, int height, int tile_size, const float* splats,
                        const int32_t* tile_offsets, const int32_t* flatten_ids, const int32_t* jobs,
@@ -611,7 +616,8 @@ typedef struct fg_step_io {
      backward call: the raster backward): a host that times the dominant kernel of the step does not have to take the
      stage-wise entry points for it */
   void *ev_raster_begin, *ev_raster_end;
-  int64_t* ckpt_need_out; /* nullable, forward only: fg_stbin_fill_jobs' ckpt_need_out (int64[9]) */
+  int64_t* ckpt_need_out; /* nullable, forward only: fg_stbin_fill_jobs' ckpt_need_out (int64[9]); + one more word, [9]:
+                             fg_raster_jobs_fwd's walk_out (the caller zeroes it) */
 } fg_step_io;
 typedef struct fg_step_layout {
   int64_t keep_bytes, tmp_bytes;

@@ -291,5 +291,13 @@ def test_learned_launch_state_scales_with_the_gaussian_count_host_logic():
     # the policy variant enters a cache key by VALUE (an address may be reused by another context's copy)
     p0, v0 = ctx.cfg_variant(False, 0, False)
     p1, v1 = ctx.cfg_variant(True, 8192, True)
-    assert v0 == (0, 0, False) and v1 == (ctx.heavy_tile_len, 8192, True) and p1 != p0
+    assert v0 == (0, 0, False, None) and v1 == (ctx.heavy_tile_len, 8192, True, None) and p1 != p0
     assert ctx.cfg_variant(True, 8192, True)[0] == p1 and ctx.cfg(True, 8192, True) == p1
+    # a shape that showed an uneven scene lately: the forward's finer content thresholds (unless it is an even one by now)
+    p2, v2 = ctx.cfg_variant(False, 0, False, True)
+    assert v2 == (0, 0, False, ctx.uneven_split_fwd) and p2 not in (p0, p1) and ctx.cfg_variant(False, 0, True, True)[1][3] is None
+    assert not ctx.uneven_shape(lkey)
+    ctx.shape_calls[lkey], ctx.even_calls[lkey] = 3, 0
+    assert ctx.uneven_shape(lkey)
+    ctx.even_calls[lkey] = 8
+    assert not ctx.uneven_shape(lkey)
