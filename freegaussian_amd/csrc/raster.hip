@@ -960,9 +960,8 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
 // WIDE jobs (fg_raster_config::heavy_wide, round 5): what a heavy tile's prefix jobs leave open, by ONE workgroup of
 // FG_WIDE_WAVES wavefronts per strip in a launch behind the main one -- instead of round 4's local + combine launches.
 //   main launch               four single-strip PREFIX jobs per heavy tile (MODE 3) walk the list's first FG_WIDE_PREFIX entries as
-//                             any strip job would -- about what a lone wavefront walks while the main launch lasts, so a tile
-//                             that closes its pixels there (a dense, opaque cluster) costs what it costs without heavy tiles --
-//                             and leave every pixel's state in the tile's first checkpoint slot.
+//                             any strip job would -- a tile that closes its pixels there (a dense, opaque cluster) costs what
+//                             it costs without heavy tiles -- and leave every pixel's state in the tile's first checkpoint slot.
 //   raster_fwd_wide_kernel    a strip with pixels still open continues in ROUNDS of FG_WIDE_WAVES 64-entry batches.  In a round
 //                             every wavefront
 //     1. stages ITS batch (its own LDS copy) and composites it by itself -- from T = 1, C = 0 -- for the pixels open at the
@@ -991,7 +990,12 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
 #define FG_WIDE_GRID 256  // workgroups of the launch (an empty launch of 512 cost 11 us)
 #endif
 #ifndef FG_WIDE_PREFIX
-#define FG_WIDE_PREFIX 1536  // entries of a heavy tile's list the four serial strip jobs walk first (a multiple of 64)
+#define FG_WIDE_PREFIX 512  // entries of a heavy tile's list the four serial strip jobs walk first (a multiple of 64)
+// (1536 while the host turned heavy tiles on by the longest LIST: what a strip job walks while the main launch lasts, so that
+// a scene whose long lists close early lost nothing.  Since it goes by reported long WALKS -- fg_raster_jobs_fwd walk_out --
+// heavy tiles are on only where strips stay open for thousands of entries, and there a short prefix and a low threshold win:
+// 80 % of the Gaussians in a ball of 0.2, prefix / threshold 1536 / 2560: forward 0.492 ms, 1024 / 1280: 0.446, 768 / 1024:
+// 0.434, 512 / 768: 0.397, 256 / 512: 0.440; profiles/r05_wide_jobs.md section 4)
 #endif
 static_assert(FG_WIDE_PREFIX % FG_SEG_ENTRIES == 0 && FG_WIDE_PREFIX >= FG_SEG_ENTRIES, "whole batches");
 template <int NWV>

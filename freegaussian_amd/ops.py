@@ -199,10 +199,12 @@ class RasterContext:
         self.heavy_tiles = e.get("FG_HEAVY_TILES", "auto")
         if self.heavy_tiles not in ("auto", "always", "never"):
             raise ValueError(f"FG_HEAVY_TILES={self.heavy_tiles!r}: auto | always | never")
-        # (2560 = the prefix the four strip jobs walk + 512: the smallest the library takes; round 4's 3072 was tuned on lists
-        # with the entries the footprint masks drop -- lists of 2900-3030 entries, just below it, had become the forward's
-        # longest jobs on the 80 % / 0.2 layout: 0.79 -> 0.69 ms, profiles/r05_clustered_thresholds.md)
-        self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "2560"))
+        self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "768"))
+        # (round 5: the policy comes on for a shape whose longest list exceeds `heavy_flag_len` AND -- where the forward reports
+        # them: the one-call path -- whose strips walked more than 2560 entries lately; while it is on, every list beyond
+        # `heavy_tile_len` = the wide jobs' prefix of 512 entries + 256 is a heavy tile.  A dense opaque cluster has lists of
+        # ten thousand entries that close after a few hundred: heavy tiles cost it 15 us and gain it nothing)
+        self.heavy_flag_len = int(e.get("FG_HEAVY_FLAG_LEN", "2560"))
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
         self.long_walks = {}  # shape -> calls left for which a reported long walk (a strip beyond 2560 entries) counts
@@ -227,6 +229,7 @@ class RasterContext:
         self.even_calls = {}  # shape -> consecutive calls without a tile list beyond three times the mean
         self.equal_stood = {}  # shape -> consecutive cost passes of the list build that kept the equal spans
         self.shape_calls = {}  # shape -> calls so far
+        self.uneven_left = {}  # shape -> calls left for which its last uneven scene (a list beyond three times the mean) counts
         self.last_seg_slots = 0  # what the last call with list shares ran with (0: a slot per 64 entries of the capacity)
         self.ckpt_need = {}  # shape -> the last calls' needs (slots of the fullest XCD band)
         self.ckpt_pending = {}  # shape -> (ring slot, generation) of the call whose report has not been read yet
@@ -270,7 +273,7 @@ class RasterContext:
     def uneven_shape(self, lkey) -> bool:
         """Has one of the shape's last eight calls shown a tile list beyond three times the mean?  Then the forward's content
         thresholds are the finer ones (`uneven_split_fwd`)."""
-        return self.shape_calls.get(lkey, 0) > 0 and self.even_calls.get(lkey, 0) < 8
+        return self.uneven_left.get(lkey, 0) > 0
 
     def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False) -> int:
         """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
@@ -837,7 +840,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
     binning, the heavy-tile policy of the raster.  -> the list length."""
     n_isects = _poll_count(count_slot)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
-                                          (2, rctx.heavy_tile_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
+                                          (2, rctx.heavy_flag_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
         over = _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many)
         # (heavy tiles: a long list AND, where the forward reports them -- the one-call path -- a long WALK lately: a dense
         # opaque cluster has lists of ten thousand entries that close after a few hundred, and heavy tiles cost it 15 us)
@@ -859,7 +862,11 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
     longest, n_tiles = _poll_count(count_slot, 2), max(lkey[1] * lkey[2], 1)
     if len(rctx.even_calls) > 256 and lkey not in rctx.even_calls:
         rctx.even_calls.pop(next(iter(rctx.even_calls)))
-    rctx.even_calls[lkey] = min(rctx.even_calls.get(lkey, 0) + 1, 1 << 20) if longest * n_tiles <= 3 * n_isects + 32 * n_tiles else 0
+    even_now = longest * n_tiles <= 3 * n_isects + 32 * n_tiles
+    rctx.even_calls[lkey] = min(rctx.even_calls.get(lkey, 0) + 1, 1 << 20) if even_now else 0
+    if len(rctx.uneven_left) > 256 and lkey not in rctx.uneven_left:
+        rctx.uneven_left.pop(next(iter(rctx.uneven_left)))
+    rctx.uneven_left[lkey] = max(rctx.uneven_left.get(lkey, 0) - 1, 0) if even_now else 8
     return _note_list_length(rctx, key, n_isects, N)
 
 

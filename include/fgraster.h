@@ -283,11 +283,11 @@ typedef struct fg_raster_config {
                               (forward 250 | 350 << 16, backward 120 | 160 << 16), 0 = off */
   int32_t prio_bwd;
   int32_t heavy_wide;      /* forward, heavy tiles (ABI 8): 1 / -1 (default) = the four strip jobs of a heavy tile walk its list's
-                              first 1536 entries; a strip with pixels still open there continues as ONE job of a 16-wavefront
+                              first 512 entries; a strip with pixels still open there continues as ONE job of a 16-wavefront
                               workgroup in a launch behind the main one: the list in rounds of 16 64-entry batches, every
                               wavefront its batch by itself, the batches folded in LDS, a batch in which a pixel may stop
                               walked again from the true state; the job ends with the round in which its last pixel stops.
-                              heavy_tiles may then be as low as 1792.  0 = round 4's form (2048 entries serially, then local
+                              heavy_tiles may then be as low as 768.  0 = round 4's form (2048 entries serially, then local
                               jobs and combine jobs in two launches; heavy_tiles >= 2560) */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);

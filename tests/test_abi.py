@@ -297,7 +297,7 @@ def test_learned_launch_state_scales_with_the_gaussian_count_host_logic():
     p2, v2 = ctx.cfg_variant(False, 0, False, True)
     assert v2 == (0, 0, False, ctx.uneven_split_fwd) and p2 not in (p0, p1) and ctx.cfg_variant(False, 0, True, True)[1][3] is None
     assert not ctx.uneven_shape(lkey)
-    ctx.shape_calls[lkey], ctx.even_calls[lkey] = 3, 0
+    ctx.uneven_left[lkey] = 8
     assert ctx.uneven_shape(lkey)
-    ctx.even_calls[lkey] = 8
+    ctx.uneven_left[lkey] = 0
     assert not ctx.uneven_shape(lkey)
