@@ -875,6 +875,9 @@ def main(argv=None):
             "longest_tile_list": int((info["raster_isect_offsets"].reshape(-1)[1:] - info["raster_isect_offsets"].reshape(-1)[:-1]).max()),
             "long_segment_calls": ops.default_context.long_calls,
             "heavy_tile_steps": ops.default_context.heavy_calls,
+            # checkpoint slots (4352 B each) of the last step's buffer: the forward's states for the backward's list shares
+            "seg_ckpt_slots": ops.default_context.last_seg_slots,
+            "seg_ckpt_mb": round(ops.default_context.last_seg_slots * 4352 / 1e6, 1),
             "untimed_steps_before_timed_region": {"warmup": args.warmup, "stage_pass": stage_steps, "settle": settle_steps,
                                                   "order": "warm-up, settle (no host sync inside), stage pass, shorter settle, fence, timed region"},
         },

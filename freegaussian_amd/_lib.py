@@ -124,7 +124,7 @@ class RasterConfig(ctypes.Structure):
         "size", "ppt_fwd", "ppt_bwd", "tile_order", "bands_nx", "tail4_fwd", "tail2_fwd", "tail4_bwd", "tail2_bwd",
         "split4_fwd", "split2_fwd", "split4_bwd", "split2_bwd", "use_liveness", "seg_parts", "seg_tail", "seg_parts2",
         "seg_tail2", "debug_only_xcd", "debug_k_mod", "balance_bands", "heavy_tiles", "seg_slots", "prio_fwd", "prio_bwd",
-        "heavy_wide")]  # fmt: skip
+        "heavy_wide", "seg_fine")]  # fmt: skip
 
     FIELDS = tuple(n for n, _ in _fields_)[1:]
 

@@ -106,6 +106,24 @@ constexpr int FG_LOCAL_CAP = 8192;         // local jobs per XCD at most
 constexpr int FG_HEAVY_CAP = 2048;         // combine jobs per XCD at most (512 heavy tiles in an XCD's band)
 constexpr int FG_LOCAL_WORDS = 8 + 8 * FG_LOCAL_CAP, FG_HEAVY_WORDS = 8 + 8 * FG_HEAVY_CAP;
 constexpr int FG_SEG_ENTRIES_H = 64;       // (= FG_SEG_ENTRIES of raster.hip: a batch)
+// CHECKPOINT GRID of a tile's list (round 5): a checkpoint in front of every 64th entry for the list's first `fine` entries,
+// in front of every 128th behind them (fine: a multiple of 64; FG_SEG_FINE_NEVER = every 64th throughout, rounds 2-4).  The
+// backward wants shares of ~100 entries: a list of the tail (400-700 entries) needs the fine grid for its five shares, a
+// list of thousands has segments to spare -- and they are most of the slots (and of the forward's checkpoint writes).
+constexpr int FG_SEG_FINE_NEVER = 1 << 30;
+__host__ __device__ __forceinline__ int seg_index(int rel, int fine) {  // the segment entry `rel` (from the list's start) lies in
+  return rel < fine ? rel >> 6 : (fine >> 6) + ((rel - fine) >> 7);
+}
+__host__ __device__ __forceinline__ int seg_bound(int c, int fine) {  // first entry of segment c
+  const int nf = fine >> 6;
+  return c <= nf ? c << 6 : fine + ((c - nf) << 7);
+}
+__host__ __device__ __forceinline__ int seg_count(int n, int fine) {  // segments of a list of n entries = its checkpoint slots
+  return n <= fine ? (n + 63) >> 6 : (fine >> 6) + ((n - fine + 127) >> 7);
+}
+__host__ __device__ __forceinline__ bool seg_starts_at(int rel, int fine) {  // a segment starts at entry `rel` (a multiple of 64)
+  return rel < fine || ((rel - fine) & 127) == 0;
+}
 __host__ __device__ __forceinline__ int heavy_batches_per_job(int len) {
   // (at most 64 jobs per tile: the longest lists -- a dense cluster seen end on -- are the ones the prefix finishes)
   const int nb = (len - FG_HEAVY_PREFIX + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H, per = (nb + 63) / 64;
@@ -171,6 +189,7 @@ struct JobBuild {
   // for the host to size the next buffer by; word 8 = what the cost pass of the shares decided (1 by cost, 0 equal, -1 not run).  slot_budget = 0: no table, slot index by formula (raster.hip seg_slot_base).
   int slot_budget, tab_offset;
   long long* need_out;
+  int seg_fine;  // the checkpoint grid (seg_count: slots per tile)
 };
 constexpr int FG_BAND_MAX_ROWS = 1024;
 #ifndef FG_BAND_COST_CAP4
@@ -342,7 +361,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       const bool slots = has_slots(idx, tile, len);
       mine += p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
-      if (track && round == 0 && candidate(idx, len)) need += (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H;
+      if (track && round == 0 && candidate(idx, len)) need += seg_count(len, jb.seg_fine);
     }
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) {
@@ -375,7 +394,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
           if (idx >= 0) {
             tile = tile_at(idx);
             const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-            nd = candidate(idx, len) ? (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H : 0;
+            nd = candidate(idx, len) ? seg_count(len, jb.seg_fine) : 0;
           }
           int incl = nd;
 #pragma unroll
@@ -441,7 +460,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       const bool slots = has_slots(idx, tile, len);
       cnt = p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
       heavy_tile = !bwd && len > thr_h && slots;
-      if (write_tab && slots) need = (len + FG_SEG_ENTRIES_H - 1) / FG_SEG_ENTRIES_H;
+      if (write_tab && slots) need = seg_count(len, jb.seg_fine);
       // forward lists: will the backward (list shares, its un-raised content threshold: a superset of
       // what its own list ends up splitting) run this tile as ONE job?  Then no checkpoints are needed.
       // (compact slots: a tile without slots is such a tile)

@@ -258,8 +258,8 @@ constexpr int FG_SEG_SLOT4 = TILE * TILE + TILE * TILE / 16;
 __device__ __forceinline__ int seg_slot_base(const int32_t* __restrict__ slot_tab, int start, int tile) {
   return slot_tab ? __builtin_amdgcn_readfirstlane(slot_tab[tile]) : start / FG_SEG_ENTRIES + tile;
 }
-__device__ __forceinline__ size_t seg_slot_index(int slot0, int start, int g) {
-  return (size_t)slot0 + (size_t)((g - start) / FG_SEG_ENTRIES);
+__device__ __forceinline__ size_t seg_slot_index(int slot0, int start, int g, int fine = FG_SEG_FINE_NEVER) {
+  return (size_t)slot0 + (size_t)seg_index(g - start, fine);  // (fine: the checkpoint grid, jobs_build.h)
 }
 struct Segments {
   float4* ckpt;             // [slots][FG_SEG_SLOT4]; nullptr = no segmentation
@@ -269,6 +269,7 @@ struct Segments {
   int parts;                // backward: jobs per split tile (1 = whole list)
   int tail;                 // backward: the last `tail` tiles of every XCD's sequence are split (0 = all)
   int prio;                 // backward: issue priority thresholds of the jobs (job_priority), 0 = off
+  int fine = FG_SEG_FINE_NEVER;  // the checkpoint grid (jobs_build.h seg_index): the forward's and the list build's
 };
 
 // Optional work counters (make stats -> libfgraster_stats.so; never in the product library).
@@ -473,7 +474,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
                                                 uint32_t* __restrict__ live_words = nullptr, int local_part = 0,
                                                 const int32_t* __restrict__ slot_tab = nullptr,
                                                 int32_t* __restrict__ open_list = nullptr,
-                                                long long* __restrict__ walk_out = nullptr) {
+                                                long long* __restrict__ walk_out = nullptr,
+                                                int seg_fine = FG_SEG_FINE_NEVER) {
   constexpr int NT = 64 * NW;
   constexpr int RSTEP = TILE / PPT;
   constexpr int NV = rec_vec4(C);
@@ -618,8 +620,8 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     }
     if constexpr (C == 3 && NW == 1 && MODE != 1) {
       // checkpoint for the segmented backward (struct Segments): the state before entry `batch`
-      if (slots && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0) {
-        float4* slot = slots + seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4;
+      if (slots && batch > start && ((batch - start) & (FG_SEG_ENTRIES - 1)) == 0 && seg_starts_at(batch - start, seg_fine)) {
+        float4* slot = slots + seg_slot_index(slot0, start, batch, seg_fine) * FG_SEG_SLOT4;
 #pragma unroll
         for (int k = 0; k < PPT; ++k)
           slot[(row0 + k * RSTEP) * TILE + col] = make_float4(T[k], acc[k][0], acc[k][1], acc[k][2]);
@@ -866,7 +868,7 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
                         float* __restrict__ alphas, int32_t* __restrict__ last_ids, Composite comp,
                         float4* __restrict__ ckpt, uint32_t* __restrict__ live_words,
                         float4* __restrict__ zero4, long long zero_n4, const int32_t* __restrict__ slot_tab, int prio,
-                        int prefix_len, int32_t* __restrict__ open_list, long long* __restrict__ walk_out) {
+                        int prefix_len, int32_t* __restrict__ open_list, long long* __restrict__ walk_out, int seg_fine) {
   __shared__ FwdShared<C, 64> sh;
   // The record-gradient array of the coming backward is zero-filled here, a slice per workgroup: this
   // kernel leaves most of the memory pipe idle, a separate fill launch costs ~10 us plus its boundary.
@@ -893,20 +895,20 @@ raster_fwd_mixed_kernel(int width, int height, int tile_w, int tile_h, int nx, i
   if constexpr (C == 3) {
     if (prefix && ckpt) {  // a strip of a heavy tile: the list's first FG_HEAVY_PREFIX entries only
       raster_fwd_body<C, 1, 1, 3>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                                  last_ids, comp, ckpt, live_words, prefix_len, slot_tab, open_list);
+                                  last_ids, comp, ckpt, live_words, prefix_len, slot_tab, open_list, nullptr, seg_fine);
       FG_TL_END(1, tile, strip, 1, 1);
       return;
     }
   }
   if (strip < 0)
     raster_fwd_body<C, 4, 1>(sh, tile, 0, width, height, tile_w, splats, tile_offsets, flatten_ids, render, alphas,
-                             last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
+                             last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out, seg_fine);
   else if (strip >= 4)
     raster_fwd_body<C, 2, 1>(sh, tile, strip - 4, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out, seg_fine);
   else
     raster_fwd_body<C, 1, 1>(sh, tile, strip, width, height, tile_w, splats, tile_offsets, flatten_ids, render,
-                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out);
+                             alphas, last_ids, comp, ckpt, live_words, 0, slot_tab, nullptr, walk_out, seg_fine);
   FG_TL_END(1, tile, strip, 0, 1);
 }
 
@@ -1018,7 +1020,8 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
                                                      float* __restrict__ alphas, int32_t* __restrict__ last_ids,
                                                      const Composite& comp, float4* __restrict__ ckpt,
                                                      uint32_t* __restrict__ live_words,
-                                                     const int32_t* __restrict__ slot_tab, long long* __restrict__ walk_out) {
+                                                     const int32_t* __restrict__ slot_tab, long long* __restrict__ walk_out,
+                                                     int seg_fine) {
   constexpr int C = 3, NV = rec_vec4(C);
   constexpr float MAY_STOP = FG_T_STOP * 1.00001f;
   const int tile_y = tile / tile_w, tile_x = tile - tile_y * tile_w;
@@ -1219,8 +1222,8 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
       }
     }
     // (nobody reads another wavefront's words behind the last vote)
-    if (batch > start && batch < end)
-      slots[seg_slot_index(slot0, start, batch) * FG_SEG_SLOT4 + row * TILE + col] = ck;
+    if (batch > start && batch < end && seg_starts_at(batch - start, seg_fine))
+      slots[seg_slot_index(slot0, start, batch, seg_fine) * FG_SEG_SLOT4 + row * TILE + col] = ck;
     // 4. liveness for the backward, exact: entry batch + j is live iff it passed the alpha test of a pixel that had not
     // stopped by then -- the bits of step 1 (taken from T = 1: a superset), cut at the pixel's last entry if it has stopped
     if (live_words && batch < end) {
@@ -1297,14 +1300,14 @@ raster_fwd_wide_kernel(int width, int height, int tile_w, int32_t* __restrict__ 
                        const int32_t* __restrict__ flatten_ids, float* __restrict__ render, float* __restrict__ alphas,
                        int32_t* __restrict__ last_ids, Composite comp, float4* __restrict__ ckpt,
                        uint32_t* __restrict__ live_words, const int32_t* __restrict__ slot_tab,
-                       long long* __restrict__ walk_out) {
+                       long long* __restrict__ walk_out, int seg_fine) {
   __shared__ WideShared<FG_WIDE_WAVES> sh;
   const int n_open = __builtin_amdgcn_readfirstlane(open_list[0]);
   for (int v = blockIdx.x; v < n_open; v += gridDim.x) {
     const int e = open_list[8 + v];
     FG_TL_BEGIN();
     raster_fwd_wide_body<FG_WIDE_WAVES>(sh, e >> 3, (e & 7) - 1, width, height, tile_w, splats, tile_offsets, flatten_ids,
-                                        render, alphas, last_ids, comp, ckpt, live_words, slot_tab, walk_out);
+                                        render, alphas, last_ids, comp, ckpt, live_words, slot_tab, walk_out, seg_fine);
     __syncthreads();  // (the next job's first words go where wavefront 0 has just read)
     FG_TL_END(1, e >> 3, (e & 7) - 1, 0, 3);
   }
@@ -1387,16 +1390,16 @@ __device__ __forceinline__ void raster_bwd_body(BwdShared<C, 64 * NW>& sh, int t
     }
     const int n_used = bin_final - start + 1;
     if (n_used <= 0) return;
-    const int nseg = (n_used + FG_SEG_ENTRIES - 1) / FG_SEG_ENTRIES;
+    const int nseg = seg_count(n_used, seg.fine);
     const int c0 = part * nseg / seg.parts, c1 = (part + 1) * nseg / seg.parts;
     if (c0 == c1) return;  // fewer segments than parts: this part is empty
-    lo = start + c0 * FG_SEG_ENTRIES;
+    lo = start + seg_bound(c0, seg.fine);
     hi = bin_final + 1;
     if (c1 < nseg) {
-      hi = start + c1 * FG_SEG_ENTRIES;
+      hi = start + seg_bound(c1, seg.fine);
       from_ckpt = true;
       ck_slot = seg.ckpt + seg_slots_offset4(tile_w * ((height + TILE - 1) / TILE), width, height) +
-                seg_slot_index(seg_slot_base(seg.slot_tab, start, tile), start, hi) * FG_SEG_SLOT4;
+                seg_slot_index(seg_slot_base(seg.slot_tab, start, tile), start, hi, seg.fine) * FG_SEG_SLOT4;
     }
   }
   FG_TL_MARK(1);  // share bounds known
@@ -2102,6 +2105,16 @@ int heavy_len(const Cfg& c) {
   const int least = heavy_wide(c) ? FG_WIDE_PREFIX + 256 : FG_HEAVY_PREFIX + 512;
   return c.heavy_tiles > 0 ? (c.heavy_tiles < least ? least : c.heavy_tiles) : 0;
 }
+// seg_fine: the checkpoint grid (jobs_build.h seg_index) -- a checkpoint per 64 entries for a list's first seg_fine entries,
+// per 128 behind; -1 = the default, 0 = per 64 throughout (rounds 2-4); the three-launch heavy tiles keep a slot per batch
+#ifndef FG_SEG_FINE_DEFAULT
+#define FG_SEG_FINE_DEFAULT 640
+#endif
+int seg_fine(const Cfg& c) {
+  if (c.seg_fine == 0 || (heavy_len(c) > 0 && !heavy_wide(c))) return FG_SEG_FINE_NEVER;
+  const int v = c.seg_fine < 0 ? FG_SEG_FINE_DEFAULT : c.seg_fine;
+  return (v + 63) / 64 * 64;
+}
 // seg_slots: checkpoint slots of the buffer the raster calls are given, eight equal shares of them an XCD band's (compact
 // slots: jobs_build.h JobBuild::slot_budget); 0 = one slot per 64 list entries of every tile, by formula
 int seg_slots(const Cfg& c) { return c.seg_slots > 0 ? (c.seg_slots + 7) / 8 * 8 : 0; }
@@ -2195,14 +2208,14 @@ int launch_fwd_mixed(const Cfg& cfg, int width, int height, int tail, const int3
                      reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render, alphas, last_ids, comp,
                      reinterpret_cast<float4*>(ckpt), live_words, reinterpret_cast<float4*>(zero_buf),
                      zero_buf ? zero_floats / 4 : 0ll, slot_tab, job_prio(cfg.prio_fwd, FG_PRIO_FWD_DEFAULT),
-                     heavy_wide(cfg) ? FG_WIDE_PREFIX : FG_HEAVY_PREFIX, wide ? open_list : nullptr, walk_out);
+                     heavy_wide(cfg) ? FG_WIDE_PREFIX : FG_HEAVY_PREFIX, wide ? open_list : nullptr, walk_out, seg_fine(cfg));
   if constexpr (C == 3) {
     // heavy tiles: their combine jobs, once every local job has left its batches' composites
     if (wide) {
       // heavy tiles: the strips their prefix jobs left open, as wide jobs
       hipLaunchKernelGGL(raster_fwd_wide_kernel, dim3(FG_WIDE_GRID), dim3(64 * FG_WIDE_WAVES), 0, s, width, height, tile_w,
                          open_list, reinterpret_cast<const float4*>(splats), tile_offsets, flatten_ids, render,
-                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab, walk_out);
+                         alphas, last_ids, comp, reinterpret_cast<float4*>(ckpt), live_words, slot_tab, walk_out, seg_fine(cfg));
     } else if (jobs && ckpt && heavy_len(cfg) > 0) {
       const int32_t* local = jobs + 8 + 8 * (size_t)cap;
       hipLaunchKernelGGL(raster_fwd_local_kernel, dim3(8 * 1024), dim3(64), 0, s, width, height, tile_w, local,
@@ -2352,6 +2365,7 @@ int raster_bwd_any(const fg_raster_config* config, int channels, int width, int 
                    seg_tail_fit(cfg, (width + TILE - 1) / TILE, (height + TILE - 1) / TILE, seg_parts(cfg, n_tiles),
                                 seg_tail(cfg, n_tiles)), 0};
   seg.prio = job_prio(cfg.prio_bwd, FG_PRIO_BWD_DEFAULT);
+  seg.fine = seg_fine(cfg);
 #define CALL(CC)                                                                                            \
   rc = (tail > 0)   ? launch_bwd_mixed<CC>(cfg, width, height, tail, jobs, splats, tile_offsets, flatten_ids,    \
                                          alphas, last_ids, v_render, v_alphas, v_splats, comp, s, seg,      \
@@ -2422,6 +2436,7 @@ extern "C" void fg_raster_config_init(fg_raster_config* c) {
   c->seg_slots = 0;
   c->prio_fwd = c->prio_bwd = -1;
   c->heavy_wide = -1;
+  c->seg_fine = -1;
 }
 
 extern "C" int64_t fg_raster_jobs_words(int width, int height, int tile_size, const fg_raster_config* config) {
@@ -2463,7 +2478,7 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd,
                           8 + 8 * jobs_cap(cfg, tile_w, tile_h), rows_limit,
                           cfg.balance_bands == 0 ? 0 : (cfg.balance_bands == 2 ? -1 : (cfg.balance_bands > 2 ? cfg.balance_bands : 115)),
-                          shares ? seg_slots(cfg) / 8 : 0, (int)slot_table_offset(cfg, tile_w, tile_h), nullptr};
+                          shares ? seg_slots(cfg) / 8 : 0, (int)slot_table_offset(cfg, tile_w, tile_h), nullptr, seg_fine(cfg)};
   return FG_OK;
 }
 

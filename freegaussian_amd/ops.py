@@ -107,7 +107,8 @@ def launch_policy_from_env(env=None) -> "_lib.RasterConfig":
     for name, field in (("FG_RASTER_PPT_FWD", "ppt_fwd"), ("FG_RASTER_PPT_BWD", "ppt_bwd"), ("FG_RASTER_BANDS", "bands_nx"),
                         ("FG_RASTER_SEG_PARTS", "seg_parts"), ("FG_RASTER_SEG_TAIL", "seg_tail"),
                         ("FG_DEBUG_ONLY_XCD", "debug_only_xcd"), ("FG_DEBUG_K_MOD", "debug_k_mod"),
-                        ("FG_RASTER_BALANCE", "balance_bands"), ("FG_RASTER_HEAVY_WIDE", "heavy_wide")):  # fmt: skip
+                        ("FG_RASTER_BALANCE", "balance_bands"), ("FG_RASTER_HEAVY_WIDE", "heavy_wide"),
+                        ("FG_RASTER_SEG_FINE", "seg_fine")):  # fmt: skip
         if env.get(name) is not None:
             f[field] = int(env[name])
     for name, field in (("FG_RASTER_PRIO_FWD", "prio_fwd"), ("FG_RASTER_PRIO_BWD", "prio_bwd")):  # "lo,hi" percent; "0" = off

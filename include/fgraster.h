@@ -289,6 +289,13 @@ typedef struct fg_raster_config {
                               walked again from the true state; the job ends with the round in which its last pixel stops.
                               heavy_tiles may then be as low as 768.  0 = round 4's form (2048 entries serially, then local
                               jobs and combine jobs in two launches; heavy_tiles >= 2560) */
+  int32_t seg_fine;        /* list segments (ABI 8): the checkpoint grid -- the forward leaves a checkpoint in front of every 64th
+                              entry of a tile's list for the list's first seg_fine entries and in front of every 128th behind
+                              them (a checkpoint slot each; the backward's shares are cut at those entries): a list of the
+                              tail needs the fine grid for its five shares, a list of thousands has segments to spare.
+                              -1 = default (640), 0 = every 64th throughout (rounds 2-4; also with heavy_wide = 0); rounded up
+                              to a multiple of 64.  The SAME value must reach the list build, the size function and both raster
+                              calls. */
 } fg_raster_config;
 void fg_raster_config_init(fg_raster_config* config);
 
