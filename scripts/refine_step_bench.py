@@ -14,8 +14,16 @@ process measures the shape; checkpoint-slot needs are read one call late)."""
 import json
 import os
 import sys
+import time
 
-import torch
+# The step behind a refinement asked the allocator for a NEW 757 MB segment in every run (REFINE_DIAG=1 shows it): the
+# refinement's small allocations -- new parameter tensors, optimizer state -- had been carved out of the cached block that the
+# raster step's workspace comes from, and some stay.  Usually 1 ms, 17 ms in two of the round's four visits.  A training
+# process that keeps torch's caching allocator from splitting its largest blocks does not pay it.
+for _v in ("PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF"):
+    os.environ.setdefault(_v, "max_split_size_mb:256")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,6 +37,7 @@ steps = int(sys.argv[3]) if len(sys.argv) > 3 else 350
 W = int(sys.argv[4]) if len(sys.argv) > 4 else 1920
 H = int(sys.argv[5]) if len(sys.argv) > 5 else 1080
 split_frac = float(os.environ.get("REFINE_SPLIT_FRAC", "0.03"))  # share of the Gaussians a refinement splits / duplicates
+DIAG = os.environ.get("REFINE_DIAG", "0") == "1"  # host timing and allocator counters around the first refinement (stderr)
 dev = torch.device("cuda", 0)
 N_VIEWS = 8
 sc = apply_layout(synthetic_scene(n, W, H, n_views=N_VIEWS, sh_degree=3, seed=42), layout)
@@ -86,7 +95,18 @@ for i in range(steps):
     if step % cfg.refine_every == 0:
         set_split_threshold()
     before = model.num_points
+    if DIAG and 98 <= i <= 102:
+        torch.cuda.synchronize()
+        st0 = torch.cuda.memory_stats()
+        t_host = time.perf_counter()
     harness.train_step(model, opts, cams[i % N_VIEWS], gts[i % N_VIEWS], step, num_train_data=N_VIEWS, metrics_every=10**9)
+    if DIAG and 98 <= i <= 102:
+        t_issue = time.perf_counter() - t_host
+        torch.cuda.synchronize()
+        st1 = torch.cuda.memory_stats()
+        print(f"diag step {step}: host issue {1e3 * t_issue:.2f} ms, to completion {1e3 * (time.perf_counter() - t_host):.2f} ms, "
+              f"device mallocs {st1['num_device_alloc'] - st0['num_device_alloc']}, frees {st1['num_device_free'] - st0['num_device_free']}, "
+              f"segments {st1['segment.all.current']}, reserved {st1['reserved_bytes.all.current'] / 1e6:.0f} MB, N {model.num_points}", file=sys.stderr)
     e = torch.cuda.Event(enable_timing=True)
     e.record()
     events.append(e)
