@@ -1911,6 +1911,7 @@ def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monk
     g = torch.Generator().manual_seed(0)
     vr = torch.randn(1, H, W, 3, generator=g).to(DEV)
     outs = []
+    heavy_calls = ops.default_context.heavy_calls
     for classic in (False, True):
         if classic:
             _setenv_policy(monkeypatch, "FG_RASTER_TAIL_FWD", "0")
@@ -1923,7 +1924,11 @@ def test_clustered_scene_content_split_jobs_match_classic_launch_and_oracle(monk
     offs, ids = info["isect_offsets"].reshape(-1), info["flatten_ids"]
     lens = torch.diff(torch.cat([offs, offs.new_tensor([ids.numel()])])) if offs.numel() == 8160 else torch.diff(offs)
     assert int(lens.max()) > 20 * ids.numel() // 65536  # some tiles really are above the quarter threshold
-    assert torch.equal(r, r_c) and torch.equal(a, a_c)
+    if ops.default_context.heavy_calls == heavy_calls:
+        assert torch.equal(r, r_c) and torch.equal(a, a_c)
+    else:  # (the shape ran with heavy tiles -- earlier tests of the process flagged it, or FG_HEAVY_TILES=always --: their wide
+        # jobs associate the same sums and products differently)
+        assert rel_err(r, r_c) < 2e-6 and rel_err(a, a_c) < 2e-6
     for x, y in zip(grads, grads_c):
         assert rel_l2(x, y) < REL_TOL  # (list shares of the backward: suffix colours by subtraction, one more rounding)
     # centre crop (the heavy tiles) against the C oracle, as in the cfg4 test
