@@ -974,7 +974,7 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
 //        T within 1e-5 of the threshold: the combine jobs' rule);
 //     3. the wavefront of the FIRST batch that may stop a pixel walks its batch again for those pixels, from the true state,
 //        entry by entry -- every wavefront for its own pixels at the same time -- and publishes the outcome as the pixel's new
-//        base (stopped, or the state behind that batch); 2-3 repeat until no pixel has a batch that may stop it (normally one
+//        base (stopped, or the state behind that batch); 2-3 are repeated only if a walked pixel did NOT stop (normally one
 //        walk: a pixel stops once);
 //     4. writes its batch's liveness bytes: an entry is live iff it passed the alpha test of a pixel that had not stopped.
 //   The round's end state is the next round's base; the job ends with the round in which its last pixel stops: at most one
@@ -997,7 +997,7 @@ raster_fwd_combine_kernel(int width, int height, int tile_w, const int32_t* __re
 // a scene whose long lists close early lost nothing.  Since it goes by reported long WALKS -- fg_raster_jobs_fwd walk_out --
 // heavy tiles are on only where strips stay open for thousands of entries, and there a short prefix and a low threshold win:
 // 80 % of the Gaussians in a ball of 0.2, prefix / threshold 1536 / 2560: forward 0.492 ms, 1024 / 1280: 0.446, 768 / 1024:
-// 0.434, 512 / 768: 0.397, 256 / 512: 0.440; profiles/r05_wide_jobs.md section 4)
+// 0.434, 512 / 768: 0.397, 256 / 512: 0.440; profiles/r05_uneven_splits.md section 4)
 #endif
 static_assert(FG_WIDE_PREFIX % FG_SEG_ENTRIES == 0 && FG_WIDE_PREFIX >= FG_SEG_ENTRIES, "whole batches");
 template <int NWV>
