@@ -840,6 +840,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
     longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
     binning, the heavy-tile policy of the raster.  -> the list length."""
     n_isects = _poll_count(count_slot)
+    _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)  # (first: the previous call's walk report decides below)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
                                           (2, rctx.heavy_flag_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
         over = _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many)
@@ -856,7 +857,6 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
             shapes[lkey] -= 1
             if shapes[lkey] <= 0:
                 del shapes[lkey]
-    _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)
     if len(rctx.shape_calls) > 256 and lkey not in rctx.shape_calls:
         rctx.shape_calls.pop(next(iter(rctx.shape_calls)))
     rctx.shape_calls[lkey] = rctx.shape_calls.get(lkey, 0) + 1

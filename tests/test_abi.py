@@ -301,3 +301,39 @@ def test_learned_launch_state_scales_with_the_gaussian_count_host_logic():
     assert ctx.uneven_shape(lkey)
     ctx.uneven_left[lkey] = 0
     assert not ctx.uneven_shape(lkey)
+
+
+def test_heavy_tiles_follow_the_walks_the_forward_reports_host_logic(monkeypatch):
+    """ops: a shape runs with heavy tiles when its longest tile list exceeds `heavy_flag_len` AND -- where the raster forward
+    reports them (fg_raster_jobs_fwd walk_out, word 13 of the call's ring slot, read one call late) -- a strip walked more
+    than 2560 entries in one of its last `heavy_cooldown` reporting calls; calls that cannot report (the stage-wise path)
+    leave the verdict alone; nothing known = the list length decides.  Pure host logic: the ring is a numpy array here."""
+    import numpy as np
+
+    from freegaussian_amd import ops
+
+    ring = np.zeros(ops._RING_WORDS * ops._COUNT_RING, dtype=np.int64)
+    monkeypatch.setattr(ops, "_count_ring_np", ring)
+    ctx = ops.RasterContext(env={})
+    lkey, key = ("dev", 120, 68), ("dev", 120, 68, "fg_stbin")
+
+    def call(slot, longest, walks=True):
+        base = ops._RING_WORDS * slot
+        ring[base : base + 4] = (4_000_000, 1000, longest, 0)  # list length, longest segment, longest tile list, segments > 3072
+        ring[base + 4 : base + 13] = 0  # (checkpoint needs, the cost pass's decision)
+        ops._count_ring_gen[slot] += 1
+        ops._note_counts(ctx, lkey, key, slot, need_reported=True, N=1_000_000, walks=walks)
+        return ctx.heavy_shapes.get(lkey, 0) > 0
+
+    assert call(0, 12_000)  # nothing reported yet: a list of 12 000 entries turns the policy on
+    assert not call(1, 12_000)  # call 0 could report and did not: a dense cluster that closes early
+    assert not call(2, 12_000)
+    ring[ops._RING_WORDS * 2 + 13] = 3100  # call 2's forward: a strip walked 3100 entries
+    assert call(3, 12_000)
+    assert call(4, 12_000, walks=False) and call(5, 12_000)  # (a stage-wise call in between: call 5 reads nothing from it)
+    for i in range(ctx.heavy_cooldown + 2):  # no report for `heavy_cooldown` reporting calls: off again
+        on = call(6 + i, 12_000)
+    assert not on
+    assert not call(100, 2000)  # below the flag length nothing turns it on
+    ring[ops._RING_WORDS * 100 + 13] = 5000
+    assert not call(101, 2000) and call(102, 12_000)

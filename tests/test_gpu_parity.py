@@ -1883,6 +1883,53 @@ def test_wide_jobs_leave_their_list_of_open_strips_empty_for_a_second_forward(mo
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1]) and torch.equal(outs[0][2], outs[1][2])
 
 
+@pytest.mark.parametrize("cluster", ["faint", "opaque"])
+def test_heavy_tiles_stay_on_only_where_the_forward_reports_long_walks(cluster):
+    """The one-call path hands the raster forward a pinned word (fg_raster_jobs_fwd walk_out; word 9 of io->ckpt_need_out); a
+    strip that walked more than 2560 list entries stores that number there, the host reads it one call late and keeps
+    `heavy_tiles` for the shape only while such walks are reported.  A faint cluster (lists of thousands that never close)
+    keeps them; an opaque one (longer lists still, closed after a few hundred entries) loses them after its first reporting
+    call.  Same image either way (2e-6: heavy tiles associate differently)."""
+    from freegaussian_amd.rasterization import rasterize_gauss_params
+
+    W, H = 1920, 1080
+    n_in = 60_000 if cluster == "faint" else 30_000  # (in the cluster; 30 000 more around it)
+    sc = synthetic_scene(n_in + 30_000, W, H, n_views=2, sh_degree=3, seed=5, log_scale_mean=math.log(0.03))
+    sc.means[:n_in] = sc.means[:n_in] * 0.1 + torch.tensor([0.8, -0.2, 0.0])
+    if cluster == "faint":
+        sc.opacities[:n_in] *= 0.04  # lists of up to 8700 entries, pixels open to the end
+    else:
+        sc.opacities[:n_in] = 0.95  # lists of up to 11 000 entries, no pixel takes more than ~2400
+    ctx = ops.RasterContext(env={})
+    if not ctx.step_calls or int(_lib.load().fg_raster_jobs_words(W, H, 16, ctx.cfg())) == 0:
+        pytest.skip("the stage-wise calls / classic launches in this environment")
+    raw = dict(means=sc.means, quats=sc.quats, log_scales=sc.scales.log(), opacity_logits=torch.logit(sc.opacities.clamp(1e-4, 1 - 1e-4)),
+               features_dc=sc.colors[:, 0, :].contiguous(), features_rest=sc.colors[:, 1:, :].contiguous())  # fmt: skip
+    t = {k: v.to(DEV).requires_grad_(True) for k, v in raw.items()}  # (a training forward: list shares, checkpoints, reports)
+    vm, K = sc.viewmats[1:2].to(DEV), sc.Ks[1:2].to(DEV)
+    images, heavy = [], []
+    with ops.use(ctx):
+        for _ in range(6):
+            calls = ctx.heavy_calls
+            r, _a, info = rasterize_gauss_params(t["means"], t["quats"], t["log_scales"], t["opacity_logits"], t["features_dc"],
+                                                 t["features_rest"], vm, K, W, H, 3)  # fmt: skip
+            torch.cuda.synchronize()
+            images.append(r.detach().clone())
+            heavy.append(ctx.heavy_calls > calls)
+            del r, _a
+    lens = torch.diff(info["raster_isect_offsets"].reshape(-1))
+    assert int(lens.max()) > ctx.heavy_flag_len  # long lists in both scenes: round 4's rule turned heavy tiles on for either
+    (lkey,) = list(ctx.long_walks)
+    print(cluster, "heavy tiles per call:", heavy, "walk countdown:", ctx.long_walks[lkey], "longest list:", int(lens.max()))
+    assert heavy[1] or heavy[2]  # (on by the list length until a forward has reported)
+    if cluster == "faint":
+        assert all(heavy[2:]) and ctx.long_walks[lkey] > 0
+    else:
+        assert not any(heavy[4:]) and ctx.long_walks[lkey] == 0
+    for im in images[1:]:
+        assert rel_err(im, images[0]) < 2e-6
+
+
 def test_full_size_cfg4_whole_frame_and_all_gradients_vs_oracle():
     """BASELINE.json's headline input itself -- 1M Gaussians, 1920x1080, SH 3, 7.2M intersections --
     forward and backward against the oracle on the WHOLE frame (torch projection / SH / sort + C
