@@ -1724,10 +1724,11 @@ def test_compact_checkpoint_slots_same_gradients_a_fraction_of_the_buffer(step_c
 
 
 def test_launch_policies_the_host_picks_per_shape_change_no_result():
-    """Round-4 policies that depend on what a shape's earlier calls reported: equal numbers of tiles per XCD without the
+    """Policies that depend on what a shape's earlier calls reported: equal numbers of tiles per XCD without the
     cost pass (`balance_bands = 2`, after eight calls without a long tile list), issue priorities for the longest jobs
-    (`prio_fwd` / `prio_bwd`), equal ROW bands (`balance_bands = 0`, rounds 1-3).  Same image bit for bit, same
-    gradients up to the order of float atomics, whichever is on."""
+    (`prio_fwd` / `prio_bwd`), equal ROW bands (`balance_bands = 0`, rounds 1-3), the finer content thresholds of shapes that
+    showed an uneven scene (round 5).  Same image bit for bit, same gradients up to the order of float atomics, whichever
+    is on."""
     from freegaussian_amd.rasterization import rasterize_gauss_params
 
     sc = synthetic_scene(120_000, 1920, 1080, n_views=1, sh_degree=3, seed=13, log_scale_mean=math.log(0.02))
@@ -1755,7 +1756,13 @@ def test_launch_policies_the_host_picks_per_shape_change_no_result():
     assert even.even_calls[lkey] >= 8 and even.even_shape(lkey) and not base.even_shape(lkey)
     rows = ops.RasterContext(env={}, policy=ops.launch_policy(balance_bands=0))
     r2, g2 = run(rows, 2)
-    for r, g in ((r1, g1), (r2, g2)):
+    # round 5: a shape that showed an uneven scene lately gets finer content thresholds (the jobs change, no pixel's walk does)
+    fine = ops.RasterContext(env={})
+    run(fine, 1)
+    fine.uneven_left[lkey] = 8
+    r3, g3 = run(fine, 2)
+    assert fine.uneven_shape(lkey) and not even.uneven_shape(lkey)
+    for r, g in ((r1, g1), (r2, g2), (r3, g3)):
         assert torch.equal(r, r0)
         diff = {k: rel_l2(g[k], g0[k]) for k in g0}
         assert all(v < 1e-5 for v in diff.values()), diff
