@@ -209,6 +209,8 @@ class RasterContext:
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
         self.long_walks = {}  # shape -> calls left for which a reported long walk (a strip beyond 2560 entries) counts
+        self.workspace_pool = e.get("FG_WORKSPACE_POOL", "1") != "0"
+        self._workspaces = {}  # (kind, device) -> [(uint8 buffer, its storage's use count when nobody else holds it)]
         # The forward's content thresholds (fg_raster_config::split4_fwd / split2_fwd: a tile is cut into four / two strip
         # jobs when its list is longer than that many 65536ths of all lists: 20 / 16 = 2.5 x / 2.0 x the mean at 8160 tiles)
         # are tuned on even scenes, where finer cuts only repeat the staging.  On a scene with a cluster the launch is full
@@ -270,6 +272,44 @@ class RasterContext:
         # is needed to rebuild the coefficient gradient) to the sink instead of writing the dense [N,K,3]
         # coefficient gradient; `colors.grad` is then filled by the exchange, not by autograd.
         self.color_grad_sink = None
+
+    def workspace(self, kind: str, numel: int, dtype, dev) -> torch.Tensor:
+        """A buffer of ``numel`` elements for the one-call path's ``keep`` / ``tmp`` workspace, from a small pool this
+        context owns (FG_WORKSPACE_POOL=0: a fresh ``torch.empty`` per call, rounds 4's way).
+
+        Why not the caching allocator alone: the workspaces are its largest blocks (0.4-0.8 GB at 1M / 1080p).  A refinement
+        step allocates hundreds of small tensors, some of them carved out of the cached block a workspace came from -- and
+        the step behind the refinement has to ask the device for a new segment of that size: one hipMalloc of 757 MB,
+        usually 1 ms, 17 ms in two of four box visits (scripts/refine_step_bench.py, REFINE_DIAG=1); keeping the allocator
+        from splitting large blocks (max_split_size_mb) trades that for misses whenever two calls' sizes differ by more
+        than 20 MB.  The pool hands out a VIEW of a buffer nobody else refers to any more -- the storage's use count is
+        back at what it was when the buffer was made: outputs, ``info`` tensors and the autograd node's saved tensors are
+        views of ``keep`` and keep it out of circulation exactly as long as they live -- that is at least as large as asked
+        for and at most 30 % (+ 32 MB) larger; else a new one with 5 % to spare.  At most four buffers per kind and device;
+        the oldest unused one goes first.  Same-stream reuse only (as the caching allocator without record_stream); never
+        under a stream capture."""
+        use_count = getattr(torch._C, "_storage_Use_Count", None)
+        # (under a stream capture the allocator's private pool of the graph is the only right place: a replay writes where the
+        # capture's tensors lived, whoever holds that memory by then)
+        if not self.workspace_pool or use_count is None or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            return torch.empty(numel, dtype=dtype, device=dev)
+        item = torch.empty(0, dtype=dtype).element_size()
+        nbytes = numel * item
+        pool = self._workspaces.setdefault((kind, str(dev)), [])
+        for i, (buf, idle) in enumerate(pool):
+            if nbytes <= buf.numel() <= int(1.3 * nbytes) + (32 << 20) and use_count(buf.untyped_storage()._cdata) == idle:
+                pool.append(pool.pop(i))  # (most recently used last)
+                return buf[:nbytes].view(dtype)
+        buf = torch.empty((int(nbytes * 1.05) + (2 << 20) - 1) // (2 << 20) * (2 << 20), dtype=torch.uint8, device=dev)
+        pool.append((buf, use_count(buf.untyped_storage()._cdata)))
+        if len(pool) > 4:
+            for i, (old, idle) in enumerate(pool[:-1]):
+                if use_count(old.untyped_storage()._cdata) == idle:
+                    pool.pop(i)
+                    break
+            else:
+                pool.pop(0)  # (all in use: the pool forgets the oldest; its users keep it alive)
+        return buf[:nbytes].view(dtype)
 
     def uneven_shape(self, lkey) -> bool:
         """Has one of the shape's last eight calls shown a tile list beyond three times the mean?  Then the forward's content
@@ -1700,8 +1740,8 @@ class _RasterStep(torch.autograd.Function):
                    near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")
-            keep = torch.empty((L.keep_bytes + 3) >> 2, dtype=torch.float32, device=dev)
-            tmp = torch.empty(max(L.tmp_bytes, 8), dtype=torch.uint8, device=dev)
+            keep = rctx.workspace("keep", (L.keep_bytes + 3) >> 2, torch.float32, dev)
+            tmp = rctx.workspace("tmp", max(L.tmp_bytes, 8), torch.uint8, dev)
             count_slot, count_ptr = _count_slot()
             io = _lib.StepIO()
             io.means, io.quats, io.d_quats, io.scales, io.d_scales = _ptr(means), _ptr(quats), _ptr(d_quats), _ptr(scales), _ptr(d_scales)

@@ -16,13 +16,6 @@ import os
 import sys
 import time
 
-# The step behind a refinement asked the allocator for a NEW 757 MB segment in every run (REFINE_DIAG=1 shows it): the
-# refinement's small allocations -- new parameter tensors, optimizer state -- had been carved out of the cached block that the
-# raster step's workspace comes from, and some stay.  Usually 1 ms, 17 ms in two of the round's four visits.  A training
-# process that keeps torch's caching allocator from splitting its largest blocks does not pay it.
-for _v in ("PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_HIP_ALLOC_CONF"):
-    os.environ.setdefault(_v, "max_split_size_mb:256")
-
 import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
