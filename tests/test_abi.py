@@ -337,3 +337,37 @@ def test_heavy_tiles_follow_the_walks_the_forward_reports_host_logic(monkeypatch
     assert not call(100, 2000)  # below the flag length nothing turns it on
     ring[ops._RING_WORDS * 100 + 13] = 5000
     assert not call(101, 2000) and call(102, 12_000)
+
+
+def test_workspace_pool_hands_out_only_buffers_nobody_refers_to_host_logic():
+    """ops.RasterContext.workspace: the one-call path's `keep` / `tmp` buffers from a pool of the context's own.  A buffer is
+    handed out again only when every view of its storage is gone (outputs, info tensors and saved tensors are views of
+    `keep`), for requests it fits within 30 % (+ 32 MB); at most four per kind and device.  CPU tensors: same logic."""
+    import torch
+
+    from freegaussian_amd import ops
+
+    if not hasattr(torch._C, "_storage_Use_Count"):
+        pytest.skip("this torch has no torch._C._storage_Use_Count: the pool is bypassed")
+    ctx, cpu = ops.RasterContext(env={}), torch.device("cpu")
+    a = ctx.workspace("keep", 100_000, torch.float32, cpu)
+    assert a.dtype == torch.float32 and a.numel() == 100_000
+    first = a.data_ptr()
+    view = a[100:200].view(torch.int32)  # (what an output or a saved tensor is)
+    b = ctx.workspace("keep", 100_000, torch.float32, cpu)
+    assert b.data_ptr() != first  # the first is still referred to
+    del a
+    c = ctx.workspace("keep", 100_000, torch.float32, cpu)
+    assert c.data_ptr() not in (first, b.data_ptr())  # ... by `view` alone, still
+    del view
+    d = ctx.workspace("keep", 99_000, torch.float32, cpu)  # a slightly smaller request: the refinement's new N
+    assert d.data_ptr() == first
+    e = ctx.workspace("tmp", 400_000, torch.uint8, cpu)
+    assert e.dtype == torch.uint8 and e.data_ptr() not in (first, b.data_ptr(), c.data_ptr())  # pools per kind
+    del d
+    big = ctx.workspace("keep", 100_000_000, torch.float32, cpu)  # far beyond any pooled buffer: a new one
+    assert big.numel() == 100_000_000 and len(ctx._workspaces[("keep", "cpu")]) == 4
+    more = ctx.workspace("keep", 300_000_000, torch.float32, cpu)
+    assert len(ctx._workspaces[("keep", "cpu")]) == 4 and more.numel() == 300_000_000  # the oldest unused one made room
+    off = ops.RasterContext(env={"FG_WORKSPACE_POOL": "0"})
+    assert off.workspace("keep", 10, torch.float32, cpu).numel() == 10 and not off._workspaces
