@@ -124,7 +124,7 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
             batch = {"image": gt_image} if mask is None else {"image": gt_image, "mask": mask}
             loss_dict = model.get_loss_dict(out, batch)
             loss = loss_dict["main_loss"] + loss_dict["scale_reg"]
-            gt = model.composite_with_background(model.get_gt_img(gt_image), out["background"])
+            gt = None  # (composited below, only on the steps whose metrics are read)
             loss.backward()
     if grad_sync is not None:
         grad_sync(model)
@@ -142,4 +142,6 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     if metrics_every > 1 and step % metrics_every != 0:
         return {"gaussian_count": model.num_points}
     with torch.no_grad():
+        if gt is None:
+            gt = model.composite_with_background(model.get_gt_img(gt_image), out["background"])
         return {"loss": float(loss), "psnr": float(psnr(out["rgb"], gt)), "gaussian_count": model.num_points}

@@ -21,7 +21,7 @@ from torch import nn
 
 from .deform import FreeGaussianControllableModel, FreeGaussianDeformableModel
 from .rasterization import num_sh_bases, rasterization
-from .utils import get_viewmat, random_quat_tensor, resize_image, transform_points
+from .utils import get_viewmat, knn_mean_distance, random_quat_tensor, resize_image, transform_points
 
 
 @dataclass
@@ -134,7 +134,11 @@ class FreeGaussianModel(nn.Module):
     """Gaussian parameter store + deform/control MLPs + ``get_outputs``."""
 
     def __init__(self, config: Optional[FreeGaussianModelConfig] = None, num_points: Optional[int] = None,
-                 seed_points: Optional[torch.Tensor] = None, is_blender: bool = True):  # fmt: skip
+                 seed_points: Optional[torch.Tensor] = None, is_blender: bool = True,
+                 init_scales: Optional[float] = None):  # fmt: skip
+        """``init_scales``: None = the reference's initial scales, the mean distance to the three nearest neighbours
+        (:158-162; a tree query over all points: a minute at 1M); a float = that log-scale everywhere, for harnesses that
+        overwrite the scales anyway."""
         super().__init__()
         self.config = config or FreeGaussianModelConfig()
         if seed_points is not None:
@@ -148,7 +152,8 @@ class FreeGaussianModel(nn.Module):
         self.gauss_params = nn.ParameterDict(
             {
                 "means": nn.Parameter(means),
-                "scales": nn.Parameter(torch.full((n, 3), -4.0)),
+                "scales": nn.Parameter(torch.log(knn_mean_distance(means, 3)).repeat(1, 3) if init_scales is None
+                                       else torch.full((n, 3), float(init_scales))),
                 "quats": nn.Parameter(random_quat_tensor(n)),
                 "features_dc": nn.Parameter(torch.rand(n, 3)),
                 "features_rest": nn.Parameter(torch.zeros(n, dim_sh - 1, 3)),

@@ -114,6 +114,29 @@ def random_quat_tensor(n: int) -> torch.Tensor:
                         b * torch.sin(2 * math.pi * w), b * torch.cos(2 * math.pi * w)], dim=-1)  # fmt: skip
 
 
+def knn_mean_distance(x: torch.Tensor, k: int = 3) -> torch.Tensor:
+    """[N,3] -> [N,1] mean Euclidean distance to the k nearest OTHER points: the initial scale of every Gaussian
+    (reference freegaussian_model.py:158-162 through ``k_nearest_sklearn``, :293-311 -- sklearn's NearestNeighbors with
+    k + 1 neighbours, the point itself dropped).  The same tree query when sklearn imports; otherwise exact brute force
+    in row chunks (the two agree to rounding: both are exact searches).  Fewer than k + 1 points: the neighbours there are."""
+    n = x.shape[0]
+    if n <= 1:
+        return torch.ones(n, 1)
+    kk = min(k, n - 1)
+    xc = x.detach().cpu().float()
+    try:
+        from sklearn.neighbors import NearestNeighbors
+
+        d, _ = NearestNeighbors(n_neighbors=kk + 1, algorithm="auto", metric="euclidean").fit(xc.numpy()).kneighbors(xc.numpy())
+        return torch.from_numpy(d[:, 1:].astype("float32")).mean(dim=-1, keepdim=True)
+    except ImportError:
+        out = torch.empty(n, 1)
+        for i in range(0, n, 2048):
+            d = torch.cdist(xc[i : i + 2048], xc)
+            out[i : i + 2048, 0] = d.topk(kk + 1, dim=1, largest=False).values[:, 1:].mean(dim=1)
+        return out
+
+
 def bilinear_interp(image: torch.Tensor, x: torch.Tensor, y: torch.Tensor, reference_quirk: bool = False):
     """Sample [B,H,W,C] at [B,N] pixel coordinates -> [B,N,C].
 

@@ -22,7 +22,7 @@ out = {}
 for layout in layouts:
     sc = apply_layout(synthetic_scene(n, W, H, n_views=N_VIEWS, sh_degree=3, seed=42), layout)
     cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9)
-    model = FreeGaussianModel(cfg, seed_points=sc.means)
+    model = FreeGaussianModel(cfg, seed_points=sc.means, init_scales=-4.0)
     with torch.no_grad():
         gp = model.gauss_params
         gp["scales"].copy_(sc.scales.log())

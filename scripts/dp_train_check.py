@@ -30,7 +30,7 @@ torch.manual_seed(0)
 cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=int(os.environ.get("FG_DP_WARM_UP", 10**9)), refine_start=10,
                               refine_every=10, reset_alpha_every=30, densify_grad_thresh=1e-4, stop_screen_size_at=0,
                               sh_degree_interval=1)
-model = FreeGaussianModel(cfg, seed_points=sc.means)
+model = FreeGaussianModel(cfg, seed_points=sc.means, init_scales=-4.0)
 with torch.no_grad():
     gp = model.gauss_params
     gp["scales"].copy_(sc.scales.log())

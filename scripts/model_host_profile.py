@@ -18,7 +18,7 @@ H = int(sys.argv[3]) if len(sys.argv) > 3 else 1080
 dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
 cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=10**9)
-model = FreeGaussianModel(cfg, seed_points=sc.means)
+model = FreeGaussianModel(cfg, seed_points=sc.means, init_scales=-4.0)
 with torch.no_grad():
     gp = model.gauss_params
     gp["scales"].copy_(sc.scales.log())

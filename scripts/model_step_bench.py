@@ -24,7 +24,7 @@ dev = torch.device("cuda", 0)
 sc = synthetic_scene(n, W, H, n_views=8, sh_degree=3, seed=42)
 cfg = FreeGaussianModelConfig(background_color="random", num_downscales=0, warm_up=int(os.environ.get("FG_MODEL_WARM_UP", 10**9)),  # (0: the deformation MLP runs)
                               fused_front_end=not os.environ.get("FG_UNFUSED"))
-model = FreeGaussianModel(cfg, seed_points=sc.means)
+model = FreeGaussianModel(cfg, seed_points=sc.means, init_scales=-4.0)
 with torch.no_grad():
     gp = model.gauss_params
     gp["scales"].copy_(sc.scales.log())

@@ -1283,7 +1283,7 @@ def _model_and_camera(n=4000, W=160, H=96, step=4000, training=True, log_scale=-
 
     torch.manual_seed(0)
     cfg = FreeGaussianModelConfig(background_color="white", num_downscales=0, warm_up=3000)
-    model = FreeGaussianModel(cfg, seed_points=(torch.rand(n, 3) - 0.5) * 2.0)
+    model = FreeGaussianModel(cfg, seed_points=(torch.rand(n, 3) - 0.5) * 2.0, init_scales=log_scale)
     with torch.no_grad():
         model.gauss_params["scales"].fill_(log_scale)
         model.gauss_params["features_rest"].normal_(0, 0.1)
@@ -2113,7 +2113,7 @@ def test_cfg5_control_stage2_matches_oracle_host_path(n, W, H):
     init_cam = type(cam)(cam.camera_to_worlds, cam.fx, cam.fy, cam.cx, cam.cy, cam.width, cam.height,
                          times=torch.tensor([[0.0]]))  # fmt: skip
     cfg = FreeGaussianModelConfig(background_color="black")
-    cm_cpu = FreeGaussianControlModel(mask, init_cam, config=cfg, seed_points=base.means.detach().clone())
+    cm_cpu = FreeGaussianControlModel(mask, init_cam, config=cfg, seed_points=base.means.detach().clone(), init_scales=-4.0)
     cm_cpu.load_state_dict(base.state_dict(), strict=False)
     with torch.no_grad():
         for p in cm_cpu.control.parameters():
