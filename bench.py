@@ -406,21 +406,62 @@ def gpu_clocks():
         return {"error": repr(e)[:120]}
 
 
-def graph_only(args):
-    """Child-process leg: the step replayed as one hipGraph; prints one JSON object."""
-    import torch
+def trained_scene_for(spec):
+    """``trained:<file>``: a ``trained_scene.npz`` of scripts/train_e2e.py.  ``trained:auto`` (or ``trained``): the file
+    ``data/trained_scene_r06.npz`` when it is there (the round's reference-schedule run, deformation net included; 46 MB, not
+    in the history), else the scene is trained HERE, in this process, before anything is timed: scripts/train_e2e.py's run from
+    random_init on the reference's schedule for 7000 steps with the deformation net left off (``warm_up`` beyond the run: the
+    target is static, and the net -- 25 of every 27 ms of a step behind step 3000 -- is a dense MLP outside the raster path;
+    ~15 s instead of ~110).  -> (Scene, provenance dict)."""
+    from freegaussian_amd.scenes import load_trained_scene
 
-    from freegaussian_amd.graphed import GraphedRaster
+    path = spec.split(":", 1)[1] if ":" in spec else "auto"
+    if path == "auto":
+        cand = os.path.join(ROOT, "data", "trained_scene_r06.npz")
+        if os.path.exists(cand) and not os.environ.get("FG_BENCH_TRAIN_HERE"):
+            path = cand
+    if path != "auto":
+        return load_trained_scene(path), {"source": os.path.relpath(path, ROOT)}
+    import tempfile
+
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    import train_e2e as E
+
+    out_dir = tempfile.mkdtemp(prefix="fg_trained_")
+    t0 = time.perf_counter()
+    _, rep, _ = E.train(steps=7000, warm_up=10**9, eval_at=(7000,), out_dir=out_dir, log=lambda *a: None, save_checkpoint=False)
+    prov = {"source": "trained in this process: scripts/train_e2e.py, 7000 steps from random_init, reference schedule, deformation net off",
+            "train_seconds": round(time.perf_counter() - t0, 1), "heldout_psnr_db": rep["evals"][-1]["heldout_psnr"],
+            "N_final": rep["N_final"], "train_step_gpu_ms": rep["step_time_gpu_ms"], "policy_counters_end": rep["policy_counters"]["end"]}  # fmt: skip
+    return load_trained_scene(os.path.join(out_dir, "trained_scene.npz")), prov
+
+
+def make_scene(args):
+    """The scene `--layout` names (+ provenance for the trained one); sets args.n_gauss / width / height from a trained file."""
     from freegaussian_amd.scenes import apply_layout, synthetic_scene
-    from freegaussian_amd.viewdp import FlatGaussianParams
 
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
+    if args.layout.split(":")[0] == "trained":
+        scene, prov = trained_scene_for(args.layout)
+        args.n_gauss, args.width, args.height, args.sh_degree = scene.means.shape[0], scene.width, scene.height, scene.sh_degree
+        return scene, prov
     scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
     try:
         apply_layout(scene, args.layout)
     except ValueError as e:
         raise SystemExit(f"--layout: {e}")
+    return scene, None
+
+
+def graph_only(args):
+    """Child-process leg: the step replayed as one hipGraph; prints one JSON object."""
+    import torch
+
+    from freegaussian_amd.graphed import GraphedRaster
+    from freegaussian_amd.viewdp import FlatGaussianParams
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    scene, _ = make_scene(args)
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)
@@ -470,7 +511,7 @@ def clustered_children(args):
     import subprocess
 
     res_all = {}
-    for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2", "needles:0.3:10", "clustered:0.5:0.4+needles:0.3:10"):
+    for lay in ("clustered:0.5:0.4", "clustered:0.8:0.2", "needles:0.3:10", "clustered:0.5:0.4+needles:0.3:10", "trained:auto"):
         left = child_budget_left()
         if left < 20:
             res_all[lay] = {"error": "skipped: the children's shared time budget is spent (FG_BENCH_CHILD_BUDGET_S)"}
@@ -488,6 +529,10 @@ def clustered_children(args):
                             "long_segment_calls": c["config"].get("long_segment_calls"),
                             "heavy_tile_steps": c["config"].get("heavy_tile_steps"), "host_step_ms": c.get("host_step_ms"),
                             "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region")}  # fmt: skip
+            for k in ("N", "V", "I", "scene", "scene_statistics"):  # (what the trained layout is: its own N, cameras, shapes)
+                if lay.startswith("trained") and k in c["config"]:
+                    res_all[lay][k] = c["config"][k]
+            res_all[lay]["host_step_ms_p99"] = (c.get("host_step_ms") or {}).get("p99")
         except Exception as e:
             res_all[lay] = {"error": repr(e)[:200]}
     return res_all
@@ -540,7 +585,6 @@ def main(argv=None):
     import torch.distributed as dist
 
     from freegaussian_amd import ops, rasterization
-    from freegaussian_amd.scenes import apply_layout, synthetic_scene
     from freegaussian_amd.viewdp import FlatGaussianParams
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -566,11 +610,7 @@ def main(argv=None):
         else:
             dist.init_process_group(backend, timeout=tmo)
 
-    scene = synthetic_scene(args.n_gauss, args.width, args.height, n_views=N_VIEWS, sh_degree=args.sh_degree, seed=42)
-    try:
-        apply_layout(scene, args.layout)
-    except ValueError as e:
-        raise SystemExit(f"--layout: {e}")
+    scene, scene_prov = make_scene(args)
     W, H = scene.width, scene.height
     params = FlatGaussianParams.from_scene(scene, dev)  # flat parameter + flat gradient buffers
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)  # all 8 poses resident
@@ -726,6 +766,11 @@ def main(argv=None):
     dt = float(t.item())
 
     N = args.n_gauss
+    scene_stats = None
+    if scene_prov is not None:
+        from freegaussian_amd.scenes import scene_statistics
+
+        scene_stats = scene_statistics(scene, info["radii"])
     V = int((info["radii"] > 0).sum())
     I_raster = int(info["raster_flatten_ids"].numel())  # entries the compositing walks (footprint rectangles)
     I = int(info["flatten_ids"].numel())  # the reference's list length (radius boxes): SURVEY section 8d's I
@@ -852,10 +897,12 @@ def main(argv=None):
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": f"north-star cfg4: {N} Gaussians, {W}x{H}, SH degree {args.sh_degree}, 1 view per rank per step, "
+            "workload": (f"north-star cfg4: {N} Gaussians" if scene_prov is None else f"TRAINED scene ({N} Gaussians, its own cameras)")
+            + f", {W}x{H}, SH degree {args.sh_degree}, 1 view per rank per step, "
             + ("view = rank (fixed)" if args.fixed_view else f"view = (rank + step) mod {N_VIEWS} around the 8-view ring")
             + ", fwd+bwd, RGB, absgrad" + (f", {'RCCL' if backend == 'nccl' else backend} gradient exchange ({exchange})" if world > 1 else ""),
             "layout": args.layout,
+            **({} if scene_prov is None else {"scene": scene_prov, "scene_statistics": scene_stats}),
             "N": N, "V": V, "I": I, "P": P, "T": T, "k": k,
             "I_raster": I_raster,
             "I_note": "I = tile intersections of the reference algorithm (radius-box rectangles; the formulas of SURVEY "
@@ -902,7 +949,7 @@ def main(argv=None):
         },
         # host-side time between consecutive returns of step(): the host waits for the GPU once per step (the
         # list length), so these follow the GPU's progress; a stall of the host or the driver shows up here
-        "host_step_ms": (lambda d: {"median": sorted(d)[len(d) // 2], "max": max(d), "argmax": d.index(max(d)),
+        "host_step_ms": (lambda d: {"median": sorted(d)[len(d) // 2], "p90": pct(d, 0.9), "p99": pct(d, 0.99), "max": max(d), "argmax": d.index(max(d)),
                                     "over_1.5x_median": sum(1 for x in d if x > 1.5 * sorted(d)[len(d) // 2])})(
             [(b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:])]),
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},

@@ -181,8 +181,9 @@ def room_scene(n_gauss: int = 200_000, width: int = 1920, height: int = 1080, n_
                seed: int = 42, focal: Optional[float] = None):  # fmt: skip
     """-> (Scene, meta).  The hidden target model of scripts/train_e2e.py: ``n_gauss`` anisotropic Gaussians laid out as
     surfaces inside [-4,4]^3 (y points up on screen with `look_at_viewmat`'s default, the floor at y = -1.6), ``n_views`` cameras at mixed radii -- two rings inside
-    the room, a ring above it looking down, and poses AMONG the objects looking outwards; every fifth view is held out.
-    ``meta``: ``train`` / ``test`` view indices, ``times`` [V] in [0,1), ``parts`` (name, first, count)."""
+    the room, a ring above it looking down, and poses AMONG the objects looking outwards; a fifth of the views is held out
+    (every fourth pose of each kind).  ``meta``: ``train`` / ``test`` view indices, ``times`` [V] (four shared instants),
+    ``parts`` (name, first, count), ``kinds`` (name, first view, count)."""
     g = torch.Generator().manual_seed(seed)
     sob = torch.quasirandom.SobolEngine(2, scramble=True, seed=seed)
     floor_y, top_y = -1.6, 2.4
@@ -310,14 +311,20 @@ def room_scene(n_gauss: int = 200_000, width: int = 1920, height: int = 1080, n_
                 if inner:  # ... and the poses among the objects look away from the one they stand next to
                     h = math.hypot(d[0], d[2]) or 1.0
                     targets[i] = [e[0] + 3.0 * d[0] / h, -0.9, e[2] + 3.0 * d[2] / h]
-    # interleave the four kinds so that "every fifth view held out" takes some of each
-    order = torch.randperm(n_views, generator=g).tolist()
-    vms = torch.stack([look_at_viewmat(torch.tensor(eyes[i]), torch.tensor(targets[i])) for i in order])
+    vms = torch.stack([look_at_viewmat(torch.tensor(eyes[i]), torch.tensor(targets[i])) for i in range(n_views)])
     K = torch.tensor([[focal, 0.0, width / 2.0], [0.0, focal, height / 2.0], [0.0, 0.0, 1.0]])
     scene = Scene(P, Q, S, opac, colors, sh_degree, vms, K.expand(n_views, 3, 3).clone(), width, height)
-    test = list(range(4, n_views, 5))
+    # held out: every fourth (rings) / eighth (top, inner) pose of each kind's own sequence -- its neighbours either side stay
+    # in the training set --, a fifth of the views in all -- the "every k-th frame of the trajectory" protocol
+    kinds = [("ring", 0, n_ring), ("mid", n_ring, n_mid), ("top", n_ring + n_mid, n_top), ("inner", n_ring + n_mid + n_top, n_inner)]
+    test = []
+    for j, (_, first_v, cnt_v) in enumerate(kinds):
+        test += [first_v + i for i in range(1 + j, cnt_v, 4 if j < 2 else 8)]  # (ring and mid: every 4th; top and inner: every 8th)
+    # time stamps: a multi-view rig (the DyNeRF setting of BASELINE.json) -- four instants, every one seen by a quarter of
+    # the cameras of each kind; the target itself does not move
     meta = {"train": [i for i in range(n_views) if i not in test], "test": test,
-            "times": [i / n_views for i in range(n_views)], "parts": parts}  # fmt: skip
+            "times": [(i % 4) / 4.0 for i in range(n_views)], "parts": parts,
+            "kinds": [(k, f, c) for k, f, c in kinds]}  # fmt: skip
     return scene, meta
 
 

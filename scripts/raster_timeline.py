@@ -22,9 +22,14 @@ from freegaussian_amd.scenes import synthetic_scene  # noqa: E402
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 sc = synthetic_scene(n, 1920, 1080, n_views=8, sh_degree=3, seed=42)
-if len(sys.argv) > 3 and sys.argv[3]:
+if len(sys.argv) > 3 and sys.argv[3].startswith("trained:"):  # trained:<trained_scene.npz of scripts/train_e2e.py>
+    from freegaussian_amd.scenes import load_trained_scene
+
+    sc = load_trained_scene(sys.argv[3].split(":", 1)[1])
+elif len(sys.argv) > 3 and sys.argv[3]:
     frac, ball = (float(v) for v in sys.argv[3].split(":"))
     sc.means[: int(frac * n)] *= ball / 2.0
+TL_VIEW = int(os.environ.get("FG_TL_VIEW", "4"))
 dev = torch.device("cuda", 0)
 ins = [t.to(dev).requires_grad_(True) for t in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
 lib = _lib.load()
@@ -39,7 +44,7 @@ info = None
 
 def step(view):
     global info
-    r, a, info = rasterization(*ins, sc.viewmats[view:view + 1].to(dev), sc.Ks[view:view + 1].to(dev), 1920, 1080,
+    r, a, info = rasterization(*ins, sc.viewmats[view:view + 1].to(dev), sc.Ks[view:view + 1].to(dev), sc.width, sc.height,
                                sh_degree=3, absgrad=True)
     r.backward(torch.randn_like(r))
     torch.cuda.synchronize()
@@ -48,7 +53,7 @@ def step(view):
 for v in range(4):
     step(v)
 lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
-step(4)
+step(TL_VIEW)
 cnt = lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
 rec = buf[:min(cnt, CAP)]
 t0, t1, hw, what = rec[:, 0].astype(np.int64), rec[:, 1].astype(np.int64), rec[:, 2], rec[:, 3]

@@ -108,7 +108,7 @@ def counters(ctx):
 
 def train(steps: int = 7000, n_target: int = 200_000, width: int = 1920, height: int = 1080, seed: int = 42,
           eval_at=(1000, 3000, 7000), warm_up: int = 3000, graphed: bool = False, out_dir=None, num_random: int = 50_000,
-          log=print, config_overrides=None, device=None):  # fmt: skip
+          log=print, config_overrides=None, device=None, save_checkpoint=True):  # fmt: skip
     from freegaussian_amd import harness, ops
     from freegaussian_amd.model import FreeGaussianModel, FreeGaussianModelConfig
     from freegaussian_amd.scenes import room_scene
@@ -207,7 +207,8 @@ def train(steps: int = 7000, n_target: int = 200_000, width: int = 1920, height:
         os.makedirs(out_dir, exist_ok=True)
         from freegaussian_amd import io as fio
 
-        fio.save_checkpoint(out_dir, steps, model, opts)
+        if save_checkpoint:
+            fio.save_checkpoint(out_dir, steps, model, opts)
         bench_views = train_ids[:: max(1, len(train_ids) // 8)][:8]
         export_scene(model, scene, bench_views, meta["times"][bench_views[0]], os.path.join(out_dir, "trained_scene.npz"))
         report["bench_views"] = bench_views
