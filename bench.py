@@ -600,7 +600,15 @@ def main(argv=None):
         raise SystemExit(f"rank {rank}: local rank {local_rank} but only {ndev} GPU(s) visible; RCCL ranks never share a device")
     dev = torch.device("cuda", local_rank % max(ndev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    force = world == 1 and os.environ.get("FG_DP_FORCE_COLLECTIVES") == "1"
+    if force:
+        # every collective call site of the step on ONE rank (viewdp._collective_world): a 1-rank communicator exercises
+        # ProcessGroupNCCL's stream / work-handle / lifetime semantics on the one GPU of a box, not the ring kernels
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+    if world > 1 or force:
         # RCCL ("nccl") over xGMI is the product path; FG_BENCH_BACKEND=gloo only exists so that the
         # N>1 control flow can be exercised on a 1-GPU box (ranks then share the device).  A bounded
         # timeout turns a desynchronised collective into an error instead of a hung box.
@@ -616,7 +624,7 @@ def main(argv=None):
     vms, Ks = scene.viewmats.to(dev), scene.Ks.to(dev)  # all 8 poses resident
     vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(1)).to(dev)
 
-    exchange = os.environ.get("FG_EXCHANGE", "factored") if world > 1 else "none"
+    exchange = os.environ.get("FG_EXCHANGE", "factored") if (world > 1 or force) else "none"
     marks = []  # per step: HIP events at start / after forward / after backward / after the exchange
     counter = [0]
 
@@ -959,7 +967,7 @@ def main(argv=None):
                           "same views with events around every call (untimed; stage_pass_ms_per_step is that pass's own wall "
                           "time per step: sixteen event records per step cost a few percent of it)"),
     }  # fmt: skip
-    if world > 1:
+    if exchange != "none":
         xm = pct(t_xchg, 0.5)
         out["exchange"] = {
             "kind": exchange,
@@ -972,6 +980,9 @@ def main(argv=None):
             else f"plain: one all-reduce of {params.flat_grad.numel() * 4} B",
             "fallback": fallback_note,
         }  # fmt: skip
+        out["exchange"]["head_all_reduce_slices"] = int(os.environ.get("FG_DP_HEAD_SLICES", "4")) if exchange == "factored" else 1
+        out["exchange"]["forced_on_one_rank"] = bool(force)
+    if world > 1:
         out["per_rank_mpix_per_s"] = [args.steps * P / float(x.item()) / 1e6 for x in per_rank]
         out["per_rank_device"] = rank_devices
         out["distinct_devices"] = len({(d or {}).get("uuid") or (d or {}).get("local_device") for d in rank_devices or []})
@@ -986,7 +997,7 @@ def main(argv=None):
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)
             out["cpu_full_frame"] = cpu_full_frame(scene, view, args.sh_degree)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if world > 1 or force:
         dist.barrier()
         dist.destroy_process_group()
 

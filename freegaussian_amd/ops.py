@@ -1342,13 +1342,27 @@ class _Preprocess(torch.autograd.Function):
         if color_grad_sink is not None and sh_degree >= 0 and colors is not None:
             # factored form: 12 B of colour gradient per Gaussian instead of the 192-B coefficient row
             v_rgb = color_grad_sink("alloc", N, means.device)  # [N,3] or [N,6] (g | unit view direction)
-            _call("fg_preprocess_bwd_factored", N, _ptr(means), _ptr(quats), _ptr(scales), _ptr(opacities),
-                  _ptr(colors), sh_degree, k_stored, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height,
-                  eps2d, int(antialiased), _ptr(radii), _ptr(v_splats.contiguous()), _ptr(v_means2d), m2_stride,
-                  _ptr(None if v_depths is None else v_depths.contiguous()),
-                  _ptr(None if v_conics is None else v_conics.contiguous()), _ptr(v_means), _ptr(v_quats),
-                  _ptr(v_scales), _ptr(v_opac), _ptr(v_rgb), int(v_rgb.shape[1]), _ptr(v_extra), _ptr(sh_jac),
-                  _stream())  # fmt: skip
+            v_dep = None if v_depths is None else v_depths.contiguous().reshape(N)
+            v_con = None if v_conics is None else v_conics.contiguous().reshape(N, 3)
+            # The sink may ask for the pass in k launches over ranges of N (every Gaussian's row is independent of the others):
+            # it is told after each launch that the range's gradients are final -- the view-DP exchange starts reducing them
+            # while the later ranges are still being computed.  Range bounds on multiples of 1024 rows (16-byte aligned rows
+            # of every array).
+            k = int(color_grad_sink("slices", N) or 1)
+            bounds = [0, N] if k <= 1 or N < 4096 * k else sorted({0, N} | {(N * i // k) // 1024 * 1024 for i in range(1, k)})
+
+            def rows(t, n0, n1):
+                return None if t is None else t[n0:n1]
+
+            for n0, n1 in zip(bounds, bounds[1:]):
+                r = lambda t: _ptr(rows(t, n0, n1))  # noqa: E731
+                _call("fg_preprocess_bwd_factored", n1 - n0, r(means), r(quats), r(scales), r(opacities),
+                      r(colors), sh_degree, k_stored, int(with_depth), n_extra, _ptr(viewmat), _ptr(K), width, height,
+                      eps2d, int(antialiased), r(radii), r(v_splats), r(v_means2d), m2_stride, r(v_dep), r(v_con),
+                      r(v_means), r(v_quats), r(v_scales), r(v_opac), r(v_rgb), int(v_rgb.shape[1]), r(v_extra), r(sh_jac),
+                      _stream())  # fmt: skip
+                if len(bounds) > 2:
+                    color_grad_sink("slice", n0, n1)
             color_grad_sink("ready", v_rgb, means, viewmat, sh_degree, colors)
             return v_means, v_quats, v_scales, v_opac, None, v_extra, pose_grad(), None, None
         v_colors = _alloc_grad(colors) if colors is not None else None

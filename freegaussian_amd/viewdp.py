@@ -12,6 +12,7 @@ Sizing for xGMI (7 links x ~153 GB/s per GPU): 59 floats = 236 B per Gaussian, 2
 Gaussians, sent as one all-reduce so RCCL can use every link of the full mesh."""
 from __future__ import annotations
 
+import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -26,6 +27,17 @@ LAYOUT: Tuple[Tuple[str, Tuple[int, ...]], ...] = (
     ("colors", (16, 3)),
 )
 FLOATS_PER_GAUSSIAN = 59
+
+
+def _collective_world(group=None):
+    """(world size, take the collective code paths?).  The paths are taken when there is more than one rank -- or, with
+    ``FG_DP_FORCE_COLLECTIVES=1`` and an initialised process group, on ONE rank too: every collective call site of this file
+    then goes through the backend (a 1-rank ``nccl`` communicator exercises ProcessGroupNCCL's stream, work-handle and
+    tensor-lifetime semantics on the one GPU a box has -- not RCCL's ring kernels or the links)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return 1, False
+    world = dist.get_world_size(group)
+    return world, (world > 1 or os.environ.get("FG_DP_FORCE_COLLECTIVES") == "1")
 
 
 def _numel(shape):
@@ -130,15 +142,22 @@ class FlatGaussianParams:
 
         from . import _lib, ops
 
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        world, collective = _collective_world(group)
         n = self.n
         state = {}
+        # The 44-byte head (means, quats, scales, opacities gradients) is final range by range as the per-Gaussian backward
+        # runs: with ``head_slices`` = k > 1 that backward is launched as k grids over ranges of N and the all-reduce of a
+        # range's four blocks is issued -- from a side stream that waits for that launch alone -- while the later ranges are
+        # still being computed, instead of one all-reduce behind the whole backward (FG_DP_HEAD_SLICES, default 4 when
+        # collectives run; shared means only: with per-view means the head is accumulated by autograd afterwards).
+        head_slices = int(os.environ.get("FG_DP_HEAD_SLICES", "4")) if (collective and not per_view_means) else 1
+        state["head_works"] = []
 
         pf = 6 if per_view_means else 3
         stride = n * 6 if per_view_means else (n + 1) * 3
 
         def gather(payload):
-            if world > 1:
+            if collective:
                 gathered = torch.empty(world * stride, device=payload.device, dtype=torch.float32)
                 if dist.get_backend(group) == "nccl":
                     state["work"] = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
@@ -149,9 +168,34 @@ class FlatGaussianParams:
             else:
                 state["gathered"] = payload
 
+        def reduce_head_slice(n0, n1, event):
+            """All-reduce rows [n0, n1) of the four head blocks, ordered behind ``event`` (the launch that wrote them)."""
+            views = [self.grad_views[k][n0:n1] for k in ("means", "quats", "scales", "opacities")]
+            side = state.get("side")
+            if side is None:
+                side = state["side"] = torch.cuda.Stream(device=self.flat.device)
+            with torch.cuda.stream(side):
+                side.wait_event(event)
+                if dist.get_backend(group) == "nccl":
+                    # one group call for the four blocks (a launch per block would be serial latency on the ring)
+                    with dist._coalescing_manager(group=group, device=self.flat.device, async_ops=True) as cm:
+                        for v in views:
+                            dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group)
+                    state["head_works"].append(cm)
+                else:
+                    state["head_works"] += [dist.all_reduce(v, op=dist.ReduceOp.SUM, group=group, async_op=True) for v in views]
+
         def sink(what, *a):
             """Protocol with ops: "view" (per-Gaussian forward: the view is known), "records" (raster backward: the
             record gradients are final), "alloc" / "ready" (per-Gaussian backward, around fg_preprocess_bwd_factored)."""
+            if what == "slices":  # how many ranges of N the per-Gaussian backward should be launched in
+                return head_slices
+            if what == "slice":  # rows [n0, n1) of the head are final once the launch just enqueued has run
+                n0, n1 = a
+                ev = torch.cuda.Event()
+                ev.record()
+                reduce_head_slice(n0, n1, ev)
+                return None
             if what == "view":  # shared means: the camera position can be put in place during the forward
                 if not per_view_means:
                     viewmat, dev = a
@@ -202,7 +246,9 @@ class FlatGaussianParams:
             if "payload" not in state:
                 raise RuntimeError("factored_exchange: no SH-coloured rasterization backward ran inside the context")
             rest = self.flat_grad[: 11 * n]
-            work = dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
+            work = None
+            if collective and not state["head_works"]:
+                work = dist.all_reduce(rest, op=dist.ReduceOp.SUM, group=group, async_op=True)
             if "work" in state:
                 state["work"].wait()
             scale = 1.0 / world if average else 1.0
@@ -215,19 +261,22 @@ class FlatGaussianParams:
             self.params["colors"].grad = vc
             if work is not None:
                 work.wait()
-                if average:
-                    rest.div_(world)
+            for w in state["head_works"]:  # (issued on the side stream: wait() orders the CURRENT stream behind them)
+                w.wait()
+            if collective and average and world > 1:
+                rest.div_(world)
 
         return cm()
 
     def all_reduce_grads(self, average: bool = True, group=None) -> None:
         """Sum (then average) the flat gradient over all ranks: the one exchange step of a
         view-sharded iteration."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        world, collective = _collective_world(group)
+        if not collective:
             return
         dist.all_reduce(self.flat_grad, op=dist.ReduceOp.SUM, group=group)
-        if average:
-            self.flat_grad.div_(dist.get_world_size(group))
+        if average and world > 1:
+            self.flat_grad.div_(world)
 
 
 def all_reduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tensor, max_2dsize: torch.Tensor,
@@ -235,7 +284,7 @@ def all_reduce_densify_stats(xys_grad_norm: torch.Tensor, vis_counts: torch.Tens
     """Keep the densification statistics identical on every rank (reference accumulates them
     per step at freegaussian_model.py:379-392): sums for the gradient norm and visibility count,
     max for the largest screen-space radius.  In place."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_world(group)[1]:
         return
     packed = torch.stack([xys_grad_norm.float(), vis_counts.float()])
     dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
@@ -249,7 +298,7 @@ def shared_seed(seed: Optional[int] = None, group=None) -> int:
     and the random background (:651) draw the same numbers on every replica."""
     if seed is None:
         seed = int(torch.seed() % (2**31))
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if _collective_world(group)[1]:
         backend = dist.get_backend(group)
         dev = torch.device("cuda", torch.cuda.current_device()) if backend == "nccl" else torch.device("cpu")
         t = torch.tensor([seed], dtype=torch.int64, device=dev)
@@ -270,7 +319,8 @@ def all_reduce_model_grads(model: torch.nn.Module, average: bool = True, group=N
     -- Gaussian parameters and the deform / control MLPs -- goes through ONE all-reduce of a
     flattened copy.  Parameters without a gradient on this rank (e.g. nothing visible) are
     treated as zeros so that all ranks reduce the same layout."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    world, collective = _collective_world(group)
+    if not collective:
         return
     params = [p for p in model.parameters() if p.requires_grad]
     for p in params:
@@ -278,8 +328,8 @@ def all_reduce_model_grads(model: torch.nn.Module, average: bool = True, group=N
             p.grad = torch.zeros_like(p)
     flat = torch.cat([p.grad.reshape(-1) for p in params])
     dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
-    if average:
-        flat.div_(dist.get_world_size(group))
+    if average and world > 1:
+        flat.div_(world)
     off = 0
     for p in params:
         n = p.grad.numel()
@@ -325,6 +375,7 @@ class ModelViewDP:
             raise ValueError(f"sparse={self.sparse!r}: auto | always | never")
         self._sparse_plan = None  # (rows per rank, payload floats per row, N) of the next step's sparse blocks
         self.sparse_steps = self.dense_steps = self.sparse_overflows = 0
+        self.force_overflow_next = False  # tests: treat the next sparse step's blocks as truncated (the dense repeat runs)
 
     def _others(self):
         gp = getattr(self.model, "gauss_params", {})
@@ -356,13 +407,13 @@ class ModelViewDP:
         from . import _lib, ops
 
         model, group = self.model, self.group
-        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        world, collective = _collective_world(group)
         gp = model.gauss_params
         n = gp["means"].shape[0]
         state: Dict[str, object] = {}
 
         def gather(payload):
-            if world > 1:
+            if collective:
                 gathered = torch.empty(world * payload.numel(), device=payload.device, dtype=torch.float32)
                 if dist.get_backend(group) == "nccl":
                     work = dist.all_gather_into_tensor(gathered, payload, group=group, async_op=True)
@@ -426,16 +477,21 @@ class ModelViewDP:
             if "gathered" not in state:
                 raise RuntimeError("ModelViewDP.step: no SH-coloured raster backward ran inside the context")
             flat = self._flat
-            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) if world > 1 else None
+            work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True) if collective else None
             if state["work"] is not None:
                 state["work"].wait()
             pf, stride, lib = state["pf"], state["stride"], _lib.load()
             stream = torch.cuda.current_stream().cuda_stream
             blocks = state["gathered"].view(world, -1)
-            # every rank's count, from the gathered headers / trailers: the same numbers on every rank
-            counts = (blocks[:, 0] if state["form"] == "sparse" else blocks[:, -1]).contiguous().view(torch.int32).tolist()
+            # every rank's count, from the gathered headers / trailers: the same numbers on every rank.  The SPARSE form needs
+            # them on the host before it expands (a truncated block means: repeat the gather densely); the dense form needs
+            # them only to plan the next step, and reads them after its kernels are enqueued -- a blocking read here would
+            # keep the host from queueing the rebuild under the all-reduce and the backward that are still running.
+            counts_dev = (blocks[:, 0] if state["form"] == "sparse" else blocks[:, -1]).contiguous().view(torch.int32)
+            counts = counts_dev.tolist() if state["form"] == "sparse" else None
             received = (world - 1) * blocks.shape[1] * 4
-            if state["form"] == "sparse" and max(counts) > state["cap"]:
+            if state["form"] == "sparse" and (max(counts) > state["cap"] or self.force_overflow_next):
+                self.force_overflow_next = False
                 # a block was truncated: all ranks see it, all repeat this step's gather densely
                 self.sparse_overflows += 1
                 state["form"] = "dense"
@@ -461,8 +517,10 @@ class ModelViewDP:
             gp["features_dc"].grad, gp["features_rest"].grad = v_dc, v_rest
             if work is not None:
                 work.wait()
-                if self.average:
+                if self.average and world > 1:
                     flat.div_(world)
+            if counts is None:
+                counts = counts_dev.tolist()
             # the next step's form: sparse blocks at 1.25 x the largest count, if that is clearly smaller than dense ones
             cap = int(max(counts) * 1.25) + 1024
             sparse_floats, dense_floats = 4 + cap * (1 + pf), stride + 1
@@ -479,7 +537,7 @@ class ModelViewDP:
 def sync_densify_stats(model, group=None) -> None:
     """Before ``refinement_after`` on every rank: make the accumulated statistics identical
     (``all_reduce_densify_stats``) and re-seed the generator that draws the split samples."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not _collective_world(group)[1]:
         return
     if model.xys_grad_norm is not None:
         all_reduce_densify_stats(model.xys_grad_norm, model.vis_counts, model.max_2Dsize, group=group)

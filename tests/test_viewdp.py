@@ -77,3 +77,34 @@ def test_two_rank_gloo_allreduce_matches_single_process(tmp_path):
     assert torch.allclose(got["grad"], fp.flat_grad, rtol=1e-5, atol=1e-6)
     assert got["g"].tolist() == [3.0] * 5 and got["vis"].tolist() == [3] * 5 and got["mx"].tolist() == [1.0] * 5
     assert got["seed"] == got1["seed"] == 1234 and torch.equal(got["r"], got1["r"])
+
+
+def _forced_worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", FG_DP_FORCE_COLLECTIVES="1")
+    from freegaussian_amd import viewdp
+
+    assert viewdp._collective_world() == (1, False)  # no process group: nothing to force
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    assert viewdp._collective_world() == (1, True)
+    sc = synthetic_scene(50, 64, 64)
+    fp = FlatGaussianParams.from_scene(sc, "cpu")
+    m, q, s, o, c = fp.raster_inputs()
+    ((m * 2).sum() + (c * 3).sum() + o.sum()).backward()
+    before = fp.flat_grad.clone()
+    fp.all_reduce_grads(average=True)  # one rank: the sum is the identity, and nothing is divided
+    g, vis, mx = torch.full((5,), 2.0), torch.full((5,), 3), torch.full((5,), 4.0)
+    all_reduce_densify_stats(g, vis, mx)
+    seed = shared_seed(77)
+    os.environ["FG_DP_FORCE_COLLECTIVES"] = "0"
+    assert viewdp._collective_world() == (1, False)
+    torch.save({"same": torch.equal(before, fp.flat_grad), "g": g, "vis": vis, "mx": mx, "seed": seed}, out)
+    dist.destroy_process_group()
+
+
+def test_forced_collectives_on_one_rank_are_the_identity(tmp_path):
+    """FG_DP_FORCE_COLLECTIVES=1: the world > 1 code paths on a 1-rank group (the GPU form: scripts/rccl_one_rank.py)."""
+    out = str(tmp_path / "f.pt")
+    mp.spawn(_forced_worker, args=(1, _free_port(), out), nprocs=1, join=True)
+    got = torch.load(out)
+    assert got["same"] and got["g"].tolist() == [2.0] * 5 and got["vis"].tolist() == [3] * 5 and got["mx"].tolist() == [4.0] * 5
+    assert got["seed"] == 77
