@@ -996,6 +996,12 @@ def main(argv=None):
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(scene, view, args.cpu_crop, args.sh_degree, args.cpu_threads)
             out["cpu_full_frame"] = cpu_full_frame(scene, view, args.sh_degree)
+        if world > 1 or force:
+            # RCCL writes a version banner through C stdio on its first collective; on a pipe that buffer is flushed when the
+            # process exits -- BEHIND this line.  Flush it now: the result stays the last line of stdout.
+            import ctypes
+
+            ctypes.CDLL(None).fflush(None)
         print(json.dumps(out), flush=True)
     if world > 1 or force:
         dist.barrier()

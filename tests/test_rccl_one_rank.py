@@ -16,7 +16,8 @@ def test_forced_collectives_match_the_step_without_them_on_both_streams():
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), FG_ONE_RANK_STEPS="20")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rccl_one_rank.py")], capture_output=True, text=True, env=env, timeout=900)
     assert res.stdout.strip(), res.stderr[-2000:]
-    out = json.loads(res.stdout.strip().splitlines()[-1])
+    # (RCCL prints its version banner to stdout when the process exits: the result is the last line that is JSON)
+    out = json.loads([ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")][-1])
     print(json.dumps(out))
     assert res.returncode == 0 and out["ok"], out["mismatches"]
     assert out["backend"] == "nccl" and out["world"] == 1 and out["head_slices"] == 4
