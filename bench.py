@@ -521,14 +521,15 @@ def clustered_children(args):
                "--height", str(args.height), "--sh-degree", str(args.sh_degree)]  # fmt: skip
         try:
             res = subprocess.run(cmd, capture_output=True, text=True, timeout=min(120, left))
-            c = json.loads(res.stdout.strip().splitlines()[-1])
+            c = json.loads([ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")][-1])
             # (ms_per_step: the child's wall-clock mean over its 40 timed steps; the median host time per step beside it)
             res_all[lay] = {"mpix_per_s": c["value"], "ms_per_step": c["ms_per_step"],
                             "ms_per_step_median": (c.get("host_step_ms") or {}).get("median"), "stage_ms": c["stage_ms"],
                             "I_raster": c["config"]["I_raster"], "longest_tile_list": c["config"].get("longest_tile_list"),
                             "long_segment_calls": c["config"].get("long_segment_calls"),
                             "heavy_tile_steps": c["config"].get("heavy_tile_steps"), "host_step_ms": c.get("host_step_ms"),
-                            "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region")}  # fmt: skip
+                            "list_capacity_redos_in_timed_region": c["config"].get("list_capacity_redos_in_timed_region"),
+                            "path_events_in_timed_region": c.get("path_events_in_timed_region")}  # fmt: skip
             for k in ("N", "V", "I", "scene", "scene_statistics"):  # (what the trained layout is: its own N, cameras, shapes)
                 if lay.startswith("trained") and k in c["config"]:
                     res_all[lay][k] = c["config"][k]
@@ -575,7 +576,7 @@ def main(argv=None):
                 if left < 20:
                     raise TimeoutError("skipped: the children's shared time budget is spent (FG_BENCH_CHILD_BUDGET_S)")
                 res = subprocess.run(cmd, capture_output=True, text=True, timeout=min(180, left))
-                graphed = json.loads(res.stdout.strip().splitlines()[-1])
+                graphed = json.loads([ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")][-1])
             except Exception as e:
                 graphed = {"error": repr(e)[:200]}
 
@@ -733,11 +734,19 @@ def main(argv=None):
     if args.settle_s > 0:
         settle_steps += settle(max(args.settle_s / 3, 0.2), per_step)
     redo0 = ops.default_context.capacity_redos
+
+    def path_events():
+        c = ops.default_context
+        return {"list_capacity_redos": c.capacity_redos, "plan_changes": c.plan_changes, "pool_new_buffers": c.pool_new_buffers,
+                "pool_fallback_calls": c.pool_fallback_calls, "stagewise_raster_calls": c.stagewise_raster_calls,
+                "full_ckpt_allocs": c.full_ckpt_allocs, **{"plan_change_" + k: v for k, v in c.plan_change_reasons.items()}}
+
     if ops.default_context.stage_timer is not None:
         # (the settle steps' events are not part of the timed region's averages; the timed region's own event pairs exist
         # before it starts)
         ops.default_context.stage_timer = ops.StageTimer(only=only, prewarm=(args.steps + 2) * max(len(only), 1) if only else 0)
     fence()
+    events0 = path_events()
     t0 = time.perf_counter()
     views_seen = []
     host_marks = [t0]
@@ -747,6 +756,7 @@ def main(argv=None):
         host_marks.append(time.perf_counter())
     fence()
     dt_local = time.perf_counter() - t0
+    events1 = path_events()
     gc.enable()
     timed_stages = ops.default_context.stage_timer.summary()
     dom_series = [a.elapsed_time(b) for a, b in ops.default_context.stage_timer.events.get(dominant, [])]
@@ -960,6 +970,11 @@ def main(argv=None):
         "host_step_ms": (lambda d: {"median": sorted(d)[len(d) // 2], "p90": pct(d, 0.9), "p99": pct(d, 0.99), "max": max(d), "argmax": d.index(max(d)),
                                     "over_1.5x_median": sum(1 for x in d if x > 1.5 * sorted(d)[len(d) // 2])})(
             [(b - a) * 1e3 for a, b in zip(host_marks, host_marks[1:])]),
+        # what the PATH itself did inside the timed region that could make one step slower than its neighbours: a list that
+        # outgrew its speculative capacity (second binning), a one-call plan that differed from the shape's previous one (a
+        # policy flip or a new capacity: new plan, maybe new buffers), a workspace the pool could not serve (a device
+        # allocation), a stage-wise fallback.  All zero + a multi-millisecond host_step_ms.max = the stall is the host's.
+        "path_events_in_timed_region": {k: events1.get(k, 0) - events0.get(k, 0) for k in events1},
         "stage_ms": {s: round(v, 4) for s, v in sorted(stages.items(), key=lambda kv: -kv[1])},
         "stage_pass_ms_per_step": round(stage_pass_ms, 4),
         "stage_ms_from": ("HIP events around every C-ABI call in the timed region" if args.stage_events == "all" else

@@ -75,7 +75,9 @@ __device__ __forceinline__ uint64_t footprint_mask(float o, float a, float b, fl
   const uint32_t row_all = (1u << nbx) - 1u;
   uint64_t all = 0;
   for (int by = 0; by < nby; ++by) all |= (uint64_t)row_all << (8 * by);
-  const float t255 = 255.f * o, det = a * c - b * b;
+  // det by a compensated difference of products: for a long diagonal needle the blur leaves det ~1e-4 against a c ~ 3, and
+  // the plain a c - b b loses 1e-3 ... 1e-2 of it -- more than the 0.1 % inflation of tau2 below keeps
+  const float t255 = 255.f * o, bb = b * b, det = __builtin_fmaf(a, c, -bb) + __builtin_fmaf(-b, b, bb);
   if (!(o == o) || !(det > 0.f) || !(a > 0.f) || !(c > 0.f) || !(t255 >= 1.f)) return all;  // (no culling possible: alpha_extent kinds 2 / 0)
   // tau2 = 2 ln(255 o), inflated by 0.1 % + 2e-3 (the pixel test's own rounding is ~1e-5 of it)
   // one tile wide or high: the rectangle was tightened against the ellipse's extents axis by axis, and a connected shape

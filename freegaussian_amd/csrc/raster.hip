@@ -1294,6 +1294,11 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
 // open_list: [0] = the strips the prefix jobs of the main launch left open, [8 ...] = tile << 3 | (strip + 1) each; [1] = a
 // ticket: the last workgroup to leave zeroes both words (the list build zeroes them too; a second forward over the same
 // lists must not find the first one's entries)
+// (the 16 stages are ~75 KB of STATIC LDS: beyond the 64 KB of earlier CDNA parts -- this library is gfx950 code)
+static_assert(sizeof(WideShared<FG_WIDE_WAVES>) <= 160 * 1024 / 2, "a wide job's stages: two workgroups per CU of gfx950's 160 KB LDS");
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libfgraster's kernels are written for gfx950 (MI355X): 160 KB of LDS per CU, wave64; build with --offload-arch=gfx950"
+#endif
 __global__ void __launch_bounds__(64 * FG_WIDE_WAVES)
 raster_fwd_wide_kernel(int width, int height, int tile_w, int32_t* __restrict__ open_list,
                        const float4* __restrict__ splats, const int32_t* __restrict__ tile_offsets,

@@ -27,8 +27,12 @@
 namespace {
 
 constexpr int SB_BLOCK = 256;                        // columns kernel
-constexpr int SB_CHUNK = 4096;                       // Gaussians per workgroup of count and scatter
+constexpr int SB_CHUNK = 4096;                       // Gaussians per workgroup of count and scatter AT MOST ...
 constexpr int SC_BLOCK = 1024, SC_WAVES = SC_BLOCK / 64, SC_PER = SB_CHUNK / SC_BLOCK;
+// ... `per` x 1024 of them (per = 1, 2, 4 by N, chunk_rounds): a trained scene of 257k Gaussians is 63 chunks of 4096 -- a
+// quarter of the chip's CUs busy, count 20 us and scatter 35 us against 21 / 29 for four times as many Gaussians --, and
+// 251 of 1024.  The [chunks][T] tables keep their size: ~250-320 chunks at every N up to 1.3M.
+__host__ __device__ __forceinline__ int chunk_rounds(int N) { return N <= 320 * 1024 ? 1 : (N <= 640 * 1024 ? 2 : SC_PER); }
 #ifndef FG_SB_SMALL_WAVES
 #define FG_SB_SMALL_WAVES 8
 #endif
@@ -203,22 +207,31 @@ __device__ __forceinline__ void for_bit_runs(uint32_t bits, F f) {
 // masks (nullable): fg::footprint_mask of every rectangle -- which blocks of it the ellipse reaches; counted (and
 // scattered, sb_scatter_kernel) are the set blocks' tiles only.  NULL: whole rectangles.
 __global__ void __launch_bounds__(SC_BLOCK)
-sb_count_kernel(int N, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks, int tile_w, int tile_h,
-                int band_rows, uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
+sb_count_kernel(int N, int per, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks, int tile_w,
+                int tile_h, int band_rows, uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
   extern __shared__ int32_t s_grid[];  // tile grid [(tile rows + 1)][tile_w + 1], then supertile grid
+  // (masks: the wavefront's round of rectangles compacted to its owners of supertile rows, as in sb_scatter_kernel)
+  __shared__ int4 s_cq[SC_WAVES][64];          // {rect.x, rect.y, footprint mask low, high}
+  __shared__ uint32_t s_cqx[SC_WAVES][64];     // items before this owner << 10 | its first supertile row
+  __shared__ unsigned long long s_cmarks[SC_WAVES];
   const Geo g = geo_of(tile_w, tile_h);
   const int chunk = blockIdx.x;
   const int gwt = tile_w + 1, gws = g.sw + 1;
   const int T = tile_w * tile_h, S = g.sw * g.sh;
-  const int g0 = chunk * SB_CHUNK + threadIdx.x;
+  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
+  // masks: a wavefront owns 256 consecutive Gaussians (64 a round); whole rectangles: thread-strided over the chunk
+  const int chunk_n = per * SC_BLOCK;
+  const int g0 = masks ? chunk * chunk_n + wave * (chunk_n / SC_WAVES) + lane : chunk * chunk_n + (int)threadIdx.x;
+  const int gstep = masks ? 64 : SC_BLOCK;
   int2 rc[SC_PER];
   unsigned long long mk[SC_PER];
 #pragma unroll
   for (int r = 0; r < SC_PER; ++r) {
-    const bool in = g0 + r * SC_BLOCK < N;
-    rc[r] = in ? rects[g0 + r * SC_BLOCK] : make_int2(0, 0);
-    mk[r] = in && masks ? masks[g0 + r * SC_BLOCK] : 0ull;
+    const bool in = r < per && g0 + r * gstep < N;
+    rc[r] = in ? rects[g0 + r * gstep] : make_int2(0, 0);
+    mk[r] = in && masks ? masks[g0 + r * gstep] : 0ull;
   }
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's grids fit the LDS)
     const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
     const int ntr = tr1 - tr0, nsr = sr1 - sr0;
@@ -226,49 +239,88 @@ sb_count_kernel(int N, const int2* __restrict__ rects, const unsigned long long*
     int32_t* gs = s_grid + (ntr + 1) * gwt;
     for (int i = threadIdx.x; i < (ntr + 1) * gwt + (nsr + 1) * gws; i += SC_BLOCK) s_grid[i] = 0;
     __syncthreads();
+    if (masks) {
+      // One ITEM = one supertile row of one rectangle: each of the row's two tile rows marks its runs of set blocks on the
+      // tile grid, the two together theirs on the supertile grid -- differences along x ONLY (marks_to_counts rowwise), two
+      // LDS atomics a run.  The items of a round's 64 rectangles are DEALT to the lanes (round 5 looped over the rows per
+      // lane: a wall splat next to the lens has 34 supertile rows at 1080p and the wavefront's other 63 lanes waited for
+      // it -- 25.7 us for 257k Gaussians of a trained scene against 21 us for the bench scene's million).
+      int4* q = s_cq[wave];
+      uint32_t* qx = s_cqx[wave];
+      unsigned long long* marks = &s_cmarks[wave];
 #pragma unroll
-    for (int r = 0; r < SC_PER; ++r) {
-      const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
-      const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
-      if (masks) {
-        if (w > 0 && yb > ya) {
-          // One pass over the rectangle's supertile rows: each of a row's two tile rows marks its runs of set blocks on the
-          // tile grid, the two together theirs on the supertile grid -- differences along x ONLY (marks_to_counts rowwise),
-          // two LDS atomics a run: 2.4 tile rows + 1.7 supertile rows per Gaussian on the 1M / 1080p scene = as many atomics
-          // as the eight corner marks of a whole rectangle, and no pass down the columns afterwards.
-          const unsigned long long m = mk[r];
-          const int sh = 31 - __builtin_clz((unsigned)fg::footprint_block(w, h)), bs = 1 << sh;
-          for (int R = max(y0 >> 1, sr0); R < min(((y0 + h - 1) >> 1) + 1, sr1); ++R) {
+      for (int r = 0; r < SC_PER; ++r) {
+        if (r >= per) break;
+        const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, y0 = rc[r].x >> 16;
+        const int Ra = max(y0 >> 1, sr0), Rb = min(((y0 + h - 1) >> 1) + 1, sr1);
+        const bool hit = w > 0 && h > 0 && Rb > Ra;
+        const uint32_t cnt = hit ? (uint32_t)(Rb - Ra) : 0u;
+        const uint32_t incl = wave_incl_scan(cnt, lane);
+        const int total = (int)__builtin_amdgcn_readlane((int)incl, 63);
+        const uint64_t hm = __ballot(hit);
+        const int ci = __popcll(hm & lt_mask);
+        if (hit) {
+          q[ci] = make_int4(rc[r].x, rc[r].y, (int)(uint32_t)mk[r], (int)(uint32_t)(mk[r] >> 32));
+          qx[ci] = ((incl - cnt) << 10) | (uint32_t)Ra;  // (rows < 1024: fg_stbin_supported; items of a round <= 64 * 512)
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int s0 = 0; s0 < total; s0 += 64) {
+          // owner of slot s0 + lane: the owners that ended before the window (a ballot) + the end marks below this lane's
+          // bit (sb_scatter_kernel's scheme)
+          if (lane == 0) *marks = 0ull;
+          __builtin_amdgcn_wave_barrier();
+          const int endpos = (int)incl - 1 - s0;
+          if (hit && endpos >= 0 && endpos < 64) atomicOr(marks, 1ull << endpos);
+          __builtin_amdgcn_wave_barrier();
+          const uint64_t em = __hip_atomic_load(marks, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+          const int before = __popcll(__ballot(hit && (int)incl <= s0));
+          const int slot = s0 + lane;
+          if (slot < total) {
+            const int lo = before + __popcll(em & lt_mask);
+            const int4 o = q[lo];
+            const uint32_t ox = qx[lo];
+            const unsigned long long m = ((unsigned long long)(uint32_t)o.w << 32) | (uint32_t)o.z;
+            const int ow = o.y & 0xFFFF, oh = o.y >> 16, ox0 = o.x & 0xFFFF, oy0 = o.x >> 16;
+            const int R = (int)(ox & 1023u) + (slot - (int)(ox >> 10));
+            const int sh = 31 - __builtin_clz((unsigned)fg::footprint_block(ow, oh)), bs = 1 << sh;
             uint32_t both = 0;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
               const int ty = 2 * R + i;
-              if (ty < y0 || ty >= y0 + h) continue;
-              const uint32_t bits = (uint32_t)(m >> (8 * ((ty - y0) >> sh))) & 0xFFu;
+              if (ty < oy0 || ty >= oy0 + oh) continue;
+              const uint32_t bits = (uint32_t)(m >> (8 * ((ty - oy0) >> sh))) & 0xFFu;
               both |= bits;
-              for_bit_runs(bits, [&](int s0, int s1) {
-                atomicAdd(&gt[(ty - tr0) * gwt + x0 + s0 * bs], 1);
-                atomicAdd(&gt[(ty - tr0) * gwt + min(x0 + s1 * bs, x0 + w)], -1);
+              for_bit_runs(bits, [&](int a0, int a1) {
+                atomicAdd(&gt[(ty - tr0) * gwt + ox0 + a0 * bs], 1);
+                atomicAdd(&gt[(ty - tr0) * gwt + min(ox0 + a1 * bs, ox0 + ow)], -1);
               });
             }
-            for_bit_runs(both, [&](int s0, int s1) {
-              atomicAdd(&gs[(R - sr0) * gws + ((x0 + s0 * bs) >> 1)], 1);
-              atomicAdd(&gs[(R - sr0) * gws + ((min(x0 + s1 * bs, x0 + w) - 1) >> 1) + 1], -1);
+            for_bit_runs(both, [&](int a0, int a1) {
+              atomicAdd(&gs[(R - sr0) * gws + ((ox0 + a0 * bs) >> 1)], 1);
+              atomicAdd(&gs[(R - sr0) * gws + ((min(ox0 + a1 * bs, ox0 + ow) - 1) >> 1) + 1], -1);
             });
           }
         }
-      } else if (w > 0 && yb > ya) {
-        const int ra = ya - tr0, rb = yb - tr0;
-        atomicAdd(&gt[ra * gwt + x0], 1);
-        atomicAdd(&gt[ra * gwt + x0 + w], -1);
-        atomicAdd(&gt[rb * gwt + x0], -1);
-        atomicAdd(&gt[rb * gwt + x0 + w], 1);
-        const int sxa = x0 >> 1, sxb = ((x0 + w - 1) >> 1) + 1;
-        const int sya = (ya >> 1) - sr0, syb = ((yb - 1) >> 1) + 1 - sr0;
-        atomicAdd(&gs[sya * gws + sxa], 1);
-        atomicAdd(&gs[sya * gws + sxb], -1);
-        atomicAdd(&gs[syb * gws + sxa], -1);
-        atomicAdd(&gs[syb * gws + sxb], 1);
+        __builtin_amdgcn_wave_barrier();
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < SC_PER; ++r) {
+        const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
+        const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
+        if (w > 0 && yb > ya) {
+          const int ra = ya - tr0, rb = yb - tr0;
+          atomicAdd(&gt[ra * gwt + x0], 1);
+          atomicAdd(&gt[ra * gwt + x0 + w], -1);
+          atomicAdd(&gt[rb * gwt + x0], -1);
+          atomicAdd(&gt[rb * gwt + x0 + w], 1);
+          const int sxa = x0 >> 1, sxb = ((x0 + w - 1) >> 1) + 1;
+          const int sya = (ya >> 1) - sr0, syb = ((yb - 1) >> 1) + 1 - sr0;
+          atomicAdd(&gs[sya * gws + sxa], 1);
+          atomicAdd(&gs[sya * gws + sxb], -1);
+          atomicAdd(&gs[syb * gws + sxa], -1);
+          atomicAdd(&gs[syb * gws + sxb], 1);
+        }
       }
     }
     __syncthreads();
@@ -530,7 +582,7 @@ __device__ __forceinline__ void build_segment_lists(int S, const int32_t* __rest
 // (a chunk of huge rectangles) are stored directly, as without STAGE.
 template <bool STAGE>
 __global__ void __launch_bounds__(SC_BLOCK)
-sb_scatter_kernel(int N, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks,
+sb_scatter_kernel(int N, int per, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks,
                   const uint32_t* __restrict__ depth_keys, int tile_w,
                   int tile_h, int band_rows, int stage_cap, const uint32_t* __restrict__ table_s,
                   const int32_t* __restrict__ tile_offsets, const int32_t* __restrict__ st_offsets,
@@ -582,13 +634,14 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const unsigned long lon
   int32_t* ex = s_excl[wave];
   unsigned long long* marks = &s_marks[wave];
   // the wavefront's rectangles and depth bits: all loads in flight together
-  const int g0 = chunk * SB_CHUNK + wave * (SB_CHUNK / SC_WAVES) + lane;
+  const int chunk_n = per * SC_BLOCK;
+  const int g0 = chunk * chunk_n + wave * (chunk_n / SC_WAVES) + lane;
   int2 rc[SC_PER];
   uint32_t dk[SC_PER];
   unsigned long long mk[SC_PER];
 #pragma unroll
   for (int r = 0; r < SC_PER; ++r) {
-    const bool in = g0 + r * 64 < N;
+    const bool in = r < per && g0 + r * 64 < N;
     rc[r] = in ? rects[g0 + r * 64] : make_int2(0, 0);
     dk[r] = in ? depth_keys[g0 + r * 64] : 0u;
     mk[r] = in && masks ? masks[g0 + r * 64] : 0ull;
@@ -601,7 +654,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const unsigned long lon
   uint32_t chunk_pairs = 0;
   if (STAGE) {
     const uint32_t* row = table_s + (size_t)chunk * S;
-    const bool last = (chunk + 1) * SB_CHUNK >= N;
+    const bool last = (chunk + 1) * chunk_n >= N;
     auto count_of = [&](int i) {  // this chunk's pairs in supertile i: the next chunk's prefix minus this one's
       return (last ? (uint32_t)(st_offsets[i + 1] - st_offsets[i]) : row[S + i]) - row[i];
     };
@@ -634,6 +687,7 @@ sb_scatter_kernel(int N, const int2* __restrict__ rects, const unsigned long lon
     __syncthreads();
 #pragma unroll
     for (int r = 0; r < SC_PER; ++r) {
+      if (r >= per) break;
       const int w = rc[r].y & 0xFFFF, h = rc[r].y >> 16, x0 = rc[r].x & 0xFFFF, y0 = rc[r].x >> 16;
       const int ya = max(y0, tr0), yb = min(y0 + h, tr1);
       const bool hit = w > 0 && yb > ya;
@@ -1605,7 +1659,10 @@ sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_
 }
 
 size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-int n_chunks_of(int N) { return (N + SB_CHUNK - 1) / SB_CHUNK; }
+int n_chunks_of(int N) {
+  const int c = chunk_rounds(N) * SC_BLOCK;
+  return (N + c - 1) / c;
+}
 
 struct CountWs {
   uint32_t *table_t, *table_s;
@@ -1664,7 +1721,7 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, const uint64_t* 
   if (workspace_bytes < w.bytes) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
   const int T = tile_w * tile_h, S = g.sw * g.sh, nc = n_chunks_of(N);
-  hipLaunchKernelGGL(sb_count_kernel, dim3(nc), dim3(SC_BLOCK), count_lds_bytes(g), s, N,
+  hipLaunchKernelGGL(sb_count_kernel, dim3(nc), dim3(SC_BLOCK), count_lds_bytes(g), s, N, chunk_rounds(N),
                      reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks), tile_w,
                      tile_h, count_band_rows(g), w.table_t, w.table_s);
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
@@ -1761,7 +1818,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
   if (stage_cap) {
     const size_t lds = (size_t)8 * s_pad + (size_t)10 * stage_cap;
     // (the job lists and the segment lists ride here; without the staged scatter: in the large-segment sort launch / chunk 0)
-    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N,
+    hipLaunchKernelGGL(sb_scatter_kernel<true>, dim3(nc + (want_jobs ? 8 : 0) + 1), dim3(SC_BLOCK), lds, s, N, chunk_rounds(N),
                        reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks),
                        depth_keys, tile_w, tile_h, band_rows, stage_cap, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,
@@ -1770,7 +1827,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
     want_jobs = false;
     bwd_jobs_in_sort = jobs && jobs->jobs_bwd;
   } else {
-    hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N,
+    hipLaunchKernelGGL(sb_scatter_kernel<false>, dim3(nc), dim3(SC_BLOCK), (size_t)band_rows * g.sw * 4, s, N, chunk_rounds(N),
                        reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks),
                        depth_keys, tile_w, tile_h, band_rows, 0, w.table_s,
                        tile_offsets, w.st_offsets, entries, (long long)capacity, small_max, w.large_list, w.long_list,

@@ -22,6 +22,11 @@ SPLAT_FLOATS = 16
 MAX_CHANNELS = 8
 
 
+# The workspace pool tells a free buffer by its storage's use count (a private torch hook: looked up HERE, once; a context
+# created without it warns and counts its fallbacks)
+_STORAGE_USE_COUNT = getattr(torch._C, "_storage_Use_Count", None)
+
+
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else t.data_ptr()
 
@@ -210,7 +215,18 @@ class RasterContext:
         self.heavy_shapes = {}
         self.long_walks = {}  # shape -> calls left for which a reported long walk (a strip beyond 2560 entries) counts
         self.workspace_pool = e.get("FG_WORKSPACE_POOL", "1") != "0"
-        self._workspaces = {}  # (kind, device) -> [(uint8 buffer, its storage's use count when nobody else holds it)]
+        self._workspaces = {}  # (kind, device, stream) -> [(uint8 buffer, its storage's use count when nobody else holds it)]
+        self.pool_fallback_calls = 0  # workspace requests that fell back to torch.empty because the use-count hook is missing
+        self.pool_new_buffers = 0  # workspace requests no pooled buffer could serve: a new device allocation
+        self.plan_changes = 0  # one-call steps whose plan key differed from the shape's previous call ...
+        self.plan_change_reasons = {}  # ... and which of its fields did: N, shares, long_mode, capacity, variant (heavy / slots / even / splits)
+        self._last_plan = {}
+        if self.workspace_pool and _STORAGE_USE_COUNT is None:
+            import warnings
+
+            warnings.warn("freegaussian_amd: torch._C._storage_Use_Count is missing in this torch build -- the workspace pool is "
+                          "off and every step allocates its 0.4-0.8 GB workspaces through the caching allocator (a device "
+                          "allocation behind every refinement); RasterContext.pool_fallback_calls counts them", RuntimeWarning)
         # The forward's content thresholds (fg_raster_config::split4_fwd / split2_fwd: a tile is cut into four / two strip
         # jobs when its list is longer than that many 65536ths of all lists: 20 / 16 = 2.5 x / 2.0 x the mean at 8160 tiles)
         # are tuned on even scenes, where finer cuts only repeat the staging.  On a scene with a cluster the launch is full
@@ -288,19 +304,27 @@ class RasterContext:
         for and at most 30 % (+ 32 MB) larger; else a new one with 5 % to spare.  At most four buffers per kind and device;
         the oldest unused one goes first.  Same-stream reuse only (as the caching allocator without record_stream); never
         under a stream capture."""
-        use_count = getattr(torch._C, "_storage_Use_Count", None)
+        use_count = _STORAGE_USE_COUNT
         # (under a stream capture the allocator's private pool of the graph is the only right place: a replay writes where the
         # capture's tensors lived, whoever holds that memory by then)
         if not self.workspace_pool or use_count is None or (dev.type == "cuda" and torch.cuda.is_current_stream_capturing()):
+            # (pool on but torch's private use-count hook gone: the 17-21 ms hipMalloc behind every refinement is back -- counted,
+            # warned about once at context creation, reported by bench.py as `pool_fallback_calls`)
+            self.pool_fallback_calls += int(self.workspace_pool and use_count is None)
             return torch.empty(numel, dtype=dtype, device=dev)
         item = torch.empty(0, dtype=dtype).element_size()
         nbytes = numel * item
-        pool = self._workspaces.setdefault((kind, str(dev)), [])
+        # keyed by the STREAM too: the caching allocator ties a block to the stream it was allocated on; a buffer released by
+        # one stream's call must not be handed to a call on another stream whose kernels could overwrite what the first is
+        # still reading (eval on a side stream, two training streams sharing a context)
+        stream_key = _stream() if dev.type == "cuda" else 0
+        pool = self._workspaces.setdefault((kind, str(dev), stream_key), [])
         for i, (buf, idle) in enumerate(pool):
             if nbytes <= buf.numel() <= int(1.3 * nbytes) + (32 << 20) and use_count(buf.untyped_storage()._cdata) == idle:
                 pool.append(pool.pop(i))  # (most recently used last)
                 return buf[:nbytes].view(dtype)
         buf = torch.empty((int(nbytes * 1.05) + (2 << 20) - 1) // (2 << 20) * (2 << 20), dtype=torch.uint8, device=dev)
+        self.pool_new_buffers += 1
         pool.append((buf, use_count(buf.untyped_storage()._cdata)))
         if len(pool) > 4:
             for i, (old, idle) in enumerate(pool[:-1]):
@@ -311,24 +335,42 @@ class RasterContext:
                 pool.pop(0)  # (all in use: the pool forgets the oldest; its users keep it alive)
         return buf[:nbytes].view(dtype)
 
+    def heavy_lens(self, lkey):
+        """(longest list that turns heavy tiles on, list length from which a tile IS heavy while they are on) for a shape.
+        The round-5 pair (2560 / 768) belongs to the walk reports: a shape keeps heavy tiles only while its strips report
+        walks beyond 2560 entries.  Only the one-call path asks the forward for those reports; a shape that has never
+        delivered one (stage-wise calls: FG_STEP_CALLS=0, a stage timer, images the step path refuses) would keep heavy
+        tiles on by list LENGTH alone -- a dense opaque cluster, 15 us lost per step -- so it stays on round 4's pair."""
+        if lkey in self.long_walks:
+            return self.heavy_flag_len, self.heavy_tile_len
+        return max(self.heavy_flag_len, 3072), max(self.heavy_tile_len, 3072)
+
+    def release_workspaces(self) -> int:
+        """Drop the pool's buffers (up to four per kind, device and stream: 0.4-0.8 GB each at 1M / 1080p, which
+        ``torch.cuda.empty_cache()`` cannot reach while the pool holds them); buffers still referenced by live outputs stay
+        alive through those.  -> bytes the pool let go of."""
+        freed = sum(buf.numel() for pool in self._workspaces.values() for buf, _ in pool)
+        self._workspaces.clear()
+        return freed
+
     def uneven_shape(self, lkey) -> bool:
         """Has one of the shape's last eight calls shown a tile list beyond three times the mean?  Then the forward's content
         thresholds are the finer ones (`uneven_split_fwd`)."""
         return self.uneven_left.get(lkey, 0) > 0
 
-    def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False) -> int:
+    def cfg(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False, heavy_len: int = 0) -> int:
         """Address of the launch policy (the `const fg_raster_config*` argument); ``heavy``: the same policy with
         ``heavy_tiles`` set (unless the policy sets it itself); ``seg_slots`` > 0: with compact checkpoint slots, that many;
         ``even``: with ``balance_bands = 2`` (equal numbers of tiles per XCD without looking at the costs: a shape whose
         recent calls had no tile list far above the mean).  The copies live as long as the context: autograd nodes and
         cached step plans hold their addresses."""
-        return self.cfg_variant(heavy, seg_slots, even, uneven)[0]
+        return self.cfg_variant(heavy, seg_slots, even, uneven, heavy_len)[0]
 
-    def cfg_variant(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False):
+    def cfg_variant(self, heavy: bool = False, seg_slots: int = 0, even: bool = False, uneven: bool = False, heavy_len: int = 0):
         """``cfg`` and the VALUES that tell the variant from the context's own policy: (address, (heavy_len, seg_slots,
         even)) -- what a cache of anything derived from the policy is keyed on (an address can be reused by another
         context's copy)."""
-        heavy_len = self.heavy_tile_len if heavy and self.policy.heavy_tiles <= 0 else 0
+        heavy_len = (int(heavy_len) or self.heavy_tile_len) if heavy and self.policy.heavy_tiles <= 0 else 0
         if self.policy.seg_slots > 0:
             seg_slots = 0  # (the policy's own value stands)
         seg_slots = max(int(seg_slots), 0)
@@ -882,7 +924,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
     n_isects = _poll_count(count_slot)
     _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)  # (first: the previous call's walk report decides below)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
-                                          (2, rctx.heavy_flag_len, rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
+                                          (2, rctx.heavy_lens(lkey)[0], rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
         over = _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many)
         # (heavy tiles: a long list AND, where the forward reports them -- the one-call path -- a long WALK lately: a dense
         # opaque cluster has lists of ten thousand entries that close after a few hundred, and heavy tiles cost it 15 us)
@@ -931,7 +973,8 @@ def _plan_job_lists(rctx, raster_hint, n_list, dev, heavy=False, lkey=None, N=0)
     channels, width, height = (int(v) for v in raster_hint)
     n_tiles = ((width + 15) // 16) * ((height + 15) // 16)
     seg_slots = rctx.seg_slots_for(lkey, n_list, n_tiles, N) if lkey is not None and channels == 3 else 0
-    cfgp = rctx.cfg(heavy, seg_slots, lkey is not None and rctx.even_shape(lkey), lkey is not None and rctx.uneven_shape(lkey))
+    cfgp = rctx.cfg(heavy, seg_slots, lkey is not None and rctx.even_shape(lkey), lkey is not None and rctx.uneven_shape(lkey),
+                    rctx.heavy_lens(lkey)[1] if lkey is not None else 0)
     words = int(_lib.load().fg_raster_jobs_words(width, height, TILE_SIZE, cfgp))
     if words <= 0:
         return None
@@ -1744,7 +1787,7 @@ class _RasterStep(torch.autograd.Function):
         capacity = rctx.capacity_for(ckey, N)
         while True:
             seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h, N) if channels == 3 and want_backward else 0
-            cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey), rctx.uneven_shape(lkey))
+            cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey), rctx.uneven_shape(lkey), rctx.heavy_lens(lkey)[1])
             shares = want_backward and _seg_ckpt_floats(rctx, channels, width, height, TILE_SIZE, capacity, cfgp) > 0
             # (the launch policy enters the key by VALUE -- its bytes and the variant's fields -- never by the address of a
             # context's copy, which another context's copy may reuse)
@@ -1754,6 +1797,16 @@ class _RasterStep(torch.autograd.Function):
                    near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")
+            # what changed against the shape's previous call (bench.py reports the tallies of its timed region: a step of
+            # several milliseconds in a steady state is either one of these -- a new capacity = new buffers, a policy flip = a
+            # new plan -- or it is the host's)
+            last = rctx._last_plan.get(lkey)
+            if last is not None and last != key:
+                rctx.plan_changes += 1
+                for name, i in (("N", 1), ("shares", 13), ("long_mode", 14), ("capacity", 15), ("variant", 20)):
+                    if last[i] != key[i]:
+                        rctx.plan_change_reasons[name] = rctx.plan_change_reasons.get(name, 0) + 1
+            rctx._last_plan[lkey] = key
             keep = rctx.workspace("keep", (L.keep_bytes + 3) >> 2, torch.float32, dev)
             tmp = rctx.workspace("tmp", max(L.tmp_bytes, 8), torch.uint8, dev)
             count_slot, count_ptr = _count_slot()

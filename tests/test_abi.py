@@ -366,8 +366,54 @@ def test_workspace_pool_hands_out_only_buffers_nobody_refers_to_host_logic():
     assert e.dtype == torch.uint8 and e.data_ptr() not in (first, b.data_ptr(), c.data_ptr())  # pools per kind
     del d
     big = ctx.workspace("keep", 100_000_000, torch.float32, cpu)  # far beyond any pooled buffer: a new one
-    assert big.numel() == 100_000_000 and len(ctx._workspaces[("keep", "cpu")]) == 4
+    assert big.numel() == 100_000_000 and len(ctx._workspaces[("keep", "cpu", 0)]) == 4
     more = ctx.workspace("keep", 300_000_000, torch.float32, cpu)
-    assert len(ctx._workspaces[("keep", "cpu")]) == 4 and more.numel() == 300_000_000  # the oldest unused one made room
+    assert len(ctx._workspaces[("keep", "cpu", 0)]) == 4 and more.numel() == 300_000_000  # the oldest unused one made room
     off = ops.RasterContext(env={"FG_WORKSPACE_POOL": "0"})
     assert off.workspace("keep", 10, torch.float32, cpu).numel() == 10 and not off._workspaces
+    # release_workspaces: the pool lets go of everything it holds (what torch.cuda.empty_cache() cannot reach)
+    del big, more, b, c, e
+    freed = ctx.release_workspaces()
+    assert freed >= 4 * 300_000_000 and not ctx._workspaces
+
+
+def test_workspace_pool_is_keyed_by_stream_and_counts_its_fallbacks(monkeypatch):
+    """A buffer released by one stream's call is never handed to a call on another stream (the caching allocator's rule for
+    the blocks the pool replaces); without torch's private use-count hook the pool is OFF, says so once, and counts."""
+    import warnings
+
+    import torch
+
+    from freegaussian_amd import ops
+
+    cpu = torch.device("cpu")
+    if ops._STORAGE_USE_COUNT is not None:
+        ctx = ops.RasterContext(env={})
+        streams = iter([11, 11, 22, 11])
+        monkeypatch.setattr(ops, "_stream", lambda: next(streams))
+        cuda_like = type("D", (), {"type": "cuda", "__str__": lambda self: "cuda:0"})()
+        monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: False)
+        made = []
+        monkeypatch.setattr(torch, "empty", (lambda real: (lambda *a, **k: made.append(a) or real(*a, **{**k, "device": cpu})))(torch.empty))
+        a = ctx.workspace("keep", 1000, torch.float32, cuda_like)
+        p = a.data_ptr()
+        del a
+        b = ctx.workspace("keep", 1000, torch.float32, cuda_like)  # same stream: the released buffer again
+        assert b.data_ptr() == p
+        del b
+        c = ctx.workspace("keep", 1000, torch.float32, cuda_like)  # ANOTHER stream: never the first stream's buffer
+        assert c.data_ptr() != p and ("keep", "cuda:0", 22) in ctx._workspaces
+        del c
+        d = ctx.workspace("keep", 1000, torch.float32, cuda_like)  # back on the first stream: its own buffer
+        assert d.data_ptr() == p and ctx.pool_fallback_calls == 0
+        monkeypatch.undo()
+    monkeypatch.setattr(ops, "_STORAGE_USE_COUNT", None)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ctx = ops.RasterContext(env={})
+    assert any("_storage_Use_Count" in str(x.message) for x in w)
+    assert ctx.workspace("keep", 10, torch.float32, cpu).numel() == 10 and ctx.pool_fallback_calls == 1 and not ctx._workspaces
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        ops.RasterContext(env={"FG_WORKSPACE_POOL": "0"})  # pool off by choice: nothing to warn about
+    assert not w
