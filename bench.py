@@ -628,6 +628,7 @@ def main(argv=None):
     exchange = os.environ.get("FG_EXCHANGE", "factored") if (world > 1 or force) else "none"
     marks = []  # per step: HIP events at start / after forward / after backward / after the exchange
     counter = [0]
+    last_info = [None]
 
     def step(timed=False):
         view = rank % N_VIEWS if args.fixed_view else (rank + counter[0]) % N_VIEWS
@@ -654,6 +655,12 @@ def main(argv=None):
         if ev:
             ev[3].record()
             marks.append(ev)
+        # (EVERY loop of this file keeps the previous step's `info` alive while the next step runs -- the timed loop reads it
+        # afterwards --, so the workspace pool sees the same two-buffer pattern from the first warm-up step on.  Round 5's
+        # loops dropped it everywhere but in the timed region: the region's SECOND step then found the pool's only buffer
+        # still referenced and asked the device for a new one -- the 4.6 / 15.7 ms steps of the clustered lines
+        # (`path_events_in_timed_region.pool_new_buffers` = 1).)
+        last_info[0] = info
         return info, view
 
     def fence():

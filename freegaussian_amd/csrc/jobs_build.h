@@ -321,8 +321,24 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
   if (jb.nx == 1 && !bwd && xcd == 0 && jb.need_out && threadIdx.x == 0 && !reuse_bands)
     __hip_atomic_store(jb.need_out + 8, (long long)s_row0[9], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   const bool spans = jb.nx == 1;
-  const int n = spans ? span.t1 - span.t0 : band.nrows * band.ncols;
-  auto tile_at = [&](int idx) { return spans ? span_tile(span, idx, tile_w) : band_tile(band, idx, tile_w); };
+  // INTERLEAVED shares (balance_percent == -2, fg_raster_config::balance_bands = 3): the 2 x 2-tile blocks of the image (the
+  // binning's supertiles: four tiles that share most of their splats) dealt to the XCDs round-robin in raster order -- every
+  // XCD a uniform sample of the image, balanced on ANY content without a cost model.  (Round 6, profiles/r06_xcd_shares.md:
+  // the cost bands price a tile by its list length capped at three times the mean; on 17 layouts they had not been tuned on
+  // they lost up to 12 % to plain equal spans and won up to 40 % against them -- and a trained scene ran 10 % faster with
+  // interleaved blocks than with either.)  A block at an odd grid's right / bottom edge holds tiles outside the image:
+  // tile_at = -1, no job.
+  const bool inter = spans && jb.balance_percent == -2;
+  const int sw2 = (tile_w + 1) >> 1, n_blocks = sw2 * ((tile_h + 1) >> 1);
+  const int n = inter ? 4 * ((n_blocks - xcd + 7) / 8) : (spans ? span.t1 - span.t0 : band.nrows * band.ncols);
+  auto tile_at = [&](int idx) {
+    if (inter) {
+      const int g = (idx >> 2) * 8 + xcd, sy = g / sw2, sx = g - sy * sw2;
+      const int ty = 2 * sy + ((idx >> 1) & 1), tx = 2 * sx + (idx & 1);
+      return tx < tile_w && ty < tile_h ? ty * tile_w + tx : -1;
+    }
+    return spans ? span_tile(span, idx, tile_w) : band_tile(band, idx, tile_w);
+  };
   const int total = tile_offsets[tile_w * tile_h];
   const int tail4 = min(p.tail4, n), tail2 = min(p.tail2, n - tail4);
   // thresholds in 1/65536 of the total list length (64-bit product: total can exceed 2^31 / 65536)
@@ -358,6 +374,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     int mine = 0, need = 0;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = tile_at(idx);
+      if (tile < 0) continue;
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       const bool slots = has_slots(idx, tile, len);
       mine += p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
@@ -393,8 +410,10 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
           int nd = 0, tile = 0;
           if (idx >= 0) {
             tile = tile_at(idx);
-            const int len = tile_offsets[tile + 1] - tile_offsets[tile];
-            nd = candidate(idx, len) ? seg_count(len, jb.seg_fine) : 0;
+            if (tile >= 0) {
+              const int len = tile_offsets[tile + 1] - tile_offsets[tile];
+              nd = candidate(idx, len) ? seg_count(len, jb.seg_fine) : 0;
+            }
           }
           int incl = nd;
 #pragma unroll
@@ -408,7 +427,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
 #pragma unroll
           for (int w = 0; w < NWV; ++w)
             if (w < wave) pos += wave_tot[w];
-          if (idx >= 0) slot_tab[tile] = nd > 0 && pos + nd <= jb.slot_budget ? xcd * jb.slot_budget + pos : -1;
+          if (idx >= 0 && tile >= 0) slot_tab[tile] = nd > 0 && pos + nd <= jb.slot_budget ? xcd * jb.slot_budget + pos : -1;
           __syncthreads();
           if (threadIdx.x == NTH - 1) carry = pos + nd;
           __syncthreads();
@@ -424,6 +443,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
       long long heavy = 0;  // heavy tiles | their local jobs << 32 (a band of an 8K frame holds more than 4096 tiles)
       for (int idx = threadIdx.x; idx < n; idx += NTH) {
         const int tile = tile_at(idx);
+        if (tile < 0) continue;
         const int len = tile_offsets[tile + 1] - tile_offsets[tile];
         if (len > thr_h && has_slots(idx, tile, len)) heavy += 1ll + ((long long)(p.heavy_wide ? 0 : heavy_local_jobs(len)) << 32);
       }
@@ -454,8 +474,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     const int idx = base + (int)threadIdx.x;
     int cnt = 0, tile = 0, flag = 0, need = 0;
     bool heavy_tile = false;
-    if (idx < n) {
-      tile = tile_at(idx);
+    if (idx < n && (tile = tile_at(idx)) >= 0) {
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       const bool slots = has_slots(idx, tile, len);
       cnt = p.seg_parts > 1 && !slots ? 1 : job_count(p, idx, n, tail4, tail2, thr4, thr2, len, slots ? thr_h : 0x7fffffff);
@@ -487,7 +506,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
         pos += wave_tot[w];
         npos += need_tot[w];
       }
-    if (write_tab && idx < n) slot_tab[tile] = need > 0 ? xcd * jb.slot_budget + npos : -1;
+    if (write_tab && idx < n && tile >= 0) slot_tab[tile] = need > 0 ? xcd * jb.slot_budget + npos : -1;
     if (p.seg_parts > 1) {
       for (int j = 0; j < cnt; ++j) seg[pos + j] = tile << 12 | ((j + idx) % cnt) << 6 | (cnt - 1);
     } else if (heavy_tile) {
@@ -520,6 +539,7 @@ __device__ __forceinline__ void build_jobs_block(int block, const JobBuild& jb, 
     int32_t* hv = lc + FG_LOCAL_WORDS;
     for (int idx = threadIdx.x; idx < n; idx += NTH) {
       const int tile = tile_at(idx);
+      if (tile < 0) continue;
       const int len = tile_offsets[tile + 1] - tile_offsets[tile];
       if (len > thr_h && has_slots(idx, tile, len)) {
         const int nl = p.heavy_wide ? 0 : heavy_local_jobs(len);

@@ -2051,7 +2051,7 @@ int band_nx(const Cfg& c) {
 // what lets a light XCD take rows off a heavy one; the workgroups it adds to a launch return at once (~1 ns each).
 int band_rows_limit(const Cfg& c, int tile_h) {
   const int equal = (tile_h + 7) / 8;
-  if (band_nx(c) != 1 || c.balance_bands == 0 || c.balance_bands == 2) return 0;  // (equal rows / equal spans: no band beyond its equal share)
+  if (band_nx(c) != 1 || c.balance_bands == 0 || c.balance_bands == 2) return 0;  // (equal rows / equal spans / interleaved blocks: no band beyond its equal share)
   const int lim = equal + (equal + 1) / 2;
   return lim < tile_h ? lim : tile_h;
 }
@@ -2482,7 +2482,7 @@ int fgjobs::plan_jobs(int width, int height, int tile_size, int32_t* jobs_fwd, i
   const int rows_limit = band_rows_limit(cfg, tile_h);  // (the grids and list segments are sized for it: band_tiles_max)
   *out = fgjobs::JobBuild{tile_w, tile_h, band_nx(cfg), jobs_cap(cfg, tile_w, tile_h), pf, pb, jobs_fwd, jobs_bwd,
                           8 + 8 * jobs_cap(cfg, tile_w, tile_h), rows_limit,
-                          cfg.balance_bands == 0 ? 0 : (cfg.balance_bands == 2 ? -1 : (cfg.balance_bands > 2 ? cfg.balance_bands : 115)),
+                          cfg.balance_bands == 0 ? 0 : (cfg.balance_bands == 2 ? -1 : (cfg.balance_bands == 3 ? -2 : (cfg.balance_bands > 3 ? cfg.balance_bands : 115))),
                           shares ? seg_slots(cfg) / 8 : 0, (int)slot_table_offset(cfg, tile_w, tile_h), nullptr, seg_fine(cfg)};
   return FG_OK;
 }

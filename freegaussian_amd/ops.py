@@ -227,17 +227,24 @@ class RasterContext:
             warnings.warn("freegaussian_amd: torch._C._storage_Use_Count is missing in this torch build -- the workspace pool is "
                           "off and every step allocates its 0.4-0.8 GB workspaces through the caching allocator (a device "
                           "allocation behind every refinement); RasterContext.pool_fallback_calls counts them", RuntimeWarning)
-        # The forward's content thresholds (fg_raster_config::split4_fwd / split2_fwd: a tile is cut into four / two strip
-        # jobs when its list is longer than that many 65536ths of all lists: 20 / 16 = 2.5 x / 2.0 x the mean at 8160 tiles)
-        # are tuned on even scenes, where finer cuts only repeat the staging.  On a scene with a cluster the launch is full
-        # for half of its time and then waits for whole-tile and two-strip jobs over lists of 1.6-2.2 x the mean that
-        # started in its first microsecond (profiles/r05_uneven_splits.md): a shape that has shown a list beyond three
-        # times the mean lately gets 12 / 8 (half of the Gaussians in a ball of 0.4: forward 0.255 -> 0.226 ms; the even
-        # bench scene would lose 4 %).  FG_UNEVEN_SPLIT_FWD="a4,a2" ("0" = off); a policy that sets its own thresholds wins.
-        sp = [int(x) for x in e.get("FG_UNEVEN_SPLIT_FWD", "12,8").split(",")]
+        # UNEVEN shapes (a tile list beyond three times the mean in one of the shape's last eight calls: a cluster, a scene
+        # seen from inside, a trained scene) get another cut of the work, in three parts (round 6, profiles/r06_xcd_shares.md):
+        #  * the XCDs' shares are INTERLEAVED 2 x 2-tile blocks (fg_raster_config::balance_bands = 3) instead of row bands
+        #    priced by a cost model -- list length capped at three times the mean -- that was tuned on the bench layouts: on
+        #    17 layouts it had never seen the bands lost up to 12 % to plain equal spans and won up to 40 % against them; a
+        #    trained scene runs 10 % faster interleaved than with either (FG_UNEVEN_INTERLEAVE=0: the cost bands);
+        #  * the forward's content thresholds (split4_fwd / split2_fwd: a tile is cut into four / two strip jobs when its list
+        #    is longer than that many 65536ths of all lists; 20 / 16 = 2.5 x / 2.0 x the mean on even scenes, where finer cuts
+        #    only repeat the staging) are 8 / 5: with every XCD equally loaded nothing hides a long serial walk any more
+        #    (FG_UNEVEN_SPLIT_FWD="a4,a2", "0" = off; round 5: 12 / 8 with the cost bands);
+        #  * the backward gives a tile list shares from 4 / 65536 of all lists (FG_UNEVEN_SPLIT2_BWD; round 5: 12): whole-tile
+        #    backward jobs over unsaturated lists of 400-900 entries at a cluster's rim were the launch (433 of 433 us).
+        # Measured (1M / 1080p, median step): 80 % in a ball of 0.2: 0.96 (cost bands 0.96-0.98); half in a ball of 0.4: 0.84
+        # (0.855); the trained scene 0.61 (0.68).  Even scenes keep equal spans and their thresholds (they would lose 3 %).
+        sp = [int(x) for x in e.get("FG_UNEVEN_SPLIT_FWD", "8,5").split(",")]
         self.uneven_split_fwd = (sp[0], sp[1] if len(sp) > 1 else 0)
-        # (the backward's share threshold with them: 16 -> 12, backward 0.334 -> 0.330 / 0.352 -> 0.344 ms on the two clustered layouts)
-        self.uneven_split2_bwd = int(e.get("FG_UNEVEN_SPLIT2_BWD", "12"))
+        self.uneven_split2_bwd = int(e.get("FG_UNEVEN_SPLIT2_BWD", "4"))
+        self.uneven_interleave = e.get("FG_UNEVEN_INTERLEAVE", "1") != "0"
         self.heavy_calls = 0  # raster steps planned with heavy tiles on
         self._policy_copies = {}
         # Compact checkpoint slots (FG_COMPACT_SLOTS=0: off): the buffer of the backward's list shares sized by what the tiles
@@ -380,7 +387,7 @@ class RasterContext:
         if not heavy_len and seg_slots <= 0 and not even and split is None:
             return self.policy.ptr(), variant
         # (the policy may have been replaced or changed in place; few keys per policy: seg_slots comes in steps of 4096 slots)
-        key = (bytes(self.policy), heavy_len, int(seg_slots), even, split)
+        key = (bytes(self.policy), heavy_len, int(seg_slots), even, split, self.uneven_split2_bwd, self.uneven_interleave)
         copy = self._policy_copies.get(key)
         if copy is None:
             copy = type(self.policy).from_buffer_copy(self.policy)
@@ -388,6 +395,8 @@ class RasterContext:
                 copy.split4_fwd, copy.split2_fwd = split
                 if self.policy.split4_bwd < 0 and self.uneven_split2_bwd > 0:  # (list shares: only the second threshold counts)
                     copy.split4_bwd, copy.split2_bwd = 20, self.uneven_split2_bwd
+                if self.uneven_interleave and self.policy.balance_bands in (-1, 1):
+                    copy.balance_bands = 3
             if heavy_len:
                 copy.heavy_tiles = heavy_len
             if seg_slots > 0:

@@ -258,6 +258,9 @@ typedef struct fg_raster_config {
                               (rounds 1-3: 8 or 9 of a 1080p frame's 68); 2 = equal numbers of tiles always, the costs are
                               not looked at and lists and grids are sized for equal shares (for a host that knows the
                               scene is even: fg_stbin_count's count_out[2] against the mean list; 5-10 us less per step);
+                              3 (ABI 8, round 6) = INTERLEAVED: the image's 2 x 2-tile blocks dealt to the XCDs round-robin in
+                              raster order -- every XCD a uniform sample of the image, balanced on any content without a
+                              cost model (what a host picks for uneven scenes; lists and grids sized as for the cost bands);
                               -1 / 1 = default; p >= 100: the threshold in percent of the mean (100 = always by cost) */
   int32_t heavy_tiles;     /* forward, job lists + list segments (ABI 7): a tile whose list is longer than this many entries
                               is walked serially for its first 2048 entries only; if pixels are still open there, the rest

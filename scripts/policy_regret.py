@@ -1,0 +1,158 @@
+"""How far is the launch policy's `auto` from the best FIXED setting on scenes it was not tuned on?
+
+``ops.RasterContext`` learns ten switches per shape from what its calls report (heavy tiles, long segments, uneven
+splits, even bands ...), with thresholds swept on the five bench layouts.  This script draws 16 random layouts -- cluster
+fraction / extent, needle fraction / ratio, opacity distribution, scale ceiling and mean, Gaussian count, camera radius
+down to INSIDE the cloud -- plus the trained checkpoint (scripts/train_e2e.py), and runs each with `auto` and with every
+fixed setting of {heavy tiles, long segments, the uneven-scene cut (interleaved shares + finer thresholds; round 5's), footprint
+masks, even bands, interleaved shares}, one switch at a time, in one
+process (a fresh RasterContext per setting: ``RasterContext(env=...)``).  Prints a JSON object and, with an output path, a
+markdown table of `auto` / best.
+
+Usage: python scripts/policy_regret.py [out.json] [out.md] [n_layouts=16] [seed=5]"""
+import json
+import math
+import os
+import random
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from freegaussian_amd import ops, rasterization  # noqa: E402
+from freegaussian_amd.scenes import apply_layout, load_trained_scene, synthetic_scene  # noqa: E402
+
+SETTINGS = {
+    "auto": {},
+    "heavy=always": {"FG_HEAVY_TILES": "always"}, "heavy=never": {"FG_HEAVY_TILES": "never"},
+    "long=always": {"FG_LONG_SEGMENTS": "always"}, "long=never": {"FG_LONG_SEGMENTS": "never"},
+    "uneven=off": {"FG_UNEVEN_SPLIT_FWD": "0"}, "uneven=on": {"FG_RASTER_BALANCE": "3", "FG_RASTER_SPLIT_FWD": "8,5", "FG_RASTER_SPLIT_BWD": "20,4"},
+    "uneven=r05": {"FG_UNEVEN_INTERLEAVE": "0", "FG_UNEVEN_SPLIT_FWD": "12,8", "FG_UNEVEN_SPLIT2_BWD": "12"},
+    "masks=off": {"FG_EXACT_TILES": "0"},
+    "even=never": {"FG_EVEN_BANDS": "0"}, "even=always": {"FG_RASTER_BALANCE": "2"}, "bands=interleaved": {"FG_RASTER_BALANCE": "3"},
+}  # fmt: skip
+WARM, TIMED = int(os.environ.get("REGRET_WARM", "24")), int(os.environ.get("REGRET_TIMED", "32"))
+if os.environ.get("REGRET_SETTINGS"):  # a subset, e.g. "auto,even=always" (A/B of library builds)
+    SETTINGS = {k: SETTINGS[k] for k in os.environ["REGRET_SETTINGS"].split(",")}
+
+
+def draw_layouts(n, seed):
+    rng = random.Random(seed)
+    out = []
+    for i in range(n):
+        d = {"n": rng.choice([300_000, 1_000_000, 1_000_000]), "cam_radius": rng.choice([4.0, 4.0, 2.5, 1.2, 0.5]),
+             "scale_mean": rng.choice([0.005, 0.01, 0.01, 0.02]), "scale_max": rng.choice([0.05, 0.05, 0.15, 0.4]),
+             "opac_std": rng.choice([0.5, 1.5, 3.0]), "opac_shift": rng.choice([-1.0, 0.0, 0.0, 2.0])}  # fmt: skip
+        parts = []
+        if rng.random() < 0.6:
+            parts.append(f"clustered:{rng.choice([0.2, 0.4, 0.6, 0.8])}:{rng.choice([0.2, 0.3, 0.4, 0.6])}")
+        if rng.random() < 0.6:
+            parts.append(f"needles:{rng.choice([0.1, 0.3, 0.5])}:{rng.choice([5, 10, 20])}")
+        d["layout"] = "+".join(parts) or "uniform"
+        out.append(d)
+    return out
+
+
+def build_scene(d):
+    sc = synthetic_scene(d["n"], 1920, 1080, n_views=8, sh_degree=3, seed=42, cam_radius=d["cam_radius"],
+                         log_scale_mean=math.log(d["scale_mean"]))  # fmt: skip
+    # (synthetic_scene clips the scales to 0.05 and draws opacity = sigmoid(N(0, 1.5^2)): redrawn here with this layout's)
+    g = torch.Generator().manual_seed(11)
+    ls = torch.randn(d["n"], 3, generator=g) * 0.5 + math.log(d["scale_mean"])
+    sc.scales = torch.exp(ls.clamp(math.log(0.002), math.log(d["scale_max"])))
+    sc.opacities = torch.sigmoid(torch.randn(d["n"], generator=g) * d["opac_std"] + d["opac_shift"])
+    return apply_layout(sc, d["layout"])
+
+
+def measure(sc, env, dev, warm=None, timed=None):
+    WARM_, TIMED_ = warm or WARM, timed or TIMED
+    ctx = ops.RasterContext(env=env)
+    g = [getattr(sc, k).to(dev).requires_grad_(True) for k in ("means", "quats", "scales", "opacities", "colors")]
+    vms, Ks = sc.viewmats.to(dev), sc.Ks.to(dev)
+    vr = torch.randn(1, sc.height, sc.width, 3, generator=torch.Generator().manual_seed(1)).to(dev)
+    V = vms.shape[0]
+    info = None
+
+    def step(i):
+        nonlocal info
+        for t in g:
+            t.grad = None
+        with ops.use(ctx):
+            r, _, info = rasterization(*g, vms[i % V : i % V + 1], Ks[i % V : i % V + 1], sc.width, sc.height, sh_degree=sc.sh_degree,
+                                       render_mode="RGB", packed=False, absgrad=True)  # fmt: skip
+            r.backward(vr)
+
+    for i in range(WARM_):
+        step(i)
+    torch.cuda.synchronize()
+    marks = [time.perf_counter()]
+    for i in range(TIMED_):
+        step(i)
+        marks.append(time.perf_counter())
+    torch.cuda.synchronize()
+    total = (time.perf_counter() - marks[0]) / TIMED_ * 1e3
+    per = sorted((b - a) * 1e3 for a, b in zip(marks, marks[1:]))
+    offs = info["raster_isect_offsets"].reshape(-1)
+    res = {"ms": total, "median_ms": per[len(per) // 2], "heavy_calls": ctx.heavy_calls, "long_calls": ctx.long_calls,
+           "redos": ctx.capacity_redos, "uneven": any(v > 0 for v in ctx.uneven_left.values()),
+           "even": any(ctx.even_shape(k) for k in ctx.shape_calls),
+           "I_raster": int(info["raster_flatten_ids"].numel()), "longest": int((offs[1:] - offs[:-1]).max()),
+           "V": int((info["radii"] > 0).sum())}  # fmt: skip
+    ctx.release_workspaces()
+    return res
+
+
+def main():
+    out_json = sys.argv[1] if len(sys.argv) > 1 else None
+    out_md = sys.argv[2] if len(sys.argv) > 2 else None
+    n_layouts = int(sys.argv[3]) if len(sys.argv) > 3 else 16
+    seed = int(sys.argv[4]) if len(sys.argv) > 4 else 5
+    dev = torch.device("cuda", 0)
+    layouts = draw_layouts(n_layouts, seed)
+    trained = os.path.join(ROOT, "data", "trained_scene_r06.npz")
+    if os.path.exists(trained):
+        layouts.append({"layout": "trained", "file": trained})
+    rows = []
+    for d in layouts:
+        sc = load_trained_scene(d["file"]) if "file" in d else build_scene(d)
+        res = {}
+        warm = timed = None
+        for name, env in SETTINGS.items():
+            try:
+                res[name] = measure(sc, dict(env), dev, warm, timed)
+                if name == "auto" and res[name]["median_ms"] > 5.0:  # (a camera inside a cloud of large splats: fewer steps)
+                    warm, timed = 16, 16
+            except Exception as e:  # noqa: BLE001
+                res[name] = {"error": repr(e)[:160]}
+        ok = {k: v["median_ms"] for k, v in res.items() if "median_ms" in v}
+        best = min(ok, key=ok.get)
+        row = {"layout": {k: v for k, v in d.items() if k != "file"}, "auto_ms": ok.get("auto"), "best": best, "best_ms": ok[best],
+               "regret": ok["auto"] / ok[best] if "auto" in ok else None, "settings_ms": {k: round(v, 4) for k, v in ok.items()},
+               "auto_state": {k: res["auto"].get(k) for k in ("heavy_calls", "long_calls", "redos", "uneven", "even", "I_raster", "longest", "V")},
+               "errors": {k: v["error"] for k, v in res.items() if "error" in v}}  # fmt: skip
+        rows.append(row)
+        print(f"[regret] {row['layout']}: auto {row['auto_ms']:.3f} best {best} {row['best_ms']:.3f} -> {row['regret']:.3f}", file=sys.stderr, flush=True)
+    regrets = [r["regret"] for r in rows if r["regret"]]
+    summary = {"layouts": len(rows), "within_3pct": sum(1 for x in regrets if x <= 1.03), "worst": max(regrets), "mean": sum(regrets) / len(regrets),
+               "warm_steps": WARM, "timed_steps": TIMED, "metric": "median host time per step (fwd + bwd, 8 views cycling; the host waits for every step's list length)"}  # fmt: skip
+    out = {"summary": summary, "rows": rows, "settings": {k: v for k, v in SETTINGS.items()}}
+    if out_json:
+        json.dump(out, open(out_json, "w"), indent=1)
+    if out_md:
+        names = [k for k in SETTINGS if k != "auto"]
+        lines = ["| layout | N | V | I_raster | longest list | auto (ms) | " + " | ".join(names) + " | best | auto / best |", "|" + "---|" * (8 + len(names))]
+        for r in rows:
+            L = r["layout"]
+            desc = L["layout"] if L["layout"] == "trained" else (
+                f"{L['layout']}; cam {L['cam_radius']}, scale {L['scale_mean']}..{L['scale_max']}, opac N({L['opac_shift']}, {L['opac_std']})")
+            st = r["auto_state"]
+            lines.append(f"| {desc} | {L.get('n', '')} | {st['V']} | {st['I_raster']} | {st['longest']} | {r['auto_ms']:.3f} | "
+                         + " | ".join(f"{r['settings_ms'].get(k, float('nan')):.3f}" for k in names) + f" | {r['best']} | **{r['regret']:.3f}** |")
+        open(out_md, "w").write("\n".join(lines) + "\n\n" + json.dumps(summary) + "\n")
+    print(json.dumps(summary))
+
+
+if __name__ == "__main__":
+    main()

@@ -26,6 +26,11 @@ if len(sys.argv) > 3 and sys.argv[3].startswith("trained:"):  # trained:<trained
     from freegaussian_amd.scenes import load_trained_scene
 
     sc = load_trained_scene(sys.argv[3].split(":", 1)[1])
+elif len(sys.argv) > 3 and sys.argv[3].startswith("{"):  # a layout of scripts/policy_regret.py, as JSON
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from policy_regret import build_scene
+
+    sc = build_scene(json.loads(sys.argv[3]))
 elif len(sys.argv) > 3 and sys.argv[3]:
     frac, ball = (float(v) for v in sys.argv[3].split(":"))
     sc.means[: int(frac * n)] *= ball / 2.0
