@@ -934,7 +934,10 @@ def main(argv=None):
             "section 8d use it); I_raster = entries of the lists actually binned and composited: the footprint rectangles "
             "and, inside them, the footprint masks (the blocks of the rectangle the ellipse itself reaches) drop (splat, "
             "tile) pairs in which the splat reaches alpha >= 1/255 nowhere (same image, same gradients)",
-            "footprint_masks": bool(ops.current().exact_tiles),
+            # (per image size, where they pay: the share of the rectangles' (splat, tile) pairs the masks kept in the shape's last
+            # masked calls; above RasterContext.mask_keep_max the shape runs without them and looks again every 64th call)
+            "footprint_masks": {"on_for_the_next_call": bool(ops.current().masks_on((dev, info["tile_width"], info["tile_height"]))),
+                                "kept_share_of_last_masked_calls": [round(x, 3) for x in (ops.current().mask_keep.get((dev, info["tile_width"], info["tile_height"])) or [[]])[0]]},
             "counts_are_for_view": view,
             "binning": {
                 "supertile": "supertile (csrc/stbin.hip): count by corner marks -> column scan -> one 8-byte element per "

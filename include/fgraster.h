@@ -44,7 +44,7 @@ typedef void* fg_stream_t;
 #define FG_MAX_CHANNELS 8    /* composited feature channels per splat (RGB, depth, flow, ...) */
 #define FG_SPLAT_FLOATS 16   /* one 64-byte record per Gaussian, see fg_pack_splats */
 #define FG_SH_JAC_FLOATS 10  /* per-Gaussian note of the SH colour for the backward, see fg_preprocess_fwd */
-#define FG_ABI_VERSION 8
+#define FG_ABI_VERSION 9
 
 int fg_abi_version(void);
 const char* fg_error_string(int code);
@@ -150,10 +150,14 @@ int fg_bin_prepare_keys(int N, uint32_t* depth_keys, const int32_t* tile_rects, 
  * 6 launches instead of the 26 of fg_bin_prepare_keys + fg_bin_emit_sort, 2.5x fewer scattered and sorted
  * elements than (Gaussian, tile) pairs on the 1M / 1080p scene (csrc/stbin.hip).
  * tile_rects / depth_keys: the optional outputs of fg_preprocess_fwd.  fg_stbin_count writes
- * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, FOUR words with
- * system scope (pinned host memory): count_out[0] the list length, count_out[2] the longest tile list (a host
- * turns fg_raster_config::heavy_tiles on from it), count_out[1] the longest supertile segment and count_out[3] the
- * number of segments of more than 3072 elements
+ * tile_offsets[T + 1] (exact, independent of any capacity) and, if count_out is not NULL, FIVE words of a block of
+ * SIXTEEN int64 (ABI 9; a block of four before) with system scope (pinned host memory): count_out[0] the list length,
+ * count_out[2] the longest tile list (a host turns fg_raster_config::heavy_tiles on from it), count_out[1] the longest
+ * supertile segment, count_out[3] the number of segments of more than 3072 elements, and count_out[14] the summed AREA of
+ * the footprint rectangles in tiles -- what the list length would be without tile_masks: a host keeps the masks for an
+ * image size only while list length / area says they drop enough (ops.RasterContext.masks_on: below 0.8).  (Words 4..13
+ * and 15 belong to fg_stbin_fill_jobs' ckpt_need_out and fg_raster_jobs_fwd's walk_out when the host hands them the same
+ * block, as ops.py does.)
  * (segments beyond 7936 elements are sorted by one workgroup through global memory -- correct, slow -- unless
  * fg_stbin_fill is called with FG_STBIN_LONG_SEGMENTS, see below).  fg_stbin_fill writes flatten_ids[0 .. tile_offsets[T]) and
  * list_offsets[T + 1] = tile_offsets -- or, when the list is longer than `capacity`, no ids at all and

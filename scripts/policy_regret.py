@@ -30,7 +30,7 @@ SETTINGS = {
     "long=always": {"FG_LONG_SEGMENTS": "always"}, "long=never": {"FG_LONG_SEGMENTS": "never"},
     "uneven=off": {"FG_UNEVEN_SPLIT_FWD": "0"}, "uneven=on": {"FG_RASTER_BALANCE": "3", "FG_RASTER_SPLIT_FWD": "8,5", "FG_RASTER_SPLIT_BWD": "20,4"},
     "uneven=r05": {"FG_UNEVEN_INTERLEAVE": "0", "FG_UNEVEN_SPLIT_FWD": "12,8", "FG_UNEVEN_SPLIT2_BWD": "12"},
-    "masks=off": {"FG_EXACT_TILES": "0"},
+    "masks=off": {"FG_EXACT_TILES": "0"}, "long_many=off": {"FG_LONG_MANY": "1000000"},
     "even=never": {"FG_EVEN_BANDS": "0"}, "even=always": {"FG_RASTER_BALANCE": "2"}, "bands=interleaved": {"FG_RASTER_BALANCE": "3"},
 }  # fmt: skip
 WARM, TIMED = int(os.environ.get("REGRET_WARM", "24")), int(os.environ.get("REGRET_TIMED", "32"))

@@ -179,6 +179,7 @@ def test_footprint_rectangles_cull_only_dead_entries(mode, layout, monkeypatch):
     for tight, exact in ((True, True), (True, False), (False, False)):
         monkeypatch.setattr(ops.default_context, "tight_rects", tight)
         monkeypatch.setattr(ops.default_context, "exact_tiles", exact)
+        monkeypatch.setattr(ops.default_context, "masks_always", exact)  # (not "where they pay": this test wants them)
         t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
         r, a, info = rasterization(*t, vm, K, sc.width, sc.height, sh_degree=3, packed=False, absgrad=True,
                                    rasterize_mode=mode)  # fmt: skip
@@ -830,6 +831,7 @@ def test_learned_launch_state_carries_over_a_change_of_the_gaussian_count():
     sc = synthetic_scene(1_000_000, 1920, 1080, n_views=2, sh_degree=3, seed=42)
     vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
     ctx = ops.RasterContext()
+    ctx.masks_always = True  # (the lists of two contexts are compared below: both with footprint masks, whatever they keep)
     if not ctx.step_calls or ctx.binning != "supertile" or not ctx.compact_slots:
         pytest.skip("the environment selects the stage-wise path")
     vr = torch.randn(1, 1080, 1920, 3, generator=torch.Generator().manual_seed(1)).to(DEV)
@@ -856,6 +858,7 @@ def test_learned_launch_state_carries_over_a_change_of_the_gaussian_count():
         assert (ctx.stagewise_raster_calls, ctx.capacity_redos, ctx.full_ckpt_allocs) == before, (n, before)
         fresh = ops.RasterContext()
         fresh.step_calls = False
+        fresh.masks_always = True
         ref = run(fresh, n)
         assert torch.equal(got[0], ref[0]) and torch.equal(got[1], ref[1]) and torch.equal(got[2], ref[2])
         for k in ref[3]:
@@ -2644,3 +2647,46 @@ def test_randomised_parity_big(case):
     ok, msg = fuzz_cases.check(fuzz_cases.Case(4, case, big=True), device=DEV)
     print(msg)
     assert ok, msg
+
+
+@pytest.mark.gpu
+def test_footprint_masks_only_where_they_pay():
+    """fg_stbin_count reports the footprint rectangles' area beside the list length (count_out[14], ABI 9); a shape keeps
+    its footprint masks only while list length / area -- what the masks keep -- stays below RasterContext.mask_keep_max.
+    Round splats (the bench cloud: 0.88 kept) lose the masks after their first masked call and look again every 64th call;
+    needles (0.43) keep them.  Same image in both states, bit for bit; the lists of the unmasked call are the rectangles'."""
+    from freegaussian_amd.scenes import apply_layout
+
+    def run(sc, ctx, n_calls):
+        vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+        ins = [getattr(sc, k).to(DEV) for k in ("means", "quats", "scales", "opacities", "colors")]
+        out = []
+        for _ in range(n_calls):
+            on = ctx.masks_on((torch.device(DEV, torch.cuda.current_device()), 60, 34))
+            with torch.no_grad():
+                r, a, info = rasterization(*ins, vm, K, 960, 540, sh_degree=3, packed=False, ctx=ctx)
+            out.append((on, r.clone(), int(info["raster_flatten_ids"].numel())))
+        return out
+
+    round_ = synthetic_scene(200_000, 960, 540, n_views=1, sh_degree=3, seed=42)
+    ctx = ops.RasterContext(env={"FG_MASK_KEEP_MAX": "0.8"})  # (the switch is off by default: RasterContext.mask_keep_max)
+    got = run(round_, ctx, 80)
+    lkey = next(iter(ctx.mask_keep))
+    assert got[0][0] and 0.8 < ctx.mask_keep[lkey][0][0] < 0.97  # the first call is masked; round splats keep ~0.9
+    # masked while the shape has not shown eight even scenes in a row, then off, with a look every 64th call
+    flags = [on for on, _, _ in got]
+    first_off = flags.index(False)
+    assert 8 <= first_off <= 10 and not any(flags[first_off : first_off + 63]) and flags[first_off + 63] and not flags[first_off + 64]
+    assert got[first_off][2] > got[0][2] and got[first_off + 63][2] == got[0][2]  # the unmasked lists are the rectangles'
+    for _, r, _ in got[1:]:
+        assert torch.equal(r, got[0][1])  # the masks drop only pairs no pixel takes
+    always = run(round_, ops.RasterContext(env={"FG_EXACT_TILES": "always"}), 3)
+    never = run(round_, ops.RasterContext(env={"FG_EXACT_TILES": "0"}), 3)
+    assert all(on for on, _, _ in always) and not any(on for on, _, _ in never)
+    assert always[2][2] == got[0][2] and never[2][2] == got[first_off][2]
+    needles = apply_layout(synthetic_scene(200_000, 960, 540, n_views=1, sh_degree=3, seed=42), "needles:0.4:10")
+    ctx2 = ops.RasterContext(env={"FG_MASK_KEEP_MAX": "0.8"})
+    got2 = run(needles, ctx2, 6)
+    dflt = run(round_, ops.RasterContext(env={}), 12)
+    assert all(on for on, _, _ in dflt)  # default: masks stay on (the measured ratio is reported, not acted on)
+    assert all(on for on, _, _ in got2) and max(next(iter(ctx2.mask_keep.values()))[0]) < 0.7
