@@ -12,6 +12,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 from freegaussian_amd.model import FreeGaussianModel, FreeGaussianModelConfig  # noqa: E402
 from freegaussian_amd.scenes import load_trained_scene, room_scene  # noqa: E402
@@ -133,6 +134,39 @@ def test_twin_training_run_hip_vs_cpu_oracle():
     assert sum(rel[-50:]) / 50 < 0.10
 
 
+def _trained_frame_vs_oracle(model, scene, meta):
+    """What the OPTIMISER produced -- anisotropic splats, some hundreds of pixels wide, some next to the lens -- through the HIP
+    path and the CPU oracle: the reference's lists bit for bit, the walked lists an order-preserving subsequence of them, image
+    and every gradient at the suite's bar.  One ring view and one view from among the objects."""
+    from helpers import REL_TOL, close_except_knife_edge, rel_l2
+    from oracle import raster_oracle as O
+
+    from freegaussian_amd import rasterization
+
+    gp = model.gauss_params
+    with torch.no_grad():
+        ins = [gp["means"], gp["quats"] / gp["quats"].norm(dim=-1, keepdim=True), torch.exp(gp["scales"]),
+               torch.sigmoid(gp["opacities"]).squeeze(-1), torch.cat([gp["features_dc"][:, None, :], gp["features_rest"]], 1)]  # fmt: skip
+    ins = [t.detach().clone() for t in ins]
+    W, H = scene.width, scene.height
+    for v in (meta["kinds"][0][1], meta["kinds"][3][1] + 2):
+        vm, K = scene.viewmats[v : v + 1], scene.Ks[v : v + 1]
+        vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(v))
+        g = [t.clone().requires_grad_(True) for t in ins]
+        r, a, info = rasterization(*g, vm.to(g[0].device), K.to(g[0].device), W, H, sh_degree=3, packed=False, absgrad=True)
+        (r * vr.to(r.device)).sum().backward()
+        c = [t.cpu().clone().requires_grad_(True) for t in ins]
+        r0, a0, info0 = O.rasterization(*c, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
+        (r0 * vr).sum().backward()
+        assert torch.equal(info["radii"].cpu(), info0["radii"]) and torch.equal(info["flatten_ids"].cpu(), info0["flatten_ids"]), v
+        assert torch.equal(info["isect_offsets"].cpu(), info0["isect_offsets"])
+        assert close_except_knife_edge(r, r0) and close_except_knife_edge(a, a0), v
+        worst = max(rel_l2(x.grad.cpu(), y.grad) for x, y in zip(g, c))
+        print(f"trained frame, view {v}: V {int((info0['radii'] > 0).sum())} of {ins[0].shape[0]}, I {info0['flatten_ids'].numel()}, "
+              f"largest radius {int(info0['radii'].max())} px, worst gradient rel L2 {worst:.1e}")
+        assert worst < REL_TOL, (v, worst)
+
+
 @pytest.mark.gpu
 def test_short_end_to_end_run_learns_the_scene():
     """A bounded version of scripts/train_e2e.py inside the gate: 240x135 target, schedule compressed 10x (resolution 150 / 300,
@@ -146,6 +180,7 @@ def test_short_end_to_end_run_learns_the_scene():
                             num_random=8000, log=lambda *a: None, config_overrides=over)  # fmt: skip
     ps = [e["heldout_psnr"] for e in rep["evals"]]
     print("short e2e: held-out PSNR", [round(p, 2) for p in ps], "N", [e["N"] for e in rep["evals"]])
+    _trained_frame_vs_oracle(model, _[0], _[1])
     assert ps[0] < ps[1] < ps[2] and ps[2] > 18.0  # (19.9 ... 20.9 over the round's visits: two runs differ by ~1 dB, profiles/r06_trained_scene.md)
     assert rep["N_final"] > 8000
     assert rep["policy_counters"]["end"]["capacity_redos"] <= 6
