@@ -2690,3 +2690,43 @@ def test_footprint_masks_only_where_they_pay():
     dflt = run(round_, ops.RasterContext(env={}), 12)
     assert all(on for on, _, _ in dflt)  # default: masks stay on (the measured ratio is reported, not acted on)
     assert all(on for on, _, _ in got2) and max(next(iter(ctx2.mask_keep.values()))[0]) < 0.7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", [(400, 240), (1000, 600), (1912, 1080)])
+def test_interleaved_xcd_shares_on_odd_and_even_tile_grids(size):
+    """fg_raster_config::balance_bands = 3: the image's 2 x 2-tile blocks dealt to the XCDs round-robin (what uneven shapes
+    get since round 6).  Tile grids with an odd width and / or height (25 x 15, 63 x 38, 120 x 68): the edge blocks' missing
+    tiles have no job, every real tile exactly one owner -- the image is the default policy's bit for bit, the gradients
+    equal up to the order of float atomics; with list shares, finer thresholds and heavy tiles on top."""
+    W, H = size
+    sc = synthetic_scene(150_000, W, H, n_views=1, sh_degree=3, seed=21, log_scale_mean=math.log(0.02), focal=1200.0 * W / 1920.0)
+    sc.means[:60_000] *= 0.15  # a cluster: long lists at the centre, uneven by any measure
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(2)).to(DEV)
+    ins = {k: getattr(sc, k).to(DEV) for k in ("means", "quats", "scales", "opacities", "colors")}
+
+    def run(ctx, calls=3):
+        for _ in range(calls):
+            t = {k: v.clone().requires_grad_(True) for k, v in ins.items()}
+            r, a, info = rasterization(*t.values(), vm, K, W, H, sh_degree=3, packed=False, absgrad=True, ctx=ctx)
+            ((r * vr).sum() + a.sum()).backward()
+        torch.cuda.synchronize()
+        return r.detach(), a.detach(), {k: v.grad for k, v in t.items()}, info
+
+    base = ops.RasterContext(env={"FG_UNEVEN_SPLIT_FWD": "0", "FG_HEAVY_TILES": "never"})
+    if int(_lib.load().fg_raster_jobs_words(W, H, 16, base.cfg())) == 0:
+        pytest.skip("classic launches at this size: no job lists")
+    r0, a0, g0, _ = run(base)
+    for env, policy in (({"FG_HEAVY_TILES": "never"}, ops.launch_policy(balance_bands=3)),
+                        ({"FG_HEAVY_TILES": "never"}, ops.launch_policy(balance_bands=3, split4_fwd=8, split2_fwd=5, split4_bwd=20, split2_bwd=4)),
+                        ({}, None)):  # (the host's own choice for this shape: uneven from its second call on)
+        ctx = ops.RasterContext(env=env, policy=policy)
+        r, a, g, info = run(ctx)
+        if policy is None:
+            assert ctx.uneven_shape(next(iter(ctx.uneven_left))) and ctx.cfg_variant(False, 0, False, True)[1][3] == (8, 5)
+            assert rel_err(r, r0) < 2e-6 and rel_err(a, a0) < 2e-6  # (heavy tiles may be on: not the serial walk bit for bit)
+        else:
+            assert torch.equal(r, r0) and torch.equal(a, a0)
+        diff = {k: rel_l2(g[k], g0[k]) for k in g0}
+        assert all(v < 1e-5 for v in diff.values()), (env, diff)
