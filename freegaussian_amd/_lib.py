@@ -107,6 +107,7 @@ _EXTRA = {"fg_debug_wave_reduce16": (c_int, [P, P, P])}
 
 ABI_VERSION = 9
 STBIN_LONG_SEGMENTS = 1  # FG_STBIN_LONG_SEGMENTS
+STBIN_TEST_SMALL_SLABS = 4  # FG_STBIN_TEST_SMALL_SLABS (tests: the sample sort's overflow path)
 STEP_NO_FOOTPRINT_MASKS = 2  # FG_STEP_NO_FOOTPRINT_MASKS
 SH_JAC_FLOATS = 10  # FG_SH_JAC_FLOATS
 _lib = None

@@ -70,6 +70,8 @@ constexpr int LG_KMAX = 1008;                        // buckets per segment at m
 constexpr int LG_SA = 32;                            // samples per bucket (fewer when LG_SA * k exceeds one LDS sort): a bucket twice its target is a 1e-6 event
 constexpr int LG_BLOCK = 512, LG_PER = 8, LG_CHUNK = LG_BLOCK * LG_PER;  // count / scatter passes over a long segment
 constexpr int LG_GRID = 1024, LG_SORT_GRID = 1024;   // persistent workgroups of those passes / of the bucket sort
+constexpr int SB_LONG_OVER_GRID = 64;                // workgroups of sb_long_overflow_kernel
+constexpr int SB_LONG_SLAB = SB_LONG_SPLIT;          // elements of `scratch` a bucket owns: what the LDS sort of sb_long_sort_kernel takes (2 x LG_T)
 __host__ __device__ __forceinline__ int long_buckets(int n) {
   const int k = (n + LG_T - 1) / LG_T;
   return k > LG_KMAX ? LG_KMAX : (k < 2 ? 2 : k);
@@ -94,6 +96,7 @@ struct LongTables {
   // follow: -(supertile + 1) at [2 ..], bucket slots at [2 + over_cap ..]
   int32_t* over_list;
   int over_cap;
+  uint64_t* arena;     // sb_long_overflow_kernel: SB_LONG_OVER_GRID x 7936 elements, a stretch per workgroup
 };
 __device__ __forceinline__ int n_slots_cap(const LongTables& lt) { return lt.over_cap; }
 
@@ -1381,112 +1384,39 @@ __device__ __forceinline__ int long_bucket_of(const uint64_t* s_split, int k, ui
 }
 static_assert(LG_KMAX <= 1024, "long_bucket_of bisects 10 levels");
 
+static_assert(LG_CHUNK < 65536, "16-bit per-chunk tile counters");
+
+// COUNT AND SCATTER IN ONE PASS (round 6; rounds 4-5: a count launch, then a scatter launch that needed the counts' prefix
+// sums for the buckets' starts).  Every bucket owns a SLAB of SB_LONG_SLAB elements of `scratch` -- twice its target size,
+// what the LDS sort takes -- at (first bucket slot of the segment + bucket) x SB_LONG_SLAB: a chunk reserves a run per
+// (chunk, bucket) with ONE returning atomic on the bucket's cursor and stores at slab + run + rank; the cursor is the
+// bucket's element count when the launch ends.  An element beyond the slab (the sample was unlucky by a factor of two: a
+// 1e-6 event per bucket) is NOT stored; the cursor still counts it and sb_long_overflow_kernel sends the bucket's whole SEGMENT
+// through global memory from `entries`, which this pass leaves intact.  Per (bucket, tile of the supertile) counts ride
+// along as before.  Order inside a bucket: any.
 __global__ void __launch_bounds__(LG_BLOCK)
-sb_long_count_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long long capacity,
-                     const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list,
-                     const uint64_t* __restrict__ entries, LongTables lt) {
+sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long long capacity,
+                       const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list,
+                       const uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, LongTables lt, int slab_limit) {
   __shared__ uint64_t s_split[LG_KMAX];
-  __shared__ uint32_t s_cnt[LG_KMAX];
+  __shared__ uint32_t s_hist[LG_KMAX], s_base[LG_KMAX];
   __shared__ unsigned long long s_tc[LG_KMAX];  // four 16-bit counters: elements of this chunk per tile of the supertile
   if ((long long)tile_offsets[n_tiles] > capacity) return;
   const int4 hdr = long_list[0];
   int cur = -1;
   for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
-    const int4 ci = lt.chunk_seg[w];
-    const int4 ls = make_int4(0, 0, ci.x, ci.z);  // (.z: first bucket slot, .w: elements)
-    const int n = ci.z, k = long_buckets(n), c = ci.w, seg = ci.x;
+    const int4 ci = lt.chunk_seg[w];  // {first bucket slot, first element, elements, chunk in the segment}
+    const int slot0 = ci.x, n = ci.z, k = long_buckets(n), c = ci.w;
     const uint64_t* __restrict__ src = entries + ci.y;
-    if (seg != cur) {
-      for (int t = threadIdx.x; t < k - 1; t += LG_BLOCK) s_split[t] = lt.split[ls.z + t];
-      cur = seg;
+    if (slot0 != cur) {
+      __syncthreads();
+      for (int t = threadIdx.x; t < k - 1; t += LG_BLOCK) s_split[t] = lt.split[slot0 + t];
+      cur = slot0;
     }
     for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
-      s_cnt[t] = 0u;
+      s_hist[t] = 0u;
       s_tc[t] = 0ull;
     }
-    __syncthreads();
-    uint64_t e[LG_PER];
-#pragma unroll
-    for (int q = 0; q < LG_PER; ++q) {
-      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
-      e[q] = src[min(i, n - 1)];
-    }
-#pragma unroll
-    for (int q = 0; q < LG_PER; ++q) {
-      const int i = c * LG_CHUNK + q * LG_BLOCK + (int)threadIdx.x;
-      if (i < n) {
-        const int b = long_bucket_of(s_split, k, e[q]);
-        const uint32_t m = (uint32_t)e[q] & 15u;
-        atomicAdd(&s_cnt[b], 1u);
-        atomicAdd(&s_tc[b], (unsigned long long)(m & 1u) | ((unsigned long long)((m >> 1) & 1u) << 16) |
-                                ((unsigned long long)((m >> 2) & 1u) << 32) | ((unsigned long long)((m >> 3) & 1u) << 48));
-      }
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
-      const uint32_t cn = s_cnt[t];
-      if (cn) {
-        const unsigned long long tc = s_tc[t];
-        atomicAdd(&lt.cnt[ls.z + t], cn);
-        uint32_t* tg = reinterpret_cast<uint32_t*>(&lt.tcnt[ls.z + t]);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const uint32_t v = (uint32_t)(tc >> (16 * j)) & 0xFFFFu;
-          if (v) atomicAdd(&tg[j], v);
-        }
-      }
-    }
-    __syncthreads();
-  }
-}
-static_assert(LG_CHUNK < 65536, "16-bit per-chunk tile counters");
-
-// exclusive prefix sums over k <= 2 * LG_BLOCK values in LDS, in place; returns nothing (all threads call)
-__device__ __forceinline__ void long_excl_scan(uint32_t* vals, int k, uint32_t* s_wtot) {
-  const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
-  const int i = 2 * (int)threadIdx.x;
-  const uint32_t a = i < k ? vals[i] : 0u, b = i + 1 < k ? vals[i + 1] : 0u;
-  const uint32_t incl = wave_incl_scan(a + b, lane);
-  __syncthreads();
-  if (lane == 63) s_wtot[wave] = incl;
-  __syncthreads();
-  uint32_t run = incl - (a + b);
-#pragma unroll
-  for (int w = 0; w < LG_BLOCK / 64; ++w)
-    if (w < wave) run += s_wtot[w];
-  if (i < k) vals[i] = run;
-  if (i + 1 < k) vals[i + 1] = run + a;
-  __syncthreads();
-}
-static_assert(LG_KMAX <= 2 * LG_BLOCK, "long_excl_scan takes two values per thread");
-
-__global__ void __launch_bounds__(LG_BLOCK)
-sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, long long capacity,
-                       const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list,
-                       const uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, LongTables lt) {
-  __shared__ uint64_t s_split[LG_KMAX];
-  __shared__ uint32_t s_boff[LG_KMAX], s_hist[LG_KMAX], s_tmp[LG_KMAX];
-  __shared__ uint32_t s_wtot[LG_BLOCK / 64];
-  if ((long long)tile_offsets[n_tiles] > capacity) return;
-  const int4 hdr = long_list[0];
-  int cur = -1;
-  for (int w = blockIdx.x; w < hdr.y; w += gridDim.x) {
-    const int4 ci = lt.chunk_seg[w];
-    const int4 ls = make_int4(0, 0, ci.x, ci.z);  // (.z: first bucket slot, .w: elements)
-    const int n = ci.z, k = long_buckets(n), c = ci.w, seg = ci.x;
-    const int off = ci.y;
-    const uint64_t* __restrict__ src = entries + off;
-    if (seg != cur) {
-      __syncthreads();
-      for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
-        if (t + 1 < k) s_split[t] = lt.split[ls.z + t];
-        s_boff[t] = lt.cnt[ls.z + t];
-      }
-      __syncthreads();
-      long_excl_scan(s_boff, k, s_wtot);  // bucket starts inside the segment
-      cur = seg;
-    }
-    for (int t = threadIdx.x; t < k; t += LG_BLOCK) s_hist[t] = 0u;
     __syncthreads();
     uint64_t e[LG_PER];
     int bk[LG_PER];
@@ -1504,18 +1434,33 @@ sb_long_scatter_kernel(const int32_t* __restrict__ tile_offsets, int n_tiles, lo
       if (i < n) {
         bk[q] = long_bucket_of(s_split, k, e[q]);
         rk[q] = atomicAdd(&s_hist[bk[q]], 1u);
+        const uint32_t m = (uint32_t)e[q] & 15u;
+        atomicAdd(&s_tc[bk[q]], (unsigned long long)(m & 1u) | ((unsigned long long)((m >> 1) & 1u) << 16) |
+                                    ((unsigned long long)((m >> 2) & 1u) << 32) | ((unsigned long long)((m >> 3) & 1u) << 48));
       }
     }
     __syncthreads();
-    // one run per (chunk, bucket): s_tmp[b] = the run's first slot in the segment
+    // one run per (chunk, bucket): s_base[b] = the run's first slot in the bucket's slab
     for (int t = threadIdx.x; t < k; t += LG_BLOCK) {
       const uint32_t h = s_hist[t];
-      if (h) s_tmp[t] = s_boff[t] + atomicAdd(&lt.cursor[ls.z + t], h);
+      if (h) {
+        s_base[t] = atomicAdd(&lt.cursor[slot0 + t], h);
+        const unsigned long long tc = s_tc[t];
+        uint32_t* tg = reinterpret_cast<uint32_t*>(&lt.tcnt[slot0 + t]);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const uint32_t v = (uint32_t)(tc >> (16 * j)) & 0xFFFFu;
+          if (v) atomicAdd(&tg[j], v);
+        }
+      }
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < LG_PER; ++q)
-      if (bk[q] >= 0) scratch[(size_t)off + s_tmp[bk[q]] + rk[q]] = e[q];
+      if (bk[q] >= 0) {
+        const uint32_t pos = s_base[bk[q]] + rk[q];
+        if (pos < (uint32_t)slab_limit) scratch[(size_t)(slot0 + bk[q]) * SB_LONG_SLAB + pos] = e[q];
+      }
     __syncthreads();
   }
 }
@@ -1571,60 +1516,57 @@ sb_sort_small_kernel(int tile_w, int tile_h, const int32_t* __restrict__ tile_of
 }
 
 // The buckets of the long segments (slot = work item) and the skewed segments the small launch left: LG_SORT_GRID
-// persistent workgroups, the small launch's LDS sort with the splitter path for skew.  A bucket beyond the LDS sort's
-// capacity (the sample was unlucky by a factor of two: with 32 samples per bucket a 1e-6 event per bucket) goes on
-// over_list's second list for sb_long_overflow_kernel.
+// persistent workgroups, the small launch's LDS sort with the splitter path for skew.  A bucket whose cursor ran beyond its
+// slab (the sample was unlucky by a factor of two: with 32 samples per bucket a 1e-6 event per bucket) goes on over_list's
+// second list for sb_long_overflow_kernel.
 // (eight wavefronts per SIMD = four workgroups per CU, as the small launch: 9 spilled registers on the skew path)
 __global__ void __launch_bounds__(64 * SB_SMALL_WAVES) __attribute__((amdgpu_waves_per_eu(8, 8)))
 sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
                     const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list, LongTables lt,
                     const uint64_t* __restrict__ entries, const uint64_t* __restrict__ scratch,
-                    int32_t* __restrict__ flatten_ids) {
+                    int32_t* __restrict__ flatten_ids, int slab_limit) {
   using Sh = SortShared<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>;
   __shared__ Sh sh;
   __shared__ int s_tile_base[4];
   constexpr int NT = 64 * SB_SMALL_WAVES;
-  static_assert(2 * LG_T <= Sh::MAXN, "a bucket twice its target still fits the LDS sort");
+  static_assert(2 * LG_T <= Sh::MAXN && SB_LONG_SLAB == Sh::MAXN, "a bucket's slab is what the LDS sort takes: twice the target");
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const int n_slots = long_list[0].z, n_items = n_slots + lt.over_list[0];
   for (int item = blockIdx.x; item < n_items; item += gridDim.x) {
     const uint64_t* src;
-    int n, st, seg_off = 0;
-    uint32_t pre[5] = {0, 0, 0, 0, 0};
+    int n, st;
+    uint32_t pre[4] = {0, 0, 0, 0};
     if (item >= n_slots) {  // a whole (skewed) segment
       st = -lt.over_list[2 + item - n_slots] - 1;
       const int off = st_offsets[st];
       n = st_offsets[st + 1] - off;
       src = entries + off;
     } else {
-      // a bucket: where it starts in its segment and in each of the four tile lists = sums over the buckets in front
-      const int4 bi = lt.bucket_seg[item];
-      const int4 ls = make_int4(bi.z, 0, bi.x, 0);  // (.x: supertile, .z: first bucket slot)
-      st = ls.x;
-      seg_off = bi.y;
+      // a bucket: where it starts in each of the four tile lists = sums over the buckets in front of it
+      const int4 bi = lt.bucket_seg[item];  // {first bucket slot, first element, supertile, bucket in the segment}
+      st = bi.z;
       const int b = bi.w;
       for (int t = threadIdx.x; t < b; t += NT) {
-        const uint4 tc = lt.tcnt[ls.z + t];
-        pre[0] += lt.cnt[ls.z + t];
-        pre[1] += tc.x; pre[2] += tc.y; pre[3] += tc.z; pre[4] += tc.w;
+        const uint4 tc = lt.tcnt[bi.x + t];
+        pre[0] += tc.x; pre[1] += tc.y; pre[2] += tc.z; pre[3] += tc.w;
       }
 #pragma unroll
-      for (int f = 0; f < 5; ++f) {
+      for (int f = 0; f < 4; ++f) {
 #pragma unroll
         for (int m = 1; m < 64; m <<= 1) pre[f] += (uint32_t)__shfl_xor((int)pre[f], m);
         if (lane == 0) sh.bucket[f * SB_SMALL_WAVES + wave] = pre[f];
       }
       __syncthreads();
 #pragma unroll
-      for (int f = 0; f < 5; ++f) {
+      for (int f = 0; f < 4; ++f) {
         pre[f] = 0;
 #pragma unroll
         for (int w = 0; w < SB_SMALL_WAVES; ++w) pre[f] += sh.bucket[f * SB_SMALL_WAVES + w];
       }
-      n = (int)lt.cnt[item];
-      src = scratch + (size_t)seg_off + pre[0];
-      if (n > Sh::MAXN) {
+      n = (int)lt.cursor[item];  // (the scatter pass's cursor: the bucket's element count)
+      src = scratch + (size_t)item * SB_LONG_SLAB;
+      if (n > slab_limit) {
         if (threadIdx.x == 0) lt.over_list[2 + n_slots_cap(lt) + atomicAdd(lt.over_list + 1, 1)] = item;
         n = 0;
       }
@@ -1633,7 +1575,7 @@ sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* _
       int tile_base[4], tile_id[4];
       supertile_tile_bases(st, tile_w, tile_h, tile_offsets, tile_base, tile_id);
       __syncthreads();  // (sh.bucket is the sort's from here; s_tile_base is free again)
-      if (threadIdx.x < 4) s_tile_base[threadIdx.x] = tile_base[threadIdx.x] + (int)pre[1 + threadIdx.x];
+      if (threadIdx.x < 4) s_tile_base[threadIdx.x] = tile_base[threadIdx.x] + (int)pre[threadIdx.x];
     }
     if (n > 0)  // (uniform; the sort's first barrier publishes s_tile_base)
       sort_emit_lds<SB_SMALL_WAVES, SB_SMALL_KPT, SB_SMALL_BUCKET_BITS>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n,
@@ -1642,52 +1584,82 @@ sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* _
   }
 }
 
-// The buckets sb_long_sort_kernel left on over_list's second list, one workgroup each through global memory
-// (exact TIES of the whole 64-bit element cannot occur)
+// The buckets that outgrew their slabs (over_list's second list; normally none: 5 us of an empty grid -- a bucket of twice its
+// target size is a 1e-4 ... 1e-6 event, seen about once in a hundred calls on a scene with a hundred buckets), one workgroup each.
+// The scatter pass dropped what did not fit the slab but left `entries` intact: the bucket's elements are gathered from its
+// segment again -- those between the bucket's two splitters -- into the workgroup's own stretch of a small arena (64 x 7936
+// elements of the workspace), then sorted and emitted like any bucket, by the large launch's LDS sort (7936 elements).  A bucket beyond even that -- the sample missed it by a factor of five -- sends its
+// whole segment through global memory and emits all of the segment's tile lists again (the same values where its other buckets
+// had written theirs).  (Measured and dropped: this as the tail of sb_long_sort_kernel's last workgroup, found by a ticket --
+// 1024 same-address returning atomics and the global sort's registers in that kernel: 34 -> 218 us.)
 __global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
 sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
-                        const int32_t* __restrict__ st_offsets, const int4* __restrict__ long_list, LongTables lt,
-                        uint64_t* __restrict__ entries, uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
+                        const int32_t* __restrict__ st_offsets, LongTables lt, uint64_t* __restrict__ entries,
+                        uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
   using Sh = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>;
   __shared__ Sh sh;
+  __shared__ int s_tile_base[4];
+  __shared__ uint32_t s_n;
   constexpr int NT = 64 * SB_LARGE_WAVES;
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
-  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
   const int count = lt.over_list[1];
-  for (int item = blockIdx.x; item < count; item += gridDim.x) {
-    const int slot = lt.over_list[2 + n_slots_cap(lt) + item];
-    const int4 bi = lt.bucket_seg[slot];
-    const int4 ls = make_int4(bi.z, 0, bi.x, 0);  // (.x: supertile, .z: first bucket slot)
-    const int b = bi.w;
-    uint32_t pre[5] = {0, 0, 0, 0, 0};
+  uint32_t(*wave_cnt)[256] = reinterpret_cast<uint32_t(*)[256]>(sh.bucket);
+  for (int v = blockIdx.x; v < count; v += gridDim.x) {
+    const int slot = lt.over_list[2 + n_slots_cap(lt) + v];
+    const int4 bi = lt.bucket_seg[slot];  // {first bucket slot, first element, supertile, bucket in the segment}
+    const int st = bi.z, b = bi.w, off = bi.y, n_seg = st_offsets[st + 1] - st_offsets[st], k = long_buckets(n_seg);
+    const uint64_t lo = b > 0 ? lt.split[bi.x + b - 1] : 0ull, hi = b + 1 < k ? lt.split[bi.x + b] : ~0ull;
+    uint64_t* tmp = lt.arena + (size_t)blockIdx.x * Sh::MAXN;
+    if (threadIdx.x == 0) s_n = 0u;
+    __syncthreads();
+    // (bucket of e = the number of splitters <= e: bucket b holds lo <= e < hi; the last bucket has no upper splitter)
+    for (int i = threadIdx.x; i < n_seg; i += NT) {
+      const uint64_t e = entries[(size_t)off + i];
+      if (e >= lo && (b + 1 >= k || e < hi)) {
+        const uint32_t pos = atomicAdd(&s_n, 1u);
+        if (pos < (uint32_t)Sh::MAXN) tmp[pos] = e;
+      }
+    }
+    __syncthreads();
+    const int n_b = (int)s_n;
+    int tile_base[4], tile_id[4];
+    supertile_tile_bases(st, tile_w, tile_h, tile_offsets, tile_base, tile_id);
+    if (n_b > Sh::MAXN) {  // (uniform) the whole segment, once (lt.cnt of its first bucket slot: zeroed by the sample step, the claim)
+      __shared__ int s_mine;
+      if (threadIdx.x == 0) s_mine = atomicCAS(lt.cnt + bi.x, 0u, 0xFFFFFFFFu) == 0u ? 1 : 0;
+      __syncthreads();
+      if (s_mine) {
+        const uint64_t* fin = sort_segment_global<SB_LARGE_WAVES>(entries + off, scratch + (size_t)bi.x * SB_LONG_SLAB, n_seg, wave_cnt,
+                                                                   sh.scan_tmp, sh.red);
+        emit_tiles<SB_LARGE_WAVES>(fin, n_seg, tile_base, flatten_ids, sh.tcnt);
+      }
+      __syncthreads();
+      continue;
+    }
+    uint32_t pre[4] = {0, 0, 0, 0};
     for (int t = threadIdx.x; t < b; t += NT) {
-      const uint4 tc = lt.tcnt[ls.z + t];
-      pre[0] += lt.cnt[ls.z + t];
-      pre[1] += tc.x; pre[2] += tc.y; pre[3] += tc.z; pre[4] += tc.w;
+      const uint4 tc = lt.tcnt[bi.x + t];
+      pre[0] += tc.x; pre[1] += tc.y; pre[2] += tc.z; pre[3] += tc.w;
     }
 #pragma unroll
-    for (int f = 0; f < 5; ++f) {
+    for (int f = 0; f < 4; ++f) {
 #pragma unroll
       for (int m = 1; m < 64; m <<= 1) pre[f] += (uint32_t)__shfl_xor((int)pre[f], m);
       if (lane == 0) sh.bucket[f * SB_LARGE_WAVES + wave] = pre[f];
     }
     __syncthreads();
 #pragma unroll
-    for (int f = 0; f < 5; ++f) {
+    for (int f = 0; f < 4; ++f) {
       pre[f] = 0;
 #pragma unroll
       for (int w = 0; w < SB_LARGE_WAVES; ++w) pre[f] += sh.bucket[f * SB_LARGE_WAVES + w];
     }
     __syncthreads();
-    const int n_b = (int)lt.cnt[slot];
-    const size_t off = (size_t)bi.y + pre[0];
-    int tile_base[4], tile_id[4];
-    supertile_tile_bases(ls.x, tile_w, tile_h, tile_offsets, tile_base, tile_id);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) tile_base[j] += (int)pre[1 + j];
-    const uint64_t* fin = sort_segment_global<SB_LARGE_WAVES>(scratch + off, entries + off, n_b, wave_cnt, sh.scan_tmp, sh.red);
-    emit_tiles<SB_LARGE_WAVES>(fin, n_b, tile_base, flatten_ids, sh.tcnt);
+    if (threadIdx.x < 4) s_tile_base[threadIdx.x] = tile_base[threadIdx.x] + (int)pre[threadIdx.x];
+    const uint64_t* src = tmp;
+    sort_emit_lds<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>(sh, (int)threadIdx.x, [src](int i) { return src[i]; }, n_b,
+                                                                       s_tile_base, flatten_ids);
     __syncthreads();
   }
 }
@@ -1784,7 +1756,8 @@ FillWs fill_ws(void* base, size_t capacity) {
   w.entries = ws_at<uint64_t>(base, o);
   o += al256(capacity * 8);
   w.scratch = ws_at<uint64_t>(base, o);
-  o += al256(capacity * 8);
+  // (the long segments' buckets own SLABS of SB_LONG_SLAB elements here, a slab per bucket slot: 3 x capacity at most)
+  o += al256((kb * (size_t)SB_LONG_SLAB > capacity ? kb * (size_t)SB_LONG_SLAB : capacity) * 8);
   w.lt.split = ws_at<uint64_t>(base, o);
   o += al256(kb * 8);
   w.lt.tcnt = ws_at<uint4>(base, o);
@@ -1800,6 +1773,8 @@ FillWs fill_ws(void* base, size_t capacity) {
   o += al256((2 + (size_t)w.lt.over_cap + kb) * 4);
   w.lt.chunk_seg = ws_at<int4>(base, o);
   o += al256((capacity / LG_CHUNK + capacity / SB_LONG_SPLIT + 2) * 16);
+  w.lt.arena = ws_at<uint64_t>(base, o);
+  o += al256((size_t)SB_LONG_OVER_GRID * SB_LONG_MIN * 8);
   w.bytes = o;
   return w;
 }
@@ -1818,7 +1793,7 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
   if (N <= 0 || capacity <= 0 || tile_w <= 0 || tile_h <= 0) return FG_ERR_INVALID_ARG;
   if (!depth_keys || !tile_rects || !tile_offsets || !count_workspace || !flatten_ids || !list_offsets || !workspace)
     return FG_ERR_INVALID_ARG;
-  if (flags & ~FG_STBIN_LONG_SEGMENTS) return FG_ERR_INVALID_ARG;
+  if (flags & ~(FG_STBIN_LONG_SEGMENTS | FG_STBIN_TEST_SMALL_SLABS)) return FG_ERR_INVALID_ARG;
   if (!fg_stbin_supported(N, tile_w, tile_h)) return FG_ERR_UNSUPPORTED;
   if (workspace_bytes < fg_stbin_fill_workspace_bytes(capacity)) return FG_ERR_WORKSPACE;
   hipStream_t s = fg_hip_stream(stream);
@@ -1881,15 +1856,16 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
                      tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
                      long_mode ? fw.lt.over_list : nullptr, bwd_jobs_in_sort ? 8 : 0,
                      bwd_jobs_in_sort ? *jobs : fgjobs::JobBuild{}, w.long_list, fw.lt);
-  if (long_mode) {
-    hipLaunchKernelGGL(sb_long_count_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
-                       w.st_offsets, w.long_list, entries, fw.lt);
+  // (FG_STBIN_TEST_SMALL_SLABS: a bucket counts as overflowing from LG_T + 64 elements -- two of five do -- so that tests reach
+  // the whole-segment path of sb_long_sort_kernel's last workgroup, which a 1e-6 event would not)
+  const int slab_limit = (flags & FG_STBIN_TEST_SMALL_SLABS) ? LG_T + 64 : SB_LONG_SLAB;
+  if (long_mode) {  // (three launches behind the small sort -- round 5: four, a count pass in front of the scatter)
     hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
-                       w.st_offsets, w.long_list, entries, scratch, fw.lt);
+                       w.st_offsets, w.long_list, entries, scratch, fw.lt, slab_limit);
     hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
-                       (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
-    hipLaunchKernelGGL(sb_long_overflow_kernel, dim3(64), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, (long long)capacity,
-                       tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids);
+                       (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids, slab_limit);
+    hipLaunchKernelGGL(sb_long_overflow_kernel, dim3(SB_LONG_OVER_GRID), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, (long long)capacity,
+                       tile_offsets, w.st_offsets, fw.lt, entries, scratch, flatten_ids);
   }
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;

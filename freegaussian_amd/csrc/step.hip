@@ -129,7 +129,7 @@ extern "C" int fg_step_fwd(const fg_step_desc* d, const fg_raster_config* config
   float* seg_ckpt = at<float>(keep, L, FG_STEP_SEG_CKPT);
   rc = fg_stbin_fill_jobs(N, depth_keys, tile_rects, tile_masks, tile_w, tile_h, d->capacity, tile_offsets, count_ws, flatten_ids,
                           list_offsets, at<char>(tmp, L, FG_STEP_FILL_WS), (size_t)L->nbytes[FG_STEP_FILL_WS], W, H, 16, jobs,
-                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags & FG_STBIN_LONG_SEGMENTS, io->ckpt_need_out,
+                          jobs + L->jobs_words, seg_ckpt != nullptr, config, d->flags & (FG_STBIN_LONG_SEGMENTS | FG_STBIN_TEST_SMALL_SLABS), io->ckpt_need_out,
                           stream);
   if (rc != FG_OK) return rc;
   float* v_splats = at<float>(keep, L, FG_STEP_V_SPLATS);

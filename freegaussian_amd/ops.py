@@ -215,6 +215,7 @@ class RasterContext:
         self.long_cooldown = 64
         self.long_shapes = {}  # shape key -> calls left with the flag set
         self.long_calls = 0  # calls of fg_stbin_fill* that carried the flag
+        self.test_small_slabs = False  # tests: FG_STBIN_TEST_SMALL_SLABS with it (the sample sort's whole-segment fallback runs)
         # HEAVY tiles (fg_raster_config::heavy_tiles): a tile list of thousands of entries that does not saturate is four
         # serial walks of ~100 ns per entry in the forward (1.4 ms for the rim tiles of a dense ball while the chip
         # idles); with the policy field set such a tile is composited by many jobs over shares of its list (+ one more
@@ -1076,7 +1077,7 @@ def _bin_tiles_supertile(rctx, abi, N, keys_rects, tile_w, tile_h, offsets, defe
                 _ptr(offsets), _ptr(ws2), ws2.numel())  # fmt: skip
         # long segments seen on this shape lately (or FG_LONG_SEGMENTS=always): the multi-workgroup sample sort
         long_mode = rctx.long_segments == "always" or (rctx.long_segments == "auto" and rctx.long_shapes.get(lkey, 0) > 0)
-        flags = _lib.STBIN_LONG_SEGMENTS if long_mode else 0
+        flags = (_lib.STBIN_LONG_SEGMENTS | (_lib.STBIN_TEST_SMALL_SLABS if rctx.test_small_slabs else 0)) if long_mode else 0
         rctx.long_calls += int(long_mode)
         heavy = rctx.heavy_tiles == "always" or (rctx.heavy_tiles == "auto" and rctx.heavy_shapes.get(lkey, 0) > 0)
         prebuilt = _plan_job_lists(rctx, raster_hint, cap, dev, heavy, lkey, N) if rctx.jobs_in_fill else None
@@ -1857,7 +1858,8 @@ class _RasterStep(torch.autograd.Function):
             # context's copy, which another context's copy may reuse)
             key = (dev, N, width, height, int(raw), sh_degree, k_stored, n_color, int(with_depth), n_extra, int(antialiased),
                    n_clamp, int(want_backward), int(shares),
-                   (_lib.STBIN_LONG_SEGMENTS if long_mode else 0) | (0 if masked else _lib.STEP_NO_FOOTPRINT_MASKS), capacity, eps2d,
+                   ((_lib.STBIN_LONG_SEGMENTS | (_lib.STBIN_TEST_SMALL_SLABS if rctx.test_small_slabs else 0)) if long_mode else 0)
+                   | (0 if masked else _lib.STEP_NO_FOOTPRINT_MASKS), capacity, eps2d,
                    near, far, radius_clip, variant, bytes(rctx.policy))  # fmt: skip
             d, L, rc = _step_plan(key, cfgp)
             _lib.check(rc, "fg_step_layout_query")

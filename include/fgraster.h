@@ -186,9 +186,14 @@ size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
  * segment per 1024-thread workgroup in LDS (up to 7936 elements) or by ONE workgroup through global memory (beyond).
  * Same lists bit for bit either way; a host sets the flag for shapes whose earlier calls reported a segment beyond
  * 7936 elements (count_out[1]) or more than a handful beyond 3072 (count_out[3]) -- ops.bin_tiles does -- on scenes
- * without such segments the flag only costs the four empty launches. */
+ * without such segments the flag only costs three empty launches (ABI 9: count + scatter of the long elements in one pass
+ * into per-bucket slabs of the workspace; four launches before). */
 #define FG_STBIN_LONG_SEGMENTS 1
 #define FG_STEP_NO_FOOTPRINT_MASKS 2 /* (fg_step_desc::flags only) */
+/* (ABI 9, with FG_STBIN_LONG_SEGMENTS; a TEST hook: a bucket of the sample sort counts as having outgrown its slab from 1600
+ * elements instead of 3072, so that the whole-segment path behind it -- a 1e-6 event per bucket otherwise -- runs in tests;
+ * same lists) */
+#define FG_STBIN_TEST_SMALL_SLABS 4
 int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w,
                   int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
                   int32_t* flatten_ids, int32_t* list_offsets, void* workspace, size_t workspace_bytes,

@@ -1795,12 +1795,15 @@ def test_clustered_1m_scene_lists_equal_the_oracles_through_the_long_segment_sor
         pytest.skip("the environment selects another binning path")
     ctx.long_segments = "always"
     with ops.use(ctx):
-        for _ in range(2):  # exact capacity, then speculative
+        for k in range(3):  # exact capacity, then speculative, then with buckets "outgrowing" their slabs from 1600 elements
+            # (round 6: count + scatter in one pass into per-bucket slabs; a bucket beyond its slab sends its whole segment
+            # through global memory in the bucket sort's last workgroup -- FG_STBIN_TEST_SMALL_SLABS makes two of five do so)
+            ctx.test_small_slabs = k == 2
             _, ids, offs = ops.bin_tiles(*args, keys_rects=(keys.to(DEV), rects), want_keys=False)
             assert torch.equal(offs.cpu(), offs_ref)
-            assert torch.equal(ids.cpu(), vals_s)
+            assert torch.equal(ids.cpu(), vals_s), k
     lens = torch.diff(offs_ref)
-    assert int(lens.max()) > 100_000 and ctx.long_calls == 2
+    assert int(lens.max()) > 100_000 and ctx.long_calls == 3
 
 
 @pytest.mark.parametrize("form", ["wide", "three"])
