@@ -55,8 +55,8 @@ def step(view):
     torch.cuda.synchronize()
 
 
-for v in range(4):
-    step(v)
+for v in range(int(os.environ.get("FG_TL_WARM", "4"))):  # (the host's per-shape policy settles over its first calls: uneven after one, even after eight)
+    step(v % sc.viewmats.shape[0])
 lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
 step(TL_VIEW)
 cnt = lib.fg_debug_raster_timeline(buf.ctypes.data, CAP, 1)
