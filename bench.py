@@ -429,8 +429,11 @@ def trained_scene_for(spec):
 
     out_dir = tempfile.mkdtemp(prefix="fg_trained_")
     t0 = time.perf_counter()
-    _, rep, _ = E.train(steps=7000, warm_up=10**9, eval_at=(7000,), out_dir=out_dir, log=lambda *a: None, save_checkpoint=False)
-    prov = {"source": "trained in this process: scripts/train_e2e.py, 7000 steps from random_init, reference schedule, deformation net off",
+    # (FG_BENCH_TRAIN="steps,n_target,width,height,num_random": a smaller run -- the gate's check of this fallback, tests/test_e2e.py)
+    steps, n_target, tw, th, n_rand = (int(x) for x in os.environ.get("FG_BENCH_TRAIN", "7000,200000,1920,1080,50000").split(","))
+    _, rep, _ = E.train(steps=steps, n_target=n_target, width=tw, height=th, num_random=n_rand, warm_up=10**9, eval_at=(steps,),
+                        out_dir=out_dir, log=lambda *a: None, save_checkpoint=False)
+    prov = {"source": f"trained in this process: scripts/train_e2e.py, {steps} steps from random_init, reference schedule, deformation net off",
             "train_seconds": round(time.perf_counter() - t0, 1), "heldout_psnr_db": rep["evals"][-1]["heldout_psnr"],
             "N_final": rep["N_final"], "train_step_gpu_ms": rep["step_time_gpu_ms"], "policy_counters_end": rep["policy_counters"]["end"]}  # fmt: skip
     return load_trained_scene(os.path.join(out_dir, "trained_scene.npz")), prov

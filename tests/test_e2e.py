@@ -184,3 +184,23 @@ def test_short_end_to_end_run_learns_the_scene():
     assert ps[0] < ps[1] < ps[2] and ps[2] > 18.0  # (19.9 ... 20.9 over the round's visits: two runs differ by ~1 dB, profiles/r06_trained_scene.md)
     assert rep["N_final"] > 8000
     assert rep["policy_counters"]["end"]["capacity_redos"] <= 6
+
+
+@pytest.mark.gpu
+def test_bench_trains_its_own_scene_when_the_checkpoint_file_is_absent():
+    """`bench.py --layout trained:auto` without `data/trained_scene_r06.npz` (46 MB, not in the history -- the state of a fresh
+    checkout): the child trains the scene in its own process before anything is timed and reports where the scene came from.
+    A small run here (FG_BENCH_TRAIN); the default is scripts/train_e2e.py's 7000 steps at 1080p, ~10 s."""
+    import json
+    import subprocess
+
+    env = dict(os.environ, FG_BENCH_TRAIN_HERE="1", FG_BENCH_TRAIN="400,20000,480,270,6000")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--layout", "trained:auto", "--steps", "12", "--warmup", "4",
+                          "--settle-s", "0.2", "--no-cpu-baseline", "--no-graph", "--no-clustered"], capture_output=True, text=True, env=env, timeout=600)  # fmt: skip
+    lines = [ln for ln in res.stdout.strip().splitlines() if ln.startswith("{")]
+    assert res.returncode == 0 and lines, res.stderr[-2000:]
+    d = json.loads(lines[-1])
+    c = d["config"]
+    assert c["layout"] == "trained:auto" and "trained in this process" in c["scene"]["source"] and c["scene"]["heldout_psnr_db"] > 12.0
+    assert c["N"] == c["scene"]["N_final"] and 0 < c["V"] <= c["N"] and c["P"] == 480 * 270 and d["value"] > 0
+    assert "axis_ratio_hist" in c["scene_statistics"] and d["path_events_in_timed_region"]["stagewise_raster_calls"] == 0
