@@ -150,8 +150,8 @@ class GraphedModelStep:
         from .model import FreeGaussianModel
 
         m = self.model
-        if not m.training or m.crop_box is not None or m.device.type != "cuda":
-            return False
+        if not m.training or m.crop_box is not None or m.device.type != "cuda" or m.config.use_bilateral_grid:
+            return False  # (the grid of a training image is picked on the host, per camera)
         if m.step >= m.config.warm_up or m._render_mode() != "RGB":
             return False  # torch reductions (MLP bias gradients, depth max) are not replay-safe here: see the class docstring
         if type(m)._get_outputs_on_active_rows is not FreeGaussianModel._get_outputs_on_active_rows:

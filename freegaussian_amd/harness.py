@@ -107,7 +107,8 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
     synchronisation) only on steps divisible by k, as a trainer that logs every k steps does; the other steps return
     the Gaussian count alone and the host runs ahead of the GPU."""
     model.step_cb(step)
-    plain_loss = mask is None and gt_image.shape[-1] == 3 and not model.config.use_scale_regularization
+    plain_loss = (mask is None and gt_image.shape[-1] == 3 and not model.config.use_scale_regularization
+                  and not model.config.use_bilateral_grid)
     if graphed is not None and dp is None and plain_loss and graphed.applicable(camera):
         # (no zero_grad: the replay refills the .grad tensors, which are static buffers of the graph)
         out, loss = graphed.step(camera, gt_image)
@@ -124,6 +125,8 @@ def train_step(model: FreeGaussianModel, opts, camera: Camera, gt_image: torch.T
             batch = {"image": gt_image} if mask is None else {"image": gt_image, "mask": mask}
             loss_dict = model.get_loss_dict(out, batch)
             loss = loss_dict["main_loss"] + loss_dict["scale_reg"]
+            if "tv_loss" in loss_dict:  # (bilateral grids: freegaussian_model.py:988-989)
+                loss = loss + loss_dict["tv_loss"]
             gt = None  # (composited below, only on the steps whose metrics are read)
             loss.backward()
     if grad_sync is not None:

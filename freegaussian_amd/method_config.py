@@ -39,6 +39,11 @@ STAGE1_OPTIMIZERS: Dict[str, OptimSpec] = {
     "quats": OptimSpec(0.001),
     "deform": OptimSpec(1.6e-4 * 5, lr_final=1.6e-6, max_steps=30000),
     "control": OptimSpec(1.6e-4 * 5, lr_final=1.6e-6, max_steps=15000),
+    # NOT in the reference's table: its `use_bilateral_grid` switch adds a "bilateral_grid" parameter group
+    # (freegaussian_model.py:617-618) that its own method spec has no optimizer for, so the switch cannot train upstream.
+    # This is the entry of nerfstudio's splatfacto method, which the model class inherits the branch from (without its
+    # 1000-step warm-up); harness.build_optimizers uses it only when the model has the group.
+    "bilateral_grid": OptimSpec(2e-3, lr_final=1e-4, max_steps=30000),
 }
 STAGE2_OPTIMIZERS: Dict[str, OptimSpec] = {k: v for k, v in STAGE1_OPTIMIZERS.items() if k != "deform"}
 

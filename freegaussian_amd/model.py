@@ -103,6 +103,9 @@ class FreeGaussianModelConfig:
     ssim_lambda: float = 0.2  # (:96)
     use_scale_regularization: bool = False  # (:102; the PhysGaussian ratio penalty, every 10th step)
     max_gauss_ratio: float = 10.0  # (:104)
+    use_bilateral_grid: bool = False  # (:122; per-image affine colour grids, freegaussian_amd/bilagrid.py)
+    grid_shape: tuple = (16, 16, 8)  # (:124; X, Y, W)
+    color_corrected_metrics: bool = False  # (:126)
     rasterize_mode: str = "classic"
     num_random: int = 50000
     random_scale: float = 10.0
@@ -135,8 +138,8 @@ class FreeGaussianModel(nn.Module):
 
     def __init__(self, config: Optional[FreeGaussianModelConfig] = None, num_points: Optional[int] = None,
                  seed_points: Optional[torch.Tensor] = None, is_blender: bool = True,
-                 init_scales: Optional[float] = None):  # fmt: skip
-        """``init_scales``: None = the reference's initial scales, the mean distance to the three nearest neighbours
+                 init_scales: Optional[float] = None, num_train_data: Optional[int] = None):  # fmt: skip
+        """``num_train_data``: the number of training images (one bilateral grid each, :227-233).  ``init_scales``: None = the reference's initial scales, the mean distance to the three nearest neighbours
         (:158-162; a tree query over all points: a minute at 1M); a float = that log-scale everywhere, for harnesses that
         overwrite the scales anyway."""
         super().__init__()
@@ -162,6 +165,13 @@ class FreeGaussianModel(nn.Module):
         )
         self.deform = FreeGaussianDeformableModel(is_blender=is_blender)  # :198
         self.control = FreeGaussianControllableModel()  # :200
+        if self.config.use_bilateral_grid:  # (:227-233)
+            from .bilagrid import BilateralGrid
+
+            if not num_train_data:
+                raise ValueError("use_bilateral_grid needs num_train_data (one grid per training image)")
+            gx, gy, gw = self.config.grid_shape
+            self.bil_grids = BilateralGrid(num=int(num_train_data), grid_X=gx, grid_Y=gy, grid_W=gw)
         self.step = 0
         self.background_color = torch.zeros(3)
         self.xys: Optional[torch.Tensor] = None
@@ -261,13 +271,20 @@ class FreeGaussianModel(nn.Module):
         """(:924-941) without the colour-corrected variant and the camera optimizer (mode "off", :120)."""
         gt_rgb = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
         mse = torch.nn.functional.mse_loss(outputs["rgb"], gt_rgb)
-        return {"psnr": -10.0 * torch.log10(mse), "gaussian_count": self.num_points}
+        metrics = {"psnr": -10.0 * torch.log10(mse)}
+        if self.config.color_corrected_metrics:  # (:935-937)
+            from .bilagrid import color_correct
+
+            cc = color_correct(outputs["rgb"].detach(), gt_rgb)
+            metrics["cc_psnr"] = -10.0 * torch.log10(torch.nn.functional.mse_loss(cc, gt_rgb))
+        metrics["gaussian_count"] = self.num_points
+        return metrics
 
     def get_loss_dict(self, outputs, batch, metrics_dict=None):
         """(:944-990) main loss (1 - ssim_lambda) L1 + ssim_lambda (1 - SSIM) on the composited ground truth, the
-        optional mask (both images blacked out), the optional scale-ratio regulariser on every 10th step.  The
-        camera-optimizer and bilateral-grid terms of the reference are not mirrored (both off in every shipped
-        config)."""
+        optional mask (both images blacked out), the optional scale-ratio regulariser on every 10th step, and while
+        training with bilateral grids 10 x their total variation (:988-989).  The camera-optimizer term of the reference
+        is not mirrored (mode "off" in every shipped config)."""
         from .harness import l1_and_ssim
 
         gt_img = self.composite_with_background(self.get_gt_img(batch["image"]), outputs["background"])
@@ -289,7 +306,12 @@ class FreeGaussianModel(nn.Module):
         else:
             scale_reg = torch.tensor(0.0, device=self.device)
         lam = self.config.ssim_lambda
-        return {"main_loss": (1 - lam) * l1 + lam * simloss, "scale_reg": scale_reg}
+        loss_dict = {"main_loss": (1 - lam) * l1 + lam * simloss, "scale_reg": scale_reg}
+        if self.training and self.config.use_bilateral_grid:
+            from .bilagrid import total_variation_loss
+
+            loss_dict["tv_loss"] = 10 * total_variation_loss(self.bil_grids.grids)
+        return loss_dict
 
     # -- the pieces of get_outputs shared by stage 1 and stage 2 ------------------------------------
     def _camera_setup(self, camera: Camera):
@@ -440,7 +462,16 @@ class FreeGaussianModel(nn.Module):
 
     def _get_outputs_on_active_rows(self, camera: Camera):
         viewmat, K, W, H = self._camera_setup(camera)
-        return self._outputs_from(viewmat, K, W, H, camera.times)
+        return self._bilateral(self._outputs_from(viewmat, K, W, H, camera.times), camera)
+
+    def _bilateral(self, out, camera: Camera):
+        """(:879-882) while training, the rendered image through the bilateral grid of its training camera."""
+        if self.config.use_bilateral_grid and self.training and camera.metadata is not None and "cam_idx" in camera.metadata:
+            from .bilagrid import apply_to_render
+
+            rgb = out["rgb"]
+            out["rgb"] = apply_to_render(self.bil_grids, rgb.unsqueeze(0), camera.metadata["cam_idx"], rgb.shape[0], rgb.shape[1]).squeeze(0)
+        return out
 
     def _outputs_from(self, viewmat, K, W, H, times):
         """H4 + the raster call on device-resident camera data: everything of ``get_outputs`` behind the host
@@ -499,6 +530,8 @@ class FreeGaussianModel(nn.Module):
         groups = self.get_gaussian_param_groups()
         groups["deform"] = list(self.deform.parameters())
         groups["control"] = list(self.control.parameters())
+        if self.config.use_bilateral_grid:  # (:617-618)
+            groups["bilateral_grid"] = list(self.bil_grids.parameters())
         return groups
 
 
@@ -550,7 +583,7 @@ class FreeGaussianControlModel(FreeGaussianModel):
         means = all_means + torch.zeros_like(all_means).index_put(idx, d_xyz)
         d_scaling = torch.zeros_like(all_scales).index_put(idx, d_scale)
         d_rotation = torch.zeros_like(all_quats).index_put(idx, d_rot)
-        return self._render(means, d_rotation, d_scaling, viewmat, K, W, H)
+        return self._bilateral(self._render(means, d_rotation, d_scaling, viewmat, K, W, H), camera)  # (control model :190-193)
 
     def get_param_groups(self):
         groups = super().get_param_groups()
