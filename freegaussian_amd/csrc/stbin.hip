@@ -1590,16 +1590,18 @@ sb_long_sort_kernel(int tile_w, int tile_h, long long capacity, const int32_t* _
 // segment again -- those between the bucket's two splitters -- into the workgroup's own stretch of a small arena (64 x 7936
 // elements of the workspace), then sorted and emitted like any bucket, by the large launch's LDS sort (7936 elements).  A bucket beyond even that -- the sample missed it by a factor of five -- sends its
 // whole segment through global memory and emits all of the segment's tile lists again (the same values where its other buckets
-// had written theirs).  (Measured and dropped: this as the tail of sb_long_sort_kernel's last workgroup, found by a ticket --
+// had written theirs).  That sort permutes the segment's `entries` in place, so it is decided per SEGMENT from the cursors
+// before anything is gathered: no workgroup re-gathers a bucket of a segment another one is sorting whole.  (Measured and dropped: this as the tail of sb_long_sort_kernel's last workgroup, found by a ticket --
 // 1024 same-address returning atomics and the global sort's registers in that kernel: 34 -> 218 us.)
 __global__ void __launch_bounds__(64 * SB_LARGE_WAVES)
 sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_t* __restrict__ tile_offsets,
                         const int32_t* __restrict__ st_offsets, LongTables lt, uint64_t* __restrict__ entries,
-                        uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids) {
+                        uint64_t* __restrict__ scratch, int32_t* __restrict__ flatten_ids, int whole_limit) {
   using Sh = SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>;
   __shared__ Sh sh;
   __shared__ int s_tile_base[4];
   __shared__ uint32_t s_n;
+  __shared__ int s_mine;
   constexpr int NT = 64 * SB_LARGE_WAVES;
   if ((long long)tile_offsets[tile_w * tile_h] > capacity) return;
   const int lane = fg::lane_id(), wave = threadIdx.x >> 6;
@@ -1611,22 +1613,19 @@ sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_
     const int st = bi.z, b = bi.w, off = bi.y, n_seg = st_offsets[st + 1] - st_offsets[st], k = long_buckets(n_seg);
     const uint64_t lo = b > 0 ? lt.split[bi.x + b - 1] : 0ull, hi = b + 1 < k ? lt.split[bi.x + b] : ~0ull;
     uint64_t* tmp = lt.arena + (size_t)blockIdx.x * Sh::MAXN;
-    if (threadIdx.x == 0) s_n = 0u;
-    __syncthreads();
-    // (bucket of e = the number of splitters <= e: bucket b holds lo <= e < hi; the last bucket has no upper splitter)
-    for (int i = threadIdx.x; i < n_seg; i += NT) {
-      const uint64_t e = entries[(size_t)off + i];
-      if (e >= lo && (b + 1 >= k || e < hi)) {
-        const uint32_t pos = atomicAdd(&s_n, 1u);
-        if (pos < (uint32_t)Sh::MAXN) tmp[pos] = e;
-      }
-    }
-    __syncthreads();
-    const int n_b = (int)s_n;
     int tile_base[4], tile_id[4];
     supertile_tile_bases(st, tile_w, tile_h, tile_offsets, tile_base, tile_id);
-    if (n_b > Sh::MAXN) {  // (uniform) the whole segment, once (lt.cnt of its first bucket slot: zeroed by the sample step, the claim)
-      __shared__ int s_mine;
+    // A segment with ANY bucket beyond the arena's stretch goes through global memory whole, once (the claim: lt.cnt of its
+    // first bucket slot, zeroed by the sample step), and that sort permutes `entries` in place: no workgroup may gather a
+    // bucket of that segment from `entries` meanwhile.  The scatter pass's cursors hold every bucket's count, so every
+    // workgroup that meets the segment decides the same way before touching it.
+    // (whole_limit < 0, FG_STBIN_TEST_SMALL_SLABS: from LG_T + 192 elements in even supertiles -- both paths run in the tests)
+    const uint32_t limit = whole_limit >= 0 ? (uint32_t)whole_limit : (st & 1) ? (uint32_t)Sh::MAXN : (uint32_t)(LG_T + 192);
+    int big = 0;
+    for (int t = threadIdx.x; t < k; t += NT) big |= lt.cursor[bi.x + t] > limit ? 1 : 0;
+    if (threadIdx.x == 0) s_n = 0u;
+    const int whole = __syncthreads_or(big);
+    if (whole) {
       if (threadIdx.x == 0) s_mine = atomicCAS(lt.cnt + bi.x, 0u, 0xFFFFFFFFu) == 0u ? 1 : 0;
       __syncthreads();
       if (s_mine) {
@@ -1637,6 +1636,16 @@ sb_long_overflow_kernel(int tile_w, int tile_h, long long capacity, const int32_
       __syncthreads();
       continue;
     }
+    // (bucket of e = the number of splitters <= e: bucket b holds lo <= e < hi; the last bucket has no upper splitter)
+    for (int i = threadIdx.x; i < n_seg; i += NT) {
+      const uint64_t e = entries[(size_t)off + i];
+      if (e >= lo && (b + 1 >= k || e < hi)) {
+        const uint32_t pos = atomicAdd(&s_n, 1u);
+        if (pos < (uint32_t)Sh::MAXN) tmp[pos] = e;
+      }
+    }
+    __syncthreads();
+    const int n_b = min((int)s_n, Sh::MAXN);  // (= the bucket's cursor: the scatter pass's rule, <= whole_limit <= MAXN)
     uint32_t pre[4] = {0, 0, 0, 0};
     for (int t = threadIdx.x; t < b; t += NT) {
       const uint4 tc = lt.tcnt[bi.x + t];
@@ -1856,8 +1865,9 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
                      tile_offsets, w.st_offsets, entries, scratch, (long long)capacity, flatten_ids, list_offsets,
                      long_mode ? fw.lt.over_list : nullptr, bwd_jobs_in_sort ? 8 : 0,
                      bwd_jobs_in_sort ? *jobs : fgjobs::JobBuild{}, w.long_list, fw.lt);
-  // (FG_STBIN_TEST_SMALL_SLABS: a bucket counts as overflowing from LG_T + 64 elements -- two of five do -- so that tests reach
-  // the whole-segment path of sb_long_sort_kernel's last workgroup, which a 1e-6 event would not)
+  // (FG_STBIN_TEST_SMALL_SLABS: a bucket counts as overflowing from LG_T + 64 elements -- two of five do -- and a segment of an
+  // even supertile with a bucket beyond LG_T + 192 goes through global memory whole, so that tests reach both paths of
+  // sb_long_overflow_kernel, which a 1e-6 event would not)
   const int slab_limit = (flags & FG_STBIN_TEST_SMALL_SLABS) ? LG_T + 64 : SB_LONG_SLAB;
   if (long_mode) {  // (three launches behind the small sort -- round 5: four, a count pass in front of the scatter)
     hipLaunchKernelGGL(sb_long_scatter_kernel, dim3(LG_GRID), dim3(LG_BLOCK), 0, s, tile_offsets, T, (long long)capacity,
@@ -1865,7 +1875,8 @@ int stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, con
     hipLaunchKernelGGL(sb_long_sort_kernel, dim3(LG_SORT_GRID), dim3(64 * SB_SMALL_WAVES), 0, s, tile_w, tile_h,
                        (long long)capacity, tile_offsets, w.st_offsets, w.long_list, fw.lt, entries, scratch, flatten_ids, slab_limit);
     hipLaunchKernelGGL(sb_long_overflow_kernel, dim3(SB_LONG_OVER_GRID), dim3(64 * SB_LARGE_WAVES), 0, s, tile_w, tile_h, (long long)capacity,
-                       tile_offsets, w.st_offsets, fw.lt, entries, scratch, flatten_ids);
+                       tile_offsets, w.st_offsets, fw.lt, entries, scratch, flatten_ids,
+                       (flags & FG_STBIN_TEST_SMALL_SLABS) ? -1 : SortShared<SB_LARGE_WAVES, SB_LARGE_KPT, SB_LARGE_BUCKET_BITS>::MAXN);
   }
   FG_RETURN_IF_LAUNCH_FAILED();
   return FG_OK;

@@ -452,9 +452,13 @@ def _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False)
     args = (torch.zeros(N, 2, device=DEV), z.int(), z, z.int(), 16, tw, th)
     outs = []
     # (the supertile path twice: long segments through one workgroup / through the multi-workgroup sample sort)
-    for mode, long_segments in (("depthfirst", "auto"), ("supertile", "never"), ("supertile", "always")):
+    # ... and (round 6) with the sample sort's per-bucket slabs cut to 1600 elements: buckets outgrow them and are
+    # re-gathered between their splitters, or their whole segment goes through global memory
+    for mode, long_segments, small in (("depthfirst", "auto", False), ("supertile", "never", False), ("supertile", "always", False),
+                                       ("supertile", "always", True)):
         monkeypatch.setattr(ops.default_context, "binning", mode)
         monkeypatch.setattr(ops.default_context, "long_segments", long_segments)
+        monkeypatch.setattr(ops.default_context, "test_small_slabs", small)
         ops.default_context.isect_capacity.clear()
         runs = [ops.bin_tiles(*args, keys_rects=(keys.clone(), rects), want_keys=False) for _ in range(2)]  # exact, speculative
         if overflow:
@@ -464,10 +468,11 @@ def _supertile_vs_depth_first(N, W, H, rects, keys, monkeypatch, overflow=False)
         for _, f, o in runs[1:]:
             assert torch.equal(f, runs[0][1]) and torch.equal(o, runs[0][2])
         outs.append(runs[0])
-    (_, f0, o0), (_, f1, o1), (_, f2, o2) = outs
-    assert torch.equal(o1, o0) and torch.equal(o2, o0), "tile ranges differ"
+    (_, f0, o0), (_, f1, o1), (_, f2, o2), (_, f3, o3) = outs
+    assert torch.equal(o1, o0) and torch.equal(o2, o0) and torch.equal(o3, o0), "tile ranges differ"
     assert torch.equal(f1, f0), "lists differ"
     assert torch.equal(f2, f0), "lists differ (long-segment sample sort)"
+    assert torch.equal(f3, f0), "lists differ (long-segment sample sort, buckets beyond their slabs)"
     return f2, o2
 
 
