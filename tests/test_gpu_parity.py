@@ -1569,6 +1569,62 @@ def test_full_size_cfg4_properties_and_oracle_crop():
 
 
 
+def test_six_million_gaussians_at_1440p_properties():
+    """Beyond BASELINE.json's sizes (a card with 288 GB holds scenes of several million Gaussians): 6M Gaussians at
+    2560 x 1440 -- 14 400 tiles, a list of tens of millions of entries -- through the whole path, twice (the first call sizes
+    the list exactly, the second runs on the speculative capacity and the learned launch policy), checked through the
+    size-independent properties of the integer path and of both passes."""
+    sc = synthetic_scene(6_000_000, 2560, 1440, n_views=1, sh_degree=3, seed=9, log_scale_mean=math.log(0.007))
+    W, H = sc.width, sc.height
+    t = [x.to(DEV).requires_grad_(True) for x in (sc.means, sc.quats, sc.scales, sc.opacities, sc.colors)]
+    vm, K = sc.viewmats[:1].to(DEV), sc.Ks[:1].to(DEV)
+    ctx = ops.RasterContext()
+    with ops.use(ctx):
+        outs = []
+        for _ in range(2):
+            r, a, info = rasterization(*t, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
+            outs.append((r.detach().clone(), a.detach().clone()))
+        assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+        keys, ids, offs = info["isect_ids"], info["flatten_ids"], info["isect_offsets"]
+        I, T = ids.numel(), info["tile_width"] * info["tile_height"]
+        assert T == 14_400 and I > 20_000_000
+        assert int(info["tiles_per_gauss"].sum()) == I and int(offs[-1]) == I and int(offs[0]) == 0
+        assert bool((keys[1:] >= keys[:-1]).all())
+        same = keys[1:] == keys[:-1]
+        assert bool((ids[1:][same] > ids[:-1][same]).all())
+        tile_of = (keys >> 32).to(torch.int32)
+        assert torch.equal(offs, torch.searchsorted(tile_of, torch.arange(T + 1, device=DEV, dtype=torch.int32)).int())
+        del keys, same, tile_of
+        assert bool((info["radii"][0][ids.long()] > 0).all())
+        assert bool(torch.isfinite(r).all()) and float(a.detach().min()) >= 0.0 and float(a.detach().max()) <= 1.0
+        assert float(a.detach().mean()) > 0.5
+        g = torch.Generator().manual_seed(0)
+        v1, v2 = torch.randn(r.shape, generator=g).to(DEV), torch.randn(r.shape, generator=g).to(DEV)
+        grads = [torch.autograd.grad(r, t, v, retain_graph=True) for v in (v1, v2, v1 + v2)]
+        for g1, g2, g12 in zip(*grads):
+            assert rel_l2(g1 + g2, g12) < 1e-4
+        assert all(bool(torch.isfinite(x).all()) for x in grads[2])
+        # Gaussians outside every list get no gradient at all
+        seen = torch.zeros(sc.means.shape[0], dtype=torch.bool, device=DEV)
+        seen[ids.long()] = True
+        assert bool((grads[2][0][~seen] == 0).all()) and bool((grads[2][4][~seen] == 0).all())
+    ctx.release_workspaces()
+
+
+def test_forty_eight_million_gaussians_pass_the_32_bit_element_counts():
+    """48M Gaussians (x 48 SH floats = 2.3e9 elements: every flat index of the coefficient rows and their gradients is
+    beyond 32 bits for the last fifteenth of the set), a list of 108M entries, 53 GiB at the peak: scripts/big_scene_check.py
+    -- integer-path properties, gradients exactly zero outside the lists and present inside them for the highest ids, and the
+    top sixteenth of the ids rendered alone equal, bit for bit, to the full call with everyone else's opacity at zero.
+    (The same script at 100M Gaussians / 3840 x 2160 / 276M entries / 116 GiB: profiles/r06_big_scenes.txt.)"""
+    if torch.cuda.get_device_properties(0).total_memory < 120 * 2**30:
+        pytest.skip("needs ~60 GiB of device memory")
+    from scripts.big_scene_check import check
+
+    check(48.0, 1920, 1080, 0.003)
+    torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------------------------------
 def _oracle_full_res(sc, view, render_mode, sh_degree, seed=0, with_alpha_grad=True):
     """O.rasterization with the scalar C compositing (oracle/c_oracle.composite; it agrees with the
