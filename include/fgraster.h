@@ -191,8 +191,9 @@ size_t fg_stbin_fill_workspace_bytes(int64_t capacity);
 #define FG_STBIN_LONG_SEGMENTS 1
 #define FG_STEP_NO_FOOTPRINT_MASKS 2 /* (fg_step_desc::flags only) */
 /* (ABI 9, with FG_STBIN_LONG_SEGMENTS; a TEST hook: a bucket of the sample sort counts as having outgrown its slab from 1600
- * elements instead of 3072, so that the whole-segment path behind it -- a 1e-6 event per bucket otherwise -- runs in tests;
- * same lists) */
+ * elements instead of 3072 -- it is gathered again from its segment and sorted by a larger LDS sort -- and, in even
+ * supertiles, a segment with a bucket beyond 1728 elements instead of 7936 goes through global memory whole, so that both
+ * paths behind an outgrown slab -- a 1e-6 event per bucket otherwise -- run in tests; same lists) */
 #define FG_STBIN_TEST_SMALL_SLABS 4
 int fg_stbin_fill(int N, const uint32_t* depth_keys, const int32_t* tile_rects, const uint64_t* tile_masks, int tile_w,
                   int tile_h, int64_t capacity, const int32_t* tile_offsets, const void* count_workspace,
