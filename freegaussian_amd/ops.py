@@ -965,8 +965,11 @@ def _note_list_length(rctx, key, n_isects: int, N: int) -> int:
         recent_all.pop(key, None)  # another scene on the same tile grid: its lengths say nothing about this one
     recent = recent_all.setdefault(key, [])
     recent.append((n_isects, N))
-    del recent[:-16]
-    # 25% headroom over the heaviest of the last 16 views of this shape, rounded up to 1/32..1/16 of its magnitude: a
+    del recent[:-64]
+    # (64: a training run draws its views at random from tens to hundreds of cameras whose lists differ by a factor of six
+    # on a captured scene; with the last 16 alone the heaviest view was absent from the window more often than not and 1.3-1.9 %
+    # of the steps of the end-to-end runs repeated their fill -- profiles/r06_train_e2e_soak.json)
+    # 25% headroom over the heaviest of the last 64 views of this shape, rounded up to 1/32..1/16 of its magnitude: a
     # camera moving between light and heavy views neither overflows on every return nor asks the allocator for a new block
     # size every step (every list-sized buffer of the step -- ids, sort workspace, liveness words, checkpoints -- is sized
     # from this number)
