@@ -206,7 +206,8 @@ class RasterContext:
             raise ValueError(f"FG_LONG_SEGMENTS={self.long_segments!r}: auto | always | never")
         # (the flag is set for a shape while its calls report a segment beyond the large launch's LDS capacity, or more
         # than `long_many` beyond the small launch's: there the bucket passes beat one-segment-per-workgroup sorts)
-        self.long_segment = 7936
+        self.long_segment = int(e.get("FG_LONG_SEGMENT", "7936"))
+        self.longest_segment_seen = 0  # (the last call's longest supertile segment: scripts)
         # (round 6: the count criterion is OFF by default.  On layouts the thresholds were not tuned on -- scripts/policy_regret.py
         # -- hundreds of segments of 3072..7936 elements and none beyond are sorted faster by the large launch, one segment per
         # workgroup in LDS, than by the bucket passes: needles 0.3 / 10 fill 0.160 -> 0.123 ms, a uniform cloud of large opaque
@@ -990,6 +991,7 @@ def _note_counts(rctx, lkey, key, count_slot, need_reported: bool = False, N: in
         _poll_count(count_slot, 1)
         rctx.note_mask_ratio(lkey, bool(masked), n_isects, int(_count_ring_np[_RING_WORDS * count_slot + 14]))
     _note_ckpt_need(rctx, lkey, count_slot, need_reported, N, walks)  # (first: the previous call's walk report decides below)
+    rctx.longest_segment_seen = _poll_count(count_slot, 1)
     for word, limit, shapes, cooldown in ((1, rctx.long_segment, rctx.long_shapes, rctx.long_cooldown),
                                           (2, rctx.heavy_lens(lkey)[0], rctx.heavy_shapes, rctx.heavy_cooldown)):  # fmt: skip
         over = _poll_count(count_slot, word) > limit or (word == 1 and _poll_count(count_slot, 3) > rctx.long_many)

@@ -31,6 +31,7 @@ SETTINGS = {
     "uneven=off": {"FG_UNEVEN_SPLIT_FWD": "0"}, "uneven=on": {"FG_RASTER_BALANCE": "3", "FG_RASTER_SPLIT_FWD": "8,5", "FG_RASTER_SPLIT_BWD": "20,4"},
     "uneven=r05": {"FG_UNEVEN_INTERLEAVE": "0", "FG_UNEVEN_SPLIT_FWD": "12,8", "FG_UNEVEN_SPLIT2_BWD": "12"},
     "masks=off": {"FG_EXACT_TILES": "0"}, "long_many=off": {"FG_LONG_MANY": "1000000"},
+    "long_seg=12k": {"FG_LONG_SEGMENT": "12000"}, "long_seg=16k": {"FG_LONG_SEGMENT": "16000"}, "long_seg=24k": {"FG_LONG_SEGMENT": "24000"},
     "even=never": {"FG_EVEN_BANDS": "0"}, "even=always": {"FG_RASTER_BALANCE": "2"}, "bands=interleaved": {"FG_RASTER_BALANCE": "3"},
 }  # fmt: skip
 WARM, TIMED = int(os.environ.get("REGRET_WARM", "24")), int(os.environ.get("REGRET_TIMED", "32"))
@@ -99,7 +100,7 @@ def measure(sc, env, dev, warm=None, timed=None):
            "redos": ctx.capacity_redos, "uneven": any(v > 0 for v in ctx.uneven_left.values()),
            "even": any(ctx.even_shape(k) for k in ctx.shape_calls),
            "I_raster": int(info["raster_flatten_ids"].numel()), "longest": int((offs[1:] - offs[:-1]).max()),
-           "V": int((info["radii"] > 0).sum())}  # fmt: skip
+           "V": int((info["radii"] > 0).sum()), "longest_segment": int(ctx.longest_segment_seen)}  # fmt: skip
     ctx.release_workspaces()
     return res
 
@@ -130,7 +131,7 @@ def main():
         best = min(ok, key=ok.get)
         row = {"layout": {k: v for k, v in d.items() if k != "file"}, "auto_ms": ok.get("auto"), "best": best, "best_ms": ok[best],
                "regret": ok["auto"] / ok[best] if "auto" in ok else None, "settings_ms": {k: round(v, 4) for k, v in ok.items()},
-               "auto_state": {k: res["auto"].get(k) for k in ("heavy_calls", "long_calls", "redos", "uneven", "even", "I_raster", "longest", "V")},
+               "auto_state": {k: res["auto"].get(k) for k in ("heavy_calls", "long_calls", "redos", "uneven", "even", "I_raster", "longest", "V", "longest_segment")},
                "errors": {k: v["error"] for k, v in res.items() if "error" in v}}  # fmt: skip
         rows.append(row)
         print(f"[regret] {row['layout']}: auto {row['auto_ms']:.3f} best {best} {row['best_ms']:.3f} -> {row['regret']:.3f}", file=sys.stderr, flush=True)

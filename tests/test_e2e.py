@@ -154,17 +154,37 @@ def _trained_frame_vs_oracle(model, scene, meta):
         vr = torch.randn(1, H, W, 3, generator=torch.Generator().manual_seed(v))
         g = [t.clone().requires_grad_(True) for t in ins]
         r, a, info = rasterization(*g, vm.to(g[0].device), K.to(g[0].device), W, H, sh_degree=3, packed=False, absgrad=True)
-        (r * vr.to(r.device)).sum().backward()
+        gh = torch.autograd.grad(r, g, vr.to(r.device), retain_graph=True)
         c = [t.cpu().clone().requires_grad_(True) for t in ins]
         r0, a0, info0 = O.rasterization(*c, vm, K, W, H, sh_degree=3, packed=False, absgrad=True)
-        (r0 * vr).sum().backward()
+        go = torch.autograd.grad(r0, c, vr, retain_graph=True)
         assert torch.equal(info["radii"].cpu(), info0["radii"]) and torch.equal(info["flatten_ids"].cpu(), info0["flatten_ids"]), v
         assert torch.equal(info["isect_offsets"].cpu(), info0["isect_offsets"])
         assert close_except_knife_edge(r, r0) and close_except_knife_edge(a, a0), v
-        worst = max(rel_l2(x.grad.cpu(), y.grad) for x, y in zip(g, c))
+        errs = [rel_l2(x.cpu(), y) for x, y in zip(gh, go)]
+        worst = max(errs)
         print(f"trained frame, view {v}: V {int((info0['radii'] > 0).sum())} of {ins[0].shape[0]}, I {info0['flatten_ids'].numel()}, "
               f"largest radius {int(info0['radii'].max())} px, worst gradient rel L2 {worst:.1e}")
-        assert worst < REL_TOL, (v, worst)
+        if worst >= REL_TOL or os.environ.get("FG_TEST_FORCE_KNIFE_EDGE"):
+            # The training run is not bit-reproducible (atomic sums): every run of the gate checks ANOTHER trained frame.  Two of
+            # ~220 frames so far had a gradient 1.4e-4 from the oracle's where the others are at 2e-6 ... 1.3e-5
+            # (scripts/e2e_parity_outlier.py): a discrete event, not noise.  The suite's rule for images -- a pixel whose alpha or
+            # transmittance is within rounding of a threshold may take the other branch -- applied to the backward, which is
+            # linear in the cotangent: with the cotangent zeroed on the pixels where the two IMAGES differ, few of them,
+            # every gradient must meet the bar.
+            import helpers
+
+            scale = float(r0.detach().abs().max())
+            d_img = (r.detach().cpu() - r0.detach()).abs().amax(-1)[0]
+            flipped = d_img > 1e-5 * scale  # (ordinary pixels are ~1e-6 apart; a flipped 1/255 decision moves one by up to 4e-3)
+            n_flipped = int(flipped.sum())
+            keep = (~flipped).float()[None, :, :, None]
+            gh2 = torch.autograd.grad(r, g, (vr * keep).to(r.device))
+            go2 = torch.autograd.grad(r0, c, vr * keep)
+            errs2 = [rel_l2(x.cpu(), y) for x, y in zip(gh2, go2)]
+            helpers._record("knife_edge_gradient_pixels_masked", n_flipped)
+            print(f"  beyond the bar ({worst:.1e}); with the cotangent zeroed on {n_flipped} knife-edge pixels: {max(errs2):.1e}")
+            assert n_flipped <= 16 and max(errs2) < REL_TOL, (v, errs, n_flipped, errs2)
 
 
 @pytest.mark.gpu
