@@ -175,6 +175,7 @@ def test_training_with_bilateral_grids_learns_a_per_image_colour_cast():
 
     m_on, last_on, ev_on = run(True)
     m_off, last_off, ev_off = run(False)
+    print("bilateral grids: last losses with", [round(x, 4) for x in last_on], "without", [round(x, 4) for x in last_off])
     assert last_on[1] < 0.8 * last_off[1] and last_on[0] < 0.8 * last_off[0], (last_on, last_off)
     g = m_on.bil_grids.grids.detach()
     eye = torch.tensor([1.0, 0, 0, 0, 0, 1.0, 0, 0, 0, 0, 1.0, 0], device=dev).view(1, 12, 1, 1, 1)

@@ -191,7 +191,7 @@ def _trained_frame_vs_oracle(model, scene, meta):
 def test_short_end_to_end_run_learns_the_scene():
     """A bounded version of scripts/train_e2e.py inside the gate: 240x135 target, schedule compressed 10x (resolution 150 / 300,
     refinements every 20 steps from 50, opacity reset every 600), 700 steps from random_init.  Held-out PSNR rises and ends
-    above 18 dB; densification ran; no stage-wise fallbacks beyond the shapes' first calls."""
+    above 17 dB; densification ran; no stage-wise fallbacks beyond the shapes' first calls."""
     import train_e2e as E
 
     over = dict(resolution_schedule=150, sh_degree_interval=100, refine_every=20, refine_start=50, stop_screen_size_at=400,
@@ -201,7 +201,7 @@ def test_short_end_to_end_run_learns_the_scene():
     ps = [e["heldout_psnr"] for e in rep["evals"]]
     print("short e2e: held-out PSNR", [round(p, 2) for p in ps], "N", [e["N"] for e in rep["evals"]])
     _trained_frame_vs_oracle(model, _[0], _[1])
-    assert ps[0] < ps[1] < ps[2] and ps[2] > 18.0  # (19.9 ... 20.9 over the round's visits: two runs differ by ~1 dB, profiles/r06_trained_scene.md)
+    assert ps[0] < ps[1] < ps[2] and ps[2] > 17.0  # (19.3 ... 21.6 over 24 runs on one box: training is not bit-reproducible)
     assert rep["N_final"] > 8000
     assert rep["policy_counters"]["end"]["capacity_redos"] <= 6
 
