@@ -206,6 +206,10 @@ class RasterContext:
             raise ValueError(f"FG_LONG_SEGMENTS={self.long_segments!r}: auto | always | never")
         # (the flag is set for a shape while its calls report a segment beyond the large launch's LDS capacity, or more
         # than `long_many` beyond the small launch's: there the bucket passes beat one-segment-per-workgroup sorts)
+        # (Tried: 10 000.  On layouts drawn with other seeds -- scripts/policy_regret.py 16 {7, 11, 23} -- shapes whose longest
+        # segment is 8776 / 8856 / 9796 elements run 3-5 % faster with that one segment through global memory than with the three
+        # extra launches; but the TRAINED scene, whose longest segments sit in that range in some of its views, loses 2-5 %
+        # (0.567 -> 0.577-0.599 ms), and shapes at 10 658 / 11 858 lose 9-16 % without the launches.  The LDS sort's limit stands.)
         self.long_segment = int(e.get("FG_LONG_SEGMENT", "7936"))
         self.longest_segment_seen = 0  # (the last call's longest supertile segment: scripts)
         # (round 6: the count criterion is OFF by default.  On layouts the thresholds were not tuned on -- scripts/policy_regret.py

@@ -120,6 +120,9 @@ def main():
         sc = load_trained_scene(d["file"]) if "file" in d else build_scene(d)
         res = {}
         warm = timed = None
+        # (not timed: the first setting of a layout otherwise runs behind the seconds of idle of the scene's construction on the
+        # host -- clocks and allocator cold, 3-10 % against `auto`, which is first; half a second of steps)
+        measure(sc, {}, dev, int(os.environ.get("REGRET_SETTLE_STEPS", "600")), 12)
         for name, env in SETTINGS.items():
             try:
                 res[name] = measure(sc, dict(env), dev, warm, timed)
