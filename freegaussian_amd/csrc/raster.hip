@@ -214,7 +214,14 @@ static_assert(FG_SEG_ENTRIES == fgjobs::FG_SEG_ENTRIES_H, "a heavy tile's batch 
 #define FG_HEAVY_AHEAD 8
 #endif
 #ifndef FG_WALK_REPORT
-#define FG_WALK_REPORT 2560  // entries a strip walked before a forward job reports it (fg_raster_jobs_fwd walk_out)
+// What a forward job reports (fg_raster_jobs_fwd walk_out): the list entries it EVALUATED for its strips -- those whose strip mask
+// reaches them -- when more than this.  (Until late in round 6: the entries it WALKED.  On layouts the thresholds were never looked
+// at with -- scripts/policy_regret.py 16 11, scripts/walk_values.py -- clouds of a million small half-transparent splats walk 2575-2862
+// entries in every view, of which a one-strip job evaluates a fraction: heavy tiles then serve a remainder of a few hundred entries
+// behind the 2560-entry prefix with a launch of their own and lose 13 % of the step, and the trained scene 1-2 %; the gate's faint
+// cluster of LARGE splats walks 2700-4700 entries, evaluates every one of them for every strip, and gains 12 % from heavy tiles: what
+// separates them is the work of the serial job, not the length of its walk.)
+#define FG_WALK_REPORT 2560
 #endif
 #ifndef FG_HEAVY_SUB
 #define FG_HEAVY_SUB 4  // workgroups per listed local job
@@ -558,6 +565,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
     if (!__any(open)) return;  // the prefix finished every pixel: its outputs stand
   }
   int batch = first;
+  int evaluated = 0;  // (uniform) entries that reached this job's strips so far: what it reports as its work (FG_WALK_REPORT)
   // (Round 5, measured and dropped: the ids of batch b + 1 fetched while batch b is walked -- one register, 62 -> 64 VGPRs.  A
   // batch's staging is two dependent round trips, the id, then the record: a third of a strip job's life on a long list once
   // its SIMD's other wavefronts have gone.  Forward +-0 on the uniform scene and on half of the Gaussians in a ball, +8 us
@@ -660,6 +668,7 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
       cnt += __popcll(bal);
     }
     __builtin_amdgcn_wave_barrier();  // the list is private to this wavefront
+    evaluated += cnt;
     // LIVENESS for the backward (one wavefront per job only): bit j of live[k] = "list entry batch + j
     // had a contributing pixel in slot k".  Written out per batch, one byte per (entry, strip); the
     // backward then evaluates exactly the (entry, strip) pairs that did something here instead of
@@ -784,10 +793,11 @@ __device__ __forceinline__ void raster_fwd_body(FwdShared<C, 64 * NW>& sh, int t
         if (lane == 0) tl[wave + k * (4 / PPT)] = m;
         walked = max(walked, m - start + 1);
       }
-      // LONG WALKS reported to the host (nullable; pinned memory, system scope; any of them, not the longest): a strip
-      // that needed more than FG_WALK_REPORT entries is what heavy tiles are for -- the host turns them on by it
-      if (MODE == 0 && walk_out && walked > FG_WALK_REPORT && lane == 0)
-        __hip_atomic_store(walk_out, (long long)walked, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      // LONG JOBS reported to the host (nullable; pinned memory, system scope; any of them, not the longest): a job that
+      // evaluated more than FG_WALK_REPORT entries for its strips is what heavy tiles are for -- the host turns them on by it
+      (void)walked;
+      if (MODE == 0 && walk_out && evaluated > FG_WALK_REPORT && lane == 0)
+        __hip_atomic_store(walk_out, (long long)evaluated, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
   }
 #pragma unroll
@@ -1055,6 +1065,7 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
     }
   }
   int cnt = 0;  // entries of this wavefront's batch that reach the strip (its private list)
+  int ev_mine = 0, sc_mine = 0;  // ... summed over this wavefront's batches, and the entries those batches held (the job's report)
   // one batch, entry by entry, from the state given (raster_fwd_body's loop, one pixel per lane).  BITS: bit j of
   // vlo | vhi << 32 = "entry batch + j passed this lane's alpha test" (step 4)
   uint32_t vlo = 0, vhi = 0;
@@ -1137,6 +1148,8 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
       const uint64_t bal = __ballot(rel);
       if (rel) st.list[0][__popcll(bal & lt_mask)] = (uint16_t)(lane | (mask << 8));
       cnt = __popcll(bal);
+      ev_mine += cnt;
+      sc_mine += min(64, end - batch);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();  // records and list are private to this wavefront
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1263,8 +1276,11 @@ __device__ __forceinline__ void raster_fwd_wide_body(WideShared<NWV>& sh, int ti
   {
     const int m = fg::wave_max_i32(last);
     if (lane == 0) reinterpret_cast<int32_t*>(ckpt)[4 * tile + strip] = m;
-    if (walk_out && m - start + 1 > FG_WALK_REPORT && lane == 0)
-      __hip_atomic_store(walk_out, (long long)(m - start + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    // the job's report, in the measure of the serial jobs' (FG_WALK_REPORT): the entries of the walk that reach this strip --
+    // the share seen in wavefront 0's batches (one in sixteen of the remainder) applied to the whole walk, prefix included
+    const long long reach = (long long)(m - start + 1) * ev_mine / max(sc_mine, 1);
+    if (walk_out && reach > FG_WALK_REPORT && lane == 0)
+      __hip_atomic_store(walk_out, reach, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
   if (inside) {
     const float alpha_out = 1.f - b.x;

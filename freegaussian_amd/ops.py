@@ -232,13 +232,14 @@ class RasterContext:
             raise ValueError(f"FG_HEAVY_TILES={self.heavy_tiles!r}: auto | always | never")
         self.heavy_tile_len = int(e.get("FG_HEAVY_TILE_LEN", "768"))
         # (round 5: the policy comes on for a shape whose longest list exceeds `heavy_flag_len` AND -- where the forward reports
-        # them: the one-call path -- whose strips walked more than 2560 entries lately; while it is on, every list beyond
+        # them: the one-call path -- whose jobs evaluated more than 2560 entries for their strips lately; while it is on, every list beyond
         # `heavy_tile_len` = the wide jobs' prefix of 512 entries + 256 is a heavy tile.  A dense opaque cluster has lists of
         # ten thousand entries that close after a few hundred: heavy tiles cost it 15 us and gain it nothing)
         self.heavy_flag_len = int(e.get("FG_HEAVY_FLAG_LEN", "2560"))
         self.heavy_cooldown = 64
         self.heavy_shapes = {}
-        self.long_walks = {}  # shape -> calls left for which a reported long walk (a strip beyond 2560 entries) counts
+        self.last_walk = 0
+        self.long_walks = {}  # shape -> calls left for which a reported long job (more than 2560 entries evaluated for its strips) counts
         self.workspace_pool = e.get("FG_WORKSPACE_POOL", "1") != "0"
         self._workspaces = {}  # (kind, device, stream) -> [(uint8 buffer, its storage's use count when nobody else holds it)]
         self.pool_fallback_calls = 0  # workspace requests that fell back to torch.empty because the use-count hook is missing
@@ -401,7 +402,7 @@ class RasterContext:
     def heavy_lens(self, lkey):
         """(longest list that turns heavy tiles on, list length from which a tile IS heavy while they are on) for a shape.
         The round-5 pair (2560 / 768) belongs to the walk reports: a shape keeps heavy tiles only while its strips report
-        walks beyond 2560 entries.  Only the one-call path asks the forward for those reports; a shape that has never
+        jobs that evaluated more than 2560 entries.  Only the one-call path asks the forward for those reports; a shape that has never
         delivered one (stage-wise calls: FG_STEP_CALLS=0, a stage timer, images the step path refuses) would keep heavy
         tiles on by list LENGTH alone -- a dense opaque cluster, 15 us lost per step -- so it stays on round 4's pair."""
         if lkey in self.long_walks:
@@ -764,7 +765,7 @@ def _count_slot():
         _count_ring_next = (i + 1) % _COUNT_RING
         _count_ring_gen[i] += 1
         _count_ring_np[_RING_WORDS * i : _RING_WORDS * i + 13] = -1
-        _count_ring_np[_RING_WORDS * i + 13] = 0  # (fg_raster_jobs_fwd's walk_out: strips that walked more than 2560 entries)
+        _count_ring_np[_RING_WORDS * i + 13] = 0  # (fg_raster_jobs_fwd's walk_out: jobs that evaluated more than 2560 entries for their strips)
         _count_ring_np[_RING_WORDS * i + 14] = -1  # (fg_stbin_count: the footprint rectangles' area)
         _count_ring_stream[i] = torch.cuda.current_stream()  # (under the lock: slot i is this caller's from here on)
     return i, _count_ring.data_ptr() + 8 * _RING_WORDS * i
@@ -788,7 +789,8 @@ def _note_ckpt_need(rctx, lkey, count_slot, reported: bool, N: int = 0, walks: b
             if len(rctx.long_walks) > 256 and lkey not in rctx.long_walks:
                 rctx.long_walks.pop(next(iter(rctx.long_walks)))
             left = rctx.long_walks.get(lkey, 0)
-            rctx.long_walks[lkey] = rctx.heavy_cooldown if int(_count_ring_np[_RING_WORDS * prev[0] + 13]) > 0 else max(left - 1, 0)
+            rctx.last_walk = int(_count_ring_np[_RING_WORDS * prev[0] + 13])  # (one of the reporting strips' walks; scripts)
+            rctx.long_walks[lkey] = rctx.heavy_cooldown if rctx.last_walk > 0 else max(left - 1, 0)
         decided = int(_count_ring_np[_RING_WORDS * prev[0] + 12])
         if decided >= 0:  # (the cost pass ran: 1 = it balanced the shares by cost, 0 = the equal spans stood)
             if len(rctx.equal_stood) > 256 and lkey not in rctx.equal_stood:

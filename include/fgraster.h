@@ -391,7 +391,7 @@ int fg_raster_build_jobs(int width, int height, int tile_size, const int32_t* ti
  * word, + a margin, is the seg_slots that leaves no tile without.  Word 8 (whenever the forward list is built): what the
  * cost pass over the XCDs' shares decided -- 1 = bands balanced by cost, 0 = the equal spans stood, -1 = it did not run
  * (balance_bands 0 / 2, small or huge grids): a host whose last calls of a shape all read 0 can set balance_bands = 2.  * walk_out (ABI 8; nullable; one int64 in pinned host or device memory, zeroed by the caller): a forward job whose strip
- * walked more than 2560 list entries stores that number there (system scope; any such job's, not the largest) -- lists
+ * evaluated more than 2560 list entries for its strips (the entries its strip mask reaches; until late in round 6: walked) stores that number there (system scope; any such job's, not the largest) -- lists
  * that are long AND stay open, which is what fg_raster_config::heavy_tiles is for: a host turns the policy on by it
  * instead of by the longest LIST alone (a dense opaque cluster has lists of ten thousand entries and closes after a few
  * hundred).

@@ -1960,7 +1960,7 @@ def test_wide_jobs_leave_their_list_of_open_strips_empty_for_a_second_forward(mo
 @pytest.mark.parametrize("cluster", ["faint", "opaque"])
 def test_heavy_tiles_stay_on_only_where_the_forward_reports_long_walks(cluster):
     """The one-call path hands the raster forward a pinned word (fg_raster_jobs_fwd walk_out; word 9 of io->ckpt_need_out); a
-    strip that walked more than 2560 list entries stores that number there, the host reads it one call late and keeps
+    strip that evaluated more than 2560 list entries for its strips (until late in round 6: walked) stores that number there, the host reads it one call late and keeps
     `heavy_tiles` for the shape only while such walks are reported.  A faint cluster (lists of thousands that never close)
     keeps them; an opaque one (longer lists still, closed after a few hundred entries) loses them after its first reporting
     call.  Same image either way (2e-6: heavy tiles associate differently)."""
