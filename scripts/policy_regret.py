@@ -30,7 +30,7 @@ SETTINGS = {
     "long=always": {"FG_LONG_SEGMENTS": "always"}, "long=never": {"FG_LONG_SEGMENTS": "never"},
     "uneven=off": {"FG_UNEVEN_SPLIT_FWD": "0"}, "uneven=on": {"FG_RASTER_BALANCE": "3", "FG_RASTER_SPLIT_FWD": "8,5", "FG_RASTER_SPLIT_BWD": "20,4"},
     "uneven=r05": {"FG_UNEVEN_INTERLEAVE": "0", "FG_UNEVEN_SPLIT_FWD": "12,8", "FG_UNEVEN_SPLIT2_BWD": "12"},
-    "masks=off": {"FG_EXACT_TILES": "0"}, "long_many=off": {"FG_LONG_MANY": "1000000"},
+    "masks=off": {"FG_EXACT_TILES": "0"}, "masks_keep=0.97": {"FG_MASK_KEEP_MAX": "0.97"}, "masks_keep=0.94": {"FG_MASK_KEEP_MAX": "0.94"}, "long_many=off": {"FG_LONG_MANY": "1000000"},
     "long_seg=12k": {"FG_LONG_SEGMENT": "12000"}, "long_seg=16k": {"FG_LONG_SEGMENT": "16000"}, "long_seg=24k": {"FG_LONG_SEGMENT": "24000"},
     "even=never": {"FG_EVEN_BANDS": "0"}, "even=always": {"FG_RASTER_BALANCE": "2"}, "bands=interleaved": {"FG_RASTER_BALANCE": "3"},
 }  # fmt: skip
